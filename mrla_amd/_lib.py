@@ -1,0 +1,75 @@
+"""ctypes binding of libmrla_hip.so (C ABI: include/mrla_hip.h).
+
+The shared library is the product's only compute path for the MRLA operators: if it is missing the
+import of any operator fails loudly with build instructions -- there is no Python/CPU fallback.
+"""
+import ctypes
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libmrla_hip.so")
+
+OK, EINVAL, EUNSUPPORTED, EHIP = 0, -1, -2, -3
+F32, BF16, F16 = 0, 1, 2
+NCHW, NHWC = 0, 1
+ACT_NONE, ACT_GELU = 0, 1
+BN_NONE, BN_TRAIN, BN_EVAL = 0, 1, 2
+FWD_MOMENTS, BWD_MOMENTS = 6, 3
+
+_ERR = {EINVAL: "invalid argument", EUNSUPPORTED: "unsupported shape/layout for the HIP kernels",
+        EHIP: "HIP runtime error at kernel launch"}
+
+_P, _I, _F = ctypes.c_void_p, ctypes.c_int, ctypes.c_float
+
+# name -> argument types (return type is always int).  Kept in one table so tests can check that every
+# symbol declared in include/mrla_hip.h is exported and bound.
+SIGNATURES = {
+    "mrla_abi_version": [],
+    "mrla_light_wgrad_rows": [_I] * 6,
+    "mrla_light_stats_fwd": [_P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P],
+    "mrla_light_gate_fwd": [_P, _P, _P, _I, _P, _I, _I, _I, _I, _P],
+    "mrla_light_bn_fwd": [_P, _P, _P, _P, _P, _P, _P, _I, _F, _F, _P, _P, _P, _P, _I, _I, _I, _I, _P],
+    "mrla_light_apply_fwd": [_P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P],
+    "mrla_light_stats_bwd": [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P],
+    "mrla_light_bn_bwd": [_P, _P, _P, _P, _P, _P, _P, _P, _I, _P, _P, _P, _P, _I, _I, _I, _I, _P],
+    "mrla_light_gate_bwd": [_P, _P, _P, _P, _P, _P, _P, _I, _P, _P, _I, _I, _I, _I, _P],
+    "mrla_light_apply_bwd": [_P] * 12 + [_I] * 9 + [_P],
+    "mrla_reduce_rows": [_P, _P, _I, _I, _P],
+}
+
+
+class MrlaHipError(RuntimeError):
+    pass
+
+
+_lib = None
+
+
+def load():
+    """Load (once) and return the ctypes handle; raises MrlaHipError if the library is not built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise MrlaHipError(
+            f"{LIB_PATH} not found: the MRLA HIP extension is not built. Run `python -c 'import __graft_entry__ as g; "
+            "g.build()'` (or `make -C mrla_amd/csrc`) -- mrla_amd has no CPU/PyTorch fallback for its operators.")
+    lib = ctypes.CDLL(LIB_PATH)
+    for name, argtypes in SIGNATURES.items():
+        fn = getattr(lib, name)          # AttributeError here = header/library mismatch: fail loudly
+        fn.argtypes = argtypes
+        fn.restype = ctypes.c_int
+    if lib.mrla_abi_version() != 1:
+        raise MrlaHipError("libmrla_hip.so ABI version mismatch; rebuild it")
+    _lib = lib
+    return lib
+
+
+def check(rc, what):
+    if rc != OK:
+        raise MrlaHipError(f"{what}: {_ERR.get(rc, 'error')} (code {rc})")
+
+
+def call(name, *args):
+    rc = getattr(load(), name)(*args)
+    check(rc, name)

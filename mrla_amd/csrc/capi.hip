@@ -1,0 +1,165 @@
+// extern "C" surface of libmrla_hip.so (declared in include/mrla_hip.h): argument validation, slab
+// geometry, dispatch on dtype / layout.  No global state; nothing here allocates or synchronises.
+#include <algorithm>
+
+#include "mrla_kernels.h"
+
+namespace mrla {
+
+constexpr int kWavesPerGroup = 4;
+static int gcd_i(int a, int b) { while (b) { int t = a % b; a = b; b = t; } return a; }
+
+// LDS budget: keep a slab's staged arrays near 40 KB so >= 3-4 workgroups share a CU (the copy-in /
+// march / copy-out phases of different workgroups overlap), never above 150 KB (160 KB per CU).
+int make_slab_geo(SlabGeo* g, int B, int C, int H, int W, int dtype, int arrays, int bg_hint) {
+  if (W > 64) return MRLA_EUNSUPPORTED;               // a plane row must fit one wave
+  const int es = (int)dtype_size(dtype);
+  const int HW = H * W;
+  const int soft = 40 * 1024, hard = 150 * 1024;
+  const int target = std::min(4096, soft / (arrays * es));
+  const int max_tasks = kMaxTasksPerWave * kWavesPerGroup;
+  const int maxplanes = std::max(1, std::min(C, target / HW));
+  int PW = std::max(1, std::min(64 / W, maxplanes));
+  int NGc = std::max(1, maxplanes / PW);
+  if (NGc >= kWavesPerGroup) NGc -= NGc % kWavesPerGroup;     // whole rounds over the 4 waves
+  NGc = std::min(NGc, max_tasks);
+  int CP = PW * NGc;
+  // make every slab start 16-byte aligned when the tensor allows it
+  const int q = (16 / es) / gcd_i(16 / es, HW);
+  if (CP >= q) CP -= CP % q;
+  if (PW > CP) PW = CP;
+  const int NG = (CP + PW - 1) / PW;
+  int NB = std::max(1, (kWavesPerGroup + NG - 1) / NG);
+  NB = std::min(NB, std::max(1, H / 4));
+  NB = std::min(NB, max_tasks / NG > 0 ? max_tasks / NG : 1);
+  const int RB = (H + NB - 1) / NB;
+  NB = (H + RB - 1) / RB;
+  const int vec = 16 / es;
+  const int astride = ((CP * HW + vec - 1) / vec) * vec;
+  const size_t lds = (size_t)astride * es * arrays + (size_t)NG * NB * PW * 9 * sizeof(float);
+  if (lds > (size_t)hard) return MRLA_EUNSUPPORTED;
+  const int slabs = (C + CP - 1) / CP;
+  int BG = bg_hint;
+  if (BG <= 0) {
+    const long total = (long)B * slabs;
+    BG = (int)std::max(1L, std::min(8L, total / 2048));
+  }
+  *g = SlabGeo{B, C, H, W, HW, CP, slabs, PW, NG, NB, RB, BG, astride};
+  return MRLA_OK;
+}
+
+static bool bad_dims(int b, int c, int h, int w) { return b <= 0 || c <= 0 || h <= 0 || w <= 0; }
+static bool bad_dtype(int dt) { return dt != MRLA_F32 && dt != MRLA_BF16 && dt != MRLA_F16; }
+
+// One geometry for all four streaming kernels of a problem (sized for the 5-array backward pass), so
+// the wgrad partial-row count is a pure function of the shape.
+static int light_geo(SlabGeo* g, int b, int c, int h, int w, int dtype) { return make_slab_geo(g, b, c, h, w, dtype, 5, 0); }
+
+}  // namespace mrla
+
+using namespace mrla;
+
+extern "C" {
+
+int mrla_abi_version(void) { return 1; }
+
+int mrla_light_wgrad_rows(int b, int c, int h, int w, int dtype, int layout) {
+  if (bad_dims(b, c, h, w) || bad_dtype(dtype)) return MRLA_EINVAL;
+  if (layout != MRLA_NCHW) return MRLA_EUNSUPPORTED;
+  SlabGeo g;
+  const int rc = light_geo(&g, b, c, h, w, dtype);
+  if (rc != MRLA_OK) return rc;
+  return (b + g.BG - 1) / g.BG;
+}
+
+int mrla_light_stats_fwd(const void* x, const void* o_prev, const float* wv, float* mom, int b, int c, int h, int w,
+                         int dtype, int layout, int act, void* stream) {
+  if (!x || !wv || !mom || bad_dims(b, c, h, w) || bad_dtype(dtype)) return MRLA_EINVAL;
+  if (layout != MRLA_NCHW) return MRLA_EUNSUPPORTED;
+  SlabGeo g;
+  const int rc = light_geo(&g, b, c, h, w, dtype);
+  if (rc != MRLA_OK) return rc;
+  return launch_light_stats_fwd_nchw(x, o_prev, wv, mom, g, dtype, act, (hipStream_t)stream);
+}
+
+int mrla_light_gate_fwd(const float* mom, const float* wq, const float* wk, int ksize, float* gate, int b, int c,
+                        int hw, int d, void* stream) {
+  if (!mom || !wq || !wk || !gate || b <= 0 || c <= 0 || hw <= 0 || d <= 0 || c % d || ksize <= 0 || !(ksize & 1))
+    return MRLA_EINVAL;
+  return launch_gate_fwd(mom, wq, wk, ksize, gate, b, c, hw, d, (hipStream_t)stream);
+}
+
+int mrla_light_bn_fwd(const float* mom, const float* gate, const float* lam, const float* gamma, const float* beta,
+                      float* running_mean, float* running_var, int bn_mode, float momentum, float eps, float* sc,
+                      float* sh, float* save_mean, float* save_inv, int b, int c, int hw, int d, void* stream) {
+  if (!mom || !gate || !gamma || !beta || !running_mean || !running_var || !sc || !sh || !save_mean || !save_inv ||
+      b <= 0 || c <= 0 || hw <= 0 || d <= 0 || c % d || (bn_mode != MRLA_BN_TRAIN && bn_mode != MRLA_BN_EVAL))
+    return MRLA_EINVAL;
+  return launch_bn_fwd(mom, gate, lam, gamma, beta, running_mean, running_var, bn_mode == MRLA_BN_TRAIN, momentum, eps,
+                       sc, sh, save_mean, save_inv, b, c, hw, d, (hipStream_t)stream);
+}
+
+int mrla_light_apply_fwd(const void* x, const void* o_prev, const float* wv, const float* gate, const float* sc,
+                         const float* sh, const float* lam, const float* dp, void* out, int b, int c, int h, int w,
+                         int d, int res, int dtype, int layout, int act, void* stream) {
+  if (!x || !wv || !gate || !out || bad_dims(b, c, h, w) || bad_dtype(dtype) || d <= 0 || c % d) return MRLA_EINVAL;
+  if (o_prev && !lam) return MRLA_EINVAL;
+  if (layout != MRLA_NCHW) return MRLA_EUNSUPPORTED;
+  SlabGeo g;
+  const int rc = light_geo(&g, b, c, h, w, dtype);
+  if (rc != MRLA_OK) return rc;
+  return launch_light_apply_fwd_nchw(x, o_prev, wv, gate, sc, sh, lam, dp, out, g, d, res, dtype, act,
+                                     (hipStream_t)stream);
+}
+
+int mrla_light_stats_bwd(const void* dout, const void* x, const void* o_prev, const float* wv, float* bmom, int b,
+                         int c, int h, int w, int dtype, int layout, int act, void* stream) {
+  if (!dout || !x || !wv || !bmom || bad_dims(b, c, h, w) || bad_dtype(dtype)) return MRLA_EINVAL;
+  if (layout != MRLA_NCHW) return MRLA_EUNSUPPORTED;
+  SlabGeo g;
+  const int rc = light_geo(&g, b, c, h, w, dtype);
+  if (rc != MRLA_OK) return rc;
+  return launch_light_stats_bwd_nchw(dout, x, o_prev, wv, bmom, g, dtype, act, (hipStream_t)stream);
+}
+
+int mrla_light_bn_bwd(const float* mom, const float* bmom, const float* gate, const float* lam, const float* gamma,
+                      const float* dp, const float* save_mean, const float* save_inv, int bn_mode, float* cb,
+                      float* dgamma, float* dbeta, float* dlam, int b, int c, int hw, int d, void* stream) {
+  if (!mom || !bmom || !gate || !cb || b <= 0 || c <= 0 || hw <= 0 || d <= 0 || c % d) return MRLA_EINVAL;
+  if (gamma && (!save_mean || !save_inv || !dgamma || !dbeta)) return MRLA_EINVAL;
+  if (dlam && !lam) return MRLA_EINVAL;
+  return launch_bn_bwd(mom, bmom, gate, lam, gamma, dp, save_mean, save_inv, bn_mode == MRLA_BN_TRAIN, cb, dgamma,
+                       dbeta, dlam, b, c, hw, d, (hipStream_t)stream);
+}
+
+int mrla_light_gate_bwd(const float* mom, const float* bmom, const float* gate, const float* cb, const float* dp,
+                        const float* wq, const float* wk, int ksize, float* dyx, float* dwqk_part, int b, int c,
+                        int hw, int d, void* stream) {
+  if (!mom || !bmom || !gate || !wq || !wk || !dyx || !dwqk_part || b <= 0 || c <= 0 || hw <= 0 || d <= 0 || c % d ||
+      ksize <= 0 || !(ksize & 1))
+    return MRLA_EINVAL;
+  return launch_gate_bwd(mom, bmom, gate, cb, dp, wq, wk, ksize, dyx, dwqk_part, b, c, hw, d, (hipStream_t)stream);
+}
+
+int mrla_light_apply_bwd(const void* dout, const void* x, const void* o_prev, const float* wv, const float* gate,
+                         const float* cb, const float* lam, const float* dp, const float* dyx, void* dx,
+                         void* do_prev, float* dwv_part, int b, int c, int h, int w, int d, int res, int dtype,
+                         int layout, int act, void* stream) {
+  if (!dout || !x || !wv || !gate || !dyx || !dx || !dwv_part || bad_dims(b, c, h, w) || bad_dtype(dtype) || d <= 0 ||
+      c % d)
+    return MRLA_EINVAL;
+  if (o_prev && (!lam || !do_prev)) return MRLA_EINVAL;
+  if (layout != MRLA_NCHW) return MRLA_EUNSUPPORTED;
+  SlabGeo g;
+  const int rc = light_geo(&g, b, c, h, w, dtype);
+  if (rc != MRLA_OK) return rc;
+  return launch_light_apply_bwd_nchw(dout, x, o_prev, wv, gate, cb, lam, dp, dyx, dx, do_prev, dwv_part, g, d, res,
+                                     dtype, act, (hipStream_t)stream);
+}
+
+int mrla_reduce_rows(const float* in, float* out, int rows, int n, void* stream) {
+  if (!in || !out || rows <= 0 || n <= 0) return MRLA_EINVAL;
+  return launch_reduce_rows(in, out, rows, n, (hipStream_t)stream);
+}
+
+}  // extern "C"

@@ -1,0 +1,321 @@
+// The small kernels of the MRLA-light path: everything that lives on [b, c] / [b, g] / [c] tensors.
+// They turn the per-plane moments produced by the streaming passes into the gate, the BatchNorm
+// statistics and all parameter gradients in closed form (derivation: DESIGN.md section 3).
+//
+// Reference statements covered: mrla_light_module.py:59-60,67,70 (Wq/Wk conv1d, per-head dot product,
+// sigmoid); nn.BatchNorm2d statistics / running update / backward of `bn_mrla`
+// (resnet_mrla_light.py:85,116); the reductions autograd performs for lambda_t, Wq, Wk.
+#include "mrla_device.h"
+#include "mrla_kernels.h"
+
+namespace mrla {
+
+constexpr int kBnCh = 16;                    // channels per workgroup in the per-channel kernels
+constexpr int kBnLanes = kThreads / kBnCh;   // images summed in parallel per channel
+
+// ------------------------------------------------------------------------------------------------
+// gate forward: one workgroup per image
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(kThreads) void gate_fwd_kernel(const float* __restrict__ mom, const float* __restrict__ wq,
+                                                            const float* __restrict__ wk, int ks,
+                                                            float* __restrict__ gate, int C, int HW, int d) {
+  extern __shared__ float sm[];
+  const int p = (ks - 1) / 2;
+  float* ys = sm;                 // [C + 2p], zero padded
+  float* qk = ys + C + 2 * p;     // [C]
+  const int b = blockIdx.x, tid = threadIdx.x;
+  const float inv_hw = 1.0f / (float)HW;
+  for (int i = tid; i < C + 2 * p; i += kThreads) {
+    const int c = i - p;
+    ys[i] = (c >= 0 && c < C) ? mom[((size_t)b * C + c) * M_N + M_SX] * inv_hw : 0.f;
+  }
+  __syncthreads();
+  for (int c = tid; c < C; c += kThreads) {
+    float q = 0.f, k = 0.f;
+    for (int j = 0; j < ks; ++j) {
+      q = fmaf(wq[j], ys[c + j], q);
+      k = fmaf(wk[j], ys[c + j], k);
+    }
+    qk[c] = q * k;
+  }
+  __syncthreads();
+  const int G = C / d;
+  const float s = rsqrtf((float)d);
+  for (int g = tid; g < G; g += kThreads) {
+    float acc = 0.f;
+    for (int i = 0; i < d; ++i) acc += qk[g * d + i];
+    gate[(size_t)b * G + g] = 1.0f / (1.0f + expf(-acc * s));
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// BatchNorm statistics of m = a*V + lam*o from the moments: kBnCh channels x kBnLanes image lanes
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(kThreads) void bn_fwd_kernel(
+    const float* __restrict__ mom, const float* __restrict__ gate, const float* __restrict__ lam,
+    const float* __restrict__ gamma, const float* __restrict__ beta, float* __restrict__ run_mean,
+    float* __restrict__ run_var, int training, float momentum, float eps, float* __restrict__ sc,
+    float* __restrict__ sh, float* __restrict__ save_mean, float* __restrict__ save_inv, int B, int C, int HW, int d) {
+  __shared__ double r1[kBnLanes][kBnCh], r2[kBnLanes][kBnCh];
+  const int cc = threadIdx.x % kBnCh, bl = threadIdx.x / kBnCh;
+  const int c = blockIdx.x * kBnCh + cc;
+  const bool live = c < C;
+  const int G = C / d;
+  double mean = 0.0, var = 1.0;
+  if (training) {
+    double s1 = 0.0, s2 = 0.0;
+    if (live) {
+      const float l = lam ? lam[c] : 0.f;
+      for (int b = bl; b < B; b += kBnLanes) {
+        const float* m = mom + ((size_t)b * C + c) * M_N;
+        const float a = gate[(size_t)b * G + c / d];
+        s1 += (double)a * m[M_SV] + (double)l * m[M_SO];
+        s2 += (double)a * a * m[M_SVV] + 2.0 * a * l * m[M_SVO] + (double)l * l * m[M_SOO];
+      }
+    }
+    r1[bl][cc] = s1; r2[bl][cc] = s2;
+    __syncthreads();
+    if (bl == 0 && live) {
+      s1 = 0.0; s2 = 0.0;
+      for (int i = 0; i < kBnLanes; ++i) { s1 += r1[i][cc]; s2 += r2[i][cc]; }
+      const double M = (double)B * HW;
+      mean = s1 / M;
+      var = s2 / M - mean * mean;
+      if (var < 0.0) var = 0.0;
+      const double unbiased = var * (M / (M > 1.0 ? M - 1.0 : 1.0));
+      run_mean[c] = (float)((1.0 - momentum) * run_mean[c] + momentum * mean);
+      run_var[c] = (float)((1.0 - momentum) * run_var[c] + momentum * unbiased);
+    }
+  } else if (bl == 0 && live) {
+    mean = run_mean[c];
+    var = run_var[c];
+  }
+  if (bl == 0 && live) {
+    const double inv = 1.0 / sqrt(var + (double)eps);
+    const double scale = gamma[c] * inv;
+    sc[c] = (float)scale;
+    sh[c] = (float)(beta[c] - scale * mean);
+    save_mean[c] = (float)mean;
+    save_inv[c] = (float)inv;
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// BatchNorm backward constants, dgamma, dbeta, dlambda
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(kThreads) void bn_bwd_kernel(
+    const float* __restrict__ mom, const float* __restrict__ bmom, const float* __restrict__ gate,
+    const float* __restrict__ lam, const float* __restrict__ gamma, const float* __restrict__ dp,
+    const float* __restrict__ save_mean, const float* __restrict__ save_inv, int training, float* __restrict__ cb,
+    float* __restrict__ dgamma, float* __restrict__ dbeta, float* __restrict__ dlam, int B, int C, int HW, int d) {
+  __shared__ double r1[kBnLanes][kBnCh], r2[kBnLanes][kBnCh];
+  __shared__ float coef[4][kBnCh];
+  const int cc = threadIdx.x % kBnCh, bl = threadIdx.x / kBnCh;
+  const int c = blockIdx.x * kBnCh + cc;
+  const bool live = c < C;
+  const int G = C / d;
+  const float l = (live && lam) ? lam[c] : 0.f;
+  double s1 = 0.0, s2 = 0.0;
+  if (live) {
+    for (int b = bl; b < B; b += kBnLanes) {
+      const float* bm = bmom + ((size_t)b * C + c) * D_N;
+      const float a = gate[(size_t)b * G + c / d];
+      const double dpb = dp ? dp[b] : 1.f;
+      s1 += dpb * bm[D_D];
+      s2 += dpb * ((double)a * bm[D_DV] + (double)l * bm[D_DO]);
+    }
+  }
+  r1[bl][cc] = s1; r2[bl][cc] = s2;
+  __syncthreads();
+  if (bl == 0 && live) {
+    s1 = 0.0; s2 = 0.0;
+    for (int i = 0; i < kBnLanes; ++i) { s1 += r1[i][cc]; s2 += r2[i][cc]; }
+    double e = 1.0, f = 0.0, Gc = 0.0, Hc = 0.0;
+    if (gamma) {
+      const double mean = save_mean[c], inv = save_inv[c];
+      const double dbe = s1;
+      const double dga = inv * (s2 - mean * s1);
+      e = gamma[c] * inv;
+      if (training) {
+        const double M = (double)B * HW;
+        const double c1 = dbe / M, c2 = dga / M;
+        f = -e * inv * c2;
+        Gc = f * l;
+        Hc = e * (-c1 + inv * mean * c2);
+      }
+      dgamma[c] = (float)dga;
+      dbeta[c] = (float)dbe;
+    }
+    coef[0][cc] = (float)e; coef[1][cc] = (float)f; coef[2][cc] = (float)Gc; coef[3][cc] = (float)Hc;
+    cb[c * 4 + 0] = (float)e; cb[c * 4 + 1] = (float)f; cb[c * 4 + 2] = (float)Gc; cb[c * 4 + 3] = (float)Hc;
+  }
+  __syncthreads();
+  if (!dlam) return;
+  double s3 = 0.0;
+  if (live) {
+    const float e = coef[0][cc], f = coef[1][cc], Gc = coef[2][cc], Hc = coef[3][cc];
+    for (int b = bl; b < B; b += kBnLanes) {
+      const float* m = mom + ((size_t)b * C + c) * M_N;
+      const float* bm = bmom + ((size_t)b * C + c) * D_N;
+      const float a = gate[(size_t)b * G + c / d];
+      const double dpb = dp ? dp[b] : 1.f;
+      s3 += (double)e * dpb * bm[D_DO] + (double)f * a * m[M_SVO] + (double)Gc * m[M_SOO] + (double)Hc * m[M_SO];
+    }
+  }
+  r1[bl][cc] = s3;
+  __syncthreads();
+  if (bl == 0 && live) {
+    s3 = 0.0;
+    for (int i = 0; i < kBnLanes; ++i) s3 += r1[i][cc];
+    dlam[c] = (float)s3;
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// gate backward: one workgroup per image
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ float block_sum(float v, float* scratch /*[kWaves]*/) {
+  v = wave_sum(v);
+  const int lane = threadIdx.x & (kWave - 1), wave = threadIdx.x / kWave;
+  __syncthreads();
+  if (lane == 0) scratch[wave] = v;
+  __syncthreads();
+  float s = 0.f;
+#pragma unroll
+  for (int i = 0; i < kWaves; ++i) s += scratch[i];
+  return s;
+}
+
+__global__ __launch_bounds__(kThreads) void gate_bwd_kernel(
+    const float* __restrict__ mom, const float* __restrict__ bmom, const float* __restrict__ gate,
+    const float* __restrict__ cb, const float* __restrict__ dp, const float* __restrict__ wq,
+    const float* __restrict__ wk, int ks, float* __restrict__ dyx, float* __restrict__ dwqk_part, int C, int HW, int d) {
+  extern __shared__ float sm[];
+  const int p = (ks - 1) / 2;
+  const int CPD = C + 2 * p;
+  float* ys = sm;            // [CPD] padded y
+  float* qs = ys + CPD;      // [C]
+  float* kk = qs + C;        // [C]
+  float* dqs = kk + C;       // [CPD] padded dq   (first used as da-per-channel scratch)
+  float* dks = dqs + CPD;    // [CPD] padded dk
+  float* dl = dks + CPD;     // [G]
+  float* scratch = dl + C / d;   // [kWaves]
+  const int b = blockIdx.x, tid = threadIdx.x;
+  const int G = C / d;
+  const float inv_hw = 1.0f / (float)HW;
+  const float dpb = dp ? dp[b] : 1.f;
+  for (int i = tid; i < CPD; i += kThreads) {
+    const int c = i - p;
+    ys[i] = (c >= 0 && c < C) ? mom[((size_t)b * C + c) * M_N + M_SX] * inv_hw : 0.f;
+    dqs[i] = 0.f;
+    dks[i] = 0.f;
+  }
+  __syncthreads();
+  for (int c = tid; c < C; c += kThreads) {
+    float q = 0.f, k = 0.f;
+    for (int j = 0; j < ks; ++j) {
+      q = fmaf(wq[j], ys[c + j], q);
+      k = fmaf(wk[j], ys[c + j], k);
+    }
+    qs[c] = q;
+    kk[c] = k;
+    const float* m = mom + ((size_t)b * C + c) * M_N;
+    const float* bm = bmom + ((size_t)b * C + c) * D_N;
+    const float a = gate[(size_t)b * G + c / d];
+    float e = 1.f, f = 0.f, Gc = 0.f, Hc = 0.f;
+    if (cb) { e = cb[c * 4 + 0]; f = cb[c * 4 + 1]; Gc = cb[c * 4 + 2]; Hc = cb[c * 4 + 3]; }
+    // sum_hw dm * V  for this channel
+    dqs[p + c] = e * dpb * bm[D_DV] + f * a * m[M_SVV] + Gc * m[M_SVO] + Hc * m[M_SV];
+  }
+  __syncthreads();
+  const float s = rsqrtf((float)d);
+  for (int g = tid; g < G; g += kThreads) {
+    float da = 0.f;
+    for (int i = 0; i < d; ++i) da += dqs[p + g * d + i];
+    const float a = gate[(size_t)b * G + g];
+    dl[g] = da * a * (1.f - a) * s;
+  }
+  __syncthreads();
+  for (int c = tid; c < C; c += kThreads) {
+    const float t = dl[c / d];
+    dqs[p + c] = t * kk[c];
+    dks[p + c] = t * qs[c];
+  }
+  __syncthreads();
+  for (int c = tid; c < C; c += kThreads) {
+    // dy[c] = sum_j wq[j]*dq[c-j+p] + wk[j]*dk[c-j+p]; padded index of (c-j+p) is c-j+2p
+    float dy = 0.f;
+    for (int j = 0; j < ks; ++j) {
+      dy = fmaf(wq[j], dqs[c - j + 2 * p], dy);
+      dy = fmaf(wk[j], dks[c - j + 2 * p], dy);
+    }
+    dyx[(size_t)b * C + c] = dy * inv_hw;
+  }
+  for (int j = 0; j < ks; ++j) {
+    float aq = 0.f, ak = 0.f;
+    for (int c = tid; c < C; c += kThreads) {
+      aq = fmaf(dqs[p + c], ys[c + j], aq);
+      ak = fmaf(dks[p + c], ys[c + j], ak);
+    }
+    aq = block_sum(aq, scratch);
+    ak = block_sum(ak, scratch);
+    if (tid == 0) {
+      dwqk_part[(size_t)b * 2 * ks + j] = aq;
+      dwqk_part[(size_t)b * 2 * ks + ks + j] = ak;
+    }
+  }
+}
+
+__global__ __launch_bounds__(kThreads) void reduce_rows_kernel(const float* __restrict__ in, float* __restrict__ out,
+                                                               int rows, int n) {
+  const int i = blockIdx.x * kThreads + threadIdx.x;
+  if (i >= n) return;
+  double s = 0.0;
+  for (int r = 0; r < rows; ++r) s += in[(size_t)r * n + i];
+  out[i] = (float)s;
+}
+
+// ------------------------------------------------------------------------------------------------
+// launchers
+// ------------------------------------------------------------------------------------------------
+int launch_gate_fwd(const float* mom, const float* wq, const float* wk, int ks, float* gate, int B, int C, int HW,
+                    int d, hipStream_t st) {
+  const size_t lds = (size_t)(2 * C + 2 * ((ks - 1) / 2)) * sizeof(float);
+  if (lds > 64 * 1024) return MRLA_EUNSUPPORTED;
+  hipLaunchKernelGGL(gate_fwd_kernel, dim3(B), dim3(kThreads), lds, st, mom, wq, wk, ks, gate, C, HW, d);
+  return hip_status(hipGetLastError());
+}
+
+int launch_bn_fwd(const float* mom, const float* gate, const float* lam, const float* gamma, const float* beta,
+                  float* run_mean, float* run_var, int training, float momentum, float eps, float* sc, float* sh,
+                  float* save_mean, float* save_inv, int B, int C, int HW, int d, hipStream_t st) {
+  hipLaunchKernelGGL(bn_fwd_kernel, dim3((C + kBnCh - 1) / kBnCh), dim3(kThreads), 0, st, mom, gate, lam, gamma, beta,
+                     run_mean, run_var, training, momentum, eps, sc, sh, save_mean, save_inv, B, C, HW, d);
+  return hip_status(hipGetLastError());
+}
+
+int launch_bn_bwd(const float* mom, const float* bmom, const float* gate, const float* lam, const float* gamma,
+                  const float* dp, const float* save_mean, const float* save_inv, int training, float* cb,
+                  float* dgamma, float* dbeta, float* dlam, int B, int C, int HW, int d, hipStream_t st) {
+  hipLaunchKernelGGL(bn_bwd_kernel, dim3((C + kBnCh - 1) / kBnCh), dim3(kThreads), 0, st, mom, bmom, gate, lam, gamma,
+                     dp, save_mean, save_inv, training, cb, dgamma, dbeta, dlam, B, C, HW, d);
+  return hip_status(hipGetLastError());
+}
+
+int launch_gate_bwd(const float* mom, const float* bmom, const float* gate, const float* cb, const float* dp,
+                    const float* wq, const float* wk, int ks, float* dyx, float* dwqk_part, int B, int C, int HW,
+                    int d, hipStream_t st) {
+  const int p = (ks - 1) / 2;
+  const size_t lds = (size_t)(3 * (C + 2 * p) + 2 * C + C / d + kWaves) * sizeof(float);
+  if (lds > 64 * 1024) return MRLA_EUNSUPPORTED;
+  hipLaunchKernelGGL(gate_bwd_kernel, dim3(B), dim3(kThreads), lds, st, mom, bmom, gate, cb, dp, wq, wk, ks, dyx,
+                     dwqk_part, C, HW, d);
+  return hip_status(hipGetLastError());
+}
+
+int launch_reduce_rows(const float* in, float* out, int rows, int n, hipStream_t st) {
+  hipLaunchKernelGGL(reduce_rows_kernel, dim3((n + kThreads - 1) / kThreads), dim3(kThreads), 0, st, in, out, rows, n);
+  return hip_status(hipGetLastError());
+}
+
+}  // namespace mrla

@@ -1,0 +1,59 @@
+// Host-visible declarations shared by the kernel translation units and the C-ABI glue (capi.hip).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stddef.h>
+#include <stdint.h>
+
+#include "../../include/mrla_hip.h"
+
+namespace mrla {
+
+constexpr int kMaxTasksPerWave = 4;   // apply_bwd keeps this many (plane-group, row-band) wgrad slots per wave
+
+// Geometry of the NCHW slab decomposition; built on the host by make_slab_geo().
+struct SlabGeo {
+  int B, C, H, W, HW;
+  int CP;        // channel planes per slab (one slab = CP*HW contiguous elements of one image)
+  int slabs;     // slabs per image = ceil(C / CP)
+  int PW;        // planes marched side by side by one wave = floor(64 / W)
+  int NG;        // wave groups per slab = ceil(CP / PW)
+  int NB;        // row bands per plane group
+  int RB;        // rows per band
+  int BG;        // images looped over by one workgroup
+  int astride;   // LDS elements reserved per staged array (16-byte multiple)
+};
+
+inline size_t dtype_size(int dtype) { return dtype == MRLA_F32 ? 4 : 2; }
+
+inline int hip_status(hipError_t e) { return e == hipSuccess ? MRLA_OK : MRLA_EHIP; }
+
+// Returns MRLA_OK or MRLA_EUNSUPPORTED (plane wider than a wave / slab does not fit LDS).
+int make_slab_geo(SlabGeo* g, int B, int C, int H, int W, int dtype, int arrays, int bg_hint);
+
+int launch_light_stats_fwd_nchw(const void* x, const void* o, const float* wv, float* mom, const SlabGeo& g,
+                                int dtype, int act, hipStream_t st);
+int launch_light_apply_fwd_nchw(const void* x, const void* o, const float* wv, const float* gate, const float* sc,
+                                const float* sh, const float* lam, const float* dp, void* out, const SlabGeo& g,
+                                int d, int res, int dtype, int act, hipStream_t st);
+int launch_light_stats_bwd_nchw(const void* dout, const void* x, const void* o, const float* wv, float* bmom,
+                                const SlabGeo& g, int dtype, int act, hipStream_t st);
+int launch_light_apply_bwd_nchw(const void* dout, const void* x, const void* o, const float* wv, const float* gate,
+                                const float* cb, const float* lam, const float* dp, const float* dyx, void* dx,
+                                void* dprev, float* dwv_part, const SlabGeo& g, int d, int res, int dtype, int act,
+                                hipStream_t st);
+
+// gate.hip -- the small per-(image, channel) kernels
+int launch_gate_fwd(const float* mom, const float* wq, const float* wk, int ks, float* gate, int B, int C, int HW,
+                    int d, hipStream_t st);
+int launch_bn_fwd(const float* mom, const float* gate, const float* lam, const float* gamma, const float* beta,
+                  float* run_mean, float* run_var, int training, float momentum, float eps, float* sc, float* sh,
+                  float* save_mean, float* save_inv, int B, int C, int HW, int d, hipStream_t st);
+int launch_bn_bwd(const float* mom, const float* bmom, const float* gate, const float* lam, const float* gamma,
+                  const float* dp, const float* save_mean, const float* save_inv, int training, float* cb,
+                  float* dgamma, float* dbeta, float* dlam, int B, int C, int HW, int d, hipStream_t st);
+int launch_gate_bwd(const float* mom, const float* bmom, const float* gate, const float* cb, const float* dp,
+                    const float* wq, const float* wk, int ks, float* dyx, float* dwqk_part, int B, int C, int HW,
+                    int d, hipStream_t st);
+int launch_reduce_rows(const float* in, float* out, int rows, int n, hipStream_t st);
+
+}  // namespace mrla

@@ -1,0 +1,180 @@
+"""torch.autograd wrappers around the C ABI (include/mrla_hip.h).
+
+PyTorch is plumbing here: it owns the device buffers and the stream and records the autograd edge; all
+arithmetic of the MRLA path happens in libmrla_hip.so.  There is deliberately no fallback: CPU tensors or
+a missing library raise.
+"""
+import ctypes
+from math import log
+
+import torch
+
+from . import _lib as L
+
+_DT = {torch.float32: L.F32, torch.bfloat16: L.BF16, torch.float16: L.F16}
+
+
+def k_size_for(c):
+    """Conv1d tap count of Wq / Wk (reference: mrla_light_module.py:40-42)."""
+    t = int(abs((log(c, 2) + 1) / 2.0))
+    return t if t % 2 else t + 1
+
+
+def _ptr(t):
+    return ctypes.c_void_p(t.data_ptr()) if t is not None else None
+
+
+def _stream():
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _f32(t):
+    """Parameters / statistics as contiguous float32 (no copy when they already are)."""
+    if t is None:
+        return None
+    t = t.detach()
+    if t.dtype != torch.float32:
+        t = t.float()
+    return t.contiguous()
+
+
+def _require_cuda(x, what):
+    if not x.is_cuda:
+        raise L.MrlaHipError(f"{what}: got a {x.device} tensor. mrla_amd runs only on an AMD GPU through libmrla_hip.so; "
+                             "the CPU restatement lives in oracle/ and is test infrastructure, not a fallback.")
+    if x.dtype not in _DT:
+        raise L.MrlaHipError(f"{what}: unsupported dtype {x.dtype}")
+
+
+def _layout_of(x):
+    """(layout enum, tensor to hand to the kernels).  NCHW-contiguous is the reference's contract."""
+    if x.is_contiguous():
+        return L.NCHW, x
+    return L.NCHW, x.contiguous()
+
+
+class LightConfig:
+    """Static configuration of one MRLA-light call."""
+    __slots__ = ("d", "bn_mode", "momentum", "eps", "res", "act")
+
+    def __init__(self, d, bn_mode=L.BN_NONE, momentum=0.1, eps=1e-5, res=0, act=L.ACT_NONE):
+        self.d, self.bn_mode, self.momentum, self.eps, self.res, self.act = d, bn_mode, momentum, eps, res, act
+
+
+class _LightFn(torch.autograd.Function):
+    """out = res*x + dp[b] * BN( a[b,g] * act(dwconv3x3(x, wv)) + lam * o_prev )
+
+    Covers mrla_light_layer (o_prev = lam = BN = dp = None, res = 0), the light mrla_module (+ lam*o_prev)
+    and the fused block tail of resnet_mrla_light.py:116 (BN + DropPath + residual).
+    """
+
+    @staticmethod
+    def forward(ctx, x, o_prev, wq, wk, wv, lam, gamma, beta, running_mean, running_var, dp, cfg):
+        _require_cuda(x, "mrla light forward")
+        layout, xc = _layout_of(x)
+        b, c, h, w = xc.shape
+        d = cfg.d
+        if c % d:
+            raise L.MrlaHipError(f"channels ({c}) not divisible by dim_perhead ({d})")
+        oc = None
+        if o_prev is not None:
+            if o_prev.shape != x.shape or o_prev.dtype != x.dtype:
+                raise L.MrlaHipError("o_prev must match x in shape and dtype")
+            oc = _layout_of(o_prev)[1]
+        dt = _DT[xc.dtype]
+        dev = xc.device
+        wq32, wk32 = _f32(wq).reshape(-1), _f32(wk).reshape(-1)
+        wv32 = _f32(wv).reshape(c, 9)
+        lam32 = _f32(lam).reshape(-1) if lam is not None else None
+        dp32 = _f32(dp).reshape(-1) if dp is not None else None
+        ks = wq32.numel()
+        G = c // d
+        st = _stream()
+
+        mom = torch.empty((b, c, L.FWD_MOMENTS), dtype=torch.float32, device=dev)
+        L.call("mrla_light_stats_fwd", _ptr(xc), _ptr(oc), _ptr(wv32), _ptr(mom), b, c, h, w, dt, layout, cfg.act, st)
+        gate = torch.empty((b, G), dtype=torch.float32, device=dev)
+        L.call("mrla_light_gate_fwd", _ptr(mom), _ptr(wq32), _ptr(wk32), ks, _ptr(gate), b, c, h * w, d, st)
+        bnbuf = gamma32 = None
+        if cfg.bn_mode != L.BN_NONE:
+            gamma32, beta32 = _f32(gamma), _f32(beta)
+            if running_mean.dtype != torch.float32 or not running_mean.is_contiguous():
+                raise L.MrlaHipError("running statistics must be contiguous float32 buffers")
+            bnbuf = torch.empty((4, c), dtype=torch.float32, device=dev)       # sc, sh, save_mean, save_inv
+            L.call("mrla_light_bn_fwd", _ptr(mom), _ptr(gate), _ptr(lam32), _ptr(gamma32), _ptr(beta32),
+                   _ptr(running_mean), _ptr(running_var), cfg.bn_mode, float(cfg.momentum), float(cfg.eps),
+                   _ptr(bnbuf[0]), _ptr(bnbuf[1]), _ptr(bnbuf[2]), _ptr(bnbuf[3]), b, c, h * w, d, st)
+        out = torch.empty_like(xc)
+        L.call("mrla_light_apply_fwd", _ptr(xc), _ptr(oc), _ptr(wv32), _ptr(gate),
+               _ptr(bnbuf[0]) if bnbuf is not None else None, _ptr(bnbuf[1]) if bnbuf is not None else None,
+               _ptr(lam32), _ptr(dp32), _ptr(out), b, c, h, w, d, cfg.res, dt, layout, cfg.act, st)
+
+        ctx.cfg, ctx.layout, ctx.ks = cfg, layout, ks
+        ctx.shapes = (wq.shape, wk.shape, wv.shape, lam.shape if lam is not None else None)
+        ctx.pdtypes = (wq.dtype, wk.dtype, wv.dtype, lam.dtype if lam is not None else None,
+                       gamma.dtype if gamma is not None else None)
+        ctx.save_for_backward(xc, oc, wq32, wk32, wv32, lam32, gamma32, dp32, mom, gate, bnbuf)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        xc, oc, wq32, wk32, wv32, lam32, gamma32, dp32, mom, gate, bnbuf = ctx.saved_tensors
+        cfg, layout, ks = ctx.cfg, ctx.layout, ctx.ks
+        b, c, h, w = xc.shape
+        d = cfg.d
+        dt = _DT[xc.dtype]
+        dev = xc.device
+        st = _stream()
+        if dout.dtype != xc.dtype:
+            dout = dout.to(xc.dtype)
+        dout = dout.contiguous()
+
+        bmom = torch.empty((b, c, L.BWD_MOMENTS), dtype=torch.float32, device=dev)
+        L.call("mrla_light_stats_bwd", _ptr(dout), _ptr(xc), _ptr(oc), _ptr(wv32), _ptr(bmom), b, c, h, w, dt, layout,
+               cfg.act, st)
+        small = torch.empty((7, c), dtype=torch.float32, device=dev)      # cb[c,4] | dgamma | dbeta | dlam
+        cb = small[:4].view(c, 4)
+        has_bn = cfg.bn_mode != L.BN_NONE
+        L.call("mrla_light_bn_bwd", _ptr(mom), _ptr(bmom), _ptr(gate), _ptr(lam32), _ptr(gamma32) if has_bn else None,
+               _ptr(dp32), _ptr(bnbuf[2]) if has_bn else None, _ptr(bnbuf[3]) if has_bn else None, cfg.bn_mode,
+               _ptr(cb), _ptr(small[4]) if has_bn else None, _ptr(small[5]) if has_bn else None,
+               _ptr(small[6]) if lam32 is not None else None, b, c, h * w, d, st)
+        dyx = torch.empty((b, c), dtype=torch.float32, device=dev)
+        dwqk_part = torch.empty((b, 2 * ks), dtype=torch.float32, device=dev)
+        L.call("mrla_light_gate_bwd", _ptr(mom), _ptr(bmom), _ptr(gate), _ptr(cb), _ptr(dp32), _ptr(wq32), _ptr(wk32), ks,
+               _ptr(dyx), _ptr(dwqk_part), b, c, h * w, d, st)
+        rows = L.load().mrla_light_wgrad_rows(b, c, h, w, dt, layout)
+        L.check(min(rows, 0), "mrla_light_wgrad_rows")
+        dwv_part = torch.empty((rows, c * 9), dtype=torch.float32, device=dev)
+        dx = torch.empty_like(xc)
+        do = torch.empty_like(oc) if oc is not None else None
+        L.call("mrla_light_apply_bwd", _ptr(dout), _ptr(xc), _ptr(oc), _ptr(wv32), _ptr(gate), _ptr(cb), _ptr(lam32),
+               _ptr(dp32), _ptr(dyx), _ptr(dx), _ptr(do), _ptr(dwv_part), b, c, h, w, d, cfg.res, dt, layout, cfg.act, st)
+        wsum = torch.empty((c * 9 + 2 * ks,), dtype=torch.float32, device=dev)
+        L.call("mrla_reduce_rows", _ptr(dwv_part), _ptr(wsum), rows, c * 9, st)
+        L.call("mrla_reduce_rows", _ptr(dwqk_part), _ptr(wsum[c * 9:]), b, 2 * ks, st)
+
+        sq, sk, sv, sl = ctx.shapes
+        tq, tk, tv, tl, tg = ctx.pdtypes
+        dwv = wsum[:c * 9].view(sv).to(tv)
+        dwq = wsum[c * 9:c * 9 + ks].view(sq).to(tq)
+        dwk = wsum[c * 9 + ks:].view(sk).to(tk)
+        dlam = small[6].view(sl).to(tl) if lam32 is not None else None
+        dgamma = small[4].to(tg) if has_bn else None
+        dbeta = small[5].to(tg) if has_bn else None
+        return dx, do, dwq, dwk, dwv, dlam, dgamma, dbeta, None, None, None, None
+
+
+def mrla_light(x, wq, wk, wv, d, o_prev=None, lam=None, bn=None, dp=None, res=False, act_gelu=False):
+    """Functional entry point.
+
+    bn: None or dict(weight, bias, running_mean, running_var, training, momentum, eps).
+    dp: per-sample drop-path multiplier [b] (mask / keep_prob) or None.
+    """
+    if bn is None:
+        cfg = LightConfig(d, L.BN_NONE, res=int(res), act=L.ACT_GELU if act_gelu else L.ACT_NONE)
+        return _LightFn.apply(x, o_prev, wq, wk, wv, lam, None, None, None, None, dp, cfg)
+    cfg = LightConfig(d, L.BN_TRAIN if bn["training"] else L.BN_EVAL, bn.get("momentum", 0.1), bn.get("eps", 1e-5),
+                      int(res), L.ACT_GELU if act_gelu else L.ACT_NONE)
+    return _LightFn.apply(x, o_prev, wq, wk, wv, lam, bn["weight"], bn["bias"], bn["running_mean"], bn["running_var"],
+                          dp, cfg)

@@ -1,0 +1,164 @@
+"""GPU parity: HIP MRLA-light path (through the C ABI) vs the numpy oracle and the reference's goldens.
+
+Protocol (SURVEY.md section 7 "bf16 tolerance"):
+  fp32  : kernel vs fp64 oracle on the same fp32 inputs, error relative to the tensor's max-abs; bound 5e-6 for
+          activations (the reference's own fp32 result differs from the fp64 oracle by about as much).
+  bf16  : inputs/weights pre-rounded to bf16; kernel output (bf16) vs the fp64 oracle rounded once to bf16 must
+          agree within 1 bf16 ulp (2^-7 relative), plus an absolute floor for values near zero.
+"""
+import numpy as np
+import pytest
+import torch
+
+from oracle import mrla_numpy as mn
+from tests import cases
+
+pytestmark = pytest.mark.gpu
+
+ACT_TOL = 5e-6
+PAR_TOL = 5e-5
+
+
+def relmax(got, want):
+    want = np.asarray(want, np.float64)
+    return np.abs(np.asarray(got, np.float64) - want).max() / max(np.abs(want).max(), 1e-12)
+
+
+def to_dev(a, dtype=torch.float32):
+    return torch.from_numpy(np.ascontiguousarray(a)).to("cuda", dtype)
+
+
+def run_light(x, o, P, d, mode, dp_mask, p_drop, gup, dtype=torch.float32, rm=None, rv=None):
+    from mrla_amd.functional import mrla_light
+    xt = to_dev(x, dtype).requires_grad_(True)
+    ot = to_dev(o, dtype).requires_grad_(True)
+    prm = {k: to_dev(v).requires_grad_(True) for k, v in P.items() if "running" not in k}
+    rmt = to_dev(P["bn_mrla.running_mean"] if rm is None else rm)
+    rvt = to_dev(P["bn_mrla.running_var"] if rv is None else rv)
+    dp = None
+    if dp_mask is not None:
+        dp = to_dev(dp_mask / (1.0 - p_drop))
+    out = mrla_light(xt, prm["mrla.mrla.Wq.weight"], prm["mrla.mrla.Wk.weight"], prm["mrla.mrla.Wv.weight"], d,
+                     o_prev=ot, lam=prm["mrla.lambda_t"],
+                     bn=dict(weight=prm["bn_mrla.weight"], bias=prm["bn_mrla.bias"], running_mean=rmt, running_var=rvt,
+                             training=(mode != "eval"), momentum=0.1, eps=1e-5), dp=dp, res=True)
+    out.backward(to_dev(gup, dtype))
+    torch.cuda.synchronize()
+    g = dict(out=out.detach().float().cpu().numpy(), dx=xt.grad.float().cpu().numpy(), do=ot.grad.float().cpu().numpy(),
+             rm=rmt.cpu().numpy(), rv=rvt.cpu().numpy())
+    for k, v in prm.items():
+        g["grad/" + k] = v.grad.cpu().numpy()
+    return g
+
+
+def oracle_light(x, o, P, d, mode, dp_mask, p_drop, gup):
+    P = {k: np.asarray(v, np.float64) for k, v in P.items()}
+    dp = None if dp_mask is None else mn.drop_path_scale(dp_mask, p_drop)
+    out, cache = mn.light_tail_fwd(np.asarray(x, np.float64), np.asarray(o, np.float64),
+                                   P["mrla.mrla.Wq.weight"].ravel(), P["mrla.mrla.Wk.weight"].ravel(),
+                                   P["mrla.mrla.Wv.weight"][:, 0], P["mrla.lambda_t"].ravel(), P["bn_mrla.weight"],
+                                   P["bn_mrla.bias"], P["bn_mrla.running_mean"], P["bn_mrla.running_var"], d,
+                                   training=(mode != "eval"), dp=dp)
+    g = mn.light_tail_bwd(np.asarray(gup, np.float64), cache)
+    return out, cache, g
+
+
+@pytest.mark.parametrize("case", cases.LIGHT_CASES, ids=lambda c: c[0])
+@pytest.mark.parametrize("mode", ["train", "eval", "traindp"])
+def test_light_tail_fp32_vs_oracle_and_reference(case, mode):
+    name, b, c, h, w, d = case
+    G = cases.golden("light_blocks")
+    x, o, gup = cases.light_inputs(name, b, c, h, w)
+    P = cases.block_params(c, 1)
+    key = f"{name}/{mode}/"
+    mask = G[key + "dp_mask"] if mode == "traindp" else None
+    got = run_light(x, o, P, d, mode, mask, 0.25, gup)
+    out, cache, g = oracle_light(x, o, P, d, mode, mask, 0.25, gup)
+    assert relmax(got["out"], out) < ACT_TOL
+    assert relmax(got["dx"], g["dx"]) < ACT_TOL
+    assert relmax(got["do"], g["do_prev"]) < ACT_TOL
+    assert relmax(got["rm"], cache["bn"]["new_rm"]) < ACT_TOL
+    assert relmax(got["rv"], cache["bn"]["new_rv"]) < ACT_TOL
+    for ours, theirs in (("mrla.mrla.Wq.weight", "dwq"), ("mrla.mrla.Wk.weight", "dwk"), ("mrla.mrla.Wv.weight", "dwv"),
+                         ("mrla.lambda_t", "dlam"), ("bn_mrla.weight", "dgamma"), ("bn_mrla.bias", "dbeta")):
+        assert relmax(got["grad/" + ours].ravel(), np.asarray(g[theirs]).ravel()) < PAR_TOL, ours
+    # and directly against what the reference itself produced (fp32, so its own rounding is in the budget)
+    sub = (lambda a: a[:, ::8]) if name == "s2048" else (lambda a: a)
+    assert relmax(sub(got["out"]), G[key + "out"]) < 2e-5
+    assert relmax(sub(got["dx"]), G[key + "dx"]) < 2e-5
+    assert relmax(sub(got["do"]), G[key + "do"]) < 2e-5
+    assert relmax(got["grad/mrla.mrla.Wv.weight"], G[key + "grad/mrla.mrla.Wv.weight"]) < 1e-4
+    assert relmax(got["grad/mrla.lambda_t"], G[key + "grad/mrla.lambda_t"]) < 1e-4
+
+
+def bf16_round(a):
+    return torch.from_numpy(np.ascontiguousarray(a, dtype=np.float32)).to(torch.bfloat16).float().numpy()
+
+
+def assert_bf16_close(got, want64, what):
+    want = bf16_round(want64)
+    tol = np.abs(want) * 2.0 ** -7 + 1e-3 * np.abs(want64).max() * 2.0 ** -7 + 1e-30
+    bad = np.abs(got - want) > tol
+    assert not bad.any(), f"{what}: {bad.sum()} of {bad.size} beyond 1 bf16 ulp; worst {np.abs(got - want).max()}"
+
+
+STAGE_SHAPES = [(4, 256, 56, 56, 32), (4, 512, 28, 28, 32), (4, 1024, 14, 14, 32), (3, 2048, 7, 7, 32)]
+
+
+@pytest.mark.parametrize("shape", STAGE_SHAPES, ids=lambda s: "x".join(map(str, s[:4])))
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16], ids=["fp32", "bf16"])
+def test_light_tail_resnet50_stage_shapes(shape, dtype):
+    b, c, h, w, d = shape
+    from oracle import detgen
+    s = detgen.seed_of(f"stage/{c}")
+    x = np.maximum(detgen.normalish((b, c, h, w), s), 0) + 0.1 * detgen.normalish((b, c, h, w), s + 1)
+    o = detgen.normalish((b, c, h, w), s + 2)
+    gup = detgen.normalish((b, c, h, w), s + 3)
+    P = cases.block_params(c, 7)
+    mask = np.array([1, 0, 1, 1][:b], dtype=np.float32)
+    if dtype == torch.bfloat16:
+        x, o, gup = bf16_round(x), bf16_round(o), bf16_round(gup)
+    got = run_light(x, o, P, d, "train", mask, 0.2, gup, dtype)
+    out, cache, g = oracle_light(x, o, P, d, "train", mask, 0.2, gup)
+    if dtype == torch.float32:
+        assert relmax(got["out"], out) < ACT_TOL
+        assert relmax(got["dx"], g["dx"]) < ACT_TOL
+        assert relmax(got["do"], g["do_prev"]) < ACT_TOL
+    else:
+        assert_bf16_close(got["out"], out, "out")
+        assert_bf16_close(got["dx"], g["dx"], "dx")
+        assert_bf16_close(got["do"], g["do_prev"], "do")
+    for ours, theirs in (("mrla.mrla.Wq.weight", "dwq"), ("mrla.mrla.Wk.weight", "dwk"), ("mrla.mrla.Wv.weight", "dwv"),
+                         ("mrla.lambda_t", "dlam"), ("bn_mrla.weight", "dgamma"), ("bn_mrla.bias", "dbeta")):
+        assert relmax(got["grad/" + ours].ravel(), np.asarray(g[theirs]).ravel()) < PAR_TOL, ours
+
+
+def test_layer_only_and_module_forms():
+    """mrla_light_layer (a1) and light mrla_module (a2) through the same kernels, fp32."""
+    from mrla_amd.functional import mrla_light
+    name, b, c, h, w, d = cases.LIGHT_CASES[1]
+    G = cases.golden("light_blocks")
+    x, o, gup = cases.light_inputs(name, b, c, h, w)
+    P = cases.block_params(c, 1)
+    xt, ot = to_dev(x).requires_grad_(True), to_dev(o).requires_grad_(True)
+    wq, wk, wv, lam = (to_dev(P[k]).requires_grad_(True) for k in
+                       ("mrla.mrla.Wq.weight", "mrla.mrla.Wk.weight", "mrla.mrla.Wv.weight", "mrla.lambda_t"))
+    layer = mrla_light(xt, wq, wk, wv, d)
+    assert relmax(layer.detach().cpu().numpy(), G[f"{name}/train/layer_out"]) < 2e-5
+    m = mrla_light(xt, wq, wk, wv, d, o_prev=ot, lam=lam)
+    assert relmax(m.detach().cpu().numpy(), G[f"{name}/train/m"]) < 2e-5
+    lo, cache = mn.light_layer_fwd(x.astype(np.float64), P["mrla.mrla.Wq.weight"].ravel().astype(np.float64),
+                                   P["mrla.mrla.Wk.weight"].ravel().astype(np.float64),
+                                   P["mrla.mrla.Wv.weight"][:, 0].astype(np.float64), d)
+    gl = mn.light_layer_bwd(gup.astype(np.float64), cache)
+    layer.backward(to_dev(gup))
+    assert relmax(xt.grad.cpu().numpy(), gl["dx"]) < ACT_TOL
+    assert relmax(wv.grad.cpu().numpy()[:, 0], gl["dwv"]) < PAR_TOL
+    assert relmax(wq.grad.cpu().numpy().ravel(), gl["dwq"]) < PAR_TOL
+
+
+def test_cpu_tensor_is_rejected_loudly():
+    from mrla_amd import _lib
+    from mrla_amd.functional import mrla_light
+    with pytest.raises(_lib.MrlaHipError):
+        mrla_light(torch.zeros(1, 32, 4, 4), torch.zeros(1, 1, 3), torch.zeros(1, 1, 3), torch.zeros(32, 1, 3, 3), 32)

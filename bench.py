@@ -1,0 +1,198 @@
+#!/usr/bin/env python3
+"""Headline benchmark: images/sec fwd+bwd of resnet50_mrlal, batch 256 per GPU, bf16 autocast, synthetic
+ImageNet-shaped data (BASELINE.json metric / configs[1]; configs[2] for --gpus N > 1).
+
+    python bench.py --gpus 1 --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+        bench.py --gpus N --steps K --warmup W
+
+A "step" = forward + loss + backward + SGD update on one synthetic batch already resident in HBM.  Rank 0 prints
+ONE JSON line.  Besides the contract keys it carries
+  roofline     -- HBM roofline of the dominant MRLA kernel (mrla_light_apply_bwd), timed live with HIP events on
+                  the launch stream over the timed region; algorithmic bytes = 5*N*sizeof(bf16) per launch;
+  cpu_baseline -- the eager CPU restatement (oracle/eager_models.py, kind "port") forward on the host cores,
+                  bounded sample, rank 0 at N=1 only;
+  eager_rocm   -- the same restatement run eager on this GPU (the north-star's ">=4x" denominator), N=1 only.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0     # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6300 GB/s is the measured copy ceiling
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--arch", default="resnet50_mrlal")
+    ap.add_argument("--batch", type=int, default=256, help="per-GPU batch")
+    ap.add_argument("--drop-path", type=float, default=0.2, help="resnet/train.py:67 default")
+    ap.add_argument("--no-baselines", action="store_true", help="skip the cpu_baseline / eager_rocm legs")
+    ap.add_argument("--eager", action="store_true", help="time the eager restatement instead (diagnostic)")
+    return ap.parse_args()
+
+
+def make_step(net, opt, x, y):
+    def step():
+        with torch.autocast("cuda", dtype=torch.bfloat16):
+            loss = torch.nn.functional.cross_entropy(net(x).float(), y)
+        opt.zero_grad(set_to_none=True)
+        loss.backward()
+        opt.step()
+        return loss
+    return step
+
+
+def sgd(params):
+    return torch.optim.SGD(params, lr=0.1, momentum=0.9, weight_decay=1e-4)   # resnet/train.py:199-201
+
+
+def timed(step, steps, warmup, dist_on):
+    import torch.distributed as dist
+    for _ in range(warmup):
+        step()
+    if dist_on:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        step()
+    torch.cuda.synchronize()
+    if dist_on:
+        dist.barrier()
+    dt = time.perf_counter() - t0
+    if dist_on:
+        t = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    return dt
+
+
+def cpu_baseline(arch):
+    """Eager CPU restatement, forward only, b=32 fp32, bounded to ~10-30 s."""
+    from oracle import eager_models as em
+    cores = os.cpu_count() or 1
+    threads = min(cores, 128)
+    torch.set_num_threads(threads)
+    net = getattr(em, "eager_" + arch)().eval()
+    xb = torch.randn(32, 3, 224, 224)
+    with torch.no_grad():
+        net(xb)
+        t0 = time.perf_counter()
+        n = 0
+        while n < 3 or (time.perf_counter() - t0 < 10.0 and n < 20):
+            net(xb)
+            n += 1
+        dt = time.perf_counter() - t0
+    return {"value": round(32 * n / dt, 2), "unit": "images/sec", "cores": threads, "kind": "port",
+            "sample": f"forward only (eval, no_grad), fp32, batch 32, {n} iterations after 1 warm-up, "
+                      f"torch.set_num_threads({threads}) of {cores} logical CPUs"}
+
+
+def eager_rocm(arch, batch, drop_path, steps=6):
+    from oracle import eager_models as em
+    torch.manual_seed(0)
+    net = getattr(em, "eager_" + arch)(drop_path=drop_path).cuda().train()
+    x = torch.randn(batch, 3, 224, 224, device="cuda")
+    y = torch.randint(0, 1000, (batch,), device="cuda")
+    step = make_step(net, sgd(net.parameters()), x, y)
+    dt = timed(step, steps, 3, False)
+    net.eval()
+    with torch.no_grad(), torch.autocast("cuda", dtype=torch.bfloat16):
+        for _ in range(2):
+            net(x)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            net(x)
+        torch.cuda.synchronize()
+        fw = (time.perf_counter() - t0) / steps
+    return {"fwd_bwd_images_per_sec": round(batch * steps / dt, 1), "fwd_images_per_sec": round(batch / fw, 1),
+            "what": "oracle/eager_models.py (stock ATen/MIOpen ops) on this GPU, same batch/dtype/optimizer"}
+
+
+def main():
+    args = parse()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    dist_on = world > 1
+    torch.cuda.set_device(local)
+    if dist_on:
+        import torch.distributed as dist
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+    if args.gpus != world and rank == 0:
+        print(f"warning: --gpus {args.gpus} but WORLD_SIZE={world}", file=sys.stderr)
+
+    from mrla_amd import functional as Fm
+    torch.manual_seed(0)
+    if args.eager:
+        from oracle import eager_models as em
+        net = getattr(em, "eager_" + args.arch)(drop_path=args.drop_path)
+    else:
+        from mrla_amd import models
+        import contextlib
+        import io
+        with contextlib.redirect_stdout(io.StringIO()):
+            net = getattr(models, args.arch)(drop_path=args.drop_path)
+    net = net.cuda().train()
+    if dist_on:
+        net = torch.nn.parallel.DistributedDataParallel(net, device_ids=[local], gradient_as_bucket_view=True)
+    gx = torch.Generator(device="cuda").manual_seed(0)
+    gy = torch.Generator(device="cuda").manual_seed(1)
+    x = torch.randn(args.batch, 3, 224, 224, device="cuda", generator=gx)
+    y = torch.randint(0, 1000, (args.batch,), device="cuda", generator=gy)
+    step = make_step(net, sgd(net.parameters()), x, y)
+
+    # warm-up without the timer, then the timed region with HIP-event timing of the dominant kernel
+    for _ in range(args.warmup):
+        step()
+    timer = Fm.KernelTimer(["mrla_light_apply_bwd", "mrla_light_stats_bwd", "mrla_light_apply_fwd",
+                            "mrla_light_stats_fwd"])
+    Fm.TIMER = timer
+    dt = timed(step, args.steps, 0, dist_on)
+    Fm.TIMER = None
+    ips = world * args.batch * args.steps / dt
+
+    if rank == 0:
+        ks = timer.summary()
+        dom = ks.get("mrla_light_apply_bwd")
+        roofline = None
+        if dom:
+            ach = dom["bytes"] / (dom["ms"] * 1e-3) / 1e9
+            roofline = {"bound": "hbm", "kernel": "light_apply_bwd_nchw<bf16>", "achieved": round(ach, 1),
+                        "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": None,
+                        "launches": dom["launches"], "avg_launch_us": round(1e3 * dom["ms"] / dom["launches"], 2),
+                        "algorithmic_bytes_per_launch_avg": dom["bytes"] // dom["launches"]}
+        out = {"metric": "images/sec fwd+bwd resnet50_mrlal b=256", "value": round(ips, 1), "unit": "images/sec",
+               "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(1e3 * dt / args.steps, 3),
+               "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+               "config": {"workload": f"{args.arch} fwd+bwd+SGD, {args.batch} images/GPU of 3x224x224, bf16 autocast, "
+                                      f"fp32 master weights, drop_path {args.drop_path}",
+                          "global_batch": world * args.batch, "parallelism": f"dp{world}",
+                          "path": "eager restatement" if args.eager else "mrla_amd (HIP MRLA tails + stock backbone)"},
+               "roofline": roofline,
+               "mrla_kernels": {k: {"launches": v["launches"], "ms_per_step": round(v["ms"] / args.steps, 3),
+                                    "GBps": round(v["bytes"] / (v["ms"] * 1e-3) / 1e9, 1)} for k, v in ks.items()}}
+        if world == 1 and not args.no_baselines:
+            out["eager_rocm"] = eager_rocm(args.arch, args.batch, args.drop_path)
+            out["cpu_baseline"] = cpu_baseline(args.arch)
+        print(json.dumps(out), flush=True)
+    if dist_on:
+        import torch.distributed as dist
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

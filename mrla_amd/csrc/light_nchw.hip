@@ -32,6 +32,7 @@ struct LaneTask {
   int r0, r1;   // row band [r0, r1)
   int pl;       // plane slot inside the wave group
   bool valid;
+  bool live;     // wave-uniform: this (plane group, band) holds at least one real plane
   float lmask, rmask;   // 0 at the left / right plane edge, else 1
 };
 
@@ -44,8 +45,9 @@ __device__ __forceinline__ LaneTask make_task(const SlabGeo& g, int task, int np
   t.pl = lane / g.W;
   t.col = lane - t.pl * g.W;
   t.p = grp * g.PW + t.pl;
+  t.live = grp * g.PW < np;
   t.valid = (t.pl < g.PW) && (t.p < np);
-  if (!t.valid) { t.p = grp * g.PW; t.col = 0; }          // park on a valid address
+  if (!t.valid) { t.p = t.live ? grp * g.PW : 0; t.col = 0; }   // park on a real plane (parameters are indexed by it)
   t.lmask = (t.col > 0) ? 1.f : 0.f;
   t.rmask = (t.col < g.W - 1) ? 1.f : 0.f;
   return t;
@@ -100,6 +102,7 @@ __global__ __launch_bounds__(kThreads) void light_stats_fwd_nchw(
     __syncthreads();
     for (int task = wave; task < ntasks; task += kWaves) {
       const LaneTask t = make_task(g, task, np, lane);
+      if (!t.live) continue;
       const T* xp = xs + t.p * g.HW;
       const T* op = os + t.p * g.HW;
       float w[9];
@@ -166,6 +169,7 @@ __global__ __launch_bounds__(kThreads) void light_apply_fwd_nchw(
     const float dpb = dp ? dp[b] : 1.f;
     for (int task = wave; task < ntasks; task += kWaves) {
       const LaneTask t = make_task(g, task, np, lane);
+      if (!t.live) continue;
       const int c = c0 + t.p;
       const T* xp = xs + t.p * g.HW;
       T* op = os + t.p * g.HW;
@@ -220,6 +224,7 @@ __global__ __launch_bounds__(kThreads) void light_stats_bwd_nchw(
     __syncthreads();
     for (int task = wave; task < ntasks; task += kWaves) {
       const LaneTask t = make_task(g, task, np, lane);
+      if (!t.live) continue;
       const T* xp = xs + t.p * g.HW;
       const T* gp = gs + t.p * g.HW;
       const T* op = os + t.p * g.HW;
@@ -259,7 +264,7 @@ __global__ __launch_bounds__(kThreads) void light_stats_bwd_nchw(
 // ------------------------------------------------------------------------------------------------
 // backward apply:  dx, do, and per-(image group, channel) partial sums of dwv
 // ------------------------------------------------------------------------------------------------
-template <typename T, bool GELU>
+template <typename T, bool GELU, int TPW>
 __global__ __launch_bounds__(kThreads) void light_apply_bwd_nchw(
     const T* __restrict__ dout, const T* __restrict__ x, const T* __restrict__ o, const float* __restrict__ wv,
     const float* __restrict__ gate /*[b,g]*/, const float* __restrict__ cb /*[c,4]: e,f,G,H or null*/,
@@ -281,10 +286,10 @@ __global__ __launch_bounds__(kThreads) void light_apply_bwd_nchw(
   const int G = g.C / d;
   const int b_end = min(g.B, (int)(blockIdx.y + 1) * g.BG);
   // wgrad accumulators live across the image loop; a wave revisits the same (task -> plane) mapping for
-  // every image, so up to kMaxTasksPerWave task slots are kept in registers.
-  float wg[kMaxTasksPerWave][9];
+  // every image, so its TPW = ceil(ntasks / 4) task slots are kept in registers.
+  float wg[TPW][9];
 #pragma unroll
-  for (int s = 0; s < kMaxTasksPerWave; ++s)
+  for (int s = 0; s < TPW; ++s)
 #pragma unroll
     for (int k = 0; k < 9; ++k) wg[s][k] = 0.f;
 
@@ -296,10 +301,10 @@ __global__ __launch_bounds__(kThreads) void light_apply_bwd_nchw(
     __syncthreads();
     const float dpb = dp ? dp[b] : 1.f;
 #pragma unroll
-    for (int s = 0; s < kMaxTasksPerWave; ++s) {
+    for (int s = 0; s < TPW; ++s) {
       const int task = wave + s * kWaves;
-      if (task < ntasks) {
-        const LaneTask t = make_task(g, task, np, lane);
+      const LaneTask t = make_task(g, min(task, ntasks - 1), np, lane);
+      if (task < ntasks && t.live) {
         const int c = c0 + t.p;
         const T* xp = xs + t.p * g.HW;
         const T* gp = gs + t.p * g.HW;
@@ -365,10 +370,10 @@ __global__ __launch_bounds__(kThreads) void light_apply_bwd_nchw(
   }
   // reduce the wgrad accumulators: lanes of a plane row -> bands -> one value per (plane, tap)
 #pragma unroll
-  for (int s = 0; s < kMaxTasksPerWave; ++s) {
+  for (int s = 0; s < TPW; ++s) {
     const int task = wave + s * kWaves;
-    if (task < ntasks) {
-      const LaneTask t = make_task(g, task, np, lane);
+    const LaneTask t = make_task(g, min(task, ntasks - 1), np, lane);
+    if (task < ntasks && t.live) {
 #pragma unroll
       for (int k = 0; k < 9; ++k) {
         const float v = seg_sum(t.valid ? wg[s][k] : 0.f, t.col, g.W);
@@ -459,12 +464,20 @@ int launch_light_apply_bwd_nchw(const void* dout, const void* x, const void* o, 
   const size_t es = dtype_size(dtype);
   const size_t lds = (size_t)g.astride * es * (o ? 5 : 3) + (size_t)g.NG * g.NB * g.PW * 9 * sizeof(float);
   const dim3 grid(g.slabs, (g.B + g.BG - 1) / g.BG);
+  const int tpw = (g.NG * g.NB + kWaves - 1) / kWaves;
+#define CALL_TPW(T, A, TPW)                                                                         \
+  {                                                                                                 \
+    if (set_lds(light_apply_bwd_nchw<T, A, TPW>, lds) != hipSuccess) return MRLA_EHIP;                \
+    hipLaunchKernelGGL((light_apply_bwd_nchw<T, A, TPW>), grid, dim3(kThreads), lds, st,              \
+                       (const T*)dout, (const T*)x, (const T*)o, wv, gate, cb, lam, dp, dyx, (T*)dx, \
+                       (T*)dprev, dwv_part, g, d, res);                                             \
+  }
 #define CALL(T, A)                                                                                  \
   {                                                                                                 \
-    if (set_lds(light_apply_bwd_nchw<T, A>, lds) != hipSuccess) return MRLA_EHIP;                     \
-    hipLaunchKernelGGL((light_apply_bwd_nchw<T, A>), grid, dim3(kThreads), lds, st, (const T*)dout,   \
-                       (const T*)x, (const T*)o, wv, gate, cb, lam, dp, dyx, (T*)dx, (T*)dprev,     \
-                       dwv_part, g, d, res);                                                        \
+    if (tpw <= 1) CALL_TPW(T, A, 1)                                                                 \
+    else if (tpw == 2) CALL_TPW(T, A, 2)                                                            \
+    else if (tpw <= kMaxTasksPerWave) CALL_TPW(T, A, kMaxTasksPerWave)                              \
+    else return MRLA_EUNSUPPORTED;                                                                  \
   }
   MRLA_DISPATCH_T_ACT(dtype, act, CALL)
 #undef CALL

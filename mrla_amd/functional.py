@@ -20,6 +20,39 @@ def k_size_for(c):
     return t if t % 2 else t + 1
 
 
+class KernelTimer:
+    """Optional HIP-event timing of selected C-ABI launches on the stream they are launched on (used by
+    bench.py for the roofline figure).  Events are read back only after the caller synchronises."""
+
+    def __init__(self, names):
+        self.names = set(names)
+        self.records = []          # (name, nbytes, start_event, end_event)
+
+    def summary(self):
+        out = {}
+        for name, nbytes, e0, e1 in self.records:
+            d = out.setdefault(name, dict(launches=0, ms=0.0, bytes=0))
+            d["launches"] += 1
+            d["ms"] += e0.elapsed_time(e1)
+            d["bytes"] += nbytes
+        return out
+
+
+TIMER = None      # set to a KernelTimer to time launches
+
+
+def _call(name, nbytes, *args):
+    t = TIMER
+    if t is not None and name in t.names:
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        L.call(name, *args)
+        e1.record()
+        t.records.append((name, nbytes, e0, e1))
+    else:
+        L.call(name, *args)
+
+
 def _ptr(t):
     return ctypes.c_void_p(t.data_ptr()) if t is not None else None
 
@@ -92,7 +125,7 @@ class _LightFn(torch.autograd.Function):
         st = _stream()
 
         mom = torch.empty((b, c, L.FWD_MOMENTS), dtype=torch.float32, device=dev)
-        L.call("mrla_light_stats_fwd", _ptr(xc), _ptr(oc), _ptr(wv32), _ptr(mom), b, c, h, w, dt, layout, cfg.act, st)
+        _call("mrla_light_stats_fwd", xc.numel() * xc.element_size() * (2 if oc is not None else 1), _ptr(xc), _ptr(oc), _ptr(wv32), _ptr(mom), b, c, h, w, dt, layout, cfg.act, st)
         gate = torch.empty((b, G), dtype=torch.float32, device=dev)
         L.call("mrla_light_gate_fwd", _ptr(mom), _ptr(wq32), _ptr(wk32), ks, _ptr(gate), b, c, h * w, d, st)
         bnbuf = gamma32 = None
@@ -105,7 +138,7 @@ class _LightFn(torch.autograd.Function):
                    _ptr(running_mean), _ptr(running_var), cfg.bn_mode, float(cfg.momentum), float(cfg.eps),
                    _ptr(bnbuf[0]), _ptr(bnbuf[1]), _ptr(bnbuf[2]), _ptr(bnbuf[3]), b, c, h * w, d, st)
         out = torch.empty_like(xc)
-        L.call("mrla_light_apply_fwd", _ptr(xc), _ptr(oc), _ptr(wv32), _ptr(gate),
+        _call("mrla_light_apply_fwd", xc.numel() * xc.element_size() * (3 if oc is not None else 2), _ptr(xc), _ptr(oc), _ptr(wv32), _ptr(gate),
                _ptr(bnbuf[0]) if bnbuf is not None else None, _ptr(bnbuf[1]) if bnbuf is not None else None,
                _ptr(lam32), _ptr(dp32), _ptr(out), b, c, h, w, d, cfg.res, dt, layout, cfg.act, st)
 
@@ -130,7 +163,7 @@ class _LightFn(torch.autograd.Function):
         dout = dout.contiguous()
 
         bmom = torch.empty((b, c, L.BWD_MOMENTS), dtype=torch.float32, device=dev)
-        L.call("mrla_light_stats_bwd", _ptr(dout), _ptr(xc), _ptr(oc), _ptr(wv32), _ptr(bmom), b, c, h, w, dt, layout,
+        _call("mrla_light_stats_bwd", xc.numel() * xc.element_size() * (3 if oc is not None else 2), _ptr(dout), _ptr(xc), _ptr(oc), _ptr(wv32), _ptr(bmom), b, c, h, w, dt, layout,
                cfg.act, st)
         small = torch.empty((7, c), dtype=torch.float32, device=dev)      # cb[c,4] | dgamma | dbeta | dlam
         cb = small[:4].view(c, 4)
@@ -148,7 +181,7 @@ class _LightFn(torch.autograd.Function):
         dwv_part = torch.empty((rows, c * 9), dtype=torch.float32, device=dev)
         dx = torch.empty_like(xc)
         do = torch.empty_like(oc) if oc is not None else None
-        L.call("mrla_light_apply_bwd", _ptr(dout), _ptr(xc), _ptr(oc), _ptr(wv32), _ptr(gate), _ptr(cb), _ptr(lam32),
+        _call("mrla_light_apply_bwd", xc.numel() * xc.element_size() * (5 if oc is not None else 3), _ptr(dout), _ptr(xc), _ptr(oc), _ptr(wv32), _ptr(gate), _ptr(cb), _ptr(lam32),
                _ptr(dp32), _ptr(dyx), _ptr(dx), _ptr(do), _ptr(dwv_part), b, c, h, w, d, cfg.res, dt, layout, cfg.act, st)
         wsum = torch.empty((c * 9 + 2 * ks,), dtype=torch.float32, device=dev)
         L.call("mrla_reduce_rows", _ptr(dwv_part), _ptr(wsum), rows, c * 9, st)

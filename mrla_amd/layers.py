@@ -1,0 +1,127 @@
+"""Host-side mirror of the reference's MRLA operator modules (same names, constructor arguments,
+parameter names and error behaviour), executing on libmrla_hip.so.
+
+Reference counterparts (paths relative to the reference repo):
+  mrla_light_layer   resnet/models/modules/mrla_light_module.py:9-74
+  mrla_module        resnet/models/resnet_mrla_light.py:32-43          (light: + lambda_t * o_{t-1})
+  DropPath           resnet/models/utils/drop.py:22-30
+  light_block_tail   resnet/models/resnet_mrla_light.py:116            (x + DropPath(bn_mrla(mrla(x, identity))))
+"""
+from math import sqrt
+
+import torch
+import torch.nn as nn
+
+from . import functional as F_
+from ._lib import MrlaHipError
+
+
+def _heads_and_ksize(input_dim, heads, dim_perhead, k_size):
+    if heads is None and dim_perhead is None:
+        raise ValueError("arguments heads and dim_perhead cannot be None at the same time !")
+    if dim_perhead is not None:
+        heads = int(input_dim / dim_perhead)
+    if k_size is None:
+        k_size = F_.k_size_for(input_dim)
+    return heads, k_size
+
+
+def drop_path_scale(batch, drop_prob, training, device):
+    """Per-sample multiplier of stochastic depth, floor(keep + U[0,1)) / keep, or None when inactive."""
+    if drop_prob == 0.0 or not training:
+        return None
+    keep = 1.0 - drop_prob
+    return torch.floor(keep + torch.rand((batch,), dtype=torch.float32, device=device)) / keep
+
+
+class DropPath(nn.Module):
+    """Stochastic depth per sample.  Inside the fused block tail only `drop_prob` is read (the mask is
+    applied by the HIP kernel); called on its own it behaves like the reference module."""
+
+    def __init__(self, drop_prob=None):
+        super().__init__()
+        self.drop_prob = drop_prob
+
+    def forward(self, x):
+        s = drop_path_scale(x.shape[0], self.drop_prob or 0.0, self.training, x.device)
+        if s is None:
+            return x
+        return x * s.to(x.dtype).view((-1,) + (1,) * (x.ndim - 1))
+
+
+class _QKVParams(nn.Module):
+    """Wq / Wk (Conv1d 1->1, k taps, no bias) and Wv (depthwise 3x3, no bias): parameter containers whose
+    names and shapes equal the reference's, so checkpoints interchange.  They are never called."""
+
+    def __init__(self, input_dim, heads, dim_perhead, k_size):
+        super().__init__()
+        heads, k_size = _heads_and_ksize(input_dim, heads, dim_perhead, k_size)
+        if heads <= 0 or input_dim % heads:
+            raise ValueError(f"input_dim ({input_dim}) must be divisible by heads ({heads})")
+        self.input_dim, self.heads, self.k_size = input_dim, heads, k_size
+        self.dim_perhead = input_dim // heads
+        self.Wq = nn.Conv1d(1, 1, kernel_size=k_size, padding=(k_size - 1) // 2, bias=False)
+        self.Wk = nn.Conv1d(1, 1, kernel_size=k_size, padding=(k_size - 1) // 2, bias=False)
+        self.Wv = nn.Conv2d(input_dim, input_dim, kernel_size=3, stride=1, padding=1, groups=input_dim, bias=False)
+        self._norm_fact = 1 / sqrt(input_dim / heads)
+
+    def _check(self, x):
+        if x.dim() != 4 or x.shape[1] != self.input_dim:
+            raise MrlaHipError(f"expected [b, {self.input_dim}, h, w], got {tuple(x.shape)}")
+
+
+class mrla_light_layer(_QKVParams):
+    """MRLA-light layer: sigmoid(per-head <Wq*y, Wk*y> / sqrt(d)) * dwconv3x3(x), y = GAP(x)."""
+
+    def __init__(self, input_dim, heads=None, dim_perhead=None, k_size=None):
+        super().__init__(input_dim, heads, dim_perhead, k_size)
+
+    def forward(self, x):
+        self._check(x)
+        return F_.mrla_light(x, self.Wq.weight, self.Wk.weight, self.Wv.weight, self.dim_perhead)
+
+
+class mrla_module(nn.Module):
+    """Light recurrence o_t = mrla_light(x_t) + lambda_t * o_{t-1} (one fused HIP pass)."""
+    dim_perhead = 32
+
+    def __init__(self, input_dim):
+        super().__init__()
+        self.mrla = mrla_light_layer(input_dim=input_dim, dim_perhead=self.dim_perhead)
+        self.lambda_t = nn.Parameter(torch.randn(input_dim, 1, 1))
+
+    def forward(self, xt, ot_1):
+        m = self.mrla
+        m._check(xt)
+        return F_.mrla_light(xt, m.Wq.weight, m.Wk.weight, m.Wv.weight, m.dim_perhead, o_prev=ot_1, lam=self.lambda_t)
+
+
+def _bn_args(bn):
+    """BatchNorm2d module -> argument dict of the fused tail (handles momentum=None and untracked stats)."""
+    training = bn.training or bn.running_mean is None
+    momentum = bn.momentum
+    rm, rv = bn.running_mean, bn.running_var
+    if bn.training and bn.track_running_stats and bn.num_batches_tracked is not None:
+        bn.num_batches_tracked.add_(1)
+        if momentum is None:
+            momentum = 1.0 / float(bn.num_batches_tracked)
+    if momentum is None:
+        momentum = 0.0
+    if rm is None:       # statistics not tracked: batch statistics in both modes, nothing to update
+        rm = torch.zeros_like(bn.weight, dtype=torch.float32)
+        rv = torch.ones_like(bn.weight, dtype=torch.float32)
+    return dict(weight=bn.weight, bias=bn.bias, running_mean=rm, running_var=rv, training=training,
+                momentum=momentum, eps=bn.eps)
+
+
+def light_block_tail(x, identity, mrla, bn_mrla, drop_path):
+    """x + DropPath(bn_mrla(mrla(x, identity))) -- fused into two HIP passes when bn_mrla is a BatchNorm2d."""
+    p = getattr(drop_path, "drop_prob", 0.0) or 0.0
+    if type(bn_mrla) is nn.BatchNorm2d and bn_mrla.affine:
+        m = mrla.mrla
+        m._check(x)
+        dp = drop_path_scale(x.shape[0], p, drop_path.training if isinstance(drop_path, nn.Module) else False, x.device)
+        return F_.mrla_light(x, m.Wq.weight, m.Wk.weight, m.Wv.weight, m.dim_perhead, o_prev=identity,
+                             lam=mrla.lambda_t, bn=_bn_args(bn_mrla), dp=dp, res=True)
+    # any other norm layer the caller injected: MRLA op on the GPU, then the caller's modules as they are
+    return x + drop_path(bn_mrla(mrla(x, identity)))

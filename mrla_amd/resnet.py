@@ -1,0 +1,165 @@
+"""ResNet + MRLA model classes with the reference's API surface (constructor keywords, attribute and
+state_dict names, factory names), whose MRLA block tails run on libmrla_hip.so.  The backbone
+convolutions / BatchNorms stay stock PyTorch (MIOpen), as in the reference.
+
+Reference counterparts: resnet/models/resnet_mrla_light.py:47-250, resnet/models/resnet_mrla_base.py:55-283.
+SE / ECA options (off in every BASELINE config) are accepted and rejected
+explicitly rather than silently ignored.
+"""
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from . import layers
+
+
+def _conv3x3(cin, cout, stride=1, groups=1, dilation=1):
+    return nn.Conv2d(cin, cout, 3, stride=stride, padding=dilation, groups=groups, bias=False, dilation=dilation)
+
+
+def _conv1x1(cin, cout, stride=1):
+    return nn.Conv2d(cin, cout, 1, stride=stride, bias=False)
+
+
+class _BottleneckTrunk(nn.Module):
+    """conv1x1-bn-relu, conv3x3-bn-relu, conv1x1-bn, shortcut add, relu: everything in front of the MRLA tail."""
+    expansion = 4
+
+    def __init__(self, inplanes, planes, stride, downsample, SE, ECA_size, groups, base_width, dilation, norm_layer):
+        super().__init__()
+        if SE or ECA_size is not None:
+            raise NotImplementedError("SE / ECA channel attention inside MRLA blocks is outside this build's scope")
+        norm_layer = norm_layer or nn.BatchNorm2d
+        width = int(planes * (base_width / 64.0)) * groups
+        self.conv1 = _conv1x1(inplanes, width)
+        self.bn1 = norm_layer(width)
+        self.conv2 = _conv3x3(width, width, stride, groups, dilation)
+        self.bn2 = norm_layer(width)
+        self.conv3 = _conv1x1(width, planes * self.expansion)
+        self.bn3 = norm_layer(planes * self.expansion)
+        self.relu = nn.ReLU(inplace=True)
+        self.downsample = downsample
+        self.stride = stride
+        self.se = None
+        self.eca = None
+        self._norm = norm_layer
+
+    def trunk(self, x):
+        identity = x
+        out = self.relu(self.bn1(self.conv1(x)))
+        out = self.relu(self.bn2(self.conv2(out)))
+        out = self.bn3(self.conv3(out))
+        if self.downsample is not None:
+            identity = self.downsample(x)
+        out += identity
+        return self.relu(out), identity
+
+
+class MRLA_Bottleneck(_BottleneckTrunk):
+    """Bottleneck + MRLA-light tail (resnet_mrla_light.py:47-118)."""
+
+    def __init__(self, inplanes, planes, stride=1, downsample=None, SE=False, ECA_size=None, groups=1, base_width=64,
+                 dilation=1, norm_layer=nn.BatchNorm2d, drop_path=0.0):
+        super().__init__(inplanes, planes, stride, downsample, SE, ECA_size, groups, base_width, dilation, norm_layer)
+        self.mrla = layers.mrla_module(input_dim=planes * self.expansion)
+        self.bn_mrla = self._norm(planes * self.expansion)
+        self.drop_path = layers.DropPath(drop_path) if drop_path > 0.0 else nn.Identity()
+
+    def forward(self, x):
+        out, identity = self.trunk(x)
+        return layers.light_block_tail(out, identity, self.mrla, self.bn_mrla, self.drop_path)
+
+
+class _ResNetMRLA(nn.Module):
+    """Shared construction logic of the light and base networks."""
+
+    def _setup(self, num_classes, SE, ECA, groups, width_per_group, replace_stride_with_dilation, norm_layer,
+               drop_rate, drop_path):
+        self._norm_layer = norm_layer or nn.BatchNorm2d
+        self.num_classes, self.drop_rate, self.drop_path = num_classes, drop_rate, drop_path
+        self.inplanes, self.dilation = 64, 1
+        if replace_stride_with_dilation is None:
+            replace_stride_with_dilation = [False, False, False]
+        if len(replace_stride_with_dilation) != 3:
+            raise ValueError("replace_stride_with_dilation should be None "
+                             "or a 3-element tuple, got {}".format(replace_stride_with_dilation))
+        if ECA is None:
+            ECA = [None] * 4
+        elif len(ECA) != 4:
+            raise ValueError("argument ECA should be a 4-element tuple, got {}".format(ECA))
+        self.groups, self.base_width = groups, width_per_group
+        self._SE, self._ECA, self._rswd = SE, ECA, replace_stride_with_dilation
+
+    def _make_layer(self, block, planes, blocks, SE, ECA_size, stride=1, dilate=False, **first_only):
+        norm_layer = self._norm_layer
+        downsample = None
+        previous_dilation = self.dilation
+        if dilate:
+            self.dilation *= stride
+            stride = 1
+        if stride != 1 or self.inplanes != planes * block.expansion:
+            downsample = nn.Sequential(_conv1x1(self.inplanes, planes * block.expansion, stride),
+                                       norm_layer(planes * block.expansion))
+        shared = dict(SE=SE, ECA_size=ECA_size, groups=self.groups, base_width=self.base_width, norm_layer=norm_layer,
+                      drop_path=self.drop_path)
+        rest = {k: (False if k == "init_cell" else v) for k, v in first_only.items()}
+        mods = [block(self.inplanes, planes, stride, downsample, dilation=previous_dilation, **shared, **first_only)]
+        self.inplanes = planes * block.expansion
+        mods += [block(self.inplanes, planes, dilation=self.dilation, **shared, **rest) for _ in range(1, blocks)]
+        return mods
+
+    def _head_and_init(self, block, zero_init_last_bn):
+        self.avgpool = nn.AdaptiveAvgPool2d((1, 1))
+        self.fc = nn.Linear(512 * block.expansion, self.num_classes)
+        for m in self.modules():
+            if isinstance(m, nn.Conv2d):
+                nn.init.kaiming_normal_(m.weight, mode="fan_out", nonlinearity="relu")
+            elif isinstance(m, (nn.BatchNorm2d, nn.GroupNorm)):
+                nn.init.constant_(m.weight, 1)
+                nn.init.constant_(m.bias, 0)
+        if zero_init_last_bn:
+            for m in self.modules():
+                if isinstance(m, _BottleneckTrunk):
+                    nn.init.constant_(m.bn3.weight, 0)
+
+    def forward(self, x):
+        x = self.forward_features(x)
+        x = torch.flatten(self.avgpool(x), 1)
+        if self.drop_rate:
+            x = F.dropout(x, p=float(self.drop_rate), training=self.training)
+        return self.fc(x)
+
+
+class ResNet_mrlal(_ResNetMRLA):
+    """ResNet with an MRLA-light module after every bottleneck (resnet_mrla_light.py:122-238)."""
+
+    def __init__(self, block, layers, num_classes=1000, SE=False, ECA=None, zero_init_last_bn=True, groups=1,
+                 width_per_group=64, replace_stride_with_dilation=None, norm_layer=nn.BatchNorm2d, drop_rate=0.0,
+                 drop_path=0.0):
+        super().__init__()
+        self._setup(num_classes, SE, ECA, groups, width_per_group, replace_stride_with_dilation, norm_layer, drop_rate,
+                    drop_path)
+        self.conv1 = nn.Conv2d(3, self.inplanes, kernel_size=7, stride=2, padding=3, bias=False)
+        self.bn1 = self._norm_layer(self.inplanes)
+        self.relu = nn.ReLU(inplace=True)
+        self.maxpool = nn.MaxPool2d(kernel_size=3, stride=2, padding=1)
+        E, d = self._ECA, self._rswd
+        self.layer1 = nn.Sequential(*self._make_layer(block, 64, layers[0], SE, E[0]))
+        self.layer2 = nn.Sequential(*self._make_layer(block, 128, layers[1], SE, E[1], stride=2, dilate=d[0]))
+        self.layer3 = nn.Sequential(*self._make_layer(block, 256, layers[2], SE, E[2], stride=2, dilate=d[1]))
+        self.layer4 = nn.Sequential(*self._make_layer(block, 512, layers[3], SE, E[3], stride=2, dilate=d[2]))
+        self._head_and_init(block, zero_init_last_bn)
+
+    def forward_features(self, x):
+        x = self.maxpool(self.relu(self.bn1(self.conv1(x))))
+        return self.layer4(self.layer3(self.layer2(self.layer1(x))))
+
+
+def resnet50_mrlal(**kwargs):
+    print("Constructing resnet50_mrla-light......")
+    return ResNet_mrlal(MRLA_Bottleneck, [3, 4, 6, 3], **kwargs)
+
+
+def resnet101_mrlal(**kwargs):
+    print("Constructing resnet101_mrla-light......")
+    return ResNet_mrlal(MRLA_Bottleneck, [3, 4, 23, 3], **kwargs)

@@ -1,0 +1,53 @@
+"""CPU-only checks of the host side: the C-ABI library loads and exports every declared symbol, the module
+surface mirrors the reference's (names, ctor kwargs, state_dict keys), and the product refuses CPU tensors."""
+import os
+import re
+
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_library_exports_every_declared_symbol():
+    from mrla_amd import _lib
+    lib = _lib.load()
+    hdr = open(os.path.join(ROOT, "include", "mrla_hip.h")).read()
+    declared = set(re.findall(r"^int\s+(mrla_\w+)\s*\(", hdr, flags=re.M))
+    assert declared, "no declarations parsed"
+    assert declared == set(_lib.SIGNATURES), declared ^ set(_lib.SIGNATURES)
+    for name in declared:
+        assert hasattr(lib, name), name
+    assert lib.mrla_abi_version() == 1
+
+
+def test_argument_validation_without_a_gpu():
+    from mrla_amd import _lib
+    lib = _lib.load()
+    assert lib.mrla_light_wgrad_rows(0, 64, 8, 8, _lib.F32, _lib.NCHW) == _lib.EINVAL
+    assert lib.mrla_light_wgrad_rows(2, 64, 8, 128, _lib.F32, _lib.NCHW) == _lib.EUNSUPPORTED
+    assert lib.mrla_light_wgrad_rows(256, 256, 56, 56, _lib.BF16, _lib.NCHW) > 0
+    assert lib.mrla_light_stats_fwd(None, None, None, None, 1, 32, 4, 4, _lib.F32, _lib.NCHW, 0, None) == _lib.EINVAL
+    assert lib.mrla_light_gate_fwd(None, None, None, 4, None, 1, 32, 16, 32, None) == _lib.EINVAL
+
+
+def test_model_surface_matches_reference_names():
+    from mrla_amd import models
+    from oracle import eager_models as em
+    names = sorted(n for n in models.__dict__ if n.islower() and not n.startswith("__") and callable(models.__dict__[n]))
+    assert "resnet50_mrlal" in names and "resnet101_mrlal" in names
+    net = models.resnet50_mrlal(drop_rate=0.0, drop_path=0.2)
+    assert set(net.state_dict()) == set(em.eager_resnet50_mrlal().state_dict())
+    assert tuple(net.layer1[0].mrla.lambda_t.shape) == (256, 1, 1)
+    assert tuple(net.layer4[0].mrla.mrla.Wq.weight.shape) == (1, 1, 7)
+    assert net.layer1[0].mrla.mrla.heads == 8 and net.layer1[0].mrla.dim_perhead == 32
+    with pytest.raises(ValueError):
+        from mrla_amd.layers import mrla_light_layer
+        mrla_light_layer(64)
+
+
+def test_product_has_no_cpu_fallback():
+    from mrla_amd import _lib, models
+    net = models.resnet50_mrlal()
+    with pytest.raises(_lib.MrlaHipError):
+        net(torch.zeros(1, 3, 64, 64))

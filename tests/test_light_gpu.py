@@ -102,7 +102,10 @@ def assert_bf16_close(got, want64, what):
     assert not bad.any(), f"{what}: {bad.sum()} of {bad.size} beyond 1 bf16 ulp; worst {np.abs(got - want).max()}"
 
 
-STAGE_SHAPES = [(4, 256, 56, 56, 32), (4, 512, 28, 28, 32), (4, 1024, 14, 14, 32), (3, 2048, 7, 7, 32)]
+# (17, 256, 56, 56): 4352 slabs -> workgroups loop over 2 images each, ragged last group;
+# (3, 2048, 7, 7): 2048 channels do not divide into 72-plane slabs -> ragged last slab.
+STAGE_SHAPES = [(4, 256, 56, 56, 32), (4, 512, 28, 28, 32), (4, 1024, 14, 14, 32), (3, 2048, 7, 7, 32),
+                (17, 256, 56, 56, 32)]
 
 
 @pytest.mark.parametrize("shape", STAGE_SHAPES, ids=lambda s: "x".join(map(str, s[:4])))
@@ -115,7 +118,7 @@ def test_light_tail_resnet50_stage_shapes(shape, dtype):
     o = detgen.normalish((b, c, h, w), s + 2)
     gup = detgen.normalish((b, c, h, w), s + 3)
     P = cases.block_params(c, 7)
-    mask = np.array([1, 0, 1, 1][:b], dtype=np.float32)
+    mask = np.array(([1, 0, 1, 1] * 5)[:b], dtype=np.float32)
     if dtype == torch.bfloat16:
         x, o, gup = bf16_round(x), bf16_round(o), bf16_round(gup)
     got = run_light(x, o, P, d, "train", mask, 0.2, gup, dtype)

@@ -1,0 +1,73 @@
+"""GPU parity of the full models: product (HIP MRLA tails) vs the eager restatement on the same GPU with the
+same deterministic weights, and vs logits the reference itself produced on CPU (tests/golden/models.npz)."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import detgen, eager_models as em
+from tests import cases
+
+pytestmark = pytest.mark.gpu
+
+
+def load_det(net):
+    vals = detgen.fill_state_dict(net.state_dict())
+    net.load_state_dict({k: torch.from_numpy(v) for k, v in vals.items()})
+
+
+def rel(got, want):
+    want = np.asarray(want, np.float64)
+    return np.abs(np.asarray(got, np.float64) - want).max() / max(np.abs(want).max(), 1e-9)
+
+
+def test_resnet50_mrlal_eval_logits_match_reference_and_eager():
+    from mrla_amd import models
+    torch.backends.cudnn.allow_tf32 = False
+    G = cases.golden("models")
+    net = models.resnet50_mrlal().cuda()
+    ref = em.eager_resnet50_mrlal().cuda()
+    load_det(net)
+    ref.load_state_dict(net.state_dict())           # same keys -> strict load
+    net.eval(); ref.eval()
+    x = torch.from_numpy(cases.image_batch(8)).cuda()
+    with torch.no_grad():
+        y, yr = net(x), ref(x)
+    # MIOpen fp32 convolutions differ from the CPU's by ~1e-5; the product and eager share them exactly
+    assert rel(y.cpu().numpy(), yr.cpu().numpy()) < 2e-5
+    assert rel(y.cpu().numpy(), G["resnet50_mrlal/eval8/logits"]) < 2e-4
+
+
+def test_resnet50_mrlal_train_step_matches_eager():
+    from mrla_amd import models
+    G = cases.golden("models")
+    net = models.resnet50_mrlal().cuda()
+    ref = em.eager_resnet50_mrlal().cuda()
+    load_det(net)
+    ref.load_state_dict(net.state_dict())
+    net.train(); ref.train()
+    x = torch.from_numpy(cases.image_batch(4, "img-train")).cuda()
+    tgt = (torch.arange(4) * 37 % 1000).cuda()
+    y, yr = net(x), ref(x)
+    assert rel(y.detach().cpu().numpy(), yr.detach().cpu().numpy()) < 1e-4
+    assert rel(y.detach().cpu().numpy(), G["resnet50_mrlal/train4/logits"]) < 1e-3
+    torch.nn.functional.cross_entropy(y, tgt).backward()
+    torch.nn.functional.cross_entropy(yr, tgt).backward()
+    gp, gr = dict(net.named_parameters()), dict(ref.named_parameters())
+    worst = 0.0
+    for k in gp:
+        a, b = gp[k].grad.cpu().numpy().ravel().astype(np.float64), gr[k].grad.cpu().numpy().ravel().astype(np.float64)
+        if np.abs(b).sum() < 1e-4:
+            continue                       # mathematically-zero gradients: noise
+        worst = max(worst, np.abs(a - b).sum() / np.abs(b).sum())
+    assert worst < 2e-2, worst            # fp32 noise through 16 train-mode BNs at batch 4
+    sp, sr = net.state_dict(), ref.state_dict()
+    for k in ("layer1.0.bn_mrla.running_mean", "layer4.2.bn_mrla.running_var", "layer2.1.bn_mrla.num_batches_tracked"):
+        assert rel(sp[k].float().cpu().numpy(), sr[k].float().cpu().numpy()) < 1e-4, k
+
+
+def test_state_dict_roundtrip_and_api_surface():
+    from mrla_amd import models
+    net = models.resnet50_mrlal(drop_rate=0.1, drop_path=0.2, num_classes=10)
+    sd = em.eager_resnet50_mrlal(num_classes=10).state_dict()
+    assert set(net.state_dict().keys()) == set(sd.keys())
+    assert sum(p.numel() for p in models.resnet50_mrlal().parameters()) == 25_738_452

@@ -110,6 +110,64 @@ int mrla_light_apply_bwd(const void* dout, const void* x, const void* o_prev, co
                          void* do_prev, float* dwv_part, int b, int c, int h, int w, int d, int res, int dtype,
                          int layout, int act, void* stream);
 
+/* =====================================================================================================
+ * MRLA-base: softmax over the depth of a stage (resnet/models/modules/mrla_base_module.py:54-89 and the
+ * block tail resnet/models/resnet_mrla_base.py:120-129).  The K/V history of a stage lives in caller-owned
+ * ring buffers that replace the reference's torch.cat growth (mrla_base_module.py:69-70) and the einops
+ * rearrange copies (:76-77,83):
+ *   v_ring  [b, T, c, h, w] activation dtype    k_ring [b, T, c] float32      p_all [b, c/d, T, T] float32
+ *   da_ring [b, T, c, h, w] activation dtype    dk_ring [b, T, c] float32
+ * `t` (1-based) is the history length at this layer = the slot (t-1) it appends; T is the ring capacity.
+ * The pooled descriptor comes from mrla_light_stats_fwd(x, o_prev = NULL) (slot 0 of `mom`).
+ * ===================================================================================================== */
+
+/* q_t, k_t (-> k_ring slot t-1), p_all row t-1 = softmax_j(<q_t, k_j>/sqrt(d)), j < t.
+ * Replaces mrla_base_module.py:61-62 (Wq, Wk), :69 (cat K), :76,:79,:82 (rearrange, einsum, softmax). */
+int mrla_base_gate_fwd(const float* mom, const float* wq, const float* wk, int ksize, float* k_ring, float* p_all,
+                       float* q /*[b,c]*/, int b, int c, int hw, int d, int T, int t, void* stream);
+
+/* v_t = dwconv3x3(x) -> v_ring slot t-1;  attn = sum_{j<t} p[b,g,j] * v_j;  amom[b,c,2] = (sum attn, sum attn^2).
+ * Replaces mrla_base_module.py:63 (Wv), :70 (cat V), :77,:83 (rearrange copies), :86-87 (einsum, reshape). */
+int mrla_base_attend_fwd(const void* x, const float* wv, void* v_ring, const float* p_all, void* attn, float* amom,
+                         int b, int c, int h, int w, int d, int T, int t, int dtype, int layout, void* stream);
+
+/* BatchNorm statistics from per-(image, channel) (sum, sum of squares): sc, sh, save_mean, save_inv; running
+ * statistics updated in place in TRAIN mode.  Replaces the statistics half of bn_mrla (resnet_mrla_base.py:125). */
+int mrla_bn_stats_fwd(const float* amom, const float* gamma, const float* beta, float* running_mean,
+                      float* running_var, int bn_mode, float momentum, float eps, float* sc, float* sh,
+                      float* save_mean, float* save_inv, int b, int c, int hw, void* stream);
+
+/* out = x + dp[b] * relu(sc[c]*attn + sh[c]).  Replaces the normalisation half of bn_mrla, the ReLU, DropPath and
+ * the residual add of resnet_mrla_base.py:125-127.  dp [opt]. */
+int mrla_base_tail_fwd(const void* x, const void* attn, const float* sc, const float* sh, const float* dp, void* out,
+                       int b, int c, int h, int w, int dtype, int layout, void* stream);
+
+/* tmom[b,c,2] = (sum dz, sum dz*attn), dz = dp[b]*dOut*[sc*attn + sh > 0]. */
+int mrla_base_tail_stats_bwd(const void* dout, const void* attn, const float* sc, const float* sh, const float* dp,
+                             float* tmom, int b, int c, int h, int w, int dtype, int layout, void* stream);
+
+/* cb[c,3] = (e, f, h) with d attn = e*dz + f*attn + h; dgamma, dbeta. */
+int mrla_bn_stats_bwd(const float* tmom, const float* gamma, const float* save_mean, const float* save_inv,
+                      int bn_mode, float* cb, float* dgamma, float* dbeta, int b, int c, int hw, void* stream);
+
+/* dA_t -> da_ring slot t-1; pmom[b,c,t] = sum_hw dA_t * v_j (j < t).  sc == NULL: no tail, dA_t = dOut
+ * (attn, sh, dp, cb then unused) -- the backward of a bare mrla_base_layer. */
+int mrla_base_attend_bwd(const void* dout, const void* attn, const float* sc, const float* sh, const float* dp,
+                         const float* cb, const void* v_ring, void* da_ring, float* pmom, int b, int c, int h, int w,
+                         int T, int t, int dtype, int layout, void* stream);
+
+/* softmax backward; dq_t; dk_ring[:, j] += dlogit_j * q_t (j < t; first_touch != 0: overwrite instead of add, for the
+ * first backward call of a stage); dyx[b,c] = (gradient wrt pooled y)/hw; dwqk_part[b, 2*ksize]. */
+int mrla_base_gate_bwd(const float* mom, const float* pmom, const float* p_all, const float* q, const float* k_ring,
+                       float* dk_ring, const float* wq, const float* wk, int ksize, float* dyx, float* dwqk_part,
+                       int b, int c, int hw, int d, int T, int t, int first_touch, void* stream);
+
+/* dV_t = sum_{t'=t..Tc} p_all[b,g,t'-1,t-1] * dA_t';  dx = res*dOut + dwconv3x3^T(dV_t) + dyx;  dwv_part[rows, c, 9]
+ * (rows = mrla_light_wgrad_rows()).  Tc = number of layers of the stage that ran forward. */
+int mrla_base_value_bwd(const void* dout, const void* x, const float* wv, const void* da_ring, const float* p_all,
+                        const float* dyx, void* dx, float* dwv_part, int b, int c, int h, int w, int d, int T, int t,
+                        int Tc, int res, int dtype, int layout, void* stream);
+
 /* out[n] = sum over rows of in[rows, n] (fixed order, double accumulation). */
 int mrla_reduce_rows(const float* in, float* out, int rows, int n, void* stream);
 

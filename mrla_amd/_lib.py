@@ -34,6 +34,15 @@ SIGNATURES = {
     "mrla_light_bn_bwd": [_P, _P, _P, _P, _P, _P, _P, _P, _I, _P, _P, _P, _P, _I, _I, _I, _I, _P],
     "mrla_light_gate_bwd": [_P, _P, _P, _P, _P, _P, _P, _I, _P, _P, _I, _I, _I, _I, _P],
     "mrla_light_apply_bwd": [_P] * 12 + [_I] * 9 + [_P],
+    "mrla_base_gate_fwd": [_P, _P, _P, _I, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P],
+    "mrla_base_attend_fwd": [_P, _P, _P, _P, _P, _P] + [_I] * 9 + [_P],
+    "mrla_bn_stats_fwd": [_P, _P, _P, _P, _P, _I, _F, _F, _P, _P, _P, _P, _I, _I, _I, _P],
+    "mrla_base_tail_fwd": [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P],
+    "mrla_base_tail_stats_bwd": [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P],
+    "mrla_bn_stats_bwd": [_P, _P, _P, _P, _I, _P, _P, _P, _I, _I, _I, _P],
+    "mrla_base_attend_bwd": [_P] * 9 + [_I] * 8 + [_P],
+    "mrla_base_gate_bwd": [_P, _P, _P, _P, _P, _P, _P, _P, _I, _P, _P] + [_I] * 7 + [_P],
+    "mrla_base_value_bwd": [_P] * 8 + [_I] * 11 + [_P],
     "mrla_reduce_rows": [_P, _P, _I, _I, _P],
 }
 

@@ -157,6 +157,102 @@ int mrla_light_apply_bwd(const void* dout, const void* x, const void* o_prev, co
                                      dtype, act, (hipStream_t)stream);
 }
 
+static bool bad_ring(int T, int t) { return T <= 0 || t <= 0 || t > T; }
+
+int mrla_base_gate_fwd(const float* mom, const float* wq, const float* wk, int ksize, float* k_ring, float* p_all,
+                       float* q, int b, int c, int hw, int d, int T, int t, void* stream) {
+  if (!mom || !wq || !wk || !k_ring || !p_all || !q || b <= 0 || c <= 0 || hw <= 0 || d <= 0 || c % d || ksize <= 0 ||
+      !(ksize & 1) || bad_ring(T, t))
+    return MRLA_EINVAL;
+  return launch_base_gate_fwd(mom, wq, wk, ksize, k_ring, p_all, q, b, c, hw, d, T, t, (hipStream_t)stream);
+}
+
+int mrla_base_attend_fwd(const void* x, const float* wv, void* v_ring, const float* p_all, void* attn, float* amom,
+                         int b, int c, int h, int w, int d, int T, int t, int dtype, int layout, void* stream) {
+  if (!x || !wv || !v_ring || !p_all || !attn || !amom || bad_dims(b, c, h, w) || bad_dtype(dtype) || d <= 0 || c % d ||
+      bad_ring(T, t))
+    return MRLA_EINVAL;
+  if (layout != MRLA_NCHW) return MRLA_EUNSUPPORTED;
+  SlabGeo g;
+  const int rc = light_geo(&g, b, c, h, w, dtype);
+  if (rc != MRLA_OK) return rc;
+  return launch_base_attend_fwd(x, wv, v_ring, p_all, attn, amom, g, d, T, t, dtype, (hipStream_t)stream);
+}
+
+int mrla_bn_stats_fwd(const float* amom, const float* gamma, const float* beta, float* running_mean,
+                      float* running_var, int bn_mode, float momentum, float eps, float* sc, float* sh,
+                      float* save_mean, float* save_inv, int b, int c, int hw, void* stream) {
+  if (!amom || !gamma || !beta || !running_mean || !running_var || !sc || !sh || !save_mean || !save_inv || b <= 0 ||
+      c <= 0 || hw <= 0 || (bn_mode != MRLA_BN_TRAIN && bn_mode != MRLA_BN_EVAL))
+    return MRLA_EINVAL;
+  return launch_plain_bn_fwd(amom, gamma, beta, running_mean, running_var, bn_mode == MRLA_BN_TRAIN, momentum, eps, sc,
+                             sh, save_mean, save_inv, b, c, hw, (hipStream_t)stream);
+}
+
+int mrla_base_tail_fwd(const void* x, const void* attn, const float* sc, const float* sh, const float* dp, void* out,
+                       int b, int c, int h, int w, int dtype, int layout, void* stream) {
+  if (!x || !attn || !sc || !sh || !out || bad_dims(b, c, h, w) || bad_dtype(dtype)) return MRLA_EINVAL;
+  if (layout != MRLA_NCHW) return MRLA_EUNSUPPORTED;
+  return launch_base_tail_fwd(x, attn, sc, sh, dp, out, b, c, h * w, dtype, (hipStream_t)stream);
+}
+
+int mrla_base_tail_stats_bwd(const void* dout, const void* attn, const float* sc, const float* sh, const float* dp,
+                             float* tmom, int b, int c, int h, int w, int dtype, int layout, void* stream) {
+  if (!dout || !attn || !sc || !sh || !tmom || bad_dims(b, c, h, w) || bad_dtype(dtype)) return MRLA_EINVAL;
+  if (layout != MRLA_NCHW) return MRLA_EUNSUPPORTED;
+  SlabGeo g;
+  const int rc = light_geo(&g, b, c, h, w, dtype);
+  if (rc != MRLA_OK) return rc;
+  return launch_base_tail_stats_bwd(dout, attn, sc, sh, dp, tmom, g, dtype, (hipStream_t)stream);
+}
+
+int mrla_bn_stats_bwd(const float* tmom, const float* gamma, const float* save_mean, const float* save_inv,
+                      int bn_mode, float* cb, float* dgamma, float* dbeta, int b, int c, int hw, void* stream) {
+  if (!tmom || !gamma || !save_mean || !save_inv || !cb || !dgamma || !dbeta || b <= 0 || c <= 0 || hw <= 0 ||
+      (bn_mode != MRLA_BN_TRAIN && bn_mode != MRLA_BN_EVAL))
+    return MRLA_EINVAL;
+  return launch_plain_bn_bwd(tmom, gamma, save_mean, save_inv, bn_mode == MRLA_BN_TRAIN, cb, dgamma, dbeta, b, c, hw,
+                             (hipStream_t)stream);
+}
+
+int mrla_base_attend_bwd(const void* dout, const void* attn, const float* sc, const float* sh, const float* dp,
+                         const float* cb, const void* v_ring, void* da_ring, float* pmom, int b, int c, int h, int w,
+                         int T, int t, int dtype, int layout, void* stream) {
+  if (!dout || !v_ring || !da_ring || !pmom || bad_dims(b, c, h, w) || bad_dtype(dtype) || bad_ring(T, t))
+    return MRLA_EINVAL;
+  if (sc && (!attn || !sh || !cb)) return MRLA_EINVAL;
+  if (layout != MRLA_NCHW) return MRLA_EUNSUPPORTED;
+  SlabGeo g;
+  const int rc = light_geo(&g, b, c, h, w, dtype);
+  if (rc != MRLA_OK) return rc;
+  return launch_base_attend_bwd(dout, sc ? attn : nullptr, sc, sh, dp, cb, v_ring, da_ring, pmom, g, T, t, dtype,
+                                (hipStream_t)stream);
+}
+
+int mrla_base_gate_bwd(const float* mom, const float* pmom, const float* p_all, const float* q, const float* k_ring,
+                       float* dk_ring, const float* wq, const float* wk, int ksize, float* dyx, float* dwqk_part,
+                       int b, int c, int hw, int d, int T, int t, int first_touch, void* stream) {
+  if (!mom || !pmom || !p_all || !q || !k_ring || !dk_ring || !wq || !wk || !dyx || !dwqk_part || b <= 0 || c <= 0 ||
+      hw <= 0 || d <= 0 || c % d || ksize <= 0 || !(ksize & 1) || bad_ring(T, t))
+    return MRLA_EINVAL;
+  return launch_base_gate_bwd(mom, pmom, p_all, q, k_ring, dk_ring, wq, wk, ksize, dyx, dwqk_part, b, c, hw, d, T, t,
+                              first_touch, (hipStream_t)stream);
+}
+
+int mrla_base_value_bwd(const void* dout, const void* x, const float* wv, const void* da_ring, const float* p_all,
+                        const float* dyx, void* dx, float* dwv_part, int b, int c, int h, int w, int d, int T, int t,
+                        int Tc, int res, int dtype, int layout, void* stream) {
+  if (!dout || !x || !wv || !da_ring || !p_all || !dyx || !dx || !dwv_part || bad_dims(b, c, h, w) ||
+      bad_dtype(dtype) || d <= 0 || c % d || bad_ring(T, t) || Tc < t || Tc > T)
+    return MRLA_EINVAL;
+  if (layout != MRLA_NCHW) return MRLA_EUNSUPPORTED;
+  SlabGeo g;
+  const int rc = light_geo(&g, b, c, h, w, dtype);
+  if (rc != MRLA_OK) return rc;
+  return launch_base_value_bwd(dout, x, wv, da_ring, p_all, dyx, dx, dwv_part, g, d, T, t, Tc, res, dtype,
+                               (hipStream_t)stream);
+}
+
 int mrla_reduce_rows(const float* in, float* out, int rows, int n, void* stream) {
   if (!in || !out || rows <= 0 || n <= 0) return MRLA_EINVAL;
   return launch_reduce_rows(in, out, rows, n, (hipStream_t)stream);

@@ -56,4 +56,29 @@ int launch_gate_bwd(const float* mom, const float* bmom, const float* gate, cons
                     int d, hipStream_t st);
 int launch_reduce_rows(const float* in, float* out, int rows, int n, hipStream_t st);
 
+
+// base_nchw.hip -- MRLA-base (softmax over depth) kernels
+int launch_base_gate_fwd(const float* mom, const float* wq, const float* wk, int ks, float* Kring, float* Pall,
+                         float* q, int B, int C, int HW, int d, int T, int t, hipStream_t st);
+int launch_base_attend_fwd(const void* x, const float* wv, void* Vring, const float* Pall, void* attn, float* amom,
+                           const SlabGeo& g, int d, int T, int t, int dtype, hipStream_t st);
+int launch_plain_bn_fwd(const float* amom, const float* gamma, const float* beta, float* run_mean, float* run_var,
+                        int training, float momentum, float eps, float* sc, float* sh, float* save_mean,
+                        float* save_inv, int B, int C, int HW, hipStream_t st);
+int launch_plain_bn_bwd(const float* tmom, const float* gamma, const float* save_mean, const float* save_inv,
+                        int training, float* cb, float* dgamma, float* dbeta, int B, int C, int HW, hipStream_t st);
+int launch_base_tail_fwd(const void* x, const void* attn, const float* sc, const float* sh, const float* dp, void* out,
+                         int B, int C, int HW, int dtype, hipStream_t st);
+int launch_base_tail_stats_bwd(const void* dout, const void* attn, const float* sc, const float* sh, const float* dp,
+                               float* tmom, const SlabGeo& g, int dtype, hipStream_t st);
+int launch_base_attend_bwd(const void* dout, const void* attn, const float* sc, const float* sh, const float* dp,
+                           const float* cb, const void* Vring, void* dAring, float* pmom, const SlabGeo& g, int T,
+                           int t, int dtype, hipStream_t st);
+int launch_base_gate_bwd(const float* mom, const float* pmom, const float* Pall, const float* q, const float* Kring,
+                         float* dKring, const float* wq, const float* wk, int ks, float* dyx, float* dwqk_part, int B,
+                         int C, int HW, int d, int T, int t, int first_touch, hipStream_t st);
+int launch_base_value_bwd(const void* dout, const void* x, const float* wv, const void* dAring, const float* Pall,
+                          const float* dyx, void* dx, float* dwv_part, const SlabGeo& g, int d, int T, int t, int Tc,
+                          int res, int dtype, hipStream_t st);
+
 }  // namespace mrla

@@ -211,3 +211,166 @@ def mrla_light(x, wq, wk, wv, d, o_prev=None, lam=None, bn=None, dp=None, res=Fa
                       int(res), L.ACT_GELU if act_gelu else L.ACT_NONE)
     return _LightFn.apply(x, o_prev, wq, wk, wv, lam, bn["weight"], bn["bias"], bn["running_mean"], bn["running_var"],
                           dp, cfg)
+
+
+# ======================================================================================================
+# MRLA-base
+# ======================================================================================================
+class BaseStage:
+    """Stage-resident K/V history of MRLA-base on the device (replaces the reference's torch.cat growth).
+
+    One instance lives for one forward(+backward) pass of one network stage: the `init_cell` layer creates
+    it, every later layer of the stage appends one slot.  Gradients with respect to the history do not
+    travel along autograd edges; they are accumulated in the dA / dK rings, which is valid because layer
+    t+1's backward always runs before layer t's (x_{t+1} depends on out_t through the block chain).
+    """
+
+    def __init__(self, b, c, h, w, d, dtype, device, capacity):
+        self.b, self.c, self.h, self.w, self.d = b, c, h, w, d
+        self.dtype, self.device = dtype, device
+        self.T = max(1, int(capacity))
+        self.t = 0
+        self.bwd_started = False
+        self.V = torch.empty((b, self.T, c, h, w), dtype=dtype, device=device)
+        self.K = torch.empty((b, self.T, c), dtype=torch.float32, device=device)
+        self.P = torch.empty((b, c // d, self.T, self.T), dtype=torch.float32, device=device)
+        self.dA = self.dK = None
+
+    def reserve_slot(self):
+        """Make room for one more layer (amortised doubling when the capacity hint was too small)."""
+        if self.t < self.T:
+            return
+        if self.bwd_started:
+            raise L.MrlaHipError("MRLA-base history grown after its backward pass started")
+        T2, t = 2 * self.T, self.t
+        V = torch.empty((self.b, T2, self.c, self.h, self.w), dtype=self.dtype, device=self.device)
+        K = torch.empty((self.b, T2, self.c), dtype=torch.float32, device=self.device)
+        P = torch.empty((self.b, self.c // self.d, T2, T2), dtype=torch.float32, device=self.device)
+        V[:, :t].copy_(self.V[:, :t])
+        K[:, :t].copy_(self.K[:, :t])
+        P[:, :, :t, :t].copy_(self.P[:, :, :t, :t])
+        self.V, self.K, self.P, self.T = V, K, P, T2
+
+    def backward_buffers(self):
+        if self.dA is None:
+            self.dA = torch.empty_like(self.V)
+            self.dK = torch.empty_like(self.K)
+        first = not self.bwd_started
+        self.bwd_started = True
+        return first
+
+    def views(self):
+        K, V = self.K[:, :self.t], self.V[:, :self.t]
+        K._mrla_stage = V._mrla_stage = self
+        return K, V
+
+
+class BaseConfig:
+    __slots__ = ("d", "bn_mode", "momentum", "eps", "tail")
+
+    def __init__(self, d, bn_mode=L.BN_NONE, momentum=0.1, eps=1e-5, tail=False):
+        self.d, self.bn_mode, self.momentum, self.eps, self.tail = d, bn_mode, momentum, eps, tail
+
+
+class _BaseFn(torch.autograd.Function):
+    """tail:  out = x + dp[b]*relu(BN(attn)),  attn = sum_{j<=t} softmax_j(<q_t,k_j>/sqrt(d)) * v_j
+    no tail: out = attn  (bare mrla_base_layer)."""
+
+    @staticmethod
+    def forward(ctx, x, wq, wk, wv, gamma, beta, running_mean, running_var, dp, stage, cfg):
+        _require_cuda(x, "mrla base forward")
+        layout, xc = _layout_of(x)
+        b, c, h, w = xc.shape
+        d = cfg.d
+        if (b, c, h, w, d) != (stage.b, stage.c, stage.h, stage.w, stage.d) or xc.dtype != stage.dtype:
+            raise L.MrlaHipError("input does not match the stage's K/V history (shape/dtype); is init_cell set on the "
+                                 "first block of the stage?")
+        dt, dev, st = _DT[xc.dtype], xc.device, _stream()
+        wq32, wk32 = _f32(wq).reshape(-1), _f32(wk).reshape(-1)
+        wv32 = _f32(wv).reshape(c, 9)
+        dp32 = _f32(dp).reshape(-1) if dp is not None else None
+        ks = wq32.numel()
+        stage.reserve_slot()
+        t, T = stage.t + 1, stage.T
+
+        mom = torch.empty((b, c, L.FWD_MOMENTS), dtype=torch.float32, device=dev)
+        _call("mrla_light_stats_fwd", xc.numel() * xc.element_size(), _ptr(xc), None, _ptr(wv32), _ptr(mom), b, c, h, w,
+              dt, layout, L.ACT_NONE, st)
+        q = torch.empty((b, c), dtype=torch.float32, device=dev)
+        L.call("mrla_base_gate_fwd", _ptr(mom), _ptr(wq32), _ptr(wk32), ks, _ptr(stage.K), _ptr(stage.P), _ptr(q), b, c,
+               h * w, d, T, t, st)
+        attn = torch.empty_like(xc)
+        amom = torch.empty((b, c, 2), dtype=torch.float32, device=dev)
+        _call("mrla_base_attend_fwd", xc.numel() * xc.element_size() * (t + 2), _ptr(xc), _ptr(wv32), _ptr(stage.V),
+              _ptr(stage.P), _ptr(attn), _ptr(amom), b, c, h, w, d, T, t, dt, layout, st)
+        stage.t = t
+        bnbuf = gamma32 = None
+        out = attn
+        if cfg.tail:
+            gamma32, beta32 = _f32(gamma), _f32(beta)
+            bnbuf = torch.empty((4, c), dtype=torch.float32, device=dev)
+            L.call("mrla_bn_stats_fwd", _ptr(amom), _ptr(gamma32), _ptr(beta32), _ptr(running_mean), _ptr(running_var),
+                   cfg.bn_mode, float(cfg.momentum), float(cfg.eps), _ptr(bnbuf[0]), _ptr(bnbuf[1]), _ptr(bnbuf[2]),
+                   _ptr(bnbuf[3]), b, c, h * w, st)
+            out = torch.empty_like(xc)
+            _call("mrla_base_tail_fwd", xc.numel() * xc.element_size() * 3, _ptr(xc), _ptr(attn), _ptr(bnbuf[0]),
+                  _ptr(bnbuf[1]), _ptr(dp32), _ptr(out), b, c, h, w, dt, layout, st)
+        ctx.cfg, ctx.layout, ctx.ks, ctx.stage, ctx.t = cfg, layout, ks, stage, t
+        ctx.shapes = (wq.shape, wk.shape, wv.shape)
+        ctx.pdtypes = (wq.dtype, wk.dtype, wv.dtype, gamma.dtype if gamma is not None else None)
+        ctx.save_for_backward(xc, attn if cfg.tail else None, wq32, wk32, wv32, gamma32, dp32, mom, q, bnbuf)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        xc, attn, wq32, wk32, wv32, gamma32, dp32, mom, q, bnbuf = ctx.saved_tensors
+        cfg, layout, ks, stage, t = ctx.cfg, ctx.layout, ctx.ks, ctx.stage, ctx.t
+        b, c, h, w = xc.shape
+        d, T, Tc = cfg.d, stage.T, stage.t
+        dt, dev, st = _DT[xc.dtype], xc.device, _stream()
+        if dout.dtype != xc.dtype:
+            dout = dout.to(xc.dtype)
+        dout = dout.contiguous()
+        first = stage.backward_buffers()
+        es = xc.element_size()
+
+        cb = dgamma = dbeta = None
+        if cfg.tail:
+            tmom = torch.empty((b, c, 2), dtype=torch.float32, device=dev)
+            _call("mrla_base_tail_stats_bwd", xc.numel() * es * 2, _ptr(dout), _ptr(attn), _ptr(bnbuf[0]), _ptr(bnbuf[1]),
+                  _ptr(dp32), _ptr(tmom), b, c, h, w, dt, layout, st)
+            small = torch.empty((5, c), dtype=torch.float32, device=dev)         # cb[c,3] | dgamma | dbeta
+            cb = small[:3].view(c, 3)
+            L.call("mrla_bn_stats_bwd", _ptr(tmom), _ptr(gamma32), _ptr(bnbuf[2]), _ptr(bnbuf[3]), cfg.bn_mode, _ptr(cb),
+                   _ptr(small[3]), _ptr(small[4]), b, c, h * w, st)
+            dgamma, dbeta = small[3].to(ctx.pdtypes[3]), small[4].to(ctx.pdtypes[3])
+        pmom = torch.empty((b, c, t), dtype=torch.float32, device=dev)
+        _call("mrla_base_attend_bwd", xc.numel() * es * (t + 3), _ptr(dout), _ptr(attn),
+              _ptr(bnbuf[0]) if cfg.tail else None, _ptr(bnbuf[1]) if cfg.tail else None, _ptr(dp32), _ptr(cb),
+              _ptr(stage.V), _ptr(stage.dA), _ptr(pmom), b, c, h, w, T, t, dt, layout, st)
+        dyx = torch.empty((b, c), dtype=torch.float32, device=dev)
+        dwqk_part = torch.empty((b, 2 * ks), dtype=torch.float32, device=dev)
+        L.call("mrla_base_gate_bwd", _ptr(mom), _ptr(pmom), _ptr(stage.P), _ptr(q), _ptr(stage.K), _ptr(stage.dK),
+               _ptr(wq32), _ptr(wk32), ks, _ptr(dyx), _ptr(dwqk_part), b, c, h * w, d, T, t, int(first), st)
+        rows = L.load().mrla_light_wgrad_rows(b, c, h, w, dt, layout)
+        L.check(min(rows, 0), "mrla_light_wgrad_rows")
+        dwv_part = torch.empty((rows, c * 9), dtype=torch.float32, device=dev)
+        dx = torch.empty_like(xc)
+        _call("mrla_base_value_bwd", xc.numel() * es * (Tc - t + 4), _ptr(dout), _ptr(xc), _ptr(wv32), _ptr(stage.dA),
+              _ptr(stage.P), _ptr(dyx), _ptr(dx), _ptr(dwv_part), b, c, h, w, d, T, t, Tc, int(cfg.tail), dt, layout, st)
+        wsum = torch.empty((c * 9 + 2 * ks,), dtype=torch.float32, device=dev)
+        L.call("mrla_reduce_rows", _ptr(dwv_part), _ptr(wsum), rows, c * 9, st)
+        L.call("mrla_reduce_rows", _ptr(dwqk_part), _ptr(wsum[c * 9:]), b, 2 * ks, st)
+        sq, sk, sv = ctx.shapes
+        tq, tk, tv, _ = ctx.pdtypes
+        return (dx, wsum[c * 9:c * 9 + ks].view(sq).to(tq), wsum[c * 9 + ks:].view(sk).to(tk),
+                wsum[:c * 9].view(sv).to(tv), dgamma, dbeta, None, None, None, None, None)
+
+
+def mrla_base(x, wq, wk, wv, d, stage, bn=None, dp=None):
+    """One MRLA-base layer on `stage` (a BaseStage).  bn: None (bare layer, returns attn) or the dict of
+    mrla_light(); with bn the block tail x + dp*relu(BN(attn)) is fused in."""
+    if bn is None:
+        return _BaseFn.apply(x, wq, wk, wv, None, None, None, None, None, stage, BaseConfig(d))
+    cfg = BaseConfig(d, L.BN_TRAIN if bn["training"] else L.BN_EVAL, bn.get("momentum", 0.1), bn.get("eps", 1e-5), True)
+    return _BaseFn.apply(x, wq, wk, wv, bn["weight"], bn["bias"], bn["running_mean"], bn["running_var"], dp, stage, cfg)

@@ -125,3 +125,69 @@ def light_block_tail(x, identity, mrla, bn_mrla, drop_path):
                              lam=mrla.lambda_t, bn=_bn_args(bn_mrla), dp=dp, res=True)
     # any other norm layer the caller injected: MRLA op on the GPU, then the caller's modules as they are
     return x + drop_path(bn_mrla(mrla(x, identity)))
+
+
+# ======================================================================================================
+# MRLA-base (reference: resnet/models/modules/mrla_base_module.py:10-89, resnet_mrla_base.py:32-51,120-129)
+# ======================================================================================================
+def _stage_for(layer, x, prev_K, prev_V):
+    """The BaseStage this call appends to: a new one for an init_cell layer, else the one the incoming
+    K/V views belong to."""
+    if layer.init_cell:
+        b, c, h, w = x.shape
+        return F_.BaseStage(b, c, h, w, layer.dim_perhead, x.dtype, x.device, layer.history_hint or 4)
+    stage = getattr(prev_V, "_mrla_stage", None)
+    if stage is None or getattr(prev_K, "_mrla_stage", None) is not stage:
+        raise MrlaHipError("prev_K / prev_V must be the tensors returned by the previous MRLA-base layer of the same "
+                           "stage (the K/V history lives in a device ring, not in free-standing tensors)")
+    return stage
+
+
+class mrla_base_layer(_QKVParams):
+    """MRLA-base layer: softmax over the stage's depth.  forward(x, prev_K, prev_V) -> (out, K[b,t,c], V[b,t,c,h,w]);
+    K and V are views of the stage's ring buffers."""
+
+    def __init__(self, input_dim, heads=None, dim_perhead=None, k_size=None, init_cell=False):
+        super().__init__(input_dim, heads, dim_perhead, k_size)
+        self.init_cell = init_cell
+        self.history_hint = None      # stage depth, set by the network constructor (rings grow if it is too small)
+
+    def forward(self, x, prev_K, prev_V):
+        self._check(x)
+        stage = _stage_for(self, x, prev_K, prev_V)
+        out = F_.mrla_base(x, self.Wq.weight, self.Wk.weight, self.Wv.weight, self.dim_perhead, stage)
+        K, V = stage.views()
+        return out, K, V
+
+
+class mrla_base_module(nn.Module):
+    """resnet_mrla_base.py:32-51 (`mrla_module` there)."""
+    dim_perhead = 16
+
+    def __init__(self, input_dim, init_cell=False, channel_wise=False):
+        super().__init__()
+        if channel_wise:
+            self.dim_perhead = 1
+        self.mrla = mrla_base_layer(input_dim=input_dim, dim_perhead=self.dim_perhead, init_cell=init_cell)
+        self.init_cell = init_cell
+
+    def forward(self, xt, prev_k, prev_v):
+        if self.init_cell:
+            prev_k = prev_v = None
+        return self.mrla(xt, prev_k, prev_v)
+
+
+def base_block_tail(x, prev_k, prev_v, mrla, bn_mrla, drop_path):
+    """x + DropPath(relu(bn_mrla(attn))) with attn, K, V from the MRLA-base layer (resnet_mrla_base.py:124-127)."""
+    layer = mrla.mrla
+    if type(bn_mrla) is nn.BatchNorm2d and bn_mrla.affine:
+        layer._check(x)
+        stage = _stage_for(layer, x, prev_k, prev_v)
+        p = getattr(drop_path, "drop_prob", 0.0) or 0.0
+        dp = drop_path_scale(x.shape[0], p, drop_path.training if isinstance(drop_path, nn.Module) else False, x.device)
+        out = F_.mrla_base(x, layer.Wq.weight, layer.Wk.weight, layer.Wv.weight, layer.dim_perhead, stage,
+                           bn=_bn_args(bn_mrla), dp=dp)
+        K, V = stage.views()
+        return out, K, V
+    attn, K, V = mrla(x, prev_k, prev_v)
+    return x + drop_path(torch.relu(bn_mrla(attn))), K, V

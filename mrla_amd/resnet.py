@@ -70,6 +70,22 @@ class MRLA_Bottleneck(_BottleneckTrunk):
         return layers.light_block_tail(out, identity, self.mrla, self.bn_mrla, self.drop_path)
 
 
+class MRLA_Bottleneck_base(_BottleneckTrunk):
+    """Bottleneck + MRLA-base tail (resnet_mrla_base.py:55-131; `MRLA_Bottleneck` there)."""
+
+    def __init__(self, inplanes, planes, stride=1, downsample=None, SE=False, ECA_size=None, groups=1, base_width=64,
+                 dilation=1, norm_layer=nn.BatchNorm2d, drop_path=0.0, init_cell=False, channel_wise_mrla=False):
+        super().__init__(inplanes, planes, stride, downsample, SE, ECA_size, groups, base_width, dilation, norm_layer)
+        self.mrla = layers.mrla_base_module(input_dim=planes * self.expansion, init_cell=init_cell,
+                                            channel_wise=channel_wise_mrla)
+        self.bn_mrla = self._norm(planes * self.expansion)
+        self.drop_path = layers.DropPath(drop_path) if drop_path > 0.0 else nn.Identity()
+
+    def forward(self, x, prev_k, prev_v):
+        out, _ = self.trunk(x)
+        return layers.base_block_tail(out, prev_k, prev_v, self.mrla, self.bn_mrla, self.drop_path)
+
+
 class _ResNetMRLA(nn.Module):
     """Shared construction logic of the light and base networks."""
 
@@ -153,6 +169,55 @@ class ResNet_mrlal(_ResNetMRLA):
     def forward_features(self, x):
         x = self.maxpool(self.relu(self.bn1(self.conv1(x))))
         return self.layer4(self.layer3(self.layer2(self.layer1(x))))
+
+
+class ResNet_mrlab(_ResNetMRLA):
+    """ResNet (deep 3-conv stem) with an MRLA-base module after every bottleneck; the K/V history is threaded
+    through the blocks of a stage (resnet_mrla_base.py:134-272)."""
+
+    def __init__(self, block, layers, num_classes=1000, SE=False, ECA=None, zero_init_last_bn=True, groups=1,
+                 width_per_group=64, replace_stride_with_dilation=None, norm_layer=nn.BatchNorm2d, drop_rate=0.0,
+                 drop_path=0.0, channel_wise_mrla=False):
+        super().__init__()
+        self._setup(num_classes, SE, ECA, groups, width_per_group, replace_stride_with_dilation, norm_layer, drop_rate,
+                    drop_path)
+        stem_width = 32
+        nl = self._norm_layer
+        self.conv1 = nn.Sequential(
+            nn.Conv2d(3, stem_width, 3, stride=2, padding=1, bias=False), nl(stem_width), nn.ReLU(inplace=True),
+            nn.Conv2d(stem_width, stem_width, 3, stride=1, padding=1, bias=False), nl(stem_width), nn.ReLU(inplace=True),
+            nn.Conv2d(stem_width, self.inplanes, 3, stride=1, padding=1, bias=False))
+        self.bn1 = nl(self.inplanes)
+        self.relu = nn.ReLU(inplace=True)
+        self.maxpool = nn.MaxPool2d(kernel_size=3, stride=2, padding=1)
+        E, d = self._ECA, self._rswd
+        extra = dict(init_cell=True, channel_wise_mrla=channel_wise_mrla)
+        stages = [self._make_layer(block, 64, layers[0], SE, E[0], **extra),
+                  self._make_layer(block, 128, layers[1], SE, E[1], stride=2, dilate=d[0], **extra),
+                  self._make_layer(block, 256, layers[2], SE, E[2], stride=2, dilate=d[1], **extra),
+                  self._make_layer(block, 512, layers[3], SE, E[3], stride=2, dilate=d[2], **extra)]
+        for mods in stages:                       # tell the first block how deep its stage's history gets
+            mods[0].mrla.mrla.history_hint = len(mods)
+        self.stages = nn.ModuleList([nn.ModuleList(m) for m in stages])
+        self._head_and_init(block, zero_init_last_bn)
+
+    def forward_features(self, x):
+        x = self.maxpool(self.relu(self.bn1(self.conv1(x))))
+        k = v = None
+        for stage in self.stages:
+            for blk in stage:
+                x, k, v = blk(x, k, v)
+        return x
+
+
+def resnet50_mrlab(**kwargs):
+    print("Constructing resnet50_mrla-base......")
+    return ResNet_mrlab(MRLA_Bottleneck_base, [3, 4, 6, 3], **kwargs)
+
+
+def resnet101_mrlab(**kwargs):
+    print("Constructing resnet101_mrla-base......")
+    return ResNet_mrlab(MRLA_Bottleneck_base, [3, 4, 23, 3], **kwargs)
 
 
 def resnet50_mrlal(**kwargs):

@@ -240,15 +240,21 @@ def light_tail_bwd(dout, cache):
 # ----------------------------------------------------------------------------------------------
 # a4: base layer over a growing K/V history
 # ----------------------------------------------------------------------------------------------
-def base_layer_fwd(x, wq, wk, wv, d, K_prev=None, V_prev=None):
-    """K_prev [b,t-1,c] / V_prev [b,t-1,c,h,w] or None (init_cell).  Returns (out, K, V, cache)."""
+def _ident(a):
+    return a
+
+
+def base_layer_fwd(x, wq, wk, wv, d, K_prev=None, V_prev=None, rnd=_ident):
+    """K_prev [b,t-1,c] / V_prev [b,t-1,c,h,w] or None (init_cell).  Returns (out, K, V, cache).
+    `rnd` models the storage dtype of the HIP path (identity for fp32; round-to-bf16 for bf16 activations):
+    it is applied where that path stores an activation-sized tensor (v_t, attn)."""
     b, c, h, w = x.shape
     g = c // d
     s = 1.0 / sqrt(c / g)
     y = x.mean(axis=(2, 3))
     q = corr1d(y, wq)
     kt = corr1d(y, wk)
-    vt = dwconv3x3(x, wv)
+    vt = rnd(dwconv3x3(x, wv))
     if K_prev is None:
         K = kt[:, None]
         V = vt[:, None]
@@ -260,8 +266,8 @@ def base_layer_fwd(x, wq, wk, wv, d, K_prev=None, V_prev=None):
     logits = logits - logits.max(axis=-1, keepdims=True)
     e = np.exp(logits)
     P = e / e.sum(axis=-1, keepdims=True)                       # [b,g,t]
-    out = np.einsum("bgt,btgdhw->bgdhw", P, V.reshape(b, t, g, d, h, w)).reshape(b, c, h, w)
-    cache = dict(x=x, wq=wq, wk=wk, wv=wv, d=d, s=s, y=y, q=q, K=K, V=V, P=P)
+    out = rnd(np.einsum("bgt,btgdhw->bgdhw", P, V.reshape(b, t, g, d, h, w)).reshape(b, c, h, w))
+    cache = dict(x=x, wq=wq, wk=wk, wv=wv, d=d, s=s, y=y, q=q, K=K, V=V, P=P, rnd=rnd)
     return out, K, V, cache
 
 
@@ -273,6 +279,7 @@ def base_layer_bwd(dout, dK, dV, cache):
     b, c, h, w = x.shape
     g = c // d
     t = K.shape[1]
+    dout = cache["rnd"](dout)                                    # dA_t as stored in the dA ring
     do = dout.reshape(b, g, d, h, w)
     dP = np.einsum("bgdhw,btgdhw->bgt", do, V.reshape(b, t, g, d, h, w))
     dVtot = dV + np.einsum("bgt,bgdhw->btgdhw", P, do).reshape(b, t, c, h, w)
@@ -294,8 +301,8 @@ def base_layer_bwd(dout, dK, dV, cache):
 # a5: base block tail   out = x + dp[b] * relu(BN(attn))
 # ----------------------------------------------------------------------------------------------
 def base_tail_fwd(x, wq, wk, wv, gamma, beta, run_mean, run_var, d, K_prev=None, V_prev=None,
-                  training=True, dp=None, eps=1e-5, momentum=0.1):
-    attn, K, V, c1 = base_layer_fwd(x, wq, wk, wv, d, K_prev, V_prev)
+                  training=True, dp=None, eps=1e-5, momentum=0.1, rnd=_ident):
+    attn, K, V, c1 = base_layer_fwd(x, wq, wk, wv, d, K_prev, V_prev, rnd)
     z, c2 = bn_fwd(attn, gamma, beta, run_mean, run_var, training, eps, momentum)
     r = np.maximum(z, 0)
     dpv = np.ones(x.shape[0], dtype=x.dtype) if dp is None else dp.astype(x.dtype)

@@ -168,6 +168,43 @@ int mrla_base_value_bwd(const void* dout, const void* x, const float* wv, const 
                         const float* dyx, void* dx, float* dwv_part, int b, int c, int h, int w, int d, int T, int t,
                         int Tc, int res, int dtype, int layout, void* stream);
 
+/* =====================================================================================================
+ * MRLA-light on token sequences (DeiT): x[b, n, c], n = 1 + side*side, channels contiguous.
+ * Reference: deit/deit_mrla_light.py:157-180 (mrlal_layer, GELU on V), :194-209 (mrlal_module: two LayerNorms,
+ * cls split, token<->map permutes, lambda_t, cat), :234 (block residual).  The gate itself is computed with
+ * mrla_light_gate_fwd / mrla_light_gate_bwd on the `mom` / `bmom` records written here (hw = n - 1).
+ *   stats[b, n, 4] = (mean_x, rstd_x, mean_o, rstd_o) per token;   params: lnx_* / lno_* = LayerNorm weight, bias.
+ * ===================================================================================================== */
+#define MRLA_TOKEN_PARTIALS 14 /* per (image, channel): dWv[9], dlambda, dlnx_w, dlnx_b, dlno_w, dlno_b */
+
+/* LayerNorm statistics of x and o_prev; mom[b,c,0] = (n-1) * mean_{i>=1} LN_x(x)[b,i,c], other slots 0.
+ * Replaces normx / normo statistics (deit_mrla_light.py:195-196) and avg_pool (:161). */
+int mrla_token_norm_pool(const void* x, const void* o_prev, const float* lnx_w, const float* lnx_b, float eps,
+                         float* stats, float* mom, int b, int n, int c, int dtype, void* stream);
+
+/* out[b,0] = res*x + LN_x(x);  out[b,i>=1] = res*x + a*gelu(dwconv3x3(LN_x(x) map)) + lam*LN_o(o_prev).
+ * Replaces deit_mrla_light.py:195-207 (normalisation halves, split, reshape/permute, Wv, GELU, gate multiply,
+ * flatten/permute, lambda_t term, cat) and the residual add of :234. */
+int mrla_token_apply_fwd(const void* x, const void* o_prev, const float* stats, const float* lnx_w,
+                         const float* lnx_b, const float* lno_w, const float* lno_b, const float* wv,
+                         const float* gate, const float* lam, void* out, int b, int n, int c, int d, int res,
+                         int dtype, void* stream);
+
+/* bmom[b,c,1] = sum_i dOut * gelu(U) (slots 0, 2 zeroed). */
+int mrla_token_stats_bwd(const void* dout, const void* x, const float* stats, const float* lnx_w, const float* lnx_b,
+                         const float* wv, float* bmom, int b, int n, int c, int dtype, void* stream);
+
+/* dxn[b,n,c] (float32) = gradient wrt LN_x(x) incl. the cls row; part[b,c,14] parameter-gradient partials. */
+int mrla_token_apply_bwd(const void* dout, const void* x, const void* o_prev, const float* stats, const float* lnx_w,
+                         const float* lnx_b, const float* lno_w, const float* lno_b, const float* wv,
+                         const float* gate, const float* lam, const float* dyx, float* dxn, float* part, int b, int n,
+                         int c, int d, int dtype, void* stream);
+
+/* dx = LN_x^T(dxn) + res*dOut;  do_prev = LN_o^T(lam*dOut) on map tokens, 0 on the cls row. */
+int mrla_token_ln_bwd(const void* dout, const void* x, const void* o_prev, const float* dxn, const float* stats,
+                      const float* lnx_w, const float* lno_w, const float* lam, void* dx, void* do_prev, int b, int n,
+                      int c, int res, int dtype, void* stream);
+
 /* out[n] = sum over rows of in[rows, n] (fixed order, double accumulation). */
 int mrla_reduce_rows(const float* in, float* out, int rows, int n, void* stream);
 

@@ -253,6 +253,61 @@ int mrla_base_value_bwd(const void* dout, const void* x, const float* wv, const 
                                (hipStream_t)stream);
 }
 
+static int token_side(int n) {
+  if (n < 2) return 0;
+  int s = 1;
+  while ((s + 1) * (s + 1) <= n - 1) ++s;
+  return s * s == n - 1 ? s : 0;
+}
+
+int mrla_token_norm_pool(const void* x, const void* o_prev, const float* lnx_w, const float* lnx_b, float eps,
+                         float* stats, float* mom, int b, int n, int c, int dtype, void* stream) {
+  if (!x || !o_prev || !lnx_w || !lnx_b || !stats || !mom || b <= 0 || c <= 0 || bad_dtype(dtype) || !token_side(n))
+    return MRLA_EINVAL;
+  return launch_token_norm_pool(x, o_prev, lnx_w, lnx_b, eps, stats, mom, b, n, c, dtype, (hipStream_t)stream);
+}
+
+int mrla_token_apply_fwd(const void* x, const void* o_prev, const float* stats, const float* lnx_w,
+                         const float* lnx_b, const float* lno_w, const float* lno_b, const float* wv,
+                         const float* gate, const float* lam, void* out, int b, int n, int c, int d, int res,
+                         int dtype, void* stream) {
+  if (!x || !o_prev || !stats || !lnx_w || !lnx_b || !lno_w || !lno_b || !wv || !gate || !lam || !out || b <= 0 ||
+      c <= 0 || d <= 0 || c % d || bad_dtype(dtype) || !token_side(n))
+    return MRLA_EINVAL;
+  return launch_token_apply_fwd(x, o_prev, stats, lnx_w, lnx_b, lno_w, lno_b, wv, gate, lam, out, b, n, c,
+                                token_side(n), d, res, dtype, (hipStream_t)stream);
+}
+
+int mrla_token_stats_bwd(const void* dout, const void* x, const float* stats, const float* lnx_w, const float* lnx_b,
+                         const float* wv, float* bmom, int b, int n, int c, int dtype, void* stream) {
+  if (!dout || !x || !stats || !lnx_w || !lnx_b || !wv || !bmom || b <= 0 || c <= 0 || bad_dtype(dtype) ||
+      !token_side(n))
+    return MRLA_EINVAL;
+  return launch_token_stats_bwd(dout, x, stats, lnx_w, lnx_b, wv, bmom, b, n, c, token_side(n), dtype,
+                                (hipStream_t)stream);
+}
+
+int mrla_token_apply_bwd(const void* dout, const void* x, const void* o_prev, const float* stats, const float* lnx_w,
+                         const float* lnx_b, const float* lno_w, const float* lno_b, const float* wv,
+                         const float* gate, const float* lam, const float* dyx, float* dxn, float* part, int b, int n,
+                         int c, int d, int dtype, void* stream) {
+  if (!dout || !x || !o_prev || !stats || !lnx_w || !lnx_b || !lno_w || !lno_b || !wv || !gate || !lam || !dyx ||
+      !dxn || !part || b <= 0 || c <= 0 || d <= 0 || c % d || bad_dtype(dtype) || !token_side(n))
+    return MRLA_EINVAL;
+  return launch_token_apply_bwd(dout, x, o_prev, stats, lnx_w, lnx_b, lno_w, lno_b, wv, gate, lam, dyx, dxn, part, b,
+                                n, c, token_side(n), d, dtype, (hipStream_t)stream);
+}
+
+int mrla_token_ln_bwd(const void* dout, const void* x, const void* o_prev, const float* dxn, const float* stats,
+                      const float* lnx_w, const float* lno_w, const float* lam, void* dx, void* do_prev, int b, int n,
+                      int c, int res, int dtype, void* stream) {
+  if (!dout || !x || !o_prev || !dxn || !stats || !lnx_w || !lno_w || !lam || !dx || !do_prev || b <= 0 || c <= 0 ||
+      bad_dtype(dtype) || !token_side(n))
+    return MRLA_EINVAL;
+  return launch_token_ln_bwd(dout, x, o_prev, dxn, stats, lnx_w, lno_w, lam, dx, do_prev, b, n, c, res, dtype,
+                             (hipStream_t)stream);
+}
+
 int mrla_reduce_rows(const float* in, float* out, int rows, int n, void* stream) {
   if (!in || !out || rows <= 0 || n <= 0) return MRLA_EINVAL;
   return launch_reduce_rows(in, out, rows, n, (hipStream_t)stream);

@@ -81,4 +81,21 @@ int launch_base_value_bwd(const void* dout, const void* x, const float* wv, cons
                           const float* dyx, void* dx, float* dwv_part, const SlabGeo& g, int d, int T, int t, int Tc,
                           int res, int dtype, hipStream_t st);
 
+
+// tokens.hip -- MRLA-light on token sequences (DeiT)
+int launch_token_norm_pool(const void* x, const void* o, const float* wx, const float* bx, float eps, float* stats,
+                           float* mom, int B, int n, int C, int dtype, hipStream_t st);
+int launch_token_apply_fwd(const void* x, const void* o, const float* stats, const float* wx, const float* bx,
+                           const float* wo, const float* bo, const float* wv, const float* gate, const float* lam,
+                           void* out, int B, int n, int C, int side, int d, int res, int dtype, hipStream_t st);
+int launch_token_stats_bwd(const void* dout, const void* x, const float* stats, const float* wx, const float* bx,
+                           const float* wv, float* bmom, int B, int n, int C, int side, int dtype, hipStream_t st);
+int launch_token_apply_bwd(const void* dout, const void* x, const void* o, const float* stats, const float* wx,
+                           const float* bx, const float* wo, const float* bo, const float* wv, const float* gate,
+                           const float* lam, const float* dyx, float* dxn, float* part, int B, int n, int C, int side,
+                           int d, int dtype, hipStream_t st);
+int launch_token_ln_bwd(const void* dout, const void* x, const void* o, const float* dxn, const float* stats,
+                        const float* wx, const float* wo, const float* lam, void* dx, void* dprev, int B, int n, int C,
+                        int res, int dtype, hipStream_t st);
+
 }  // namespace mrla

@@ -1,0 +1,436 @@
+// MRLA-light for token sequences (DeiT): x[b, n, c] with n = 1 + side*side, channel-contiguous (NHWC).
+//
+// Reference: deit/deit_mrla_light.py:157-180 (mrlal_layer: GAP -> Wq/Wk conv1d -> sigmoid gate -> GELU(dwconv3x3))
+// and :194-209 (mrlal_module: LayerNorm of x_t and o_{t-1}, cls split, token <-> map permutes, lambda_t, cat),
+// :234 (block residual x + mrla(x, o)).
+//
+//   xn = LN_x(x), on = LN_o(o)                       per token over c (eps = 1e-6)
+//   y[b,c] = mean_{i>=1} xn[b,i,c] ; a[b,g] = sigmoid(<Wq*y, Wk*y>_g / sqrt(d))       (gate.hip kernels)
+//   out[b,0,:]  = res*x[b,0,:] + xn[b,0,:]                                              cls row
+//   out[b,i,:]  = res*x[b,i,:] + a[b,g]*gelu(dwconv3x3(xn map)[i,:]) + lam*on[b,i,:]    i >= 1
+//
+// Kernels: token_norm_pool (per image: LN statistics of both inputs, pooled descriptor), token_apply_fwd,
+// token_stats_bwd, token_apply_bwd (per image x 64-channel chunk: the normalised map lives in LDS as fp32,
+// lanes = channels so the 3x3 neighbours are plain LDS reads), token_ln_bwd (per token: both LayerNorm backward
+// passes).  The permutes / split / cat of the reference never touch memory: they are index arithmetic here.
+#include "mrla_device.h"
+#include "mrla_kernels.h"
+
+namespace mrla {
+
+// stats[b, i, 0..3] = mean_x, rstd_x, mean_o, rstd_o
+enum { S_MX = 0, S_RX = 1, S_MO = 2, S_RO = 3, S_N = 4 };
+// per-(image, channel) parameter-gradient partials written by token_apply_bwd
+enum { Q_WV = 0, Q_LAM = 9, Q_LNXW = 10, Q_LNXB = 11, Q_LNOW = 12, Q_LNOB = 13, Q_N = 14 };
+
+// ------------------------------------------------------------------------------------------------
+// per image: LayerNorm statistics of x and o, pooled descriptor of LN_x(x) over the map tokens
+// ------------------------------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(kThreads) void token_norm_pool_kernel(
+    const T* __restrict__ x, const T* __restrict__ o, const float* __restrict__ wx, const float* __restrict__ bx,
+    float eps, float* __restrict__ stats, float* __restrict__ mom, int n, int C) {
+  extern __shared__ float ysum[];     // [kWaves][C]
+  const int b = blockIdx.x, tid = threadIdx.x, lane = tid & (kWave - 1), wave = tid / kWave;
+  for (int i = tid; i < kWaves * C; i += kThreads) ysum[i] = 0.f;
+  __syncthreads();
+  const float invc = 1.0f / (float)C;
+  for (int i = wave; i < n; i += kWaves) {
+    const T* xr = x + ((size_t)b * n + i) * C;
+    const T* orow = o + ((size_t)b * n + i) * C;
+    float sx = 0.f, so = 0.f;
+    for (int c = lane; c < C; c += kWave) { sx += to_f(xr[c]); so += to_f(orow[c]); }
+    sx = wave_sum(sx); so = wave_sum(so);
+    const float mx = __shfl(sx, 0, kWave) * invc, mo = __shfl(so, 0, kWave) * invc;
+    float vx = 0.f, vo = 0.f;
+    for (int c = lane; c < C; c += kWave) {
+      const float dxv = to_f(xr[c]) - mx, dov = to_f(orow[c]) - mo;
+      vx = fmaf(dxv, dxv, vx);
+      vo = fmaf(dov, dov, vo);
+    }
+    vx = wave_sum(vx); vo = wave_sum(vo);
+    const float rx = rsqrtf(__shfl(vx, 0, kWave) * invc + eps), ro = rsqrtf(__shfl(vo, 0, kWave) * invc + eps);
+    if (lane == 0) {
+      float* s = stats + ((size_t)b * n + i) * S_N;
+      s[S_MX] = mx; s[S_RX] = rx; s[S_MO] = mo; s[S_RO] = ro;
+    }
+    if (i >= 1)
+      for (int c = lane; c < C; c += kWave) ysum[wave * C + c] += (to_f(xr[c]) - mx) * rx;
+  }
+  __syncthreads();
+  const float hw = (float)(n - 1);
+  for (int c = tid; c < C; c += kThreads) {
+    float s = 0.f;
+#pragma unroll
+    for (int w = 0; w < kWaves; ++w) s += ysum[w * C + c];
+    float* m = mom + ((size_t)b * C + c) * M_N;
+    // slot 0 holds hw * y so that the shared gate kernels' y = Sx / hw is the LN-affine pooled value
+    m[M_SX] = fmaf(wx[c], s, bx[c] * hw);
+    m[M_SV] = 0.f; m[M_SO] = 0.f; m[M_SVV] = 0.f; m[M_SVO] = 0.f; m[M_SOO] = 0.f;
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// shared tile code: normalised map of one (image, channel chunk) in LDS, fp32, layout [hw][CC]
+// ------------------------------------------------------------------------------------------------
+template <typename T>
+__device__ __forceinline__ void load_xn_tile(float* __restrict__ tile, const T* __restrict__ x,
+                                             const float* __restrict__ stats, const float* __restrict__ wx,
+                                             const float* __restrict__ bx, int b, int n, int C, int c0, int CC, int tid) {
+  const int hw = n - 1;
+  for (int idx = tid; idx < hw * CC; idx += kThreads) {
+    const int i = idx / CC, cc = idx - i * CC;
+    const float* s = stats + ((size_t)b * n + i + 1) * S_N;
+    const float xv = to_f(x[((size_t)b * n + i + 1) * C + c0 + cc]);
+    tile[idx] = fmaf((xv - s[S_MX]) * s[S_RX], wx[c0 + cc], bx[c0 + cc]);
+  }
+}
+
+__device__ __forceinline__ float conv9_tile(const float* __restrict__ tile, const float (&w)[9], int r, int col,
+                                            int side, int CC, int cc) {
+  float u = 0.f;
+#pragma unroll
+  for (int di = -1; di <= 1; ++di) {
+    const int rr = r + di;
+    if (rr < 0 || rr >= side) continue;
+#pragma unroll
+    for (int dj = -1; dj <= 1; ++dj) {
+      const int c2 = col + dj;
+      if (c2 < 0 || c2 >= side) continue;
+      u = fmaf(w[(di + 1) * 3 + dj + 1], tile[(rr * side + c2) * CC + cc], u);
+    }
+  }
+  return u;
+}
+
+// ------------------------------------------------------------------------------------------------
+// forward apply
+// ------------------------------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(kThreads) void token_apply_fwd_kernel(
+    const T* __restrict__ x, const T* __restrict__ o, const float* __restrict__ stats, const float* __restrict__ wx,
+    const float* __restrict__ bx, const float* __restrict__ wo, const float* __restrict__ bo,
+    const float* __restrict__ wv, const float* __restrict__ gate, const float* __restrict__ lam, T* __restrict__ out,
+    int n, int C, int side, int d, int CC, int res) {
+  extern __shared__ float tile[];
+  const int b = blockIdx.y, c0 = blockIdx.x * CC, tid = threadIdx.x;
+  const int hw = n - 1;
+  load_xn_tile(tile, x, stats, wx, bx, b, n, C, c0, CC, tid);
+  __syncthreads();
+  const int cc = tid % CC, tg = tid / CC, ntg = kThreads / CC;
+  const int c = c0 + cc;
+  float w[9];
+#pragma unroll
+  for (int k = 0; k < 9; ++k) w[k] = wv[c * 9 + k];
+  const float a = gate[(size_t)b * (C / d) + c / d];
+  const float lm = lam[c], wo_c = wo[c], bo_c = bo[c];
+  for (int i = tg; i < hw; i += ntg) {
+    const int r = i / side, col = i - r * side;
+    const float u = conv9_tile(tile, w, r, col, side, CC, cc);
+    const size_t g = ((size_t)b * n + i + 1) * C + c;
+    const float* s = stats + ((size_t)b * n + i + 1) * S_N;
+    const float on = fmaf((to_f(o[g]) - s[S_MO]) * s[S_RO], wo_c, bo_c);
+    float y = fmaf(a, gelu_f(u), lm * on);
+    if (res) y += to_f(x[g]);
+    out[g] = from_f<T>(y);
+  }
+  if (tg == 0) {                                          // cls row passes LN_x(x) through
+    const size_t g = (size_t)b * n * C + c;
+    const float* s = stats + (size_t)b * n * S_N;
+    const float xv = to_f(x[g]);
+    float y = fmaf((xv - s[S_MX]) * s[S_RX], wx[c], bx[c]);
+    if (res) y += xv;
+    out[g] = from_f<T>(y);
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// backward statistics: bmom[b,c,D_DV] = sum_i dOut * gelu(U)   (D_D, D_DO zeroed: unused by the gate backward)
+// ------------------------------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(kThreads) void token_stats_bwd_kernel(
+    const T* __restrict__ dout, const T* __restrict__ x, const float* __restrict__ stats,
+    const float* __restrict__ wx, const float* __restrict__ bx, const float* __restrict__ wv,
+    float* __restrict__ bmom, int n, int C, int side, int CC) {
+  extern __shared__ float tile[];
+  float* red = tile + (n - 1) * CC;       // [ntg][CC]
+  const int b = blockIdx.y, c0 = blockIdx.x * CC, tid = threadIdx.x;
+  const int hw = n - 1;
+  load_xn_tile(tile, x, stats, wx, bx, b, n, C, c0, CC, tid);
+  __syncthreads();
+  const int cc = tid % CC, tg = tid / CC, ntg = kThreads / CC;
+  const int c = c0 + cc;
+  float w[9];
+#pragma unroll
+  for (int k = 0; k < 9; ++k) w[k] = wv[c * 9 + k];
+  float acc = 0.f;
+  for (int i = tg; i < hw; i += ntg) {
+    const int r = i / side, col = i - r * side;
+    const float u = conv9_tile(tile, w, r, col, side, CC, cc);
+    acc = fmaf(to_f(dout[((size_t)b * n + i + 1) * C + c]), gelu_f(u), acc);
+  }
+  red[tg * CC + cc] = acc;
+  __syncthreads();
+  if (tg == 0) {
+    float s = 0.f;
+    for (int k = 0; k < ntg; ++k) s += red[k * CC + cc];
+    float* bm = bmom + ((size_t)b * C + c) * D_N;
+    bm[D_D] = 0.f; bm[D_DV] = s; bm[D_DO] = 0.f;
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// backward apply: dxn (gradient wrt LN_x(x), all rows) and per-(image, channel) parameter partials
+// ------------------------------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(kThreads) void token_apply_bwd_kernel(
+    const T* __restrict__ dout, const T* __restrict__ x, const T* __restrict__ o, const float* __restrict__ stats,
+    const float* __restrict__ wx, const float* __restrict__ bx, const float* __restrict__ wo,
+    const float* __restrict__ bo, const float* __restrict__ wv, const float* __restrict__ gate,
+    const float* __restrict__ lam, const float* __restrict__ dyx, float* __restrict__ dxn /*[b,n,c] fp32*/,
+    float* __restrict__ part /*[b,c,Q_N]*/, int n, int C, int side, int d, int CC) {
+  extern __shared__ float tile[];
+  const int hw = n - 1;
+  float* dus = tile + hw * CC;            // [hw][CC] dU
+  float* red = dus + hw * CC;             // [ntg][CC][Q_N]
+  const int b = blockIdx.y, c0 = blockIdx.x * CC, tid = threadIdx.x;
+  load_xn_tile(tile, x, stats, wx, bx, b, n, C, c0, CC, tid);
+  __syncthreads();
+  const int cc = tid % CC, tg = tid / CC, ntg = kThreads / CC;
+  const int c = c0 + cc;
+  float w[9];
+#pragma unroll
+  for (int k = 0; k < 9; ++k) w[k] = wv[c * 9 + k];
+  const float a = gate[(size_t)b * (C / d) + c / d];
+  const float lm = lam[c], wo_c = wo[c], bo_c = bo[c];
+  float q[Q_N];
+#pragma unroll
+  for (int k = 0; k < Q_N; ++k) q[k] = 0.f;
+  for (int i = tg; i < hw; i += ntg) {
+    const int r = i / side, col = i - r * side;
+    const float u = conv9_tile(tile, w, r, col, side, CC, cc);
+    const size_t g = ((size_t)b * n + i + 1) * C + c;
+    const float go = to_f(dout[g]);
+    const float du = a * go * gelu_grad_f(u);
+    dus[i * CC + cc] = du;
+    const float* s = stats + ((size_t)b * n + i + 1) * S_N;
+    const float ohat = (to_f(o[g]) - s[S_MO]) * s[S_RO];
+    q[Q_LAM] = fmaf(go, fmaf(ohat, wo_c, bo_c), q[Q_LAM]);
+    q[Q_LNOW] = fmaf(lm * go, ohat, q[Q_LNOW]);
+    q[Q_LNOB] = fmaf(lm, go, q[Q_LNOB]);
+    // dWv[di][dj] += dU[i] * xn[i + (di, dj)]
+#pragma unroll
+    for (int di = -1; di <= 1; ++di) {
+      const int rr = r + di;
+      if (rr < 0 || rr >= side) continue;
+#pragma unroll
+      for (int dj = -1; dj <= 1; ++dj) {
+        const int c2 = col + dj;
+        if (c2 < 0 || c2 >= side) continue;
+        q[Q_WV + (di + 1) * 3 + dj + 1] = fmaf(du, tile[(rr * side + c2) * CC + cc], q[Q_WV + (di + 1) * 3 + dj + 1]);
+      }
+    }
+  }
+  __syncthreads();
+  const float dy = dyx[(size_t)b * C + c];
+  for (int i = tg; i < hw; i += ntg) {
+    const int r = i / side, col = i - r * side;
+    // dxn[i] = sum_{di,dj} wv[di][dj] * dU[i - (di, dj)] + dy/hw
+    float s9 = dy;
+#pragma unroll
+    for (int di = -1; di <= 1; ++di) {
+      const int rr = r - di;
+      if (rr < 0 || rr >= side) continue;
+#pragma unroll
+      for (int dj = -1; dj <= 1; ++dj) {
+        const int c2 = col - dj;
+        if (c2 < 0 || c2 >= side) continue;
+        s9 = fmaf(w[(di + 1) * 3 + dj + 1], dus[(rr * side + c2) * CC + cc], s9);
+      }
+    }
+    const size_t g = ((size_t)b * n + i + 1) * C + c;
+    dxn[g] = s9;
+    const float* s = stats + ((size_t)b * n + i + 1) * S_N;
+    const float xhat = (to_f(x[g]) - s[S_MX]) * s[S_RX];
+    q[Q_LNXW] = fmaf(s9, xhat, q[Q_LNXW]);
+    q[Q_LNXB] += s9;
+  }
+  if (tg == 0) {                                              // cls row: module output is LN_x(x) itself
+    const size_t g = (size_t)b * n * C + c;
+    const float* s = stats + (size_t)b * n * S_N;
+    const float dn = to_f(dout[g]);
+    dxn[g] = dn;
+    q[Q_LNXW] = fmaf(dn, (to_f(x[g]) - s[S_MX]) * s[S_RX], q[Q_LNXW]);
+    q[Q_LNXB] += dn;
+  }
+#pragma unroll
+  for (int k = 0; k < Q_N; ++k) red[(tg * CC + cc) * Q_N + k] = q[k];
+  __syncthreads();
+  if (tg == 0) {
+#pragma unroll
+    for (int k = 0; k < Q_N; ++k) {
+      float s = 0.f;
+      for (int t2 = 0; t2 < ntg; ++t2) s += red[(t2 * CC + cc) * Q_N + k];
+      part[((size_t)b * C + c) * Q_N + k] = s;
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// per token: backward of both LayerNorms.  dx = LN_x^T(dxn) + res*dOut ;  do = LN_o^T(lam*dOut) (cls row: 0)
+// ------------------------------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(kThreads) void token_ln_bwd_kernel(
+    const T* __restrict__ dout, const T* __restrict__ x, const T* __restrict__ o, const float* __restrict__ dxn,
+    const float* __restrict__ stats, const float* __restrict__ wx, const float* __restrict__ wo,
+    const float* __restrict__ lam, T* __restrict__ dx, T* __restrict__ dprev, int ntok, int n, int C, int res) {
+  const int lane = threadIdx.x & (kWave - 1), wave = threadIdx.x / kWave;
+  const int tok = blockIdx.x * kWaves + wave;
+  if (tok >= ntok) return;
+  const int i = tok % n;
+  const size_t base = (size_t)tok * C;
+  const float* s = stats + (size_t)tok * S_N;
+  const float mx = s[S_MX], rx = s[S_RX], mo = s[S_MO], ro = s[S_RO];
+  float s1 = 0.f, s2 = 0.f, t1 = 0.f, t2 = 0.f;
+  for (int c = lane; c < C; c += kWave) {
+    const float dh = dxn[base + c] * wx[c];
+    const float xh = (to_f(x[base + c]) - mx) * rx;
+    s1 += dh;
+    s2 = fmaf(dh, xh, s2);
+    if (i >= 1) {
+      const float dho = lam[c] * to_f(dout[base + c]) * wo[c];
+      const float oh = (to_f(o[base + c]) - mo) * ro;
+      t1 += dho;
+      t2 = fmaf(dho, oh, t2);
+    }
+  }
+  const float invc = 1.0f / (float)C;
+  s1 = __shfl(wave_sum(s1), 0, kWave) * invc;
+  s2 = __shfl(wave_sum(s2), 0, kWave) * invc;
+  t1 = __shfl(wave_sum(t1), 0, kWave) * invc;
+  t2 = __shfl(wave_sum(t2), 0, kWave) * invc;
+  for (int c = lane; c < C; c += kWave) {
+    const float go = to_f(dout[base + c]);
+    const float dh = dxn[base + c] * wx[c];
+    const float xh = (to_f(x[base + c]) - mx) * rx;
+    float y = rx * (dh - s1 - xh * s2);
+    if (res) y += go;
+    dx[base + c] = from_f<T>(y);
+    float z = 0.f;
+    if (i >= 1) {
+      const float dho = lam[c] * go * wo[c];
+      const float oh = (to_f(o[base + c]) - mo) * ro;
+      z = ro * (dho - t1 - oh * t2);
+    }
+    dprev[base + c] = from_f<T>(z);
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// launchers
+// ------------------------------------------------------------------------------------------------
+#define MRLA_DISPATCH_TT(DT, CALL)       \
+  switch (DT) {                          \
+    case MRLA_F32:  CALL(float); break;  \
+    case MRLA_BF16: CALL(bf16_t); break; \
+    case MRLA_F16:  CALL(f16_t); break;  \
+    default: return MRLA_EINVAL;         \
+  }
+
+static int chunk_for(int C) {
+  if (C % 64 == 0) return 64;
+  if (C % 32 == 0) return 32;
+  if (C % 16 == 0) return 16;
+  return 0;
+}
+
+template <typename K>
+static hipError_t set_lds3(K kernel, size_t bytes) {
+  if (bytes <= 48 * 1024) return hipSuccess;
+  return hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+}
+
+int launch_token_norm_pool(const void* x, const void* o, const float* wx, const float* bx, float eps, float* stats,
+                           float* mom, int B, int n, int C, int dtype, hipStream_t st) {
+  const size_t lds = (size_t)kWaves * C * sizeof(float);
+  if (lds > 64 * 1024) return MRLA_EUNSUPPORTED;
+#define CALL(TT)                                                                                              \
+  hipLaunchKernelGGL((token_norm_pool_kernel<TT>), dim3(B), dim3(kThreads), lds, st, (const TT*)x, (const TT*)o, \
+                     wx, bx, eps, stats, mom, n, C);
+  MRLA_DISPATCH_TT(dtype, CALL)
+#undef CALL
+  return hip_status(hipGetLastError());
+}
+
+int launch_token_apply_fwd(const void* x, const void* o, const float* stats, const float* wx, const float* bx,
+                           const float* wo, const float* bo, const float* wv, const float* gate, const float* lam,
+                           void* out, int B, int n, int C, int side, int d, int res, int dtype, hipStream_t st) {
+  const int CC = chunk_for(C);
+  if (!CC) return MRLA_EUNSUPPORTED;
+  const size_t lds = (size_t)(n - 1) * CC * sizeof(float);
+  if (lds > 150 * 1024) return MRLA_EUNSUPPORTED;
+  const dim3 grid(C / CC, B);
+#define CALL(TT)                                                                                              \
+  {                                                                                                           \
+    if (set_lds3(token_apply_fwd_kernel<TT>, lds) != hipSuccess) return MRLA_EHIP;                              \
+    hipLaunchKernelGGL((token_apply_fwd_kernel<TT>), grid, dim3(kThreads), lds, st, (const TT*)x, (const TT*)o, \
+                       stats, wx, bx, wo, bo, wv, gate, lam, (TT*)out, n, C, side, d, CC, res);               \
+  }
+  MRLA_DISPATCH_TT(dtype, CALL)
+#undef CALL
+  return hip_status(hipGetLastError());
+}
+
+int launch_token_stats_bwd(const void* dout, const void* x, const float* stats, const float* wx, const float* bx,
+                           const float* wv, float* bmom, int B, int n, int C, int side, int dtype, hipStream_t st) {
+  const int CC = chunk_for(C);
+  if (!CC) return MRLA_EUNSUPPORTED;
+  const size_t lds = ((size_t)(n - 1) * CC + (size_t)kThreads) * sizeof(float);
+  if (lds > 150 * 1024) return MRLA_EUNSUPPORTED;
+  const dim3 grid(C / CC, B);
+#define CALL(TT)                                                                                              \
+  {                                                                                                           \
+    if (set_lds3(token_stats_bwd_kernel<TT>, lds) != hipSuccess) return MRLA_EHIP;                              \
+    hipLaunchKernelGGL((token_stats_bwd_kernel<TT>), grid, dim3(kThreads), lds, st, (const TT*)dout,           \
+                       (const TT*)x, stats, wx, bx, wv, bmom, n, C, side, CC);                                \
+  }
+  MRLA_DISPATCH_TT(dtype, CALL)
+#undef CALL
+  return hip_status(hipGetLastError());
+}
+
+int launch_token_apply_bwd(const void* dout, const void* x, const void* o, const float* stats, const float* wx,
+                           const float* bx, const float* wo, const float* bo, const float* wv, const float* gate,
+                           const float* lam, const float* dyx, float* dxn, float* part, int B, int n, int C, int side,
+                           int d, int dtype, hipStream_t st) {
+  const int CC = chunk_for(C);
+  if (!CC) return MRLA_EUNSUPPORTED;
+  const size_t lds = ((size_t)2 * (n - 1) * CC + (size_t)kThreads * Q_N) * sizeof(float);
+  if (lds > 150 * 1024) return MRLA_EUNSUPPORTED;
+  const dim3 grid(C / CC, B);
+#define CALL(TT)                                                                                              \
+  {                                                                                                           \
+    if (set_lds3(token_apply_bwd_kernel<TT>, lds) != hipSuccess) return MRLA_EHIP;                              \
+    hipLaunchKernelGGL((token_apply_bwd_kernel<TT>), grid, dim3(kThreads), lds, st, (const TT*)dout,           \
+                       (const TT*)x, (const TT*)o, stats, wx, bx, wo, bo, wv, gate, lam, dyx, dxn, part, n, C, \
+                       side, d, CC);                                                                          \
+  }
+  MRLA_DISPATCH_TT(dtype, CALL)
+#undef CALL
+  return hip_status(hipGetLastError());
+}
+
+int launch_token_ln_bwd(const void* dout, const void* x, const void* o, const float* dxn, const float* stats,
+                        const float* wx, const float* wo, const float* lam, void* dx, void* dprev, int B, int n, int C,
+                        int res, int dtype, hipStream_t st) {
+  const int ntok = B * n;
+  const dim3 grid((ntok + kWaves - 1) / kWaves);
+#define CALL(TT)                                                                                              \
+  hipLaunchKernelGGL((token_ln_bwd_kernel<TT>), grid, dim3(kThreads), 0, st, (const TT*)dout, (const TT*)x,    \
+                     (const TT*)o, dxn, stats, wx, wo, lam, (TT*)dx, (TT*)dprev, ntok, n, C, res);
+  MRLA_DISPATCH_TT(dtype, CALL)
+#undef CALL
+  return hip_status(hipGetLastError());
+}
+
+}  // namespace mrla

@@ -374,3 +374,78 @@ def mrla_base(x, wq, wk, wv, d, stage, bn=None, dp=None):
         return _BaseFn.apply(x, wq, wk, wv, None, None, None, None, None, stage, BaseConfig(d))
     cfg = BaseConfig(d, L.BN_TRAIN if bn["training"] else L.BN_EVAL, bn.get("momentum", 0.1), bn.get("eps", 1e-5), True)
     return _BaseFn.apply(x, wq, wk, wv, bn["weight"], bn["bias"], bn["running_mean"], bn["running_var"], dp, stage, cfg)
+
+
+# ======================================================================================================
+# MRLA-light on token sequences (DeiT)
+# ======================================================================================================
+class _TokenLightFn(torch.autograd.Function):
+    """out = res*x + cat(LN_x(x)[:, :1], a*gelu(dwconv3x3(LN_x(x) map)) + lam*LN_o(o_prev)[:, 1:])
+    (deit_mrla_light.py:194-209 and the block residual :234)."""
+
+    @staticmethod
+    def forward(ctx, x, o_prev, lnx_w, lnx_b, lno_w, lno_b, wq, wk, wv, lam, d, eps, res):
+        _require_cuda(x, "mrla token forward")
+        if x.dim() != 3 or o_prev.shape != x.shape or o_prev.dtype != x.dtype:
+            raise L.MrlaHipError("expected x and o_prev of identical shape [b, n, c] and dtype")
+        xc, oc = x.contiguous(), o_prev.contiguous()
+        b, n, c = xc.shape
+        side = int(round((n - 1) ** 0.5))
+        if side * side != n - 1 or c % d:
+            raise L.MrlaHipError(f"token count {n} is not 1 + a perfect square, or c={c} not divisible by d={d}")
+        dt, dev, st = _DT[xc.dtype], xc.device, _stream()
+        p32 = [_f32(t).reshape(-1) for t in (lnx_w, lnx_b, lno_w, lno_b, wq, wk, lam)]
+        wxw, wxb, wow, wob, wq32, wk32, lam32 = p32
+        wv32 = _f32(wv).reshape(c, 9)
+        ks = wq32.numel()
+        stats = torch.empty((b, n, 4), dtype=torch.float32, device=dev)
+        mom = torch.empty((b, c, L.FWD_MOMENTS), dtype=torch.float32, device=dev)
+        L.call("mrla_token_norm_pool", _ptr(xc), _ptr(oc), _ptr(wxw), _ptr(wxb), float(eps), _ptr(stats), _ptr(mom), b, n,
+               c, dt, st)
+        gate = torch.empty((b, c // d), dtype=torch.float32, device=dev)
+        L.call("mrla_light_gate_fwd", _ptr(mom), _ptr(wq32), _ptr(wk32), ks, _ptr(gate), b, c, n - 1, d, st)
+        out = torch.empty_like(xc)
+        _call("mrla_token_apply_fwd", xc.numel() * xc.element_size() * 3, _ptr(xc), _ptr(oc), _ptr(stats), _ptr(wxw),
+              _ptr(wxb), _ptr(wow), _ptr(wob), _ptr(wv32), _ptr(gate), _ptr(lam32), _ptr(out), b, n, c, d, int(res), dt, st)
+        ctx.d, ctx.res, ctx.ks = d, int(res), ks
+        ctx.meta = [(t.shape, t.dtype) for t in (lnx_w, lnx_b, lno_w, lno_b, wq, wk, wv, lam)]
+        ctx.save_for_backward(xc, oc, wxw, wxb, wow, wob, wq32, wk32, wv32, lam32, stats, mom, gate)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        xc, oc, wxw, wxb, wow, wob, wq32, wk32, wv32, lam32, stats, mom, gate = ctx.saved_tensors
+        b, n, c = xc.shape
+        d, res, ks = ctx.d, ctx.res, ctx.ks
+        dt, dev, st = _DT[xc.dtype], xc.device, _stream()
+        if dout.dtype != xc.dtype:
+            dout = dout.to(xc.dtype)
+        dout = dout.contiguous()
+        es = xc.element_size()
+        bmom = torch.empty((b, c, L.BWD_MOMENTS), dtype=torch.float32, device=dev)
+        _call("mrla_token_stats_bwd", xc.numel() * es * 2, _ptr(dout), _ptr(xc), _ptr(stats), _ptr(wxw), _ptr(wxb),
+              _ptr(wv32), _ptr(bmom), b, n, c, dt, st)
+        dyx = torch.empty((b, c), dtype=torch.float32, device=dev)
+        dwqk_part = torch.empty((b, 2 * ks), dtype=torch.float32, device=dev)
+        L.call("mrla_light_gate_bwd", _ptr(mom), _ptr(bmom), _ptr(gate), None, None, _ptr(wq32), _ptr(wk32), ks, _ptr(dyx),
+               _ptr(dwqk_part), b, c, n - 1, d, st)
+        dxn = torch.empty((b, n, c), dtype=torch.float32, device=dev)
+        part = torch.empty((b, c * L.TOKEN_PARTIALS), dtype=torch.float32, device=dev)
+        _call("mrla_token_apply_bwd", xc.numel() * es * 3 + dxn.numel() * 4, _ptr(dout), _ptr(xc), _ptr(oc), _ptr(stats),
+              _ptr(wxw), _ptr(wxb), _ptr(wow), _ptr(wob), _ptr(wv32), _ptr(gate), _ptr(lam32), _ptr(dyx), _ptr(dxn),
+              _ptr(part), b, n, c, d, dt, st)
+        dx, do = torch.empty_like(xc), torch.empty_like(oc)
+        _call("mrla_token_ln_bwd", xc.numel() * es * 5 + dxn.numel() * 4, _ptr(dout), _ptr(xc), _ptr(oc), _ptr(dxn),
+              _ptr(stats), _ptr(wxw), _ptr(wow), _ptr(lam32), _ptr(dx), _ptr(do), b, n, c, res, dt, st)
+        sums = torch.empty((c * L.TOKEN_PARTIALS + 2 * ks,), dtype=torch.float32, device=dev)
+        L.call("mrla_reduce_rows", _ptr(part), _ptr(sums), b, c * L.TOKEN_PARTIALS, st)
+        L.call("mrla_reduce_rows", _ptr(dwqk_part), _ptr(sums[c * L.TOKEN_PARTIALS:]), b, 2 * ks, st)
+        pc = sums[:c * L.TOKEN_PARTIALS].view(c, L.TOKEN_PARTIALS)
+        dwqk = sums[c * L.TOKEN_PARTIALS:]
+        raw = (pc[:, 10], pc[:, 11], pc[:, 12], pc[:, 13], dwqk[:ks], dwqk[ks:], pc[:, :9], pc[:, 9])
+        grads = [g.reshape(shape).to(dtype) for g, (shape, dtype) in zip(raw, ctx.meta)]
+        return (dx, do, *grads, None, None, None)
+
+
+def mrla_token_light(x, o_prev, lnx_w, lnx_b, lno_w, lno_b, wq, wk, wv, lam, d, eps=1e-6, res=False):
+    return _TokenLightFn.apply(x, o_prev, lnx_w, lnx_b, lno_w, lno_b, wq, wk, wv, lam, d, eps, res)

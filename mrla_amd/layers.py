@@ -191,3 +191,39 @@ def base_block_tail(x, prev_k, prev_v, mrla, bn_mrla, drop_path):
         return out, K, V
     attn, K, V = mrla(x, prev_k, prev_v)
     return x + drop_path(torch.relu(bn_mrla(attn))), K, V
+
+
+# ======================================================================================================
+# DeiT token variant (reference: deit/deit_mrla_light.py:117-209)
+# ======================================================================================================
+class mrlal_layer(_QKVParams):
+    """MRLA-light layer with GELU on V, on a [b, c, h, w] map (deit_mrla_light.py:117-180)."""
+
+    def __init__(self, input_dim, heads=None, dim_perhead=None, k_size=None):
+        super().__init__(input_dim, heads, dim_perhead, k_size)
+
+    def forward(self, x):
+        self._check(x)
+        return F_.mrla_light(x, self.Wq.weight, self.Wk.weight, self.Wv.weight, self.dim_perhead, act_gelu=True)
+
+
+class mrlal_module(nn.Module):
+    """Token module: LayerNorm of x_t and o_{t-1}, MRLA-light (GELU) on the map tokens, + lambda_t * LN(o_{t-1}),
+    cls token passed through (deit_mrla_light.py:183-209).  `fused_residual=True` folds the block's x + (.) in."""
+
+    def __init__(self, input_dim, dim_perhead, norm_layer=None):
+        super().__init__()
+        self.dim_perhead = dim_perhead
+        self.mrla = mrlal_layer(input_dim=input_dim, dim_perhead=dim_perhead)
+        self.lambda_t = nn.Parameter(torch.randn(input_dim))
+        norm_layer = norm_layer or (lambda c: nn.LayerNorm(c, eps=1e-6))
+        self.normx = norm_layer(input_dim)
+        self.normo = norm_layer(input_dim)
+
+    def forward(self, xt, ot_1, fused_residual=False):
+        m, nx, no = self.mrla, self.normx, self.normo
+        if not (type(nx) is nn.LayerNorm and type(no) is nn.LayerNorm and nx.elementwise_affine and nx.bias is not None
+                and no.elementwise_affine and no.bias is not None and nx.eps == no.eps):
+            raise MrlaHipError("mrlal_module: the HIP path implements affine nn.LayerNorm for normx / normo")
+        return F_.mrla_token_light(xt, ot_1, nx.weight, nx.bias, no.weight, no.bias, m.Wq.weight, m.Wk.weight,
+                                   m.Wv.weight, self.lambda_t, m.dim_perhead, eps=nx.eps, res=fused_residual)

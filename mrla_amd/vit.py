@@ -1,0 +1,182 @@
+"""DeiT / ViT + MRLA-light with the reference's API surface (deit/deit_mrla_light.py:42-471): same class and
+factory names, constructor keywords and state_dict keys; attention / MLP / patch embedding are stock PyTorch,
+the MRLA term of every block (`x + mrla(x, o_prev)`, :234) is one fused HIP op."""
+import math
+from collections import OrderedDict
+from functools import partial
+
+import torch
+import torch.nn as nn
+
+from . import layers
+
+try:                                    # optional: expose the factories to timm.create_model when timm exists
+    from timm.models.registry import register_model
+except Exception:                       # pragma: no cover - timm is not installed in this image
+    def register_model(fn):
+        return fn
+
+__all__ = ["deit_mrlal_tiny_patch16_224", "deit_mrlal_small_patch16_224", "deit_mrlal_base_patch16_224"]
+
+
+def _pair(v):
+    return v if isinstance(v, tuple) else (v, v)
+
+
+class PatchEmbed(nn.Module):
+    def __init__(self, img_size=224, patch_size=16, in_chans=3, embed_dim=768, norm_layer=None):
+        super().__init__()
+        self.img_size, self.patch_size = _pair(img_size), _pair(patch_size)
+        self.grid_size = (self.img_size[0] // self.patch_size[0], self.img_size[1] // self.patch_size[1])
+        self.num_patches = self.grid_size[0] * self.grid_size[1]
+        self.proj = nn.Conv2d(in_chans, embed_dim, kernel_size=self.patch_size, stride=self.patch_size)
+        self.norm = norm_layer(embed_dim) if norm_layer else nn.Identity()
+
+    def forward(self, x):
+        B, C, H, W = x.shape
+        assert H == self.img_size[0] and W == self.img_size[1], \
+            f"Input image size ({H}*{W}) doesn't match model ({self.img_size[0]}*{self.img_size[1]})."
+        return self.norm(self.proj(x).flatten(2).transpose(1, 2))
+
+
+class Mlp(nn.Module):
+    def __init__(self, in_features, hidden_features=None, out_features=None, act_layer=nn.GELU, drop=0.0):
+        super().__init__()
+        out_features, hidden_features = out_features or in_features, hidden_features or in_features
+        d1, d2 = _pair(drop)
+        self.fc1, self.act, self.drop1 = nn.Linear(in_features, hidden_features), act_layer(), nn.Dropout(d1)
+        self.fc2, self.drop2 = nn.Linear(hidden_features, out_features), nn.Dropout(d2)
+
+    def forward(self, x):
+        return self.drop2(self.fc2(self.drop1(self.act(self.fc1(x)))))
+
+
+class Attention(nn.Module):
+    def __init__(self, dim, num_heads=8, qkv_bias=False, attn_drop=0.0, proj_drop=0.0):
+        super().__init__()
+        self.num_heads = num_heads
+        self.scale = (dim // num_heads) ** -0.5
+        self.qkv = nn.Linear(dim, dim * 3, bias=qkv_bias)
+        self.attn_drop = nn.Dropout(attn_drop)
+        self.proj = nn.Linear(dim, dim)
+        self.proj_drop = nn.Dropout(proj_drop)
+
+    def forward(self, x):
+        B, N, C = x.shape
+        q, k, v = self.qkv(x).reshape(B, N, 3, self.num_heads, C // self.num_heads).permute(2, 0, 3, 1, 4).unbind(0)
+        attn = self.attn_drop(((q @ k.transpose(-2, -1)) * self.scale).softmax(dim=-1))
+        return self.proj_drop(self.proj((attn @ v).transpose(1, 2).reshape(B, N, C)))
+
+
+class Block(nn.Module):
+    def __init__(self, dim, num_heads, dim_mrla, mlp_ratio=4.0, qkv_bias=False, drop=0.0, attn_drop=0.0, drop_path=0.0,
+                 act_layer=nn.GELU, norm_layer=partial(nn.LayerNorm, eps=1e-6)):
+        super().__init__()
+        self.norm1 = norm_layer(dim)
+        self.attn = Attention(dim, num_heads=num_heads, qkv_bias=qkv_bias, attn_drop=attn_drop, proj_drop=drop)
+        self.drop_path = layers.DropPath(drop_path) if drop_path > 0.0 else nn.Identity()
+        self.norm2 = norm_layer(dim)
+        self.mlp = Mlp(in_features=dim, hidden_features=int(dim * mlp_ratio), act_layer=act_layer, drop=drop)
+        self.mrla = layers.mrlal_module(input_dim=dim, dim_perhead=dim_mrla, norm_layer=norm_layer)
+
+    def forward(self, x):
+        ot = x
+        x = x + self.drop_path(self.attn(self.norm1(x)))
+        x = x + self.drop_path(self.mlp(self.norm2(x)))
+        return self.mrla(x, ot, fused_residual=True)            # x + mrla(x, ot), residual inside the HIP op
+
+
+def _init_vit_weights(module, name="", head_bias=0.0):
+    if isinstance(module, nn.Linear):
+        if name.startswith("head"):
+            nn.init.zeros_(module.weight)
+            nn.init.constant_(module.bias, head_bias)
+        else:
+            nn.init.trunc_normal_(module.weight, std=0.02)
+            if module.bias is not None:
+                nn.init.zeros_(module.bias)
+    elif isinstance(module, (nn.LayerNorm, nn.GroupNorm, nn.BatchNorm2d)):
+        nn.init.zeros_(module.bias)
+        nn.init.ones_(module.weight)
+
+
+class ViT_mrlal(nn.Module):
+    def __init__(self, img_size=224, patch_size=16, in_chans=3, num_classes=1000, embed_dim=768, depth=12, num_heads=12,
+                 dim_mrla=16, mlp_ratio=4.0, qkv_bias=True, representation_size=None, distilled=False, drop_rate=0.0,
+                 attn_drop_rate=0.0, drop_path_rate=0.0, embed_layer=PatchEmbed, norm_layer=None, act_layer=nn.GELU,
+                 weight_init=""):
+        super().__init__()
+        if weight_init not in ("",):
+            raise NotImplementedError("only the default ('') weight_init scheme is provided")
+        self.num_classes = num_classes
+        self.num_features = self.embed_dim = embed_dim
+        self.num_tokens = 2 if distilled else 1
+        if distilled:
+            raise NotImplementedError("distillation token: the MRLA token map needs n - 1 to be a perfect square")
+        norm_layer = norm_layer or partial(nn.LayerNorm, eps=1e-6)
+        act_layer = act_layer or nn.GELU
+        self.patch_embed = embed_layer(img_size=img_size, patch_size=patch_size, in_chans=in_chans, embed_dim=embed_dim)
+        self.cls_token = nn.Parameter(torch.zeros(1, 1, embed_dim))
+        self.dist_token = None
+        self.pos_embed = nn.Parameter(torch.zeros(1, self.patch_embed.num_patches + self.num_tokens, embed_dim))
+        self.pos_drop = nn.Dropout(p=drop_rate)
+        dpr = [v.item() for v in torch.linspace(0, drop_path_rate, depth)]
+        self.blocks = nn.Sequential(*[
+            Block(dim=embed_dim, num_heads=num_heads, dim_mrla=dim_mrla, mlp_ratio=mlp_ratio, qkv_bias=qkv_bias,
+                  drop=drop_rate, attn_drop=attn_drop_rate, drop_path=dpr[i], norm_layer=norm_layer, act_layer=act_layer)
+            for i in range(depth)])
+        self.norm = norm_layer(embed_dim)
+        if representation_size:
+            self.num_features = representation_size
+            self.pre_logits = nn.Sequential(OrderedDict([("fc", nn.Linear(embed_dim, representation_size)),
+                                                         ("act", nn.Tanh())]))
+        else:
+            self.pre_logits = nn.Identity()
+        self.head = nn.Linear(self.num_features, num_classes) if num_classes > 0 else nn.Identity()
+        self.head_dist = None
+        nn.init.trunc_normal_(self.pos_embed, std=0.02)
+        nn.init.trunc_normal_(self.cls_token, std=0.02)
+        self.apply(_init_vit_weights)
+
+    @torch.jit.ignore
+    def no_weight_decay(self):
+        return {"pos_embed", "cls_token", "dist_token"}
+
+    def get_classifier(self):
+        return self.head
+
+    def reset_classifier(self, num_classes, global_pool=""):
+        self.num_classes = num_classes
+        self.head = nn.Linear(self.embed_dim, num_classes) if num_classes > 0 else nn.Identity()
+
+    def forward_features(self, x):
+        x = self.patch_embed(x)
+        x = torch.cat((self.cls_token.expand(x.shape[0], -1, -1), x), dim=1)
+        x = self.norm(self.blocks(self.pos_drop(x + self.pos_embed)))
+        return self.pre_logits(x[:, 0])
+
+    def forward(self, x):
+        return self.head(self.forward_features(x))
+
+
+def _deit(embed_dim, num_heads, **kwargs):
+    kwargs.pop("pretrained", None)
+    model = ViT_mrlal(patch_size=16, embed_dim=embed_dim, depth=12, num_heads=num_heads, dim_mrla=16, mlp_ratio=4,
+                      qkv_bias=True, norm_layer=partial(nn.LayerNorm, eps=1e-6), **kwargs)
+    model.default_cfg = {"input_size": (3, 224, 224), "num_classes": 1000}
+    return model
+
+
+@register_model
+def deit_mrlal_tiny_patch16_224(pretrained=False, **kwargs):
+    return _deit(192, 3, **kwargs)
+
+
+@register_model
+def deit_mrlal_small_patch16_224(pretrained=False, **kwargs):
+    return _deit(384, 6, **kwargs)
+
+
+@register_model
+def deit_mrlal_base_patch16_224(pretrained=False, **kwargs):
+    return _deit(768, 12, **kwargs)

@@ -58,24 +58,17 @@ def sgd(params):
 
 
 def timed(step, steps, warmup, dist_on):
-    import torch.distributed as dist
+    from mrla_amd import distributed as D
     for _ in range(warmup):
         step()
-    if dist_on:
-        dist.barrier()
+    D.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(steps):
         step()
     torch.cuda.synchronize()
-    if dist_on:
-        dist.barrier()
-    dt = time.perf_counter() - t0
-    if dist_on:
-        t = torch.tensor([dt], dtype=torch.float64, device="cuda")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
-    return dt
+    D.barrier()
+    return D.max_over_ranks(time.perf_counter() - t0)
 
 
 def cpu_baseline(arch):
@@ -102,7 +95,8 @@ def cpu_baseline(arch):
 def eager_rocm(arch, batch, drop_path, steps=6):
     from oracle import eager_models as em
     torch.manual_seed(0)
-    net = getattr(em, "eager_" + arch)(drop_path=drop_path).cuda().train()
+    kw = {"drop_path_rate": drop_path} if arch.startswith("deit") else {"drop_path": drop_path}
+    net = getattr(em, "eager_" + arch)(**kw).cuda().train()
     x = torch.randn(batch, 3, 224, 224, device="cuda")
     y = torch.randint(0, 1000, (batch,), device="cuda")
     step = make_step(net, sgd(net.parameters()), x, y)
@@ -123,14 +117,11 @@ def eager_rocm(arch, batch, drop_path, steps=6):
 
 def main():
     args = parse()
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local = int(os.environ.get("LOCAL_RANK", "0"))
+    from mrla_amd import distributed as D
+    rank, local, world = D.env_world()
     dist_on = world > 1
     torch.cuda.set_device(local)
-    if dist_on:
-        import torch.distributed as dist
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+    D.init_from_env("nccl")
     if args.gpus != world and rank == 0:
         print(f"warning: --gpus {args.gpus} but WORLD_SIZE={world}", file=sys.stderr)
 
@@ -138,16 +129,18 @@ def main():
     torch.manual_seed(0)
     if args.eager:
         from oracle import eager_models as em
-        net = getattr(em, "eager_" + args.arch)(drop_path=args.drop_path)
+        kw = {"drop_path_rate": args.drop_path} if args.arch.startswith("deit") else {"drop_path": args.drop_path}
+        net = getattr(em, "eager_" + args.arch)(**kw)
     else:
-        from mrla_amd import models
+        from mrla_amd import models, vit
         import contextlib
         import io
         with contextlib.redirect_stdout(io.StringIO()):
-            net = getattr(models, args.arch)(drop_path=args.drop_path)
-    net = net.cuda().train()
-    if dist_on:
-        net = torch.nn.parallel.DistributedDataParallel(net, device_ids=[local], gradient_as_bucket_view=True)
+            if args.arch.startswith("deit"):
+                net = getattr(vit, args.arch)(drop_path_rate=args.drop_path)
+            else:
+                net = getattr(models, args.arch)(drop_path=args.drop_path)
+    net = D.wrap_data_parallel(net.cuda().train(), device_ids=[local])
     gx = torch.Generator(device="cuda").manual_seed(0)
     gy = torch.Generator(device="cuda").manual_seed(1)
     x = torch.randn(args.batch, 3, 224, 224, device="cuda", generator=gx)
@@ -158,7 +151,9 @@ def main():
     for _ in range(args.warmup):
         step()
     timer = Fm.KernelTimer(["mrla_light_apply_bwd", "mrla_light_stats_bwd", "mrla_light_apply_fwd",
-                            "mrla_light_stats_fwd"])
+                            "mrla_light_stats_fwd", "mrla_base_attend_fwd", "mrla_base_tail_fwd",
+                            "mrla_base_tail_stats_bwd", "mrla_base_attend_bwd", "mrla_base_value_bwd",
+                            "mrla_token_apply_fwd", "mrla_token_stats_bwd", "mrla_token_apply_bwd", "mrla_token_ln_bwd"])
     Fm.TIMER = timer
     dt = timed(step, args.steps, 0, dist_on)
     Fm.TIMER = None
@@ -166,15 +161,16 @@ def main():
 
     if rank == 0:
         ks = timer.summary()
-        dom = ks.get("mrla_light_apply_bwd")
+        dom_name = max(ks, key=lambda k: ks[k]["ms"]) if ks else None     # the MRLA kernel with the most time
+        dom = ks.get(dom_name)
         roofline = None
         if dom:
             ach = dom["bytes"] / (dom["ms"] * 1e-3) / 1e9
-            roofline = {"bound": "hbm", "kernel": "light_apply_bwd_nchw<bf16>", "achieved": round(ach, 1),
+            roofline = {"bound": "hbm", "kernel": dom_name + "<bf16>", "achieved": round(ach, 1),
                         "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": None,
                         "launches": dom["launches"], "avg_launch_us": round(1e3 * dom["ms"] / dom["launches"], 2),
                         "algorithmic_bytes_per_launch_avg": dom["bytes"] // dom["launches"]}
-        out = {"metric": "images/sec fwd+bwd resnet50_mrlal b=256", "value": round(ips, 1), "unit": "images/sec",
+        out = {"metric": f"images/sec fwd+bwd {args.arch} b={args.batch}", "value": round(ips, 1), "unit": "images/sec",
                "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(1e3 * dt / args.steps, 3),
                "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
                "config": {"workload": f"{args.arch} fwd+bwd+SGD, {args.batch} images/GPU of 3x224x224, bf16 autocast, "
@@ -189,9 +185,8 @@ def main():
             out["cpu_baseline"] = cpu_baseline(args.arch)
         print(json.dumps(out), flush=True)
     if dist_on:
-        import torch.distributed as dist
-        dist.barrier()
-        dist.destroy_process_group()
+        D.barrier()
+        torch.distributed.destroy_process_group()
 
 
 if __name__ == "__main__":

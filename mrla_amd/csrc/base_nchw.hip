@@ -175,6 +175,7 @@ __global__ __launch_bounds__(kThreads) void base_attend_fwd_nchw(
   float* as = reinterpret_cast<float*>(vs + g.astride);     // [astride] fp32 attn staging
   float* coef = as + g.astride;                             // [CP][t]
   const int tid = threadIdx.x, lane = tid & (kWave - 1), wave = tid / kWave;
+  const LaneMap lmap = make_lane_map(g, lane);
   const int c0 = blockIdx.x * g.CP;
   const int np = min(g.CP, g.C - c0);
   const int n = np * g.HW;
@@ -191,7 +192,7 @@ __global__ __launch_bounds__(kThreads) void base_attend_fwd_nchw(
     }
     __syncthreads();
     for (int task = wave; task < ntasks; task += kWaves) {
-      const LaneTask tk = make_task(g, task, np, lane);
+      const LaneTask tk = make_task(g, lmap, task, np);
       if (!tk.live) continue;
       const T* xp = xs + tk.p * g.HW;
       T* vp = vs + tk.p * g.HW;
@@ -583,6 +584,7 @@ __global__ __launch_bounds__(kThreads) void base_value_bwd_nchw(
   float* coef = dvs + g.astride;                            // [CP][nl]
   float* red = coef + g.CP * (Tc - t + 1);                  // [ntasks][PW][9]
   const int tid = threadIdx.x, lane = tid & (kWave - 1), wave = tid / kWave;
+  const LaneMap lmap = make_lane_map(g, lane);
   const int c0 = blockIdx.x * g.CP;
   const int np = min(g.CP, g.C - c0);
   const int n = np * g.HW;
@@ -613,7 +615,7 @@ __global__ __launch_bounds__(kThreads) void base_value_bwd_nchw(
 #pragma unroll
     for (int s = 0; s < TPW; ++s) {
       const int task = wave + s * kWaves;
-      const LaneTask tk = make_task(g, min(task, ntasks - 1), np, lane);
+      const LaneTask tk = make_task(g, lmap, min(task, ntasks - 1), np);
       if (task < ntasks && tk.live) {
         const int c = c0 + tk.p;
         const T* xp = xs + tk.p * g.HW;
@@ -653,12 +655,12 @@ __global__ __launch_bounds__(kThreads) void base_value_bwd_nchw(
 #pragma unroll
   for (int s = 0; s < TPW; ++s) {
     const int task = wave + s * kWaves;
-    const LaneTask tk = make_task(g, min(task, ntasks - 1), np, lane);
+    const LaneTask tk = make_task(g, lmap, min(task, ntasks - 1), np);
     if (task < ntasks && tk.live) {
 #pragma unroll
       for (int k = 0; k < 9; ++k) {
-        const float v = seg_sum(tk.valid ? wg[s][k] : 0.f, tk.col, g.W);
-        if (tk.valid && tk.col == 0) red[(task * g.PW + tk.pl) * 9 + k] = v;
+        const float v = seg_sum(tk.valid ? wg[s][k] : 0.f, lane, g.WS);
+        if (tk.last) red[(task * g.PW + tk.pl) * 9 + k] = v;
       }
     }
   }

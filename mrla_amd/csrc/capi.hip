@@ -9,17 +9,19 @@ namespace mrla {
 constexpr int kWavesPerGroup = 4;
 static int gcd_i(int a, int b) { while (b) { int t = a % b; a = b; b = t; } return a; }
 
-// LDS budget: keep a slab's staged arrays near 40 KB so >= 3-4 workgroups share a CU (the copy-in /
-// march / copy-out phases of different workgroups overlap), never above 150 KB (160 KB per CU).
+// LDS budget: `arrays` slab-sized LDS arrays per workgroup (double-buffered inputs + output staging; 8 for the
+// backward apply kernel).  Keep them near 64 KB so 2-3 workgroups share a CU, never above 150 KB (160 KB per CU).
 int make_slab_geo(SlabGeo* g, int B, int C, int H, int W, int dtype, int arrays, int bg_hint) {
   if (W > 64) return MRLA_EUNSUPPORTED;               // a plane row must fit one wave
   const int es = (int)dtype_size(dtype);
   const int HW = H * W;
-  const int soft = 40 * 1024, hard = 150 * 1024;
+  const int soft = 64 * 1024, hard = 150 * 1024;
   const int target = std::min(4096, soft / (arrays * es));
   const int max_tasks = kMaxTasksPerWave * kWavesPerGroup;
   const int maxplanes = std::max(1, std::min(C, target / HW));
-  int PW = std::max(1, std::min(64 / W, maxplanes));
+  int WS = 1;
+  while (WS < W) WS <<= 1;
+  int PW = std::max(1, std::min(64 / WS, maxplanes));
   int NGc = std::max(1, maxplanes / PW);
   if (NGc >= kWavesPerGroup) NGc -= NGc % kWavesPerGroup;     // whole rounds over the 4 waves
   NGc = std::min(NGc, max_tasks);
@@ -44,7 +46,7 @@ int make_slab_geo(SlabGeo* g, int B, int C, int H, int W, int dtype, int arrays,
     const long total = (long)B * slabs;
     BG = (int)std::max(1L, std::min(8L, total / 2048));
   }
-  *g = SlabGeo{B, C, H, W, HW, CP, slabs, PW, NG, NB, RB, BG, astride};
+  *g = SlabGeo{B, C, H, W, HW, CP, slabs, WS, PW, NG, NB, RB, BG, astride};
   return MRLA_OK;
 }
 
@@ -53,7 +55,7 @@ static bool bad_dtype(int dt) { return dt != MRLA_F32 && dt != MRLA_BF16 && dt !
 
 // One geometry for all four streaming kernels of a problem (sized for the 5-array backward pass), so
 // the wgrad partial-row count is a pure function of the shape.
-static int light_geo(SlabGeo* g, int b, int c, int h, int w, int dtype) { return make_slab_geo(g, b, c, h, w, dtype, 5, 0); }
+static int light_geo(SlabGeo* g, int b, int c, int h, int w, int dtype) { return make_slab_geo(g, b, c, h, w, dtype, 8, 0); }
 
 }  // namespace mrla
 

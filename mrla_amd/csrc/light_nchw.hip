@@ -27,56 +27,102 @@
 namespace mrla {
 
 // ------------------------------------------------------------------------------------------------
+// Workgroup pipeline shared by the four kernels.  A workgroup walks over up to BG images of its slab;
+// the input arrays of image i+1 are fetched by LDS-DMA into the other half of a double buffer while the
+// waves march over image i, so HBM latency overlaps the stencil arithmetic:
+//     wait(i) ; barrier ; prefetch(i+1) ; march(i) ; barrier ; store(i)
+// Every per-plane / per-image parameter the march needs (taps, gate, BN constants, drop-path scale) is
+// gathered ONCE per workgroup into small LDS tables, so the loop issues no vector-memory loads besides the
+// DMA prefetch: a `s_waitcnt vmcnt` for a parameter would also wait for the whole prefetch (vmcnt is in-order).
+// ------------------------------------------------------------------------------------------------
+constexpr int kPT = 12;   // floats per plane row of the parameter table (9 taps + 3 kernel-specific)
+constexpr int kIT = 4;    // floats per (image, plane) row of the per-image table
+
+__device__ __forceinline__ void load_taps(float (&w)[9], const float* __restrict__ prow) {
+#pragma unroll
+  for (int k = 0; k < 9; ++k) w[k] = prow[k];
+}
+
+#define MRLA_PIPELINE_PROLOGUE(NA_, SRC0, SRC1, SRC2)                                   \
+  const int tid = threadIdx.x, lane = tid & (kWave - 1), wave = tid / kWave;            \
+  const int c0 = blockIdx.x * g.CP;                                                     \
+  const int np = min(g.CP, g.C - c0);                                                   \
+  const int n = np * g.HW;                                                              \
+  const int ntasks = g.NG * g.NB;                                                       \
+  const int b0 = blockIdx.y * g.BG;                                                     \
+  const int b_end = min(g.B, b0 + g.BG);                                                \
+  const LaneMap lmap = make_lane_map(g, lane);                                          \
+  const int lastrow = (g.H - 1) * g.W;                                                  \
+  {                                                                                     \
+    const size_t off0 = ((size_t)b0 * g.C + c0) * g.HW;                                 \
+    slab_prefetch(buf, (SRC0) + off0, n, tid);                                          \
+    if ((NA_) > 1) slab_prefetch(buf + g.astride, (SRC1) + off0, n, tid);               \
+    if ((NA_) > 2) slab_prefetch(buf + 2 * g.astride, (SRC2) + off0, n, tid);           \
+  }
+
+#define MRLA_PIPELINE_NEXT(NA_, SRC0, SRC1, SRC2)                                       \
+  wait_async_copies();                                                                  \
+  __syncthreads();                                                                      \
+  if (b + 1 < b_end) {                                                                  \
+    const size_t off1 = ((size_t)(b + 1) * g.C + c0) * g.HW;                            \
+    T* nb = buf + (cur ^ 1) * (NA_) * g.astride;                                        \
+    slab_prefetch(nb, (SRC0) + off1, n, tid);                                           \
+    if ((NA_) > 1) slab_prefetch(nb + g.astride, (SRC1) + off1, n, tid);                \
+    if ((NA_) > 2) slab_prefetch(nb + 2 * g.astride, (SRC2) + off1, n, tid);            \
+  }
+
+// ------------------------------------------------------------------------------------------------
 // forward statistics:  mom[b, c, 0..5]
 // ------------------------------------------------------------------------------------------------
-template <typename T, bool GELU>
+template <typename T, bool GELU, bool HAS_O>
 __global__ __launch_bounds__(kThreads) void light_stats_fwd_nchw(
     const T* __restrict__ x, const T* __restrict__ o, const float* __restrict__ wv,
     float* __restrict__ mom, SlabGeo g) {
   extern __shared__ __align__(16) unsigned char smem[];
-  T* xs = reinterpret_cast<T*>(smem);
-  T* os = xs + g.astride;
-  float* red = reinterpret_cast<float*>(os + (o ? g.astride : 0));   // [ntasks][PW][M_N]
-  const int tid = threadIdx.x, lane = tid & (kWave - 1), wave = tid / kWave;
-  const int c0 = blockIdx.x * g.CP;
-  const int np = min(g.CP, g.C - c0);
-  const int n = np * g.HW;
-  const int ntasks = g.NG * g.NB;
-  const int b_end = min(g.B, (int)(blockIdx.y + 1) * g.BG);
-  for (int b = blockIdx.y * g.BG; b < b_end; ++b) {
-    const size_t off = ((size_t)b * g.C + c0) * g.HW;
-    slab_load(xs, x + off, n, tid);
-    if (o) slab_load(os, o + off, n, tid);
-    __syncthreads();
+  constexpr int NA = HAS_O ? 2 : 1;
+  T* buf = reinterpret_cast<T*>(smem);                                     // [2][NA][astride]
+  float* ptab = reinterpret_cast<float*>(buf + 2 * NA * g.astride);        // [CP][kPT]
+  float* red = ptab + g.CP * kPT;                                          // [ntasks][PW][M_N]
+  MRLA_PIPELINE_PROLOGUE(NA, x, o, o)
+  for (int i = tid; i < np * 9; i += kThreads) ptab[(i / 9) * kPT + i % 9] = wv[(size_t)c0 * 9 + i];
+  int cur = 0;
+  for (int b = b0; b < b_end; ++b, cur ^= 1) {
+    MRLA_PIPELINE_NEXT(NA, x, o, o)
+    const T* xs = buf + cur * NA * g.astride;
+    const T* os = xs + g.astride;
     for (int task = wave; task < ntasks; task += kWaves) {
-      const LaneTask t = make_task(g, task, np, lane);
+      const LaneTask t = make_task(g, lmap, task, np);
       if (!t.live) continue;
-      const T* xp = xs + t.p * g.HW;
-      const T* op = os + t.p * g.HW;
+      const T* xp = xs + t.p * g.HW + t.col;
+      const T* op = os + t.p * g.HW + t.col;
       float w[9];
-      load_w9(w, wv, c0 + t.p);
+      load_taps(w, ptab + t.p * kPT);
+      mask_conv(w, t);
       float acc[M_N] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-      Row3 ra = load_row3(xp, t.r0 - 1, g, t);
-      Row3 rb = load_row3(xp, t.r0, g, t);
-      for (int r = t.r0; r < t.r1; ++r) {
-        const Row3 rc = load_row3(xp, r + 1, g, t);
+      int idx = t.r0 * g.W;
+      Row3 ra = row_of(ld_centre_at(xp, idx - g.W, lastrow));
+      Row3 rb = row_of(ld_centre_at(xp, idx, lastrow));
+      float cn = ld_centre_at(xp, idx + g.W, lastrow);
+      for (int r = t.r0; r < t.r1; ++r, idx += g.W) {
+        const float cnn = ld_centre_at(xp, idx + 2 * g.W, lastrow);   // LDS read for the next iteration, issued early
+        const Row3 rc = row_of(cn);
         float v = conv9(w, ra, rb, rc);
         if (GELU) v = gelu_f(v);
         acc[M_SX] += rb.c;
         acc[M_SV] += v;
         acc[M_SVV] = fmaf(v, v, acc[M_SVV]);
-        if (o) {
-          const float ov = to_f(op[r * g.W + t.col]);
+        if (HAS_O) {
+          const float ov = to_f(op[idx]);
           acc[M_SO] += ov;
           acc[M_SVO] = fmaf(v, ov, acc[M_SVO]);
           acc[M_SOO] = fmaf(ov, ov, acc[M_SOO]);
         }
-        ra = rb; rb = rc;
+        ra = rb; rb = rc; cn = cnn;
       }
 #pragma unroll
       for (int k = 0; k < M_N; ++k) {
-        const float s = seg_sum(t.valid ? acc[k] : 0.f, t.col, g.W);
-        if (t.valid && t.col == 0) red[(task * g.PW + t.pl) * M_N + k] = s;
+        const float s = seg_sum(t.valid ? acc[k] : 0.f, lane, g.WS);
+        if (t.last) red[(task * g.PW + t.pl) * M_N + k] = s;
       }
     }
     __syncthreads();
@@ -87,114 +133,126 @@ __global__ __launch_bounds__(kThreads) void light_stats_fwd_nchw(
       for (int band = 0; band < g.NB; ++band) s += red[((grp * g.NB + band) * g.PW + pl) * M_N + k];
       mom[((size_t)b * g.C + c0 + p) * M_N + k] = s;
     }
-    __syncthreads();
   }
 }
 
 // ------------------------------------------------------------------------------------------------
 // forward apply:  out = res*x + A*V + B*o + C
 // ------------------------------------------------------------------------------------------------
-template <typename T, bool GELU>
+template <typename T, bool GELU, bool HAS_O>
 __global__ __launch_bounds__(kThreads) void light_apply_fwd_nchw(
     const T* __restrict__ x, const T* __restrict__ o, const float* __restrict__ wv,
     const float* __restrict__ gate /*[b,g]*/, const float* __restrict__ sc, const float* __restrict__ sh,
     const float* __restrict__ lam, const float* __restrict__ dp, T* __restrict__ out, SlabGeo g, int d, int res) {
   extern __shared__ __align__(16) unsigned char smem[];
-  T* xs = reinterpret_cast<T*>(smem);
-  T* os = xs + g.astride;          // o on input, `out` staging on output (same lane reads then writes)
-  const int tid = threadIdx.x, lane = tid & (kWave - 1), wave = tid / kWave;
-  const int c0 = blockIdx.x * g.CP;
-  const int np = min(g.CP, g.C - c0);
-  const int n = np * g.HW;
-  const int ntasks = g.NG * g.NB;
+  constexpr int NA = HAS_O ? 2 : 1;
+  T* buf = reinterpret_cast<T*>(smem);                       // [2][NA][astride] inputs
+  T* outs = buf + 2 * NA * g.astride;                        // [astride] output staging
+  float* ptab = reinterpret_cast<float*>(outs + g.astride);  // [CP][kPT]: taps
+  float* itab = ptab + g.CP * kPT;                           // [BG][CP][kIT]: A, B, C
+  MRLA_PIPELINE_PROLOGUE(NA, x, o, o)
   const int G = g.C / d;
-  const int b_end = min(g.B, (int)(blockIdx.y + 1) * g.BG);
-  for (int b = blockIdx.y * g.BG; b < b_end; ++b) {
-    const size_t off = ((size_t)b * g.C + c0) * g.HW;
-    slab_load(xs, x + off, n, tid);
-    if (o) slab_load(os, o + off, n, tid);
-    __syncthreads();
+  const float resf = res ? 1.f : 0.f;
+  for (int i = tid; i < np * 9; i += kThreads) ptab[(i / 9) * kPT + i % 9] = wv[(size_t)c0 * 9 + i];
+  for (int i = tid; i < (b_end - b0) * np; i += kThreads) {
+    const int bi = i / np, p = i - bi * np, c = c0 + p, b = b0 + bi;
     const float dpb = dp ? dp[b] : 1.f;
+    const float scale = dpb * (sc ? sc[c] : 1.f);
+    float* row = itab + ((size_t)bi * g.CP + p) * kIT;
+    row[0] = scale * gate[(size_t)b * G + c / d];
+    row[1] = HAS_O ? scale * lam[c] : 0.f;
+    row[2] = sh ? dpb * sh[c] : 0.f;
+  }
+  int cur = 0;
+  for (int b = b0; b < b_end; ++b, cur ^= 1) {
+    MRLA_PIPELINE_NEXT(NA, x, o, o)
+    const T* xs = buf + cur * NA * g.astride;
+    const T* os = xs + g.astride;
     for (int task = wave; task < ntasks; task += kWaves) {
-      const LaneTask t = make_task(g, task, np, lane);
+      const LaneTask t = make_task(g, lmap, task, np);
       if (!t.live) continue;
-      const int c = c0 + t.p;
-      const T* xp = xs + t.p * g.HW;
-      T* op = os + t.p * g.HW;
+      const T* xp = xs + t.p * g.HW + t.col;
+      const T* op = os + t.p * g.HW + t.col;
+      T* yp = outs + t.p * g.HW + t.col;
       float w[9];
-      load_w9(w, wv, c);
-      const float scale = dpb * (sc ? sc[c] : 1.f);
-      const float A = scale * gate[(size_t)b * G + c / d];
-      const float Bc = (o && lam) ? scale * lam[c] : (o ? scale : 0.f);
-      const float Cc = sh ? dpb * sh[c] : 0.f;
-      Row3 ra = load_row3(xp, t.r0 - 1, g, t);
-      Row3 rb = load_row3(xp, t.r0, g, t);
-      for (int r = t.r0; r < t.r1; ++r) {
-        const Row3 rc = load_row3(xp, r + 1, g, t);
-        float v = conv9(w, ra, rb, rc);
-        if (GELU) v = gelu_f(v);
-        float y = fmaf(A, v, Cc);
-        if (o) y = fmaf(Bc, to_f(op[r * g.W + t.col]), y);
-        if (res) y += rb.c;
-        if (t.valid) op[r * g.W + t.col] = from_f<T>(y);
-        ra = rb; rb = rc;
+      load_taps(w, ptab + t.p * kPT);
+      mask_conv(w, t);
+      const float* irow = itab + ((size_t)(b - b0) * g.CP + t.p) * kIT;
+      const float A = irow[0], Bc = irow[1], Cc = irow[2];
+      if (!GELU) {                                            // fold gate / BN scale into the taps and the
+#pragma unroll
+        for (int k = 0; k < 9; ++k) w[k] *= A;                // residual into the centre tap (with an activation
+        w[4] += resf;                                         // between conv and gate nothing can be folded)
+      }
+      int idx = t.r0 * g.W;
+      Row3 ra = row_of(ld_centre_at(xp, idx - g.W, lastrow));
+      Row3 rb = row_of(ld_centre_at(xp, idx, lastrow));
+      float cn = ld_centre_at(xp, idx + g.W, lastrow);
+      for (int r = t.r0; r < t.r1; ++r, idx += g.W) {
+        const float cnn = ld_centre_at(xp, idx + 2 * g.W, lastrow);
+        const Row3 rc = row_of(cn);
+        float y;
+        if (GELU) y = fmaf(A, gelu_f(conv9(w, ra, rb, rc)), fmaf(resf, rb.c, Cc));
+        else      y = conv9(w, ra, rb, rc) + Cc;
+        if (HAS_O) y = fmaf(Bc, to_f(op[idx]), y);
+        if (t.valid) yp[idx] = from_f<T>(y);
+        ra = rb; rb = rc; cn = cnn;
       }
     }
     __syncthreads();
-    slab_store(out + off, os, n, tid);
-    __syncthreads();
+    slab_store(out + ((size_t)b * g.C + c0) * g.HW, outs, n, tid);
   }
 }
 
 // ------------------------------------------------------------------------------------------------
 // backward statistics:  bmom[b, c, 0..2] = (sum dOut, sum dOut*V, sum dOut*o)
 // ------------------------------------------------------------------------------------------------
-template <typename T, bool GELU>
+template <typename T, bool GELU, bool HAS_O>
 __global__ __launch_bounds__(kThreads) void light_stats_bwd_nchw(
     const T* __restrict__ dout, const T* __restrict__ x, const T* __restrict__ o,
     const float* __restrict__ wv, float* __restrict__ bmom, SlabGeo g) {
   extern __shared__ __align__(16) unsigned char smem[];
-  T* xs = reinterpret_cast<T*>(smem);
-  T* gs = xs + g.astride;
-  T* os = gs + g.astride;
-  float* red = reinterpret_cast<float*>(os + (o ? g.astride : 0));
-  const int tid = threadIdx.x, lane = tid & (kWave - 1), wave = tid / kWave;
-  const int c0 = blockIdx.x * g.CP;
-  const int np = min(g.CP, g.C - c0);
-  const int n = np * g.HW;
-  const int ntasks = g.NG * g.NB;
-  const int b_end = min(g.B, (int)(blockIdx.y + 1) * g.BG);
-  for (int b = blockIdx.y * g.BG; b < b_end; ++b) {
-    const size_t off = ((size_t)b * g.C + c0) * g.HW;
-    slab_load(xs, x + off, n, tid);
-    slab_load(gs, dout + off, n, tid);
-    if (o) slab_load(os, o + off, n, tid);
-    __syncthreads();
+  constexpr int NA = HAS_O ? 3 : 2;
+  T* buf = reinterpret_cast<T*>(smem);                                     // [2][NA][astride]: x, dOut, o
+  float* ptab = reinterpret_cast<float*>(buf + 2 * NA * g.astride);        // [CP][kPT]
+  float* red = ptab + g.CP * kPT;
+  MRLA_PIPELINE_PROLOGUE(NA, x, dout, o)
+  for (int i = tid; i < np * 9; i += kThreads) ptab[(i / 9) * kPT + i % 9] = wv[(size_t)c0 * 9 + i];
+  int cur = 0;
+  for (int b = b0; b < b_end; ++b, cur ^= 1) {
+    MRLA_PIPELINE_NEXT(NA, x, dout, o)
+    const T* xs = buf + cur * NA * g.astride;
+    const T* gs = xs + g.astride;
+    const T* os = gs + g.astride;
     for (int task = wave; task < ntasks; task += kWaves) {
-      const LaneTask t = make_task(g, task, np, lane);
+      const LaneTask t = make_task(g, lmap, task, np);
       if (!t.live) continue;
-      const T* xp = xs + t.p * g.HW;
-      const T* gp = gs + t.p * g.HW;
-      const T* op = os + t.p * g.HW;
+      const T* xp = xs + t.p * g.HW + t.col;
+      const T* gp = gs + t.p * g.HW + t.col;
+      const T* op = os + t.p * g.HW + t.col;
       float w[9];
-      load_w9(w, wv, c0 + t.p);
+      load_taps(w, ptab + t.p * kPT);
+      mask_conv(w, t);
       float acc[D_N] = {0.f, 0.f, 0.f};
-      Row3 ra = load_row3(xp, t.r0 - 1, g, t);
-      Row3 rb = load_row3(xp, t.r0, g, t);
-      for (int r = t.r0; r < t.r1; ++r) {
-        const Row3 rc = load_row3(xp, r + 1, g, t);
+      int idx = t.r0 * g.W;
+      Row3 ra = row_of(ld_centre_at(xp, idx - g.W, lastrow));
+      Row3 rb = row_of(ld_centre_at(xp, idx, lastrow));
+      float cn = ld_centre_at(xp, idx + g.W, lastrow);
+      for (int r = t.r0; r < t.r1; ++r, idx += g.W) {
+        const float cnn = ld_centre_at(xp, idx + 2 * g.W, lastrow);
+        const Row3 rc = row_of(cn);
         float v = conv9(w, ra, rb, rc);
         if (GELU) v = gelu_f(v);
-        const float gv = to_f(gp[r * g.W + t.col]);
+        const float gv = to_f(gp[idx]);
         acc[D_D] += gv;
         acc[D_DV] = fmaf(gv, v, acc[D_DV]);
-        if (o) acc[D_DO] = fmaf(gv, to_f(op[r * g.W + t.col]), acc[D_DO]);
-        ra = rb; rb = rc;
+        if (HAS_O) acc[D_DO] = fmaf(gv, to_f(op[idx]), acc[D_DO]);
+        ra = rb; rb = rc; cn = cnn;
       }
 #pragma unroll
       for (int k = 0; k < D_N; ++k) {
-        const float s = seg_sum(t.valid ? acc[k] : 0.f, t.col, g.W);
-        if (t.valid && t.col == 0) red[(task * g.PW + t.pl) * D_N + k] = s;
+        const float s = seg_sum(t.valid ? acc[k] : 0.f, lane, g.WS);
+        if (t.last) red[(task * g.PW + t.pl) * D_N + k] = s;
       }
     }
     __syncthreads();
@@ -205,14 +263,13 @@ __global__ __launch_bounds__(kThreads) void light_stats_bwd_nchw(
       for (int band = 0; band < g.NB; ++band) s += red[((grp * g.NB + band) * g.PW + pl) * D_N + k];
       bmom[((size_t)b * g.C + c0 + p) * D_N + k] = s;
     }
-    __syncthreads();
   }
 }
 
 // ------------------------------------------------------------------------------------------------
 // backward apply:  dx, do, and per-(image group, channel) partial sums of dwv
 // ------------------------------------------------------------------------------------------------
-template <typename T, bool GELU, int TPW>
+template <typename T, bool GELU, bool HAS_O, int TPW>
 __global__ __launch_bounds__(kThreads) void light_apply_bwd_nchw(
     const T* __restrict__ dout, const T* __restrict__ x, const T* __restrict__ o, const float* __restrict__ wv,
     const float* __restrict__ gate /*[b,g]*/, const float* __restrict__ cb /*[c,4]: e,f,G,H or null*/,
@@ -220,19 +277,35 @@ __global__ __launch_bounds__(kThreads) void light_apply_bwd_nchw(
     T* __restrict__ dx, T* __restrict__ dprev, float* __restrict__ dwv_part /*[gridDim.y, c, 9]*/,
     SlabGeo g, int d, int res) {
   extern __shared__ __align__(16) unsigned char smem[];
-  T* xs = reinterpret_cast<T*>(smem);
-  T* gs = xs + g.astride;
-  T* dxs = gs + g.astride;
-  T* os = dxs + g.astride;
-  T* dos = os + (o ? g.astride : 0);
-  float* red = reinterpret_cast<float*>(dos + (o ? g.astride : 0));   // [ntasks][PW][9]
-  const int tid = threadIdx.x, lane = tid & (kWave - 1), wave = tid / kWave;
-  const int c0 = blockIdx.x * g.CP;
-  const int np = min(g.CP, g.C - c0);
-  const int n = np * g.HW;
-  const int ntasks = g.NG * g.NB;
+  constexpr int NA = HAS_O ? 3 : 2;
+  T* buf = reinterpret_cast<T*>(smem);                        // [2][NA][astride]: x, dOut, o
+  T* dxs = buf + 2 * NA * g.astride;                          // [astride] dx staging
+  T* dos = dxs + g.astride;                                   // [astride] do staging (HAS_O)
+  float* ptab = reinterpret_cast<float*>(dos + (HAS_O ? g.astride : 0));   // [CP][kPT]: taps, G, H, lambda
+  float* itab = ptab + g.CP * kPT;                            // [BG][CP][kIT]: E, F, a, dy
+  float* red = itab + g.BG * g.CP * kIT;                      // [ntasks][PW][9]
+  MRLA_PIPELINE_PROLOGUE(NA, x, dout, o)
   const int G = g.C / d;
-  const int b_end = min(g.B, (int)(blockIdx.y + 1) * g.BG);
+  const float resf = res ? 1.f : 0.f;
+  for (int i = tid; i < np * kPT; i += kThreads) {
+    const int p = i / kPT, k = i - p * kPT, c = c0 + p;
+    float v;
+    if (k < 9) v = wv[(size_t)c * 9 + k];
+    else if (k == 9) v = cb ? cb[c * 4 + 2] : 0.f;
+    else if (k == 10) v = cb ? cb[c * 4 + 3] : 0.f;
+    else v = (HAS_O && lam) ? lam[c] : 1.f;
+    ptab[i] = v;
+  }
+  for (int i = tid; i < (b_end - b0) * np; i += kThreads) {
+    const int bi = i / np, p = i - bi * np, c = c0 + p, b = b0 + bi;
+    const float dpb = dp ? dp[b] : 1.f;
+    const float a = gate[(size_t)b * G + c / d];
+    float* row = itab + ((size_t)bi * g.CP + p) * kIT;
+    row[0] = cb ? cb[c * 4 + 0] * dpb : dpb;
+    row[1] = cb ? cb[c * 4 + 1] * a : 0.f;
+    row[2] = a;
+    row[3] = dyx[(size_t)b * g.C + c];
+  }
   // wgrad accumulators live across the image loop; a wave revisits the same (task -> plane) mapping for
   // every image, so its TPW = ceil(ntasks / 4) task slots are kept in registers.
   float wg[TPW][9];
@@ -240,92 +313,101 @@ __global__ __launch_bounds__(kThreads) void light_apply_bwd_nchw(
   for (int s = 0; s < TPW; ++s)
 #pragma unroll
     for (int k = 0; k < 9; ++k) wg[s][k] = 0.f;
-
-  for (int b = blockIdx.y * g.BG; b < b_end; ++b) {
-    const size_t off = ((size_t)b * g.C + c0) * g.HW;
-    slab_load(xs, x + off, n, tid);
-    slab_load(gs, dout + off, n, tid);
-    if (o) slab_load(os, o + off, n, tid);
-    __syncthreads();
-    const float dpb = dp ? dp[b] : 1.f;
+  int cur = 0;
+  for (int b = b0; b < b_end; ++b, cur ^= 1) {
+    MRLA_PIPELINE_NEXT(NA, x, dout, o)
+    const T* xs = buf + cur * NA * g.astride;
+    const T* gs = xs + g.astride;
+    const T* os = gs + g.astride;
 #pragma unroll
     for (int s = 0; s < TPW; ++s) {
       const int task = wave + s * kWaves;
-      const LaneTask t = make_task(g, min(task, ntasks - 1), np, lane);
+      const LaneTask t = make_task(g, lmap, min(task, ntasks - 1), np);
       if (task < ntasks && t.live) {
-        const int c = c0 + t.p;
-        const T* xp = xs + t.p * g.HW;
-        const T* gp = gs + t.p * g.HW;
-        const T* op = os + t.p * g.HW;
-        T* dxp = dxs + t.p * g.HW;
-        T* dop = dos + t.p * g.HW;
-        float w[9];
-        load_w9(w, wv, c);
-        const float a = gate[(size_t)b * G + c / d];
-        const float lm = lam ? lam[c] : 1.f;
-        float E = dpb, F = 0.f, Gc = 0.f, Hc = 0.f;
-        if (cb) { E = cb[c * 4 + 0] * dpb; F = cb[c * 4 + 1] * a; Gc = cb[c * 4 + 2]; Hc = cb[c * 4 + 3]; }
-        const float dy = dyx[(size_t)b * g.C + c];
+        const T* xp = xs + t.p * g.HW + t.col;
+        const T* gp = gs + t.p * g.HW + t.col;
+        const T* op = os + t.p * g.HW + t.col;
+        T* dxp = dxs + t.p * g.HW + t.col;
+        T* dop = dos + t.p * g.HW + t.col;
+        float w[9], wt[9];
+        const float* prow = ptab + t.p * kPT;
+        load_taps(w, prow);
+#pragma unroll
+        for (int k = 0; k < 9; ++k) wt[k] = w[k];
+        mask_conv(w, t);
+        mask_convT(wt, t);
+        const float Gc = prow[9], Hc = prow[10], lm = prow[11];
+        const float* irow = itab + ((size_t)(b - b0) * g.CP + t.p) * kIT;
+        const float E = irow[0], F = irow[1], a = irow[2], dy = irow[3];
+        const float vmask = t.valid ? 1.f : 0.f;
+        const float aE = a * E * vmask, aF = a * F * vmask, aG = a * Gc * vmask, aH = a * Hc * vmask;   // dU = a*dm
         // march rr over [r0-1, r1]: produce dU[rr]; emit dx[rr-1] once dU[rr-2..rr] are known
-        Row3 xa = load_row3(xp, t.r0 - 2, g, t);   // x[rr-1]
-        Row3 xb = load_row3(xp, t.r0 - 1, g, t);   // x[rr]
-        Row3 ua = {0.f, 0.f, 0.f};                 // dU[rr-2]
-        Row3 ub = {0.f, 0.f, 0.f};                 // dU[rr-1]
-        float gprev = 0.f;                         // dOut[rr-1]
-        for (int rr = t.r0 - 1; rr <= t.r1; ++rr) {
-          const Row3 xc = load_row3(xp, rr + 1, g, t);
-          Row3 uc = {0.f, 0.f, 0.f};
-          float gcur = 0.f;
-          if (rr >= 0 && rr < g.H) {                         // wave-uniform
-            const float u = conv9(w, xa, xb, xc);
-            const float v = GELU ? gelu_f(u) : u;
-            gcur = to_f(gp[rr * g.W + t.col]);
-            float dm = fmaf(E, gcur, Hc);
-            dm = fmaf(F, v, dm);
-            if (o) dm = fmaf(Gc, to_f(op[rr * g.W + t.col]), dm);
-            float du = a * dm;
-            if (GELU) du *= gelu_grad_f(u);
-            if (!t.valid) du = 0.f;
-            uc.c = du;
-            if (rr >= t.r0 && rr < t.r1) {                   // wave-uniform: this band owns row rr
-              if (o && t.valid) dop[rr * g.W + t.col] = from_f<T>(lm * dm);
-              wg[s][0] = fmaf(du, xa.l, wg[s][0]); wg[s][1] = fmaf(du, xa.c, wg[s][1]); wg[s][2] = fmaf(du, xa.r, wg[s][2]);
-              wg[s][3] = fmaf(du, xb.l, wg[s][3]); wg[s][4] = fmaf(du, xb.c, wg[s][4]); wg[s][5] = fmaf(du, xb.r, wg[s][5]);
-              wg[s][6] = fmaf(du, xc.l, wg[s][6]); wg[s][7] = fmaf(du, xc.c, wg[s][7]); wg[s][8] = fmaf(du, xc.r, wg[s][8]);
+        int idx = (t.r0 - 1) * g.W;                            // element offset of row rr
+        Row3 xa = row_of(ld_centre_at(xp, idx - g.W, lastrow));   // x[rr-1]
+        Row3 xb = row_of(ld_centre_at(xp, idx, lastrow));         // x[rr]
+        float xn = ld_centre_at(xp, idx + g.W, lastrow);          // x[rr+1]
+        Row3 ua = {0.f, 0.f, 0.f};                             // dU[rr-2]
+        Row3 ub = {0.f, 0.f, 0.f};                             // dU[rr-1]
+        float gprev = 0.f;                                     // dOut[rr-1]
+        for (int rr = t.r0 - 1; rr <= t.r1; ++rr, idx += g.W) {
+          const float xnn = ld_centre_at(xp, idx + 2 * g.W, lastrow);
+          const Row3 xc = row_of(xn);
+          const bool inside = (rr >= 0) && (rr < g.H);                      // wave-uniform
+          const bool owned = (rr >= t.r0) && (rr < t.r1);                   // wave-uniform
+          const int icl = min(max(idx, 0), lastrow);
+          const float gcur = inside ? to_f(gp[icl]) : 0.f;
+          const float u = conv9(w, xa, xb, xc);
+          const float v = GELU ? gelu_f(u) : u;
+          // dm = E*dOut + F*V + G*o + H ; dU = a*dm (*gelu'(U)) ; all zero outside the plane
+          float du = fmaf(aE, gcur, aH);
+          du = fmaf(aF, v, du);
+          float ov = 0.f;
+          if (HAS_O) { ov = to_f(op[icl]); du = fmaf(aG, ov, du); }
+          if (GELU) du *= gelu_grad_f(u);
+          du = inside ? du : 0.f;
+          if (owned) {
+            if (HAS_O) {
+              float dm = fmaf(E, gcur, Hc);
+              dm = fmaf(F, v, dm);
+              dm = fmaf(Gc, ov, dm);
+              if (t.valid) dop[idx] = from_f<T>(lm * dm);
             }
+            wg[s][0] = fmaf(du, xa.l, wg[s][0]); wg[s][1] = fmaf(du, xa.c, wg[s][1]); wg[s][2] = fmaf(du, xa.r, wg[s][2]);
+            wg[s][3] = fmaf(du, xb.l, wg[s][3]); wg[s][4] = fmaf(du, xb.c, wg[s][4]); wg[s][5] = fmaf(du, xb.r, wg[s][5]);
+            wg[s][6] = fmaf(du, xc.l, wg[s][6]); wg[s][7] = fmaf(du, xc.c, wg[s][7]); wg[s][8] = fmaf(du, xc.r, wg[s][8]);
           }
-          uc.l = lane_prev(uc.c) * t.lmask;
-          uc.r = lane_next(uc.c) * t.rmask;
-          const int ro = rr - 1;                             // row whose dx is now complete
+          const Row3 uc = row_of(du);
+          const int ro = rr - 1;                                            // row whose dx is now complete
           if (ro >= t.r0 && ro < t.r1) {
             // dx[ro][w] = sum_{i,j} wv[i][j] * dU[ro-i+1][w-j+1]
-            float s9 = w[0] * uc.r;
-            s9 = fmaf(w[1], uc.c, s9); s9 = fmaf(w[2], uc.l, s9);
-            s9 = fmaf(w[3], ub.r, s9); s9 = fmaf(w[4], ub.c, s9); s9 = fmaf(w[5], ub.l, s9);
-            s9 = fmaf(w[6], ua.r, s9); s9 = fmaf(w[7], ua.c, s9); s9 = fmaf(w[8], ua.l, s9);
-            float y = s9 + dy;
-            if (res) y += gprev;
-            if (t.valid) dxp[ro * g.W + t.col] = from_f<T>(y);
+            float s9 = wt[0] * uc.r;
+            s9 = fmaf(wt[1], uc.c, s9); s9 = fmaf(wt[2], uc.l, s9);
+            s9 = fmaf(wt[3], ub.r, s9); s9 = fmaf(wt[4], ub.c, s9); s9 = fmaf(wt[5], ub.l, s9);
+            s9 = fmaf(wt[6], ua.r, s9); s9 = fmaf(wt[7], ua.c, s9); s9 = fmaf(wt[8], ua.l, s9);
+            const float y = fmaf(resf, gprev, s9 + dy);
+            if (t.valid) dxp[idx - g.W] = from_f<T>(y);
           }
-          xa = xb; xb = xc; ua = ub; ub = uc; gprev = gcur;
+          xa = xb; xb = xc; xn = xnn; ua = ub; ub = uc; gprev = gcur;
         }
       }
     }
     __syncthreads();
+    const size_t off = ((size_t)b * g.C + c0) * g.HW;
     slab_store(dx + off, dxs, n, tid);
-    if (o) slab_store(dprev + off, dos, n, tid);
-    __syncthreads();
+    if (HAS_O) slab_store(dprev + off, dos, n, tid);
   }
-  // reduce the wgrad accumulators: lanes of a plane row -> bands -> one value per (plane, tap)
+  // reduce the wgrad accumulators: lanes of a plane row -> bands -> one value per (plane, tap).
+  // (edge columns: the left/right x neighbours of an edge lane belong to another plane -> masked here)
 #pragma unroll
   for (int s = 0; s < TPW; ++s) {
     const int task = wave + s * kWaves;
-    const LaneTask t = make_task(g, min(task, ntasks - 1), np, lane);
+    const LaneTask t = make_task(g, lmap, min(task, ntasks - 1), np);
     if (task < ntasks && t.live) {
 #pragma unroll
       for (int k = 0; k < 9; ++k) {
-        const float v = seg_sum(t.valid ? wg[s][k] : 0.f, t.col, g.W);
-        if (t.valid && t.col == 0) red[(task * g.PW + t.pl) * 9 + k] = v;
+        const float m = (k % 3 == 0) ? t.lmask : ((k % 3 == 2) ? t.rmask : 1.f);
+        const float v = seg_sum(t.valid ? wg[s][k] * m : 0.f, lane, g.WS);
+        if (t.last) red[(task * g.PW + t.pl) * 9 + k] = v;
       }
     }
   }
@@ -342,32 +424,39 @@ __global__ __launch_bounds__(kThreads) void light_apply_bwd_nchw(
 // ------------------------------------------------------------------------------------------------
 // host-side launchers
 // ------------------------------------------------------------------------------------------------
+constexpr size_t kMaxLds = 150 * 1024;
+
 template <typename K>
 static hipError_t set_lds(K kernel, size_t bytes) {
   if (bytes <= 48 * 1024) return hipSuccess;
   return hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
 }
 
-#define MRLA_DISPATCH_T_ACT(DT, ACT, CALL)                                             \
-  switch (DT) {                                                                        \
-    case MRLA_F32:  if (ACT) { CALL(float, true); } else { CALL(float, false); } break;  \
-    case MRLA_BF16: if (ACT) { CALL(bf16_t, true); } else { CALL(bf16_t, false); } break; \
-    case MRLA_F16:  if (ACT) { CALL(f16_t, true); } else { CALL(f16_t, false); } break;  \
-    default: return MRLA_EINVAL;                                                       \
+#define MRLA_DISPATCH_AO(TT, ACT, HASO, CALL)                          \
+  if (ACT) { if (HASO) { CALL(TT, true, true); } else { CALL(TT, true, false); } } \
+  else     { if (HASO) { CALL(TT, false, true); } else { CALL(TT, false, false); } }
+#define MRLA_DISPATCH_T_ACT(DT, ACT, HASO, CALL)                       \
+  switch (DT) {                                                        \
+    case MRLA_F32:  MRLA_DISPATCH_AO(float, ACT, HASO, CALL) break;    \
+    case MRLA_BF16: MRLA_DISPATCH_AO(bf16_t, ACT, HASO, CALL) break;   \
+    case MRLA_F16:  MRLA_DISPATCH_AO(f16_t, ACT, HASO, CALL) break;    \
+    default: return MRLA_EINVAL;                                       \
   }
 
 int launch_light_stats_fwd_nchw(const void* x, const void* o, const float* wv, float* mom, const SlabGeo& g,
                                 int dtype, int act, hipStream_t st) {
   const size_t es = dtype_size(dtype);
-  const size_t lds = (size_t)g.astride * es * (o ? 2 : 1) + (size_t)g.NG * g.NB * g.PW * M_N * sizeof(float);
+  const size_t lds = (size_t)g.astride * es * 2 * (o ? 2 : 1) +
+                     ((size_t)g.CP * kPT + (size_t)g.NG * g.NB * g.PW * M_N) * sizeof(float);
+  if (lds > kMaxLds) return MRLA_EUNSUPPORTED;
   const dim3 grid(g.slabs, (g.B + g.BG - 1) / g.BG);
-#define CALL(T, A)                                                                                  \
+#define CALL(T, A, O)                                                                               \
   {                                                                                                 \
-    if (set_lds(light_stats_fwd_nchw<T, A>, lds) != hipSuccess) return MRLA_EHIP;                     \
-    hipLaunchKernelGGL((light_stats_fwd_nchw<T, A>), grid, dim3(kThreads), lds, st, (const T*)x,      \
+    if (set_lds(light_stats_fwd_nchw<T, A, O>, lds) != hipSuccess) return MRLA_EHIP;                  \
+    hipLaunchKernelGGL((light_stats_fwd_nchw<T, A, O>), grid, dim3(kThreads), lds, st, (const T*)x,   \
                        (const T*)o, wv, mom, g);                                                    \
   }
-  MRLA_DISPATCH_T_ACT(dtype, act, CALL)
+  MRLA_DISPATCH_T_ACT(dtype, act, o != nullptr, CALL)
 #undef CALL
   return hip_status(hipGetLastError());
 }
@@ -376,15 +465,16 @@ int launch_light_apply_fwd_nchw(const void* x, const void* o, const float* wv, c
                                 const float* sh, const float* lam, const float* dp, void* out, const SlabGeo& g,
                                 int d, int res, int dtype, int act, hipStream_t st) {
   const size_t es = dtype_size(dtype);
-  const size_t lds = (size_t)g.astride * es * 2;
+  const size_t lds = (size_t)g.astride * es * (2 * (o ? 2 : 1) + 1) + (size_t)g.CP * (kPT + g.BG * kIT) * sizeof(float);
+  if (lds > kMaxLds) return MRLA_EUNSUPPORTED;
   const dim3 grid(g.slabs, (g.B + g.BG - 1) / g.BG);
-#define CALL(T, A)                                                                                  \
+#define CALL(T, A, O)                                                                               \
   {                                                                                                 \
-    if (set_lds(light_apply_fwd_nchw<T, A>, lds) != hipSuccess) return MRLA_EHIP;                     \
-    hipLaunchKernelGGL((light_apply_fwd_nchw<T, A>), grid, dim3(kThreads), lds, st, (const T*)x,      \
+    if (set_lds(light_apply_fwd_nchw<T, A, O>, lds) != hipSuccess) return MRLA_EHIP;                  \
+    hipLaunchKernelGGL((light_apply_fwd_nchw<T, A, O>), grid, dim3(kThreads), lds, st, (const T*)x,   \
                        (const T*)o, wv, gate, sc, sh, lam, dp, (T*)out, g, d, res);                 \
   }
-  MRLA_DISPATCH_T_ACT(dtype, act, CALL)
+  MRLA_DISPATCH_T_ACT(dtype, act, o != nullptr, CALL)
 #undef CALL
   return hip_status(hipGetLastError());
 }
@@ -392,15 +482,17 @@ int launch_light_apply_fwd_nchw(const void* x, const void* o, const float* wv, c
 int launch_light_stats_bwd_nchw(const void* dout, const void* x, const void* o, const float* wv, float* bmom,
                                 const SlabGeo& g, int dtype, int act, hipStream_t st) {
   const size_t es = dtype_size(dtype);
-  const size_t lds = (size_t)g.astride * es * (o ? 3 : 2) + (size_t)g.NG * g.NB * g.PW * D_N * sizeof(float);
+  const size_t lds = (size_t)g.astride * es * 2 * (o ? 3 : 2) +
+                     ((size_t)g.CP * kPT + (size_t)g.NG * g.NB * g.PW * D_N) * sizeof(float);
+  if (lds > kMaxLds) return MRLA_EUNSUPPORTED;
   const dim3 grid(g.slabs, (g.B + g.BG - 1) / g.BG);
-#define CALL(T, A)                                                                                  \
+#define CALL(T, A, O)                                                                               \
   {                                                                                                 \
-    if (set_lds(light_stats_bwd_nchw<T, A>, lds) != hipSuccess) return MRLA_EHIP;                     \
-    hipLaunchKernelGGL((light_stats_bwd_nchw<T, A>), grid, dim3(kThreads), lds, st, (const T*)dout,   \
+    if (set_lds(light_stats_bwd_nchw<T, A, O>, lds) != hipSuccess) return MRLA_EHIP;                  \
+    hipLaunchKernelGGL((light_stats_bwd_nchw<T, A, O>), grid, dim3(kThreads), lds, st, (const T*)dout, \
                        (const T*)x, (const T*)o, wv, bmom, g);                                      \
   }
-  MRLA_DISPATCH_T_ACT(dtype, act, CALL)
+  MRLA_DISPATCH_T_ACT(dtype, act, o != nullptr, CALL)
 #undef CALL
   return hip_status(hipGetLastError());
 }
@@ -410,25 +502,28 @@ int launch_light_apply_bwd_nchw(const void* dout, const void* x, const void* o, 
                                 void* dprev, float* dwv_part, const SlabGeo& g, int d, int res, int dtype, int act,
                                 hipStream_t st) {
   const size_t es = dtype_size(dtype);
-  const size_t lds = (size_t)g.astride * es * (o ? 5 : 3) + (size_t)g.NG * g.NB * g.PW * 9 * sizeof(float);
+  const size_t lds = (size_t)g.astride * es * (2 * (o ? 3 : 2) + (o ? 2 : 1)) +
+                     ((size_t)g.CP * (kPT + g.BG * kIT) + (size_t)g.NG * g.NB * g.PW * 9) * sizeof(float);
+  if (lds > kMaxLds) return MRLA_EUNSUPPORTED;
   const dim3 grid(g.slabs, (g.B + g.BG - 1) / g.BG);
   const int tpw = (g.NG * g.NB + kWaves - 1) / kWaves;
-#define CALL_TPW(T, A, TPW)                                                                         \
+#define CALL_TPW(T, A, O, TPW)                                                                      \
   {                                                                                                 \
-    if (set_lds(light_apply_bwd_nchw<T, A, TPW>, lds) != hipSuccess) return MRLA_EHIP;                \
-    hipLaunchKernelGGL((light_apply_bwd_nchw<T, A, TPW>), grid, dim3(kThreads), lds, st,              \
+    if (set_lds(light_apply_bwd_nchw<T, A, O, TPW>, lds) != hipSuccess) return MRLA_EHIP;             \
+    hipLaunchKernelGGL((light_apply_bwd_nchw<T, A, O, TPW>), grid, dim3(kThreads), lds, st,           \
                        (const T*)dout, (const T*)x, (const T*)o, wv, gate, cb, lam, dp, dyx, (T*)dx, \
                        (T*)dprev, dwv_part, g, d, res);                                             \
   }
-#define CALL(T, A)                                                                                  \
+#define CALL(T, A, O)                                                                               \
   {                                                                                                 \
-    if (tpw <= 1) CALL_TPW(T, A, 1)                                                                 \
-    else if (tpw == 2) CALL_TPW(T, A, 2)                                                            \
-    else if (tpw <= kMaxTasksPerWave) CALL_TPW(T, A, kMaxTasksPerWave)                              \
+    if (tpw <= 1) CALL_TPW(T, A, O, 1)                                                              \
+    else if (tpw == 2) CALL_TPW(T, A, O, 2)                                                         \
+    else if (tpw <= kMaxTasksPerWave) CALL_TPW(T, A, O, kMaxTasksPerWave)                           \
     else return MRLA_EUNSUPPORTED;                                                                  \
   }
-  MRLA_DISPATCH_T_ACT(dtype, act, CALL)
+  MRLA_DISPATCH_T_ACT(dtype, act, o != nullptr, CALL)
 #undef CALL
+#undef CALL_TPW
   return hip_status(hipGetLastError());
 }
 

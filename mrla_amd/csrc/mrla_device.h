@@ -31,25 +31,44 @@ __device__ __forceinline__ float lane_next(float v) {
   return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x130, 0xf, 0xf, false));
 }
 
-// Sum over the `w` consecutive lanes [lane-col, lane-col+w) that hold one plane row; the result is
-// valid in the lane with col == 0.  All 64 lanes must call it.
-__device__ __forceinline__ float seg_sum(float v, int col, int w) {
-#pragma unroll
-  for (int off = 1; off < kWave; off <<= 1) {
-    float t = __shfl_down(v, off, kWave);
-    if (off < w && col + off < w) v += t;
+// ---- cross-lane sums with DPP (no LDS traffic, one VALU op per step) ------------------------------------------
+// row_shr:n shifts within a 16-lane row (zero fill), row_bcast:15 / :31 carry a row's last lane into the next
+// row(s); after the steps the LAST lane of every aligned power-of-two segment holds the segment's sum.
+#define MRLA_DPP_ADD(v, ctrl, row_mask, bank_mask) \
+  (v) += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), (ctrl), (row_mask), (bank_mask), true))
+
+// Sum over aligned segments of `ws` lanes (ws = 8, 16, 32 or 64; smaller segments use the generic path).
+// The result is valid in the last lane of each segment: (lane & (ws-1)) == ws-1.  All 64 lanes must call it.
+__device__ __forceinline__ float seg_sum(float v, int lane, int ws) {
+  if (ws >= 8) {
+    MRLA_DPP_ADD(v, 0x111, 0xf, 0xf);                       // row_shr:1
+    MRLA_DPP_ADD(v, 0x112, 0xf, 0xf);                       // row_shr:2
+    MRLA_DPP_ADD(v, 0x114, 0xf, 0xf);                       // row_shr:4
+    if (ws >= 16) MRLA_DPP_ADD(v, 0x118, 0xf, 0xf);         // row_shr:8
+    if (ws >= 32) MRLA_DPP_ADD(v, 0x142, 0xa, 0xf);         // row_bcast:15 -> rows 1, 3
+    if (ws >= 64) MRLA_DPP_ADD(v, 0x143, 0xc, 0xf);         // row_bcast:31 -> rows 2, 3
+    return v;
+  }
+  for (int off = 1; off < ws; off <<= 1) {                  // ws = 1, 2, 4: xor butterfly, every lane gets the sum
+    const float t = __shfl_xor(v, off, kWave);
+    v += t;
   }
   return v;
 }
 
+// Full-wave sum, returned in every lane.
 __device__ __forceinline__ float wave_sum(float v) {
-#pragma unroll
-  for (int off = kWave / 2; off > 0; off >>= 1) v += __shfl_down(v, off, kWave);
-  return v;   // valid in lane 0
+  MRLA_DPP_ADD(v, 0x111, 0xf, 0xf);
+  MRLA_DPP_ADD(v, 0x112, 0xf, 0xf);
+  MRLA_DPP_ADD(v, 0x114, 0xf, 0xf);
+  MRLA_DPP_ADD(v, 0x118, 0xf, 0xf);
+  MRLA_DPP_ADD(v, 0x142, 0xa, 0xf);
+  MRLA_DPP_ADD(v, 0x143, 0xc, 0xf);
+  return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63));
 }
 __device__ __forceinline__ double wave_sum(double v) {
 #pragma unroll
-  for (int off = kWave / 2; off > 0; off >>= 1) v += __shfl_down(v, off, kWave);
+  for (int off = kWave / 2; off > 0; off >>= 1) v += __shfl_xor(v, off, kWave);
   return v;
 }
 
@@ -75,6 +94,32 @@ __device__ __forceinline__ void slab_load(T* __restrict__ dst, const T* __restri
     for (int i = tid; i < n; i += kThreads) dst[i] = src[i];
   }
 }
+
+// Asynchronous HBM -> LDS copy of a slab with LDS-DMA (`global_load_lds_dwordx4`: 1 KiB per wave-instruction, no
+// VGPR staging).  The caller later executes wait_async_copies() + __syncthreads() before reading `dst`.
+// Falls back to the synchronous register-staged copy when the slab is not 16-byte granular / aligned.
+typedef __attribute__((address_space(3))) void* lds_void_ptr;
+
+template <typename T>
+__device__ __forceinline__ void slab_prefetch(T* __restrict__ dst, const T* __restrict__ src, int n, int tid) {
+  const int bytes = n * (int)sizeof(T);
+  if ((reinterpret_cast<uintptr_t>(src) & 15) == 0 && (bytes & 15) == 0) {
+    const int lane = tid & (kWave - 1), wave = tid / kWave;
+    const char* s = reinterpret_cast<const char*>(src);
+    char* d = reinterpret_cast<char*>(dst);
+    const int nchunks = (bytes + 1023) >> 10;
+    for (int ch = wave; ch < nchunks; ch += kWaves) {
+      const int off = (ch << 10) + (lane << 4);
+      if (off < bytes)
+        __builtin_amdgcn_global_load_lds(reinterpret_cast<const void*>(s + off),
+                                         (lds_void_ptr)(d + (ch << 10)), 16, 0, 0);
+    }
+  } else {
+    slab_load(dst, src, n, tid);
+  }
+}
+
+__device__ __forceinline__ void wait_async_copies() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
 
 // Cooperative linear copy LDS -> global.
 template <typename T>

@@ -15,7 +15,8 @@ struct SlabGeo {
   int B, C, H, W, HW;
   int CP;        // channel planes per slab (one slab = CP*HW contiguous elements of one image)
   int slabs;     // slabs per image = ceil(C / CP)
-  int PW;        // planes marched side by side by one wave = floor(64 / W)
+  int WS;        // lanes per plane row = smallest power of two >= W
+  int PW;        // planes marched side by side by one wave = 64 / WS
   int NG;        // wave groups per slab = ceil(CP / PW)
   int NB;        // row bands per plane group
   int RB;        // rows per band

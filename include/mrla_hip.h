@@ -57,6 +57,12 @@ int mrla_light_wgrad_rows(int b, int c, int h, int w, int dtype, int layout);
 int mrla_light_stats_fwd(const void* x, const void* o_prev, const float* wv /*[c,3,3]*/, float* mom,
                          int b, int c, int h, int w, int dtype, int layout, int act, void* stream);
 
+/* Fused producer form: `pre` is the block's pre-activation (bn3 output).  x_t = relu(pre + o_prev) is formed on
+ * the fly, written to x_out (it is what the apply pass and the backward read) and the moments are taken of it.
+ * Replaces `out += identity; out = self.relu(out)` (resnet_mrla_light.py:113-114) on top of the statistics pass. */
+int mrla_light_stats_fwd_fused(const void* pre, const void* o_prev, const float* wv, float* mom, void* x_out, int b,
+                               int c, int h, int w, int dtype, int layout, void* stream);
+
 /* ---- gate: a[b, g] ------------------------------------------------------------------------------
  * Replaces Wq/Wk Conv1d, the per-head einsum and the sigmoid of mrla_light_module.py:59-60,67,70. */
 int mrla_light_gate_fwd(const float* mom, const float* wq, const float* wk, int ksize, float* gate /*[b, c/d]*/,
@@ -104,11 +110,13 @@ int mrla_light_gate_bwd(const float* mom, const float* bmom, const float* gate, 
 
 /* ---- backward pass 2 of 2 ------------------------------------------------------------------------
  * dx = res*dOut + dwconv^T(a*dm*act'(U)) + dyx ;  do_prev = lam*dm ;  dwv_part[rows, c, 9] partial sums
- * of dWv over groups of images (rows = mrla_light_wgrad_rows()).  cb, lam, dp, o_prev, do_prev [opt]. */
+ * of dWv over groups of images (rows = mrla_light_wgrad_rows()).  cb, lam, dp, o_prev, do_prev [opt].
+ * relu_mask != 0 (fused producer, x_t = relu(pre + o_prev)): dx <- [x_t > 0]*dx is the gradient wrt `pre` and
+ * do_prev <- lam*dm + [x_t > 0]*dx the total gradient wrt o_prev (ReLU + shortcut-add backward folded in). */
 int mrla_light_apply_bwd(const void* dout, const void* x, const void* o_prev, const float* wv, const float* gate,
                          const float* cb, const float* lam, const float* dp, const float* dyx, void* dx,
-                         void* do_prev, float* dwv_part, int b, int c, int h, int w, int d, int res, int dtype,
-                         int layout, int act, void* stream);
+                         void* do_prev, float* dwv_part, int b, int c, int h, int w, int d, int res, int relu_mask,
+                         int dtype, int layout, int act, void* stream);
 
 /* =====================================================================================================
  * MRLA-base: softmax over the depth of a stage (resnet/models/modules/mrla_base_module.py:54-89 and the

@@ -81,7 +81,17 @@ int mrla_light_stats_fwd(const void* x, const void* o_prev, const float* wv, flo
   SlabGeo g;
   const int rc = light_geo(&g, b, c, h, w, dtype);
   if (rc != MRLA_OK) return rc;
-  return launch_light_stats_fwd_nchw(x, o_prev, wv, mom, g, dtype, act, (hipStream_t)stream);
+  return launch_light_stats_fwd_nchw(x, o_prev, wv, mom, nullptr, g, dtype, act, (hipStream_t)stream);
+}
+
+int mrla_light_stats_fwd_fused(const void* pre, const void* o_prev, const float* wv, float* mom, void* x_out, int b,
+                               int c, int h, int w, int dtype, int layout, void* stream) {
+  if (!pre || !o_prev || !wv || !mom || !x_out || bad_dims(b, c, h, w) || bad_dtype(dtype)) return MRLA_EINVAL;
+  if (layout != MRLA_NCHW) return MRLA_EUNSUPPORTED;
+  SlabGeo g;
+  const int rc = light_geo(&g, b, c, h, w, dtype);
+  if (rc != MRLA_OK) return rc;
+  return launch_light_stats_fwd_nchw(pre, o_prev, wv, mom, x_out, g, dtype, MRLA_ACT_NONE, (hipStream_t)stream);
 }
 
 int mrla_light_gate_fwd(const float* mom, const float* wq, const float* wk, int ksize, float* gate, int b, int c,
@@ -145,18 +155,19 @@ int mrla_light_gate_bwd(const float* mom, const float* bmom, const float* gate, 
 
 int mrla_light_apply_bwd(const void* dout, const void* x, const void* o_prev, const float* wv, const float* gate,
                          const float* cb, const float* lam, const float* dp, const float* dyx, void* dx,
-                         void* do_prev, float* dwv_part, int b, int c, int h, int w, int d, int res, int dtype,
-                         int layout, int act, void* stream) {
+                         void* do_prev, float* dwv_part, int b, int c, int h, int w, int d, int res, int relu_mask,
+                         int dtype, int layout, int act, void* stream) {
   if (!dout || !x || !wv || !gate || !dyx || !dx || !dwv_part || bad_dims(b, c, h, w) || bad_dtype(dtype) || d <= 0 ||
       c % d)
     return MRLA_EINVAL;
   if (o_prev && (!lam || !do_prev)) return MRLA_EINVAL;
+  if (relu_mask && (!o_prev || act != MRLA_ACT_NONE)) return MRLA_EINVAL;
   if (layout != MRLA_NCHW) return MRLA_EUNSUPPORTED;
   SlabGeo g;
   const int rc = light_geo(&g, b, c, h, w, dtype);
   if (rc != MRLA_OK) return rc;
   return launch_light_apply_bwd_nchw(dout, x, o_prev, wv, gate, cb, lam, dp, dyx, dx, do_prev, dwv_part, g, d, res,
-                                     dtype, act, (hipStream_t)stream);
+                                     relu_mask, dtype, act, (hipStream_t)stream);
 }
 
 static bool bad_ring(int T, int t) { return T <= 0 || t <= 0 || t > T; }

@@ -74,10 +74,32 @@ __device__ __forceinline__ void load_taps(float (&w)[9], const float* __restrict
 // ------------------------------------------------------------------------------------------------
 // forward statistics:  mom[b, c, 0..5]
 // ------------------------------------------------------------------------------------------------
-template <typename T, bool GELU, bool HAS_O>
+// elementwise x = relu(pre + o) on a slab held in LDS, in place over `pre` (rounded to T exactly as the eager
+// `out += identity; relu(out)` of resnet_mrla_light.py:113-114 would have materialised it)
+template <typename T>
+__device__ __forceinline__ void relu_add_inplace(T* __restrict__ xs, const T* __restrict__ os, int n, int tid) {
+  constexpr int VEC = 16 / sizeof(T);
+  typedef T VT __attribute__((ext_vector_type(VEC)));
+  const int nv = n / VEC;
+  VT* x4 = reinterpret_cast<VT*>(xs);
+  const VT* o4 = reinterpret_cast<const VT*>(os);
+  for (int i = tid; i < nv; i += kThreads) {
+    VT a = x4[i];
+    const VT b = o4[i];
+#pragma unroll
+    for (int k = 0; k < VEC; ++k) a[k] = from_f<T>(fmaxf(to_f(from_f<T>(to_f(a[k]) + to_f(b[k]))), 0.f));
+    x4[i] = a;
+  }
+  for (int i = nv * VEC + tid; i < n; i += kThreads)
+    xs[i] = from_f<T>(fmaxf(to_f(from_f<T>(to_f(xs[i]) + to_f(os[i]))), 0.f));
+}
+
+// FUSE: `x` is the pre-activation (bn3 output); the kernel forms x_t = relu(pre + o) itself, writes it to `xout`
+// (it is saved for backward and read by the apply pass) and takes the moments of that.
+template <typename T, bool GELU, bool HAS_O, bool FUSE>
 __global__ __launch_bounds__(kThreads) void light_stats_fwd_nchw(
     const T* __restrict__ x, const T* __restrict__ o, const float* __restrict__ wv,
-    float* __restrict__ mom, SlabGeo g) {
+    float* __restrict__ mom, T* __restrict__ xout, SlabGeo g) {
   extern __shared__ __align__(16) unsigned char smem[];
   constexpr int NA = HAS_O ? 2 : 1;
   T* buf = reinterpret_cast<T*>(smem);                                     // [2][NA][astride]
@@ -88,8 +110,13 @@ __global__ __launch_bounds__(kThreads) void light_stats_fwd_nchw(
   int cur = 0;
   for (int b = b0; b < b_end; ++b, cur ^= 1) {
     MRLA_PIPELINE_NEXT(NA, x, o, o)
-    const T* xs = buf + cur * NA * g.astride;
+    T* xs = buf + cur * NA * g.astride;
     const T* os = xs + g.astride;
+    if (FUSE) {
+      relu_add_inplace(xs, os, n, tid);
+      __syncthreads();
+      slab_store(xout + ((size_t)b * g.C + c0) * g.HW, xs, n, tid);
+    }
     for (int task = wave; task < ntasks; task += kWaves) {
       const LaneTask t = make_task(g, lmap, task, np);
       if (!t.live) continue;
@@ -269,7 +296,9 @@ __global__ __launch_bounds__(kThreads) void light_stats_bwd_nchw(
 // ------------------------------------------------------------------------------------------------
 // backward apply:  dx, do, and per-(image group, channel) partial sums of dwv
 // ------------------------------------------------------------------------------------------------
-template <typename T, bool GELU, bool HAS_O, int TPW>
+// RELU (fused producer): x_t = relu(pre + o_prev) was formed by the forward statistics kernel, so the gradient that
+// leaves here is dpre = [x > 0] * dx and the identity receives lam*dm + dpre (resnet_mrla_light.py:113-116 backward).
+template <typename T, bool GELU, bool HAS_O, int TPW, bool RELU>
 __global__ __launch_bounds__(kThreads) void light_apply_bwd_nchw(
     const T* __restrict__ dout, const T* __restrict__ x, const T* __restrict__ o, const float* __restrict__ wv,
     const float* __restrict__ gate /*[b,g]*/, const float* __restrict__ cb /*[c,4]: e,f,G,H or null*/,
@@ -349,6 +378,7 @@ __global__ __launch_bounds__(kThreads) void light_apply_bwd_nchw(
         Row3 ua = {0.f, 0.f, 0.f};                             // dU[rr-2]
         Row3 ub = {0.f, 0.f, 0.f};                             // dU[rr-1]
         float gprev = 0.f;                                     // dOut[rr-1]
+        float dohold = 0.f, dohold_new = 0.f;                  // lam*dm of rows rr-1 / rr (RELU only)
         for (int rr = t.r0 - 1; rr <= t.r1; ++rr, idx += g.W) {
           const float xnn = ld_centre_at(xp, idx + 2 * g.W, lastrow);
           const Row3 xc = row_of(xn);
@@ -370,7 +400,8 @@ __global__ __launch_bounds__(kThreads) void light_apply_bwd_nchw(
               float dm = fmaf(E, gcur, Hc);
               dm = fmaf(F, v, dm);
               dm = fmaf(Gc, ov, dm);
-              if (t.valid) dop[idx] = from_f<T>(lm * dm);
+              if (RELU) dohold_new = lm * dm;                 // written one iteration later, together with dpre
+              else if (t.valid) dop[idx] = from_f<T>(lm * dm);
             }
             wg[s][0] = fmaf(du, xa.l, wg[s][0]); wg[s][1] = fmaf(du, xa.c, wg[s][1]); wg[s][2] = fmaf(du, xa.r, wg[s][2]);
             wg[s][3] = fmaf(du, xb.l, wg[s][3]); wg[s][4] = fmaf(du, xb.c, wg[s][4]); wg[s][5] = fmaf(du, xb.r, wg[s][5]);
@@ -384,10 +415,14 @@ __global__ __launch_bounds__(kThreads) void light_apply_bwd_nchw(
             s9 = fmaf(wt[1], uc.c, s9); s9 = fmaf(wt[2], uc.l, s9);
             s9 = fmaf(wt[3], ub.r, s9); s9 = fmaf(wt[4], ub.c, s9); s9 = fmaf(wt[5], ub.l, s9);
             s9 = fmaf(wt[6], ua.r, s9); s9 = fmaf(wt[7], ua.c, s9); s9 = fmaf(wt[8], ua.l, s9);
-            const float y = fmaf(resf, gprev, s9 + dy);
+            float y = fmaf(resf, gprev, s9 + dy);
+            if (RELU) {
+              y = (xa.c > 0.f) ? y : 0.f;                                   // xa = x[rr-1] = x[ro] at this point
+              if (HAS_O && t.valid) dop[idx - g.W] = from_f<T>(dohold + y);
+            }
             if (t.valid) dxp[idx - g.W] = from_f<T>(y);
           }
-          xa = xb; xb = xc; xn = xnn; ua = ub; ub = uc; gprev = gcur;
+          xa = xb; xb = xc; xn = xnn; ua = ub; ub = uc; gprev = gcur; dohold = dohold_new;
         }
       }
     }
@@ -443,21 +478,27 @@ static hipError_t set_lds(K kernel, size_t bytes) {
     default: return MRLA_EINVAL;                                       \
   }
 
-int launch_light_stats_fwd_nchw(const void* x, const void* o, const float* wv, float* mom, const SlabGeo& g,
-                                int dtype, int act, hipStream_t st) {
+int launch_light_stats_fwd_nchw(const void* x, const void* o, const float* wv, float* mom, void* xout,
+                                const SlabGeo& g, int dtype, int act, hipStream_t st) {
   const size_t es = dtype_size(dtype);
   const size_t lds = (size_t)g.astride * es * 2 * (o ? 2 : 1) +
                      ((size_t)g.CP * kPT + (size_t)g.NG * g.NB * g.PW * M_N) * sizeof(float);
   if (lds > kMaxLds) return MRLA_EUNSUPPORTED;
   const dim3 grid(g.slabs, (g.B + g.BG - 1) / g.BG);
+#define CALL_F(T, A, O, F)                                                                          \
+  {                                                                                                 \
+    if (set_lds(light_stats_fwd_nchw<T, A, O, F>, lds) != hipSuccess) return MRLA_EHIP;               \
+    hipLaunchKernelGGL((light_stats_fwd_nchw<T, A, O, F>), grid, dim3(kThreads), lds, st,             \
+                       (const T*)x, (const T*)o, wv, mom, (T*)xout, g);                             \
+  }
 #define CALL(T, A, O)                                                                               \
   {                                                                                                 \
-    if (set_lds(light_stats_fwd_nchw<T, A, O>, lds) != hipSuccess) return MRLA_EHIP;                  \
-    hipLaunchKernelGGL((light_stats_fwd_nchw<T, A, O>), grid, dim3(kThreads), lds, st, (const T*)x,   \
-                       (const T*)o, wv, mom, g);                                                    \
+    if (xout) { if (O) CALL_F(T, A, true, true) else return MRLA_EINVAL; }                          \
+    else CALL_F(T, A, O, false)                                                                     \
   }
   MRLA_DISPATCH_T_ACT(dtype, act, o != nullptr, CALL)
 #undef CALL
+#undef CALL_F
   return hip_status(hipGetLastError());
 }
 
@@ -499,20 +540,25 @@ int launch_light_stats_bwd_nchw(const void* dout, const void* x, const void* o, 
 
 int launch_light_apply_bwd_nchw(const void* dout, const void* x, const void* o, const float* wv, const float* gate,
                                 const float* cb, const float* lam, const float* dp, const float* dyx, void* dx,
-                                void* dprev, float* dwv_part, const SlabGeo& g, int d, int res, int dtype, int act,
-                                hipStream_t st) {
+                                void* dprev, float* dwv_part, const SlabGeo& g, int d, int res, int relu, int dtype,
+                                int act, hipStream_t st) {
   const size_t es = dtype_size(dtype);
   const size_t lds = (size_t)g.astride * es * (2 * (o ? 3 : 2) + (o ? 2 : 1)) +
                      ((size_t)g.CP * (kPT + g.BG * kIT) + (size_t)g.NG * g.NB * g.PW * 9) * sizeof(float);
   if (lds > kMaxLds) return MRLA_EUNSUPPORTED;
   const dim3 grid(g.slabs, (g.B + g.BG - 1) / g.BG);
   const int tpw = (g.NG * g.NB + kWaves - 1) / kWaves;
-#define CALL_TPW(T, A, O, TPW)                                                                      \
+#define CALL_TR(T, A, O, TPW, R)                                                                    \
   {                                                                                                 \
-    if (set_lds(light_apply_bwd_nchw<T, A, O, TPW>, lds) != hipSuccess) return MRLA_EHIP;             \
-    hipLaunchKernelGGL((light_apply_bwd_nchw<T, A, O, TPW>), grid, dim3(kThreads), lds, st,           \
+    if (set_lds(light_apply_bwd_nchw<T, A, O, TPW, R>, lds) != hipSuccess) return MRLA_EHIP;          \
+    hipLaunchKernelGGL((light_apply_bwd_nchw<T, A, O, TPW, R>), grid, dim3(kThreads), lds, st,        \
                        (const T*)dout, (const T*)x, (const T*)o, wv, gate, cb, lam, dp, dyx, (T*)dx, \
                        (T*)dprev, dwv_part, g, d, res);                                             \
+  }
+#define CALL_TPW(T, A, O, TPW)                                                                      \
+  {                                                                                                 \
+    if (relu) { if (O && !(A)) CALL_TR(T, false, true, TPW, true) else return MRLA_EINVAL; }        \
+    else CALL_TR(T, A, O, TPW, false)                                                               \
   }
 #define CALL(T, A, O)                                                                               \
   {                                                                                                 \
@@ -524,6 +570,7 @@ int launch_light_apply_bwd_nchw(const void* dout, const void* x, const void* o, 
   MRLA_DISPATCH_T_ACT(dtype, act, o != nullptr, CALL)
 #undef CALL
 #undef CALL_TPW
+#undef CALL_TR
   return hip_status(hipGetLastError());
 }
 

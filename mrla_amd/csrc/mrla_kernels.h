@@ -31,8 +31,8 @@ inline int hip_status(hipError_t e) { return e == hipSuccess ? MRLA_OK : MRLA_EH
 // Returns MRLA_OK or MRLA_EUNSUPPORTED (plane wider than a wave / slab does not fit LDS).
 int make_slab_geo(SlabGeo* g, int B, int C, int H, int W, int dtype, int arrays, int bg_hint);
 
-int launch_light_stats_fwd_nchw(const void* x, const void* o, const float* wv, float* mom, const SlabGeo& g,
-                                int dtype, int act, hipStream_t st);
+int launch_light_stats_fwd_nchw(const void* x, const void* o, const float* wv, float* mom, void* xout,
+                                const SlabGeo& g, int dtype, int act, hipStream_t st);
 int launch_light_apply_fwd_nchw(const void* x, const void* o, const float* wv, const float* gate, const float* sc,
                                 const float* sh, const float* lam, const float* dp, void* out, const SlabGeo& g,
                                 int d, int res, int dtype, int act, hipStream_t st);
@@ -40,8 +40,8 @@ int launch_light_stats_bwd_nchw(const void* dout, const void* x, const void* o, 
                                 const SlabGeo& g, int dtype, int act, hipStream_t st);
 int launch_light_apply_bwd_nchw(const void* dout, const void* x, const void* o, const float* wv, const float* gate,
                                 const float* cb, const float* lam, const float* dp, const float* dyx, void* dx,
-                                void* dprev, float* dwv_part, const SlabGeo& g, int d, int res, int dtype, int act,
-                                hipStream_t st);
+                                void* dprev, float* dwv_part, const SlabGeo& g, int d, int res, int relu, int dtype,
+                                int act, hipStream_t st);
 
 // gate.hip -- the small per-(image, channel) kernels
 int launch_gate_fwd(const float* mom, const float* wq, const float* wk, int ks, float* gate, int B, int C, int HW,

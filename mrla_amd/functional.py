@@ -87,11 +87,13 @@ def _layout_of(x):
 
 
 class LightConfig:
-    """Static configuration of one MRLA-light call."""
-    __slots__ = ("d", "bn_mode", "momentum", "eps", "res", "act")
+    """Static configuration of one MRLA-light call.  fuse: the first tensor argument is the block's pre-activation
+    and x_t = relu(pre + o_prev) is formed inside the statistics kernel (resnet_mrla_light.py:113-114 folded in)."""
+    __slots__ = ("d", "bn_mode", "momentum", "eps", "res", "act", "fuse")
 
-    def __init__(self, d, bn_mode=L.BN_NONE, momentum=0.1, eps=1e-5, res=0, act=L.ACT_NONE):
+    def __init__(self, d, bn_mode=L.BN_NONE, momentum=0.1, eps=1e-5, res=0, act=L.ACT_NONE, fuse=False):
         self.d, self.bn_mode, self.momentum, self.eps, self.res, self.act = d, bn_mode, momentum, eps, res, act
+        self.fuse = fuse
 
 
 class _LightFn(torch.autograd.Function):
@@ -125,7 +127,15 @@ class _LightFn(torch.autograd.Function):
         st = _stream()
 
         mom = torch.empty((b, c, L.FWD_MOMENTS), dtype=torch.float32, device=dev)
-        _call("mrla_light_stats_fwd", xc.numel() * xc.element_size() * (2 if oc is not None else 1), _ptr(xc), _ptr(oc), _ptr(wv32), _ptr(mom), b, c, h, w, dt, layout, cfg.act, st)
+        if cfg.fuse:
+            if oc is None or cfg.act != L.ACT_NONE:
+                raise L.MrlaHipError("the fused relu(pre + o_prev) producer needs o_prev and no activation on V")
+            pre, xc = xc, torch.empty_like(xc)
+            _call("mrla_light_stats_fwd_fused", xc.numel() * xc.element_size() * 3, _ptr(pre), _ptr(oc), _ptr(wv32),
+                  _ptr(mom), _ptr(xc), b, c, h, w, dt, layout, st)
+        else:
+            _call("mrla_light_stats_fwd", xc.numel() * xc.element_size() * (2 if oc is not None else 1), _ptr(xc),
+                  _ptr(oc), _ptr(wv32), _ptr(mom), b, c, h, w, dt, layout, cfg.act, st)
         gate = torch.empty((b, G), dtype=torch.float32, device=dev)
         L.call("mrla_light_gate_fwd", _ptr(mom), _ptr(wq32), _ptr(wk32), ks, _ptr(gate), b, c, h * w, d, st)
         bnbuf = gamma32 = None
@@ -182,7 +192,8 @@ class _LightFn(torch.autograd.Function):
         dx = torch.empty_like(xc)
         do = torch.empty_like(oc) if oc is not None else None
         _call("mrla_light_apply_bwd", xc.numel() * xc.element_size() * (5 if oc is not None else 3), _ptr(dout), _ptr(xc), _ptr(oc), _ptr(wv32), _ptr(gate), _ptr(cb), _ptr(lam32),
-               _ptr(dp32), _ptr(dyx), _ptr(dx), _ptr(do), _ptr(dwv_part), b, c, h, w, d, cfg.res, dt, layout, cfg.act, st)
+               _ptr(dp32), _ptr(dyx), _ptr(dx), _ptr(do), _ptr(dwv_part), b, c, h, w, d, cfg.res, int(cfg.fuse), dt, layout,
+               cfg.act, st)
         wsum = torch.empty((c * 9 + 2 * ks,), dtype=torch.float32, device=dev)
         L.call("mrla_reduce_rows", _ptr(dwv_part), _ptr(wsum), rows, c * 9, st)
         L.call("mrla_reduce_rows", _ptr(dwqk_part), _ptr(wsum[c * 9:]), b, 2 * ks, st)
@@ -198,17 +209,19 @@ class _LightFn(torch.autograd.Function):
         return dx, do, dwq, dwk, dwv, dlam, dgamma, dbeta, None, None, None, None
 
 
-def mrla_light(x, wq, wk, wv, d, o_prev=None, lam=None, bn=None, dp=None, res=False, act_gelu=False):
+def mrla_light(x, wq, wk, wv, d, o_prev=None, lam=None, bn=None, dp=None, res=False, act_gelu=False,
+               pre_activation=False):
     """Functional entry point.
 
     bn: None or dict(weight, bias, running_mean, running_var, training, momentum, eps).
     dp: per-sample drop-path multiplier [b] (mask / keep_prob) or None.
+    pre_activation: `x` is the block's pre-activation; x_t = relu(x + o_prev) is formed inside the kernels.
     """
     if bn is None:
-        cfg = LightConfig(d, L.BN_NONE, res=int(res), act=L.ACT_GELU if act_gelu else L.ACT_NONE)
+        cfg = LightConfig(d, L.BN_NONE, res=int(res), act=L.ACT_GELU if act_gelu else L.ACT_NONE, fuse=pre_activation)
         return _LightFn.apply(x, o_prev, wq, wk, wv, lam, None, None, None, None, dp, cfg)
     cfg = LightConfig(d, L.BN_TRAIN if bn["training"] else L.BN_EVAL, bn.get("momentum", 0.1), bn.get("eps", 1e-5),
-                      int(res), L.ACT_GELU if act_gelu else L.ACT_NONE)
+                      int(res), L.ACT_GELU if act_gelu else L.ACT_NONE, fuse=pre_activation)
     return _LightFn.apply(x, o_prev, wq, wk, wv, lam, bn["weight"], bn["bias"], bn["running_mean"], bn["running_var"],
                           dp, cfg)
 

@@ -114,16 +114,20 @@ def _bn_args(bn):
                 momentum=momentum, eps=bn.eps)
 
 
-def light_block_tail(x, identity, mrla, bn_mrla, drop_path):
-    """x + DropPath(bn_mrla(mrla(x, identity))) -- fused into two HIP passes when bn_mrla is a BatchNorm2d."""
+def light_block_tail(x, identity, mrla, bn_mrla, drop_path, pre_activation=False):
+    """x + DropPath(bn_mrla(mrla(x, identity))) -- fused into two HIP passes when bn_mrla is a BatchNorm2d.
+    pre_activation=True: `x` is the bottleneck's bn3 output and x_t = relu(x + identity)
+    (resnet_mrla_light.py:113-114) is formed inside the first pass as well."""
     p = getattr(drop_path, "drop_prob", 0.0) or 0.0
     if type(bn_mrla) is nn.BatchNorm2d and bn_mrla.affine:
         m = mrla.mrla
         m._check(x)
         dp = drop_path_scale(x.shape[0], p, drop_path.training if isinstance(drop_path, nn.Module) else False, x.device)
         return F_.mrla_light(x, m.Wq.weight, m.Wk.weight, m.Wv.weight, m.dim_perhead, o_prev=identity,
-                             lam=mrla.lambda_t, bn=_bn_args(bn_mrla), dp=dp, res=True)
+                             lam=mrla.lambda_t, bn=_bn_args(bn_mrla), dp=dp, res=True, pre_activation=pre_activation)
     # any other norm layer the caller injected: MRLA op on the GPU, then the caller's modules as they are
+    if pre_activation:
+        x = torch.relu(x + identity)
     return x + drop_path(bn_mrla(mrla(x, identity)))
 
 

@@ -44,13 +44,18 @@ class _BottleneckTrunk(nn.Module):
         self.eca = None
         self._norm = norm_layer
 
-    def trunk(self, x):
+    def trunk_pre(self, x):
+        """Everything up to, but not including, the shortcut add + ReLU: (bn3 output, identity)."""
         identity = x
         out = self.relu(self.bn1(self.conv1(x)))
         out = self.relu(self.bn2(self.conv2(out)))
         out = self.bn3(self.conv3(out))
         if self.downsample is not None:
             identity = self.downsample(x)
+        return out, identity
+
+    def trunk(self, x):
+        out, identity = self.trunk_pre(x)
         out += identity
         return self.relu(out), identity
 
@@ -66,8 +71,8 @@ class MRLA_Bottleneck(_BottleneckTrunk):
         self.drop_path = layers.DropPath(drop_path) if drop_path > 0.0 else nn.Identity()
 
     def forward(self, x):
-        out, identity = self.trunk(x)
-        return layers.light_block_tail(out, identity, self.mrla, self.bn_mrla, self.drop_path)
+        pre, identity = self.trunk_pre(x)           # the shortcut add + ReLU run inside the first MRLA pass
+        return layers.light_block_tail(pre, identity, self.mrla, self.bn_mrla, self.drop_path, pre_activation=True)
 
 
 class MRLA_Bottleneck_base(_BottleneckTrunk):

@@ -12,6 +12,7 @@ from mrla_amd import _lib as L  # noqa: E402
 reps = int(sys.argv[1]) if len(sys.argv) > 1 else 20
 only = sys.argv[2] if len(sys.argv) > 2 else ""
 B = int(os.environ.get("B", 256))
+RELU = int(os.environ.get("RELU", 1))
 STAGES = [(256, 56), (512, 28), (1024, 14), (2048, 7)]
 dt = torch.bfloat16
 lib = L.load()
@@ -68,7 +69,8 @@ for c, hw in STAGES:
         "gate_bwd": (0, lambda: lib.mrla_light_gate_bwd(P(mom), P(bmom), P(gate), P(cb), P(dp), P(wq), P(wk), ks, P(dyx), P(dwqk),
                                                         B, c, hw * hw, d, st)),
         "apply_bwd": (5, lambda: lib.mrla_light_apply_bwd(P(g), P(x), P(o), P(wv), P(gate), P(cb), P(lam), P(dp), P(dyx), P(dx),
-                                                          P(do), P(dwv), B, c, hw, hw, d, 1, L.BF16, L.NCHW, 0, st)),
+                                                          P(do), P(dwv), B, c, hw, hw, d, 1, RELU, L.BF16, L.NCHW, 0, st)),
+        "stats_fused": (3, lambda: lib.mrla_light_stats_fwd_fused(P(g), P(o), P(wv), P(mom), P(out), B, c, hw, hw, L.BF16, L.NCHW, st)),
     }
     for name, (passes, fn) in K.items():
         if only and only not in name:

@@ -136,6 +136,41 @@ def test_light_tail_resnet50_stage_shapes(shape, dtype):
         assert relmax(got["grad/" + ours].ravel(), np.asarray(g[theirs]).ravel()) < PAR_TOL, ours
 
 
+def test_fused_relu_add_producer_fp32_and_bf16():
+    """pre-activation form: x_t = relu(pre + identity) formed inside the statistics kernel; the backward returns the
+    gradient wrt `pre` and the total gradient wrt the identity (resnet_mrla_light.py:113-116 as one op)."""
+    from mrla_amd.functional import mrla_light
+    from oracle import detgen
+    for dtype, (b, c, h, w, d) in ((torch.float32, (2, 256, 7, 5, 32)), (torch.float32, (3, 256, 56, 56, 32)),
+                                   (torch.bfloat16, (3, 512, 28, 28, 32)), (torch.bfloat16, (2, 2048, 7, 7, 32))):
+        s = detgen.seed_of(f"fuse/{c}/{h}")
+        pre, o, gup = (detgen.normalish((b, c, h, w), s + i) for i in range(3))
+        if dtype == torch.bfloat16:
+            pre, o, gup = bf16_round(pre), bf16_round(o), bf16_round(gup)
+        P = cases.block_params(c, 5)
+        pt, ot = to_dev(pre, dtype).requires_grad_(True), to_dev(o, dtype).requires_grad_(True)
+        prm = {k: to_dev(v).requires_grad_(True) for k, v in P.items() if "running" not in k}
+        rm, rv = to_dev(P["bn_mrla.running_mean"]), to_dev(P["bn_mrla.running_var"])
+        out = mrla_light(pt, prm["mrla.mrla.Wq.weight"], prm["mrla.mrla.Wk.weight"], prm["mrla.mrla.Wv.weight"], d, o_prev=ot,
+                         lam=prm["mrla.lambda_t"], bn=dict(weight=prm["bn_mrla.weight"], bias=prm["bn_mrla.bias"],
+                                                           running_mean=rm, running_var=rv, training=True), res=True,
+                         pre_activation=True)
+        out.backward(to_dev(gup, dtype))
+        x = pre.astype(np.float64) + o
+        if dtype == torch.bfloat16:
+            x = bf16_round(x).astype(np.float64)
+        x = np.maximum(x, 0)
+        want, cache, g = oracle_light(x, o, P, d, "train", None, 0.0, gup)
+        dpre = g["dx"] * (x > 0)
+        dot = g["do_prev"] + dpre
+        got = [t.detach().float().cpu().numpy() for t in (out, pt.grad, ot.grad)]
+        if dtype == torch.float32:
+            assert relmax(got[0], want) < ACT_TOL and relmax(got[1], dpre) < ACT_TOL and relmax(got[2], dot) < ACT_TOL
+        else:
+            assert_bf16_close(got[0], want, "out"); assert_bf16_close(got[1], dpre, "dpre"); assert_bf16_close(got[2], dot, "do")
+        assert relmax(prm["mrla.mrla.Wv.weight"].grad.cpu().numpy()[:, 0], g["dwv"]) < PAR_TOL
+
+
 def test_layer_only_and_module_forms():
     """mrla_light_layer (a1) and light mrla_module (a2) through the same kernels, fp32."""
     from mrla_amd.functional import mrla_light

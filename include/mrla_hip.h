@@ -213,6 +213,22 @@ int mrla_token_ln_bwd(const void* dout, const void* x, const void* o_prev, const
                       const float* lnx_w, const float* lno_w, const float* lam, void* dx, void* do_prev, int b, int n,
                       int c, int res, int dtype, void* stream);
 
+/* =====================================================================================================
+ * Fused BatchNorm2d (+ReLU) in front of the MRLA tail (reference call sites
+ * resnet/models/resnet_mrla_light.py:93-102: `bn1/relu`, `bn2/relu`, `bn3`, downsample BN, stem `bn1/relu`).
+ *   forward : mrla_bn_plane_moments -> mrla_bn_stats_fwd -> mrla_bn_act_fwd      y  = relu?(sc*x + sh)
+ *   backward: mrla_bn_plane_dmoments -> mrla_bn_stats_bwd -> mrla_bn_act_bwd     dx = e*dz + f*x + h, dz = dy*[y>0]
+ * ===================================================================================================== */
+int mrla_bn_plane_moments(const void* x, float* amom /*[b,c,2]: sum x, sum x^2*/, int b, int c, int h, int w, int dtype,
+                          int layout, void* stream);
+int mrla_bn_act_fwd(const void* x, const float* sc, const float* sh, int relu, void* y, int b, int c, int h, int w,
+                    int dtype, int layout, void* stream);
+int mrla_bn_plane_dmoments(const void* dy, const void* x, const float* sc, const float* sh, int relu,
+                           float* tmom /*[b,c,2]: sum dz, sum dz*x*/, int b, int c, int h, int w, int dtype, int layout,
+                           void* stream);
+int mrla_bn_act_bwd(const void* dy, const void* x, const float* sc, const float* sh, const float* cb /*[c,3]*/, int relu,
+                    void* dx, int b, int c, int h, int w, int dtype, int layout, void* stream);
+
 /* out[n] = sum over rows of in[rows, n] (fixed order, double accumulation). */
 int mrla_reduce_rows(const float* in, float* out, int rows, int n, void* stream);
 

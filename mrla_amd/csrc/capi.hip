@@ -321,6 +321,33 @@ int mrla_token_ln_bwd(const void* dout, const void* x, const void* o_prev, const
                              (hipStream_t)stream);
 }
 
+int mrla_bn_plane_moments(const void* x, float* amom, int b, int c, int h, int w, int dtype, int layout, void* stream) {
+  if (!x || !amom || bad_dims(b, c, h, w) || bad_dtype(dtype)) return MRLA_EINVAL;
+  if (layout != MRLA_NCHW) return MRLA_EUNSUPPORTED;
+  return launch_plane_moments(x, amom, b, c, h * w, dtype, (hipStream_t)stream);
+}
+
+int mrla_bn_act_fwd(const void* x, const float* sc, const float* sh, int relu, void* y, int b, int c, int h, int w,
+                    int dtype, int layout, void* stream) {
+  if (!x || !sc || !sh || !y || bad_dims(b, c, h, w) || bad_dtype(dtype)) return MRLA_EINVAL;
+  if (layout != MRLA_NCHW) return MRLA_EUNSUPPORTED;
+  return launch_affine_act(x, nullptr, nullptr, sc, sh, relu, y, b, c, h * w, dtype, 0, (hipStream_t)stream);
+}
+
+int mrla_bn_plane_dmoments(const void* dy, const void* x, const float* sc, const float* sh, int relu, float* tmom, int b,
+                           int c, int h, int w, int dtype, int layout, void* stream) {
+  if (!dy || !x || !sc || !sh || !tmom || bad_dims(b, c, h, w) || bad_dtype(dtype)) return MRLA_EINVAL;
+  if (layout != MRLA_NCHW) return MRLA_EUNSUPPORTED;
+  return launch_plane_dmoments(dy, x, sc, sh, relu, tmom, b, c, h * w, dtype, (hipStream_t)stream);
+}
+
+int mrla_bn_act_bwd(const void* dy, const void* x, const float* sc, const float* sh, const float* cb, int relu,
+                    void* dx, int b, int c, int h, int w, int dtype, int layout, void* stream) {
+  if (!dy || !x || !sc || !sh || !cb || !dx || bad_dims(b, c, h, w) || bad_dtype(dtype)) return MRLA_EINVAL;
+  if (layout != MRLA_NCHW) return MRLA_EUNSUPPORTED;
+  return launch_affine_act(x, dy, cb, sc, sh, relu, dx, b, c, h * w, dtype, 1, (hipStream_t)stream);
+}
+
 int mrla_reduce_rows(const float* in, float* out, int rows, int n, void* stream) {
   if (!in || !out || rows <= 0 || n <= 0) return MRLA_EINVAL;
   return launch_reduce_rows(in, out, rows, n, (hipStream_t)stream);

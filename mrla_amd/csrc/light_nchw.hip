@@ -296,9 +296,70 @@ __global__ __launch_bounds__(kThreads) void light_stats_bwd_nchw(
 // ------------------------------------------------------------------------------------------------
 // backward apply:  dx, do, and per-(image group, channel) partial sums of dwv
 // ------------------------------------------------------------------------------------------------
+// Per-task constants of the backward march.
+struct BwdConsts {
+  float w[9];      // conv taps, edge-masked       (U = conv(x))
+  float wt[9];     // conv^T taps, edge-masked     (dx = conv^T(dU))
+  float E, F, Gc, Hc;   // dm = E*dOut + F*V + Gc*o + Hc
+  float am;        // a[b,g] (0 on lanes that hold no real column): dU = am*dm
+  float lm;        // lambda: do = lm*dm
+  float dy;        // dyx[b,c]
+  float resf;      // residual flag
+};
+
+// One row step of the backward march at row `rr` (element offset idx = rr*W):
+//   C    <- x[rr+1] row (centre was preloaded in xn; xn <- centre of x[rr+2])
+//   UC   <- dU[rr]   (zero when !INSIDE; taken from dOut/o/x rows at rr)
+//   OWNED: row rr belongs to this band -> do[rr] (or its deferral), wgrad accumulation
+//   EMIT : dx[rr-1] = res*dOut[rr-1] + conv^T(dU[rr-2..rr]) + dyx   (+ ReLU mask / identity gradient when RELU)
+// Register roles rotate in the caller (A,B,C / UA,UB,UC), so no window copies are needed.
+template <typename T, bool GELU, bool HAS_O, bool RELU, bool INSIDE, bool OWNED, bool EMIT>
+__device__ __forceinline__ void bwd_row(const BwdConsts& k, const T* __restrict__ xp, const T* __restrict__ gp,
+                                        const T* __restrict__ op, T* __restrict__ dxp, T* __restrict__ dop, int idx,
+                                        int W, int lastrow, bool valid, const Row3& A, const Row3& B, Row3& C,
+                                        float& xn, const Row3& UA, const Row3& UB, Row3& UC, float& gprev,
+                                        float& dohold, float (&wg)[9]) {
+  C = row_of(xn);
+  xn = ld_centre_at(xp, idx + 2 * W, lastrow);
+  float gcur = 0.f, du = 0.f, dmo = 0.f;
+  if (INSIDE) {
+    gcur = to_f(gp[idx]);
+    const float u = conv9(k.w, A, B, C);
+    const float v = GELU ? gelu_f(u) : u;
+    float dm = fmaf(k.E, gcur, k.Hc);
+    dm = fmaf(k.F, v, dm);
+    if (HAS_O) dm = fmaf(k.Gc, to_f(op[idx]), dm);
+    du = k.am * dm;
+    if (GELU) du *= gelu_grad_f(u);
+    dmo = k.lm * dm;
+  }
+  if (OWNED) {
+    if (HAS_O && !RELU && valid) dop[idx] = from_f<T>(dmo);
+    wg[0] = fmaf(du, A.l, wg[0]); wg[1] = fmaf(du, A.c, wg[1]); wg[2] = fmaf(du, A.r, wg[2]);
+    wg[3] = fmaf(du, B.l, wg[3]); wg[4] = fmaf(du, B.c, wg[4]); wg[5] = fmaf(du, B.r, wg[5]);
+    wg[6] = fmaf(du, C.l, wg[6]); wg[7] = fmaf(du, C.c, wg[7]); wg[8] = fmaf(du, C.r, wg[8]);
+  }
+  UC = row_of(du);
+  if (EMIT) {
+    // dx[ro][w] = sum_{i,j} wv[i][j] * dU[ro-i+1][w-j+1],  ro = rr-1
+    float s9 = k.wt[0] * UC.r;
+    s9 = fmaf(k.wt[1], UC.c, s9); s9 = fmaf(k.wt[2], UC.l, s9);
+    s9 = fmaf(k.wt[3], UB.r, s9); s9 = fmaf(k.wt[4], UB.c, s9); s9 = fmaf(k.wt[5], UB.l, s9);
+    s9 = fmaf(k.wt[6], UA.r, s9); s9 = fmaf(k.wt[7], UA.c, s9); s9 = fmaf(k.wt[8], UA.l, s9);
+    float y = fmaf(k.resf, gprev, s9 + k.dy);
+    if (RELU) {
+      y = (A.c > 0.f) ? y : 0.f;                              // A = x[rr-1] = x[ro]
+      if (HAS_O && valid) dop[idx - W] = from_f<T>(dohold + y);
+    }
+    if (valid) dxp[idx - W] = from_f<T>(y);
+  }
+  gprev = gcur;
+  dohold = dmo;
+}
+
 // RELU (fused producer): x_t = relu(pre + o_prev) was formed by the forward statistics kernel, so the gradient that
 // leaves here is dpre = [x > 0] * dx and the identity receives lam*dm + dpre (resnet_mrla_light.py:113-116 backward).
-template <typename T, bool GELU, bool HAS_O, int TPW, bool RELU>
+template <typename T, bool GELU, bool HAS_O, bool RELU>
 __global__ __launch_bounds__(kThreads) void light_apply_bwd_nchw(
     const T* __restrict__ dout, const T* __restrict__ x, const T* __restrict__ o, const float* __restrict__ wv,
     const float* __restrict__ gate /*[b,g]*/, const float* __restrict__ cb /*[c,4]: e,f,G,H or null*/,
@@ -312,139 +373,113 @@ __global__ __launch_bounds__(kThreads) void light_apply_bwd_nchw(
   T* dos = dxs + g.astride;                                   // [astride] do staging (HAS_O)
   float* ptab = reinterpret_cast<float*>(dos + (HAS_O ? g.astride : 0));   // [CP][kPT]: taps, G, H, lambda
   float* itab = ptab + g.CP * kPT;                            // [BG][CP][kIT]: E, F, a, dy
-  float* red = itab + g.BG * g.CP * kIT;                      // [ntasks][PW][9]
+  float* red = itab + g.BG * g.CP * kIT;                      // [ntasks][PW][9] wgrad sums over the images
   MRLA_PIPELINE_PROLOGUE(NA, x, dout, o)
-  const int G = g.C / d;
-  const float resf = res ? 1.f : 0.f;
-  for (int i = tid; i < np * kPT; i += kThreads) {
-    const int p = i / kPT, k = i - p * kPT, c = c0 + p;
-    float v;
-    if (k < 9) v = wv[(size_t)c * 9 + k];
-    else if (k == 9) v = cb ? cb[c * 4 + 2] : 0.f;
-    else if (k == 10) v = cb ? cb[c * 4 + 3] : 0.f;
-    else v = (HAS_O && lam) ? lam[c] : 1.f;
-    ptab[i] = v;
+  {
+    const int G = g.C / d;
+    for (int i = tid; i < np * kPT; i += kThreads) {
+      const int p = i / kPT, k = i - p * kPT, c = c0 + p;
+      float v;
+      if (k < 9) v = wv[(size_t)c * 9 + k];
+      else if (k == 9) v = cb ? cb[c * 4 + 2] : 0.f;
+      else if (k == 10) v = cb ? cb[c * 4 + 3] : 0.f;
+      else v = (HAS_O && lam) ? lam[c] : 1.f;
+      ptab[i] = v;
+    }
+    for (int i = tid; i < (b_end - b0) * np; i += kThreads) {
+      const int bi = i / np, p = i - bi * np, c = c0 + p, b = b0 + bi;
+      const float dpb = dp ? dp[b] : 1.f;
+      const float a = gate[(size_t)b * G + c / d];
+      float* row = itab + ((size_t)bi * g.CP + p) * kIT;
+      row[0] = cb ? cb[c * 4 + 0] * dpb : dpb;
+      row[1] = cb ? cb[c * 4 + 1] * a : 0.f;
+      row[2] = a;
+      row[3] = dyx[(size_t)b * g.C + c];
+    }
+    for (int i = tid; i < ntasks * g.PW * 9; i += kThreads) red[i] = 0.f;
   }
-  for (int i = tid; i < (b_end - b0) * np; i += kThreads) {
-    const int bi = i / np, p = i - bi * np, c = c0 + p, b = b0 + bi;
-    const float dpb = dp ? dp[b] : 1.f;
-    const float a = gate[(size_t)b * G + c / d];
-    float* row = itab + ((size_t)bi * g.CP + p) * kIT;
-    row[0] = cb ? cb[c * 4 + 0] * dpb : dpb;
-    row[1] = cb ? cb[c * 4 + 1] * a : 0.f;
-    row[2] = a;
-    row[3] = dyx[(size_t)b * g.C + c];
-  }
-  // wgrad accumulators live across the image loop; a wave revisits the same (task -> plane) mapping for
-  // every image, so its TPW = ceil(ntasks / 4) task slots are kept in registers.
-  float wg[TPW][9];
-#pragma unroll
-  for (int s = 0; s < TPW; ++s)
-#pragma unroll
-    for (int k = 0; k < 9; ++k) wg[s][k] = 0.f;
+  const int W = g.W;
   int cur = 0;
   for (int b = b0; b < b_end; ++b, cur ^= 1) {
     MRLA_PIPELINE_NEXT(NA, x, dout, o)
     const T* xs = buf + cur * NA * g.astride;
     const T* gs = xs + g.astride;
     const T* os = gs + g.astride;
+    for (int task = wave; task < ntasks; task += kWaves) {
+      const LaneTask t = make_task(g, lmap, task, np);
+      if (!t.live) continue;
+      const T* xp = xs + t.p * g.HW + t.col;
+      const T* gp = gs + t.p * g.HW + t.col;
+      const T* op = os + t.p * g.HW + t.col;
+      T* dxp = dxs + t.p * g.HW + t.col;
+      T* dop = dos + t.p * g.HW + t.col;
+      BwdConsts k;
+      const float* prow = ptab + t.p * kPT;
+      load_taps(k.w, prow);
 #pragma unroll
-    for (int s = 0; s < TPW; ++s) {
-      const int task = wave + s * kWaves;
-      const LaneTask t = make_task(g, lmap, min(task, ntasks - 1), np);
-      if (task < ntasks && t.live) {
-        const T* xp = xs + t.p * g.HW + t.col;
-        const T* gp = gs + t.p * g.HW + t.col;
-        const T* op = os + t.p * g.HW + t.col;
-        T* dxp = dxs + t.p * g.HW + t.col;
-        T* dop = dos + t.p * g.HW + t.col;
-        float w[9], wt[9];
-        const float* prow = ptab + t.p * kPT;
-        load_taps(w, prow);
-#pragma unroll
-        for (int k = 0; k < 9; ++k) wt[k] = w[k];
-        mask_conv(w, t);
-        mask_convT(wt, t);
-        const float Gc = prow[9], Hc = prow[10], lm = prow[11];
-        const float* irow = itab + ((size_t)(b - b0) * g.CP + t.p) * kIT;
-        const float E = irow[0], F = irow[1], a = irow[2], dy = irow[3];
-        const float vmask = t.valid ? 1.f : 0.f;
-        const float aE = a * E * vmask, aF = a * F * vmask, aG = a * Gc * vmask, aH = a * Hc * vmask;   // dU = a*dm
-        // march rr over [r0-1, r1]: produce dU[rr]; emit dx[rr-1] once dU[rr-2..rr] are known
-        int idx = (t.r0 - 1) * g.W;                            // element offset of row rr
-        Row3 xa = row_of(ld_centre_at(xp, idx - g.W, lastrow));   // x[rr-1]
-        Row3 xb = row_of(ld_centre_at(xp, idx, lastrow));         // x[rr]
-        float xn = ld_centre_at(xp, idx + g.W, lastrow);          // x[rr+1]
-        Row3 ua = {0.f, 0.f, 0.f};                             // dU[rr-2]
-        Row3 ub = {0.f, 0.f, 0.f};                             // dU[rr-1]
-        float gprev = 0.f;                                     // dOut[rr-1]
-        float dohold = 0.f, dohold_new = 0.f;                  // lam*dm of rows rr-1 / rr (RELU only)
-        for (int rr = t.r0 - 1; rr <= t.r1; ++rr, idx += g.W) {
-          const float xnn = ld_centre_at(xp, idx + 2 * g.W, lastrow);
-          const Row3 xc = row_of(xn);
-          const bool inside = (rr >= 0) && (rr < g.H);                      // wave-uniform
-          const bool owned = (rr >= t.r0) && (rr < t.r1);                   // wave-uniform
-          const int icl = min(max(idx, 0), lastrow);
-          const float gcur = inside ? to_f(gp[icl]) : 0.f;
-          const float u = conv9(w, xa, xb, xc);
-          const float v = GELU ? gelu_f(u) : u;
-          // dm = E*dOut + F*V + G*o + H ; dU = a*dm (*gelu'(U)) ; all zero outside the plane
-          float du = fmaf(aE, gcur, aH);
-          du = fmaf(aF, v, du);
-          float ov = 0.f;
-          if (HAS_O) { ov = to_f(op[icl]); du = fmaf(aG, ov, du); }
-          if (GELU) du *= gelu_grad_f(u);
-          du = inside ? du : 0.f;
-          if (owned) {
-            if (HAS_O) {
-              float dm = fmaf(E, gcur, Hc);
-              dm = fmaf(F, v, dm);
-              dm = fmaf(Gc, ov, dm);
-              if (RELU) dohold_new = lm * dm;                 // written one iteration later, together with dpre
-              else if (t.valid) dop[idx] = from_f<T>(lm * dm);
-            }
-            wg[s][0] = fmaf(du, xa.l, wg[s][0]); wg[s][1] = fmaf(du, xa.c, wg[s][1]); wg[s][2] = fmaf(du, xa.r, wg[s][2]);
-            wg[s][3] = fmaf(du, xb.l, wg[s][3]); wg[s][4] = fmaf(du, xb.c, wg[s][4]); wg[s][5] = fmaf(du, xb.r, wg[s][5]);
-            wg[s][6] = fmaf(du, xc.l, wg[s][6]); wg[s][7] = fmaf(du, xc.c, wg[s][7]); wg[s][8] = fmaf(du, xc.r, wg[s][8]);
-          }
-          const Row3 uc = row_of(du);
-          const int ro = rr - 1;                                            // row whose dx is now complete
-          if (ro >= t.r0 && ro < t.r1) {
-            // dx[ro][w] = sum_{i,j} wv[i][j] * dU[ro-i+1][w-j+1]
-            float s9 = wt[0] * uc.r;
-            s9 = fmaf(wt[1], uc.c, s9); s9 = fmaf(wt[2], uc.l, s9);
-            s9 = fmaf(wt[3], ub.r, s9); s9 = fmaf(wt[4], ub.c, s9); s9 = fmaf(wt[5], ub.l, s9);
-            s9 = fmaf(wt[6], ua.r, s9); s9 = fmaf(wt[7], ua.c, s9); s9 = fmaf(wt[8], ua.l, s9);
-            float y = fmaf(resf, gprev, s9 + dy);
-            if (RELU) {
-              y = (xa.c > 0.f) ? y : 0.f;                                   // xa = x[rr-1] = x[ro] at this point
-              if (HAS_O && t.valid) dop[idx - g.W] = from_f<T>(dohold + y);
-            }
-            if (t.valid) dxp[idx - g.W] = from_f<T>(y);
-          }
-          xa = xb; xb = xc; xn = xnn; ua = ub; ub = uc; gprev = gcur; dohold = dohold_new;
+      for (int i = 0; i < 9; ++i) k.wt[i] = k.w[i];
+      mask_conv(k.w, t);
+      mask_convT(k.wt, t);
+      k.Gc = prow[9]; k.Hc = prow[10]; k.lm = prow[11];
+      const float* irow = itab + ((size_t)(b - b0) * g.CP + t.p) * kIT;
+      k.E = irow[0]; k.F = irow[1]; k.am = t.valid ? irow[2] : 0.f; k.dy = irow[3];
+      k.resf = res ? 1.f : 0.f;
+      float wg[9] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+      const bool valid = t.valid;
+      // window state before the step at row rr:  xa = x[rr-1], xb = x[rr], xn = centre of x[rr+1],
+      //                                          ua = dU[rr-2], ub = dU[rr-1]
+      int rr = t.r0 - 1;
+      int idx = rr * W;
+      Row3 xa = row_of(ld_centre_at(xp, idx - W, lastrow));
+      Row3 xb = row_of(ld_centre_at(xp, idx, lastrow));
+      Row3 xc;
+      float xn = ld_centre_at(xp, idx + W, lastrow);
+      Row3 ua = {0.f, 0.f, 0.f}, ub = {0.f, 0.f, 0.f}, uc;
+      float gprev = 0.f, dohold = 0.f;
+#define MRLA_BWD_STEP(INS, OWN, EMI, A, B, C, UA, UB, UC)                                                            \
+  bwd_row<T, GELU, HAS_O, RELU, INS, OWN, EMI>(k, xp, gp, op, dxp, dop, idx, W, lastrow, valid, A, B, C, xn, UA, UB, \
+                                               UC, gprev, dohold, wg);                                               \
+  ++rr; idx += W;
+      // halo row above the band: dU[r0-1] only (zero above the plane)
+      if (rr >= 0) { MRLA_BWD_STEP(true, false, false, xa, xb, xc, ua, ub, uc) }
+      else         { MRLA_BWD_STEP(false, false, false, xa, xb, xc, ua, ub, uc) }
+      // first owned row: nothing to emit yet        (roles rotated once: x = (xb, xc, xa), u = (ub, uc, ua))
+      MRLA_BWD_STEP(true, true, false, xb, xc, xa, ub, uc, ua)
+      // steady state, three rows per trip so the register roles return to (xc, xa, xb) / (uc, ua, ub)
+      while (rr + 2 < t.r1) {
+        MRLA_BWD_STEP(true, true, true, xc, xa, xb, uc, ua, ub)
+        MRLA_BWD_STEP(true, true, true, xa, xb, xc, ua, ub, uc)
+        MRLA_BWD_STEP(true, true, true, xb, xc, xa, ub, uc, ua)
+      }
+      const bool below = t.r1 < g.H;                          // is the halo row under the band inside the plane?
+      if (rr < t.r1) {
+        MRLA_BWD_STEP(true, true, true, xc, xa, xb, uc, ua, ub)
+        if (rr < t.r1) {
+          MRLA_BWD_STEP(true, true, true, xa, xb, xc, ua, ub, uc)
+          if (below) { MRLA_BWD_STEP(true, false, true, xb, xc, xa, ub, uc, ua) }
+          else       { MRLA_BWD_STEP(false, false, true, xb, xc, xa, ub, uc, ua) }
+        } else {
+          if (below) { MRLA_BWD_STEP(true, false, true, xa, xb, xc, ua, ub, uc) }
+          else       { MRLA_BWD_STEP(false, false, true, xa, xb, xc, ua, ub, uc) }
         }
+      } else {
+        if (below) { MRLA_BWD_STEP(true, false, true, xc, xa, xb, uc, ua, ub) }
+        else       { MRLA_BWD_STEP(false, false, true, xc, xa, xb, uc, ua, ub) }
+      }
+#undef MRLA_BWD_STEP
+      // fold this image's wgrad contribution into the per-(task, plane) sums
+      // (edge columns: the left/right x neighbours of an edge lane belong to another plane -> masked here)
+#pragma unroll
+      for (int i = 0; i < 9; ++i) {
+        const float m = (i % 3 == 0) ? t.lmask : ((i % 3 == 2) ? t.rmask : 1.f);
+        const float v = seg_sum(valid ? wg[i] * m : 0.f, lane, g.WS);
+        if (t.last) red[(task * g.PW + t.pl) * 9 + i] += v;
       }
     }
     __syncthreads();
     const size_t off = ((size_t)b * g.C + c0) * g.HW;
     slab_store(dx + off, dxs, n, tid);
     if (HAS_O) slab_store(dprev + off, dos, n, tid);
-  }
-  // reduce the wgrad accumulators: lanes of a plane row -> bands -> one value per (plane, tap).
-  // (edge columns: the left/right x neighbours of an edge lane belong to another plane -> masked here)
-#pragma unroll
-  for (int s = 0; s < TPW; ++s) {
-    const int task = wave + s * kWaves;
-    const LaneTask t = make_task(g, lmap, min(task, ntasks - 1), np);
-    if (task < ntasks && t.live) {
-#pragma unroll
-      for (int k = 0; k < 9; ++k) {
-        const float m = (k % 3 == 0) ? t.lmask : ((k % 3 == 2) ? t.rmask : 1.f);
-        const float v = seg_sum(t.valid ? wg[s][k] * m : 0.f, lane, g.WS);
-        if (t.last) red[(task * g.PW + t.pl) * 9 + k] = v;
-      }
-    }
   }
   __syncthreads();
   for (int idx = tid; idx < np * 9; idx += kThreads) {
@@ -547,29 +582,20 @@ int launch_light_apply_bwd_nchw(const void* dout, const void* x, const void* o, 
                      ((size_t)g.CP * (kPT + g.BG * kIT) + (size_t)g.NG * g.NB * g.PW * 9) * sizeof(float);
   if (lds > kMaxLds) return MRLA_EUNSUPPORTED;
   const dim3 grid(g.slabs, (g.B + g.BG - 1) / g.BG);
-  const int tpw = (g.NG * g.NB + kWaves - 1) / kWaves;
-#define CALL_TR(T, A, O, TPW, R)                                                                    \
+#define CALL_TR(T, A, O, R)                                                                         \
   {                                                                                                 \
-    if (set_lds(light_apply_bwd_nchw<T, A, O, TPW, R>, lds) != hipSuccess) return MRLA_EHIP;          \
-    hipLaunchKernelGGL((light_apply_bwd_nchw<T, A, O, TPW, R>), grid, dim3(kThreads), lds, st,        \
+    if (set_lds(light_apply_bwd_nchw<T, A, O, R>, lds) != hipSuccess) return MRLA_EHIP;               \
+    hipLaunchKernelGGL((light_apply_bwd_nchw<T, A, O, R>), grid, dim3(kThreads), lds, st,             \
                        (const T*)dout, (const T*)x, (const T*)o, wv, gate, cb, lam, dp, dyx, (T*)dx, \
                        (T*)dprev, dwv_part, g, d, res);                                             \
   }
-#define CALL_TPW(T, A, O, TPW)                                                                      \
-  {                                                                                                 \
-    if (relu) { if (O && !(A)) CALL_TR(T, false, true, TPW, true) else return MRLA_EINVAL; }        \
-    else CALL_TR(T, A, O, TPW, false)                                                               \
-  }
 #define CALL(T, A, O)                                                                               \
   {                                                                                                 \
-    if (tpw <= 1) CALL_TPW(T, A, O, 1)                                                              \
-    else if (tpw == 2) CALL_TPW(T, A, O, 2)                                                         \
-    else if (tpw <= kMaxTasksPerWave) CALL_TPW(T, A, O, kMaxTasksPerWave)                           \
-    else return MRLA_EUNSUPPORTED;                                                                  \
+    if (relu) { if (O && !(A)) CALL_TR(T, false, true, true) else return MRLA_EINVAL; }             \
+    else CALL_TR(T, A, O, false)                                                                    \
   }
   MRLA_DISPATCH_T_ACT(dtype, act, o != nullptr, CALL)
 #undef CALL
-#undef CALL_TPW
 #undef CALL_TR
   return hip_status(hipGetLastError());
 }

@@ -99,4 +99,12 @@ int launch_token_ln_bwd(const void* dout, const void* x, const void* o, const fl
                         const float* wx, const float* wo, const float* lam, void* dx, void* dprev, int B, int n, int C,
                         int res, int dtype, hipStream_t st);
 
+
+// bnact_nchw.hip -- fused BatchNorm2d (+ReLU) passes
+int launch_plane_moments(const void* x, float* amom, int B, int C, int HW, int dtype, hipStream_t st);
+int launch_plane_dmoments(const void* dy, const void* x, const float* sc, const float* sh, int relu, float* tmom, int B,
+                          int C, int HW, int dtype, hipStream_t st);
+int launch_affine_act(const void* x, const void* dy, const float* a, const float* sc, const float* sh, int relu,
+                      void* out, int B, int C, int HW, int dtype, int bwd, hipStream_t st);
+
 }  // namespace mrla

@@ -462,3 +462,69 @@ class _TokenLightFn(torch.autograd.Function):
 
 def mrla_token_light(x, o_prev, lnx_w, lnx_b, lno_w, lno_b, wq, wk, wv, lam, d, eps=1e-6, res=False):
     return _TokenLightFn.apply(x, o_prev, lnx_w, lnx_b, lno_w, lno_b, wq, wk, wv, lam, d, eps, res)
+
+
+# ======================================================================================================
+# fused BatchNorm2d (+ReLU)  -- the producer-side epilogue in front of the MRLA tail
+# ======================================================================================================
+class _BnActFn(torch.autograd.Function):
+    """y = relu?(BatchNorm2d(x)): one statistics pass + one elementwise pass per direction."""
+
+    @staticmethod
+    def forward(ctx, x, gamma, beta, running_mean, running_var, training, momentum, eps, relu):
+        _require_cuda(x, "fused bn/act forward")
+        xc = x.contiguous()
+        b, c, h, w = xc.shape
+        dt, dev, st = _DT[xc.dtype], xc.device, _stream()
+        gamma32, beta32 = _f32(gamma), _f32(beta)
+        bnbuf = torch.empty((4, c), dtype=torch.float32, device=dev)       # sc, sh, save_mean, save_inv
+        amom = torch.empty((b, c, 2), dtype=torch.float32, device=dev)
+        if training:
+            _call("mrla_bn_plane_moments", xc.numel() * xc.element_size(), _ptr(xc), _ptr(amom), b, c, h, w, dt, L.NCHW, st)
+        L.call("mrla_bn_stats_fwd", _ptr(amom), _ptr(gamma32), _ptr(beta32), _ptr(running_mean), _ptr(running_var),
+               L.BN_TRAIN if training else L.BN_EVAL, float(momentum), float(eps), _ptr(bnbuf[0]), _ptr(bnbuf[1]),
+               _ptr(bnbuf[2]), _ptr(bnbuf[3]), b, c, h * w, st)
+        y = torch.empty_like(xc)
+        _call("mrla_bn_act_fwd", xc.numel() * xc.element_size() * 2, _ptr(xc), _ptr(bnbuf[0]), _ptr(bnbuf[1]), int(relu),
+              _ptr(y), b, c, h, w, dt, L.NCHW, st)
+        ctx.training, ctx.relu, ctx.gdtype = training, int(relu), gamma.dtype
+        ctx.save_for_backward(xc, gamma32, bnbuf)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        xc, gamma32, bnbuf = ctx.saved_tensors
+        b, c, h, w = xc.shape
+        dt, dev, st = _DT[xc.dtype], xc.device, _stream()
+        if dy.dtype != xc.dtype:
+            dy = dy.to(xc.dtype)
+        dy = dy.contiguous()
+        es = xc.element_size()
+        tmom = torch.empty((b, c, 2), dtype=torch.float32, device=dev)
+        _call("mrla_bn_plane_dmoments", xc.numel() * es * 2, _ptr(dy), _ptr(xc), _ptr(bnbuf[0]), _ptr(bnbuf[1]), ctx.relu,
+              _ptr(tmom), b, c, h, w, dt, L.NCHW, st)
+        small = torch.empty((5, c), dtype=torch.float32, device=dev)          # cb[c,3] | dgamma | dbeta
+        cb = small[:3].view(c, 3)
+        L.call("mrla_bn_stats_bwd", _ptr(tmom), _ptr(gamma32), _ptr(bnbuf[2]), _ptr(bnbuf[3]),
+               L.BN_TRAIN if ctx.training else L.BN_EVAL, _ptr(cb), _ptr(small[3]), _ptr(small[4]), b, c, h * w, st)
+        dx = torch.empty_like(xc)
+        _call("mrla_bn_act_bwd", xc.numel() * es * 3, _ptr(dy), _ptr(xc), _ptr(bnbuf[0]), _ptr(bnbuf[1]), _ptr(cb), ctx.relu,
+              _ptr(dx), b, c, h, w, dt, L.NCHW, st)
+        return dx, small[3].to(ctx.gdtype), small[4].to(ctx.gdtype), None, None, None, None, None, None
+
+
+def bn_act(x, bn, relu):
+    """relu?(bn(x)) for an nn.BatchNorm2d module `bn` on the fused HIP passes; any other norm layer (or a layout /
+    device the kernels do not handle) runs as the caller's module followed by torch.relu."""
+    if (type(bn) is torch.nn.BatchNorm2d and bn.affine and bn.track_running_stats and x.is_cuda and x.dim() == 4
+            and x.dtype in _DT and x.is_contiguous()):
+        training = bn.training
+        momentum = bn.momentum
+        if training and bn.num_batches_tracked is not None:
+            bn.num_batches_tracked.add_(1)
+            if momentum is None:
+                momentum = 1.0 / float(bn.num_batches_tracked)
+        return _BnActFn.apply(x, bn.weight, bn.bias, bn.running_mean, bn.running_var, training, momentum or 0.0, bn.eps,
+                              relu)
+    y = bn(x)
+    return torch.relu(y) if relu else y

@@ -10,6 +10,7 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
+from . import functional as F_
 from . import layers
 
 
@@ -47,11 +48,15 @@ class _BottleneckTrunk(nn.Module):
     def trunk_pre(self, x):
         """Everything up to, but not including, the shortcut add + ReLU: (bn3 output, identity)."""
         identity = x
-        out = self.relu(self.bn1(self.conv1(x)))
-        out = self.relu(self.bn2(self.conv2(out)))
-        out = self.bn3(self.conv3(out))
+        out = F_.bn_act(self.conv1(x), self.bn1, relu=True)          # fused BatchNorm+ReLU HIP passes
+        out = F_.bn_act(self.conv2(out), self.bn2, relu=True)
+        out = F_.bn_act(self.conv3(out), self.bn3, relu=False)
         if self.downsample is not None:
-            identity = self.downsample(x)
+            ds = self.downsample
+            if isinstance(ds, nn.Sequential) and len(ds) == 2 and isinstance(ds[0], nn.Conv2d):
+                identity = F_.bn_act(ds[0](x), ds[1], relu=False)
+            else:
+                identity = ds(x)
         return out, identity
 
     def trunk(self, x):
@@ -172,7 +177,7 @@ class ResNet_mrlal(_ResNetMRLA):
         self._head_and_init(block, zero_init_last_bn)
 
     def forward_features(self, x):
-        x = self.maxpool(self.relu(self.bn1(self.conv1(x))))
+        x = self.maxpool(F_.bn_act(self.conv1(x), self.bn1, relu=True))
         return self.layer4(self.layer3(self.layer2(self.layer1(x))))
 
 
@@ -207,7 +212,7 @@ class ResNet_mrlab(_ResNetMRLA):
         self._head_and_init(block, zero_init_last_bn)
 
     def forward_features(self, x):
-        x = self.maxpool(self.relu(self.bn1(self.conv1(x))))
+        x = self.maxpool(F_.bn_act(self.conv1(x), self.bn1, relu=True))
         k = v = None
         for stage in self.stages:
             for blk in stage:

@@ -39,6 +39,8 @@ def parse():
     ap.add_argument("--drop-path", type=float, default=0.2, help="resnet/train.py:67 default")
     ap.add_argument("--no-baselines", action="store_true", help="skip the cpu_baseline / eager_rocm legs")
     ap.add_argument("--eager", action="store_true", help="time the eager restatement instead (diagnostic)")
+    ap.add_argument("--graph", type=int, default=0, help="1: replay the whole step (fwd+bwd+SGD) from one HIP graph")
+    ap.add_argument("--backend", default=os.environ.get("MRLA_DIST_BACKEND", "nccl"))
     return ap.parse_args()
 
 
@@ -121,7 +123,7 @@ def main():
     rank, local, world = D.env_world()
     dist_on = world > 1
     torch.cuda.set_device(local)
-    D.init_from_env("nccl")
+    D.init_from_env(args.backend)
     if args.gpus != world and rank == 0:
         print(f"warning: --gpus {args.gpus} but WORLD_SIZE={world}", file=sys.stderr)
 
@@ -150,6 +152,19 @@ def main():
     # warm-up without the timer, then the timed region with HIP-event timing of the dominant kernel
     for _ in range(args.warmup):
         step()
+    if args.graph:
+        # the whole training step is launch-order static (no host sync inside): capture it once, replay it
+        torch.cuda.synchronize()
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            for _ in range(2):
+                step()
+        torch.cuda.current_stream().wait_stream(side)
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph):
+            step()
+        eager_step, step = step, graph.replay
     timer = Fm.KernelTimer(["mrla_light_apply_bwd", "mrla_light_stats_bwd", "mrla_light_apply_fwd",
                             "mrla_light_stats_fwd", "mrla_base_attend_fwd", "mrla_base_tail_fwd",
                             "mrla_base_tail_stats_bwd", "mrla_base_attend_bwd", "mrla_base_value_bwd",

@@ -55,7 +55,7 @@ static bool bad_dtype(int dt) { return dt != MRLA_F32 && dt != MRLA_BF16 && dt !
 
 // One geometry for all four streaming kernels of a problem (sized for the 5-array backward pass), so
 // the wgrad partial-row count is a pure function of the shape.
-static int light_geo(SlabGeo* g, int b, int c, int h, int w, int dtype) { return make_slab_geo(g, b, c, h, w, dtype, 8, 0); }
+static int light_geo(SlabGeo* g, int b, int c, int h, int w, int dtype) { return make_slab_geo(g, b, c, h, w, dtype, 6, 0); }
 
 }  // namespace mrla
 

@@ -174,8 +174,7 @@ __global__ __launch_bounds__(kThreads) void light_apply_fwd_nchw(
   extern __shared__ __align__(16) unsigned char smem[];
   constexpr int NA = HAS_O ? 2 : 1;
   T* buf = reinterpret_cast<T*>(smem);                       // [2][NA][astride] inputs
-  T* outs = buf + 2 * NA * g.astride;                        // [astride] output staging
-  float* ptab = reinterpret_cast<float*>(outs + g.astride);  // [CP][kPT]: taps
+  float* ptab = reinterpret_cast<float*>(buf + 2 * NA * g.astride);  // [CP][kPT]: taps
   float* itab = ptab + g.CP * kPT;                           // [BG][CP][kIT]: A, B, C
   MRLA_PIPELINE_PROLOGUE(NA, x, o, o)
   const int G = g.C / d;
@@ -200,7 +199,9 @@ __global__ __launch_bounds__(kThreads) void light_apply_fwd_nchw(
       if (!t.live) continue;
       const T* xp = xs + t.p * g.HW + t.col;
       const T* op = os + t.p * g.HW + t.col;
-      T* yp = outs + t.p * g.HW + t.col;
+      // results leave straight from the marching lanes (one 2..4-byte store per lane and row, a contiguous run per
+      // wave): no LDS staging, no second barrier; the L2 merges the row pieces into full lines
+      T* yp = out + ((size_t)b * g.C + c0) * g.HW + t.p * g.HW + t.col;
       float w[9];
       load_taps(w, ptab + t.p * kPT);
       mask_conv(w, t);
@@ -226,8 +227,6 @@ __global__ __launch_bounds__(kThreads) void light_apply_fwd_nchw(
         ra = rb; rb = rc; cn = cnn;
       }
     }
-    __syncthreads();
-    slab_store(out + ((size_t)b * g.C + c0) * g.HW, outs, n, tid);
   }
 }
 
@@ -369,9 +368,7 @@ __global__ __launch_bounds__(kThreads) void light_apply_bwd_nchw(
   extern __shared__ __align__(16) unsigned char smem[];
   constexpr int NA = HAS_O ? 3 : 2;
   T* buf = reinterpret_cast<T*>(smem);                        // [2][NA][astride]: x, dOut, o
-  T* dxs = buf + 2 * NA * g.astride;                          // [astride] dx staging
-  T* dos = dxs + g.astride;                                   // [astride] do staging (HAS_O)
-  float* ptab = reinterpret_cast<float*>(dos + (HAS_O ? g.astride : 0));   // [CP][kPT]: taps, G, H, lambda
+  float* ptab = reinterpret_cast<float*>(buf + 2 * NA * g.astride);        // [CP][kPT]: taps, G, H, lambda
   float* itab = ptab + g.CP * kPT;                            // [BG][CP][kIT]: E, F, a, dy
   float* red = itab + g.BG * g.CP * kIT;                      // [ntasks][PW][9] wgrad sums over the images
   MRLA_PIPELINE_PROLOGUE(NA, x, dout, o)
@@ -411,8 +408,9 @@ __global__ __launch_bounds__(kThreads) void light_apply_bwd_nchw(
       const T* xp = xs + t.p * g.HW + t.col;
       const T* gp = gs + t.p * g.HW + t.col;
       const T* op = os + t.p * g.HW + t.col;
-      T* dxp = dxs + t.p * g.HW + t.col;
-      T* dop = dos + t.p * g.HW + t.col;
+      const size_t goff = ((size_t)b * g.C + c0) * g.HW + t.p * g.HW + t.col;   // results leave straight from the lanes
+      T* dxp = dx + goff;
+      T* dop = HAS_O ? dprev + goff : nullptr;
       BwdConsts k;
       const float* prow = ptab + t.p * kPT;
       load_taps(k.w, prow);
@@ -476,10 +474,6 @@ __global__ __launch_bounds__(kThreads) void light_apply_bwd_nchw(
         if (t.last) red[(task * g.PW + t.pl) * 9 + i] += v;
       }
     }
-    __syncthreads();
-    const size_t off = ((size_t)b * g.C + c0) * g.HW;
-    slab_store(dx + off, dxs, n, tid);
-    if (HAS_O) slab_store(dprev + off, dos, n, tid);
   }
   __syncthreads();
   for (int idx = tid; idx < np * 9; idx += kThreads) {
@@ -541,7 +535,7 @@ int launch_light_apply_fwd_nchw(const void* x, const void* o, const float* wv, c
                                 const float* sh, const float* lam, const float* dp, void* out, const SlabGeo& g,
                                 int d, int res, int dtype, int act, hipStream_t st) {
   const size_t es = dtype_size(dtype);
-  const size_t lds = (size_t)g.astride * es * (2 * (o ? 2 : 1) + 1) + (size_t)g.CP * (kPT + g.BG * kIT) * sizeof(float);
+  const size_t lds = (size_t)g.astride * es * 2 * (o ? 2 : 1) + (size_t)g.CP * (kPT + g.BG * kIT) * sizeof(float);
   if (lds > kMaxLds) return MRLA_EUNSUPPORTED;
   const dim3 grid(g.slabs, (g.B + g.BG - 1) / g.BG);
 #define CALL(T, A, O)                                                                               \
@@ -578,7 +572,7 @@ int launch_light_apply_bwd_nchw(const void* dout, const void* x, const void* o, 
                                 void* dprev, float* dwv_part, const SlabGeo& g, int d, int res, int relu, int dtype,
                                 int act, hipStream_t st) {
   const size_t es = dtype_size(dtype);
-  const size_t lds = (size_t)g.astride * es * (2 * (o ? 3 : 2) + (o ? 2 : 1)) +
+  const size_t lds = (size_t)g.astride * es * 2 * (o ? 3 : 2) +
                      ((size_t)g.CP * (kPT + g.BG * kIT) + (size_t)g.NG * g.NB * g.PW * 9) * sizeof(float);
   if (lds > kMaxLds) return MRLA_EUNSUPPORTED;
   const dim3 grid(g.slabs, (g.B + g.BG - 1) / g.BG);

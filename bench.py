@@ -122,6 +122,7 @@ def main():
     from mrla_amd import distributed as D
     rank, local, world = D.env_world()
     dist_on = world > 1
+    local = local % max(1, torch.cuda.device_count())     # (lets a 1-GPU box exercise the N>1 code path over gloo)
     torch.cuda.set_device(local)
     D.init_from_env(args.backend)
     if args.gpus != world and rank == 0:

@@ -24,6 +24,7 @@ def init_from_env(backend=None):
             backend = "nccl" if torch.cuda.is_available() else "gloo"
         kw = {}
         if backend == "nccl":
+            local = local % max(1, torch.cuda.device_count())
             torch.cuda.set_device(local)
             kw["device_id"] = torch.device("cuda", local)
         dist.init_process_group(backend, **kw)

@@ -171,7 +171,9 @@ int mrla_base_gate_bwd(const float* mom, const float* pmom, const float* p_all, 
                        int b, int c, int hw, int d, int T, int t, int first_touch, void* stream);
 
 /* dV_t = sum_{t'=t..Tc} p_all[b,g,t'-1,t-1] * dA_t';  dx = res*dOut + dwconv3x3^T(dV_t) + dyx;  dwv_part[rows, c, 9]
- * (rows = mrla_light_wgrad_rows()).  Tc = number of layers of the stage that ran forward. */
+ * (rows = mrla_light_wgrad_rows()).  Tc = number of layers of the stage that ran forward.
+ * res bit 0: add dOut (block residual); bit 1: multiply by [x > 0] (x_t = relu(pre + identity) was formed by
+ * mrla_light_stats_fwd_fused, so dx is the gradient wrt the pre-activation and wrt the identity alike). */
 int mrla_base_value_bwd(const void* dout, const void* x, const float* wv, const void* da_ring, const float* p_all,
                         const float* dyx, void* dx, float* dwv_part, int b, int c, int h, int w, int d, int T, int t,
                         int Tc, int res, int dtype, int layout, void* stream);

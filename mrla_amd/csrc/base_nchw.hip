@@ -641,7 +641,8 @@ __global__ __launch_bounds__(kThreads) void base_value_bwd_nchw(
           wg[s][3] = fmaf(du, xb.l, wg[s][3]); wg[s][4] = fmaf(du, xb.c, wg[s][4]); wg[s][5] = fmaf(du, xb.r, wg[s][5]);
           wg[s][6] = fmaf(du, xc.l, wg[s][6]); wg[s][7] = fmaf(du, xc.c, wg[s][7]); wg[s][8] = fmaf(du, xc.r, wg[s][8]);
           if (tk.valid) {
-            const float y = (res ? to_f(gp[r * g.W + tk.col]) : 0.f) + s9 + dy;
+            float y = ((res & 1) ? to_f(gp[r * g.W + tk.col]) : 0.f) + s9 + dy;
+            if ((res & 2) && !(xb.c > 0.f)) y = 0.f;          // x_t = relu(pre + identity): gradient wrt the pre-activation
             gp[r * g.W + tk.col] = from_f<T>(y);
           }
           ua = ub; ub = uc; xa = xb; xb = xc;

@@ -279,10 +279,10 @@ class BaseStage:
 
 
 class BaseConfig:
-    __slots__ = ("d", "bn_mode", "momentum", "eps", "tail")
+    __slots__ = ("d", "bn_mode", "momentum", "eps", "tail", "fuse")
 
-    def __init__(self, d, bn_mode=L.BN_NONE, momentum=0.1, eps=1e-5, tail=False):
-        self.d, self.bn_mode, self.momentum, self.eps, self.tail = d, bn_mode, momentum, eps, tail
+    def __init__(self, d, bn_mode=L.BN_NONE, momentum=0.1, eps=1e-5, tail=False, fuse=False):
+        self.d, self.bn_mode, self.momentum, self.eps, self.tail, self.fuse = d, bn_mode, momentum, eps, tail, fuse
 
 
 class _BaseFn(torch.autograd.Function):
@@ -290,7 +290,7 @@ class _BaseFn(torch.autograd.Function):
     no tail: out = attn  (bare mrla_base_layer)."""
 
     @staticmethod
-    def forward(ctx, x, wq, wk, wv, gamma, beta, running_mean, running_var, dp, stage, cfg):
+    def forward(ctx, x, identity, wq, wk, wv, gamma, beta, running_mean, running_var, dp, stage, cfg):
         _require_cuda(x, "mrla base forward")
         layout, xc = _layout_of(x)
         b, c, h, w = xc.shape
@@ -307,8 +307,14 @@ class _BaseFn(torch.autograd.Function):
         t, T = stage.t + 1, stage.T
 
         mom = torch.empty((b, c, L.FWD_MOMENTS), dtype=torch.float32, device=dev)
-        _call("mrla_light_stats_fwd", xc.numel() * xc.element_size(), _ptr(xc), None, _ptr(wv32), _ptr(mom), b, c, h, w,
-              dt, layout, L.ACT_NONE, st)
+        if cfg.fuse:            # x is the pre-activation: x_t = relu(x + identity) formed by the pooling pass
+            idc = _layout_of(identity)[1]
+            pre, xc = xc, torch.empty_like(xc)
+            _call("mrla_light_stats_fwd_fused", xc.numel() * xc.element_size() * 3, _ptr(pre), _ptr(idc), _ptr(wv32),
+                  _ptr(mom), _ptr(xc), b, c, h, w, dt, layout, st)
+        else:
+            _call("mrla_light_stats_fwd", xc.numel() * xc.element_size(), _ptr(xc), None, _ptr(wv32), _ptr(mom), b, c, h,
+                  w, dt, layout, L.ACT_NONE, st)
         q = torch.empty((b, c), dtype=torch.float32, device=dev)
         L.call("mrla_base_gate_fwd", _ptr(mom), _ptr(wq32), _ptr(wk32), ks, _ptr(stage.K), _ptr(stage.P), _ptr(q), b, c,
                h * w, d, T, t, st)
@@ -370,23 +376,28 @@ class _BaseFn(torch.autograd.Function):
         dwv_part = torch.empty((rows, c * 9), dtype=torch.float32, device=dev)
         dx = torch.empty_like(xc)
         _call("mrla_base_value_bwd", xc.numel() * es * (Tc - t + 4), _ptr(dout), _ptr(xc), _ptr(wv32), _ptr(stage.dA),
-              _ptr(stage.P), _ptr(dyx), _ptr(dx), _ptr(dwv_part), b, c, h, w, d, T, t, Tc, int(cfg.tail), dt, layout, st)
+              _ptr(stage.P), _ptr(dyx), _ptr(dx), _ptr(dwv_part), b, c, h, w, d, T, t, Tc,
+              int(cfg.tail) | (2 if cfg.fuse else 0), dt, layout, st)
         wsum = torch.empty((c * 9 + 2 * ks,), dtype=torch.float32, device=dev)
         L.call("mrla_reduce_rows", _ptr(dwv_part), _ptr(wsum), rows, c * 9, st)
         L.call("mrla_reduce_rows", _ptr(dwqk_part), _ptr(wsum[c * 9:]), b, 2 * ks, st)
         sq, sk, sv = ctx.shapes
         tq, tk, tv, _ = ctx.pdtypes
-        return (dx, wsum[c * 9:c * 9 + ks].view(sq).to(tq), wsum[c * 9 + ks:].view(sk).to(tk),
+        return (dx, dx if cfg.fuse else None, wsum[c * 9:c * 9 + ks].view(sq).to(tq), wsum[c * 9 + ks:].view(sk).to(tk),
                 wsum[:c * 9].view(sv).to(tv), dgamma, dbeta, None, None, None, None, None)
 
 
-def mrla_base(x, wq, wk, wv, d, stage, bn=None, dp=None):
+def mrla_base(x, wq, wk, wv, d, stage, bn=None, dp=None, identity=None):
     """One MRLA-base layer on `stage` (a BaseStage).  bn: None (bare layer, returns attn) or the dict of
-    mrla_light(); with bn the block tail x + dp*relu(BN(attn)) is fused in."""
+    mrla_light(); with bn the block tail x + dp*relu(BN(attn)) is fused in.  identity: when given, `x` is the
+    bottleneck's pre-activation and x_t = relu(x + identity) is formed inside the pooling pass."""
+    fuse = identity is not None
     if bn is None:
-        return _BaseFn.apply(x, wq, wk, wv, None, None, None, None, None, stage, BaseConfig(d))
-    cfg = BaseConfig(d, L.BN_TRAIN if bn["training"] else L.BN_EVAL, bn.get("momentum", 0.1), bn.get("eps", 1e-5), True)
-    return _BaseFn.apply(x, wq, wk, wv, bn["weight"], bn["bias"], bn["running_mean"], bn["running_var"], dp, stage, cfg)
+        return _BaseFn.apply(x, identity, wq, wk, wv, None, None, None, None, None, stage, BaseConfig(d, fuse=fuse))
+    cfg = BaseConfig(d, L.BN_TRAIN if bn["training"] else L.BN_EVAL, bn.get("momentum", 0.1), bn.get("eps", 1e-5), True,
+                     fuse)
+    return _BaseFn.apply(x, identity, wq, wk, wv, bn["weight"], bn["bias"], bn["running_mean"], bn["running_var"], dp,
+                         stage, cfg)
 
 
 # ======================================================================================================

@@ -181,8 +181,9 @@ class mrla_base_module(nn.Module):
         return self.mrla(xt, prev_k, prev_v)
 
 
-def base_block_tail(x, prev_k, prev_v, mrla, bn_mrla, drop_path):
-    """x + DropPath(relu(bn_mrla(attn))) with attn, K, V from the MRLA-base layer (resnet_mrla_base.py:124-127)."""
+def base_block_tail(x, prev_k, prev_v, mrla, bn_mrla, drop_path, identity=None):
+    """x + DropPath(relu(bn_mrla(attn))) with attn, K, V from the MRLA-base layer (resnet_mrla_base.py:124-127).
+    identity given: `x` is the bottleneck's bn3 output and x_t = relu(x + identity) (:120-121) is formed in-kernel."""
     layer = mrla.mrla
     if type(bn_mrla) is nn.BatchNorm2d and bn_mrla.affine:
         layer._check(x)
@@ -190,9 +191,11 @@ def base_block_tail(x, prev_k, prev_v, mrla, bn_mrla, drop_path):
         p = getattr(drop_path, "drop_prob", 0.0) or 0.0
         dp = drop_path_scale(x.shape[0], p, drop_path.training if isinstance(drop_path, nn.Module) else False, x.device)
         out = F_.mrla_base(x, layer.Wq.weight, layer.Wk.weight, layer.Wv.weight, layer.dim_perhead, stage,
-                           bn=_bn_args(bn_mrla), dp=dp)
+                           bn=_bn_args(bn_mrla), dp=dp, identity=identity)
         K, V = stage.views()
         return out, K, V
+    if identity is not None:
+        x = torch.relu(x + identity)
     attn, K, V = mrla(x, prev_k, prev_v)
     return x + drop_path(torch.relu(bn_mrla(attn))), K, V
 

@@ -92,8 +92,8 @@ class MRLA_Bottleneck_base(_BottleneckTrunk):
         self.drop_path = layers.DropPath(drop_path) if drop_path > 0.0 else nn.Identity()
 
     def forward(self, x, prev_k, prev_v):
-        out, _ = self.trunk(x)
-        return layers.base_block_tail(out, prev_k, prev_v, self.mrla, self.bn_mrla, self.drop_path)
+        pre, identity = self.trunk_pre(x)           # shortcut add + ReLU run inside the MRLA pooling pass
+        return layers.base_block_tail(pre, prev_k, prev_v, self.mrla, self.bn_mrla, self.drop_path, identity=identity)
 
 
 class _ResNetMRLA(nn.Module):

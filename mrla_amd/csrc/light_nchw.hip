@@ -201,7 +201,8 @@ __global__ __launch_bounds__(kThreads) void light_apply_fwd_nchw(
       const T* op = os + t.p * g.HW + t.col;
       // results leave straight from the marching lanes (one 2..4-byte store per lane and row, a contiguous run per
       // wave): no LDS staging, no second barrier; the L2 merges the row pieces into full lines
-      T* yp = out + ((size_t)b * g.C + c0) * g.HW + t.p * g.HW + t.col;
+      T* yb = out + ((size_t)b * g.C + c0) * g.HW;            // wave-uniform base + 32-bit lane offset
+      const int lo = t.p * g.HW + t.col;
       float w[9];
       load_taps(w, ptab + t.p * kPT);
       mask_conv(w, t);
@@ -212,19 +213,21 @@ __global__ __launch_bounds__(kThreads) void light_apply_fwd_nchw(
         for (int k = 0; k < 9; ++k) w[k] *= A;                // residual into the centre tap (with an activation
         w[4] += resf;                                         // between conv and gate nothing can be folded)
       }
-      int idx = t.r0 * g.W;
-      Row3 ra = row_of(ld_centre_at(xp, idx - g.W, lastrow));
-      Row3 rb = row_of(ld_centre_at(xp, idx, lastrow));
-      float cn = ld_centre_at(xp, idx + g.W, lastrow);
-      for (int r = t.r0; r < t.r1; ++r, idx += g.W) {
-        const float cnn = ld_centre_at(xp, idx + 2 * g.W, lastrow);
-        const Row3 rc = row_of(cn);
-        float y;
-        if (GELU) y = fmaf(A, gelu_f(conv9(w, ra, rb, rc)), fmaf(resf, rb.c, Cc));
-        else      y = conv9(w, ra, rb, rc) + Cc;
-        if (HAS_O) y = fmaf(Bc, to_f(op[idx]), y);
-        if (t.valid) yp[idx] = from_f<T>(y);
-        ra = rb; rb = rc; cn = cnn;
+      if (t.valid) {                                          // lanes without a real column sit the march out
+        int idx = t.r0 * g.W;
+        Row3 ra = row_of(ld_centre_at(xp, idx - g.W, lastrow));
+        Row3 rb = row_of(ld_centre_at(xp, idx, lastrow));
+        float cn = ld_centre_at(xp, idx + g.W, lastrow);
+        for (int r = t.r0; r < t.r1; ++r, idx += g.W) {
+          const float cnn = ld_centre_at(xp, idx + 2 * g.W, lastrow);
+          const Row3 rc = row_of(cn);
+          float y;
+          if (GELU) y = fmaf(A, gelu_f(conv9(w, ra, rb, rc)), fmaf(resf, rb.c, Cc));
+          else      y = conv9(w, ra, rb, rc) + Cc;
+          if (HAS_O) y = fmaf(Bc, to_f(op[idx]), y);
+          yb[(unsigned)(lo + idx)] = from_f<T>(y);
+          ra = rb; rb = rc; cn = cnn;
+        }
       }
     }
   }
@@ -314,8 +317,8 @@ struct BwdConsts {
 // Register roles rotate in the caller (A,B,C / UA,UB,UC), so no window copies are needed.
 template <typename T, bool GELU, bool HAS_O, bool RELU, bool INSIDE, bool OWNED, bool EMIT>
 __device__ __forceinline__ void bwd_row(const BwdConsts& k, const T* __restrict__ xp, const T* __restrict__ gp,
-                                        const T* __restrict__ op, T* __restrict__ dxp, T* __restrict__ dop, int idx,
-                                        int W, int lastrow, bool valid, const Row3& A, const Row3& B, Row3& C,
+                                        const T* __restrict__ op, T* __restrict__ dxb, T* __restrict__ dob, int lo,
+                                        int idx, int W, int lastrow, const Row3& A, const Row3& B, Row3& C,
                                         float& xn, const Row3& UA, const Row3& UB, Row3& UC, float& gprev,
                                         float& dohold, float (&wg)[9]) {
   C = row_of(xn);
@@ -333,7 +336,7 @@ __device__ __forceinline__ void bwd_row(const BwdConsts& k, const T* __restrict_
     dmo = k.lm * dm;
   }
   if (OWNED) {
-    if (HAS_O && !RELU && valid) dop[idx] = from_f<T>(dmo);
+    if (HAS_O && !RELU) dob[(unsigned)(lo + idx)] = from_f<T>(dmo);
     wg[0] = fmaf(du, A.l, wg[0]); wg[1] = fmaf(du, A.c, wg[1]); wg[2] = fmaf(du, A.r, wg[2]);
     wg[3] = fmaf(du, B.l, wg[3]); wg[4] = fmaf(du, B.c, wg[4]); wg[5] = fmaf(du, B.r, wg[5]);
     wg[6] = fmaf(du, C.l, wg[6]); wg[7] = fmaf(du, C.c, wg[7]); wg[8] = fmaf(du, C.r, wg[8]);
@@ -348,9 +351,9 @@ __device__ __forceinline__ void bwd_row(const BwdConsts& k, const T* __restrict_
     float y = fmaf(k.resf, gprev, s9 + k.dy);
     if (RELU) {
       y = (A.c > 0.f) ? y : 0.f;                              // A = x[rr-1] = x[ro]
-      if (HAS_O && valid) dop[idx - W] = from_f<T>(dohold + y);
+      if (HAS_O) dob[(unsigned)(lo + idx - W)] = from_f<T>(dohold + y);
     }
-    if (valid) dxp[idx - W] = from_f<T>(y);
+    dxb[(unsigned)(lo + idx - W)] = from_f<T>(y);
   }
   gprev = gcur;
   dohold = dmo;
@@ -408,9 +411,10 @@ __global__ __launch_bounds__(kThreads) void light_apply_bwd_nchw(
       const T* xp = xs + t.p * g.HW + t.col;
       const T* gp = gs + t.p * g.HW + t.col;
       const T* op = os + t.p * g.HW + t.col;
-      const size_t goff = ((size_t)b * g.C + c0) * g.HW + t.p * g.HW + t.col;   // results leave straight from the lanes
-      T* dxp = dx + goff;
-      T* dop = HAS_O ? dprev + goff : nullptr;
+      // results leave straight from the lanes: wave-uniform base + 32-bit lane offset
+      T* dxb = dx + ((size_t)b * g.C + c0) * g.HW;
+      T* dob = HAS_O ? dprev + ((size_t)b * g.C + c0) * g.HW : nullptr;
+      const int lo = t.p * g.HW + t.col;
       BwdConsts k;
       const float* prow = ptab + t.p * kPT;
       load_taps(k.w, prow);
@@ -420,10 +424,13 @@ __global__ __launch_bounds__(kThreads) void light_apply_bwd_nchw(
       mask_convT(k.wt, t);
       k.Gc = prow[9]; k.Hc = prow[10]; k.lm = prow[11];
       const float* irow = itab + ((size_t)(b - b0) * g.CP + t.p) * kIT;
-      k.E = irow[0]; k.F = irow[1]; k.am = t.valid ? irow[2] : 0.f; k.dy = irow[3];
+      k.E = irow[0]; k.F = irow[1]; k.am = irow[2]; k.dy = irow[3];
       k.resf = res ? 1.f : 0.f;
       float wg[9] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
       const bool valid = t.valid;
+      // Lanes that hold no real column sit out the whole march (EXEC off): DPP reads from them return 0, which is what
+      // the edge-masked taps assume anyway, and the stores need no per-row predicate.  Trip counts are wave-uniform.
+      if (valid) {
       // window state before the step at row rr:  xa = x[rr-1], xb = x[rr], xn = centre of x[rr+1],
       //                                          ua = dU[rr-2], ub = dU[rr-1]
       int rr = t.r0 - 1;
@@ -435,8 +442,8 @@ __global__ __launch_bounds__(kThreads) void light_apply_bwd_nchw(
       Row3 ua = {0.f, 0.f, 0.f}, ub = {0.f, 0.f, 0.f}, uc;
       float gprev = 0.f, dohold = 0.f;
 #define MRLA_BWD_STEP(INS, OWN, EMI, A, B, C, UA, UB, UC)                                                            \
-  bwd_row<T, GELU, HAS_O, RELU, INS, OWN, EMI>(k, xp, gp, op, dxp, dop, idx, W, lastrow, valid, A, B, C, xn, UA, UB, \
-                                               UC, gprev, dohold, wg);                                               \
+  bwd_row<T, GELU, HAS_O, RELU, INS, OWN, EMI>(k, xp, gp, op, dxb, dob, lo, idx, W, lastrow, A, B, C, xn, UA, UB, UC, \
+                                               gprev, dohold, wg);                                                   \
   ++rr; idx += W;
       // halo row above the band: dU[r0-1] only (zero above the plane)
       if (rr >= 0) { MRLA_BWD_STEP(true, false, false, xa, xb, xc, ua, ub, uc) }
@@ -465,6 +472,7 @@ __global__ __launch_bounds__(kThreads) void light_apply_bwd_nchw(
         else       { MRLA_BWD_STEP(false, false, true, xc, xa, xb, uc, ua, ub) }
       }
 #undef MRLA_BWD_STEP
+      }
       // fold this image's wgrad contribution into the per-(task, plane) sums
       // (edge columns: the left/right x neighbours of an edge lane belong to another plane -> masked here)
 #pragma unroll

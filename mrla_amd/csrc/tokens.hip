@@ -78,11 +78,12 @@ __device__ __forceinline__ void load_xn_tile(float* __restrict__ tile, const T* 
                                              const float* __restrict__ stats, const float* __restrict__ wx,
                                              const float* __restrict__ bx, int b, int n, int C, int c0, int CC, int tid) {
   const int hw = n - 1;
-  for (int idx = tid; idx < hw * CC; idx += kThreads) {
-    const int i = idx / CC, cc = idx - i * CC;
-    const float* s = stats + ((size_t)b * n + i + 1) * S_N;
+  const int cc = tid % CC, tg = tid / CC, ntg = kThreads / CC;      // lanes = channels: coalesced along c
+  const float w = wx[c0 + cc], bb = bx[c0 + cc];
+  for (int i = tg; i < hw; i += ntg) {
+    const float2 s = *reinterpret_cast<const float2*>(stats + ((size_t)b * n + i + 1) * S_N);   // (mean, rstd): uniform per row
     const float xv = to_f(x[((size_t)b * n + i + 1) * C + c0 + cc]);
-    tile[idx] = fmaf((xv - s[S_MX]) * s[S_RX], wx[c0 + cc], bx[c0 + cc]);
+    tile[i * CC + cc] = fmaf((xv - s.x) * s.y, w, bb);
   }
 }
 
@@ -337,8 +338,8 @@ __global__ __launch_bounds__(kThreads) void token_ln_bwd_kernel(
     default: return MRLA_EINVAL;         \
   }
 
+// 32-channel chunks: 2-3 workgroups per CU fit their fp32 map tiles in LDS (64 would leave one per CU)
 static int chunk_for(int C) {
-  if (C % 64 == 0) return 64;
   if (C % 32 == 0) return 32;
   if (C % 16 == 0) return 16;
   return 0;

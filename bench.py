@@ -117,6 +117,17 @@ def eager_rocm(arch, batch, drop_path, steps=6):
             "what": "oracle/eager_models.py (stock ATen/MIOpen ops) on this GPU, same batch/dtype/optimizer"}
 
 
+def pmc_traffic(args, kernel):
+    """HBM bytes per launch of `kernel` from the committed rocprofv3 PMC passes (2*FETCH_SIZE + WRITE_SIZE, gfx950
+    correction of MI355X_MICROARCH.md; collected by scripts/pmc_bench.sh on this exact workload), else None."""
+    path = os.path.join(ROOT, "profiles", f"r01_pmc_traffic_{args.arch}_b{args.batch}.json")
+    try:
+        rec = json.load(open(path)).get(kernel.replace("mrla_", ""))
+        return int(rec["hbm_bytes_per_launch"]) if rec else None
+    except (OSError, ValueError, KeyError):
+        return None
+
+
 def main():
     args = parse()
     from mrla_amd import distributed as D
@@ -186,7 +197,8 @@ def main():
         if dom:
             ach = dom["bytes"] / (dom["ms"] * 1e-3) / 1e9
             roofline = {"bound": "hbm", "kernel": dom_name + "<bf16>", "achieved": round(ach, 1),
-                        "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": None,
+                        "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4),
+                        "traffic": pmc_traffic(args, dom_name),
                         "launches": dom["launches"], "avg_launch_us": round(1e3 * dom["ms"] / dom["launches"], 2),
                         "algorithmic_bytes_per_launch_avg": dom["bytes"] // dom["launches"]}
         out = {"metric": f"images/sec fwd+bwd {args.arch} b={args.batch}", "value": round(ips, 1), "unit": "images/sec",

@@ -1,0 +1,64 @@
+"""Condense rocprofv3 outputs of scripts/pmc_bench.sh into small committed summaries:
+  <out>/summary_kernels.csv   steady-state per-kernel time per step (from the kernel trace, warm-up/find excluded)
+  <out>/summary_traffic.json  HBM bytes per launch of the MRLA kernels: 2*FETCH_SIZE + WRITE_SIZE (gfx950: FETCH_SIZE
+                              reports half of a wide coalesced read, MI355X_MICROARCH.md section HBM), units of KB -> bytes
+"""
+import collections
+import csv
+import glob
+import json
+import os
+import sys
+
+raw = sys.argv[1]
+out = sys.argv[2] if len(sys.argv) > 2 else raw
+
+
+def short(name):
+    for key in ("light_stats_fwd", "light_apply_fwd", "light_stats_bwd", "light_apply_bwd", "plane_moments_small",
+                "plane_moments", "affine_act", "base_attend_fwd", "base_attend_bwd", "base_value_bwd", "base_tail"):
+        if key in name:
+            return key
+    return name[:80]
+
+
+def pmc(kind, counter):
+    f = glob.glob(os.path.join(raw, kind, "*", "*_counter_collection.csv"))
+    agg = collections.defaultdict(list)
+    if not f:
+        return agg
+    for r in csv.DictReader(open(f[0])):
+        if "mrla" in r["Kernel_Name"] and r["Counter_Name"] == counter:
+            agg[short(r["Kernel_Name"])].append(float(r["Counter_Value"]))
+    return agg
+
+
+fetch, write = pmc("fetch", "FETCH_SIZE"), pmc("write", "WRITE_SIZE")
+traffic = {}
+for k in sorted(set(fetch) | set(write)):
+    fl, wl = fetch.get(k, []), write.get(k, [])
+    if not fl or not wl:
+        continue
+    traffic[k] = {"launches_profiled": len(fl), "fetch_kb_per_launch_raw": sum(fl) / len(fl),
+                  "write_kb_per_launch": sum(wl) / len(wl),
+                  "hbm_bytes_per_launch": (2.0 * sum(fl) / len(fl) + sum(wl) / len(wl)) * 1024.0}
+json.dump(traffic, open(os.path.join(out, "summary_traffic.json"), "w"), indent=1)
+
+f = glob.glob(os.path.join(raw, "trace", "*", "*_kernel_trace.csv"))
+if f:
+    rows = sorted(csv.DictReader(open(f[0])), key=lambda r: int(r["Start_Timestamp"]))
+    marks = [i for i, r in enumerate(rows) if "max_pool_backward" in r["Kernel_Name"]]
+    if len(marks) >= 5:
+        sel, steps = rows[marks[-5]:marks[-1]], 4
+        agg = collections.defaultdict(lambda: [0, 0.0])
+        for r in sel:
+            a = agg[short(r["Kernel_Name"])]
+            a[0] += 1
+            a[1] += (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3
+        wall = (int(rows[marks[-1]]["Start_Timestamp"]) - int(rows[marks[-5]]["Start_Timestamp"])) / 1e6 / steps
+        with open(os.path.join(out, "summary_kernels.csv"), "w") as g:
+            g.write(f"# steady state over {steps} steps; GPU kernel time {sum(v[1] for v in agg.values()) / 1e3 / steps:.2f} "
+                    f"ms/step, wall {wall:.2f} ms/step (profiler attached)\nkernel,calls_per_step,ms_per_step,avg_us\n")
+            for k, (c, us) in sorted(agg.items(), key=lambda kv: -kv[1][1])[:45]:
+                g.write(f"\"{k}\",{c / steps:.1f},{us / 1e3 / steps:.3f},{us / c:.2f}\n")
+print(open(os.path.join(out, "summary_traffic.json")).read()[:1500])

@@ -39,6 +39,8 @@ def parse():
     ap.add_argument("--drop-path", type=float, default=0.2, help="resnet/train.py:67 default")
     ap.add_argument("--no-baselines", action="store_true", help="skip the cpu_baseline / eager_rocm legs")
     ap.add_argument("--eager", action="store_true", help="time the eager restatement instead (diagnostic)")
+    ap.add_argument("--channels-last", type=int, default=0, help="1: run the network in torch.channels_last (NHWC kernels)")
+    ap.add_argument("--benchmark", type=int, default=0, help="torch.backends.cudnn.benchmark (resnet/train.py:247 sets it)")
     ap.add_argument("--graph", type=int, default=0, help="1: replay the whole step (fwd+bwd+SGD) from one HIP graph")
     ap.add_argument("--backend", default=os.environ.get("MRLA_DIST_BACKEND", "nccl"))
     return ap.parse_args()
@@ -140,6 +142,7 @@ def main():
         print(f"warning: --gpus {args.gpus} but WORLD_SIZE={world}", file=sys.stderr)
 
     from mrla_amd import functional as Fm
+    torch.backends.cudnn.benchmark = bool(args.benchmark)
     torch.manual_seed(0)
     if args.eager:
         from oracle import eager_models as em
@@ -154,11 +157,16 @@ def main():
                 net = getattr(vit, args.arch)(drop_path_rate=args.drop_path)
             else:
                 net = getattr(models, args.arch)(drop_path=args.drop_path)
-    net = D.wrap_data_parallel(net.cuda().train(), device_ids=[local])
+    net = net.cuda().train()
+    if args.channels_last:
+        net = net.to(memory_format=torch.channels_last)
+    net = D.wrap_data_parallel(net, device_ids=[local])
     gx = torch.Generator(device="cuda").manual_seed(0)
     gy = torch.Generator(device="cuda").manual_seed(1)
     x = torch.randn(args.batch, 3, 224, 224, device="cuda", generator=gx)
     y = torch.randint(0, 1000, (args.batch,), device="cuda", generator=gy)
+    if args.channels_last:
+        x = x.contiguous(memory_format=torch.channels_last)
     step = make_step(net, sgd(net.parameters()), x, y)
 
     # warm-up without the timer, then the timed region with HIP-event timing of the dominant kernel

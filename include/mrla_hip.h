@@ -35,7 +35,7 @@ extern "C" {
 #define MRLA_EHIP (-3)          /* the HIP runtime reported an error at launch */
 
 enum { MRLA_F32 = 0, MRLA_BF16 = 1, MRLA_F16 = 2 };
-enum { MRLA_NCHW = 0, MRLA_NHWC = 1 };
+enum { MRLA_NCHW = 0, MRLA_NHWC = 1 };   /* NHWC = torch.channels_last: x[b,h,w,c], dims are still passed as b,c,h,w */
 enum { MRLA_ACT_NONE = 0, MRLA_ACT_GELU = 1 };
 enum { MRLA_BN_NONE = 0, MRLA_BN_TRAIN = 1, MRLA_BN_EVAL = 2 };
 
@@ -221,7 +221,10 @@ int mrla_token_ln_bwd(const void* dout, const void* x, const void* o_prev, const
  *   forward : mrla_bn_plane_moments -> mrla_bn_stats_fwd -> mrla_bn_act_fwd      y  = relu?(sc*x + sh)
  *   backward: mrla_bn_plane_dmoments -> mrla_bn_stats_bwd -> mrla_bn_act_bwd     dx = e*dz + f*x + h, dz = dy*[y>0]
  * ===================================================================================================== */
-int mrla_bn_plane_moments(const void* x, float* amom /*[b,c,2]: sum x, sum x^2*/, int b, int c, int h, int w, int dtype,
+/* Rows of the partial-moment buffers written by mrla_bn_plane_moments / _dmoments: b for NCHW, b*nsplit for NHWC
+ * (pixels of an image are split over nsplit workgroups).  Pass (rows, b*h*w/rows) as (b, hw) to mrla_bn_stats_*. */
+int mrla_bn_moment_rows(int b, int c, int h, int w, int layout);
+int mrla_bn_plane_moments(const void* x, float* amom /*[rows,c,2]: sum x, sum x^2*/, int b, int c, int h, int w, int dtype,
                           int layout, void* stream);
 int mrla_bn_act_fwd(const void* x, const float* sc, const float* sh, int relu, void* y, int b, int c, int h, int w,
                     int dtype, int layout, void* stream);

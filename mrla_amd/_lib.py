@@ -49,6 +49,7 @@ SIGNATURES = {
     "mrla_token_stats_bwd": [_P] * 7 + [_I] * 4 + [_P],
     "mrla_token_apply_bwd": [_P] * 14 + [_I] * 5 + [_P],
     "mrla_token_ln_bwd": [_P] * 10 + [_I] * 5 + [_P],
+    "mrla_bn_moment_rows": [_I] * 5,
     "mrla_bn_plane_moments": [_P, _P, _I, _I, _I, _I, _I, _I, _P],
     "mrla_bn_act_fwd": [_P, _P, _P, _I, _P, _I, _I, _I, _I, _I, _I, _P],
     "mrla_bn_plane_dmoments": [_P, _P, _P, _P, _I, _P, _I, _I, _I, _I, _I, _I, _P],

@@ -67,17 +67,25 @@ int mrla_abi_version(void) { return 1; }
 
 int mrla_light_wgrad_rows(int b, int c, int h, int w, int dtype, int layout) {
   if (bad_dims(b, c, h, w) || bad_dtype(dtype)) return MRLA_EINVAL;
-  if (layout != MRLA_NCHW) return MRLA_EUNSUPPORTED;
+  if (layout == MRLA_NHWC) { const int bg = nhwc_images_per_group(b, c); return (b + bg - 1) / bg; }
+  if (layout != MRLA_NCHW) return MRLA_EINVAL;
   SlabGeo g;
   const int rc = light_geo(&g, b, c, h, w, dtype);
   if (rc != MRLA_OK) return rc;
   return (b + g.BG - 1) / g.BG;
 }
 
+int mrla_bn_moment_rows(int b, int c, int h, int w, int layout) {
+  if (bad_dims(b, c, h, w)) return MRLA_EINVAL;
+  return layout == MRLA_NHWC ? b * nhwc_bn_splits(b, c, h * w) : b;
+}
+
 int mrla_light_stats_fwd(const void* x, const void* o_prev, const float* wv, float* mom, int b, int c, int h, int w,
                          int dtype, int layout, int act, void* stream) {
   if (!x || !wv || !mom || bad_dims(b, c, h, w) || bad_dtype(dtype)) return MRLA_EINVAL;
-  if (layout != MRLA_NCHW) return MRLA_EUNSUPPORTED;
+  if (layout == MRLA_NHWC)
+    return launch_light_stats_fwd_nhwc(x, o_prev, wv, mom, nullptr, b, c, h, w, dtype, act, (hipStream_t)stream);
+  if (layout != MRLA_NCHW) return MRLA_EINVAL;
   SlabGeo g;
   const int rc = light_geo(&g, b, c, h, w, dtype);
   if (rc != MRLA_OK) return rc;
@@ -87,7 +95,9 @@ int mrla_light_stats_fwd(const void* x, const void* o_prev, const float* wv, flo
 int mrla_light_stats_fwd_fused(const void* pre, const void* o_prev, const float* wv, float* mom, void* x_out, int b,
                                int c, int h, int w, int dtype, int layout, void* stream) {
   if (!pre || !o_prev || !wv || !mom || !x_out || bad_dims(b, c, h, w) || bad_dtype(dtype)) return MRLA_EINVAL;
-  if (layout != MRLA_NCHW) return MRLA_EUNSUPPORTED;
+  if (layout == MRLA_NHWC)
+    return launch_light_stats_fwd_nhwc(pre, o_prev, wv, mom, x_out, b, c, h, w, dtype, MRLA_ACT_NONE, (hipStream_t)stream);
+  if (layout != MRLA_NCHW) return MRLA_EINVAL;
   SlabGeo g;
   const int rc = light_geo(&g, b, c, h, w, dtype);
   if (rc != MRLA_OK) return rc;
@@ -116,7 +126,10 @@ int mrla_light_apply_fwd(const void* x, const void* o_prev, const float* wv, con
                          int d, int res, int dtype, int layout, int act, void* stream) {
   if (!x || !wv || !gate || !out || bad_dims(b, c, h, w) || bad_dtype(dtype) || d <= 0 || c % d) return MRLA_EINVAL;
   if (o_prev && !lam) return MRLA_EINVAL;
-  if (layout != MRLA_NCHW) return MRLA_EUNSUPPORTED;
+  if (layout == MRLA_NHWC)
+    return launch_light_apply_fwd_nhwc(x, o_prev, wv, gate, sc, sh, lam, dp, out, b, c, h, w, d, res, dtype, act,
+                                       (hipStream_t)stream);
+  if (layout != MRLA_NCHW) return MRLA_EINVAL;
   SlabGeo g;
   const int rc = light_geo(&g, b, c, h, w, dtype);
   if (rc != MRLA_OK) return rc;
@@ -127,7 +140,9 @@ int mrla_light_apply_fwd(const void* x, const void* o_prev, const float* wv, con
 int mrla_light_stats_bwd(const void* dout, const void* x, const void* o_prev, const float* wv, float* bmom, int b,
                          int c, int h, int w, int dtype, int layout, int act, void* stream) {
   if (!dout || !x || !wv || !bmom || bad_dims(b, c, h, w) || bad_dtype(dtype)) return MRLA_EINVAL;
-  if (layout != MRLA_NCHW) return MRLA_EUNSUPPORTED;
+  if (layout == MRLA_NHWC)
+    return launch_light_stats_bwd_nhwc(dout, x, o_prev, wv, bmom, b, c, h, w, dtype, act, (hipStream_t)stream);
+  if (layout != MRLA_NCHW) return MRLA_EINVAL;
   SlabGeo g;
   const int rc = light_geo(&g, b, c, h, w, dtype);
   if (rc != MRLA_OK) return rc;
@@ -162,7 +177,10 @@ int mrla_light_apply_bwd(const void* dout, const void* x, const void* o_prev, co
     return MRLA_EINVAL;
   if (o_prev && (!lam || !do_prev)) return MRLA_EINVAL;
   if (relu_mask && (!o_prev || act != MRLA_ACT_NONE)) return MRLA_EINVAL;
-  if (layout != MRLA_NCHW) return MRLA_EUNSUPPORTED;
+  if (layout == MRLA_NHWC)
+    return launch_light_apply_bwd_nhwc(dout, x, o_prev, wv, gate, cb, lam, dp, dyx, dx, do_prev, dwv_part, b, c, h, w, d,
+                                       res, relu_mask, dtype, act, (hipStream_t)stream);
+  if (layout != MRLA_NCHW) return MRLA_EINVAL;
   SlabGeo g;
   const int rc = light_geo(&g, b, c, h, w, dtype);
   if (rc != MRLA_OK) return rc;
@@ -323,28 +341,36 @@ int mrla_token_ln_bwd(const void* dout, const void* x, const void* o_prev, const
 
 int mrla_bn_plane_moments(const void* x, float* amom, int b, int c, int h, int w, int dtype, int layout, void* stream) {
   if (!x || !amom || bad_dims(b, c, h, w) || bad_dtype(dtype)) return MRLA_EINVAL;
-  if (layout != MRLA_NCHW) return MRLA_EUNSUPPORTED;
+  if (layout == MRLA_NHWC)
+    return launch_nhwc_moments(x, nullptr, nullptr, nullptr, 0, amom, b, c, h * w, dtype, 0, (hipStream_t)stream);
+  if (layout != MRLA_NCHW) return MRLA_EINVAL;
   return launch_plane_moments(x, amom, b, c, h * w, dtype, (hipStream_t)stream);
 }
 
 int mrla_bn_act_fwd(const void* x, const float* sc, const float* sh, int relu, void* y, int b, int c, int h, int w,
                     int dtype, int layout, void* stream) {
   if (!x || !sc || !sh || !y || bad_dims(b, c, h, w) || bad_dtype(dtype)) return MRLA_EINVAL;
-  if (layout != MRLA_NCHW) return MRLA_EUNSUPPORTED;
+  if (layout == MRLA_NHWC)
+    return launch_nhwc_affine(x, nullptr, nullptr, sc, sh, relu, y, b, c, h * w, dtype, 0, (hipStream_t)stream);
+  if (layout != MRLA_NCHW) return MRLA_EINVAL;
   return launch_affine_act(x, nullptr, nullptr, sc, sh, relu, y, b, c, h * w, dtype, 0, (hipStream_t)stream);
 }
 
 int mrla_bn_plane_dmoments(const void* dy, const void* x, const float* sc, const float* sh, int relu, float* tmom, int b,
                            int c, int h, int w, int dtype, int layout, void* stream) {
   if (!dy || !x || !sc || !sh || !tmom || bad_dims(b, c, h, w) || bad_dtype(dtype)) return MRLA_EINVAL;
-  if (layout != MRLA_NCHW) return MRLA_EUNSUPPORTED;
+  if (layout == MRLA_NHWC)
+    return launch_nhwc_moments(x, dy, sc, sh, relu, tmom, b, c, h * w, dtype, 1, (hipStream_t)stream);
+  if (layout != MRLA_NCHW) return MRLA_EINVAL;
   return launch_plane_dmoments(dy, x, sc, sh, relu, tmom, b, c, h * w, dtype, (hipStream_t)stream);
 }
 
 int mrla_bn_act_bwd(const void* dy, const void* x, const float* sc, const float* sh, const float* cb, int relu,
                     void* dx, int b, int c, int h, int w, int dtype, int layout, void* stream) {
   if (!dy || !x || !sc || !sh || !cb || !dx || bad_dims(b, c, h, w) || bad_dtype(dtype)) return MRLA_EINVAL;
-  if (layout != MRLA_NCHW) return MRLA_EUNSUPPORTED;
+  if (layout == MRLA_NHWC)
+    return launch_nhwc_affine(x, dy, cb, sc, sh, relu, dx, b, c, h * w, dtype, 1, (hipStream_t)stream);
+  if (layout != MRLA_NCHW) return MRLA_EINVAL;
   return launch_affine_act(x, dy, cb, sc, sh, relu, dx, b, c, h * w, dtype, 1, (hipStream_t)stream);
 }
 

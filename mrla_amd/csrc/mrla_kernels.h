@@ -107,4 +107,24 @@ int launch_plane_dmoments(const void* dy, const void* x, const float* sc, const 
 int launch_affine_act(const void* x, const void* dy, const float* a, const float* sc, const float* sh, int relu,
                       void* out, int B, int C, int HW, int dtype, int bwd, hipStream_t st);
 
+
+// light_nhwc.hip / bnact_nhwc.hip -- channels_last variants
+int nhwc_images_per_group(int B, int C);
+int launch_light_stats_fwd_nhwc(const void* x, const void* o, const float* wv, float* mom, void* xout, int B, int C,
+                                int H, int W, int dtype, int act, hipStream_t st);
+int launch_light_apply_fwd_nhwc(const void* x, const void* o, const float* wv, const float* gate, const float* sc,
+                                const float* sh, const float* lam, const float* dp, void* out, int B, int C, int H,
+                                int W, int d, int res, int dtype, int act, hipStream_t st);
+int launch_light_stats_bwd_nhwc(const void* dout, const void* x, const void* o, const float* wv, float* bmom, int B,
+                                int C, int H, int W, int dtype, int act, hipStream_t st);
+int launch_light_apply_bwd_nhwc(const void* dout, const void* x, const void* o, const float* wv, const float* gate,
+                                const float* cb, const float* lam, const float* dp, const float* dyx, void* dx,
+                                void* dprev, float* dwv_part, int B, int C, int H, int W, int d, int res, int relu,
+                                int dtype, int act, hipStream_t st);
+int nhwc_bn_splits(int B, int C, int HW);
+int launch_nhwc_moments(const void* x, const void* dy, const float* sc, const float* sh, int relu, float* out, int B,
+                        int C, int HW, int dtype, int mode, hipStream_t st);
+int launch_nhwc_affine(const void* x, const void* dy, const float* a, const float* sc, const float* sh, int relu,
+                       void* out, int B, int C, int HW, int dtype, int bwd, hipStream_t st);
+
 }  // namespace mrla

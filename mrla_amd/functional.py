@@ -79,10 +79,20 @@ def _require_cuda(x, what):
         raise L.MrlaHipError(f"{what}: unsupported dtype {x.dtype}")
 
 
-def _layout_of(x):
-    """(layout enum, tensor to hand to the kernels).  NCHW-contiguous is the reference's contract."""
-    if x.is_contiguous():
-        return L.NCHW, x
+_CL = torch.channels_last
+
+
+def _layout_of(x, want=None):
+    """(layout enum, tensor to hand to the kernels).  NCHW-contiguous is the reference's contract; channels_last
+    (NHWC) tensors run on the NHWC kernels without any conversion.  `want` forces the layout of a second operand."""
+    if want is None:
+        if x.is_contiguous():
+            return L.NCHW, x
+        if x.dim() == 4 and x.is_contiguous(memory_format=_CL):
+            return L.NHWC, x
+        return L.NCHW, x.contiguous()
+    if want == L.NHWC:
+        return L.NHWC, x.contiguous(memory_format=_CL)
     return L.NCHW, x.contiguous()
 
 
@@ -115,7 +125,7 @@ class _LightFn(torch.autograd.Function):
         if o_prev is not None:
             if o_prev.shape != x.shape or o_prev.dtype != x.dtype:
                 raise L.MrlaHipError("o_prev must match x in shape and dtype")
-            oc = _layout_of(o_prev)[1]
+            oc = _layout_of(o_prev, layout)[1]
         dt = _DT[xc.dtype]
         dev = xc.device
         wq32, wk32 = _f32(wq).reshape(-1), _f32(wk).reshape(-1)
@@ -170,7 +180,7 @@ class _LightFn(torch.autograd.Function):
         st = _stream()
         if dout.dtype != xc.dtype:
             dout = dout.to(xc.dtype)
-        dout = dout.contiguous()
+        dout = _layout_of(dout, layout)[1]
 
         bmom = torch.empty((b, c, L.BWD_MOMENTS), dtype=torch.float32, device=dev)
         _call("mrla_light_stats_bwd", xc.numel() * xc.element_size() * (3 if oc is not None else 2), _ptr(dout), _ptr(xc), _ptr(oc), _ptr(wv32), _ptr(bmom), b, c, h, w, dt, layout,
@@ -292,7 +302,7 @@ class _BaseFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, identity, wq, wk, wv, gamma, beta, running_mean, running_var, dp, stage, cfg):
         _require_cuda(x, "mrla base forward")
-        layout, xc = _layout_of(x)
+        layout, xc = _layout_of(x, L.NCHW)          # the MRLA-base rings are NCHW
         b, c, h, w = xc.shape
         d = cfg.d
         if (b, c, h, w, d) != (stage.b, stage.c, stage.h, stage.w, stage.d) or xc.dtype != stage.dtype:
@@ -308,7 +318,7 @@ class _BaseFn(torch.autograd.Function):
 
         mom = torch.empty((b, c, L.FWD_MOMENTS), dtype=torch.float32, device=dev)
         if cfg.fuse:            # x is the pre-activation: x_t = relu(x + identity) formed by the pooling pass
-            idc = _layout_of(identity)[1]
+            idc = _layout_of(identity, L.NCHW)[1]
             pre, xc = xc, torch.empty_like(xc)
             _call("mrla_light_stats_fwd_fused", xc.numel() * xc.element_size() * 3, _ptr(pre), _ptr(idc), _ptr(wv32),
                   _ptr(mom), _ptr(xc), b, c, h, w, dt, layout, st)
@@ -484,21 +494,24 @@ class _BnActFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, gamma, beta, running_mean, running_var, training, momentum, eps, relu):
         _require_cuda(x, "fused bn/act forward")
-        xc = x.contiguous()
+        layout, xc = _layout_of(x)
         b, c, h, w = xc.shape
+        if layout == L.NHWC and c % (16 // xc.element_size()):
+            layout, xc = _layout_of(x, L.NCHW)           # the NHWC passes move 16-byte channel vectors
         dt, dev, st = _DT[xc.dtype], xc.device, _stream()
         gamma32, beta32 = _f32(gamma), _f32(beta)
         bnbuf = torch.empty((4, c), dtype=torch.float32, device=dev)       # sc, sh, save_mean, save_inv
-        amom = torch.empty((b, c, 2), dtype=torch.float32, device=dev)
+        rows = L.load().mrla_bn_moment_rows(b, c, h, w, layout)           # partial-sum rows (b, or b*nsplit for NHWC)
+        amom = torch.empty((rows, c, 2), dtype=torch.float32, device=dev)
         if training:
-            _call("mrla_bn_plane_moments", xc.numel() * xc.element_size(), _ptr(xc), _ptr(amom), b, c, h, w, dt, L.NCHW, st)
+            _call("mrla_bn_plane_moments", xc.numel() * xc.element_size(), _ptr(xc), _ptr(amom), b, c, h, w, dt, layout, st)
         L.call("mrla_bn_stats_fwd", _ptr(amom), _ptr(gamma32), _ptr(beta32), _ptr(running_mean), _ptr(running_var),
                L.BN_TRAIN if training else L.BN_EVAL, float(momentum), float(eps), _ptr(bnbuf[0]), _ptr(bnbuf[1]),
-               _ptr(bnbuf[2]), _ptr(bnbuf[3]), b, c, h * w, st)
+               _ptr(bnbuf[2]), _ptr(bnbuf[3]), rows, c, b * h * w // rows, st)
         y = torch.empty_like(xc)
         _call("mrla_bn_act_fwd", xc.numel() * xc.element_size() * 2, _ptr(xc), _ptr(bnbuf[0]), _ptr(bnbuf[1]), int(relu),
-              _ptr(y), b, c, h, w, dt, L.NCHW, st)
-        ctx.training, ctx.relu, ctx.gdtype = training, int(relu), gamma.dtype
+              _ptr(y), b, c, h, w, dt, layout, st)
+        ctx.training, ctx.relu, ctx.gdtype, ctx.layout, ctx.rows = training, int(relu), gamma.dtype, layout, rows
         ctx.save_for_backward(xc, gamma32, bnbuf)
         return y
 
@@ -509,18 +522,20 @@ class _BnActFn(torch.autograd.Function):
         dt, dev, st = _DT[xc.dtype], xc.device, _stream()
         if dy.dtype != xc.dtype:
             dy = dy.to(xc.dtype)
-        dy = dy.contiguous()
+        layout, rows = ctx.layout, ctx.rows
+        dy = _layout_of(dy, layout)[1]
         es = xc.element_size()
-        tmom = torch.empty((b, c, 2), dtype=torch.float32, device=dev)
+        tmom = torch.empty((rows, c, 2), dtype=torch.float32, device=dev)
         _call("mrla_bn_plane_dmoments", xc.numel() * es * 2, _ptr(dy), _ptr(xc), _ptr(bnbuf[0]), _ptr(bnbuf[1]), ctx.relu,
-              _ptr(tmom), b, c, h, w, dt, L.NCHW, st)
+              _ptr(tmom), b, c, h, w, dt, layout, st)
         small = torch.empty((5, c), dtype=torch.float32, device=dev)          # cb[c,3] | dgamma | dbeta
         cb = small[:3].view(c, 3)
         L.call("mrla_bn_stats_bwd", _ptr(tmom), _ptr(gamma32), _ptr(bnbuf[2]), _ptr(bnbuf[3]),
-               L.BN_TRAIN if ctx.training else L.BN_EVAL, _ptr(cb), _ptr(small[3]), _ptr(small[4]), b, c, h * w, st)
+               L.BN_TRAIN if ctx.training else L.BN_EVAL, _ptr(cb), _ptr(small[3]), _ptr(small[4]), rows, c,
+               b * h * w // rows, st)
         dx = torch.empty_like(xc)
         _call("mrla_bn_act_bwd", xc.numel() * es * 3, _ptr(dy), _ptr(xc), _ptr(bnbuf[0]), _ptr(bnbuf[1]), _ptr(cb), ctx.relu,
-              _ptr(dx), b, c, h, w, dt, L.NCHW, st)
+              _ptr(dx), b, c, h, w, dt, layout, st)
         return dx, small[3].to(ctx.gdtype), small[4].to(ctx.gdtype), None, None, None, None, None, None
 
 
@@ -528,7 +543,7 @@ def bn_act(x, bn, relu):
     """relu?(bn(x)) for an nn.BatchNorm2d module `bn` on the fused HIP passes; any other norm layer (or a layout /
     device the kernels do not handle) runs as the caller's module followed by torch.relu."""
     if (type(bn) is torch.nn.BatchNorm2d and bn.affine and bn.track_running_stats and x.is_cuda and x.dim() == 4
-            and x.dtype in _DT and x.is_contiguous()):
+            and x.dtype in _DT and (x.is_contiguous() or x.is_contiguous(memory_format=_CL))):
         training = bn.training
         momentum = bn.momentum
         if training and bn.num_batches_tracked is not None:

@@ -13,12 +13,14 @@ SHAPES = [(3, 64, 112, 112), (4, 64, 56, 56), (2, 128, 28, 28), (3, 256, 14, 14)
 @pytest.mark.parametrize("shape", SHAPES, ids=lambda s: "x".join(map(str, s)))
 @pytest.mark.parametrize("relu", [True, False])
 @pytest.mark.parametrize("training", [True, False])
-def test_bn_act_matches_torch(shape, relu, training):
+@pytest.mark.parametrize("cl", [False, True], ids=["nchw", "nhwc"])
+def test_bn_act_matches_torch(shape, relu, training, cl):
     from mrla_amd.functional import bn_act
     torch.manual_seed(0)
     b, c, h, w = shape
-    x = (torch.randn(shape, device="cuda") * 1.7 + 0.4)
-    g = torch.randn(shape, device="cuda")
+    fmt = torch.channels_last if cl else torch.contiguous_format
+    x = (torch.randn(shape, device="cuda") * 1.7 + 0.4).contiguous(memory_format=fmt)
+    g = torch.randn(shape, device="cuda").contiguous(memory_format=fmt)
     bn = torch.nn.BatchNorm2d(c).cuda()
     with torch.no_grad():
         bn.weight.uniform_(0.5, 1.5); bn.bias.uniform_(-0.3, 0.3)

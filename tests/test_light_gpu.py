@@ -28,10 +28,11 @@ def to_dev(a, dtype=torch.float32):
     return torch.from_numpy(np.ascontiguousarray(a)).to("cuda", dtype)
 
 
-def run_light(x, o, P, d, mode, dp_mask, p_drop, gup, dtype=torch.float32, rm=None, rv=None):
+def run_light(x, o, P, d, mode, dp_mask, p_drop, gup, dtype=torch.float32, rm=None, rv=None, cl=False):
     from mrla_amd.functional import mrla_light
-    xt = to_dev(x, dtype).requires_grad_(True)
-    ot = to_dev(o, dtype).requires_grad_(True)
+    fmt = torch.channels_last if cl else torch.contiguous_format
+    xt = to_dev(x, dtype).contiguous(memory_format=fmt).requires_grad_(True)
+    ot = to_dev(o, dtype).contiguous(memory_format=fmt).requires_grad_(True)
     prm = {k: to_dev(v).requires_grad_(True) for k, v in P.items() if "running" not in k}
     rmt = to_dev(P["bn_mrla.running_mean"] if rm is None else rm)
     rvt = to_dev(P["bn_mrla.running_var"] if rv is None else rv)
@@ -42,7 +43,9 @@ def run_light(x, o, P, d, mode, dp_mask, p_drop, gup, dtype=torch.float32, rm=No
                      o_prev=ot, lam=prm["mrla.lambda_t"],
                      bn=dict(weight=prm["bn_mrla.weight"], bias=prm["bn_mrla.bias"], running_mean=rmt, running_var=rvt,
                              training=(mode != "eval"), momentum=0.1, eps=1e-5), dp=dp, res=True)
-    out.backward(to_dev(gup, dtype))
+    if cl:
+        assert out.is_contiguous(memory_format=torch.channels_last)
+    out.backward(to_dev(gup, dtype).contiguous(memory_format=fmt))
     torch.cuda.synchronize()
     g = dict(out=out.detach().float().cpu().numpy(), dx=xt.grad.float().cpu().numpy(), do=ot.grad.float().cpu().numpy(),
              rm=rmt.cpu().numpy(), rv=rvt.cpu().numpy())
@@ -65,14 +68,15 @@ def oracle_light(x, o, P, d, mode, dp_mask, p_drop, gup):
 
 @pytest.mark.parametrize("case", cases.LIGHT_CASES, ids=lambda c: c[0])
 @pytest.mark.parametrize("mode", ["train", "eval", "traindp"])
-def test_light_tail_fp32_vs_oracle_and_reference(case, mode):
+@pytest.mark.parametrize("cl", [False, True], ids=["nchw", "nhwc"])
+def test_light_tail_fp32_vs_oracle_and_reference(case, mode, cl):
     name, b, c, h, w, d = case
     G = cases.golden("light_blocks")
     x, o, gup = cases.light_inputs(name, b, c, h, w)
     P = cases.block_params(c, 1)
     key = f"{name}/{mode}/"
     mask = G[key + "dp_mask"] if mode == "traindp" else None
-    got = run_light(x, o, P, d, mode, mask, 0.25, gup)
+    got = run_light(x, o, P, d, mode, mask, 0.25, gup, cl=cl)
     out, cache, g = oracle_light(x, o, P, d, mode, mask, 0.25, gup)
     assert relmax(got["out"], out) < ACT_TOL
     assert relmax(got["dx"], g["dx"]) < ACT_TOL
@@ -110,7 +114,8 @@ STAGE_SHAPES = [(4, 256, 56, 56, 32), (4, 512, 28, 28, 32), (4, 1024, 14, 14, 32
 
 @pytest.mark.parametrize("shape", STAGE_SHAPES, ids=lambda s: "x".join(map(str, s[:4])))
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16], ids=["fp32", "bf16"])
-def test_light_tail_resnet50_stage_shapes(shape, dtype):
+@pytest.mark.parametrize("cl", [False, True], ids=["nchw", "nhwc"])
+def test_light_tail_resnet50_stage_shapes(shape, dtype, cl):
     b, c, h, w, d = shape
     from oracle import detgen
     s = detgen.seed_of(f"stage/{c}")
@@ -121,7 +126,7 @@ def test_light_tail_resnet50_stage_shapes(shape, dtype):
     mask = np.array(([1, 0, 1, 1] * 5)[:b], dtype=np.float32)
     if dtype == torch.bfloat16:
         x, o, gup = bf16_round(x), bf16_round(o), bf16_round(gup)
-    got = run_light(x, o, P, d, "train", mask, 0.2, gup, dtype)
+    got = run_light(x, o, P, d, "train", mask, 0.2, gup, dtype, cl=cl)
     out, cache, g = oracle_light(x, o, P, d, "train", mask, 0.2, gup)
     if dtype == torch.float32:
         assert relmax(got["out"], out) < ACT_TOL
@@ -141,21 +146,26 @@ def test_fused_relu_add_producer_fp32_and_bf16():
     gradient wrt `pre` and the total gradient wrt the identity (resnet_mrla_light.py:113-116 as one op)."""
     from mrla_amd.functional import mrla_light
     from oracle import detgen
-    for dtype, (b, c, h, w, d) in ((torch.float32, (2, 256, 7, 5, 32)), (torch.float32, (3, 256, 56, 56, 32)),
-                                   (torch.bfloat16, (3, 512, 28, 28, 32)), (torch.bfloat16, (2, 2048, 7, 7, 32))):
+    for dtype, (b, c, h, w, d), cl in ((torch.float32, (2, 256, 7, 5, 32), False), (torch.float32, (3, 256, 56, 56, 32), False),
+                                       (torch.bfloat16, (3, 512, 28, 28, 32), False), (torch.bfloat16, (2, 2048, 7, 7, 32), False),
+                                       (torch.float32, (2, 256, 7, 5, 32), True), (torch.float32, (3, 256, 56, 56, 32), True),
+                                       (torch.bfloat16, (3, 512, 28, 28, 32), True), (torch.bfloat16, (2, 2048, 7, 7, 32), True),
+                                       (torch.float32, (2, 64, 9, 17, 32), True)):
+        fmt = torch.channels_last if cl else torch.contiguous_format
         s = detgen.seed_of(f"fuse/{c}/{h}")
         pre, o, gup = (detgen.normalish((b, c, h, w), s + i) for i in range(3))
         if dtype == torch.bfloat16:
             pre, o, gup = bf16_round(pre), bf16_round(o), bf16_round(gup)
         P = cases.block_params(c, 5)
-        pt, ot = to_dev(pre, dtype).requires_grad_(True), to_dev(o, dtype).requires_grad_(True)
+        pt = to_dev(pre, dtype).contiguous(memory_format=fmt).requires_grad_(True)
+        ot = to_dev(o, dtype).contiguous(memory_format=fmt).requires_grad_(True)
         prm = {k: to_dev(v).requires_grad_(True) for k, v in P.items() if "running" not in k}
         rm, rv = to_dev(P["bn_mrla.running_mean"]), to_dev(P["bn_mrla.running_var"])
         out = mrla_light(pt, prm["mrla.mrla.Wq.weight"], prm["mrla.mrla.Wk.weight"], prm["mrla.mrla.Wv.weight"], d, o_prev=ot,
                          lam=prm["mrla.lambda_t"], bn=dict(weight=prm["bn_mrla.weight"], bias=prm["bn_mrla.bias"],
                                                            running_mean=rm, running_var=rv, training=True), res=True,
                          pre_activation=True)
-        out.backward(to_dev(gup, dtype))
+        out.backward(to_dev(gup, dtype).contiguous(memory_format=fmt))
         x = pre.astype(np.float64) + o
         if dtype == torch.bfloat16:
             x = bf16_round(x).astype(np.float64)

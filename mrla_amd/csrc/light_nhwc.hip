@@ -11,6 +11,8 @@
 //     workgroup through LDS, in a fixed order (bitwise reproducible).
 // A workgroup = (image group, 64-channel chunk); its waves = column strips.  ResNet stage widths 56/28/14/7 give
 // 8/4/2/1 strips of exactly 7 columns.
+#include <algorithm>
+
 #include "mrla_device.h"
 #include "mrla_kernels.h"
 
@@ -24,6 +26,84 @@ __device__ __forceinline__ float ldpix(const T* __restrict__ img, int r, int col
   // wave-uniform predicate: all lanes look at the same pixel
   if (r < 0 || r >= H || col < 0 || col >= W) return 0.f;
   return to_f(img[((size_t)r * W + col) * C + c]);
+}
+
+// ---- wide row access -------------------------------------------------------------------------------------------
+// A 2-byte-per-lane access costs the texture-addresser as much as a 16-byte one, so rows are fetched with 16 B per
+// lane (lane = (pixel, 8-channel group): one wave-instruction = 8 pixels x 64 channels) and re-distributed to the
+// LANE = CHANNEL compute mapping through a wave-private LDS scratch (ds_write_b128, then one ds_read_u16 per pixel).
+// Needs C % 64 == 0 (the chunk is 64 real channels, 16-byte aligned); otherwise the kernels use ldpix().
+// bytes per gather / scatter buffer: the widest row piece is kS+4 = 11 pixels x 64 channels, in whole 1 KiB loads
+template <typename T> constexpr int scratch_bytes() { return 1024 * ((11 * 64 * (int)sizeof(T) + 1023) / 1024); }
+
+// A row piece in flight: the 16-byte loads have been issued, nothing has been waited for yet.
+template <typename T, int NPX>
+struct RowLoad {
+  static constexpr int VEC = 16 / sizeof(T);
+  static constexpr int UPP = 64 / VEC;          // lanes per pixel
+  static constexpr int PPL = 64 / UPP;          // pixels per wave-instruction
+  static constexpr int NL = (NPX + PPL - 1) / PPL;
+  u32x4 regs[NL];
+  bool live;                                    // wave-uniform: row inside the image
+};
+
+template <typename T, int NPX>
+__device__ __forceinline__ void issue_row(RowLoad<T, NPX>& q, const T* __restrict__ img, int r, int col0, int H, int W,
+                                          int C, int cbase, int lane) {
+  typedef RowLoad<T, NPX> Q;
+  static_assert(Q::NL * 1024 <= scratch_bytes<T>(), "scratch too small");
+  q.live = r >= 0 && r < H;
+  const int px = lane / Q::UPP, part = lane - px * Q::UPP;
+#pragma unroll
+  for (int l = 0; l < Q::NL; ++l) {
+    const int p = l * Q::PPL + px, col = col0 + p;
+    q.regs[l] = (u32x4){0u, 0u, 0u, 0u};
+    if (q.live && p < NPX && col >= 0 && col < W)
+      q.regs[l] = *reinterpret_cast<const u32x4*>(img + ((size_t)r * W + col) * C + cbase + part * Q::VEC);
+  }
+}
+
+template <typename T, int NPX>
+__device__ __forceinline__ void finish_row(const RowLoad<T, NPX>& q, int lane, T* __restrict__ scratch, float (&out)[NPX]) {
+  typedef RowLoad<T, NPX> Q;
+  if (!q.live) {                                // wave-uniform
+#pragma unroll
+    for (int j = 0; j < NPX; ++j) out[j] = 0.f;
+    return;
+  }
+  u32x4* s4 = reinterpret_cast<u32x4*>(scratch);
+#pragma unroll
+  for (int l = 0; l < Q::NL; ++l) s4[l * kWave + lane] = q.regs[l];
+#pragma unroll
+  for (int j = 0; j < NPX; ++j) out[j] = to_f(scratch[j * kWave + lane]);
+}
+
+template <typename T, int NPX>
+__device__ __forceinline__ void gather_row(const T* __restrict__ img, int r, int col0, int H, int W, int C, int cbase,
+                                           int lane, T* __restrict__ scratch, float (&out)[NPX]) {
+  RowLoad<T, NPX> q;
+  issue_row<T, NPX>(q, img, r, col0, H, W, C, cbase, lane);
+  finish_row<T, NPX>(q, lane, scratch, out);
+}
+
+// lane = channel values v[j] of pixels col0 .. col0+npx-1 of row r -> global, 16 B per lane
+template <typename T, int NPX>
+__device__ __forceinline__ void scatter_row(T* __restrict__ img, int r, int col0, int npx, int W, int C, int cbase,
+                                            int lane, T* __restrict__ scratch, const float (&v)[NPX]) {
+  constexpr int VEC = 16 / sizeof(T);
+  constexpr int UPP = 64 / VEC;
+  constexpr int PPL = 64 / UPP;
+  constexpr int NL = (NPX + PPL - 1) / PPL;
+#pragma unroll
+  for (int j = 0; j < NPX; ++j) scratch[j * kWave + lane] = from_f<T>(v[j]);
+  const u32x4* s4 = reinterpret_cast<const u32x4*>(scratch);
+  const int px = lane / UPP, part = lane - px * UPP;
+#pragma unroll
+  for (int l = 0; l < NL; ++l) {
+    const int p = l * PPL + px;
+    if (p < npx)
+      *reinterpret_cast<u32x4*>(img + ((size_t)r * W + col0 + p) * C + cbase + part * VEC) = s4[l * kWave + lane];
+  }
 }
 
 __device__ __forceinline__ float conv_at(const float (&w)[9], const float* __restrict__ ra, const float* __restrict__ rb,
@@ -53,18 +133,54 @@ __device__ __forceinline__ void wg_reduce(float (&acc)[K], float* __restrict__ r
   }
 }
 
+// Row readers / writers used by the kernels: WIDE -> 16-byte accesses through the wave-private scratch, else ldpix().
+template <typename T, bool WIDE, int NPX>
+__device__ __forceinline__ void read_row(const T* __restrict__ img, int r, int col0, int H, int W, int C, int cbase,
+                                         int cc, int lane, T* __restrict__ scratch, float (&out)[NPX]) {
+  if constexpr (WIDE) {
+    gather_row<T, NPX>(img, r, col0, H, W, C, cbase, lane, scratch, out);
+  } else {
+#pragma unroll
+    for (int j = 0; j < NPX; ++j) out[j] = ldpix(img, r, col0 + j, H, W, C, cc);
+  }
+}
+template <typename T, bool WIDE, int NPX>
+__device__ __forceinline__ void write_row(T* __restrict__ img, int r, int col0, int npx, int W, int C, int cbase, int c,
+                                          bool cv, int lane, T* __restrict__ scratch, const float (&v)[NPX]) {
+  if constexpr (WIDE) {
+    scatter_row<T, NPX>(img, r, col0, npx, W, C, cbase, lane, scratch, v);
+  } else {
+#pragma unroll
+    for (int j = 0; j < NPX; ++j)
+      if (j < npx && cv) img[((size_t)r * W + col0 + j) * C + c] = from_f<T>(v[j]);
+  }
+}
+
+#define MRLA_NHWC_PROLOGUE(NRED)                                                                          \
+  extern __shared__ __align__(16) unsigned char smem_raw[];                                               \
+  const int lane = threadIdx.x & (kWave - 1), wave = threadIdx.x / kWave, nwaves = blockDim.x / kWave;    \
+  float* red = reinterpret_cast<float*>(smem_raw);                                                        \
+  T* scr = reinterpret_cast<T*>(smem_raw + (size_t)nwaves * (NRED) * kWave * sizeof(float) +              \
+                                (size_t)wave * kScrBufs * scratch_bytes<T>());                                 \
+  const int cbase = blockIdx.x * kWave;                                                                   \
+  const int c = cbase + lane;                                                                             \
+  const bool cv = c < C;                                                                                  \
+  const int cc = cv ? c : C - 1;                                                                          \
+  const int nstrips = (W + kS - 1) / kS;                                                                  \
+  (void)red; (void)scr;
+// scratch buffers per wave: one for gathers, one for scatters (LDS operations of a wave execute in order, so a buffer
+// can be re-filled right after its previous contents were read back)
+constexpr int kScrBufs = 2;
+#define SCR(i) (scr + ((i) >= 3 ? 1 : 0) * (scratch_bytes<T>() / (int)sizeof(T)))
+
 // ------------------------------------------------------------------------------------------------
 // forward statistics (+ optional fused producer x = relu(pre + o))
 // ------------------------------------------------------------------------------------------------
-template <typename T, bool GELU, bool HAS_O, bool FUSE>
-__global__ __launch_bounds__(kMaxStrips * kWave) void light_stats_fwd_nhwc(const T* __restrict__ x, const T* __restrict__ o, const float* __restrict__ wv,
-                                     float* __restrict__ mom, T* __restrict__ xout, int B, int C, int H, int W, int BG) {
-  extern __shared__ float red[];
-  const int lane = threadIdx.x & (kWave - 1), wave = threadIdx.x / kWave, nwaves = blockDim.x / kWave;
-  const int c = blockIdx.x * kWave + lane;
-  const bool cv = c < C;
-  const int cc = cv ? c : C - 1;
-  const int nstrips = (W + kS - 1) / kS;
+template <typename T, bool GELU, bool HAS_O, bool FUSE, bool WIDE>
+__global__ __launch_bounds__(kMaxStrips * kWave) void light_stats_fwd_nhwc(
+    const T* __restrict__ x, const T* __restrict__ o, const float* __restrict__ wv, float* __restrict__ mom,
+    T* __restrict__ xout, int B, int C, int H, int W, int BG) {
+  MRLA_NHWC_PROLOGUE(M_N)
   float w[9];
 #pragma unroll
   for (int k = 0; k < 9; ++k) w[k] = wv[cc * 9 + k];
@@ -78,24 +194,40 @@ __global__ __launch_bounds__(kMaxStrips * kWave) void light_stats_fwd_nhwc(const
     for (int s = wave; s < nstrips; s += nwaves) {
       const int s0 = s * kS, nc = min(kS, W - s0);
       float ra[kS + 2], rb[kS + 2], rc[kS + 2];        // x rows r-1, r, r+1 over columns s0-1 .. s0+kS
-      auto load_row = [&](int r, float* dst) {
+      float ob[kS + 2], oc[kS + 2];                    // o rows r, r+1 (same columns)
+      // row pieces of the NEXT load_row() call are already in flight (WIDE): software pipeline of depth one row
+      RowLoad<T, kS + 2> qx, qo;
+      if (WIDE) {
+        issue_row<T, kS + 2>(qx, xi, 0, s0 - 1, H, W, C, cbase, lane);
+        if (HAS_O) issue_row<T, kS + 2>(qo, oi, 0, s0 - 1, H, W, C, cbase, lane);
+      }
+      // loads row r into (dst, odst); FUSE forms x = relu(pre + o) and stores the owned pixels to xout
+      auto load_row = [&](int r, float (&dst)[kS + 2], float (&odst)[kS + 2]) {
+        if (WIDE) {
+          finish_row<T, kS + 2>(qx, lane, SCR(0), dst);
+          if (HAS_O) finish_row<T, kS + 2>(qo, lane, SCR(1), odst);
+          issue_row<T, kS + 2>(qx, xi, r + 1, s0 - 1, H, W, C, cbase, lane);
+          if (HAS_O) issue_row<T, kS + 2>(qo, oi, r + 1, s0 - 1, H, W, C, cbase, lane);
+        } else {
+          read_row<T, false, kS + 2>(xi, r, s0 - 1, H, W, C, cbase, cc, lane, SCR(0), dst);
+          if (HAS_O) read_row<T, false, kS + 2>(oi, r, s0 - 1, H, W, C, cbase, cc, lane, SCR(1), odst);
+        }
+        if (FUSE) {
 #pragma unroll
-        for (int j = 0; j < kS + 2; ++j) {
-          const int col = s0 - 1 + j;
-          float v = ldpix(xi, r, col, H, W, C, cc);
-          if (FUSE) {
-            const bool in = r >= 0 && r < H && col >= 0 && col < W;
-            v = in ? fmaxf(to_f(from_f<T>(v + ldpix(oi, r, col, H, W, C, cc))), 0.f) : 0.f;
-            if (in && j >= 1 && j <= nc && cv) xo[((size_t)r * W + col) * C + c] = from_f<T>(v);
+          for (int j = 0; j < kS + 2; ++j) dst[j] = fmaxf(to_f(from_f<T>(dst[j] + odst[j])), 0.f);   // zeros stay zeros
+          if (r >= 0 && r < H) {
+            float own[kS];
+#pragma unroll
+            for (int j = 0; j < kS; ++j) own[j] = dst[j + 1];
+            write_row<T, WIDE, kS>(xo, r, s0, nc, W, C, cbase, c, cv, lane, SCR(3), own);
           }
-          dst[j] = v;
         }
       };
 #pragma unroll
       for (int j = 0; j < kS + 2; ++j) ra[j] = 0.f;
-      load_row(0, rb);
+      load_row(0, rb, ob);
       for (int r = 0; r < H; ++r) {
-        load_row(r + 1, rc);
+        load_row(r + 1, rc, oc);
 #pragma unroll
         for (int j = 0; j < kS; ++j) {
           if (j < nc) {
@@ -105,7 +237,7 @@ __global__ __launch_bounds__(kMaxStrips * kWave) void light_stats_fwd_nhwc(const
             acc[M_SV] += v;
             acc[M_SVV] = fmaf(v, v, acc[M_SVV]);
             if (HAS_O) {
-              const float ov = to_f(oi[((size_t)r * W + s0 + j) * C + cc]);
+              const float ov = ob[j + 1];
               acc[M_SO] += ov;
               acc[M_SVO] = fmaf(v, ov, acc[M_SVO]);
               acc[M_SOO] = fmaf(ov, ov, acc[M_SOO]);
@@ -113,7 +245,7 @@ __global__ __launch_bounds__(kMaxStrips * kWave) void light_stats_fwd_nhwc(const
           }
         }
 #pragma unroll
-        for (int j = 0; j < kS + 2; ++j) { ra[j] = rb[j]; rb[j] = rc[j]; }
+        for (int j = 0; j < kS + 2; ++j) { ra[j] = rb[j]; rb[j] = rc[j]; ob[j] = oc[j]; }
       }
     }
     wg_reduce<M_N>(acc, red, lane, wave, nwaves);
@@ -127,17 +259,12 @@ __global__ __launch_bounds__(kMaxStrips * kWave) void light_stats_fwd_nhwc(const
 // ------------------------------------------------------------------------------------------------
 // forward apply:  out = res*x + A*V + B*o + C
 // ------------------------------------------------------------------------------------------------
-template <typename T, bool GELU, bool HAS_O>
-__global__ __launch_bounds__(kMaxStrips * kWave) void light_apply_fwd_nhwc(const T* __restrict__ x, const T* __restrict__ o, const float* __restrict__ wv,
-                                     const float* __restrict__ gate, const float* __restrict__ sc,
-                                     const float* __restrict__ sh, const float* __restrict__ lam,
-                                     const float* __restrict__ dp, T* __restrict__ out, int B, int C, int H, int W,
-                                     int BG, int d, int res) {
-  const int lane = threadIdx.x & (kWave - 1), wave = threadIdx.x / kWave, nwaves = blockDim.x / kWave;
-  const int c = blockIdx.x * kWave + lane;
-  const bool cv = c < C;
-  const int cc = cv ? c : C - 1;
-  const int nstrips = (W + kS - 1) / kS;
+template <typename T, bool GELU, bool HAS_O, bool WIDE>
+__global__ __launch_bounds__(kMaxStrips * kWave) void light_apply_fwd_nhwc(
+    const T* __restrict__ x, const T* __restrict__ o, const float* __restrict__ wv, const float* __restrict__ gate,
+    const float* __restrict__ sc, const float* __restrict__ sh, const float* __restrict__ lam,
+    const float* __restrict__ dp, T* __restrict__ out, int B, int C, int H, int W, int BG, int d, int res) {
+  MRLA_NHWC_PROLOGUE(0)
   const int G = C / d;
   float w0[9];
 #pragma unroll
@@ -162,21 +289,32 @@ __global__ __launch_bounds__(kMaxStrips * kWave) void light_apply_fwd_nhwc(const
       const int s0 = s * kS, nc = min(kS, W - s0);
       float ra[kS + 2], rb[kS + 2], rc[kS + 2];
 #pragma unroll
-      for (int j = 0; j < kS + 2; ++j) { ra[j] = 0.f; rb[j] = ldpix(xi, 0, s0 - 1 + j, H, W, C, cc); }
+      for (int j = 0; j < kS + 2; ++j) ra[j] = 0.f;
+      read_row<T, WIDE, kS + 2>(xi, 0, s0 - 1, H, W, C, cbase, cc, lane, SCR(0), rb);
+      RowLoad<T, kS + 2> qx;
+      RowLoad<T, kS> qo;
+      if (WIDE) {
+        issue_row<T, kS + 2>(qx, xi, 1, s0 - 1, H, W, C, cbase, lane);
+        if (HAS_O) issue_row<T, kS>(qo, oi, 0, s0, H, W, C, cbase, lane);
+      }
       for (int r = 0; r < H; ++r) {
-#pragma unroll
-        for (int j = 0; j < kS + 2; ++j) rc[j] = ldpix(xi, r + 1, s0 - 1 + j, H, W, C, cc);
+        float ov[kS], y[kS];
+        if (WIDE) {
+          finish_row<T, kS + 2>(qx, lane, SCR(0), rc);
+          if (HAS_O) finish_row<T, kS>(qo, lane, SCR(1), ov);
+          issue_row<T, kS + 2>(qx, xi, r + 2, s0 - 1, H, W, C, cbase, lane);
+          if (HAS_O) issue_row<T, kS>(qo, oi, r + 1, s0, H, W, C, cbase, lane);
+        } else {
+          read_row<T, false, kS + 2>(xi, r + 1, s0 - 1, H, W, C, cbase, cc, lane, SCR(0), rc);
+          if (HAS_O) read_row<T, false, kS>(oi, r, s0, H, W, C, cbase, cc, lane, SCR(1), ov);
+        }
 #pragma unroll
         for (int j = 0; j < kS; ++j) {
-          if (j < nc) {
-            const size_t e = ((size_t)r * W + s0 + j) * C + cc;
-            float y;
-            if (GELU) y = fmaf(A, gelu_f(conv_at(w, ra, rb, rc, j)), fmaf(resf, rb[j + 1], Cc));
-            else      y = conv_at(w, ra, rb, rc, j) + Cc;
-            if (HAS_O) y = fmaf(Bc, to_f(oi[e]), y);
-            if (cv) yo[e] = from_f<T>(y);
-          }
+          if (GELU) y[j] = fmaf(A, gelu_f(conv_at(w, ra, rb, rc, j)), fmaf(resf, rb[j + 1], Cc));
+          else      y[j] = conv_at(w, ra, rb, rc, j) + Cc;
+          if (HAS_O) y[j] = fmaf(Bc, ov[j], y[j]);
         }
+        write_row<T, WIDE, kS>(yo, r, s0, nc, W, C, cbase, c, cv, lane, SCR(3), y);
 #pragma unroll
         for (int j = 0; j < kS + 2; ++j) { ra[j] = rb[j]; rb[j] = rc[j]; }
       }
@@ -187,16 +325,11 @@ __global__ __launch_bounds__(kMaxStrips * kWave) void light_apply_fwd_nhwc(const
 // ------------------------------------------------------------------------------------------------
 // backward statistics
 // ------------------------------------------------------------------------------------------------
-template <typename T, bool GELU, bool HAS_O>
-__global__ __launch_bounds__(kMaxStrips * kWave) void light_stats_bwd_nhwc(const T* __restrict__ dout, const T* __restrict__ x, const T* __restrict__ o,
-                                     const float* __restrict__ wv, float* __restrict__ bmom, int B, int C, int H, int W,
-                                     int BG) {
-  extern __shared__ float red[];
-  const int lane = threadIdx.x & (kWave - 1), wave = threadIdx.x / kWave, nwaves = blockDim.x / kWave;
-  const int c = blockIdx.x * kWave + lane;
-  const bool cv = c < C;
-  const int cc = cv ? c : C - 1;
-  const int nstrips = (W + kS - 1) / kS;
+template <typename T, bool GELU, bool HAS_O, bool WIDE>
+__global__ __launch_bounds__(kMaxStrips * kWave) void light_stats_bwd_nhwc(
+    const T* __restrict__ dout, const T* __restrict__ x, const T* __restrict__ o, const float* __restrict__ wv,
+    float* __restrict__ bmom, int B, int C, int H, int W, int BG) {
+  MRLA_NHWC_PROLOGUE(D_N)
   float w[9];
 #pragma unroll
   for (int k = 0; k < 9; ++k) w[k] = wv[cc * 9 + k];
@@ -211,20 +344,37 @@ __global__ __launch_bounds__(kMaxStrips * kWave) void light_stats_bwd_nhwc(const
       const int s0 = s * kS, nc = min(kS, W - s0);
       float ra[kS + 2], rb[kS + 2], rc[kS + 2];
 #pragma unroll
-      for (int j = 0; j < kS + 2; ++j) { ra[j] = 0.f; rb[j] = ldpix(xi, 0, s0 - 1 + j, H, W, C, cc); }
+      for (int j = 0; j < kS + 2; ++j) ra[j] = 0.f;
+      read_row<T, WIDE, kS + 2>(xi, 0, s0 - 1, H, W, C, cbase, cc, lane, SCR(0), rb);
+      RowLoad<T, kS + 2> qx;
+      RowLoad<T, kS> qg, qo;
+      if (WIDE) {
+        issue_row<T, kS + 2>(qx, xi, 1, s0 - 1, H, W, C, cbase, lane);
+        issue_row<T, kS>(qg, gi, 0, s0, H, W, C, cbase, lane);
+        if (HAS_O) issue_row<T, kS>(qo, oi, 0, s0, H, W, C, cbase, lane);
+      }
       for (int r = 0; r < H; ++r) {
-#pragma unroll
-        for (int j = 0; j < kS + 2; ++j) rc[j] = ldpix(xi, r + 1, s0 - 1 + j, H, W, C, cc);
+        float gv[kS], ov[kS];
+        if (WIDE) {
+          finish_row<T, kS + 2>(qx, lane, SCR(0), rc);
+          finish_row<T, kS>(qg, lane, SCR(1), gv);
+          if (HAS_O) finish_row<T, kS>(qo, lane, SCR(2), ov);
+          issue_row<T, kS + 2>(qx, xi, r + 2, s0 - 1, H, W, C, cbase, lane);
+          issue_row<T, kS>(qg, gi, r + 1, s0, H, W, C, cbase, lane);
+          if (HAS_O) issue_row<T, kS>(qo, oi, r + 1, s0, H, W, C, cbase, lane);
+        } else {
+          read_row<T, false, kS + 2>(xi, r + 1, s0 - 1, H, W, C, cbase, cc, lane, SCR(0), rc);
+          read_row<T, false, kS>(gi, r, s0, H, W, C, cbase, cc, lane, SCR(1), gv);
+          if (HAS_O) read_row<T, false, kS>(oi, r, s0, H, W, C, cbase, cc, lane, SCR(2), ov);
+        }
 #pragma unroll
         for (int j = 0; j < kS; ++j) {
           if (j < nc) {
-            const size_t e = ((size_t)r * W + s0 + j) * C + cc;
             float v = conv_at(w, ra, rb, rc, j);
             if (GELU) v = gelu_f(v);
-            const float gv = to_f(gi[e]);
-            acc[D_D] += gv;
-            acc[D_DV] = fmaf(gv, v, acc[D_DV]);
-            if (HAS_O) acc[D_DO] = fmaf(gv, to_f(oi[e]), acc[D_DO]);
+            acc[D_D] += gv[j];
+            acc[D_DV] = fmaf(gv[j], v, acc[D_DV]);
+            if (HAS_O) acc[D_DO] = fmaf(gv[j], ov[j], acc[D_DO]);
           }
         }
 #pragma unroll
@@ -245,19 +395,13 @@ __global__ __launch_bounds__(kMaxStrips * kWave) void light_stats_bwd_nhwc(const
 // Strip-local windows (columns relative to s0):  x rows rr-1..rr+1 over cols -2..kS+1 (kS+4 wide),
 // dU rows rr-2..rr over cols -1..kS (kS+2 wide).  At step rr: U[rr] on cols -1..kS -> dU[rr]; then dx[rr-1] on the
 // owned cols from dU rows rr-2..rr.
-template <typename T, bool GELU, bool HAS_O, bool RELU>
-__global__ __launch_bounds__(kMaxStrips * kWave) void light_apply_bwd_nhwc(const T* __restrict__ dout, const T* __restrict__ x, const T* __restrict__ o,
-                                     const float* __restrict__ wv, const float* __restrict__ gate,
-                                     const float* __restrict__ cb, const float* __restrict__ lam,
-                                     const float* __restrict__ dp, const float* __restrict__ dyx, T* __restrict__ dx,
-                                     T* __restrict__ dprev, float* __restrict__ dwv_part, int B, int C, int H, int W,
-                                     int BG, int d, int res) {
-  extern __shared__ float red[];
-  const int lane = threadIdx.x & (kWave - 1), wave = threadIdx.x / kWave, nwaves = blockDim.x / kWave;
-  const int c = blockIdx.x * kWave + lane;
-  const bool cv = c < C;
-  const int cc = cv ? c : C - 1;
-  const int nstrips = (W + kS - 1) / kS;
+template <typename T, bool GELU, bool HAS_O, bool RELU, bool WIDE>
+__global__ __launch_bounds__(kMaxStrips * kWave) void light_apply_bwd_nhwc(
+    const T* __restrict__ dout, const T* __restrict__ x, const T* __restrict__ o, const float* __restrict__ wv,
+    const float* __restrict__ gate, const float* __restrict__ cb, const float* __restrict__ lam,
+    const float* __restrict__ dp, const float* __restrict__ dyx, T* __restrict__ dx, T* __restrict__ dprev,
+    float* __restrict__ dwv_part, int B, int C, int H, int W, int BG, int d, int res) {
+  MRLA_NHWC_PROLOGUE(9)
   const int G = C / d;
   float w[9];
 #pragma unroll
@@ -285,67 +429,80 @@ __global__ __launch_bounds__(kMaxStrips * kWave) void light_apply_bwd_nhwc(const
       float ua[kS + 2], ub[kS + 2], uc[kS + 2];      // dU rows rr-2, rr-1, rr
       float gprev[kS], dmprev[kS];                   // dOut[rr-1], lam*dm[rr-1] on the owned columns
 #pragma unroll
-      for (int j = 0; j < kS + 4; ++j) { xa[j] = 0.f; xb[j] = ldpix(xi, 0, s0 - 2 + j, H, W, C, cc); }
+      for (int j = 0; j < kS + 4; ++j) xa[j] = 0.f;
+      read_row<T, WIDE, kS + 4>(xi, 0, s0 - 2, H, W, C, cbase, cc, lane, SCR(0), xb);
 #pragma unroll
       for (int j = 0; j < kS + 2; ++j) { ua[j] = 0.f; ub[j] = 0.f; }
 #pragma unroll
       for (int j = 0; j < kS; ++j) { gprev[j] = 0.f; dmprev[j] = 0.f; }
+      // software pipeline (WIDE): the row pieces of step rr+1 are in flight while step rr computes
+      RowLoad<T, kS + 4> qx;
+      RowLoad<T, kS + 2> qg, qo;
+      if (WIDE) {
+        issue_row<T, kS + 4>(qx, xi, 1, s0 - 2, H, W, C, cbase, lane);
+        issue_row<T, kS + 2>(qg, gi, 0, s0 - 1, H, W, C, cbase, lane);
+        if (HAS_O) issue_row<T, kS + 2>(qo, oi, 0, s0 - 1, H, W, C, cbase, lane);
+      }
       for (int rr = 0; rr <= H; ++rr) {
-#pragma unroll
-        for (int j = 0; j < kS + 4; ++j) xc[j] = ldpix(xi, rr + 1, s0 - 2 + j, H, W, C, cc);
-        float gcur[kS], dmcur[kS];
+        float gv[kS + 2], ov[kS + 2];                // dOut / o of row rr on columns -1 .. kS (zero outside the image)
+        if (WIDE) {
+          finish_row<T, kS + 4>(qx, lane, SCR(0), xc);
+          finish_row<T, kS + 2>(qg, lane, SCR(1), gv);
+          if (HAS_O) finish_row<T, kS + 2>(qo, lane, SCR(2), ov);
+          issue_row<T, kS + 4>(qx, xi, rr + 2, s0 - 2, H, W, C, cbase, lane);
+          issue_row<T, kS + 2>(qg, gi, rr + 1, s0 - 1, H, W, C, cbase, lane);
+          if (HAS_O) issue_row<T, kS + 2>(qo, oi, rr + 1, s0 - 1, H, W, C, cbase, lane);
+        } else {
+          read_row<T, false, kS + 4>(xi, rr + 1, s0 - 2, H, W, C, cbase, cc, lane, SCR(0), xc);
+          read_row<T, false, kS + 2>(gi, rr, s0 - 1, H, W, C, cbase, cc, lane, SCR(1), gv);
+          if (HAS_O) read_row<T, false, kS + 2>(oi, rr, s0 - 1, H, W, C, cbase, cc, lane, SCR(2), ov);
+        }
+        float gcur[kS], dmcur[kS], dorow[kS];
         // dU[rr] on columns -1 .. kS (zero outside the image)
 #pragma unroll
         for (int j = 0; j < kS + 2; ++j) {
           const int col = s0 - 1 + j;
-          float du = 0.f;
-          if (rr < H && col >= 0 && col < W) {                              // wave-uniform
-            const size_t e = ((size_t)rr * W + col) * C + cc;
-            const float u = conv_at(w, xa, xb, xc, j);                      // window cols j..j+2 <-> image cols col-1..col+1
-            const float v = GELU ? gelu_f(u) : u;
-            const float gv = to_f(gi[e]);
-            float dm = fmaf(E, gv, Hc);
-            dm = fmaf(F, v, dm);
-            if (HAS_O) dm = fmaf(Gc, to_f(oi[e]), dm);
-            du = a * dm;
-            if (GELU) du *= gelu_grad_f(u);
-            if (j >= 1 && j <= kS) {                                        // owned column (compile-time after unroll)
-              if (j - 1 < nc) {
-                gcur[j - 1] = gv;
-                dmcur[j - 1] = lm * dm;
-                if (HAS_O && !RELU && cv) doo[e] = from_f<T>(lm * dm);
-                // dWv[i][k] += dU[rr][col] * x[rr+i-1][col+k-1]
-                wg[0] = fmaf(du, xa[j], wg[0]); wg[1] = fmaf(du, xa[j + 1], wg[1]); wg[2] = fmaf(du, xa[j + 2], wg[2]);
-                wg[3] = fmaf(du, xb[j], wg[3]); wg[4] = fmaf(du, xb[j + 1], wg[4]); wg[5] = fmaf(du, xb[j + 2], wg[5]);
-                wg[6] = fmaf(du, xc[j], wg[6]); wg[7] = fmaf(du, xc[j + 1], wg[7]); wg[8] = fmaf(du, xc[j + 2], wg[8]);
-              }
+          const bool in = rr < H && col >= 0 && col < W;                    // wave-uniform
+          const float u = conv_at(w, xa, xb, xc, j);                        // window cols j..j+2 <-> image cols col-1..col+1
+          const float v = GELU ? gelu_f(u) : u;
+          float dm = fmaf(E, gv[j], Hc);
+          dm = fmaf(F, v, dm);
+          if (HAS_O) dm = fmaf(Gc, ov[j], dm);
+          float du = a * dm;
+          if (GELU) du *= gelu_grad_f(u);
+          du = in ? du : 0.f;
+          if (j >= 1 && j <= kS) {                                          // owned column (compile-time after unroll)
+            gcur[j - 1] = gv[j];
+            dmcur[j - 1] = in ? lm * dm : 0.f;
+            dorow[j - 1] = dmcur[j - 1];
+            if (j - 1 < nc) {
+              // dWv[i][k] += dU[rr][col] * x[rr+i-1][col+k-1]
+              wg[0] = fmaf(du, xa[j], wg[0]); wg[1] = fmaf(du, xa[j + 1], wg[1]); wg[2] = fmaf(du, xa[j + 2], wg[2]);
+              wg[3] = fmaf(du, xb[j], wg[3]); wg[4] = fmaf(du, xb[j + 1], wg[4]); wg[5] = fmaf(du, xb[j + 2], wg[5]);
+              wg[6] = fmaf(du, xc[j], wg[6]); wg[7] = fmaf(du, xc[j + 1], wg[7]); wg[8] = fmaf(du, xc[j + 2], wg[8]);
             }
-          } else if (j >= 1 && j <= kS) {
-            gcur[j - 1] = 0.f;
-            dmcur[j - 1] = 0.f;
           }
           uc[j] = du;
         }
+        if (HAS_O && !RELU && rr < H) write_row<T, WIDE, kS>(doo, rr, s0, nc, W, C, cbase, c, cv, lane, SCR(4), dorow);
         // dx[rr-1] on the owned columns:  dx[ro][col] = sum_{i,k} w[i][k] * dU[ro-i+1][col-k+1]
         if (rr >= 1) {
           const int ro = rr - 1;
+          float yrow[kS], dsum[kS];
 #pragma unroll
           for (int j = 0; j < kS; ++j) {
-            if (j < nc) {
-              // window index of column (col + 1 - k) in the dU arrays (which start at col -1): j + 2 - k
-              float s9 = w[0] * uc[j + 2];
-              s9 = fmaf(w[1], uc[j + 1], s9); s9 = fmaf(w[2], uc[j], s9);
-              s9 = fmaf(w[3], ub[j + 2], s9); s9 = fmaf(w[4], ub[j + 1], s9); s9 = fmaf(w[5], ub[j], s9);
-              s9 = fmaf(w[6], ua[j + 2], s9); s9 = fmaf(w[7], ua[j + 1], s9); s9 = fmaf(w[8], ua[j], s9);
-              float y = fmaf(resf, gprev[j], s9 + dy);
-              const size_t e = ((size_t)ro * W + s0 + j) * C + cc;
-              if (RELU) {
-                y = (xa[j + 2] > 0.f) ? y : 0.f;                            // xa = x[rr-1] = x[ro]; owned col j <-> window j+2
-                if (HAS_O && cv) doo[e] = from_f<T>(dmprev[j] + y);
-              }
-              if (cv) dxo[e] = from_f<T>(y);
-            }
+            // window index of column (col + 1 - k) in the dU arrays (which start at col -1): j + 2 - k
+            float s9 = w[0] * uc[j + 2];
+            s9 = fmaf(w[1], uc[j + 1], s9); s9 = fmaf(w[2], uc[j], s9);
+            s9 = fmaf(w[3], ub[j + 2], s9); s9 = fmaf(w[4], ub[j + 1], s9); s9 = fmaf(w[5], ub[j], s9);
+            s9 = fmaf(w[6], ua[j + 2], s9); s9 = fmaf(w[7], ua[j + 1], s9); s9 = fmaf(w[8], ua[j], s9);
+            float y = fmaf(resf, gprev[j], s9 + dy);
+            if (RELU) y = (xa[j + 2] > 0.f) ? y : 0.f;                      // xa = x[rr-1] = x[ro]; owned col j <-> window j+2
+            yrow[j] = y;
+            dsum[j] = dmprev[j] + y;
           }
+          write_row<T, WIDE, kS>(dxo, ro, s0, nc, W, C, cbase, c, cv, lane, SCR(3), yrow);
+          if (RELU && HAS_O) write_row<T, WIDE, kS>(doo, ro, s0, nc, W, C, cbase, c, cv, lane, SCR(4), dsum);
         }
 #pragma unroll
         for (int j = 0; j < kS + 4; ++j) { xa[j] = xb[j]; xb[j] = xc[j]; }
@@ -382,55 +539,77 @@ int nhwc_images_per_group(int B, int C) {
     default: return MRLA_EINVAL;                                     \
   }
 
-struct NhwcLaunch { dim3 grid, block; size_t lds; int BG; };
-static NhwcLaunch nhwc_launch(int B, int C, int W, int nred) {
+struct NhwcLaunch { dim3 grid, block; size_t lds; int BG; bool wide; };
+static NhwcLaunch nhwc_launch(int B, int C, int W, int nred, int dtype) {
   NhwcLaunch L;
   const int nstrips = (W + kS - 1) / kS;
   const int nwaves = std::min(nstrips, kMaxStrips);
   L.BG = nhwc_images_per_group(B, C);
   L.grid = dim3((C + kWave - 1) / kWave, (B + L.BG - 1) / L.BG);
   L.block = dim3(nwaves * kWave);
-  L.lds = nwaves > 1 ? (size_t)nwaves * nred * kWave * sizeof(float) : 0;
+  L.wide = (C % kWave) == 0;
+  const size_t sb = dtype == MRLA_F32 ? scratch_bytes<float>() : scratch_bytes<bf16_t>();
+  L.lds = (size_t)nwaves * nred * kWave * sizeof(float) + (L.wide ? (size_t)nwaves * kScrBufs * sb : 0);
   return L;
+}
+template <typename K>
+static hipError_t set_lds_n(K kernel, size_t bytes) {
+  if (bytes <= 48 * 1024) return hipSuccess;
+  return hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
 }
 
 int launch_light_stats_fwd_nhwc(const void* x, const void* o, const float* wv, float* mom, void* xout, int B, int C,
                                 int H, int W, int dtype, int act, hipStream_t st) {
-  const NhwcLaunch L = nhwc_launch(B, C, W, M_N);
-#define CALL_F(T, A, O, F)                                                                                          \
-  hipLaunchKernelGGL((light_stats_fwd_nhwc<T, A, O, F>), L.grid, L.block, L.lds, st, (const T*)x, (const T*)o, wv, mom, \
-                     (T*)xout, B, C, H, W, L.BG);
+  const NhwcLaunch L = nhwc_launch(B, C, W, M_N, dtype);
+#define CALL_W(T, A, O, F, WD)                                                                                       \
+  {                                                                                                                  \
+    if (set_lds_n(light_stats_fwd_nhwc<T, A, O, F, WD>, L.lds) != hipSuccess) return MRLA_EHIP;                        \
+    hipLaunchKernelGGL((light_stats_fwd_nhwc<T, A, O, F, WD>), L.grid, L.block, L.lds, st, (const T*)x, (const T*)o,  \
+                       wv, mom, (T*)xout, B, C, H, W, L.BG);                                                         \
+  }
+#define CALL_F(T, A, O, F) { if (L.wide) CALL_W(T, A, O, F, true) else CALL_W(T, A, O, F, false) }
 #define CALL(T, A, O)                                                        \
   {                                                                          \
-    if (xout) { if (O) { CALL_F(T, A, true, true) } else return MRLA_EINVAL; } \
-    else { CALL_F(T, A, O, false) }                                          \
+    if (xout) { if (O) CALL_F(T, A, true, true) else return MRLA_EINVAL; }   \
+    else CALL_F(T, A, O, false)                                              \
   }
   MRLA_DISPATCH_T_N(dtype, act, o != nullptr, CALL)
 #undef CALL
 #undef CALL_F
+#undef CALL_W
   return hip_status(hipGetLastError());
 }
 
 int launch_light_apply_fwd_nhwc(const void* x, const void* o, const float* wv, const float* gate, const float* sc,
                                 const float* sh, const float* lam, const float* dp, void* out, int B, int C, int H,
                                 int W, int d, int res, int dtype, int act, hipStream_t st) {
-  const NhwcLaunch L = nhwc_launch(B, C, W, 1);
-#define CALL(T, A, O)                                                                                               \
-  hipLaunchKernelGGL((light_apply_fwd_nhwc<T, A, O>), L.grid, L.block, 0, st, (const T*)x, (const T*)o, wv, gate, sc, \
-                     sh, lam, dp, (T*)out, B, C, H, W, L.BG, d, res);
+  const NhwcLaunch L = nhwc_launch(B, C, W, 0, dtype);
+#define CALL_W(T, A, O, WD)                                                                                          \
+  {                                                                                                                  \
+    if (set_lds_n(light_apply_fwd_nhwc<T, A, O, WD>, L.lds) != hipSuccess) return MRLA_EHIP;                           \
+    hipLaunchKernelGGL((light_apply_fwd_nhwc<T, A, O, WD>), L.grid, L.block, L.lds, st, (const T*)x, (const T*)o, wv, \
+                       gate, sc, sh, lam, dp, (T*)out, B, C, H, W, L.BG, d, res);                                    \
+  }
+#define CALL(T, A, O) { if (L.wide) CALL_W(T, A, O, true) else CALL_W(T, A, O, false) }
   MRLA_DISPATCH_T_N(dtype, act, o != nullptr, CALL)
 #undef CALL
+#undef CALL_W
   return hip_status(hipGetLastError());
 }
 
 int launch_light_stats_bwd_nhwc(const void* dout, const void* x, const void* o, const float* wv, float* bmom, int B,
                                 int C, int H, int W, int dtype, int act, hipStream_t st) {
-  const NhwcLaunch L = nhwc_launch(B, C, W, D_N);
-#define CALL(T, A, O)                                                                                               \
-  hipLaunchKernelGGL((light_stats_bwd_nhwc<T, A, O>), L.grid, L.block, L.lds, st, (const T*)dout, (const T*)x,       \
-                     (const T*)o, wv, bmom, B, C, H, W, L.BG);
+  const NhwcLaunch L = nhwc_launch(B, C, W, D_N, dtype);
+#define CALL_W(T, A, O, WD)                                                                                          \
+  {                                                                                                                  \
+    if (set_lds_n(light_stats_bwd_nhwc<T, A, O, WD>, L.lds) != hipSuccess) return MRLA_EHIP;                           \
+    hipLaunchKernelGGL((light_stats_bwd_nhwc<T, A, O, WD>), L.grid, L.block, L.lds, st, (const T*)dout, (const T*)x,  \
+                       (const T*)o, wv, bmom, B, C, H, W, L.BG);                                                     \
+  }
+#define CALL(T, A, O) { if (L.wide) CALL_W(T, A, O, true) else CALL_W(T, A, O, false) }
   MRLA_DISPATCH_T_N(dtype, act, o != nullptr, CALL)
 #undef CALL
+#undef CALL_W
   return hip_status(hipGetLastError());
 }
 
@@ -438,18 +617,24 @@ int launch_light_apply_bwd_nhwc(const void* dout, const void* x, const void* o, 
                                 const float* cb, const float* lam, const float* dp, const float* dyx, void* dx,
                                 void* dprev, float* dwv_part, int B, int C, int H, int W, int d, int res, int relu,
                                 int dtype, int act, hipStream_t st) {
-  const NhwcLaunch L = nhwc_launch(B, C, W, 9);
-#define CALL_R(T, A, O, R)                                                                                          \
-  hipLaunchKernelGGL((light_apply_bwd_nhwc<T, A, O, R>), L.grid, L.block, L.lds, st, (const T*)dout, (const T*)x,    \
-                     (const T*)o, wv, gate, cb, lam, dp, dyx, (T*)dx, (T*)dprev, dwv_part, B, C, H, W, L.BG, d, res);
+  const NhwcLaunch L = nhwc_launch(B, C, W, 9, dtype);
+#define CALL_W(T, A, O, R, WD)                                                                                       \
+  {                                                                                                                  \
+    if (set_lds_n(light_apply_bwd_nhwc<T, A, O, R, WD>, L.lds) != hipSuccess) return MRLA_EHIP;                        \
+    hipLaunchKernelGGL((light_apply_bwd_nhwc<T, A, O, R, WD>), L.grid, L.block, L.lds, st, (const T*)dout,            \
+                       (const T*)x, (const T*)o, wv, gate, cb, lam, dp, dyx, (T*)dx, (T*)dprev, dwv_part, B, C, H, W, \
+                       L.BG, d, res);                                                                                \
+  }
+#define CALL_R(T, A, O, R) { if (L.wide) CALL_W(T, A, O, R, true) else CALL_W(T, A, O, R, false) }
 #define CALL(T, A, O)                                                                        \
   {                                                                                          \
-    if (relu) { if (O && !(A)) { CALL_R(T, false, true, true) } else return MRLA_EINVAL; }   \
-    else { CALL_R(T, A, O, false) }                                                          \
+    if (relu) { if (O && !(A)) CALL_R(T, false, true, true) else return MRLA_EINVAL; }       \
+    else CALL_R(T, A, O, false)                                                              \
   }
   MRLA_DISPATCH_T_N(dtype, act, o != nullptr, CALL)
 #undef CALL
 #undef CALL_R
+#undef CALL_W
   return hip_status(hipGetLastError());
 }
 

@@ -13,6 +13,8 @@ reps = int(sys.argv[1]) if len(sys.argv) > 1 else 20
 only = sys.argv[2] if len(sys.argv) > 2 else ""
 B = int(os.environ.get("B", 256))
 RELU = int(os.environ.get("RELU", 1))
+LAY = L.NHWC if os.environ.get("LAYOUT", "nchw") == "nhwc" else L.NCHW
+FMT = torch.channels_last if LAY == L.NHWC else torch.contiguous_format
 STAGES = [(256, 56), (512, 28), (1024, 14), (2048, 7)]
 dt = torch.bfloat16
 lib = L.load()
@@ -37,9 +39,9 @@ tot = {}
 for c, hw in STAGES:
     d, ks = 32, (7 if c == 2048 else 5)
     n = B * c * hw * hw
-    x = torch.randn(B, c, hw, hw, device="cuda").to(dt)
-    o = torch.randn(B, c, hw, hw, device="cuda").to(dt)
-    g = torch.randn(B, c, hw, hw, device="cuda").to(dt)
+    x = torch.randn(B, c, hw, hw, device="cuda").to(dt).contiguous(memory_format=FMT)
+    o = torch.randn(B, c, hw, hw, device="cuda").to(dt).contiguous(memory_format=FMT)
+    g = torch.randn(B, c, hw, hw, device="cuda").to(dt).contiguous(memory_format=FMT)
     out, dx, do = torch.empty_like(x), torch.empty_like(x), torch.empty_like(x)
     wv = torch.randn(c, 9, device="cuda") * 0.3
     wq, wk = torch.randn(ks, device="cuda"), torch.randn(ks, device="cuda")
@@ -54,23 +56,23 @@ for c, hw in STAGES:
     small = torch.empty(3, c, device="cuda")
     dyx = torch.empty(B, c, device="cuda")
     dwqk = torch.empty(B, 2 * ks, device="cuda")
-    rows = lib.mrla_light_wgrad_rows(B, c, hw, hw, L.BF16, L.NCHW)
+    rows = lib.mrla_light_wgrad_rows(B, c, hw, hw, L.BF16, LAY)
     dwv = torch.empty(rows, c * 9, device="cuda")
     K = {
-        "stats_fwd": (2, lambda: lib.mrla_light_stats_fwd(P(x), P(o), P(wv), P(mom), B, c, hw, hw, L.BF16, L.NCHW, 0, st)),
+        "stats_fwd": (2, lambda: lib.mrla_light_stats_fwd(P(x), P(o), P(wv), P(mom), B, c, hw, hw, L.BF16, LAY, 0, st)),
         "gate_fwd": (0, lambda: lib.mrla_light_gate_fwd(P(mom), P(wq), P(wk), ks, P(gate), B, c, hw * hw, d, st)),
         "bn_fwd": (0, lambda: lib.mrla_light_bn_fwd(P(mom), P(gate), P(lam), P(gamma), P(beta), P(rm), P(rv), 1, 0.1, 1e-5,
                                                      P(bn[0]), P(bn[1]), P(bn[2]), P(bn[3]), B, c, hw * hw, d, st)),
         "apply_fwd": (3, lambda: lib.mrla_light_apply_fwd(P(x), P(o), P(wv), P(gate), P(bn[0]), P(bn[1]), P(lam), P(dp), P(out),
-                                                          B, c, hw, hw, d, 1, L.BF16, L.NCHW, 0, st)),
-        "stats_bwd": (3, lambda: lib.mrla_light_stats_bwd(P(g), P(x), P(o), P(wv), P(bmom), B, c, hw, hw, L.BF16, L.NCHW, 0, st)),
+                                                          B, c, hw, hw, d, 1, L.BF16, LAY, 0, st)),
+        "stats_bwd": (3, lambda: lib.mrla_light_stats_bwd(P(g), P(x), P(o), P(wv), P(bmom), B, c, hw, hw, L.BF16, LAY, 0, st)),
         "bn_bwd": (0, lambda: lib.mrla_light_bn_bwd(P(mom), P(bmom), P(gate), P(lam), P(gamma), P(dp), P(bn[2]), P(bn[3]), 1,
                                                      P(cb), P(small[0]), P(small[1]), P(small[2]), B, c, hw * hw, d, st)),
         "gate_bwd": (0, lambda: lib.mrla_light_gate_bwd(P(mom), P(bmom), P(gate), P(cb), P(dp), P(wq), P(wk), ks, P(dyx), P(dwqk),
                                                         B, c, hw * hw, d, st)),
         "apply_bwd": (5, lambda: lib.mrla_light_apply_bwd(P(g), P(x), P(o), P(wv), P(gate), P(cb), P(lam), P(dp), P(dyx), P(dx),
-                                                          P(do), P(dwv), B, c, hw, hw, d, 1, RELU, L.BF16, L.NCHW, 0, st)),
-        "stats_fused": (3, lambda: lib.mrla_light_stats_fwd_fused(P(g), P(o), P(wv), P(mom), P(out), B, c, hw, hw, L.BF16, L.NCHW, st)),
+                                                          P(do), P(dwv), B, c, hw, hw, d, 1, RELU, L.BF16, LAY, 0, st)),
+        "stats_fused": (3, lambda: lib.mrla_light_stats_fwd_fused(P(g), P(o), P(wv), P(mom), P(out), B, c, hw, hw, L.BF16, LAY, st)),
     }
     for name, (passes, fn) in K.items():
         if only and only not in name:

@@ -39,7 +39,8 @@ def parse():
     ap.add_argument("--drop-path", type=float, default=0.2, help="resnet/train.py:67 default")
     ap.add_argument("--no-baselines", action="store_true", help="skip the cpu_baseline / eager_rocm legs")
     ap.add_argument("--eager", action="store_true", help="time the eager restatement instead (diagnostic)")
-    ap.add_argument("--channels-last", type=int, default=0, help="1: run the network in torch.channels_last (NHWC kernels)")
+    ap.add_argument("--channels-last", type=int, default=-1,
+                    help="1 / 0: force torch.channels_last on / off; -1: the model class default (on for resnet*_mrlal)")
     ap.add_argument("--benchmark", type=int, default=0, help="torch.backends.cudnn.benchmark (resnet/train.py:247 sets it)")
     ap.add_argument("--graph", type=int, default=0, help="1: replay the whole step (fwd+bwd+SGD) from one HIP graph")
     ap.add_argument("--backend", default=os.environ.get("MRLA_DIST_BACKEND", "nccl"))
@@ -157,16 +158,15 @@ def main():
                 net = getattr(vit, args.arch)(drop_path_rate=args.drop_path)
             else:
                 net = getattr(models, args.arch)(drop_path=args.drop_path)
-    net = net.cuda().train()
-    if args.channels_last:
-        net = net.to(memory_format=torch.channels_last)
-    net = D.wrap_data_parallel(net, device_ids=[local])
+    if args.channels_last >= 0 and hasattr(net, "channels_last"):
+        net.channels_last = bool(args.channels_last)
+        net.to(memory_format=torch.channels_last if args.channels_last else torch.contiguous_format)
+    layout = "channels_last" if getattr(net, "channels_last", False) else "NCHW"
+    net = D.wrap_data_parallel(net.cuda().train(), device_ids=[local])
     gx = torch.Generator(device="cuda").manual_seed(0)
     gy = torch.Generator(device="cuda").manual_seed(1)
     x = torch.randn(args.batch, 3, 224, 224, device="cuda", generator=gx)
     y = torch.randint(0, 1000, (args.batch,), device="cuda", generator=gy)
-    if args.channels_last:
-        x = x.contiguous(memory_format=torch.channels_last)
     step = make_step(net, sgd(net.parameters()), x, y)
 
     # warm-up without the timer, then the timed region with HIP-event timing of the dominant kernel
@@ -216,7 +216,7 @@ def main():
                                       f"fp32 master weights, drop_path {args.drop_path}",
                           "global_batch": world * args.batch, "parallelism": f"dp{world}",
                           "path": "eager restatement" if args.eager else
-                                  "mrla_amd (HIP MRLA tails incl. shortcut add+ReLU, HIP BatchNorm+ReLU, stock convolutions)"},
+                                  f"mrla_amd (HIP MRLA tails incl. shortcut add+ReLU, HIP BatchNorm+ReLU, stock convolutions; {layout})"},
                "roofline": roofline,
                "mrla_kernels": {k: {"launches": v["launches"], "ms_per_step": round(v["ms"] / args.steps, 3),
                                     "GBps": round(v["bytes"] / (v["ms"] * 1e-3) / 1e9, 1)} for k, v in ks.items()}}

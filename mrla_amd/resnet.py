@@ -157,7 +157,13 @@ class _ResNetMRLA(nn.Module):
 
 
 class ResNet_mrlal(_ResNetMRLA):
-    """ResNet with an MRLA-light module after every bottleneck (resnet_mrla_light.py:122-238)."""
+    """ResNet with an MRLA-light module after every bottleneck (resnet_mrla_light.py:122-238).
+
+    `channels_last` (class attribute, default True): activations and convolution weights are kept in
+    torch.channels_last inside the network -- MIOpen's fast bf16 kernels on gfx950 are NHWC-native (no layout
+    transposes around every convolution) and the MRLA / BatchNorm HIP kernels have NHWC variants.  Inputs may be
+    NCHW-contiguous as in the reference; logits, parameters' logical shapes and state_dict keys are unaffected."""
+    channels_last = True
 
     def __init__(self, block, layers, num_classes=1000, SE=False, ECA=None, zero_init_last_bn=True, groups=1,
                  width_per_group=64, replace_stride_with_dilation=None, norm_layer=nn.BatchNorm2d, drop_rate=0.0,
@@ -175,8 +181,12 @@ class ResNet_mrlal(_ResNetMRLA):
         self.layer3 = nn.Sequential(*self._make_layer(block, 256, layers[2], SE, E[2], stride=2, dilate=d[1]))
         self.layer4 = nn.Sequential(*self._make_layer(block, 512, layers[3], SE, E[3], stride=2, dilate=d[2]))
         self._head_and_init(block, zero_init_last_bn)
+        if self.channels_last:
+            self.to(memory_format=torch.channels_last)
 
     def forward_features(self, x):
+        if self.channels_last and x.is_cuda:
+            x = x.contiguous(memory_format=torch.channels_last)
         x = self.maxpool(F_.bn_act(self.conv1(x), self.bn1, relu=True))
         return self.layer4(self.layer3(self.layer2(self.layer1(x))))
 

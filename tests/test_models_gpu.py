@@ -70,6 +70,27 @@ def test_resnet50_mrlal_train_step_matches_eager():
         assert rel(sp[k].float().cpu().numpy(), sr[k].float().cpu().numpy()) < 1e-4, k
 
 
+def test_resnet50_mrlal_nchw_and_channels_last_paths_agree():
+    """The class default runs NHWC inside; switching it off runs the NCHW kernels: same logits, same gradients."""
+    from mrla_amd import models
+    a, b = models.resnet50_mrlal().cuda(), models.resnet50_mrlal().cuda()
+    load_det(a)
+    b.load_state_dict(a.state_dict())
+    b.channels_last = False
+    b.to(memory_format=torch.contiguous_format)
+    assert a.conv1.weight.is_contiguous(memory_format=torch.channels_last) and b.conv1.weight.is_contiguous()
+    a.train(); b.train()
+    x = torch.from_numpy(cases.image_batch(4, "img-train")).cuda()
+    ya, yb = a(x), b(x)
+    assert rel(ya.detach().cpu().numpy(), yb.detach().cpu().numpy()) < 2e-4
+    ya.square().mean().backward(); yb.square().mean().backward()
+    dots = np.zeros(3)
+    for (k, pa), (_, pb) in zip(a.named_parameters(), b.named_parameters()):
+        ga, gb = pa.grad.cpu().numpy().ravel().astype(np.float64), pb.grad.cpu().numpy().ravel().astype(np.float64)
+        dots += np.array([ga @ gb, ga @ ga, gb @ gb])
+    assert dots[0] / np.sqrt(dots[1] * dots[2]) > 0.9999
+
+
 def test_state_dict_roundtrip_and_api_surface():
     from mrla_amd import models
     net = models.resnet50_mrlal(drop_rate=0.1, drop_path=0.2, num_classes=10)

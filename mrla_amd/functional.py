@@ -164,6 +164,7 @@ class _LightFn(torch.autograd.Function):
 
         ctx.cfg, ctx.layout, ctx.ks = cfg, layout, ks
         ctx.shapes = (wq.shape, wk.shape, wv.shape, lam.shape if lam is not None else None)
+        ctx.wv_stride = wv.stride()          # gradient layout contract of DDP: same strides as the parameter
         ctx.pdtypes = (wq.dtype, wk.dtype, wv.dtype, lam.dtype if lam is not None else None,
                        gamma.dtype if gamma is not None else None)
         ctx.save_for_backward(xc, oc, wq32, wk32, wv32, lam32, gamma32, dp32, mom, gate, bnbuf)
@@ -210,7 +211,7 @@ class _LightFn(torch.autograd.Function):
 
         sq, sk, sv, sl = ctx.shapes
         tq, tk, tv, tl, tg = ctx.pdtypes
-        dwv = wsum[:c * 9].view(sv).to(tv)
+        dwv = wsum[:c * 9].view(sv).to(tv).as_strided(sv, ctx.wv_stride)
         dwq = wsum[c * 9:c * 9 + ks].view(sq).to(tq)
         dwk = wsum[c * 9 + ks:].view(sk).to(tk)
         dlam = small[6].view(sl).to(tl) if lam32 is not None else None
@@ -346,6 +347,7 @@ class _BaseFn(torch.autograd.Function):
                   _ptr(bnbuf[1]), _ptr(dp32), _ptr(out), b, c, h, w, dt, layout, st)
         ctx.cfg, ctx.layout, ctx.ks, ctx.stage, ctx.t = cfg, layout, ks, stage, t
         ctx.shapes = (wq.shape, wk.shape, wv.shape)
+        ctx.wv_stride = wv.stride()
         ctx.pdtypes = (wq.dtype, wk.dtype, wv.dtype, gamma.dtype if gamma is not None else None)
         ctx.save_for_backward(xc, attn if cfg.tail else None, wq32, wk32, wv32, gamma32, dp32, mom, q, bnbuf)
         return out
@@ -394,7 +396,7 @@ class _BaseFn(torch.autograd.Function):
         sq, sk, sv = ctx.shapes
         tq, tk, tv, _ = ctx.pdtypes
         return (dx, dx if cfg.fuse else None, wsum[c * 9:c * 9 + ks].view(sq).to(tq), wsum[c * 9 + ks:].view(sk).to(tk),
-                wsum[:c * 9].view(sv).to(tv), dgamma, dbeta, None, None, None, None, None)
+                wsum[:c * 9].view(sv).to(tv).as_strided(sv, ctx.wv_stride), dgamma, dbeta, None, None, None, None, None)
 
 
 def mrla_base(x, wq, wk, wv, d, stage, bn=None, dp=None, identity=None):

@@ -266,13 +266,22 @@ __global__ __launch_bounds__(kThreads) void gate_bwd_kernel(
   }
 }
 
+// out[i] = sum_r in[r, i].  A workgroup covers `cpb` columns (power of two <= 64) with 256/cpb row lanes each, so
+// narrow matrices (the [b, 2k] Wq/Wk partials) still get hundreds of loads in flight; fixed summation order.
 __global__ __launch_bounds__(kThreads) void reduce_rows_kernel(const float* __restrict__ in, float* __restrict__ out,
-                                                               int rows, int n) {
-  const int i = blockIdx.x * kThreads + threadIdx.x;
-  if (i >= n) return;
+                                                               int rows, int n, int cpb) {
+  __shared__ double part[kThreads];
+  const int cx = threadIdx.x % cpb, ry = threadIdx.x / cpb, rl = kThreads / cpb;
+  const int i = blockIdx.x * cpb + cx;
   double s = 0.0;
-  for (int r = 0; r < rows; ++r) s += in[(size_t)r * n + i];
-  out[i] = (float)s;
+  if (i < n)
+    for (int r = ry; r < rows; r += rl) s += in[(size_t)r * n + i];
+  part[threadIdx.x] = s;
+  __syncthreads();
+  if (ry == 0 && i < n) {
+    for (int k = 1; k < rl; ++k) s += part[k * cpb + cx];
+    out[i] = (float)s;
+  }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -314,7 +323,10 @@ int launch_gate_bwd(const float* mom, const float* bmom, const float* gate, cons
 }
 
 int launch_reduce_rows(const float* in, float* out, int rows, int n, hipStream_t st) {
-  hipLaunchKernelGGL(reduce_rows_kernel, dim3((n + kThreads - 1) / kThreads), dim3(kThreads), 0, st, in, out, rows, n);
+  int cpb = 64;
+  while (cpb > 1 && cpb / 2 >= n) cpb >>= 1;                  // narrow matrices: fewer columns, more row lanes
+  if (rows < 16) cpb = 64;
+  hipLaunchKernelGGL(reduce_rows_kernel, dim3((n + cpb - 1) / cpb), dim3(kThreads), 0, st, in, out, rows, n, cpb);
   return hip_status(hipGetLastError());
 }
 

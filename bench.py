@@ -27,6 +27,10 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0     # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6300 GB/s is the measured copy ceiling
+MFMA_BF16_PEAK_TFLOPS = 2500.0   # dense bf16 MFMA peak (same guide)
+# forward+backward flops per 224x224 image (3 x the hook-counted forward MACs*2 of SURVEY.md section 8d); these are
+# almost entirely MIOpen convolution flops, not this build's kernels -- reported for the "fraction of compute roofline"
+MODEL_GFLOP_PER_IMAGE = {"resnet50_mrlal": 24.8, "resnet101_mrlab": 48.7}
 
 
 def parse():
@@ -220,6 +224,11 @@ def main():
                "roofline": roofline,
                "mrla_kernels": {k: {"launches": v["launches"], "ms_per_step": round(v["ms"] / args.steps, 3),
                                     "GBps": round(v["bytes"] / (v["ms"] * 1e-3) / 1e9, 1)} for k, v in ks.items()}}
+        if args.arch in MODEL_GFLOP_PER_IMAGE:
+            tf = ips * MODEL_GFLOP_PER_IMAGE[args.arch] / 1e3
+            out["compute_roofline"] = {"model_tflops": round(tf, 1), "peak_bf16_mfma_tflops": MFMA_BF16_PEAK_TFLOPS * world,
+                                       "frac": round(tf / (MFMA_BF16_PEAK_TFLOPS * world), 4),
+                                       "note": "whole-model flops (MIOpen convolutions); the MRLA kernels are HBM/VALU work"}
         if world == 1 and not args.no_baselines:
             out["eager_rocm"] = eager_rocm(args.arch, args.batch, args.drop_path)
             out["cpu_baseline"] = cpu_baseline(args.arch)

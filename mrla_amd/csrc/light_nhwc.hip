@@ -47,19 +47,36 @@ struct RowLoad {
   bool live;                                    // wave-uniform: row inside the image
 };
 
+// Per-strip lane addressing of a row piece: element offset of this lane's 16 bytes inside an image row and whether
+// its pixel exists.  Computed once per strip; per row only a wave-uniform row pointer is added.
 template <typename T, int NPX>
-__device__ __forceinline__ void issue_row(RowLoad<T, NPX>& q, const T* __restrict__ img, int r, int col0, int H, int W,
-                                          int C, int cbase, int lane) {
+struct RowAddr {
+  int off[RowLoad<T, NPX>::NL];
+  bool ok[RowLoad<T, NPX>::NL];
+};
+template <typename T, int NPX>
+__device__ __forceinline__ void make_row_addr(RowAddr<T, NPX>& a, int col0, int W, int C, int cbase, int lane) {
   typedef RowLoad<T, NPX> Q;
-  static_assert(Q::NL * 1024 <= scratch_bytes<T>(), "scratch too small");
-  q.live = r >= 0 && r < H;
   const int px = lane / Q::UPP, part = lane - px * Q::UPP;
 #pragma unroll
   for (int l = 0; l < Q::NL; ++l) {
     const int p = l * Q::PPL + px, col = col0 + p;
+    a.ok[l] = p < NPX && col >= 0 && col < W;
+    a.off[l] = a.ok[l] ? col * C + cbase + part * Q::VEC : 0;
+  }
+}
+
+template <typename T, int NPX>
+__device__ __forceinline__ void issue_row(RowLoad<T, NPX>& q, const T* __restrict__ img, int r, int H, int rowstride,
+                                          const RowAddr<T, NPX>& a) {
+  typedef RowLoad<T, NPX> Q;
+  static_assert(Q::NL * 1024 <= scratch_bytes<T>(), "scratch too small");
+  q.live = r >= 0 && r < H;
+  const T* rowp = img + (size_t)(q.live ? r : 0) * rowstride;          // wave-uniform
+#pragma unroll
+  for (int l = 0; l < Q::NL; ++l) {
     q.regs[l] = (u32x4){0u, 0u, 0u, 0u};
-    if (q.live && p < NPX && col >= 0 && col < W)
-      q.regs[l] = *reinterpret_cast<const u32x4*>(img + ((size_t)r * W + col) * C + cbase + part * Q::VEC);
+    if (q.live && a.ok[l]) q.regs[l] = *reinterpret_cast<const u32x4*>(rowp + (unsigned)a.off[l]);
   }
 }
 
@@ -82,7 +99,9 @@ template <typename T, int NPX>
 __device__ __forceinline__ void gather_row(const T* __restrict__ img, int r, int col0, int H, int W, int C, int cbase,
                                            int lane, T* __restrict__ scratch, float (&out)[NPX]) {
   RowLoad<T, NPX> q;
-  issue_row<T, NPX>(q, img, r, col0, H, W, C, cbase, lane);
+  RowAddr<T, NPX> a;
+  make_row_addr<T, NPX>(a, col0, W, C, cbase, lane);
+  issue_row<T, NPX>(q, img, r, H, W * C, a);
   finish_row<T, NPX>(q, lane, scratch, out);
 }
 
@@ -197,17 +216,20 @@ __global__ __launch_bounds__(kMaxStrips * kWave) void light_stats_fwd_nhwc(
       float ob[kS + 2], oc[kS + 2];                    // o rows r, r+1 (same columns)
       // row pieces of the NEXT load_row() call are already in flight (WIDE): software pipeline of depth one row
       RowLoad<T, kS + 2> qx, qo;
+      RowAddr<T, kS + 2> ax, ao;
       if (WIDE) {
-        issue_row<T, kS + 2>(qx, xi, 0, s0 - 1, H, W, C, cbase, lane);
-        if (HAS_O) issue_row<T, kS + 2>(qo, oi, 0, s0 - 1, H, W, C, cbase, lane);
+        make_row_addr<T, kS + 2>(ax, s0 - 1, W, C, cbase, lane);
+        make_row_addr<T, kS + 2>(ao, s0 - 1, W, C, cbase, lane);
+        issue_row<T, kS + 2>(qx, xi, 0, H, W * C, ax);
+        if (HAS_O) issue_row<T, kS + 2>(qo, oi, 0, H, W * C, ao);
       }
       // loads row r into (dst, odst); FUSE forms x = relu(pre + o) and stores the owned pixels to xout
       auto load_row = [&](int r, float (&dst)[kS + 2], float (&odst)[kS + 2]) {
         if (WIDE) {
           finish_row<T, kS + 2>(qx, lane, SCR(0), dst);
           if (HAS_O) finish_row<T, kS + 2>(qo, lane, SCR(1), odst);
-          issue_row<T, kS + 2>(qx, xi, r + 1, s0 - 1, H, W, C, cbase, lane);
-          if (HAS_O) issue_row<T, kS + 2>(qo, oi, r + 1, s0 - 1, H, W, C, cbase, lane);
+          issue_row<T, kS + 2>(qx, xi, r + 1, H, W * C, ax);
+          if (HAS_O) issue_row<T, kS + 2>(qo, oi, r + 1, H, W * C, ao);
         } else {
           read_row<T, false, kS + 2>(xi, r, s0 - 1, H, W, C, cbase, cc, lane, SCR(0), dst);
           if (HAS_O) read_row<T, false, kS + 2>(oi, r, s0 - 1, H, W, C, cbase, cc, lane, SCR(1), odst);
@@ -293,17 +315,21 @@ __global__ __launch_bounds__(kMaxStrips * kWave) void light_apply_fwd_nhwc(
       read_row<T, WIDE, kS + 2>(xi, 0, s0 - 1, H, W, C, cbase, cc, lane, SCR(0), rb);
       RowLoad<T, kS + 2> qx;
       RowLoad<T, kS> qo;
+      RowAddr<T, kS + 2> ax;
+      RowAddr<T, kS> ao;
       if (WIDE) {
-        issue_row<T, kS + 2>(qx, xi, 1, s0 - 1, H, W, C, cbase, lane);
-        if (HAS_O) issue_row<T, kS>(qo, oi, 0, s0, H, W, C, cbase, lane);
+        make_row_addr<T, kS + 2>(ax, s0 - 1, W, C, cbase, lane);
+        make_row_addr<T, kS>(ao, s0, W, C, cbase, lane);
+        issue_row<T, kS + 2>(qx, xi, 1, H, W * C, ax);
+        if (HAS_O) issue_row<T, kS>(qo, oi, 0, H, W * C, ao);
       }
       for (int r = 0; r < H; ++r) {
         float ov[kS], y[kS];
         if (WIDE) {
           finish_row<T, kS + 2>(qx, lane, SCR(0), rc);
           if (HAS_O) finish_row<T, kS>(qo, lane, SCR(1), ov);
-          issue_row<T, kS + 2>(qx, xi, r + 2, s0 - 1, H, W, C, cbase, lane);
-          if (HAS_O) issue_row<T, kS>(qo, oi, r + 1, s0, H, W, C, cbase, lane);
+          issue_row<T, kS + 2>(qx, xi, r + 2, H, W * C, ax);
+          if (HAS_O) issue_row<T, kS>(qo, oi, r + 1, H, W * C, ao);
         } else {
           read_row<T, false, kS + 2>(xi, r + 1, s0 - 1, H, W, C, cbase, cc, lane, SCR(0), rc);
           if (HAS_O) read_row<T, false, kS>(oi, r, s0, H, W, C, cbase, cc, lane, SCR(1), ov);
@@ -348,10 +374,15 @@ __global__ __launch_bounds__(kMaxStrips * kWave) void light_stats_bwd_nhwc(
       read_row<T, WIDE, kS + 2>(xi, 0, s0 - 1, H, W, C, cbase, cc, lane, SCR(0), rb);
       RowLoad<T, kS + 2> qx;
       RowLoad<T, kS> qg, qo;
+      RowAddr<T, kS + 2> ax;
+      RowAddr<T, kS> ag, ao;
       if (WIDE) {
-        issue_row<T, kS + 2>(qx, xi, 1, s0 - 1, H, W, C, cbase, lane);
-        issue_row<T, kS>(qg, gi, 0, s0, H, W, C, cbase, lane);
-        if (HAS_O) issue_row<T, kS>(qo, oi, 0, s0, H, W, C, cbase, lane);
+        make_row_addr<T, kS + 2>(ax, s0 - 1, W, C, cbase, lane);
+        make_row_addr<T, kS>(ag, s0, W, C, cbase, lane);
+        make_row_addr<T, kS>(ao, s0, W, C, cbase, lane);
+        issue_row<T, kS + 2>(qx, xi, 1, H, W * C, ax);
+        issue_row<T, kS>(qg, gi, 0, H, W * C, ag);
+        if (HAS_O) issue_row<T, kS>(qo, oi, 0, H, W * C, ao);
       }
       for (int r = 0; r < H; ++r) {
         float gv[kS], ov[kS];
@@ -359,9 +390,9 @@ __global__ __launch_bounds__(kMaxStrips * kWave) void light_stats_bwd_nhwc(
           finish_row<T, kS + 2>(qx, lane, SCR(0), rc);
           finish_row<T, kS>(qg, lane, SCR(1), gv);
           if (HAS_O) finish_row<T, kS>(qo, lane, SCR(2), ov);
-          issue_row<T, kS + 2>(qx, xi, r + 2, s0 - 1, H, W, C, cbase, lane);
-          issue_row<T, kS>(qg, gi, r + 1, s0, H, W, C, cbase, lane);
-          if (HAS_O) issue_row<T, kS>(qo, oi, r + 1, s0, H, W, C, cbase, lane);
+          issue_row<T, kS + 2>(qx, xi, r + 2, H, W * C, ax);
+          issue_row<T, kS>(qg, gi, r + 1, H, W * C, ag);
+          if (HAS_O) issue_row<T, kS>(qo, oi, r + 1, H, W * C, ao);
         } else {
           read_row<T, false, kS + 2>(xi, r + 1, s0 - 1, H, W, C, cbase, cc, lane, SCR(0), rc);
           read_row<T, false, kS>(gi, r, s0, H, W, C, cbase, cc, lane, SCR(1), gv);
@@ -427,43 +458,49 @@ __global__ __launch_bounds__(kMaxStrips * kWave) void light_apply_bwd_nhwc(
       const int s0 = s * kS, nc = min(kS, W - s0);
       float xa[kS + 4], xb[kS + 4], xc[kS + 4];      // x rows rr-1, rr, rr+1
       float ua[kS + 2], ub[kS + 2], uc[kS + 2];      // dU rows rr-2, rr-1, rr
-      float gprev[kS], dmprev[kS];                   // dOut[rr-1], lam*dm[rr-1] on the owned columns
 #pragma unroll
       for (int j = 0; j < kS + 4; ++j) xa[j] = 0.f;
       read_row<T, WIDE, kS + 4>(xi, 0, s0 - 2, H, W, C, cbase, cc, lane, SCR(0), xb);
 #pragma unroll
       for (int j = 0; j < kS + 2; ++j) { ua[j] = 0.f; ub[j] = 0.f; }
-#pragma unroll
-      for (int j = 0; j < kS; ++j) { gprev[j] = 0.f; dmprev[j] = 0.f; }
       // software pipeline (WIDE): the row pieces of step rr+1 are in flight while step rr computes
       RowLoad<T, kS + 4> qx;
       RowLoad<T, kS + 2> qg, qo;
+      RowAddr<T, kS + 4> ax;
+      RowAddr<T, kS + 2> ag, ao;
       if (WIDE) {
-        issue_row<T, kS + 4>(qx, xi, 1, s0 - 2, H, W, C, cbase, lane);
-        issue_row<T, kS + 2>(qg, gi, 0, s0 - 1, H, W, C, cbase, lane);
-        if (HAS_O) issue_row<T, kS + 2>(qo, oi, 0, s0 - 1, H, W, C, cbase, lane);
+        make_row_addr<T, kS + 4>(ax, s0 - 2, W, C, cbase, lane);
+        make_row_addr<T, kS + 2>(ag, s0 - 1, W, C, cbase, lane);
+        make_row_addr<T, kS + 2>(ao, s0 - 1, W, C, cbase, lane);
+        issue_row<T, kS + 4>(qx, xi, 1, H, W * C, ax);
+        issue_row<T, kS + 2>(qg, gi, 0, H, W * C, ag);
+        if (HAS_O) issue_row<T, kS + 2>(qo, oi, 0, H, W * C, ao);
       }
-      for (int rr = 0; rr <= H; ++rr) {
+      // One row step.  The window arrays rotate by NAME (XA/XB/XC, UA/UB/UC, G*/D* below), three steps per loop trip,
+      // so no register copies are spent on shifting the windows.
+      auto step = [&](int rr, float (&XA)[kS + 4], float (&XB)[kS + 4], float (&XC)[kS + 4], float (&UA)[kS + 2],
+                      float (&UB)[kS + 2], float (&UC)[kS + 2], float (&GP)[kS], float (&GC)[kS], float (&DP)[kS],
+                      float (&DC)[kS]) {
         float gv[kS + 2], ov[kS + 2];                // dOut / o of row rr on columns -1 .. kS (zero outside the image)
         if (WIDE) {
-          finish_row<T, kS + 4>(qx, lane, SCR(0), xc);
+          finish_row<T, kS + 4>(qx, lane, SCR(0), XC);
           finish_row<T, kS + 2>(qg, lane, SCR(1), gv);
           if (HAS_O) finish_row<T, kS + 2>(qo, lane, SCR(2), ov);
-          issue_row<T, kS + 4>(qx, xi, rr + 2, s0 - 2, H, W, C, cbase, lane);
-          issue_row<T, kS + 2>(qg, gi, rr + 1, s0 - 1, H, W, C, cbase, lane);
-          if (HAS_O) issue_row<T, kS + 2>(qo, oi, rr + 1, s0 - 1, H, W, C, cbase, lane);
+          issue_row<T, kS + 4>(qx, xi, rr + 2, H, W * C, ax);
+          issue_row<T, kS + 2>(qg, gi, rr + 1, H, W * C, ag);
+          if (HAS_O) issue_row<T, kS + 2>(qo, oi, rr + 1, H, W * C, ao);
         } else {
-          read_row<T, false, kS + 4>(xi, rr + 1, s0 - 2, H, W, C, cbase, cc, lane, SCR(0), xc);
+          read_row<T, false, kS + 4>(xi, rr + 1, s0 - 2, H, W, C, cbase, cc, lane, SCR(0), XC);
           read_row<T, false, kS + 2>(gi, rr, s0 - 1, H, W, C, cbase, cc, lane, SCR(1), gv);
           if (HAS_O) read_row<T, false, kS + 2>(oi, rr, s0 - 1, H, W, C, cbase, cc, lane, SCR(2), ov);
         }
-        float gcur[kS], dmcur[kS], dorow[kS];
+        float dorow[kS];
         // dU[rr] on columns -1 .. kS (zero outside the image)
 #pragma unroll
         for (int j = 0; j < kS + 2; ++j) {
           const int col = s0 - 1 + j;
           const bool in = rr < H && col >= 0 && col < W;                    // wave-uniform
-          const float u = conv_at(w, xa, xb, xc, j);                        // window cols j..j+2 <-> image cols col-1..col+1
+          const float u = conv_at(w, XA, XB, XC, j);                        // window cols j..j+2 <-> image cols col-1..col+1
           const float v = GELU ? gelu_f(u) : u;
           float dm = fmaf(E, gv[j], Hc);
           dm = fmaf(F, v, dm);
@@ -472,17 +509,17 @@ __global__ __launch_bounds__(kMaxStrips * kWave) void light_apply_bwd_nhwc(
           if (GELU) du *= gelu_grad_f(u);
           du = in ? du : 0.f;
           if (j >= 1 && j <= kS) {                                          // owned column (compile-time after unroll)
-            gcur[j - 1] = gv[j];
-            dmcur[j - 1] = in ? lm * dm : 0.f;
-            dorow[j - 1] = dmcur[j - 1];
+            GC[j - 1] = gv[j];
+            DC[j - 1] = in ? lm * dm : 0.f;
+            dorow[j - 1] = DC[j - 1];
             if (j - 1 < nc) {
               // dWv[i][k] += dU[rr][col] * x[rr+i-1][col+k-1]
-              wg[0] = fmaf(du, xa[j], wg[0]); wg[1] = fmaf(du, xa[j + 1], wg[1]); wg[2] = fmaf(du, xa[j + 2], wg[2]);
-              wg[3] = fmaf(du, xb[j], wg[3]); wg[4] = fmaf(du, xb[j + 1], wg[4]); wg[5] = fmaf(du, xb[j + 2], wg[5]);
-              wg[6] = fmaf(du, xc[j], wg[6]); wg[7] = fmaf(du, xc[j + 1], wg[7]); wg[8] = fmaf(du, xc[j + 2], wg[8]);
+              wg[0] = fmaf(du, XA[j], wg[0]); wg[1] = fmaf(du, XA[j + 1], wg[1]); wg[2] = fmaf(du, XA[j + 2], wg[2]);
+              wg[3] = fmaf(du, XB[j], wg[3]); wg[4] = fmaf(du, XB[j + 1], wg[4]); wg[5] = fmaf(du, XB[j + 2], wg[5]);
+              wg[6] = fmaf(du, XC[j], wg[6]); wg[7] = fmaf(du, XC[j + 1], wg[7]); wg[8] = fmaf(du, XC[j + 2], wg[8]);
             }
           }
-          uc[j] = du;
+          UC[j] = du;
         }
         if (HAS_O && !RELU && rr < H) write_row<T, WIDE, kS>(doo, rr, s0, nc, W, C, cbase, c, cv, lane, SCR(4), dorow);
         // dx[rr-1] on the owned columns:  dx[ro][col] = sum_{i,k} w[i][k] * dU[ro-i+1][col-k+1]
@@ -492,24 +529,32 @@ __global__ __launch_bounds__(kMaxStrips * kWave) void light_apply_bwd_nhwc(
 #pragma unroll
           for (int j = 0; j < kS; ++j) {
             // window index of column (col + 1 - k) in the dU arrays (which start at col -1): j + 2 - k
-            float s9 = w[0] * uc[j + 2];
-            s9 = fmaf(w[1], uc[j + 1], s9); s9 = fmaf(w[2], uc[j], s9);
-            s9 = fmaf(w[3], ub[j + 2], s9); s9 = fmaf(w[4], ub[j + 1], s9); s9 = fmaf(w[5], ub[j], s9);
-            s9 = fmaf(w[6], ua[j + 2], s9); s9 = fmaf(w[7], ua[j + 1], s9); s9 = fmaf(w[8], ua[j], s9);
-            float y = fmaf(resf, gprev[j], s9 + dy);
-            if (RELU) y = (xa[j + 2] > 0.f) ? y : 0.f;                      // xa = x[rr-1] = x[ro]; owned col j <-> window j+2
+            float s9 = w[0] * UC[j + 2];
+            s9 = fmaf(w[1], UC[j + 1], s9); s9 = fmaf(w[2], UC[j], s9);
+            s9 = fmaf(w[3], UB[j + 2], s9); s9 = fmaf(w[4], UB[j + 1], s9); s9 = fmaf(w[5], UB[j], s9);
+            s9 = fmaf(w[6], UA[j + 2], s9); s9 = fmaf(w[7], UA[j + 1], s9); s9 = fmaf(w[8], UA[j], s9);
+            float y = fmaf(resf, GP[j], s9 + dy);
+            if (RELU) y = (XA[j + 2] > 0.f) ? y : 0.f;                      // XA = x[rr-1] = x[ro]; owned col j <-> window j+2
             yrow[j] = y;
-            dsum[j] = dmprev[j] + y;
+            dsum[j] = DP[j] + y;
           }
           write_row<T, WIDE, kS>(dxo, ro, s0, nc, W, C, cbase, c, cv, lane, SCR(3), yrow);
           if (RELU && HAS_O) write_row<T, WIDE, kS>(doo, ro, s0, nc, W, C, cbase, c, cv, lane, SCR(4), dsum);
         }
+      };
+      float g0[kS], g1[kS], g2[kS], d0[kS], d1[kS], d2[kS];
 #pragma unroll
-        for (int j = 0; j < kS + 4; ++j) { xa[j] = xb[j]; xb[j] = xc[j]; }
-#pragma unroll
-        for (int j = 0; j < kS + 2; ++j) { ua[j] = ub[j]; ub[j] = uc[j]; }
-#pragma unroll
-        for (int j = 0; j < kS; ++j) { gprev[j] = gcur[j]; dmprev[j] = dmcur[j]; }
+      for (int j = 0; j < kS; ++j) { g0[j] = 0.f; d0[j] = 0.f; }
+      // steps rr = 0 .. H; after three steps every array is back in its starting role
+      int rr = 0;
+      for (; rr + 2 <= H; rr += 3) {
+        step(rr,     xa, xb, xc, ua, ub, uc, g0, g1, d0, d1);
+        step(rr + 1, xb, xc, xa, ub, uc, ua, g1, g2, d1, d2);
+        step(rr + 2, xc, xa, xb, uc, ua, ub, g2, g0, d2, d0);
+      }
+      if (rr <= H) {
+        step(rr, xa, xb, xc, ua, ub, uc, g0, g1, d0, d1);
+        if (rr + 1 <= H) step(rr + 1, xb, xc, xa, ub, uc, ua, g1, g2, d1, d2);
       }
     }
   }

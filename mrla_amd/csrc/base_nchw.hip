@@ -236,7 +236,8 @@ __global__ __launch_bounds__(kThreads) void base_attend_fwd_nchw(
 // ------------------------------------------------------------------------------------------------
 // plain BatchNorm statistics from per-(image, channel) (sum, sum of squares)
 // ------------------------------------------------------------------------------------------------
-constexpr int kBnCh2 = 16;
+// 4 channels x 64 row lanes: the NHWC moment passes leave up to b*nsplit (thousands of) partial rows per channel
+constexpr int kBnCh2 = 4;
 constexpr int kBnLanes2 = kThreads / kBnCh2;
 
 __global__ __launch_bounds__(kThreads) void plain_bn_fwd_kernel(

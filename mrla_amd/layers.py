@@ -9,6 +9,8 @@ Reference counterparts (paths relative to the reference repo):
 """
 from math import sqrt
 
+import math
+
 import torch
 import torch.nn as nn
 
@@ -234,3 +236,32 @@ class mrlal_module(nn.Module):
             raise MrlaHipError("mrlal_module: the HIP path implements affine nn.LayerNorm for normx / normo")
         return F_.mrla_token_light(xt, ot_1, nx.weight, nx.bias, no.weight, no.bias, m.Wq.weight, m.Wk.weight,
                                    m.Wv.weight, self.lambda_t, m.dim_perhead, eps=nx.eps, res=fused_residual)
+
+
+class mrlab_layer(mrla_base_layer):
+    """MRLA-base layer of the DeiT variant (deit/deit_mrla_base.py:120-201): identical math to the ResNet one."""
+
+
+class mrlab_module(nn.Module):
+    """Token module of DeiT + MRLA-base (deit/deit_mrla_base.py:204-243): LayerNorm(x_t), the 14x14 map tokens
+    through the MRLA-base layer (softmax over the stage history on HIP), cls token passed through."""
+
+    def __init__(self, input_dim, dim_perhead, init_cell=False, channel_wise=False, norm_layer=None):
+        super().__init__()
+        self.dim_perhead = 1 if channel_wise else dim_perhead
+        self.init_cell = init_cell
+        norm_layer = norm_layer or (lambda c: nn.LayerNorm(c, eps=1e-6))
+        self.normx = norm_layer(input_dim)
+        self.mrla = mrlab_layer(input_dim=input_dim, dim_perhead=self.dim_perhead, init_cell=init_cell)
+
+    def forward(self, xt, prev_k, prev_v):
+        xt = self.normx(xt)
+        if self.init_cell:
+            prev_k = prev_v = None
+        b, n, c = xt.shape
+        side = math.isqrt(n - 1)
+        if side * side != n - 1:
+            raise MrlaHipError(f"mrlab_module: {n - 1} map tokens do not form a square map")
+        fmap = xt[:, 1:].reshape(b, side, side, c).permute(0, 3, 1, 2).contiguous()
+        out, kt, vt = self.mrla(fmap, prev_k, prev_v)
+        return torch.cat((xt[:, :1], out.flatten(2).transpose(1, 2)), dim=1), kt, vt

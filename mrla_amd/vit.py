@@ -16,7 +16,8 @@ except Exception:                       # pragma: no cover - timm is not install
     def register_model(fn):
         return fn
 
-__all__ = ["deit_mrlal_tiny_patch16_224", "deit_mrlal_small_patch16_224", "deit_mrlal_base_patch16_224"]
+__all__ = ["deit_mrlal_tiny_patch16_224", "deit_mrlal_small_patch16_224", "deit_mrlal_base_patch16_224",
+           "deit_mrlab_tiny_patch16_224", "deit_mrlab_small_patch16_224", "deit_mrlab_base_patch16_224"]
 
 
 def _pair(v):
@@ -120,11 +121,9 @@ class ViT_mrlal(nn.Module):
         self.dist_token = None
         self.pos_embed = nn.Parameter(torch.zeros(1, self.patch_embed.num_patches + self.num_tokens, embed_dim))
         self.pos_drop = nn.Dropout(p=drop_rate)
-        dpr = [v.item() for v in torch.linspace(0, drop_path_rate, depth)]
-        self.blocks = nn.Sequential(*[
-            Block(dim=embed_dim, num_heads=num_heads, dim_mrla=dim_mrla, mlp_ratio=mlp_ratio, qkv_bias=qkv_bias,
-                  drop=drop_rate, attn_drop=attn_drop_rate, drop_path=dpr[i], norm_layer=norm_layer, act_layer=act_layer)
-            for i in range(depth)])
+        self.blocks = self._make_blocks(depth, drop_path_rate, dim=embed_dim, num_heads=num_heads, dim_mrla=dim_mrla,
+                                        mlp_ratio=mlp_ratio, qkv_bias=qkv_bias, drop=drop_rate, attn_drop=attn_drop_rate,
+                                        norm_layer=norm_layer, act_layer=act_layer)
         self.norm = norm_layer(embed_dim)
         if representation_size:
             self.num_features = representation_size
@@ -137,6 +136,11 @@ class ViT_mrlal(nn.Module):
         nn.init.trunc_normal_(self.pos_embed, std=0.02)
         nn.init.trunc_normal_(self.cls_token, std=0.02)
         self.apply(_init_vit_weights)
+
+    @staticmethod
+    def _make_blocks(depth, drop_path_rate, **kw):
+        dpr = [v.item() for v in torch.linspace(0, drop_path_rate, depth, device="cpu")]
+        return nn.Sequential(*[Block(drop_path=dpr[i], **kw) for i in range(depth)])
 
     @torch.jit.ignore
     def no_weight_decay(self):
@@ -157,6 +161,70 @@ class ViT_mrlal(nn.Module):
 
     def forward(self, x):
         return self.head(self.forward_features(x))
+
+
+class Block_base(nn.Module):
+    """deit/deit_mrla_base.py:246-277 (`Block` there): the K/V history restarts every `mrlab_size` blocks."""
+
+    def __init__(self, dim, num_heads, dim_mrla, init_cell=False, layer_index=0, mrlab_size=4, mlp_ratio=4.0,
+                 qkv_bias=False, drop=0.0, attn_drop=0.0, drop_path=0.0, act_layer=nn.GELU,
+                 norm_layer=partial(nn.LayerNorm, eps=1e-6)):
+        super().__init__()
+        self.norm1 = norm_layer(dim)
+        self.attn = Attention(dim, num_heads=num_heads, qkv_bias=qkv_bias, attn_drop=attn_drop, proj_drop=drop)
+        self.drop_path = layers.DropPath(drop_path) if drop_path > 0.0 else nn.Identity()
+        self.norm2 = norm_layer(dim)
+        self.mlp = Mlp(in_features=dim, hidden_features=int(dim * mlp_ratio), act_layer=act_layer, drop=drop)
+        self.mrla = layers.mrlab_module(input_dim=dim, dim_perhead=dim_mrla, init_cell=(layer_index % mrlab_size == 0))
+        self.mrla.mrla.history_hint = mrlab_size
+
+    def forward(self, x, prev_k, prev_v):
+        x = x + self.drop_path(self.attn(self.norm1(x)))
+        x = x + self.drop_path(self.mlp(self.norm2(x)))
+        attn_t, k, v = self.mrla(x, prev_k, prev_v)
+        return x + attn_t, k, v
+
+
+class ViT_mrlab(ViT_mrlal):
+    """deit/deit_mrla_base.py:280-413.  As there, every block's stochastic depth rate is 0.1 whatever
+    `drop_path_rate` says (:340), the blocks are an nn.ModuleList and K/V thread through them (:398-401)."""
+    mrlab_size = 4
+
+    @classmethod
+    def _make_blocks(cls, depth, drop_path_rate, **kw):
+        return nn.ModuleList([Block_base(layer_index=i, mrlab_size=cls.mrlab_size, drop_path=0.1, **kw)
+                              for i in range(depth)])
+
+    def forward_features(self, x):
+        x = self.patch_embed(x)
+        x = self.pos_drop(torch.cat((self.cls_token.expand(x.shape[0], -1, -1), x), dim=1) + self.pos_embed)
+        k = v = None
+        for blk in self.blocks:
+            x, k, v = blk(x, k, v)
+        return self.pre_logits(self.norm(x)[:, 0])
+
+
+def _deit_base_variant(embed_dim, num_heads, **kwargs):
+    kwargs.pop("pretrained", None)
+    model = ViT_mrlab(patch_size=16, embed_dim=embed_dim, depth=12, num_heads=num_heads, dim_mrla=16, mlp_ratio=4,
+                      qkv_bias=True, norm_layer=partial(nn.LayerNorm, eps=1e-6), **kwargs)
+    model.default_cfg = {"input_size": (3, 224, 224), "num_classes": 1000}
+    return model
+
+
+@register_model
+def deit_mrlab_tiny_patch16_224(pretrained=False, **kwargs):
+    return _deit_base_variant(192, 3, **kwargs)
+
+
+@register_model
+def deit_mrlab_small_patch16_224(pretrained=False, **kwargs):
+    return _deit_base_variant(384, 6, **kwargs)
+
+
+@register_model
+def deit_mrlab_base_patch16_224(pretrained=False, **kwargs):
+    return _deit_base_variant(768, 12, **kwargs)
 
 
 def _deit(embed_dim, num_heads, **kwargs):

@@ -420,3 +420,73 @@ class EagerViTLight(nn.Module):
 
 def eager_deit_mrlal_tiny_patch16_224(**kw):
     return EagerViTLight(embed_dim=192, depth=12, num_heads=3, dim_mrla=16, **kw)
+
+
+# ------------------------------------------------------------------------------------------------
+# DeiT + MRLA-base (token layout; history reset every 4 blocks)  -- deit/deit_mrla_base.py:120-277,280-450
+# ------------------------------------------------------------------------------------------------
+class EagerTokenBaseModule(nn.Module):
+    """deit_mrla_base.py:204-243."""
+
+    def __init__(self, c, d, init_cell=False):
+        super().__init__()
+        self.init_cell = init_cell
+        self.normx = nn.LayerNorm(c, eps=1e-6)
+        self.mrla = EagerBaseLayer(c, d, init_cell)
+
+    def forward(self, xt, K_prev, V_prev):
+        xn = self.normx(xt)
+        if self.init_cell:
+            K_prev = V_prev = None
+        b, n, c = xn.shape
+        side = int(sqrt(n - 1))
+        fmap = xn[:, 1:].reshape(b, side, side, c).permute(0, 3, 1, 2)
+        out, K, V = self.mrla(fmap, K_prev, V_prev)
+        return torch.cat([xn[:, :1], out.flatten(2).transpose(1, 2)], dim=1), K, V
+
+
+class EagerViTBaseBlock(nn.Module):
+    """deit_mrla_base.py:246-277."""
+
+    def __init__(self, dim, heads, dim_mrla, layer_index, mrlab_size=4, mlp_ratio=4.0, qkv_bias=True, drop_path=0.0):
+        super().__init__()
+        ln = partial(nn.LayerNorm, eps=1e-6)
+        self.norm1, self.norm2 = ln(dim), ln(dim)
+        self.attn = _EagerAttention(dim, heads, qkv_bias)
+        self.mlp = _EagerMlp(dim, int(dim * mlp_ratio))
+        self.mrla = EagerTokenBaseModule(dim, dim_mrla, init_cell=(layer_index % mrlab_size == 0))
+        self.p_drop = drop_path
+
+    def forward(self, x, K, V):
+        x = x + stochastic_depth(self.attn(self.norm1(x)), self.p_drop, self.training)
+        x = x + stochastic_depth(self.mlp(self.norm2(x)), self.p_drop, self.training)
+        a, K, V = self.mrla(x, K, V)
+        return x + a, K, V
+
+
+class EagerViTBase(nn.Module):
+    """deit_mrla_base.py:280-450 (drop-path is hard-coded to 0.1 for every block there, :340)."""
+
+    def __init__(self, img_size=224, patch_size=16, in_chans=3, num_classes=1000, embed_dim=768, depth=12, num_heads=12,
+                 dim_mrla=16, mlp_ratio=4.0, qkv_bias=True, drop_path_rate=0.0):
+        super().__init__()
+        del drop_path_rate          # ignored by the reference too (:340)
+        self.patch_embed = _EagerPatchEmbed(img_size, patch_size, in_chans, embed_dim)
+        self.cls_token = nn.Parameter(torch.zeros(1, 1, embed_dim))
+        self.pos_embed = nn.Parameter(torch.zeros(1, self.patch_embed.num_patches + 1, embed_dim))
+        self.blocks = nn.ModuleList([EagerViTBaseBlock(embed_dim, num_heads, dim_mrla, i, 4, mlp_ratio, qkv_bias, 0.1)
+                                     for i in range(depth)])
+        self.norm = nn.LayerNorm(embed_dim, eps=1e-6)
+        self.head = nn.Linear(embed_dim, num_classes)
+
+    def forward(self, x):
+        x = self.patch_embed(x)
+        x = torch.cat([self.cls_token.expand(x.shape[0], -1, -1), x], dim=1) + self.pos_embed
+        K = V = None
+        for blk in self.blocks:
+            x, K, V = blk(x, K, V)
+        return self.head(self.norm(x)[:, 0])
+
+
+def eager_deit_mrlab_tiny_patch16_224(**kw):
+    return EagerViTBase(embed_dim=192, depth=12, num_heads=3, dim_mrla=16, **kw)

@@ -237,6 +237,34 @@ def gen_tokens(deit_light):
     print("token_modules.npz", sum(v.nbytes for v in out.values()) // 1024, "KiB")
 
 
+def gen_token_base(deit_base):
+    """deit_mrla_base.py mrlab_module chain of 5 (history reset at index 4), x_t + module(x_t) as in Block.forward."""
+    out = {}
+    b, n, c, d = 2, 17, 32, 16
+    mods, xs, loss, K, V = [], [], 0.0, None, None
+    for t in range(5):
+        m = deit_base.mrlab_module(c, d, init_cell=(t % 4 == 0))
+        load_det(m, salt=30 + t)
+        s_ = detgen.seed_of(f"tokbase/{t}")
+        x = T(detgen.normalish((b, n, c), s_) * 1.2 + 0.1).requires_grad_(True)
+        y, K, V = m(x, K, V)
+        loss = loss + ((x + y) * T(detgen.normalish((b, n, c), s_ + 1))).sum()
+        out[f"{t}/module_out"] = N(y)
+        mods.append(m); xs.append(x)
+    loss.backward()
+    for t in range(5):
+        out[f"{t}/dx"] = N(xs[t].grad)
+        for pn, pv in mods[t].named_parameters():
+            out[f"{t}/grad/{pn}"] = N(pv.grad)
+    net = deit_base.deit_mrlab_tiny_patch16_224()
+    load_det(net)
+    net.eval()
+    with torch.no_grad():
+        out["deit_mrlab_tiny/eval2/logits"] = N(net(T(image_batch(2))))
+    np.savez_compressed(os.path.join(OUT, "token_base.npz"), **out)
+    print("token_base.npz", sum(v.nbytes for v in out.values()) // 1024, "KiB")
+
+
 # ------------------------------------------------------------------------------------------------
 # (iv) full models
 # ------------------------------------------------------------------------------------------------
@@ -304,12 +332,34 @@ def gen_models(ref, deit_light):
     print("models.npz", sum(v.nbytes for v in out.values()) // 1024, "KiB")
 
 
+def gen_state_dict_layout(ref, deit_light, deit_base):
+    """Names and shapes of every state_dict entry of the reference models: the checkpoint-compatibility contract
+    (resnet/train.py:226-245,333-338 save / resume plain state_dicts)."""
+    import json
+    layout = {}
+    for name, factory in (("resnet50_mrlal", ref["resnet_mrla_light"].resnet50_mrlal),
+                          ("resnet101_mrlal", ref["resnet_mrla_light"].resnet101_mrlal),
+                          ("resnet50_mrlab", ref["resnet_mrla_base"].resnet50_mrlab),
+                          ("resnet101_mrlab", ref["resnet_mrla_base"].resnet101_mrlab),
+                          ("deit_mrlal_tiny_patch16_224", deit_light.deit_mrlal_tiny_patch16_224),
+                          ("deit_mrlal_small_patch16_224", deit_light.deit_mrlal_small_patch16_224),
+                          ("deit_mrlab_tiny_patch16_224", deit_base.deit_mrlab_tiny_patch16_224)):
+        layout[name] = {k: list(v.shape) for k, v in factory().state_dict().items()}
+    with open(os.path.join(OUT, "state_dict_layout.json"), "w") as f:
+        json.dump(layout, f, separators=(",", ":"))
+    print("state_dict_layout.json", {k: len(v) for k, v in layout.items()})
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
     torch.manual_seed(0)
     ref = import_reference_resnet()
-    deit_light, _ = import_reference_deit()
-    which = sys.argv[1:] or ["light", "base", "tokens", "models"]
+    deit_light, deit_base = import_reference_deit()
+    which = sys.argv[1:] or ["light", "base", "tokens", "models", "layout", "tokbase"]
+    if "tokbase" in which:
+        gen_token_base(deit_base)
+    if "layout" in which:
+        gen_state_dict_layout(ref, deit_light, deit_base)
     if "light" in which:
         gen_light(ref)
     if "base" in which:

@@ -51,3 +51,37 @@ def test_product_has_no_cpu_fallback():
     net = models.resnet50_mrlal()
     with pytest.raises(_lib.MrlaHipError):
         net(torch.zeros(1, 3, 64, 64))
+
+
+def test_state_dict_layout_equals_reference():
+    """Checkpoint compatibility (resnet/train.py:226-245,333-338): every state_dict key and shape of the reference models,
+    recorded from the reference itself in tests/golden/state_dict_layout.json, must be reproduced exactly."""
+    import io
+    import json
+    from contextlib import redirect_stdout
+
+    from mrla_amd import models, vit
+    layout = json.load(open(os.path.join(ROOT, "tests", "golden", "state_dict_layout.json")))
+    built = {"resnet50_mrlal": models.resnet50_mrlal, "resnet101_mrlal": models.resnet101_mrlal,
+             "resnet50_mrlab": models.resnet50_mrlab, "resnet101_mrlab": models.resnet101_mrlab,
+             "deit_mrlal_tiny_patch16_224": vit.deit_mrlal_tiny_patch16_224,
+             "deit_mrlal_small_patch16_224": vit.deit_mrlal_small_patch16_224,
+             "deit_mrlab_tiny_patch16_224": vit.deit_mrlab_tiny_patch16_224}
+    for name, factory in built.items():
+        with redirect_stdout(io.StringIO()):
+            sd = factory().state_dict()
+        want = layout[name]
+        assert set(sd) == set(want), (name, sorted(set(sd) ^ set(want))[:5])
+        for k, shape in want.items():
+            assert list(sd[k].shape) == shape, (name, k)
+    # a checkpoint in the reference's format round-trips through the product model
+    with redirect_stdout(io.StringIO()):
+        net = models.resnet50_mrlal()
+    ckpt = {"epoch": 3, "arch": "resnet50_mrlal", "state_dict": {"module." + k: v.clone() for k, v in net.state_dict().items()}}
+    buf = io.BytesIO()
+    torch.save(ckpt, buf)
+    buf.seek(0)
+    loaded = torch.load(buf, map_location="cpu")
+    with redirect_stdout(io.StringIO()):
+        net2 = models.resnet50_mrlal()
+    net2.load_state_dict({k[len("module."):]: v for k, v in loaded["state_dict"].items()})   # DDP prefix, as train.py saves it

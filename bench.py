@@ -124,6 +124,24 @@ def eager_rocm(arch, batch, drop_path, steps=6):
             "what": "oracle/eager_models.py (stock ATen/MIOpen ops) on this GPU, same batch/dtype/optimizer"}
 
 
+def forward_only(net, x, steps=10):
+    """Inference pass (eval, no_grad, bf16 autocast) of the product network: the numerator of the north-star's
+    ">= 4x the eager PyTorch-ROCm forward" target (eager_rocm.fwd_images_per_sec is its denominator)."""
+    was = net.training
+    net.eval()
+    with torch.no_grad(), torch.autocast("cuda", dtype=torch.bfloat16):
+        for _ in range(3):
+            net(x)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            net(x)
+        torch.cuda.synchronize()
+        fw = (time.perf_counter() - t0) / steps
+    net.train(was)
+    return {"fwd_images_per_sec": round(x.shape[0] / fw, 1), "ms": round(1e3 * fw, 3), "mode": "eval, no_grad, bf16 autocast"}
+
+
 def pmc_traffic(args, kernel):
     """HBM bytes per launch of `kernel` from the committed rocprofv3 PMC passes (2*FETCH_SIZE + WRITE_SIZE, gfx950
     correction of MI355X_MICROARCH.md; collected by scripts/pmc_bench.sh on this exact workload), else None."""
@@ -229,8 +247,12 @@ def main():
             out["compute_roofline"] = {"model_tflops": round(tf, 1), "peak_bf16_mfma_tflops": MFMA_BF16_PEAK_TFLOPS * world,
                                        "frac": round(tf / (MFMA_BF16_PEAK_TFLOPS * world), 4),
                                        "note": "whole-model flops (MIOpen convolutions); the MRLA kernels are HBM/VALU work"}
+        if world == 1:
+            out["forward_only"] = forward_only(net, x)
         if world == 1 and not args.no_baselines:
             out["eager_rocm"] = eager_rocm(args.arch, args.batch, args.drop_path)
+            out["forward_only"]["vs_eager_rocm"] = round(out["forward_only"]["fwd_images_per_sec"] /
+                                                         out["eager_rocm"]["fwd_images_per_sec"], 2)
             out["cpu_baseline"] = cpu_baseline(args.arch)
         print(json.dumps(out), flush=True)
     if dist_on:

@@ -59,9 +59,13 @@ int mrla_light_stats_fwd(const void* x, const void* o_prev, const float* wv /*[c
 
 /* Fused producer form: `pre` is the block's pre-activation (bn3 output).  x_t = relu(pre + o_prev) is formed on
  * the fly, written to x_out (it is what the apply pass and the backward read) and the moments are taken of it.
- * Replaces `out += identity; out = self.relu(out)` (resnet_mrla_light.py:113-114) on top of the statistics pass. */
-int mrla_light_stats_fwd_fused(const void* pre, const void* o_prev, const float* wv, float* mom, void* x_out, int b,
-                               int c, int h, int w, int dtype, int layout, void* stream);
+ * Replaces `out += identity; out = self.relu(out)` (resnet_mrla_light.py:113-114) on top of the statistics pass.
+ * pre_sc / pre_sh [opt, c floats each]: the affine of the BatchNorm in front (bn3, resnet_mrla_light.py:102) when the
+ * caller defers its elementwise pass: x_t = relu((pre_sc*pre + pre_sh) + o_prev), the affine result rounded to the
+ * storage type as the stand-alone pass would have stored it; `pre` is then conv3's raw output. */
+int mrla_light_stats_fwd_fused(const void* pre, const float* pre_sc, const float* pre_sh, const void* o_prev,
+                               const float* wv, float* mom, void* x_out, int b, int c, int h, int w, int dtype,
+                               int layout, void* stream);
 
 /* ---- gate: a[b, g] ------------------------------------------------------------------------------
  * Replaces Wq/Wk Conv1d, the per-head einsum and the sigmoid of mrla_light_module.py:59-60,67,70. */

@@ -84,24 +84,29 @@ int mrla_light_stats_fwd(const void* x, const void* o_prev, const float* wv, flo
                          int dtype, int layout, int act, void* stream) {
   if (!x || !wv || !mom || bad_dims(b, c, h, w) || bad_dtype(dtype)) return MRLA_EINVAL;
   if (layout == MRLA_NHWC)
-    return launch_light_stats_fwd_nhwc(x, o_prev, wv, mom, nullptr, b, c, h, w, dtype, act, (hipStream_t)stream);
+    return launch_light_stats_fwd_nhwc(x, o_prev, wv, mom, nullptr, nullptr, nullptr, b, c, h, w, dtype, act,
+                                       (hipStream_t)stream);
   if (layout != MRLA_NCHW) return MRLA_EINVAL;
   SlabGeo g;
   const int rc = light_geo(&g, b, c, h, w, dtype);
   if (rc != MRLA_OK) return rc;
-  return launch_light_stats_fwd_nchw(x, o_prev, wv, mom, nullptr, g, dtype, act, (hipStream_t)stream);
+  return launch_light_stats_fwd_nchw(x, o_prev, wv, mom, nullptr, nullptr, nullptr, g, dtype, act, (hipStream_t)stream);
 }
 
-int mrla_light_stats_fwd_fused(const void* pre, const void* o_prev, const float* wv, float* mom, void* x_out, int b,
-                               int c, int h, int w, int dtype, int layout, void* stream) {
+int mrla_light_stats_fwd_fused(const void* pre, const float* pre_sc, const float* pre_sh, const void* o_prev,
+                               const float* wv, float* mom, void* x_out, int b, int c, int h, int w, int dtype,
+                               int layout, void* stream) {
   if (!pre || !o_prev || !wv || !mom || !x_out || bad_dims(b, c, h, w) || bad_dtype(dtype)) return MRLA_EINVAL;
+  if ((pre_sc == nullptr) != (pre_sh == nullptr)) return MRLA_EINVAL;
   if (layout == MRLA_NHWC)
-    return launch_light_stats_fwd_nhwc(pre, o_prev, wv, mom, x_out, b, c, h, w, dtype, MRLA_ACT_NONE, (hipStream_t)stream);
+    return launch_light_stats_fwd_nhwc(pre, o_prev, wv, mom, x_out, pre_sc, pre_sh, b, c, h, w, dtype, MRLA_ACT_NONE,
+                                       (hipStream_t)stream);
   if (layout != MRLA_NCHW) return MRLA_EINVAL;
   SlabGeo g;
   const int rc = light_geo(&g, b, c, h, w, dtype);
   if (rc != MRLA_OK) return rc;
-  return launch_light_stats_fwd_nchw(pre, o_prev, wv, mom, x_out, g, dtype, MRLA_ACT_NONE, (hipStream_t)stream);
+  return launch_light_stats_fwd_nchw(pre, o_prev, wv, mom, x_out, pre_sc, pre_sh, g, dtype, MRLA_ACT_NONE,
+                                     (hipStream_t)stream);
 }
 
 int mrla_light_gate_fwd(const float* mom, const float* wq, const float* wk, int ksize, float* gate, int b, int c,

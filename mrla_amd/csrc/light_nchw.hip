@@ -94,12 +94,24 @@ __device__ __forceinline__ void relu_add_inplace(T* __restrict__ xs, const T* __
     xs[i] = from_f<T>(fmaxf(to_f(from_f<T>(to_f(xs[i]) + to_f(os[i]))), 0.f));
 }
 
+// x = relu(round(sc[p]*pre + sh[p]) + o) on an LDS slab of `np` planes (the bn3 affine handed over by the caller)
+template <typename T>
+__device__ __forceinline__ void relu_affine_add_inplace(T* xs, const T* os, int n, int hw, const float* __restrict__ sc,
+                                                        const float* __restrict__ sh, int tid) {
+  for (int i = tid; i < n; i += kThreads) {
+    const int p = i / hw;
+    const float z = to_f(from_f<T>(fmaf(sc[p], to_f(xs[i]), sh[p])));
+    xs[i] = from_f<T>(fmaxf(to_f(from_f<T>(z + to_f(os[i]))), 0.f));
+  }
+}
+
 // FUSE: `x` is the pre-activation (bn3 output); the kernel forms x_t = relu(pre + o) itself, writes it to `xout`
 // (it is saved for backward and read by the apply pass) and takes the moments of that.
 template <typename T, bool GELU, bool HAS_O, bool FUSE>
 __global__ __launch_bounds__(kThreads) void light_stats_fwd_nchw(
     const T* __restrict__ x, const T* __restrict__ o, const float* __restrict__ wv,
-    float* __restrict__ mom, T* __restrict__ xout, SlabGeo g) {
+    float* __restrict__ mom, T* __restrict__ xout, const float* __restrict__ psc, const float* __restrict__ psh,
+    SlabGeo g) {
   extern __shared__ __align__(16) unsigned char smem[];
   constexpr int NA = HAS_O ? 2 : 1;
   T* buf = reinterpret_cast<T*>(smem);                                     // [2][NA][astride]
@@ -113,7 +125,8 @@ __global__ __launch_bounds__(kThreads) void light_stats_fwd_nchw(
     T* xs = buf + cur * NA * g.astride;
     const T* os = xs + g.astride;
     if (FUSE) {
-      relu_add_inplace(xs, os, n, tid);
+      if (psc) relu_affine_add_inplace(xs, os, n, g.HW, psc + c0, psh + c0, tid);
+      else relu_add_inplace(xs, os, n, tid);
       __syncthreads();
       slab_store(xout + ((size_t)b * g.C + c0) * g.HW, xs, n, tid);
     }
@@ -516,7 +529,8 @@ static hipError_t set_lds(K kernel, size_t bytes) {
   }
 
 int launch_light_stats_fwd_nchw(const void* x, const void* o, const float* wv, float* mom, void* xout,
-                                const SlabGeo& g, int dtype, int act, hipStream_t st) {
+                                const float* psc, const float* psh, const SlabGeo& g, int dtype, int act,
+                                hipStream_t st) {
   const size_t es = dtype_size(dtype);
   const size_t lds = (size_t)g.astride * es * 2 * (o ? 2 : 1) +
                      ((size_t)g.CP * kPT + (size_t)g.NG * g.NB * g.PW * M_N) * sizeof(float);
@@ -526,7 +540,7 @@ int launch_light_stats_fwd_nchw(const void* x, const void* o, const float* wv, f
   {                                                                                                 \
     if (set_lds(light_stats_fwd_nchw<T, A, O, F>, lds) != hipSuccess) return MRLA_EHIP;               \
     hipLaunchKernelGGL((light_stats_fwd_nchw<T, A, O, F>), grid, dim3(kThreads), lds, st,             \
-                       (const T*)x, (const T*)o, wv, mom, (T*)xout, g);                             \
+                       (const T*)x, (const T*)o, wv, mom, (T*)xout, psc, psh, g);                   \
   }
 #define CALL(T, A, O)                                                                               \
   {                                                                                                 \

@@ -193,16 +193,20 @@ constexpr int kScrBufs = 2;
 #define SCR(i) (scr + ((i) >= 3 ? 1 : 0) * (scratch_bytes<T>() / (int)sizeof(T)))
 
 // ------------------------------------------------------------------------------------------------
-// forward statistics (+ optional fused producer x = relu(pre + o))
+// forward statistics (+ optional fused producer x = relu(pre + o), or x = relu((psc*pre + psh) + o) when the
+// per-channel affine of the BatchNorm in front (bn3) is handed over instead of being applied in a pass of its own)
 // ------------------------------------------------------------------------------------------------
 template <typename T, bool GELU, bool HAS_O, bool FUSE, bool WIDE>
 __global__ __launch_bounds__(kMaxStrips * kWave) void light_stats_fwd_nhwc(
     const T* __restrict__ x, const T* __restrict__ o, const float* __restrict__ wv, float* __restrict__ mom,
-    T* __restrict__ xout, int B, int C, int H, int W, int BG) {
+    T* __restrict__ xout, const float* __restrict__ psc, const float* __restrict__ psh, int B, int C, int H, int W,
+    int BG) {
   MRLA_NHWC_PROLOGUE(M_N)
   float w[9];
 #pragma unroll
   for (int k = 0; k < 9; ++k) w[k] = wv[cc * 9 + k];
+  const bool aff = FUSE && psc != nullptr;
+  const float asc = aff ? psc[cc] : 1.f, ash = aff ? psh[cc] : 0.f;
   const int b_end = min(B, (int)(blockIdx.y + 1) * BG);
   for (int b = blockIdx.y * BG; b < b_end; ++b) {
     const size_t ioff = (size_t)b * H * W * C;
@@ -235,6 +239,16 @@ __global__ __launch_bounds__(kMaxStrips * kWave) void light_stats_fwd_nhwc(
           if (HAS_O) read_row<T, false, kS + 2>(oi, r, s0 - 1, H, W, C, cbase, cc, lane, SCR(1), odst);
         }
         if (FUSE) {
+          if (aff) {      // BatchNorm affine of the pre-activation, rounded to T as the stand-alone pass stores it;
+                          // pixels outside the image must stay zero (the padding of the 3x3 taps)
+            const bool rowok = r >= 0 && r < H;
+            const int lim = W - s0;
+#pragma unroll
+            for (int j = 0; j < kS + 2; ++j) {
+              const bool ok = rowok && (j == 0 ? s0 > 0 : j <= lim);
+              dst[j] = ok ? to_f(from_f<T>(fmaf(asc, dst[j], ash))) : 0.f;
+            }
+          }
 #pragma unroll
           for (int j = 0; j < kS + 2; ++j) dst[j] = fmaxf(to_f(from_f<T>(dst[j] + odst[j])), 0.f);   // zeros stay zeros
           if (r >= 0 && r < H) {
@@ -603,14 +617,15 @@ static hipError_t set_lds_n(K kernel, size_t bytes) {
   return hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
 }
 
-int launch_light_stats_fwd_nhwc(const void* x, const void* o, const float* wv, float* mom, void* xout, int B, int C,
-                                int H, int W, int dtype, int act, hipStream_t st) {
+int launch_light_stats_fwd_nhwc(const void* x, const void* o, const float* wv, float* mom, void* xout,
+                                const float* psc, const float* psh, int B, int C, int H, int W, int dtype, int act,
+                                hipStream_t st) {
   const NhwcLaunch L = nhwc_launch(B, C, W, M_N, dtype);
 #define CALL_W(T, A, O, F, WD)                                                                                       \
   {                                                                                                                  \
     if (set_lds_n(light_stats_fwd_nhwc<T, A, O, F, WD>, L.lds) != hipSuccess) return MRLA_EHIP;                        \
     hipLaunchKernelGGL((light_stats_fwd_nhwc<T, A, O, F, WD>), L.grid, L.block, L.lds, st, (const T*)x, (const T*)o,  \
-                       wv, mom, (T*)xout, B, C, H, W, L.BG);                                                         \
+                       wv, mom, (T*)xout, psc, psh, B, C, H, W, L.BG);                                               \
   }
 #define CALL_F(T, A, O, F) { if (L.wide) CALL_W(T, A, O, F, true) else CALL_W(T, A, O, F, false) }
 #define CALL(T, A, O)                                                        \

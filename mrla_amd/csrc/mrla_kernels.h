@@ -32,7 +32,8 @@ inline int hip_status(hipError_t e) { return e == hipSuccess ? MRLA_OK : MRLA_EH
 int make_slab_geo(SlabGeo* g, int B, int C, int H, int W, int dtype, int arrays, int bg_hint);
 
 int launch_light_stats_fwd_nchw(const void* x, const void* o, const float* wv, float* mom, void* xout,
-                                const SlabGeo& g, int dtype, int act, hipStream_t st);
+                                const float* psc, const float* psh, const SlabGeo& g, int dtype, int act,
+                                hipStream_t st);
 int launch_light_apply_fwd_nchw(const void* x, const void* o, const float* wv, const float* gate, const float* sc,
                                 const float* sh, const float* lam, const float* dp, void* out, const SlabGeo& g,
                                 int d, int res, int dtype, int act, hipStream_t st);
@@ -110,8 +111,9 @@ int launch_affine_act(const void* x, const void* dy, const float* a, const float
 
 // light_nhwc.hip / bnact_nhwc.hip -- channels_last variants
 int nhwc_images_per_group(int B, int C);
-int launch_light_stats_fwd_nhwc(const void* x, const void* o, const float* wv, float* mom, void* xout, int B, int C,
-                                int H, int W, int dtype, int act, hipStream_t st);
+int launch_light_stats_fwd_nhwc(const void* x, const void* o, const float* wv, float* mom, void* xout,
+                                const float* psc, const float* psh, int B, int C, int H, int W, int dtype, int act,
+                                hipStream_t st);
 int launch_light_apply_fwd_nhwc(const void* x, const void* o, const float* wv, const float* gate, const float* sc,
                                 const float* sh, const float* lam, const float* dp, void* out, int B, int C, int H,
                                 int W, int d, int res, int dtype, int act, hipStream_t st);

@@ -99,10 +99,11 @@ def _layout_of(x, want=None):
 class LightConfig:
     """Static configuration of one MRLA-light call.  fuse: the first tensor argument is the block's pre-activation
     and x_t = relu(pre + o_prev) is formed inside the statistics kernel (resnet_mrla_light.py:113-114 folded in)."""
-    __slots__ = ("d", "bn_mode", "momentum", "eps", "res", "act", "fuse")
+    __slots__ = ("d", "bn_mode", "momentum", "eps", "res", "act", "fuse", "pre_affine")
 
-    def __init__(self, d, bn_mode=L.BN_NONE, momentum=0.1, eps=1e-5, res=0, act=L.ACT_NONE, fuse=False):
+    def __init__(self, d, bn_mode=L.BN_NONE, momentum=0.1, eps=1e-5, res=0, act=L.ACT_NONE, fuse=False, pre_affine=None):
         self.d, self.bn_mode, self.momentum, self.eps, self.res, self.act = d, bn_mode, momentum, eps, res, act
+        self.pre_affine = pre_affine     # (scale[c], shift[c]) fp32 of a deferred BatchNorm in front of the fused producer
         self.fuse = fuse
 
 
@@ -141,8 +142,9 @@ class _LightFn(torch.autograd.Function):
             if oc is None or cfg.act != L.ACT_NONE:
                 raise L.MrlaHipError("the fused relu(pre + o_prev) producer needs o_prev and no activation on V")
             pre, xc = xc, torch.empty_like(xc)
-            _call("mrla_light_stats_fwd_fused", xc.numel() * xc.element_size() * 3, _ptr(pre), _ptr(oc), _ptr(wv32),
-                  _ptr(mom), _ptr(xc), b, c, h, w, dt, layout, st)
+            psc, psh = cfg.pre_affine if cfg.pre_affine is not None else (None, None)
+            _call("mrla_light_stats_fwd_fused", xc.numel() * xc.element_size() * 3, _ptr(pre), _ptr(psc), _ptr(psh),
+                  _ptr(oc), _ptr(wv32), _ptr(mom), _ptr(xc), b, c, h, w, dt, layout, st)
         else:
             _call("mrla_light_stats_fwd", xc.numel() * xc.element_size() * (2 if oc is not None else 1), _ptr(xc),
                   _ptr(oc), _ptr(wv32), _ptr(mom), b, c, h, w, dt, layout, cfg.act, st)
@@ -226,13 +228,18 @@ def mrla_light(x, wq, wk, wv, d, o_prev=None, lam=None, bn=None, dp=None, res=Fa
 
     bn: None or dict(weight, bias, running_mean, running_var, training, momentum, eps).
     dp: per-sample drop-path multiplier [b] (mask / keep_prob) or None.
-    pre_activation: `x` is the block's pre-activation; x_t = relu(x + o_prev) is formed inside the kernels.
+    pre_activation: `x` is the block's pre-activation; x_t = relu(x + o_prev) is formed inside the kernels.  When `x`
+    came out of `bn_act(..., defer=True)` its BatchNorm affine is applied there too (x then aliases the conv output).
     """
+    pre_affine = getattr(x, "_mrla_affine", None)
+    if pre_affine is not None and not pre_activation:
+        raise L.MrlaHipError("a deferred BatchNorm output can only feed the fused producer (pre_activation=True)")
     if bn is None:
-        cfg = LightConfig(d, L.BN_NONE, res=int(res), act=L.ACT_GELU if act_gelu else L.ACT_NONE, fuse=pre_activation)
+        cfg = LightConfig(d, L.BN_NONE, res=int(res), act=L.ACT_GELU if act_gelu else L.ACT_NONE, fuse=pre_activation,
+                          pre_affine=pre_affine)
         return _LightFn.apply(x, o_prev, wq, wk, wv, lam, None, None, None, None, dp, cfg)
     cfg = LightConfig(d, L.BN_TRAIN if bn["training"] else L.BN_EVAL, bn.get("momentum", 0.1), bn.get("eps", 1e-5),
-                      int(res), L.ACT_GELU if act_gelu else L.ACT_NONE, fuse=pre_activation)
+                      int(res), L.ACT_GELU if act_gelu else L.ACT_NONE, fuse=pre_activation, pre_affine=pre_affine)
     return _LightFn.apply(x, o_prev, wq, wk, wv, lam, bn["weight"], bn["bias"], bn["running_mean"], bn["running_var"],
                           dp, cfg)
 
@@ -491,10 +498,12 @@ def mrla_token_light(x, o_prev, lnx_w, lnx_b, lno_w, lno_b, wq, wk, wv, lam, d, 
 # fused BatchNorm2d (+ReLU)  -- the producer-side epilogue in front of the MRLA tail
 # ======================================================================================================
 class _BnActFn(torch.autograd.Function):
-    """y = relu?(BatchNorm2d(x)): one statistics pass + one elementwise pass per direction."""
+    """y = relu?(BatchNorm2d(x)): one statistics pass + one elementwise pass per direction.
+    defer: skip the forward elementwise pass; the result aliases x and (scale, shift) are returned beside it for the
+    consumer (the fused MRLA producer) to apply.  The backward is the same either way."""
 
     @staticmethod
-    def forward(ctx, x, gamma, beta, running_mean, running_var, training, momentum, eps, relu):
+    def forward(ctx, x, gamma, beta, running_mean, running_var, training, momentum, eps, relu, defer=False):
         _require_cuda(x, "fused bn/act forward")
         layout, xc = _layout_of(x)
         b, c, h, w = xc.shape
@@ -510,15 +519,20 @@ class _BnActFn(torch.autograd.Function):
         L.call("mrla_bn_stats_fwd", _ptr(amom), _ptr(gamma32), _ptr(beta32), _ptr(running_mean), _ptr(running_var),
                L.BN_TRAIN if training else L.BN_EVAL, float(momentum), float(eps), _ptr(bnbuf[0]), _ptr(bnbuf[1]),
                _ptr(bnbuf[2]), _ptr(bnbuf[3]), rows, c, b * h * w // rows, st)
+        ctx.training, ctx.relu, ctx.gdtype, ctx.layout, ctx.rows = training, int(relu), gamma.dtype, layout, rows
+        ctx.save_for_backward(xc, gamma32, bnbuf)
+        if defer:
+            if relu:
+                raise L.MrlaHipError("a deferred BatchNorm cannot carry a ReLU")
+            ctx.mark_non_differentiable(bnbuf)
+            return xc.detach(), bnbuf
         y = torch.empty_like(xc)
         _call("mrla_bn_act_fwd", xc.numel() * xc.element_size() * 2, _ptr(xc), _ptr(bnbuf[0]), _ptr(bnbuf[1]), int(relu),
               _ptr(y), b, c, h, w, dt, layout, st)
-        ctx.training, ctx.relu, ctx.gdtype, ctx.layout, ctx.rows = training, int(relu), gamma.dtype, layout, rows
-        ctx.save_for_backward(xc, gamma32, bnbuf)
         return y
 
     @staticmethod
-    def backward(ctx, dy):
+    def backward(ctx, dy, _dbuf=None):
         xc, gamma32, bnbuf = ctx.saved_tensors
         b, c, h, w = xc.shape
         dt, dev, st = _DT[xc.dtype], xc.device, _stream()
@@ -538,12 +552,14 @@ class _BnActFn(torch.autograd.Function):
         dx = torch.empty_like(xc)
         _call("mrla_bn_act_bwd", xc.numel() * es * 3, _ptr(dy), _ptr(xc), _ptr(bnbuf[0]), _ptr(bnbuf[1]), _ptr(cb), ctx.relu,
               _ptr(dx), b, c, h, w, dt, layout, st)
-        return dx, small[3].to(ctx.gdtype), small[4].to(ctx.gdtype), None, None, None, None, None, None
+        return dx, small[3].to(ctx.gdtype), small[4].to(ctx.gdtype), None, None, None, None, None, None, None
 
 
-def bn_act(x, bn, relu):
+def bn_act(x, bn, relu, defer=False):
     """relu?(bn(x)) for an nn.BatchNorm2d module `bn` on the fused HIP passes; any other norm layer (or a layout /
-    device the kernels do not handle) runs as the caller's module followed by torch.relu."""
+    device the kernels do not handle) runs as the caller's module followed by torch.relu.
+    defer=True (relu must be False): only the statistics are taken; the returned tensor aliases x and carries the
+    per-channel affine as `._mrla_affine` for `mrla_light(..., pre_activation=True)` to apply in its first pass."""
     if (type(bn) is torch.nn.BatchNorm2d and bn.affine and bn.track_running_stats and x.is_cuda and x.dim() == 4
             and x.dtype in _DT and (x.is_contiguous() or x.is_contiguous(memory_format=_CL))):
         training = bn.training
@@ -552,6 +568,11 @@ def bn_act(x, bn, relu):
             bn.num_batches_tracked.add_(1)
             if momentum is None:
                 momentum = 1.0 / float(bn.num_batches_tracked)
+        if defer:
+            y, buf = _BnActFn.apply(x, bn.weight, bn.bias, bn.running_mean, bn.running_var, training, momentum or 0.0,
+                                    bn.eps, False, True)
+            y._mrla_affine = (buf[0], buf[1])
+            return y
         return _BnActFn.apply(x, bn.weight, bn.bias, bn.running_mean, bn.running_var, training, momentum or 0.0, bn.eps,
                               relu)
     y = bn(x)

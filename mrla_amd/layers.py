@@ -116,12 +116,17 @@ def _bn_args(bn):
                 momentum=momentum, eps=bn.eps)
 
 
+def light_tail_is_fused(bn_mrla):
+    """True when light_block_tail runs as the two fused HIP passes (then bn3's affine may be deferred into them)."""
+    return type(bn_mrla) is nn.BatchNorm2d and bn_mrla.affine
+
+
 def light_block_tail(x, identity, mrla, bn_mrla, drop_path, pre_activation=False):
     """x + DropPath(bn_mrla(mrla(x, identity))) -- fused into two HIP passes when bn_mrla is a BatchNorm2d.
     pre_activation=True: `x` is the bottleneck's bn3 output and x_t = relu(x + identity)
     (resnet_mrla_light.py:113-114) is formed inside the first pass as well."""
     p = getattr(drop_path, "drop_prob", 0.0) or 0.0
-    if type(bn_mrla) is nn.BatchNorm2d and bn_mrla.affine:
+    if light_tail_is_fused(bn_mrla):
         m = mrla.mrla
         m._check(x)
         dp = drop_path_scale(x.shape[0], p, drop_path.training if isinstance(drop_path, nn.Module) else False, x.device)

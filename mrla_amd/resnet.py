@@ -45,12 +45,13 @@ class _BottleneckTrunk(nn.Module):
         self.eca = None
         self._norm = norm_layer
 
-    def trunk_pre(self, x):
-        """Everything up to, but not including, the shortcut add + ReLU: (bn3 output, identity)."""
+    def trunk_pre(self, x, defer_bn3=False):
+        """Everything up to, but not including, the shortcut add + ReLU: (bn3 output, identity).
+        defer_bn3: only bn3's statistics are taken here; its affine is applied by the consumer's first pass."""
         identity = x
         out = F_.bn_act(self.conv1(x), self.bn1, relu=True)          # fused BatchNorm+ReLU HIP passes
         out = F_.bn_act(self.conv2(out), self.bn2, relu=True)
-        out = F_.bn_act(self.conv3(out), self.bn3, relu=False)
+        out = F_.bn_act(self.conv3(out), self.bn3, relu=False, defer=defer_bn3)
         if self.downsample is not None:
             ds = self.downsample
             if isinstance(ds, nn.Sequential) and len(ds) == 2 and isinstance(ds[0], nn.Conv2d):
@@ -76,7 +77,8 @@ class MRLA_Bottleneck(_BottleneckTrunk):
         self.drop_path = layers.DropPath(drop_path) if drop_path > 0.0 else nn.Identity()
 
     def forward(self, x):
-        pre, identity = self.trunk_pre(x)           # the shortcut add + ReLU run inside the first MRLA pass
+        # bn3's affine, the shortcut add and the ReLU all run inside the first MRLA pass
+        pre, identity = self.trunk_pre(x, defer_bn3=layers.light_tail_is_fused(self.bn_mrla))
         return layers.light_block_tail(pre, identity, self.mrla, self.bn_mrla, self.drop_path, pre_activation=True)
 
 

@@ -62,3 +62,58 @@ def test_bn_act_bf16():
     gg = xa.grad.float().cpu().numpy()
     bad = np.abs(gg - gw) > 2.0 ** -7 * (np.abs(gw) + 0.05 * np.abs(gw).max())
     assert bad.mean() < 1e-4        # a y that rounds across zero flips its ReLU mask
+
+
+DEFER_SHAPES = [(2, 64, 9, 6), (3, 72, 7, 7), (2, 128, 5, 61), (1, 256, 12, 75), (4, 256, 56, 56)]
+
+
+@pytest.mark.parametrize("shape", DEFER_SHAPES, ids=lambda s: "x".join(map(str, s)))
+@pytest.mark.parametrize("training", [True, False], ids=["train", "eval"])
+@pytest.mark.parametrize("cl", [False, True], ids=["nchw", "nhwc"])
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16], ids=["fp32", "bf16"])
+def test_deferred_bn3_affine_is_bit_identical_to_the_separate_pass(shape, training, cl, dtype):
+    """bn3's elementwise pass folded into the first MRLA pass (resnet_mrla_light.py:101-102,113-116): outputs and every
+    gradient must equal, bit for bit, what the stand-alone BatchNorm pass followed by the same fused tail produces."""
+    from mrla_amd.functional import bn_act, mrla_light
+    b, c, h, w = shape
+    if not cl and w > 64:
+        pytest.skip("NCHW kernels: rows wider than one wave are served by the channels_last path")
+    torch.manual_seed(5)
+    mk = lambda *s: torch.randn(*s, device="cuda")
+    conv_out, idn, g = mk(b, c, h, w).to(dtype), mk(b, c, h, w).to(dtype), mk(b, c, h, w).to(dtype)
+    if cl:
+        conv_out, idn, g = (t.contiguous(memory_format=torch.channels_last) for t in (conv_out, idn, g))
+    k = 3 if c == 64 else 5
+    wq, wk, wv, lam = mk(1, 1, k) * 0.5, mk(1, 1, k) * 0.5, mk(c, 1, 3, 3) * 0.3, mk(c, 1, 1)
+    results = []
+    for defer in (False, True):
+        bn3, bnm = torch.nn.BatchNorm2d(c).cuda(), torch.nn.BatchNorm2d(c).cuda()
+        with torch.no_grad():
+            for bn in (bn3, bnm):
+                bn.weight.copy_(torch.linspace(0.5, 1.5, c)); bn.bias.copy_(torch.linspace(-0.3, 0.3, c))
+                bn.running_mean.copy_(torch.linspace(-0.2, 0.2, c)); bn.running_var.copy_(torch.linspace(0.8, 1.2, c))
+        bn3.train(training); bnm.train(training)
+        xin, oin = conv_out.clone().requires_grad_(True), idn.clone().requires_grad_(True)
+        prm = [p.clone().requires_grad_(True) for p in (wq, wk, wv, lam)]
+        pre = bn_act(xin, bn3, relu=False, defer=defer)
+        assert (getattr(pre, "_mrla_affine", None) is not None) == defer
+        out = mrla_light(pre, prm[0], prm[1], prm[2], 8 if c % 32 else 32, o_prev=oin, lam=prm[3],
+                         bn=dict(weight=bnm.weight, bias=bnm.bias, running_mean=bnm.running_mean,
+                                 running_var=bnm.running_var, training=training, momentum=0.1, eps=1e-5),
+                         res=True, pre_activation=True)
+        out.backward(g)
+        torch.cuda.synchronize()
+        results.append([out.detach(), xin.grad, oin.grad, bn3.weight.grad, bn3.bias.grad, bn3.running_var.clone(),
+                        bnm.weight.grad, bnm.running_mean.clone()] + [p.grad for p in prm])
+    for i, (a, bb) in enumerate(zip(*results)):
+        assert torch.equal(a, bb), i
+
+
+def test_deferred_bn_output_is_refused_outside_the_fused_producer():
+    from mrla_amd.functional import bn_act, mrla_light
+    from mrla_amd._lib import MrlaHipError
+    bn = torch.nn.BatchNorm2d(64).cuda()
+    x = torch.randn(2, 64, 8, 8, device="cuda")
+    pre = bn_act(x, bn, relu=False, defer=True)
+    with pytest.raises(MrlaHipError):
+        mrla_light(pre, torch.randn(1, 1, 3).cuda(), torch.randn(1, 1, 3).cuda(), torch.randn(64, 1, 3, 3).cuda(), 32)

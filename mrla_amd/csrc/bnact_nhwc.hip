@@ -132,16 +132,158 @@ __global__ __launch_bounds__(kThreads) void nhwc_affine_kernel(const T* __restri
 }
 
 // ------------------------------------------------------------------------------------------------
+// "flat" forms for C % 64 == 0 (every BatchNorm of the networks here): a workgroup iteration covers 256 consecutive
+// 16-byte vectors = PPI whole pixels x CW channels (CW = largest power of two <= 256*VEC dividing C), so the
+// accesses of a workgroup are contiguous 4 KiB pieces when CW == C, a thread keeps the same channels from iteration to
+// iteration, and UNR independent loads per lane are in flight.
+// ------------------------------------------------------------------------------------------------
+constexpr int kUnr = 4;
+
+template <int N>
+__device__ __forceinline__ void ldf(const float* __restrict__ p, float (&v)[N]) {
+  static_assert(N % 4 == 0, "vector loads of 4 floats");
+#pragma unroll
+  for (int i = 0; i < N; i += 4) {
+    const float4 t = *reinterpret_cast<const float4*>(p + i);
+    v[i] = t.x; v[i + 1] = t.y; v[i + 2] = t.z; v[i + 3] = t.w;
+  }
+}
+
+// grid: (C / CW, b * nsplit).  out[b*nsplit, c, 2]
+template <typename T, int MODE>
+__global__ __launch_bounds__(kThreads) void nhwc_moments_flat_kernel(const T* __restrict__ x, const T* __restrict__ dy,
+                                                                     const float* __restrict__ sc,
+                                                                     const float* __restrict__ sh, int relu,
+                                                                     float* __restrict__ out, int C, int HW, int nsplit,
+                                                                     int CW) {
+  constexpr int VEC = 16 / sizeof(T);
+  __shared__ float red[2][kThreads * VEC];
+  const int t = threadIdx.x;
+  const int lpc = CW / VEC;                      // lanes per pixel piece (power of two, <= 256)
+  const int ppi = kThreads / lpc;                // pixels per workgroup iteration
+  const int cl = (t & (lpc - 1)) * VEC, ps = t / lpc;
+  const int c0 = blockIdx.x * CW + cl;
+  const int bs = blockIdx.y, b = bs / nsplit, sp = bs - b * nsplit;
+  const int npix = HW / nsplit;
+  const T* xp = x + ((size_t)b * HW + (size_t)sp * npix) * C + c0;
+  const T* gp = MODE ? dy + ((size_t)b * HW + (size_t)sp * npix) * C + c0 : nullptr;
+  float scv[VEC], shv[VEC];
+  if (MODE && relu) { ldf<VEC>(sc + c0, scv); ldf<VEC>(sh + c0, shv); }
+  else {
+#pragma unroll
+    for (int i = 0; i < VEC; ++i) { scv[i] = 0.f; shv[i] = 0.f; }
+  }
+  float s1[VEC], s2[VEC];
+#pragma unroll
+  for (int i = 0; i < VEC; ++i) { s1[i] = 0.f; s2[i] = 0.f; }
+  auto accumulate = [&](const float (&xv)[VEC], const float (&gv)[VEC]) {
+#pragma unroll
+    for (int i = 0; i < VEC; ++i) {
+      if (MODE == 0) { s1[i] += xv[i]; s2[i] = fmaf(xv[i], xv[i], s2[i]); }
+      else {
+        const float dz = (!relu || fmaf(scv[i], xv[i], shv[i]) > 0.f) ? gv[i] : 0.f;
+        s1[i] += dz;
+        s2[i] = fmaf(dz, xv[i], s2[i]);
+      }
+    }
+  };
+  constexpr int UN = MODE ? kUnr : 2 * kUnr;       // independent 16-byte loads in flight per lane: 8 either way
+  int p = ps;
+  for (; p + (UN - 1) * ppi < npix; p += UN * ppi) {
+    float xv[UN][VEC], gv[UN][VEC];
+#pragma unroll
+    for (int u = 0; u < UN; ++u) {
+      ld16<T>(xp + (size_t)(p + u * ppi) * C, xv[u]);
+      if (MODE) ld16<T>(gp + (size_t)(p + u * ppi) * C, gv[u]);
+    }
+#pragma unroll
+    for (int u = 0; u < UN; ++u) accumulate(xv[u], gv[u]);
+  }
+  for (; p < npix; p += ppi) {
+    float xv[VEC], gv[VEC];
+    ld16<T>(xp + (size_t)p * C, xv);
+    if (MODE) ld16<T>(gp + (size_t)p * C, gv);
+    accumulate(xv, gv);
+  }
+  // thread t holds channels cl.. of pixel sub-index ps: element t*VEC + i of the [ppi][CW] tile
+#pragma unroll
+  for (int i = 0; i < VEC; ++i) { red[0][t * VEC + i] = s1[i]; red[1][t * VEC + i] = s2[i]; }
+  __syncthreads();
+  for (int j = t; j < 2 * CW; j += kThreads) {
+    const int k = j / CW, ch = j - k * CW;
+    float sum = 0.f;
+    for (int r = 0; r < ppi; ++r) sum += red[k][r * CW + ch];
+    out[((size_t)bs * C + blockIdx.x * CW + ch) * 2 + k] = sum;
+  }
+}
+
+// Elementwise over the flat tensor; requires (kThreads * VEC) % C == 0 (then a thread's channels never change).
+template <typename T, bool BWD>
+__global__ __launch_bounds__(kThreads) void nhwc_affine_flat_kernel(const T* __restrict__ x, const T* __restrict__ dy,
+                                                                    const float* __restrict__ a,
+                                                                    const float* __restrict__ sc,
+                                                                    const float* __restrict__ sh, int relu,
+                                                                    T* __restrict__ out, size_t total, int C, int iters) {
+  constexpr int VEC = 16 / sizeof(T);
+  constexpr size_t STEP = (size_t)kThreads * VEC;
+  const int c0 = (int)((threadIdx.x * VEC) & (unsigned)(C - 1));       // C is a power of two here
+  float scv[VEC], shv[VEC], cbv[BWD ? 3 * VEC : 4];
+  ldf<VEC>(sc + c0, scv);
+  ldf<VEC>(sh + c0, shv);
+  if constexpr (BWD) ldf<3 * VEC>(a + (size_t)c0 * 3, cbv);
+  size_t e = (size_t)blockIdx.x * iters * STEP + (size_t)threadIdx.x * VEC;
+  auto one = [&](const float (&xv)[VEC], const float (&gv)[VEC], size_t at) {
+    float y[VEC];
+#pragma unroll
+    for (int i = 0; i < VEC; ++i) {
+      const float z = fmaf(scv[i], xv[i], shv[i]);
+      if (!BWD) y[i] = relu ? fmaxf(z, 0.f) : z;
+      else {
+        const float dz = (!relu || z > 0.f) ? gv[i] : 0.f;
+        y[i] = fmaf(cbv[3 * i], dz, fmaf(cbv[3 * i + 1], xv[i], cbv[3 * i + 2]));
+      }
+    }
+    st16<T>(out + at, y);
+  };
+  int it = 0;
+  for (; it + kUnr <= iters && e + (kUnr - 1) * STEP < total; it += kUnr, e += kUnr * STEP) {
+    float xv[kUnr][VEC], gv[kUnr][VEC];
+#pragma unroll
+    for (int u = 0; u < kUnr; ++u) {
+      ld16<T>(x + e + u * STEP, xv[u]);
+      if (BWD) ld16<T>(dy + e + u * STEP, gv[u]);
+    }
+#pragma unroll
+    for (int u = 0; u < kUnr; ++u) one(xv[u], gv[u], e + u * STEP);
+  }
+  for (; it < iters && e < total; ++it, e += STEP) {
+    float xv[VEC], gv[VEC];
+    ld16<T>(x + e, xv);
+    if (BWD) ld16<T>(dy + e, gv);
+    one(xv, gv, e);
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// partial-moment rows per image: independent of the storage type (the caller sizes its buffers from it)
 int nhwc_bn_splits(int B, int C, int HW) {
-  const long chunks = (C + 63) / 64;
+  (void)C;
   static const int cand[] = {1, 2, 4, 7, 8, 14, 16, 28, 32, 49, 56, 64};
   int best = 1;
   for (int s : cand) {
-    if (HW % s) continue;
+    if (HW % s || (s > 1 && HW / s < 16)) continue;     // keep >= 16 pixels per workgroup: the partial sums are traffic too
     best = s;
-    if ((long)B * chunks * s >= 2048) break;
+    if ((long)B * s >= 1024) break;
   }
   return best;
+}
+
+// widest power-of-two channel piece a workgroup iteration can cover, or 0 when the flat kernels do not apply
+static int flat_cw(int C, int vec) {
+  if (C % 64) return 0;
+  int cw = 64;
+  while (cw * 2 <= kThreads * vec && C % (cw * 2) == 0) cw *= 2;
+  return cw;
 }
 
 #define MRLA_DISPATCH_N(DT, CALL)        \
@@ -157,6 +299,18 @@ int launch_nhwc_moments(const void* x, const void* dy, const float* sc, const fl
   const int vec = 16 / (int)dtype_size(dtype);
   if (C % vec) return MRLA_EUNSUPPORTED;
   const int ns = nhwc_bn_splits(B, C, HW);
+  const int cw = flat_cw(C, vec);
+  if (cw) {
+    const dim3 fgrid(C / cw, B * ns);
+#define CALL(TT)                                                                                                       \
+  if (mode) hipLaunchKernelGGL((nhwc_moments_flat_kernel<TT, 1>), fgrid, dim3(kThreads), 0, st, (const TT*)x,          \
+                               (const TT*)dy, sc, sh, relu, out, C, HW, ns, cw);                                       \
+  else      hipLaunchKernelGGL((nhwc_moments_flat_kernel<TT, 0>), fgrid, dim3(kThreads), 0, st, (const TT*)x,          \
+                               (const TT*)dy, sc, sh, relu, out, C, HW, ns, cw);
+    MRLA_DISPATCH_N(dtype, CALL)
+#undef CALL
+    return hip_status(hipGetLastError());
+  }
   const dim3 grid((C + 63) / 64, B * ns);
 #define CALL(TT)                                                                                                     \
   if (mode) hipLaunchKernelGGL((nhwc_moments_kernel<TT, 1>), grid, dim3(kThreads), 0, st, (const TT*)x, (const TT*)dy, \
@@ -174,6 +328,18 @@ int launch_nhwc_affine(const void* x, const void* dy, const float* a, const floa
   const int vec = 16 / (int)dtype_size(dtype);
   if (C % vec) return MRLA_EUNSUPPORTED;
   const size_t want = (total / vec + kThreads - 1) / kThreads;
+  if ((C & (C - 1)) == 0 && C >= vec && C <= kThreads * vec) {        // power-of-two channel count: flat form
+    const int iters = (int)std::max<size_t>(1, std::min<size_t>((want + 4095) / 4096, 64));
+    const int fgrid = (int)((want + iters - 1) / iters);
+#define CALL(TT)                                                                                                       \
+  if (bwd) hipLaunchKernelGGL((nhwc_affine_flat_kernel<TT, true>), dim3(fgrid), dim3(kThreads), 0, st, (const TT*)x,   \
+                              (const TT*)dy, a, sc, sh, relu, (TT*)out, total, C, iters);                              \
+  else     hipLaunchKernelGGL((nhwc_affine_flat_kernel<TT, false>), dim3(fgrid), dim3(kThreads), 0, st, (const TT*)x,  \
+                              (const TT*)dy, a, sc, sh, relu, (TT*)out, total, C, iters);
+    MRLA_DISPATCH_N(dtype, CALL)
+#undef CALL
+    return hip_status(hipGetLastError());
+  }
   const int grid = (int)std::max<size_t>(1, std::min<size_t>(want, 256 * 16));
 #define CALL(TT)                                                                                                   \
   if (bwd) hipLaunchKernelGGL((nhwc_affine_kernel<TT, true>), dim3(grid), dim3(kThreads), 0, st, (const TT*)x,     \

@@ -72,7 +72,7 @@ for c, hw in STAGES:
                                                         B, c, hw * hw, d, st)),
         "apply_bwd": (5, lambda: lib.mrla_light_apply_bwd(P(g), P(x), P(o), P(wv), P(gate), P(cb), P(lam), P(dp), P(dyx), P(dx),
                                                           P(do), P(dwv), B, c, hw, hw, d, 1, RELU, L.BF16, LAY, 0, st)),
-        "stats_fused": (3, lambda: lib.mrla_light_stats_fwd_fused(P(g), P(o), P(wv), P(mom), P(out), B, c, hw, hw, L.BF16, LAY, st)),
+        "stats_fused": (3, lambda: lib.mrla_light_stats_fwd_fused(P(g), P(bn[0]), P(bn[1]), P(o), P(wv), P(mom), P(out), B, c, hw, hw, L.BF16, LAY, st)),
     }
     for name, (passes, fn) in K.items():
         if only and only not in name:

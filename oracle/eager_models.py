@@ -297,6 +297,43 @@ class EagerResNetBase(_EagerResNet):
         return x
 
 
+class EagerDetBackbone(EagerResNetLight):
+    """mmdetection/mmdet/models/backbones/resnet_mrlal.py:116-367: the light network without head, four feature maps
+    out, no stochastic depth on the MRLA term (:112), frozen stages / norm_eval handled by train() (:333-367)."""
+
+    def __init__(self, layers=(3, 4, 6, 3), frozen_stages=-1, norm_eval=True, zero_init_last_bn=True, **kw):
+        kw.pop("drop_path", None)
+        super().__init__(list(layers), num_classes=1, zero_init_last_bn=zero_init_last_bn, drop_path=0.0, **kw)
+        del self.avgpool, self.fc
+        self.frozen_stages, self.norm_eval = frozen_stages, norm_eval
+
+    def forward(self, x):
+        x = self.maxpool(F.relu(self.bn1(self.conv1(x))))
+        outs = []
+        for stage in (self.layer1, self.layer2, self.layer3, self.layer4):
+            x = stage(x)
+            outs.append(x)
+        return tuple(outs)
+
+    def train(self, mode=True):
+        super().train(mode)
+        if self.frozen_stages >= 0:
+            self.bn1.eval()
+            for m in (self.conv1, self.bn1):
+                for p_ in m.parameters():
+                    p_.requires_grad = False
+        for i in range(1, self.frozen_stages + 1):
+            m = getattr(self, f"layer{i}")
+            m.eval()
+            for p_ in m.parameters():
+                p_.requires_grad = False
+        if mode and self.norm_eval:
+            for m in self.modules():
+                if isinstance(m, nn.modules.batchnorm._BatchNorm):
+                    m.eval()
+        return self
+
+
 def eager_resnet50_mrlal(**kw):
     return EagerResNetLight([3, 4, 6, 3], **kw)
 

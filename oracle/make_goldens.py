@@ -237,6 +237,84 @@ def gen_tokens(deit_light):
     print("token_modules.npz", sum(v.nbytes for v in out.values()) // 1024, "KiB")
 
 
+def import_mmdet_backbone():
+    """mmdetection/mmdet/models/backbones/resnet_mrlal.py with mmcv / mmdet stubbed: BaseModule -> nn.Module carrying
+    init_cfg, BACKBONES.register_module() -> identity.  No arithmetic lives in the stubs."""
+    import importlib
+    import types
+    root = os.path.join(REF, "mmdetection", "mmdet")
+
+    class BaseModule(torch.nn.Module):
+        def __init__(self, init_cfg=None):
+            super().__init__()
+            self.init_cfg = init_cfg
+
+    class _Registry:
+        def register_module(self, *a, **k):
+            return lambda cls: cls
+
+    def mod(name, **attrs):
+        m = types.ModuleType(name)
+        m.__dict__.update(attrs)
+        sys.modules[name] = m
+        return m
+
+    nothing = lambda *a, **k: None
+    mod("mmcv")
+    mod("mmcv.cnn", build_conv_layer=nothing, build_norm_layer=nothing, build_plugin_layer=nothing,
+        constant_init=nothing, kaiming_init=nothing)
+    mod("mmcv.runner", load_checkpoint=nothing, BaseModule=BaseModule)
+    for name, path in (("mmdet", root), ("mmdet.models", os.path.join(root, "models")),
+                       ("mmdet.models.backbones", os.path.join(root, "models", "backbones"))):
+        mod(name).__path__ = [path]
+    mod("mmdet.utils", get_root_logger=nothing)
+    mod("mmdet.models.builder", BACKBONES=_Registry())
+    return importlib.import_module("mmdet.models.backbones.resnet_mrlal")
+
+
+DET_SHAPE = (2, 3, 96, 160)
+
+
+def det_inputs():
+    x = detgen.normalish(DET_SHAPE, detgen.seed_of("det/img")).astype(np.float32)
+    gs = [detgen.normalish((2, c, 96 // s, 160 // s), detgen.seed_of(f"det/g{c}")).astype(np.float32)
+          for c, s in ((256, 4), (512, 8), (1024, 16), (2048, 32))]
+    return x, gs
+
+
+def gen_det():
+    """Detection backbone: the four maps in eval mode, and one norm_eval / frozen_stages=1 training step."""
+    R = import_mmdet_backbone()
+    out = {}
+    net = R.ResNet_mrlal(frozen_stages=1, norm_eval=True)
+    load_det(net)
+    x_np, gs = det_inputs()
+    net.eval()
+    with torch.no_grad():
+        maps = net(T(x_np))
+    for i, m in enumerate(maps):
+        out[f"eval/map{i}"] = N(m)[:, ::8]                       # every 8th channel
+        out[f"eval/map{i}_sum"] = np.array([float(m.double().sum()), float(m.double().abs().sum())])
+    net.train()
+    maps = net(T(x_np))
+    loss = sum((m * T(g)).mean() for m, g in zip(maps, gs))
+    loss.backward()
+    out["train/loss"] = np.array([float(loss)])
+    for i, m in enumerate(maps):
+        out[f"train/map{i}_sum"] = np.array([float(m.double().sum()), float(m.double().abs().sum())])
+    frozen = []
+    for k, p in net.named_parameters():
+        if p.grad is None:
+            frozen.append(k)
+        else:
+            g = p.grad.double()
+            out["train/gsum/" + k] = np.array([float(g.sum()), float(g.abs().sum())])
+    out["train/frozen"] = np.array(sorted(frozen))
+    out["state_keys"] = np.array(sorted(net.state_dict().keys()))
+    np.savez_compressed(os.path.join(OUT, "det_backbone.npz"), **out)
+    print("det_backbone.npz", sum(v.nbytes for v in out.values()) // 1024, "KiB", len(frozen), "frozen tensors")
+
+
 def gen_token_base(deit_base):
     """deit_mrla_base.py mrlab_module chain of 5 (history reset at index 4), x_t + module(x_t) as in Block.forward."""
     out = {}
@@ -355,9 +433,11 @@ def main():
     torch.manual_seed(0)
     ref = import_reference_resnet()
     deit_light, deit_base = import_reference_deit()
-    which = sys.argv[1:] or ["light", "base", "tokens", "models", "layout", "tokbase"]
+    which = sys.argv[1:] or ["light", "base", "tokens", "models", "layout", "tokbase", "det"]
     if "tokbase" in which:
         gen_token_base(deit_base)
+    if "det" in which:
+        gen_det()
     if "layout" in which:
         gen_state_dict_layout(ref, deit_light, deit_base)
     if "light" in which:

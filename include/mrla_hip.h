@@ -182,6 +182,37 @@ int mrla_base_value_bwd(const void* dout, const void* x, const float* wv, const 
                         const float* dyx, void* dx, float* dwv_part, int b, int c, int h, int w, int d, int T, int t,
                         int Tc, int res, int dtype, int layout, void* stream);
 
+/* ---- channels_last (MRLA_NHWC) MRLA-base --------------------------------------------------------------------
+ * The rings are SLOT-MAJOR for this layout: v_ring / da_ring [T, b, h, w, c] (a slot is an ordinary NHWC tensor).
+ * Call sequence per layer (same reference lines as above):
+ *   forward : mrla_base_pool_value_fwd -> mrla_base_gate_fwd -> mrla_base_attend_fwd (x, wv ignored; amom has
+ *             mrla_base_tile_rows() rows) -> mrla_bn_stats_fwd(rows, hw*b/rows) -> mrla_base_tail_fwd
+ *   backward: mrla_base_tail_stats_bwd (tmom: mrla_bn_moment_rows() rows) -> mrla_bn_stats_bwd -> mrla_base_attend_bwd
+ *             (pmom argument = partial buffer [mrla_base_pmom_rows(), t, c]) -> mrla_base_pmom_reduce ->
+ *             mrla_base_gate_bwd -> mrla_base_dv_combine -> mrla_base_value_bwd_dv
+ * Supported when c % 64 == 0 and 256 % (c / (16 / sizeof(dtype))) == 0 (c a power of two up to 2048 for 16-bit types);
+ * mrla_base_tile_rows returns MRLA_EUNSUPPORTED otherwise and the caller keeps the stage in MRLA_NCHW. */
+int mrla_base_tile_rows(int b, int c, int h, int w, int dtype, int layout);
+int mrla_base_pmom_rows(int b, int c, int h, int w, int dtype, int layout);
+
+/* mom[b,c,6] <- pooling moments of x_t (slot 0 = sum x_t);  v_slot <- V_t = dwconv3x3(x_t) (ring slot t-1).
+ * identity [opt]: x is the pre-activation, x_t = relu(x + identity) is formed here and also written to x_out.
+ * Replaces avg_pool + Wv of mrla_base_module.py:57-58,63 and resnet_mrla_base.py:120-121. */
+int mrla_base_pool_value_fwd(const void* x, const void* identity, const float* wv, float* mom, void* x_out,
+                             void* v_slot, int b, int c, int h, int w, int dtype, int layout, void* stream);
+
+/* pmom[b, c, t] <- sum over the rows/b tiles of an image of part[rows, t, c]. */
+int mrla_base_pmom_reduce(const float* part, float* pmom, int b, int c, int t, int rows, void* stream);
+
+/* dv[b,h,w,c] (float32) <- dV_t = sum_{t'=t..Tc} p_all[b,g,t'-1,t-1] * dA_t'. */
+int mrla_base_dv_combine(const void* da_ring, const float* p_all, float* dv, int b, int c, int h, int w, int d, int T,
+                         int t, int Tc, int dtype, int layout, void* stream);
+
+/* dx = [x > 0 if res bit 1] * ((res bit 0) * dOut + dwconv3x3^T(dv) + dyx);  dwv_part[rows, c, 9]
+ * (rows = mrla_light_wgrad_rows()). */
+int mrla_base_value_bwd_dv(const void* dout, const void* x, const float* wv, const float* dv, const float* dyx, void* dx,
+                           float* dwv_part, int b, int c, int h, int w, int res, int dtype, int layout, void* stream);
+
 /* =====================================================================================================
  * MRLA-light on token sequences (DeiT): x[b, n, c], n = 1 + side*side, channels contiguous.
  * Reference: deit/deit_mrla_light.py:157-180 (mrlal_layer, GELU on V), :194-209 (mrlal_module: two LayerNorms,

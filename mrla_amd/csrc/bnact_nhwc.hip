@@ -154,6 +154,7 @@ template <typename T, int MODE>
 __global__ __launch_bounds__(kThreads) void nhwc_moments_flat_kernel(const T* __restrict__ x, const T* __restrict__ dy,
                                                                      const float* __restrict__ sc,
                                                                      const float* __restrict__ sh, int relu,
+                                                                     const float* __restrict__ dp /*[b] or null*/,
                                                                      float* __restrict__ out, int C, int HW, int nsplit,
                                                                      int CW) {
   constexpr int VEC = 16 / sizeof(T);
@@ -165,6 +166,7 @@ __global__ __launch_bounds__(kThreads) void nhwc_moments_flat_kernel(const T* __
   const int c0 = blockIdx.x * CW + cl;
   const int bs = blockIdx.y, b = bs / nsplit, sp = bs - b * nsplit;
   const int npix = HW / nsplit;
+  const float dpb = (MODE && dp) ? dp[b] : 1.f;        // MRLA-base tail: dz = dp[b] * dOut * [sc*attn + sh > 0]
   const T* xp = x + ((size_t)b * HW + (size_t)sp * npix) * C + c0;
   const T* gp = MODE ? dy + ((size_t)b * HW + (size_t)sp * npix) * C + c0 : nullptr;
   float scv[VEC], shv[VEC];
@@ -181,7 +183,7 @@ __global__ __launch_bounds__(kThreads) void nhwc_moments_flat_kernel(const T* __
     for (int i = 0; i < VEC; ++i) {
       if (MODE == 0) { s1[i] += xv[i]; s2[i] = fmaf(xv[i], xv[i], s2[i]); }
       else {
-        const float dz = (!relu || fmaf(scv[i], xv[i], shv[i]) > 0.f) ? gv[i] : 0.f;
+        const float dz = (!relu || fmaf(scv[i], xv[i], shv[i]) > 0.f) ? dpb * gv[i] : 0.f;
         s1[i] += dz;
         s2[i] = fmaf(dz, xv[i], s2[i]);
       }
@@ -294,8 +296,8 @@ static int flat_cw(int C, int vec) {
     default: return MRLA_EINVAL;         \
   }
 
-int launch_nhwc_moments(const void* x, const void* dy, const float* sc, const float* sh, int relu, float* out, int B,
-                        int C, int HW, int dtype, int mode, hipStream_t st) {
+int launch_nhwc_moments(const void* x, const void* dy, const float* sc, const float* sh, int relu, const float* dp,
+                        float* out, int B, int C, int HW, int dtype, int mode, hipStream_t st) {
   const int vec = 16 / (int)dtype_size(dtype);
   if (C % vec) return MRLA_EUNSUPPORTED;
   const int ns = nhwc_bn_splits(B, C, HW);
@@ -304,13 +306,14 @@ int launch_nhwc_moments(const void* x, const void* dy, const float* sc, const fl
     const dim3 fgrid(C / cw, B * ns);
 #define CALL(TT)                                                                                                       \
   if (mode) hipLaunchKernelGGL((nhwc_moments_flat_kernel<TT, 1>), fgrid, dim3(kThreads), 0, st, (const TT*)x,          \
-                               (const TT*)dy, sc, sh, relu, out, C, HW, ns, cw);                                       \
+                               (const TT*)dy, sc, sh, relu, dp, out, C, HW, ns, cw);                                   \
   else      hipLaunchKernelGGL((nhwc_moments_flat_kernel<TT, 0>), fgrid, dim3(kThreads), 0, st, (const TT*)x,          \
-                               (const TT*)dy, sc, sh, relu, out, C, HW, ns, cw);
+                               (const TT*)dy, sc, sh, relu, dp, out, C, HW, ns, cw);
     MRLA_DISPATCH_N(dtype, CALL)
 #undef CALL
     return hip_status(hipGetLastError());
   }
+  if (dp) return MRLA_EUNSUPPORTED;                 // per-image scaling exists in the flat form only
   const dim3 grid((C + 63) / 64, B * ns);
 #define CALL(TT)                                                                                                     \
   if (mode) hipLaunchKernelGGL((nhwc_moments_kernel<TT, 1>), grid, dim3(kThreads), 0, st, (const TT*)x, (const TT*)dy, \

@@ -84,7 +84,7 @@ int mrla_light_stats_fwd(const void* x, const void* o_prev, const float* wv, flo
                          int dtype, int layout, int act, void* stream) {
   if (!x || !wv || !mom || bad_dims(b, c, h, w) || bad_dtype(dtype)) return MRLA_EINVAL;
   if (layout == MRLA_NHWC)
-    return launch_light_stats_fwd_nhwc(x, o_prev, wv, mom, nullptr, nullptr, nullptr, b, c, h, w, dtype, act,
+    return launch_light_stats_fwd_nhwc(x, o_prev, wv, mom, nullptr, nullptr, nullptr, nullptr, b, c, h, w, dtype, act,
                                        (hipStream_t)stream);
   if (layout != MRLA_NCHW) return MRLA_EINVAL;
   SlabGeo g;
@@ -99,8 +99,8 @@ int mrla_light_stats_fwd_fused(const void* pre, const float* pre_sc, const float
   if (!pre || !o_prev || !wv || !mom || !x_out || bad_dims(b, c, h, w) || bad_dtype(dtype)) return MRLA_EINVAL;
   if ((pre_sc == nullptr) != (pre_sh == nullptr)) return MRLA_EINVAL;
   if (layout == MRLA_NHWC)
-    return launch_light_stats_fwd_nhwc(pre, o_prev, wv, mom, x_out, pre_sc, pre_sh, b, c, h, w, dtype, MRLA_ACT_NONE,
-                                       (hipStream_t)stream);
+    return launch_light_stats_fwd_nhwc(pre, o_prev, wv, mom, x_out, pre_sc, pre_sh, nullptr, b, c, h, w, dtype,
+                                       MRLA_ACT_NONE, (hipStream_t)stream);
   if (layout != MRLA_NCHW) return MRLA_EINVAL;
   SlabGeo g;
   const int rc = light_geo(&g, b, c, h, w, dtype);
@@ -205,10 +205,11 @@ int mrla_base_gate_fwd(const float* mom, const float* wq, const float* wk, int k
 
 int mrla_base_attend_fwd(const void* x, const float* wv, void* v_ring, const float* p_all, void* attn, float* amom,
                          int b, int c, int h, int w, int d, int T, int t, int dtype, int layout, void* stream) {
-  if (!x || !wv || !v_ring || !p_all || !attn || !amom || bad_dims(b, c, h, w) || bad_dtype(dtype) || d <= 0 || c % d ||
-      bad_ring(T, t))
+  if (!v_ring || !p_all || !attn || !amom || bad_dims(b, c, h, w) || bad_dtype(dtype) || d <= 0 || c % d || bad_ring(T, t))
     return MRLA_EINVAL;
-  if (layout != MRLA_NCHW) return MRLA_EUNSUPPORTED;
+  if (layout == MRLA_NHWC)      // slot t-1 was written by mrla_base_pool_value_fwd; x / wv are not read
+    return launch_base_attend_fwd_nhwc(v_ring, p_all, attn, amom, b, c, h * w, d, T, t, dtype, (hipStream_t)stream);
+  if (layout != MRLA_NCHW || !x || !wv) return MRLA_EINVAL;
   SlabGeo g;
   const int rc = light_geo(&g, b, c, h, w, dtype);
   if (rc != MRLA_OK) return rc;
@@ -228,14 +229,18 @@ int mrla_bn_stats_fwd(const float* amom, const float* gamma, const float* beta, 
 int mrla_base_tail_fwd(const void* x, const void* attn, const float* sc, const float* sh, const float* dp, void* out,
                        int b, int c, int h, int w, int dtype, int layout, void* stream) {
   if (!x || !attn || !sc || !sh || !out || bad_dims(b, c, h, w) || bad_dtype(dtype)) return MRLA_EINVAL;
-  if (layout != MRLA_NCHW) return MRLA_EUNSUPPORTED;
+  if (layout == MRLA_NHWC)
+    return launch_base_tail_fwd_nhwc(x, attn, sc, sh, dp, out, b, c, h * w, dtype, (hipStream_t)stream);
+  if (layout != MRLA_NCHW) return MRLA_EINVAL;
   return launch_base_tail_fwd(x, attn, sc, sh, dp, out, b, c, h * w, dtype, (hipStream_t)stream);
 }
 
 int mrla_base_tail_stats_bwd(const void* dout, const void* attn, const float* sc, const float* sh, const float* dp,
                              float* tmom, int b, int c, int h, int w, int dtype, int layout, void* stream) {
   if (!dout || !attn || !sc || !sh || !tmom || bad_dims(b, c, h, w) || bad_dtype(dtype)) return MRLA_EINVAL;
-  if (layout != MRLA_NCHW) return MRLA_EUNSUPPORTED;
+  if (layout == MRLA_NHWC)      // tmom then has mrla_bn_moment_rows() rows
+    return launch_nhwc_moments(attn, dout, sc, sh, 1, dp, tmom, b, c, h * w, dtype, 1, (hipStream_t)stream);
+  if (layout != MRLA_NCHW) return MRLA_EINVAL;
   SlabGeo g;
   const int rc = light_geo(&g, b, c, h, w, dtype);
   if (rc != MRLA_OK) return rc;
@@ -257,7 +262,10 @@ int mrla_base_attend_bwd(const void* dout, const void* attn, const float* sc, co
   if (!dout || !v_ring || !da_ring || !pmom || bad_dims(b, c, h, w) || bad_dtype(dtype) || bad_ring(T, t))
     return MRLA_EINVAL;
   if (sc && (!attn || !sh || !cb)) return MRLA_EINVAL;
-  if (layout != MRLA_NCHW) return MRLA_EUNSUPPORTED;
+  if (layout == MRLA_NHWC)      // pmom is the [mrla_base_tile_rows(), t, c] partial buffer; see mrla_base_pmom_reduce
+    return launch_base_attend_bwd_nhwc(dout, sc ? attn : nullptr, sc, sh, dp, cb, v_ring, da_ring, pmom, b, c, h * w, T, t,
+                                       dtype, (hipStream_t)stream);
+  if (layout != MRLA_NCHW) return MRLA_EINVAL;
   SlabGeo g;
   const int rc = light_geo(&g, b, c, h, w, dtype);
   if (rc != MRLA_OK) return rc;
@@ -287,6 +295,54 @@ int mrla_base_value_bwd(const void* dout, const void* x, const float* wv, const 
   if (rc != MRLA_OK) return rc;
   return launch_base_value_bwd(dout, x, wv, da_ring, p_all, dyx, dx, dwv_part, g, d, T, t, Tc, res, dtype,
                                (hipStream_t)stream);
+}
+
+// ---- channels_last MRLA-base: entry points that exist for the slot-major NHWC rings only ------------------------
+int mrla_base_tile_rows(int b, int c, int h, int w, int dtype, int layout) {
+  if (bad_dims(b, c, h, w) || bad_dtype(dtype)) return MRLA_EINVAL;
+  if (layout == MRLA_NCHW) return b;
+  if (layout != MRLA_NHWC) return MRLA_EINVAL;
+  if (!base_nhwc_supported(c, dtype)) return MRLA_EUNSUPPORTED;
+  return b * base_nhwc_tiles(b, c, h * w, dtype);
+}
+
+int mrla_base_pmom_rows(int b, int c, int h, int w, int dtype, int layout) {
+  if (bad_dims(b, c, h, w) || bad_dtype(dtype)) return MRLA_EINVAL;
+  if (layout == MRLA_NCHW) return b;
+  if (layout != MRLA_NHWC) return MRLA_EINVAL;
+  if (!base_nhwc_supported(c, dtype)) return MRLA_EUNSUPPORTED;
+  return b * base_nhwc_pmom_tiles(b, c, h * w, dtype);
+}
+
+int mrla_base_pool_value_fwd(const void* x, const void* identity, const float* wv, float* mom, void* x_out,
+                             void* v_slot, int b, int c, int h, int w, int dtype, int layout, void* stream) {
+  if (!x || !wv || !mom || !v_slot || bad_dims(b, c, h, w) || bad_dtype(dtype)) return MRLA_EINVAL;
+  if ((identity == nullptr) != (x_out == nullptr)) return MRLA_EINVAL;
+  if (layout != MRLA_NHWC) return MRLA_EUNSUPPORTED;
+  return launch_light_stats_fwd_nhwc(x, identity, wv, mom, x_out, nullptr, nullptr, v_slot, b, c, h, w, dtype,
+                                     MRLA_ACT_NONE, (hipStream_t)stream);
+}
+
+int mrla_base_pmom_reduce(const float* part, float* pmom, int b, int c, int t, int rows, void* stream) {
+  if (!part || !pmom || b <= 0 || c <= 0 || t <= 0 || rows <= 0 || rows % b) return MRLA_EINVAL;
+  return launch_base_pmom_reduce(part, pmom, b, c, t, rows / b, (hipStream_t)stream);
+}
+
+int mrla_base_dv_combine(const void* da_ring, const float* p_all, float* dv, int b, int c, int h, int w, int d, int T,
+                         int t, int Tc, int dtype, int layout, void* stream) {
+  if (!da_ring || !p_all || !dv || bad_dims(b, c, h, w) || bad_dtype(dtype) || d <= 0 || c % d || bad_ring(T, t) ||
+      Tc < t || Tc > T)
+    return MRLA_EINVAL;
+  if (layout != MRLA_NHWC) return MRLA_EUNSUPPORTED;
+  return launch_base_dv_combine_nhwc(da_ring, p_all, dv, b, c, h * w, d, T, t, Tc, dtype, (hipStream_t)stream);
+}
+
+int mrla_base_value_bwd_dv(const void* dout, const void* x, const float* wv, const float* dv, const float* dyx, void* dx,
+                           float* dwv_part, int b, int c, int h, int w, int res, int dtype, int layout, void* stream) {
+  if (!dout || !x || !wv || !dv || !dyx || !dx || !dwv_part || bad_dims(b, c, h, w) || bad_dtype(dtype))
+    return MRLA_EINVAL;
+  if (layout != MRLA_NHWC) return MRLA_EUNSUPPORTED;
+  return launch_base_value_bwd_nhwc(dout, x, wv, dv, dyx, dx, dwv_part, b, c, h, w, res, dtype, (hipStream_t)stream);
 }
 
 static int token_side(int n) {
@@ -347,7 +403,7 @@ int mrla_token_ln_bwd(const void* dout, const void* x, const void* o_prev, const
 int mrla_bn_plane_moments(const void* x, float* amom, int b, int c, int h, int w, int dtype, int layout, void* stream) {
   if (!x || !amom || bad_dims(b, c, h, w) || bad_dtype(dtype)) return MRLA_EINVAL;
   if (layout == MRLA_NHWC)
-    return launch_nhwc_moments(x, nullptr, nullptr, nullptr, 0, amom, b, c, h * w, dtype, 0, (hipStream_t)stream);
+    return launch_nhwc_moments(x, nullptr, nullptr, nullptr, 0, nullptr, amom, b, c, h * w, dtype, 0, (hipStream_t)stream);
   if (layout != MRLA_NCHW) return MRLA_EINVAL;
   return launch_plane_moments(x, amom, b, c, h * w, dtype, (hipStream_t)stream);
 }
@@ -365,7 +421,7 @@ int mrla_bn_plane_dmoments(const void* dy, const void* x, const float* sc, const
                            int c, int h, int w, int dtype, int layout, void* stream) {
   if (!dy || !x || !sc || !sh || !tmom || bad_dims(b, c, h, w) || bad_dtype(dtype)) return MRLA_EINVAL;
   if (layout == MRLA_NHWC)
-    return launch_nhwc_moments(x, dy, sc, sh, relu, tmom, b, c, h * w, dtype, 1, (hipStream_t)stream);
+    return launch_nhwc_moments(x, dy, sc, sh, relu, nullptr, tmom, b, c, h * w, dtype, 1, (hipStream_t)stream);
   if (layout != MRLA_NCHW) return MRLA_EINVAL;
   return launch_plane_dmoments(dy, x, sc, sh, relu, tmom, b, c, h * w, dtype, (hipStream_t)stream);
 }

@@ -22,8 +22,8 @@ namespace mrla {
 template <typename T, bool GELU, bool HAS_O, bool FUSE, bool WIDE>
 __global__ __launch_bounds__(kMaxStrips * kWave) void light_stats_fwd_nhwc(
     const T* __restrict__ x, const T* __restrict__ o, const float* __restrict__ wv, float* __restrict__ mom,
-    T* __restrict__ xout, const float* __restrict__ psc, const float* __restrict__ psh, int B, int C, int H, int W,
-    int BG) {
+    T* __restrict__ xout, const float* __restrict__ psc, const float* __restrict__ psh, T* __restrict__ vout, int B,
+    int C, int H, int W, int BG) {
   MRLA_NHWC_PROLOGUE(M_N)
   float w[9];
 #pragma unroll
@@ -36,6 +36,7 @@ __global__ __launch_bounds__(kMaxStrips * kWave) void light_stats_fwd_nhwc(
     const T* xi = x + ioff;
     const T* oi = HAS_O ? o + ioff : nullptr;
     T* xo = FUSE ? xout + ioff : nullptr;
+    T* vo = vout ? vout + ioff : nullptr;          // MRLA-base: V = dwconv3x3(x) is kept (the stage's value history)
     float acc[M_N] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
     for (int s = wave; s < nstrips; s += nwaves) {
       const int s0 = s * kS, nc = min(kS, W - s0);
@@ -87,11 +88,14 @@ __global__ __launch_bounds__(kMaxStrips * kWave) void light_stats_fwd_nhwc(
       load_row(0, rb, ob);
       for (int r = 0; r < H; ++r) {
         load_row(r + 1, rc, oc);
+        float vrow[kS];
 #pragma unroll
         for (int j = 0; j < kS; ++j) {
+          vrow[j] = 0.f;
           if (j < nc) {
             float v = conv_at(w, ra, rb, rc, j);
             if (GELU) v = gelu_f(v);
+            vrow[j] = v;
             acc[M_SX] += rb[j + 1];
             acc[M_SV] += v;
             acc[M_SVV] = fmaf(v, v, acc[M_SVV]);
@@ -103,6 +107,7 @@ __global__ __launch_bounds__(kMaxStrips * kWave) void light_stats_fwd_nhwc(
             }
           }
         }
+        if (vo) write_row<T, WIDE, kS>(vo, r, s0, nc, W, C, cbase, c, cv, lane, SCR(3), vrow);
 #pragma unroll
         for (int j = 0; j < kS + 2; ++j) { ra[j] = rb[j]; rb[j] = rc[j]; ob[j] = oc[j]; }
       }
@@ -258,14 +263,14 @@ __global__ __launch_bounds__(kMaxStrips * kWave) void light_stats_bwd_nhwc(
 }
 
 int launch_light_stats_fwd_nhwc(const void* x, const void* o, const float* wv, float* mom, void* xout,
-                                const float* psc, const float* psh, int B, int C, int H, int W, int dtype, int act,
-                                hipStream_t st) {
+                                const float* psc, const float* psh, void* vout, int B, int C, int H, int W, int dtype,
+                                int act, hipStream_t st) {
   const NhwcLaunch L = nhwc_launch(B, C, W, M_N, dtype);
 #define CALL_W(T, A, O, F, WD)                                                                                       \
   {                                                                                                                  \
     if (set_lds_n(light_stats_fwd_nhwc<T, A, O, F, WD>, L.lds) != hipSuccess) return MRLA_EHIP;                        \
     hipLaunchKernelGGL((light_stats_fwd_nhwc<T, A, O, F, WD>), L.grid, L.block, L.lds, st, (const T*)x, (const T*)o,  \
-                       wv, mom, (T*)xout, psc, psh, B, C, H, W, L.BG);                                               \
+                       wv, mom, (T*)xout, psc, psh, (T*)vout, B, C, H, W, L.BG);                                     \
   }
 #define CALL_F(T, A, O, F) { if (L.wide) CALL_W(T, A, O, F, true) else CALL_W(T, A, O, F, false) }
 #define CALL(T, A, O)                                                        \

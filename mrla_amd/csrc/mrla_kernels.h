@@ -84,6 +84,25 @@ int launch_base_value_bwd(const void* dout, const void* x, const float* wv, cons
                           int res, int dtype, hipStream_t st);
 
 
+// base_nhwc.hip -- MRLA-base for channels_last activations; rings are slot-major [T][b,h,w,c]
+bool base_nhwc_supported(int C, int dtype);
+int base_nhwc_tiles(int B, int C, int HW, int dtype);
+int base_nhwc_pmom_tiles(int B, int C, int HW, int dtype);
+int launch_base_attend_fwd_nhwc(const void* Vring, const float* Pall, void* attn, float* amom_part, int B, int C, int HW,
+                                int d, int T, int t, int dtype, hipStream_t st);
+int launch_base_dv_combine_nhwc(const void* dAring, const float* Pall, float* dv, int B, int C, int HW, int d, int T,
+                                int t, int Tc, int dtype, hipStream_t st);
+int launch_base_tail_fwd_nhwc(const void* x, const void* attn, const float* sc, const float* sh, const float* dp,
+                              void* out, int B, int C, int HW, int dtype, hipStream_t st);
+int launch_base_attend_bwd_nhwc(const void* dout, const void* attn, const float* sc, const float* sh, const float* dp,
+                                const float* cb, const void* Vring, void* dAring, float* pmom_part, int B, int C, int HW,
+                                int T, int t, int dtype, hipStream_t st);
+int launch_base_pmom_reduce(const float* part, float* pmom, int B, int C, int t, int tiles, hipStream_t st);
+int launch_base_value_bwd_nhwc(const void* dout, const void* x, const float* wv, const float* dv, const float* dyx,
+                               void* dx, float* dwv_part, int B, int C, int H, int W, int res, int dtype,
+                               hipStream_t st);
+
+
 // tokens.hip -- MRLA-light on token sequences (DeiT)
 int launch_token_norm_pool(const void* x, const void* o, const float* wx, const float* bx, float eps, float* stats,
                            float* mom, int B, int n, int C, int dtype, hipStream_t st);
@@ -112,8 +131,8 @@ int launch_affine_act(const void* x, const void* dy, const float* a, const float
 // light_nhwc.hip / bnact_nhwc.hip -- channels_last variants
 int nhwc_images_per_group(int B, int C);
 int launch_light_stats_fwd_nhwc(const void* x, const void* o, const float* wv, float* mom, void* xout,
-                                const float* psc, const float* psh, int B, int C, int H, int W, int dtype, int act,
-                                hipStream_t st);
+                                const float* psc, const float* psh, void* vout, int B, int C, int H, int W, int dtype,
+                                int act, hipStream_t st);
 int launch_light_apply_fwd_nhwc(const void* x, const void* o, const float* wv, const float* gate, const float* sc,
                                 const float* sh, const float* lam, const float* dp, void* out, int B, int C, int H,
                                 int W, int d, int res, int dtype, int act, hipStream_t st);
@@ -124,8 +143,8 @@ int launch_light_apply_bwd_nhwc(const void* dout, const void* x, const void* o, 
                                 void* dprev, float* dwv_part, int B, int C, int H, int W, int d, int res, int relu,
                                 int dtype, int act, hipStream_t st);
 int nhwc_bn_splits(int B, int C, int HW);
-int launch_nhwc_moments(const void* x, const void* dy, const float* sc, const float* sh, int relu, float* out, int B,
-                        int C, int HW, int dtype, int mode, hipStream_t st);
+int launch_nhwc_moments(const void* x, const void* dy, const float* sc, const float* sh, int relu, const float* dp,
+                        float* out, int B, int C, int HW, int dtype, int mode, hipStream_t st);
 int launch_nhwc_affine(const void* x, const void* dy, const float* a, const float* sc, const float* sh, int relu,
                        void* out, int B, int C, int HW, int dtype, int bwd, hipStream_t st);
 

@@ -256,16 +256,34 @@ class BaseStage:
     t+1's backward always runs before layer t's (x_{t+1} depends on out_t through the block chain).
     """
 
-    def __init__(self, b, c, h, w, d, dtype, device, capacity):
+    def __init__(self, b, c, h, w, d, dtype, device, capacity, layout=L.NCHW):
         self.b, self.c, self.h, self.w, self.d = b, c, h, w, d
-        self.dtype, self.device = dtype, device
+        self.dtype, self.device, self.layout = dtype, device, layout
         self.T = max(1, int(capacity))
         self.t = 0
         self.bwd_started = False
-        self.V = torch.empty((b, self.T, c, h, w), dtype=dtype, device=device)
+        self.V = torch.empty(self._vshape(self.T), dtype=dtype, device=device)
         self.K = torch.empty((b, self.T, c), dtype=torch.float32, device=device)
         self.P = torch.empty((b, c // d, self.T, self.T), dtype=torch.float32, device=device)
         self.dA = self.dK = None
+
+    @staticmethod
+    def layout_for(x, d):
+        """MRLA_NHWC when `x` is a channels_last tensor the slot-major NHWC kernels handle, else MRLA_NCHW."""
+        if x.dim() == 4 and not x.is_contiguous() and x.is_contiguous(memory_format=_CL) and x.dtype in _DT:
+            b, c, h, w = x.shape
+            if L.load().mrla_base_tile_rows(b, c, h, w, _DT[x.dtype], L.NHWC) > 0:
+                return L.NHWC
+        return L.NCHW
+
+    def _vshape(self, T):
+        """NCHW: [b, T, c, h, w] (the reference's V layout).  NHWC: slot-major [T, b, h, w, c]."""
+        if self.layout == L.NHWC:
+            return (T, self.b, self.h, self.w, self.c)
+        return (self.b, T, self.c, self.h, self.w)
+
+    def slot(self, ring, j):
+        return ring[j] if self.layout == L.NHWC else ring[:, j]
 
     def reserve_slot(self):
         """Make room for one more layer (amortised doubling when the capacity hint was too small)."""
@@ -274,10 +292,13 @@ class BaseStage:
         if self.bwd_started:
             raise L.MrlaHipError("MRLA-base history grown after its backward pass started")
         T2, t = 2 * self.T, self.t
-        V = torch.empty((self.b, T2, self.c, self.h, self.w), dtype=self.dtype, device=self.device)
+        V = torch.empty(self._vshape(T2), dtype=self.dtype, device=self.device)
         K = torch.empty((self.b, T2, self.c), dtype=torch.float32, device=self.device)
         P = torch.empty((self.b, self.c // self.d, T2, T2), dtype=torch.float32, device=self.device)
-        V[:, :t].copy_(self.V[:, :t])
+        if self.layout == L.NHWC:
+            V[:t].copy_(self.V[:t])
+        else:
+            V[:, :t].copy_(self.V[:, :t])
         K[:, :t].copy_(self.K[:, :t])
         P[:, :, :t, :t].copy_(self.P[:, :, :t, :t])
         self.V, self.K, self.P, self.T = V, K, P, T2
@@ -291,7 +312,9 @@ class BaseStage:
         return first
 
     def views(self):
-        K, V = self.K[:, :self.t], self.V[:, :self.t]
+        """(K[b,t,c], V[b,t,c,h,w]) as the reference returns them -- views of the rings."""
+        K = self.K[:, :self.t]
+        V = self.V[:self.t].permute(1, 0, 4, 2, 3) if self.layout == L.NHWC else self.V[:, :self.t]
         K._mrla_stage = V._mrla_stage = self
         return K, V
 
@@ -310,7 +333,7 @@ class _BaseFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, identity, wq, wk, wv, gamma, beta, running_mean, running_var, dp, stage, cfg):
         _require_cuda(x, "mrla base forward")
-        layout, xc = _layout_of(x, L.NCHW)          # the MRLA-base rings are NCHW
+        layout, xc = _layout_of(x, stage.layout)    # the stage's rings fix the layout (NHWC rings are slot-major)
         b, c, h, w = xc.shape
         d = cfg.d
         if (b, c, h, w, d) != (stage.b, stage.c, stage.h, stage.w, stage.d) or xc.dtype != stage.dtype:
@@ -325,11 +348,21 @@ class _BaseFn(torch.autograd.Function):
         t, T = stage.t + 1, stage.T
 
         mom = torch.empty((b, c, L.FWD_MOMENTS), dtype=torch.float32, device=dev)
-        if cfg.fuse:            # x is the pre-activation: x_t = relu(x + identity) formed by the pooling pass
+        nhwc = layout == L.NHWC
+        es = xc.element_size()
+        if nhwc:                # one pass: pooling moments, V_t -> ring slot (and x_t = relu(x + identity) when fused)
+            idc = pre = None
+            if cfg.fuse:
+                idc = _layout_of(identity, layout)[1]
+                pre, xc = xc, torch.empty_like(xc)
+            _call("mrla_base_pool_value_fwd", xc.numel() * es * (4 if cfg.fuse else 2), _ptr(pre if cfg.fuse else xc),
+                  _ptr(idc), _ptr(wv32), _ptr(mom), _ptr(xc) if cfg.fuse else None, _ptr(stage.V[t - 1]), b, c, h, w, dt,
+                  layout, st)
+        elif cfg.fuse:          # x is the pre-activation: x_t = relu(x + identity) formed by the pooling pass
             idc = _layout_of(identity, L.NCHW)[1]
             pre, xc = xc, torch.empty_like(xc)
-            _call("mrla_light_stats_fwd_fused", xc.numel() * xc.element_size() * 3, _ptr(pre), _ptr(idc), _ptr(wv32),
-                  _ptr(mom), _ptr(xc), b, c, h, w, dt, layout, st)
+            _call("mrla_light_stats_fwd_fused", xc.numel() * xc.element_size() * 3, _ptr(pre), None, None, _ptr(idc),
+                  _ptr(wv32), _ptr(mom), _ptr(xc), b, c, h, w, dt, layout, st)
         else:
             _call("mrla_light_stats_fwd", xc.numel() * xc.element_size(), _ptr(xc), None, _ptr(wv32), _ptr(mom), b, c, h,
                   w, dt, layout, L.ACT_NONE, st)
@@ -337,9 +370,11 @@ class _BaseFn(torch.autograd.Function):
         L.call("mrla_base_gate_fwd", _ptr(mom), _ptr(wq32), _ptr(wk32), ks, _ptr(stage.K), _ptr(stage.P), _ptr(q), b, c,
                h * w, d, T, t, st)
         attn = torch.empty_like(xc)
-        amom = torch.empty((b, c, 2), dtype=torch.float32, device=dev)
-        _call("mrla_base_attend_fwd", xc.numel() * xc.element_size() * (t + 2), _ptr(xc), _ptr(wv32), _ptr(stage.V),
-              _ptr(stage.P), _ptr(attn), _ptr(amom), b, c, h, w, d, T, t, dt, layout, st)
+        arows = L.load().mrla_base_tile_rows(b, c, h, w, dt, layout)      # rows of the (sum, sum^2) partials
+        L.check(min(arows, 0), "mrla_base_tile_rows")
+        amom = torch.empty((arows, c, 2), dtype=torch.float32, device=dev)
+        _call("mrla_base_attend_fwd", xc.numel() * es * ((t + 1) if nhwc else (t + 2)), None if nhwc else _ptr(xc),
+              _ptr(wv32), _ptr(stage.V), _ptr(stage.P), _ptr(attn), _ptr(amom), b, c, h, w, d, T, t, dt, layout, st)
         stage.t = t
         bnbuf = gamma32 = None
         out = attn
@@ -348,7 +383,7 @@ class _BaseFn(torch.autograd.Function):
             bnbuf = torch.empty((4, c), dtype=torch.float32, device=dev)
             L.call("mrla_bn_stats_fwd", _ptr(amom), _ptr(gamma32), _ptr(beta32), _ptr(running_mean), _ptr(running_var),
                    cfg.bn_mode, float(cfg.momentum), float(cfg.eps), _ptr(bnbuf[0]), _ptr(bnbuf[1]), _ptr(bnbuf[2]),
-                   _ptr(bnbuf[3]), b, c, h * w, st)
+                   _ptr(bnbuf[3]), arows, c, b * h * w // arows, st)
             out = torch.empty_like(xc)
             _call("mrla_base_tail_fwd", xc.numel() * xc.element_size() * 3, _ptr(xc), _ptr(attn), _ptr(bnbuf[0]),
                   _ptr(bnbuf[1]), _ptr(dp32), _ptr(out), b, c, h, w, dt, layout, st)
@@ -368,24 +403,30 @@ class _BaseFn(torch.autograd.Function):
         dt, dev, st = _DT[xc.dtype], xc.device, _stream()
         if dout.dtype != xc.dtype:
             dout = dout.to(xc.dtype)
-        dout = dout.contiguous()
+        dout = _layout_of(dout, layout)[1]
+        nhwc = layout == L.NHWC
         first = stage.backward_buffers()
         es = xc.element_size()
 
         cb = dgamma = dbeta = None
         if cfg.tail:
-            tmom = torch.empty((b, c, 2), dtype=torch.float32, device=dev)
+            trows = L.load().mrla_bn_moment_rows(b, c, h, w, layout) if nhwc else b
+            tmom = torch.empty((trows, c, 2), dtype=torch.float32, device=dev)
             _call("mrla_base_tail_stats_bwd", xc.numel() * es * 2, _ptr(dout), _ptr(attn), _ptr(bnbuf[0]), _ptr(bnbuf[1]),
                   _ptr(dp32), _ptr(tmom), b, c, h, w, dt, layout, st)
             small = torch.empty((5, c), dtype=torch.float32, device=dev)         # cb[c,3] | dgamma | dbeta
             cb = small[:3].view(c, 3)
             L.call("mrla_bn_stats_bwd", _ptr(tmom), _ptr(gamma32), _ptr(bnbuf[2]), _ptr(bnbuf[3]), cfg.bn_mode, _ptr(cb),
-                   _ptr(small[3]), _ptr(small[4]), b, c, h * w, st)
+                   _ptr(small[3]), _ptr(small[4]), trows, c, b * h * w // trows, st)
             dgamma, dbeta = small[3].to(ctx.pdtypes[3]), small[4].to(ctx.pdtypes[3])
         pmom = torch.empty((b, c, t), dtype=torch.float32, device=dev)
+        prows = L.load().mrla_base_pmom_rows(b, c, h, w, dt, layout)
+        ppart = torch.empty((prows, t, c), dtype=torch.float32, device=dev) if nhwc else pmom
         _call("mrla_base_attend_bwd", xc.numel() * es * (t + 3), _ptr(dout), _ptr(attn),
               _ptr(bnbuf[0]) if cfg.tail else None, _ptr(bnbuf[1]) if cfg.tail else None, _ptr(dp32), _ptr(cb),
-              _ptr(stage.V), _ptr(stage.dA), _ptr(pmom), b, c, h, w, T, t, dt, layout, st)
+              _ptr(stage.V), _ptr(stage.dA), _ptr(ppart), b, c, h, w, T, t, dt, layout, st)
+        if nhwc:
+            L.call("mrla_base_pmom_reduce", _ptr(ppart), _ptr(pmom), b, c, t, prows, st)
         dyx = torch.empty((b, c), dtype=torch.float32, device=dev)
         dwqk_part = torch.empty((b, 2 * ks), dtype=torch.float32, device=dev)
         L.call("mrla_base_gate_bwd", _ptr(mom), _ptr(pmom), _ptr(stage.P), _ptr(q), _ptr(stage.K), _ptr(stage.dK),
@@ -394,9 +435,17 @@ class _BaseFn(torch.autograd.Function):
         L.check(min(rows, 0), "mrla_light_wgrad_rows")
         dwv_part = torch.empty((rows, c * 9), dtype=torch.float32, device=dev)
         dx = torch.empty_like(xc)
-        _call("mrla_base_value_bwd", xc.numel() * es * (Tc - t + 4), _ptr(dout), _ptr(xc), _ptr(wv32), _ptr(stage.dA),
-              _ptr(stage.P), _ptr(dyx), _ptr(dx), _ptr(dwv_part), b, c, h, w, d, T, t, Tc,
-              int(cfg.tail) | (2 if cfg.fuse else 0), dt, layout, st)
+        res = int(cfg.tail) | (2 if cfg.fuse else 0)
+        if nhwc:                # dV_t (fp32) from the dA slots t..Tc, then the transposed 3x3 pass
+            dv = torch.empty((b, h, w, c), dtype=torch.float32, device=dev)
+            _call("mrla_base_dv_combine", xc.numel() * (es * (Tc - t + 1) + 4), _ptr(stage.dA), _ptr(stage.P), _ptr(dv),
+                  b, c, h, w, d, T, t, Tc, dt, layout, st)
+            _call("mrla_base_value_bwd_dv", xc.numel() * (es * 3 + 4), _ptr(dout), _ptr(xc), _ptr(wv32), _ptr(dv),
+                  _ptr(dyx), _ptr(dx), _ptr(dwv_part), b, c, h, w, res, dt, layout, st)
+        else:
+            _call("mrla_base_value_bwd", xc.numel() * es * (Tc - t + 4), _ptr(dout), _ptr(xc), _ptr(wv32),
+                  _ptr(stage.dA), _ptr(stage.P), _ptr(dyx), _ptr(dx), _ptr(dwv_part), b, c, h, w, d, T, t, Tc, res, dt,
+                  layout, st)
         wsum = torch.empty((c * 9 + 2 * ks,), dtype=torch.float32, device=dev)
         L.call("mrla_reduce_rows", _ptr(dwv_part), _ptr(wsum), rows, c * 9, st)
         L.call("mrla_reduce_rows", _ptr(dwqk_part), _ptr(wsum[c * 9:]), b, 2 * ks, st)

@@ -146,7 +146,8 @@ def _stage_for(layer, x, prev_K, prev_V):
     K/V views belong to."""
     if layer.init_cell:
         b, c, h, w = x.shape
-        return F_.BaseStage(b, c, h, w, layer.dim_perhead, x.dtype, x.device, layer.history_hint or 4)
+        return F_.BaseStage(b, c, h, w, layer.dim_perhead, x.dtype, x.device, layer.history_hint or 4,
+                            F_.BaseStage.layout_for(x, layer.dim_perhead))
     stage = getattr(prev_V, "_mrla_stage", None)
     if stage is None or getattr(prev_K, "_mrla_stage", None) is not stage:
         raise MrlaHipError("prev_K / prev_V must be the tensors returned by the previous MRLA-base layer of the same "

@@ -195,7 +195,9 @@ class ResNet_mrlal(_ResNetMRLA):
 
 class ResNet_mrlab(_ResNetMRLA):
     """ResNet (deep 3-conv stem) with an MRLA-base module after every bottleneck; the K/V history is threaded
-    through the blocks of a stage (resnet_mrla_base.py:134-272)."""
+    through the blocks of a stage (resnet_mrla_base.py:134-272).  `channels_last` as in ResNet_mrlal: the stage's value
+    history then lives in slot-major NHWC rings."""
+    channels_last = True
 
     def __init__(self, block, layers, num_classes=1000, SE=False, ECA=None, zero_init_last_bn=True, groups=1,
                  width_per_group=64, replace_stride_with_dilation=None, norm_layer=nn.BatchNorm2d, drop_rate=0.0,
@@ -222,8 +224,12 @@ class ResNet_mrlab(_ResNetMRLA):
             mods[0].mrla.mrla.history_hint = len(mods)
         self.stages = nn.ModuleList([nn.ModuleList(m) for m in stages])
         self._head_and_init(block, zero_init_last_bn)
+        if self.channels_last:
+            self.to(memory_format=torch.channels_last)
 
     def forward_features(self, x):
+        if self.channels_last and x.is_cuda:
+            x = x.contiguous(memory_format=torch.channels_last)
         x = self.maxpool(F_.bn_act(self.conv1(x), self.bn1, relu=True))
         k = v = None
         for stage in self.stages:

@@ -11,17 +11,27 @@ from tests.test_light_gpu import ACT_TOL, PAR_TOL, assert_bf16_close, bf16_round
 pytestmark = pytest.mark.gpu
 
 
-def run_chain(xs, gups, params, d, training, dtype=torch.float32, hint=None, dp=None):
-    """Fused block tails of a whole stage on the GPU; returns per-layer outs / grads."""
-    from mrla_amd import functional as Fm
+def run_chain(xs, gups, params, d, training, dtype=torch.float32, hint=None, dp=None, cl=False):
+    """Fused block tails of a whole stage on the GPU; returns per-layer outs / grads.  cl: channels_last activations
+    and slot-major NHWC rings."""
+    from mrla_amd import _lib as L, functional as Fm
     Tn = len(xs)
     b, c, h, w = xs[0].shape
-    stage = Fm.BaseStage(b, c, h, w, d, dtype, torch.device("cuda"), hint or Tn)
+    layout = L.NCHW
+    if cl:
+        probe = torch.empty((b, c, h, w), dtype=dtype, device="cuda").contiguous(memory_format=torch.channels_last)
+        layout = Fm.BaseStage.layout_for(probe, d)
+        if layout != L.NHWC:
+            pytest.skip("shape not served by the NHWC MRLA-base kernels (the stage stays NCHW)")
+    stage = Fm.BaseStage(b, c, h, w, d, dtype, torch.device("cuda"), hint or Tn, layout)
     xts, prms, rms, rvs, outs = [], [], [], [], []
     loss = 0.0
     for t in range(Tn):
         P = params[t]
-        xt = to_dev(xs[t], dtype).requires_grad_(True)
+        xt = to_dev(xs[t], dtype)
+        if cl:
+            xt = xt.contiguous(memory_format=torch.channels_last)
+        xt.requires_grad_(True)
         prm = {k: to_dev(v).requires_grad_(True) for k, v in P.items() if "running" not in k}
         rm, rv = to_dev(P["bn_mrla.running_mean"]), to_dev(P["bn_mrla.running_var"])
         out = Fm.mrla_base(xt, prm["mrla.mrla.Wq.weight"], prm["mrla.mrla.Wk.weight"], prm["mrla.mrla.Wv.weight"], d, stage,
@@ -79,12 +89,13 @@ PAIRS = (("mrla.mrla.Wq.weight", "dwq"), ("mrla.mrla.Wk.weight", "dwk"), ("mrla.
 
 @pytest.mark.parametrize("case", cases.BASE_CASES, ids=lambda c: c[0])
 @pytest.mark.parametrize("mode", ["train", "eval"])
-def test_base_chain_fp32_vs_oracle_and_reference(case, mode):
+@pytest.mark.parametrize("cl", [False, True], ids=["nchw", "nhwc"])
+def test_base_chain_fp32_vs_oracle_and_reference(case, mode, cl):
     name, b, c, h, w, d, Tn = case
     G = cases.golden("base_chains")
     xs, gups = zip(*[cases.base_inputs(name, t, b, c, h, w) for t in range(Tn)])
     params = [cases.block_params(c, 10 + t, light=False) for t in range(Tn)]
-    got, K, V = run_chain(xs, gups, params, d, mode == "train", hint=2 if name == "chain5" else None)   # chain5: ring growth
+    got, K, V = run_chain(xs, gups, params, d, mode == "train", hint=2 if name == "chain5" else None, cl=cl)   # chain5: ring growth
     outs, caches, grads, Ko, Vo = oracle_chain(xs, gups, params, d, mode == "train")
     assert relmax(K, Ko) < ACT_TOL and relmax(V, Vo) < ACT_TOL
     assert relmax(K, G[f"{name}/{mode}/K"]) < 2e-5 and relmax(V, G[f"{name}/{mode}/V"]) < 2e-5
@@ -103,7 +114,8 @@ def test_base_chain_fp32_vs_oracle_and_reference(case, mode):
 @pytest.mark.parametrize("shape", [(3, 256, 56, 56, 16, 3), (2, 1024, 14, 14, 16, 6), (2, 2048, 7, 7, 16, 3)],
                          ids=lambda s: "x".join(map(str, s)))
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16], ids=["fp32", "bf16"])
-def test_base_chain_resnet_stage_shapes(shape, dtype):
+@pytest.mark.parametrize("cl", [False, True], ids=["nchw", "nhwc"])
+def test_base_chain_resnet_stage_shapes(shape, dtype, cl):
     b, c, h, w, d, Tn = shape
     xs, gups, dps = [], [], []
     for t in range(Tn):
@@ -115,7 +127,7 @@ def test_base_chain_resnet_stage_shapes(shape, dtype):
         xs.append(x); gups.append(gu)
         dps.append(np.array(([1, 1, 0] * 2)[t % 2:t % 2 + b], dtype=np.float64) / 0.8)
     params = [cases.block_params(c, 20 + t, light=False) for t in range(Tn)]
-    got, K, V = run_chain(xs, gups, params, d, True, dtype, dp=dps)
+    got, K, V = run_chain(xs, gups, params, d, True, dtype, dp=dps, cl=cl)
     if dtype == torch.float32:
         outs, caches, grads, Ko, Vo = oracle_chain(xs, gups, params, d, True, dp=dps)
         for t in range(Tn):

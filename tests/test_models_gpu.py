@@ -70,15 +70,19 @@ def test_resnet50_mrlal_train_step_matches_eager():
         assert rel(sp[k].float().cpu().numpy(), sr[k].float().cpu().numpy()) < 1e-4, k
 
 
-def test_resnet50_mrlal_nchw_and_channels_last_paths_agree():
-    """The class default runs NHWC inside; switching it off runs the NCHW kernels: same logits, same gradients."""
+@pytest.mark.parametrize("arch", ["resnet50_mrlal", "resnet50_mrlab"])
+def test_nchw_and_channels_last_paths_agree(arch):
+    """The class default runs NHWC inside (MRLA-base: slot-major NHWC history rings); switching it off runs the NCHW
+    kernels: same logits, same gradients."""
     from mrla_amd import models
-    a, b = models.resnet50_mrlal().cuda(), models.resnet50_mrlal().cuda()
+    a, b = getattr(models, arch)().cuda(), getattr(models, arch)().cuda()
     load_det(a)
     b.load_state_dict(a.state_dict())
     b.channels_last = False
     b.to(memory_format=torch.contiguous_format)
-    assert a.conv1.weight.is_contiguous(memory_format=torch.channels_last) and b.conv1.weight.is_contiguous()
+    wa, wb = next(m.weight for m in a.modules() if isinstance(m, torch.nn.Conv2d) and m.kernel_size == (3, 3)), \
+        next(m.weight for m in b.modules() if isinstance(m, torch.nn.Conv2d) and m.kernel_size == (3, 3))
+    assert wa.is_contiguous(memory_format=torch.channels_last) and wb.is_contiguous()
     a.train(); b.train()
     x = torch.from_numpy(cases.image_batch(4, "img-train")).cuda()
     ya, yb = a(x), b(x)

@@ -196,10 +196,12 @@ int mrla_base_tile_rows(int b, int c, int h, int w, int dtype, int layout);
 int mrla_base_pmom_rows(int b, int c, int h, int w, int dtype, int layout);
 
 /* mom[b,c,6] <- pooling moments of x_t (slot 0 = sum x_t);  v_slot <- V_t = dwconv3x3(x_t) (ring slot t-1).
- * identity [opt]: x is the pre-activation, x_t = relu(x + identity) is formed here and also written to x_out.
+ * identity [opt]: x is the pre-activation, x_t = relu(x + identity) is formed here and also written to x_out;
+ * pre_sc / pre_sh [opt, with identity]: deferred bn3 affine as in mrla_light_stats_fwd_fused.
  * Replaces avg_pool + Wv of mrla_base_module.py:57-58,63 and resnet_mrla_base.py:120-121. */
-int mrla_base_pool_value_fwd(const void* x, const void* identity, const float* wv, float* mom, void* x_out,
-                             void* v_slot, int b, int c, int h, int w, int dtype, int layout, void* stream);
+int mrla_base_pool_value_fwd(const void* x, const float* pre_sc, const float* pre_sh, const void* identity,
+                             const float* wv, float* mom, void* x_out, void* v_slot, int b, int c, int h, int w,
+                             int dtype, int layout, void* stream);
 
 /* pmom[b, c, t] <- sum over the rows/b tiles of an image of part[rows, t, c]. */
 int mrla_base_pmom_reduce(const float* part, float* pmom, int b, int c, int t, int rows, void* stream);

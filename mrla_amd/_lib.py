@@ -37,7 +37,7 @@ SIGNATURES = {
     "mrla_light_stats_fwd_fused": [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P],
     "mrla_base_tile_rows": [_I] * 6,
     "mrla_base_pmom_rows": [_I] * 6,
-    "mrla_base_pool_value_fwd": [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P],
+    "mrla_base_pool_value_fwd": [_P] * 8 + [_I] * 6 + [_P],
     "mrla_base_pmom_reduce": [_P, _P, _I, _I, _I, _I, _P],
     "mrla_base_dv_combine": [_P, _P, _P] + [_I] * 10 + [_P],
     "mrla_base_value_bwd_dv": [_P] * 7 + [_I] * 7 + [_P],

@@ -314,12 +314,14 @@ int mrla_base_pmom_rows(int b, int c, int h, int w, int dtype, int layout) {
   return b * base_nhwc_pmom_tiles(b, c, h * w, dtype);
 }
 
-int mrla_base_pool_value_fwd(const void* x, const void* identity, const float* wv, float* mom, void* x_out,
-                             void* v_slot, int b, int c, int h, int w, int dtype, int layout, void* stream) {
+int mrla_base_pool_value_fwd(const void* x, const float* pre_sc, const float* pre_sh, const void* identity,
+                             const float* wv, float* mom, void* x_out, void* v_slot, int b, int c, int h, int w,
+                             int dtype, int layout, void* stream) {
   if (!x || !wv || !mom || !v_slot || bad_dims(b, c, h, w) || bad_dtype(dtype)) return MRLA_EINVAL;
   if ((identity == nullptr) != (x_out == nullptr)) return MRLA_EINVAL;
+  if ((pre_sc == nullptr) != (pre_sh == nullptr) || (pre_sc && !identity)) return MRLA_EINVAL;
   if (layout != MRLA_NHWC) return MRLA_EUNSUPPORTED;
-  return launch_light_stats_fwd_nhwc(x, identity, wv, mom, x_out, nullptr, nullptr, v_slot, b, c, h, w, dtype,
+  return launch_light_stats_fwd_nhwc(x, identity, wv, mom, x_out, pre_sc, pre_sh, v_slot, b, c, h, w, dtype,
                                      MRLA_ACT_NONE, (hipStream_t)stream);
 }
 

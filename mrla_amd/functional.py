@@ -320,10 +320,11 @@ class BaseStage:
 
 
 class BaseConfig:
-    __slots__ = ("d", "bn_mode", "momentum", "eps", "tail", "fuse")
+    __slots__ = ("d", "bn_mode", "momentum", "eps", "tail", "fuse", "pre_affine")
 
-    def __init__(self, d, bn_mode=L.BN_NONE, momentum=0.1, eps=1e-5, tail=False, fuse=False):
+    def __init__(self, d, bn_mode=L.BN_NONE, momentum=0.1, eps=1e-5, tail=False, fuse=False, pre_affine=None):
         self.d, self.bn_mode, self.momentum, self.eps, self.tail, self.fuse = d, bn_mode, momentum, eps, tail, fuse
+        self.pre_affine = pre_affine     # deferred bn3 affine (NHWC stages only), see bn_act(defer=True)
 
 
 class _BaseFn(torch.autograd.Function):
@@ -355,9 +356,10 @@ class _BaseFn(torch.autograd.Function):
             if cfg.fuse:
                 idc = _layout_of(identity, layout)[1]
                 pre, xc = xc, torch.empty_like(xc)
+            psc, psh = cfg.pre_affine if cfg.pre_affine is not None else (None, None)
             _call("mrla_base_pool_value_fwd", xc.numel() * es * (4 if cfg.fuse else 2), _ptr(pre if cfg.fuse else xc),
-                  _ptr(idc), _ptr(wv32), _ptr(mom), _ptr(xc) if cfg.fuse else None, _ptr(stage.V[t - 1]), b, c, h, w, dt,
-                  layout, st)
+                  _ptr(psc), _ptr(psh), _ptr(idc), _ptr(wv32), _ptr(mom), _ptr(xc) if cfg.fuse else None,
+                  _ptr(stage.V[t - 1]), b, c, h, w, dt, layout, st)
         elif cfg.fuse:          # x is the pre-activation: x_t = relu(x + identity) formed by the pooling pass
             idc = _layout_of(identity, L.NCHW)[1]
             pre, xc = xc, torch.empty_like(xc)
@@ -460,10 +462,14 @@ def mrla_base(x, wq, wk, wv, d, stage, bn=None, dp=None, identity=None):
     mrla_light(); with bn the block tail x + dp*relu(BN(attn)) is fused in.  identity: when given, `x` is the
     bottleneck's pre-activation and x_t = relu(x + identity) is formed inside the pooling pass."""
     fuse = identity is not None
+    pre_affine = getattr(x, "_mrla_affine", None)
+    if pre_affine is not None and not (fuse and stage.layout == L.NHWC):
+        raise L.MrlaHipError("a deferred BatchNorm output can only feed the fused producer of an NHWC MRLA-base stage")
     if bn is None:
-        return _BaseFn.apply(x, identity, wq, wk, wv, None, None, None, None, None, stage, BaseConfig(d, fuse=fuse))
+        return _BaseFn.apply(x, identity, wq, wk, wv, None, None, None, None, None, stage,
+                             BaseConfig(d, fuse=fuse, pre_affine=pre_affine))
     cfg = BaseConfig(d, L.BN_TRAIN if bn["training"] else L.BN_EVAL, bn.get("momentum", 0.1), bn.get("eps", 1e-5), True,
-                     fuse)
+                     fuse, pre_affine)
     return _BaseFn.apply(x, identity, wq, wk, wv, bn["weight"], bn["bias"], bn["running_mean"], bn["running_var"], dp,
                          stage, cfg)
 

@@ -189,6 +189,20 @@ class mrla_base_module(nn.Module):
         return self.mrla(xt, prev_k, prev_v)
 
 
+def base_tail_defers_bn3(mrla, bn_mrla, prev_v):
+    """Predicate on conv3's output: True when base_block_tail will run its fused path on an NHWC stage, so that bn3's
+    elementwise pass can be folded into the MRLA pooling pass."""
+    def decide(conv_out):
+        if not (type(bn_mrla) is nn.BatchNorm2d and bn_mrla.affine):
+            return False
+        layer = mrla.mrla
+        if layer.init_cell:
+            return F_.BaseStage.layout_for(conv_out, layer.dim_perhead) == F_.L.NHWC
+        stage = getattr(prev_v, "_mrla_stage", None)
+        return stage is not None and stage.layout == F_.L.NHWC
+    return decide
+
+
 def base_block_tail(x, prev_k, prev_v, mrla, bn_mrla, drop_path, identity=None):
     """x + DropPath(relu(bn_mrla(attn))) with attn, K, V from the MRLA-base layer (resnet_mrla_base.py:124-127).
     identity given: `x` is the bottleneck's bn3 output and x_t = relu(x + identity) (:120-121) is formed in-kernel."""

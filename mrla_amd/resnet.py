@@ -47,11 +47,13 @@ class _BottleneckTrunk(nn.Module):
 
     def trunk_pre(self, x, defer_bn3=False):
         """Everything up to, but not including, the shortcut add + ReLU: (bn3 output, identity).
-        defer_bn3: only bn3's statistics are taken here; its affine is applied by the consumer's first pass."""
+        defer_bn3 (bool, or a predicate on conv3's output): only bn3's statistics are taken here; its affine is applied
+        by the consumer's first pass."""
         identity = x
         out = F_.bn_act(self.conv1(x), self.bn1, relu=True)          # fused BatchNorm+ReLU HIP passes
         out = F_.bn_act(self.conv2(out), self.bn2, relu=True)
-        out = F_.bn_act(self.conv3(out), self.bn3, relu=False, defer=defer_bn3)
+        out = self.conv3(out)
+        out = F_.bn_act(out, self.bn3, relu=False, defer=defer_bn3(out) if callable(defer_bn3) else defer_bn3)
         if self.downsample is not None:
             ds = self.downsample
             if isinstance(ds, nn.Sequential) and len(ds) == 2 and isinstance(ds[0], nn.Conv2d):
@@ -94,7 +96,8 @@ class MRLA_Bottleneck_base(_BottleneckTrunk):
         self.drop_path = layers.DropPath(drop_path) if drop_path > 0.0 else nn.Identity()
 
     def forward(self, x, prev_k, prev_v):
-        pre, identity = self.trunk_pre(x)           # shortcut add + ReLU run inside the MRLA pooling pass
+        # shortcut add + ReLU (and, on channels_last stages, bn3's affine) run inside the MRLA pooling pass
+        pre, identity = self.trunk_pre(x, defer_bn3=layers.base_tail_defers_bn3(self.mrla, self.bn_mrla, prev_v))
         return layers.base_block_tail(pre, prev_k, prev_v, self.mrla, self.bn_mrla, self.drop_path, identity=identity)
 
 

@@ -45,7 +45,7 @@ for c, hw, T, ts in ((256, 56, 3, (1, 3)), (512, 28, 4, (1, 4)), (1024, 14, 23, 
     dwv = torch.empty(wrows, c * 9, device="cuda")
     mom = torch.empty(B, c, 6, device="cuda")
     print(f"--- c={c} {hw}x{hw} T={T} tile rows/image={rows // B}  tensor {n * 2 / 1e6:.0f} MB")
-    t0 = timeit(lambda: lib.mrla_base_pool_value_fwd(P(x), None, P(wv), P(mom), None, P(ring[0]), B, c, hw, hw, L.BF16, L.NHWC, st))
+    t0 = timeit(lambda: lib.mrla_base_pool_value_fwd(P(x), None, None, None, P(wv), P(mom), None, P(ring[0]), B, c, hw, hw, L.BF16, L.NHWC, st))
     print(f"   pool_value          {t0 * 1e6:8.1f} us  {2 * n * 2 / t0 / 1e12:5.2f} TB/s")
     t0 = timeit(lambda: lib.mrla_base_tail_fwd(P(x), P(attn), P(sc), P(sh), None, P(out), B, c, hw, hw, L.BF16, L.NHWC, st))
     print(f"   tail_fwd            {t0 * 1e6:8.1f} us  {3 * n * 2 / t0 / 1e12:5.2f} TB/s")

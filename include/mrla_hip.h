@@ -67,6 +67,18 @@ int mrla_light_stats_fwd_fused(const void* pre, const float* pre_sc, const float
                                const float* wv, float* mom, void* x_out, int b, int c, int h, int w, int dtype,
                                int layout, void* stream);
 
+/* ---- inference form of the fused block tail (MRLA_NHWC, no gradients asked for): 5N instead of 6N elements ----
+ * x_t = relu((pre_sc*pre + pre_sh) + o_prev) is never written: mrla_light_pool_fused takes its pooled sums (slot 0 of
+ * mom[b,c,6]; part = workspace of mrla_bn_moment_rows() x c x 2 floats), mrla_light_gate_fwd / mrla_light_bn_fwd
+ * (MRLA_BN_EVAL) follow as usual, and mrla_light_apply_fwd_fused re-forms x_t from pre and o_prev while it applies
+ * out = res*x_t + dp*(sc*(a*dwconv3x3(x_t) + lam*o_prev) + sh).  Same reference lines as the two passes above. */
+int mrla_light_pool_fused(const void* pre, const float* pre_sc, const float* pre_sh, const void* o_prev, float* part,
+                          float* mom, int b, int c, int h, int w, int dtype, int layout, void* stream);
+int mrla_light_apply_fwd_fused(const void* pre, const float* pre_sc, const float* pre_sh, const void* o_prev,
+                               const float* wv, const float* gate, const float* sc, const float* sh, const float* lam,
+                               const float* dp, void* out, int b, int c, int h, int w, int d, int res, int dtype,
+                               int layout, void* stream);
+
 /* ---- gate: a[b, g] ------------------------------------------------------------------------------
  * Replaces Wq/Wk Conv1d, the per-head einsum and the sigmoid of mrla_light_module.py:59-60,67,70. */
 int mrla_light_gate_fwd(const float* mom, const float* wq, const float* wk, int ksize, float* gate /*[b, c/d]*/,

@@ -170,7 +170,7 @@ __global__ __launch_bounds__(kThreads) void nhwc_moments_flat_kernel(const T* __
   const T* xp = x + ((size_t)b * HW + (size_t)sp * npix) * C + c0;
   const T* gp = MODE ? dy + ((size_t)b * HW + (size_t)sp * npix) * C + c0 : nullptr;
   float scv[VEC], shv[VEC];
-  if (MODE && relu) { ldf<VEC>(sc + c0, scv); ldf<VEC>(sh + c0, shv); }
+  if ((MODE == 1 && relu) || (MODE == 2 && sc)) { ldf<VEC>(sc + c0, scv); ldf<VEC>(sh + c0, shv); }
   else {
 #pragma unroll
     for (int i = 0; i < VEC; ++i) { scv[i] = 0.f; shv[i] = 0.f; }
@@ -182,7 +182,10 @@ __global__ __launch_bounds__(kThreads) void nhwc_moments_flat_kernel(const T* __
 #pragma unroll
     for (int i = 0; i < VEC; ++i) {
       if (MODE == 0) { s1[i] += xv[i]; s2[i] = fmaf(xv[i], xv[i], s2[i]); }
-      else {
+      else if (MODE == 2) {     // pooling of x_t = relu(round(sc*pre + sh) + o) for the inference path (x = pre, dy = o)
+        const float z = sc ? to_f(from_f<T>(fmaf(scv[i], xv[i], shv[i]))) : xv[i];
+        s1[i] += fmaxf(to_f(from_f<T>(z + gv[i])), 0.f);
+      } else {
         const float dz = (!relu || fmaf(scv[i], xv[i], shv[i]) > 0.f) ? dpb * gv[i] : 0.f;
         s1[i] += dz;
         s2[i] = fmaf(dz, xv[i], s2[i]);
@@ -217,6 +220,18 @@ __global__ __launch_bounds__(kThreads) void nhwc_moments_flat_kernel(const T* __
     for (int r = 0; r < ppi; ++r) sum += red[k][r * CW + ch];
     out[((size_t)bs * C + blockIdx.x * CW + ch) * 2 + k] = sum;
   }
+}
+
+// mom[b, c, slot 0 of 6] = sum over the nsplit partial rows of an image (the pooled x_t of the inference path)
+__global__ __launch_bounds__(kThreads) void nhwc_pool_finish_kernel(const float* __restrict__ part /*[b*ns, c, 2]*/,
+                                                                    float* __restrict__ mom /*[b, c, 6]*/, int BC, int C,
+                                                                    int ns) {
+  const int i = blockIdx.x * kThreads + threadIdx.x;
+  if (i >= BC) return;
+  const int b = i / C, c = i - b * C;
+  float s = 0.f;
+  for (int k = 0; k < ns; ++k) s += part[(((size_t)b * ns + k) * C + c) * 2];
+  mom[(size_t)i * 6] = s;
 }
 
 // Elementwise over the flat tensor; requires (kThreads * VEC) % C == 0 (then a thread's channels never change).
@@ -322,6 +337,24 @@ int launch_nhwc_moments(const void* x, const void* dy, const float* sc, const fl
                                sc, sh, relu, out, C, HW, ns);
   MRLA_DISPATCH_N(dtype, CALL)
 #undef CALL
+  return hip_status(hipGetLastError());
+}
+
+// mom[b,c,0] = sum_hw relu(round(sc*pre + sh) + o)  (sc null: relu(pre + o)); part: [b*nhwc_bn_splits, c, 2] workspace
+int launch_nhwc_pool_fused(const void* pre, const float* sc, const float* sh, const void* o, float* part, float* mom,
+                           int B, int C, int HW, int dtype, hipStream_t st) {
+  const int vec = 16 / (int)dtype_size(dtype);
+  const int cw = flat_cw(C, vec);
+  if (!cw) return MRLA_EUNSUPPORTED;
+  const int ns = nhwc_bn_splits(B, C, HW);
+  const dim3 fgrid(C / cw, B * ns);
+#define CALL(TT)                                                                                                 \
+  hipLaunchKernelGGL((nhwc_moments_flat_kernel<TT, 2>), fgrid, dim3(kThreads), 0, st, (const TT*)pre, (const TT*)o, \
+                     sc, sh, 0, (const float*)nullptr, part, C, HW, ns, cw);
+  MRLA_DISPATCH_N(dtype, CALL)
+#undef CALL
+  hipLaunchKernelGGL(nhwc_pool_finish_kernel, dim3((B * C + kThreads - 1) / kThreads), dim3(kThreads), 0, st, part, mom,
+                     B * C, C, ns);
   return hip_status(hipGetLastError());
 }
 

@@ -109,6 +109,26 @@ int mrla_light_stats_fwd_fused(const void* pre, const float* pre_sc, const float
                                      (hipStream_t)stream);
 }
 
+int mrla_light_pool_fused(const void* pre, const float* pre_sc, const float* pre_sh, const void* o_prev, float* part,
+                          float* mom, int b, int c, int h, int w, int dtype, int layout, void* stream) {
+  if (!pre || !o_prev || !part || !mom || bad_dims(b, c, h, w) || bad_dtype(dtype)) return MRLA_EINVAL;
+  if ((pre_sc == nullptr) != (pre_sh == nullptr)) return MRLA_EINVAL;
+  if (layout != MRLA_NHWC) return MRLA_EUNSUPPORTED;
+  return launch_nhwc_pool_fused(pre, pre_sc, pre_sh, o_prev, part, mom, b, c, h * w, dtype, (hipStream_t)stream);
+}
+
+int mrla_light_apply_fwd_fused(const void* pre, const float* pre_sc, const float* pre_sh, const void* o_prev,
+                               const float* wv, const float* gate, const float* sc, const float* sh, const float* lam,
+                               const float* dp, void* out, int b, int c, int h, int w, int d, int res, int dtype,
+                               int layout, void* stream) {
+  if (!pre || !o_prev || !wv || !gate || !out || bad_dims(b, c, h, w) || bad_dtype(dtype) || d <= 0 || c % d)
+    return MRLA_EINVAL;
+  if ((pre_sc == nullptr) != (pre_sh == nullptr) || (sc == nullptr) != (sh == nullptr)) return MRLA_EINVAL;
+  if (layout != MRLA_NHWC) return MRLA_EUNSUPPORTED;
+  return launch_light_apply_fwd_pre_nhwc(pre, o_prev, pre_sc, pre_sh, wv, gate, sc, sh, lam, dp, out, b, c, h, w, d, res,
+                                         dtype, (hipStream_t)stream);
+}
+
 int mrla_light_gate_fwd(const float* mom, const float* wq, const float* wk, int ksize, float* gate, int b, int c,
                         int hw, int d, void* stream) {
   if (!mom || !wq || !wk || !gate || b <= 0 || c <= 0 || hw <= 0 || d <= 0 || c % d || ksize <= 0 || !(ksize & 1))

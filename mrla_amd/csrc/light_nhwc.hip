@@ -191,6 +191,89 @@ __global__ __launch_bounds__(kMaxStrips * kWave) void light_apply_fwd_nhwc(
 }
 
 // ------------------------------------------------------------------------------------------------
+// inference form of the apply pass: x_t = relu(round(psc*pre + psh) + o) is formed on the fly from conv3's output and the
+// shortcut (it is neither needed again nor saved when no gradient is asked for), so the block tail moves 5N instead of 6N
+// elements:  pooling pass (bnact_nhwc.hip, reads pre and o) + this pass (reads pre and o, writes out).
+// ------------------------------------------------------------------------------------------------
+template <typename T, bool WIDE>
+__global__ __launch_bounds__(kMaxStrips * kWave) void light_apply_fwd_pre_nhwc(
+    const T* __restrict__ pre, const T* __restrict__ o, const float* __restrict__ psc, const float* __restrict__ psh,
+    const float* __restrict__ wv, const float* __restrict__ gate, const float* __restrict__ sc,
+    const float* __restrict__ sh, const float* __restrict__ lam, const float* __restrict__ dp, T* __restrict__ out, int B,
+    int C, int H, int W, int BG, int d, int res) {
+  MRLA_NHWC_PROLOGUE(0)
+  const int G = C / d;
+  float w0[9];
+#pragma unroll
+  for (int k = 0; k < 9; ++k) w0[k] = wv[cc * 9 + k];
+  const float scc = sc ? sc[cc] : 1.f, shc = sh ? sh[cc] : 0.f, lmc = lam ? lam[cc] : 0.f;
+  const float resf = res ? 1.f : 0.f;
+  const bool aff = psc != nullptr;
+  const float asc = aff ? psc[cc] : 1.f, ash = aff ? psh[cc] : 0.f;
+  const int b_end = min(B, (int)(blockIdx.y + 1) * BG);
+  for (int b = blockIdx.y * BG; b < b_end; ++b) {
+    const size_t ioff = (size_t)b * H * W * C;
+    const T* xi = pre + ioff;
+    const T* oi = o + ioff;
+    T* yo = out + ioff;
+    const float dpb = dp ? dp[b] : 1.f;
+    const float scale = dpb * scc;
+    const float A = scale * gate[(size_t)b * G + cc / d];
+    const float Bc = scale * lmc, Cc = dpb * shc;
+    float w[9];
+#pragma unroll
+    for (int k = 0; k < 9; ++k) w[k] = w0[k] * A;
+    w[4] += resf;
+    for (int s = wave; s < nstrips; s += nwaves) {
+      const int s0 = s * kS, nc = min(kS, W - s0);
+      const int lim = W - s0;
+      float ra[kS + 2], rb[kS + 2], rc[kS + 2];          // x_t rows r-1, r, r+1 on columns s0-1 .. s0+kS
+      float ob[kS + 2], oc[kS + 2];                      // o rows r, r+1
+      RowLoad<T, kS + 2> qx, qo;
+      RowAddr<T, kS + 2> ax;
+      if (WIDE) {
+        make_row_addr<T, kS + 2>(ax, s0 - 1, W, C, cbase, lane);
+        issue_row<T, kS + 2>(qx, xi, 0, H, W * C, ax);
+        issue_row<T, kS + 2>(qo, oi, 0, H, W * C, ax);
+      }
+      auto form_row = [&](int r, float (&dst)[kS + 2], float (&odst)[kS + 2]) {
+        if (WIDE) {
+          finish_row<T, kS + 2>(qx, lane, SCR(0), dst);
+          finish_row<T, kS + 2>(qo, lane, SCR(1), odst);
+          issue_row<T, kS + 2>(qx, xi, r + 1, H, W * C, ax);
+          issue_row<T, kS + 2>(qo, oi, r + 1, H, W * C, ax);
+        } else {
+          read_row<T, false, kS + 2>(xi, r, s0 - 1, H, W, C, cbase, cc, lane, SCR(0), dst);
+          read_row<T, false, kS + 2>(oi, r, s0 - 1, H, W, C, cbase, cc, lane, SCR(1), odst);
+        }
+        if (aff) {
+          const bool rowok = r >= 0 && r < H;
+#pragma unroll
+          for (int j = 0; j < kS + 2; ++j) {
+            const bool ok = rowok && (j == 0 ? s0 > 0 : j <= lim);
+            dst[j] = ok ? to_f(from_f<T>(fmaf(asc, dst[j], ash))) : 0.f;
+          }
+        }
+#pragma unroll
+        for (int j = 0; j < kS + 2; ++j) dst[j] = fmaxf(to_f(from_f<T>(dst[j] + odst[j])), 0.f);
+      };
+#pragma unroll
+      for (int j = 0; j < kS + 2; ++j) ra[j] = 0.f;
+      form_row(0, rb, ob);
+      for (int r = 0; r < H; ++r) {
+        form_row(r + 1, rc, oc);
+        float y[kS];
+#pragma unroll
+        for (int j = 0; j < kS; ++j) y[j] = fmaf(Bc, ob[j + 1], conv_at(w, ra, rb, rc, j) + Cc);
+        write_row<T, WIDE, kS>(yo, r, s0, nc, W, C, cbase, c, cv, lane, SCR(3), y);
+#pragma unroll
+        for (int j = 0; j < kS + 2; ++j) { ra[j] = rb[j]; rb[j] = rc[j]; ob[j] = oc[j]; }
+      }
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
 // backward statistics
 // ------------------------------------------------------------------------------------------------
 template <typename T, bool GELU, bool HAS_O, bool WIDE>
@@ -297,6 +380,29 @@ int launch_light_apply_fwd_nhwc(const void* x, const void* o, const float* wv, c
   }
 #define CALL(T, A, O) { if (L.wide) CALL_W(T, A, O, true) else CALL_W(T, A, O, false) }
   MRLA_DISPATCH_T_N(dtype, act, o != nullptr, CALL)
+#undef CALL
+#undef CALL_W
+  return hip_status(hipGetLastError());
+}
+
+int launch_light_apply_fwd_pre_nhwc(const void* pre, const void* o, const float* psc, const float* psh, const float* wv,
+                                    const float* gate, const float* sc, const float* sh, const float* lam,
+                                    const float* dp, void* out, int B, int C, int H, int W, int d, int res, int dtype,
+                                    hipStream_t st) {
+  const NhwcLaunch L = nhwc_launch(B, C, W, 0, dtype);
+#define CALL_W(T, WD)                                                                                                 \
+  {                                                                                                                   \
+    if (set_lds_n(light_apply_fwd_pre_nhwc<T, WD>, L.lds) != hipSuccess) return MRLA_EHIP;                              \
+    hipLaunchKernelGGL((light_apply_fwd_pre_nhwc<T, WD>), L.grid, L.block, L.lds, st, (const T*)pre, (const T*)o, psc, \
+                       psh, wv, gate, sc, sh, lam, dp, (T*)out, B, C, H, W, L.BG, d, res);                            \
+  }
+#define CALL(T) { if (L.wide) CALL_W(T, true) else CALL_W(T, false) }
+  switch (dtype) {
+    case MRLA_F32:  CALL(float) break;
+    case MRLA_BF16: CALL(bf16_t) break;
+    case MRLA_F16:  CALL(f16_t) break;
+    default: return MRLA_EINVAL;
+  }
 #undef CALL
 #undef CALL_W
   return hip_status(hipGetLastError());

@@ -143,6 +143,12 @@ int launch_light_apply_bwd_nhwc(const void* dout, const void* x, const void* o, 
                                 void* dprev, float* dwv_part, int B, int C, int H, int W, int d, int res, int relu,
                                 int dtype, int act, hipStream_t st);
 int nhwc_bn_splits(int B, int C, int HW);
+int launch_nhwc_pool_fused(const void* pre, const float* sc, const float* sh, const void* o, float* part, float* mom,
+                           int B, int C, int HW, int dtype, hipStream_t st);
+int launch_light_apply_fwd_pre_nhwc(const void* pre, const void* o, const float* psc, const float* psh, const float* wv,
+                                    const float* gate, const float* sc, const float* sh, const float* lam,
+                                    const float* dp, void* out, int B, int C, int H, int W, int d, int res, int dtype,
+                                    hipStream_t st);
 int launch_nhwc_moments(const void* x, const void* dy, const float* sc, const float* sh, int relu, const float* dp,
                         float* out, int B, int C, int HW, int dtype, int mode, hipStream_t st);
 int launch_nhwc_affine(const void* x, const void* dy, const float* a, const float* sc, const float* sh, int relu,

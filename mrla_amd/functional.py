@@ -99,11 +99,12 @@ def _layout_of(x, want=None):
 class LightConfig:
     """Static configuration of one MRLA-light call.  fuse: the first tensor argument is the block's pre-activation
     and x_t = relu(pre + o_prev) is formed inside the statistics kernel (resnet_mrla_light.py:113-114 folded in)."""
-    __slots__ = ("d", "bn_mode", "momentum", "eps", "res", "act", "fuse", "pre_affine")
+    __slots__ = ("d", "bn_mode", "momentum", "eps", "res", "act", "fuse", "pre_affine", "infer")
 
     def __init__(self, d, bn_mode=L.BN_NONE, momentum=0.1, eps=1e-5, res=0, act=L.ACT_NONE, fuse=False, pre_affine=None):
         self.d, self.bn_mode, self.momentum, self.eps, self.res, self.act = d, bn_mode, momentum, eps, res, act
         self.pre_affine = pre_affine     # (scale[c], shift[c]) fp32 of a deferred BatchNorm in front of the fused producer
+        self.infer = False               # nothing will be differentiated (set by mrla_light from the autograd state)
         self.fuse = fuse
 
 
@@ -138,9 +139,33 @@ class _LightFn(torch.autograd.Function):
         st = _stream()
 
         mom = torch.empty((b, c, L.FWD_MOMENTS), dtype=torch.float32, device=dev)
+        if cfg.fuse and (oc is None or cfg.act != L.ACT_NONE):
+            raise L.MrlaHipError("the fused relu(pre + o_prev) producer needs o_prev and no activation on V")
+        # inference form: nothing will be differentiated and bn_mrla does not need the batch statistics of m, so x_t is
+        # neither materialised nor saved (pooling pass + an apply pass that re-forms x_t: 5N instead of 6N elements)
+        if (cfg.fuse and layout == L.NHWC and cfg.bn_mode != L.BN_TRAIN and c % 64 == 0
+                and cfg.infer):
+            psc, psh = cfg.pre_affine if cfg.pre_affine is not None else (None, None)
+            rows = L.load().mrla_bn_moment_rows(b, c, h, w, layout)
+            part = torch.empty((rows, c, 2), dtype=torch.float32, device=dev)
+            _call("mrla_light_pool_fused", xc.numel() * xc.element_size() * 2, _ptr(xc), _ptr(psc), _ptr(psh), _ptr(oc),
+                  _ptr(part), _ptr(mom), b, c, h, w, dt, layout, st)
+            gate = torch.empty((b, G), dtype=torch.float32, device=dev)
+            L.call("mrla_light_gate_fwd", _ptr(mom), _ptr(wq32), _ptr(wk32), ks, _ptr(gate), b, c, h * w, d, st)
+            bnbuf = None
+            if cfg.bn_mode != L.BN_NONE:
+                gamma32, beta32 = _f32(gamma), _f32(beta)
+                bnbuf = torch.empty((4, c), dtype=torch.float32, device=dev)
+                L.call("mrla_light_bn_fwd", _ptr(mom), _ptr(gate), _ptr(lam32), _ptr(gamma32), _ptr(beta32),
+                       _ptr(running_mean), _ptr(running_var), cfg.bn_mode, float(cfg.momentum), float(cfg.eps),
+                       _ptr(bnbuf[0]), _ptr(bnbuf[1]), _ptr(bnbuf[2]), _ptr(bnbuf[3]), b, c, h * w, d, st)
+            out = torch.empty_like(xc)
+            _call("mrla_light_apply_fwd_fused", xc.numel() * xc.element_size() * 3, _ptr(xc), _ptr(psc), _ptr(psh),
+                  _ptr(oc), _ptr(wv32), _ptr(gate), _ptr(bnbuf[0]) if bnbuf is not None else None,
+                  _ptr(bnbuf[1]) if bnbuf is not None else None, _ptr(lam32), _ptr(dp32), _ptr(out), b, c, h, w, d,
+                  cfg.res, dt, layout, st)
+            return out
         if cfg.fuse:
-            if oc is None or cfg.act != L.ACT_NONE:
-                raise L.MrlaHipError("the fused relu(pre + o_prev) producer needs o_prev and no activation on V")
             pre, xc = xc, torch.empty_like(xc)
             psc, psh = cfg.pre_affine if cfg.pre_affine is not None else (None, None)
             _call("mrla_light_stats_fwd_fused", xc.numel() * xc.element_size() * 3, _ptr(pre), _ptr(psc), _ptr(psh),
@@ -234,12 +259,18 @@ def mrla_light(x, wq, wk, wv, d, o_prev=None, lam=None, bn=None, dp=None, res=Fa
     pre_affine = getattr(x, "_mrla_affine", None)
     if pre_affine is not None and not pre_activation:
         raise L.MrlaHipError("a deferred BatchNorm output can only feed the fused producer (pre_activation=True)")
+    tensors = [t for t in (x, o_prev, wq, wk, wv, lam) if t is not None]
+    if bn is not None:
+        tensors += [bn["weight"], bn["bias"]]
+    infer = not (torch.is_grad_enabled() and any(t.requires_grad for t in tensors))
     if bn is None:
         cfg = LightConfig(d, L.BN_NONE, res=int(res), act=L.ACT_GELU if act_gelu else L.ACT_NONE, fuse=pre_activation,
                           pre_affine=pre_affine)
+        cfg.infer = infer
         return _LightFn.apply(x, o_prev, wq, wk, wv, lam, None, None, None, None, dp, cfg)
     cfg = LightConfig(d, L.BN_TRAIN if bn["training"] else L.BN_EVAL, bn.get("momentum", 0.1), bn.get("eps", 1e-5),
                       int(res), L.ACT_GELU if act_gelu else L.ACT_NONE, fuse=pre_activation, pre_affine=pre_affine)
+    cfg.infer = infer
     return _LightFn.apply(x, o_prev, wq, wk, wv, lam, bn["weight"], bn["bias"], bn["running_mean"], bn["running_var"],
                           dp, cfg)
 

@@ -117,3 +117,49 @@ def test_deferred_bn_output_is_refused_outside_the_fused_producer():
     pre = bn_act(x, bn, relu=False, defer=True)
     with pytest.raises(MrlaHipError):
         mrla_light(pre, torch.randn(1, 1, 3).cuda(), torch.randn(1, 1, 3).cuda(), torch.randn(64, 1, 3, 3).cuda(), 32)
+
+
+@pytest.mark.parametrize("shape", [(2, 64, 9, 6), (2, 128, 5, 61), (1, 256, 12, 75), (4, 256, 56, 56), (3, 2048, 7, 7)],
+                         ids=lambda s: "x".join(map(str, s)))
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16], ids=["fp32", "bf16"])
+@pytest.mark.parametrize("with_bn3", [True, False], ids=["bn3-deferred", "plain-pre"])
+def test_inference_form_of_the_fused_tail_matches_the_training_form(shape, dtype, with_bn3):
+    """no_grad + eval BatchNorm on channels_last: x_t is not materialised (pooling pass + an apply pass that re-forms it).
+    Same result as the two-pass form that saves x_t, up to the summation order of the pooled sums."""
+    from mrla_amd.functional import bn_act, mrla_light
+    b, c, h, w = shape
+    torch.manual_seed(11)
+    mk = lambda *s: torch.randn(*s, device="cuda")
+    cl = lambda t: t.to(dtype).contiguous(memory_format=torch.channels_last)
+    conv_out, idn = cl(mk(b, c, h, w)), cl(mk(b, c, h, w))
+    k = 3 if c == 64 else (7 if c == 2048 else 5)
+    wq, wk, wv, lam = mk(1, 1, k) * 0.5, mk(1, 1, k) * 0.5, mk(c, 1, 3, 3) * 0.3, mk(c, 1, 1)
+    bn3, bnm = torch.nn.BatchNorm2d(c).cuda().eval(), torch.nn.BatchNorm2d(c).cuda().eval()
+    with torch.no_grad():
+        for bn in (bn3, bnm):
+            bn.weight.copy_(torch.linspace(0.5, 1.5, c)); bn.bias.copy_(torch.linspace(-0.3, 0.3, c))
+            bn.running_mean.copy_(torch.linspace(-0.2, 0.2, c)); bn.running_var.copy_(torch.linspace(0.8, 1.2, c))
+    bnargs = dict(weight=bnm.weight, bias=bnm.bias, running_mean=bnm.running_mean, running_var=bnm.running_var,
+                  training=False, momentum=0.1, eps=1e-5)
+
+    def tail(xin):
+        pre = bn_act(xin, bn3, relu=False, defer=True) if with_bn3 else xin
+        return mrla_light(pre, wq, wk, wv, 32, o_prev=idn, lam=lam, bn=bnargs, res=True, pre_activation=True)
+
+    from mrla_amd import functional as Fm
+    Fm.TIMER = timer = Fm.KernelTimer(["mrla_light_pool_fused", "mrla_light_apply_fwd_fused", "mrla_light_stats_fwd_fused"])
+    try:
+        with torch.no_grad():
+            got = tail(conv_out)
+        names = {rec[0] for rec in timer.records}
+    finally:
+        Fm.TIMER = None
+    assert names == {"mrla_light_pool_fused", "mrla_light_apply_fwd_fused"}, names      # the inference form did run
+    want = tail(conv_out.clone().requires_grad_(True)).detach()          # needs a gradient: the x_t-saving form
+    torch.cuda.synchronize()
+    a, r = got.float(), want.float()
+    if dtype == torch.float32:
+        assert (a - r).abs().max().item() <= 2e-5 * r.abs().max().item()
+    else:
+        bad = (a - r).abs() > 2.0 ** -7 * (r.abs() + 0.05 * r.abs().max())
+        assert bad.float().mean().item() < 1e-4

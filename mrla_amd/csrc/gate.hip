@@ -10,7 +10,8 @@
 
 namespace mrla {
 
-constexpr int kBnCh = 16;                    // channels per workgroup in the per-channel kernels
+constexpr int kBnCh = 4;                     // channels per workgroup in the per-channel kernels (more, smaller workgroups:
+                                             // C/4 of them, 64 image lanes each -- these kernels are latency-bound)
 constexpr int kBnLanes = kThreads / kBnCh;   // images summed in parallel per channel
 
 // ------------------------------------------------------------------------------------------------

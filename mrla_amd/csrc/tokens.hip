@@ -13,6 +13,8 @@
 // token_stats_bwd, token_apply_bwd (per image x 64-channel chunk: the normalised map lives in LDS as fp32,
 // lanes = channels so the 3x3 neighbours are plain LDS reads), token_ln_bwd (per token: both LayerNorm backward
 // passes).  The permutes / split / cat of the reference never touch memory: they are index arithmetic here.
+#include <algorithm>
+
 #include "mrla_device.h"
 #include "mrla_kernels.h"
 
@@ -24,50 +26,65 @@ enum { S_MX = 0, S_RX = 1, S_MO = 2, S_RO = 3, S_N = 4 };
 enum { Q_WV = 0, Q_LAM = 9, Q_LNXW = 10, Q_LNXB = 11, Q_LNOW = 12, Q_LNOB = 13, Q_N = 14 };
 
 // ------------------------------------------------------------------------------------------------
-// per image: LayerNorm statistics of x and o, pooled descriptor of LN_x(x) over the map tokens
+// LayerNorm statistics of x and o (one wave per token, the row held in registers between the two passes of the
+// two-pass variance), then the pooled descriptor of LN_x(x) over the map tokens (one thread per channel)
 // ------------------------------------------------------------------------------------------------
+constexpr int kTokRowRegs = 16;      // channels per lane held in registers: C <= 64 * 16
+
 template <typename T>
-__global__ __launch_bounds__(kThreads) void token_norm_pool_kernel(
-    const T* __restrict__ x, const T* __restrict__ o, const float* __restrict__ wx, const float* __restrict__ bx,
-    float eps, float* __restrict__ stats, float* __restrict__ mom, int n, int C) {
-  extern __shared__ float ysum[];     // [kWaves][C]
-  const int b = blockIdx.x, tid = threadIdx.x, lane = tid & (kWave - 1), wave = tid / kWave;
-  for (int i = tid; i < kWaves * C; i += kThreads) ysum[i] = 0.f;
-  __syncthreads();
+__global__ __launch_bounds__(kThreads) void token_stats_kernel(const T* __restrict__ x, const T* __restrict__ o, float eps,
+                                                               float* __restrict__ stats, int ntok, int C) {
+  const int lane = threadIdx.x & (kWave - 1), wave = threadIdx.x / kWave;
   const float invc = 1.0f / (float)C;
-  for (int i = wave; i < n; i += kWaves) {
-    const T* xr = x + ((size_t)b * n + i) * C;
-    const T* orow = o + ((size_t)b * n + i) * C;
+  for (int tok = blockIdx.x * kWaves + wave; tok < ntok; tok += gridDim.x * kWaves) {
+    const T* xr = x + (size_t)tok * C;
+    const T* orow = o + (size_t)tok * C;
+    float xv[kTokRowRegs], ov[kTokRowRegs];
     float sx = 0.f, so = 0.f;
-    for (int c = lane; c < C; c += kWave) { sx += to_f(xr[c]); so += to_f(orow[c]); }
-    sx = wave_sum(sx); so = wave_sum(so);
-    const float mx = __shfl(sx, 0, kWave) * invc, mo = __shfl(so, 0, kWave) * invc;
+#pragma unroll
+    for (int k = 0; k < kTokRowRegs; ++k) {
+      const int c = lane + k * kWave;
+      xv[k] = c < C ? to_f(xr[c]) : 0.f;
+      ov[k] = c < C ? to_f(orow[c]) : 0.f;
+      sx += xv[k]; so += ov[k];
+    }
+    const float mx = wave_sum(sx) * invc, mo = wave_sum(so) * invc;
     float vx = 0.f, vo = 0.f;
-    for (int c = lane; c < C; c += kWave) {
-      const float dxv = to_f(xr[c]) - mx, dov = to_f(orow[c]) - mo;
+#pragma unroll
+    for (int k = 0; k < kTokRowRegs; ++k) {
+      const bool in = lane + k * kWave < C;
+      const float dxv = in ? xv[k] - mx : 0.f, dov = in ? ov[k] - mo : 0.f;
       vx = fmaf(dxv, dxv, vx);
       vo = fmaf(dov, dov, vo);
     }
-    vx = wave_sum(vx); vo = wave_sum(vo);
-    const float rx = rsqrtf(__shfl(vx, 0, kWave) * invc + eps), ro = rsqrtf(__shfl(vo, 0, kWave) * invc + eps);
-    if (lane == 0) {
-      float* s = stats + ((size_t)b * n + i) * S_N;
-      s[S_MX] = mx; s[S_RX] = rx; s[S_MO] = mo; s[S_RO] = ro;
-    }
-    if (i >= 1)
-      for (int c = lane; c < C; c += kWave) ysum[wave * C + c] += (to_f(xr[c]) - mx) * rx;
+    const float rx = rsqrtf(wave_sum(vx) * invc + eps), ro = rsqrtf(wave_sum(vo) * invc + eps);
+    if (lane == 0) *reinterpret_cast<float4*>(stats + (size_t)tok * S_N) = make_float4(mx, rx, mo, ro);
   }
-  __syncthreads();
-  const float hw = (float)(n - 1);
-  for (int c = tid; c < C; c += kThreads) {
-    float s = 0.f;
-#pragma unroll
-    for (int w = 0; w < kWaves; ++w) s += ysum[w * C + c];
-    float* m = mom + ((size_t)b * C + c) * M_N;
-    // slot 0 holds hw * y so that the shared gate kernels' y = Sx / hw is the LN-affine pooled value
-    m[M_SX] = fmaf(wx[c], s, bx[c] * hw);
-    m[M_SV] = 0.f; m[M_SO] = 0.f; m[M_SVV] = 0.f; m[M_SVO] = 0.f; m[M_SOO] = 0.f;
+}
+
+// mom[b,c,0] = wx[c] * sum_{i>=1} (x[b,i,c] - mean_i) * rstd_i + (n-1) * bx[c]   (other slots 0).  grid (C/64.., b)
+template <typename T>
+__global__ __launch_bounds__(kWave) void token_pool_kernel(const T* __restrict__ x, const float* __restrict__ stats,
+                                                           const float* __restrict__ wx, const float* __restrict__ bx,
+                                                           float* __restrict__ mom, int n, int C) {
+  const int b = blockIdx.y, c = blockIdx.x * kWave + threadIdx.x;
+  if (c >= C) return;
+  const T* xb = x + (size_t)b * n * C + c;
+  const float* sb = stats + (size_t)b * n * S_N;
+  float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;          // four independent chains, summed in a fixed order
+  int i = 1;
+  for (; i + 3 < n; i += 4) {
+    s0 = fmaf(to_f(xb[(size_t)i * C]) - sb[i * S_N + S_MX], sb[i * S_N + S_RX], s0);
+    s1 = fmaf(to_f(xb[(size_t)(i + 1) * C]) - sb[(i + 1) * S_N + S_MX], sb[(i + 1) * S_N + S_RX], s1);
+    s2 = fmaf(to_f(xb[(size_t)(i + 2) * C]) - sb[(i + 2) * S_N + S_MX], sb[(i + 2) * S_N + S_RX], s2);
+    s3 = fmaf(to_f(xb[(size_t)(i + 3) * C]) - sb[(i + 3) * S_N + S_MX], sb[(i + 3) * S_N + S_RX], s3);
   }
+  for (; i < n; ++i) s0 = fmaf(to_f(xb[(size_t)i * C]) - sb[i * S_N + S_MX], sb[i * S_N + S_RX], s0);
+  const float s = (s0 + s1) + (s2 + s3);
+  float* m = mom + ((size_t)b * C + c) * M_N;
+  // slot 0 holds hw * y so that the shared gate kernels' y = Sx / hw is the LN-affine pooled value
+  m[M_SX] = fmaf(wx[c], s, bx[c] * (float)(n - 1));
+  m[M_SV] = 0.f; m[M_SO] = 0.f; m[M_SVV] = 0.f; m[M_SVO] = 0.f; m[M_SOO] = 0.f;
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -353,11 +370,14 @@ static hipError_t set_lds3(K kernel, size_t bytes) {
 
 int launch_token_norm_pool(const void* x, const void* o, const float* wx, const float* bx, float eps, float* stats,
                            float* mom, int B, int n, int C, int dtype, hipStream_t st) {
-  const size_t lds = (size_t)kWaves * C * sizeof(float);
-  if (lds > 64 * 1024) return MRLA_EUNSUPPORTED;
-#define CALL(TT)                                                                                              \
-  hipLaunchKernelGGL((token_norm_pool_kernel<TT>), dim3(B), dim3(kThreads), lds, st, (const TT*)x, (const TT*)o, \
-                     wx, bx, eps, stats, mom, n, C);
+  if (C > kWave * kTokRowRegs) return MRLA_EUNSUPPORTED;
+  const int ntok = B * n;
+  const int wgs = std::max(1, std::min((ntok + kWaves - 1) / kWaves, 256 * 32));
+#define CALL(TT)                                                                                                     \
+  hipLaunchKernelGGL((token_stats_kernel<TT>), dim3(wgs), dim3(kThreads), 0, st, (const TT*)x, (const TT*)o, eps, stats, \
+                     ntok, C);                                                                                       \
+  hipLaunchKernelGGL((token_pool_kernel<TT>), dim3((C + kWave - 1) / kWave, B), dim3(kWave), 0, st, (const TT*)x, stats, \
+                     wx, bx, mom, n, C);
   MRLA_DISPATCH_TT(dtype, CALL)
 #undef CALL
   return hip_status(hipGetLastError());

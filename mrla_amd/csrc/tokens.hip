@@ -88,36 +88,59 @@ __global__ __launch_bounds__(kWave) void token_pool_kernel(const T* __restrict__
 }
 
 // ------------------------------------------------------------------------------------------------
-// shared tile code: normalised map of one (image, channel chunk) in LDS, fp32, layout [hw][CC]
+// shared tile code: normalised map of one (image, channel chunk) in LDS, fp32, ZERO-PADDED by one pixel on every side:
+// layout [(side+2)][(side+2)][CC], so the nine taps need no edge test.  A thread walks tokens i = tg, tg+ntg, ...; its
+// (row, column) is advanced without divisions by TokenPos.
 // ------------------------------------------------------------------------------------------------
-template <typename T>
-__device__ __forceinline__ void load_xn_tile(float* __restrict__ tile, const T* __restrict__ x,
-                                             const float* __restrict__ stats, const float* __restrict__ wx,
-                                             const float* __restrict__ bx, int b, int n, int C, int c0, int CC, int tid) {
-  const int hw = n - 1;
-  const int cc = tid % CC, tg = tid / CC, ntg = kThreads / CC;      // lanes = channels: coalesced along c
-  const float w = wx[c0 + cc], bb = bx[c0 + cc];
-  for (int i = tg; i < hw; i += ntg) {
-    const float2 s = *reinterpret_cast<const float2*>(stats + ((size_t)b * n + i + 1) * S_N);   // (mean, rstd): uniform per row
-    const float xv = to_f(x[((size_t)b * n + i + 1) * C + c0 + cc]);
-    tile[i * CC + cc] = fmaf((xv - s.x) * s.y, w, bb);
+__device__ __forceinline__ int tile_elems(int side, int CC) { return (side + 2) * (side + 2) * CC; }
+
+struct TokenPos {
+  int r, col, step_r, step_c, side;
+  __device__ __forceinline__ TokenPos(int first, int stride, int side_) : side(side_) {
+    r = first / side_; col = first - r * side_;
+    step_r = stride / side_; step_c = stride - step_r * side_;
+  }
+  __device__ __forceinline__ void advance() {
+    r += step_r; col += step_c;
+    if (col >= side) { col -= side; ++r; }
+  }
+  // index of the pixel in the padded tile (channels innermost, CC of them)
+  __device__ __forceinline__ int at(int CC, int cc) const { return ((r + 1) * (side + 2) + col + 1) * CC + cc; }
+};
+
+__device__ __forceinline__ void zero_tile_border(float* __restrict__ tile, int side, int CC, int tid) {
+  const int P = side + 2;
+  for (int k = tid; k < 4 * P * CC; k += kThreads) {          // two rows and two columns of P pixels each
+    const int which = k / (P * CC), rem = k - which * P * CC, p = rem / CC, cc = rem - p * CC;
+    const int pix = which == 0 ? p : which == 1 ? (P - 1) * P + p : which == 2 ? p * P : p * P + P - 1;
+    tile[pix * CC + cc] = 0.f;
   }
 }
 
-__device__ __forceinline__ float conv9_tile(const float* __restrict__ tile, const float (&w)[9], int r, int col,
-                                            int side, int CC, int cc) {
-  float u = 0.f;
-#pragma unroll
-  for (int di = -1; di <= 1; ++di) {
-    const int rr = r + di;
-    if (rr < 0 || rr >= side) continue;
-#pragma unroll
-    for (int dj = -1; dj <= 1; ++dj) {
-      const int c2 = col + dj;
-      if (c2 < 0 || c2 >= side) continue;
-      u = fmaf(w[(di + 1) * 3 + dj + 1], tile[(rr * side + c2) * CC + cc], u);
-    }
+template <typename T>
+__device__ __forceinline__ void load_xn_tile(float* __restrict__ tile, const T* __restrict__ x,
+                                             const float* __restrict__ stats, const float* __restrict__ wx,
+                                             const float* __restrict__ bx, int b, int n, int C, int c0, int CC, int side,
+                                             int tid) {
+  const int hw = n - 1;
+  const int cc = tid % CC, tg = tid / CC, ntg = kThreads / CC;      // lanes = channels: coalesced along c
+  const float w = wx[c0 + cc], bb = bx[c0 + cc];
+  zero_tile_border(tile, side, CC, tid);
+  TokenPos pos(tg, ntg, side);
+  for (int i = tg; i < hw; i += ntg, pos.advance()) {
+    const float2 s = *reinterpret_cast<const float2*>(stats + ((size_t)b * n + i + 1) * S_N);   // (mean, rstd): uniform per row
+    const float xv = to_f(x[((size_t)b * n + i + 1) * C + c0 + cc]);
+    tile[pos.at(CC, cc)] = fmaf((xv - s.x) * s.y, w, bb);
   }
+}
+
+// sum_k w[k] * tile[centre + offset_k]: `centre` = TokenPos::at(), rs = (side + 2) * CC
+__device__ __forceinline__ float conv9_tile(const float* __restrict__ tile, const float (&w)[9], int centre, int rs, int CC) {
+  const float* t = tile + centre;
+  float u = w[0] * t[-rs - CC];
+  u = fmaf(w[1], t[-rs], u); u = fmaf(w[2], t[-rs + CC], u);
+  u = fmaf(w[3], t[-CC], u); u = fmaf(w[4], t[0], u); u = fmaf(w[5], t[CC], u);
+  u = fmaf(w[6], t[rs - CC], u); u = fmaf(w[7], t[rs], u); u = fmaf(w[8], t[rs + CC], u);
   return u;
 }
 
@@ -133,18 +156,19 @@ __global__ __launch_bounds__(kThreads) void token_apply_fwd_kernel(
   extern __shared__ float tile[];
   const int b = blockIdx.y, c0 = blockIdx.x * CC, tid = threadIdx.x;
   const int hw = n - 1;
-  load_xn_tile(tile, x, stats, wx, bx, b, n, C, c0, CC, tid);
+  load_xn_tile(tile, x, stats, wx, bx, b, n, C, c0, CC, side, tid);
   __syncthreads();
   const int cc = tid % CC, tg = tid / CC, ntg = kThreads / CC;
   const int c = c0 + cc;
+  const int rs = (side + 2) * CC;
   float w[9];
 #pragma unroll
   for (int k = 0; k < 9; ++k) w[k] = wv[c * 9 + k];
   const float a = gate[(size_t)b * (C / d) + c / d];
   const float lm = lam[c], wo_c = wo[c], bo_c = bo[c];
-  for (int i = tg; i < hw; i += ntg) {
-    const int r = i / side, col = i - r * side;
-    const float u = conv9_tile(tile, w, r, col, side, CC, cc);
+  TokenPos pos(tg, ntg, side);
+  for (int i = tg; i < hw; i += ntg, pos.advance()) {
+    const float u = conv9_tile(tile, w, pos.at(CC, cc), rs, CC);
     const size_t g = ((size_t)b * n + i + 1) * C + c;
     const float* s = stats + ((size_t)b * n + i + 1) * S_N;
     const float on = fmaf((to_f(o[g]) - s[S_MO]) * s[S_RO], wo_c, bo_c);
@@ -171,20 +195,21 @@ __global__ __launch_bounds__(kThreads) void token_stats_bwd_kernel(
     const float* __restrict__ wx, const float* __restrict__ bx, const float* __restrict__ wv,
     float* __restrict__ bmom, int n, int C, int side, int CC) {
   extern __shared__ float tile[];
-  float* red = tile + (n - 1) * CC;       // [ntg][CC]
+  float* red = tile + tile_elems(side, CC);       // [ntg][CC]
   const int b = blockIdx.y, c0 = blockIdx.x * CC, tid = threadIdx.x;
   const int hw = n - 1;
-  load_xn_tile(tile, x, stats, wx, bx, b, n, C, c0, CC, tid);
+  load_xn_tile(tile, x, stats, wx, bx, b, n, C, c0, CC, side, tid);
   __syncthreads();
   const int cc = tid % CC, tg = tid / CC, ntg = kThreads / CC;
   const int c = c0 + cc;
+  const int rs = (side + 2) * CC;
   float w[9];
 #pragma unroll
   for (int k = 0; k < 9; ++k) w[k] = wv[c * 9 + k];
   float acc = 0.f;
-  for (int i = tg; i < hw; i += ntg) {
-    const int r = i / side, col = i - r * side;
-    const float u = conv9_tile(tile, w, r, col, side, CC, cc);
+  TokenPos pos(tg, ntg, side);
+  for (int i = tg; i < hw; i += ntg, pos.advance()) {
+    const float u = conv9_tile(tile, w, pos.at(CC, cc), rs, CC);
     acc = fmaf(to_f(dout[((size_t)b * n + i + 1) * C + c]), gelu_f(u), acc);
   }
   red[tg * CC + cc] = acc;
@@ -209,13 +234,15 @@ __global__ __launch_bounds__(kThreads) void token_apply_bwd_kernel(
     float* __restrict__ part /*[b,c,Q_N]*/, int n, int C, int side, int d, int CC) {
   extern __shared__ float tile[];
   const int hw = n - 1;
-  float* dus = tile + hw * CC;            // [hw][CC] dU
-  float* red = dus + hw * CC;             // [ntg][CC][Q_N]
+  float* dus = tile + tile_elems(side, CC);          // dU, same padded layout
+  float* red = dus + tile_elems(side, CC);           // [ntg][CC][Q_N]
   const int b = blockIdx.y, c0 = blockIdx.x * CC, tid = threadIdx.x;
-  load_xn_tile(tile, x, stats, wx, bx, b, n, C, c0, CC, tid);
+  load_xn_tile(tile, x, stats, wx, bx, b, n, C, c0, CC, side, tid);
+  zero_tile_border(dus, side, CC, tid);
   __syncthreads();
   const int cc = tid % CC, tg = tid / CC, ntg = kThreads / CC;
   const int c = c0 + cc;
+  const int rs = (side + 2) * CC;
   float w[9];
 #pragma unroll
   for (int k = 0; k < 9; ++k) w[k] = wv[c * 9 + k];
@@ -224,54 +251,47 @@ __global__ __launch_bounds__(kThreads) void token_apply_bwd_kernel(
   float q[Q_N];
 #pragma unroll
   for (int k = 0; k < Q_N; ++k) q[k] = 0.f;
-  for (int i = tg; i < hw; i += ntg) {
-    const int r = i / side, col = i - r * side;
-    const float u = conv9_tile(tile, w, r, col, side, CC, cc);
-    const size_t g = ((size_t)b * n + i + 1) * C + c;
-    const float go = to_f(dout[g]);
-    const float du = a * go * gelu_grad_f(u);
-    dus[i * CC + cc] = du;
-    const float* s = stats + ((size_t)b * n + i + 1) * S_N;
-    const float ohat = (to_f(o[g]) - s[S_MO]) * s[S_RO];
-    q[Q_LAM] = fmaf(go, fmaf(ohat, wo_c, bo_c), q[Q_LAM]);
-    q[Q_LNOW] = fmaf(lm * go, ohat, q[Q_LNOW]);
-    q[Q_LNOB] = fmaf(lm, go, q[Q_LNOB]);
-    // dWv[di][dj] += dU[i] * xn[i + (di, dj)]
-#pragma unroll
-    for (int di = -1; di <= 1; ++di) {
-      const int rr = r + di;
-      if (rr < 0 || rr >= side) continue;
-#pragma unroll
-      for (int dj = -1; dj <= 1; ++dj) {
-        const int c2 = col + dj;
-        if (c2 < 0 || c2 >= side) continue;
-        q[Q_WV + (di + 1) * 3 + dj + 1] = fmaf(du, tile[(rr * side + c2) * CC + cc], q[Q_WV + (di + 1) * 3 + dj + 1]);
-      }
+  {
+    TokenPos pos(tg, ntg, side);
+    for (int i = tg; i < hw; i += ntg, pos.advance()) {
+      const int ctr = pos.at(CC, cc);
+      const float u = conv9_tile(tile, w, ctr, rs, CC);
+      const size_t g = ((size_t)b * n + i + 1) * C + c;
+      const float go = to_f(dout[g]);
+      const float du = a * go * gelu_grad_f(u);
+      dus[ctr] = du;
+      const float* s = stats + ((size_t)b * n + i + 1) * S_N;
+      const float ohat = (to_f(o[g]) - s[S_MO]) * s[S_RO];
+      q[Q_LAM] = fmaf(go, fmaf(ohat, wo_c, bo_c), q[Q_LAM]);
+      q[Q_LNOW] = fmaf(lm * go, ohat, q[Q_LNOW]);
+      q[Q_LNOB] = fmaf(lm, go, q[Q_LNOB]);
+      // dWv[di][dj] += dU[i] * xn[i + (di, dj)]   (the padded border of xn is zero)
+      const float* t = tile + ctr;
+      q[Q_WV + 0] = fmaf(du, t[-rs - CC], q[Q_WV + 0]); q[Q_WV + 1] = fmaf(du, t[-rs], q[Q_WV + 1]);
+      q[Q_WV + 2] = fmaf(du, t[-rs + CC], q[Q_WV + 2]); q[Q_WV + 3] = fmaf(du, t[-CC], q[Q_WV + 3]);
+      q[Q_WV + 4] = fmaf(du, t[0], q[Q_WV + 4]);        q[Q_WV + 5] = fmaf(du, t[CC], q[Q_WV + 5]);
+      q[Q_WV + 6] = fmaf(du, t[rs - CC], q[Q_WV + 6]);  q[Q_WV + 7] = fmaf(du, t[rs], q[Q_WV + 7]);
+      q[Q_WV + 8] = fmaf(du, t[rs + CC], q[Q_WV + 8]);
     }
   }
   __syncthreads();
   const float dy = dyx[(size_t)b * C + c];
-  for (int i = tg; i < hw; i += ntg) {
-    const int r = i / side, col = i - r * side;
-    // dxn[i] = sum_{di,dj} wv[di][dj] * dU[i - (di, dj)] + dy/hw
-    float s9 = dy;
-#pragma unroll
-    for (int di = -1; di <= 1; ++di) {
-      const int rr = r - di;
-      if (rr < 0 || rr >= side) continue;
-#pragma unroll
-      for (int dj = -1; dj <= 1; ++dj) {
-        const int c2 = col - dj;
-        if (c2 < 0 || c2 >= side) continue;
-        s9 = fmaf(w[(di + 1) * 3 + dj + 1], dus[(rr * side + c2) * CC + cc], s9);
-      }
+  {
+    TokenPos pos(tg, ntg, side);
+    for (int i = tg; i < hw; i += ntg, pos.advance()) {
+      // dxn[i] = sum_{di,dj} wv[di][dj] * dU[i - (di, dj)] + dy/hw   (the padded border of dU is zero)
+      const float* t = dus + pos.at(CC, cc);
+      float s9 = dy;
+      s9 = fmaf(w[0], t[rs + CC], s9); s9 = fmaf(w[1], t[rs], s9); s9 = fmaf(w[2], t[rs - CC], s9);
+      s9 = fmaf(w[3], t[CC], s9);      s9 = fmaf(w[4], t[0], s9);  s9 = fmaf(w[5], t[-CC], s9);
+      s9 = fmaf(w[6], t[-rs + CC], s9); s9 = fmaf(w[7], t[-rs], s9); s9 = fmaf(w[8], t[-rs - CC], s9);
+      const size_t g = ((size_t)b * n + i + 1) * C + c;
+      dxn[g] = s9;
+      const float* s = stats + ((size_t)b * n + i + 1) * S_N;
+      const float xhat = (to_f(x[g]) - s[S_MX]) * s[S_RX];
+      q[Q_LNXW] = fmaf(s9, xhat, q[Q_LNXW]);
+      q[Q_LNXB] += s9;
     }
-    const size_t g = ((size_t)b * n + i + 1) * C + c;
-    dxn[g] = s9;
-    const float* s = stats + ((size_t)b * n + i + 1) * S_N;
-    const float xhat = (to_f(x[g]) - s[S_MX]) * s[S_RX];
-    q[Q_LNXW] = fmaf(s9, xhat, q[Q_LNXW]);
-    q[Q_LNXB] += s9;
   }
   if (tg == 0) {                                              // cls row: module output is LN_x(x) itself
     const size_t g = (size_t)b * n * C + c;
@@ -388,7 +408,7 @@ int launch_token_apply_fwd(const void* x, const void* o, const float* stats, con
                            void* out, int B, int n, int C, int side, int d, int res, int dtype, hipStream_t st) {
   const int CC = chunk_for(C);
   if (!CC) return MRLA_EUNSUPPORTED;
-  const size_t lds = (size_t)(n - 1) * CC * sizeof(float);
+  const size_t lds = (size_t)(side + 2) * (side + 2) * CC * sizeof(float);
   if (lds > 150 * 1024) return MRLA_EUNSUPPORTED;
   const dim3 grid(C / CC, B);
 #define CALL(TT)                                                                                              \
@@ -406,7 +426,7 @@ int launch_token_stats_bwd(const void* dout, const void* x, const float* stats, 
                            const float* wv, float* bmom, int B, int n, int C, int side, int dtype, hipStream_t st) {
   const int CC = chunk_for(C);
   if (!CC) return MRLA_EUNSUPPORTED;
-  const size_t lds = ((size_t)(n - 1) * CC + (size_t)kThreads) * sizeof(float);
+  const size_t lds = ((size_t)(side + 2) * (side + 2) * CC + (size_t)kThreads) * sizeof(float);
   if (lds > 150 * 1024) return MRLA_EUNSUPPORTED;
   const dim3 grid(C / CC, B);
 #define CALL(TT)                                                                                              \
@@ -426,7 +446,7 @@ int launch_token_apply_bwd(const void* dout, const void* x, const void* o, const
                            int d, int dtype, hipStream_t st) {
   const int CC = chunk_for(C);
   if (!CC) return MRLA_EUNSUPPORTED;
-  const size_t lds = ((size_t)2 * (n - 1) * CC + (size_t)kThreads * Q_N) * sizeof(float);
+  const size_t lds = ((size_t)2 * (side + 2) * (side + 2) * CC + (size_t)kThreads * Q_N) * sizeof(float);
   if (lds > 150 * 1024) return MRLA_EUNSUPPORTED;
   const dim3 grid(C / CC, B);
 #define CALL(TT)                                                                                              \

@@ -7,6 +7,7 @@ from functools import partial
 
 import torch
 import torch.nn as nn
+import torch.nn.functional as F
 
 from . import layers
 
@@ -53,6 +54,11 @@ class Mlp(nn.Module):
 
 
 class Attention(nn.Module):
+    """Multi-head self-attention of the reference blocks (deit_mrla_light.py:66-91).  `fused_attn` (class attribute):
+    evaluate softmax(q k^T * scale) v through torch's scaled_dot_product_attention (same math, attention dropout
+    included; one fused kernel on the GPU instead of two batched GEMMs and a softmax)."""
+    fused_attn = True
+
     def __init__(self, dim, num_heads=8, qkv_bias=False, attn_drop=0.0, proj_drop=0.0):
         super().__init__()
         self.num_heads = num_heads
@@ -65,8 +71,12 @@ class Attention(nn.Module):
     def forward(self, x):
         B, N, C = x.shape
         q, k, v = self.qkv(x).reshape(B, N, 3, self.num_heads, C // self.num_heads).permute(2, 0, 3, 1, 4).unbind(0)
-        attn = self.attn_drop(((q @ k.transpose(-2, -1)) * self.scale).softmax(dim=-1))
-        return self.proj_drop(self.proj((attn @ v).transpose(1, 2).reshape(B, N, C)))
+        if self.fused_attn and x.is_cuda:
+            y = F.scaled_dot_product_attention(q, k, v, dropout_p=self.attn_drop.p if self.training else 0.0,
+                                               scale=self.scale)
+        else:
+            y = self.attn_drop(((q @ k.transpose(-2, -1)) * self.scale).softmax(dim=-1)) @ v
+        return self.proj_drop(self.proj(y.transpose(1, 2).reshape(B, N, C)))
 
 
 class Block(nn.Module):

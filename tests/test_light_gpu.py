@@ -210,3 +210,33 @@ def test_cpu_tensor_is_rejected_loudly():
     from mrla_amd.functional import mrla_light
     with pytest.raises(_lib.MrlaHipError):
         mrla_light(torch.zeros(1, 32, 4, 4), torch.zeros(1, 1, 3), torch.zeros(1, 1, 3), torch.zeros(32, 1, 3, 3), 32)
+
+
+@pytest.mark.parametrize("cl", [False, True], ids=["nchw", "nhwc"])
+@pytest.mark.parametrize("shape", [(3, 256, 14, 14, 32), (2, 192, 14, 14, 16)], ids=["resnet-stage", "deit-width"])
+def test_fp16_storage_matches_fp32_arithmetic_on_the_same_values(shape, cl):
+    """float16 activations (the reference's DeiT recipe trains under fp16 autocast, deit/engine.py:37): the kernels
+    accumulate in fp32, so the fp16 path must equal the fp32 path run on the same fp16-representable inputs up to the
+    rounding of the stored results (1 fp16 ulp = 2^-10)."""
+    from mrla_amd.functional import mrla_light
+    b, c, h, w, d = shape
+    torch.manual_seed(2)
+    fmt = torch.channels_last if cl else torch.contiguous_format
+    mk = lambda *s: torch.randn(*s, device="cuda")
+    x16, o16, g16 = (mk(b, c, h, w).half().contiguous(memory_format=fmt) for _ in range(3))
+    k = 5
+    wq, wk, wv, lam = mk(1, 1, k) * 0.5, mk(1, 1, k) * 0.5, mk(c, 1, 3, 3) * 0.3, mk(c, 1, 1)
+    res = []
+    for dt in (torch.float16, torch.float32):
+        bn = torch.nn.BatchNorm2d(c).cuda()
+        xt, ot = x16.detach().to(dt).clone().requires_grad_(True), o16.detach().to(dt).clone().requires_grad_(True)
+        prm = [p.clone().requires_grad_(True) for p in (wq, wk, wv, lam)]
+        out = mrla_light(xt, prm[0], prm[1], prm[2], d, o_prev=ot, lam=prm[3],
+                         bn=dict(weight=bn.weight, bias=bn.bias, running_mean=bn.running_mean, running_var=bn.running_var,
+                                 training=True, momentum=0.1, eps=1e-5), res=True)
+        out.backward(g16.to(dt))
+        res.append([t.detach().float() for t in (out, xt.grad, ot.grad, prm[2].grad, prm[3].grad, bn.weight.grad)])
+    for i, (a, r) in enumerate(zip(*res)):
+        tol = 2.0 ** -9 if i < 3 else 2e-3          # stored fp16 tensors: 2 ulps; fp32 parameter gradients: input rounding only
+        bad = (a - r).abs() > tol * (r.abs() + 0.05 * r.abs().max())
+        assert bad.float().mean().item() < 1e-4, (i, (a - r).abs().max().item())

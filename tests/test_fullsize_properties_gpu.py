@@ -1,0 +1,143 @@
+"""GPU: BASELINE-size runs (configs 2 and 5 of BASELINE.json) checked through size-independent properties, tying the
+full-size launches to the small cases the oracle pins (tests/test_light_gpu.py, tests/test_base_gpu.py):
+
+  * eval-mode block tails treat images independently: slices of a 256-image launch equal the same images run as a batch
+    of 3 (which other tests compare with the oracle / the reference) -- bit for bit where the per-image sums are taken
+    in a batch-independent order, else to the last bf16 bit (the pooled sums are split over more workgroups when the
+    batch is small);
+  * train-mode tails: (out - x) / dp is a BatchNorm output, so per channel its mean is beta and its variance gamma^2
+    over (b, h, w), whatever the size; the running statistics move by exactly `momentum` of the batch statistics;
+  * gradients: the loss sum(out * G) is linear in lambda_t, so d/d(lambda) from one backward equals a finite difference
+    of two forwards (exact up to rounding, eval mode)."""
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def same_to_the_last_bit(a, b):
+    """bf16 tensors that may differ by one unit in the last place on a vanishing fraction of elements."""
+    a, b = a.float(), b.float()
+    bad = (a - b).abs() > 2.0 ** -7 * b.abs() + 1e-30
+    return bad.float().mean().item() < 1e-4
+
+STAGES = [(256, 256, 56, 56), (256, 512, 28, 28), (256, 1024, 14, 14), (256, 2048, 7, 7)]      # resnet50_mrlal, b=256
+
+
+def _params(c, seed):
+    g = torch.Generator(device="cuda").manual_seed(seed)
+    r = lambda *s: torch.randn(*s, device="cuda", generator=g)
+    k = 7 if c == 2048 else 5
+    bn = torch.nn.BatchNorm2d(c).cuda()
+    with torch.no_grad():
+        bn.weight.copy_(1 + 0.2 * r(c)); bn.bias.copy_(0.1 * r(c))
+        bn.running_mean.copy_(0.1 * r(c)); bn.running_var.copy_(1 + 0.1 * r(c).abs())
+    return dict(wq=r(1, 1, k) * 0.5, wk=r(1, 1, k) * 0.5, wv=r(c, 1, 3, 3) * 0.3, lam=r(c, 1, 1)), bn
+
+
+def _tail(x, o, P, bn, training, dp=None, pre_activation=False):
+    from mrla_amd.functional import mrla_light
+    return mrla_light(x, P["wq"], P["wk"], P["wv"], 32, o_prev=o, lam=P["lam"],
+                      bn=dict(weight=bn.weight, bias=bn.bias, running_mean=bn.running_mean, running_var=bn.running_var,
+                              training=training, momentum=0.1, eps=1e-5), dp=dp, res=True, pre_activation=pre_activation)
+
+
+@pytest.mark.parametrize("shape", STAGES, ids=lambda s: "x".join(map(str, s)))
+def test_light_tail_full_batch_slices_equal_small_batches(shape):
+    b, c, h, w = shape
+    g = torch.Generator(device="cuda").manual_seed(c)
+    mk = lambda: torch.randn(b, c, h, w, device="cuda", generator=g).bfloat16().contiguous(memory_format=torch.channels_last)
+    pre, idn = mk(), mk()
+    P, bn = _params(c, 1)
+    with torch.no_grad():                       # inference form (x_t not materialised) ...
+        full = _tail(pre, idn, P, bn, False, pre_activation=True)
+        for lo in (0, 101, b - 3):
+            part = _tail(pre[lo:lo + 3].contiguous(memory_format=torch.channels_last),
+                         idn[lo:lo + 3].contiguous(memory_format=torch.channels_last), P, bn, False, pre_activation=True)
+            assert same_to_the_last_bit(full[lo:lo + 3], part), lo
+    # ... and the training form in eval-BN mode (norm_eval of the detection backbone), with gradients
+    pg, ig = pre.clone().requires_grad_(True), idn.clone().requires_grad_(True)
+    out = _tail(pg, ig, P, bn, False, pre_activation=True)
+    assert (out.float() - full.float()).abs().max().item() <= 2.0 ** -6 * full.float().abs().max().item()
+    up = torch.randn(out.shape, device="cuda", generator=g).bfloat16().contiguous(memory_format=torch.channels_last)
+    out.backward(up)
+    lo = 77
+    ps = pre[lo:lo + 3].clone().contiguous(memory_format=torch.channels_last).requires_grad_(True)
+    os_ = idn[lo:lo + 3].clone().contiguous(memory_format=torch.channels_last).requires_grad_(True)
+    _tail(ps, os_, P, bn, False, pre_activation=True).backward(up[lo:lo + 3].contiguous(memory_format=torch.channels_last))
+    assert same_to_the_last_bit(pg.grad[lo:lo + 3], ps.grad) and same_to_the_last_bit(ig.grad[lo:lo + 3], os_.grad)
+
+
+@pytest.mark.parametrize("shape", STAGES[:2] + STAGES[3:], ids=lambda s: "x".join(map(str, s)))
+def test_light_tail_train_mode_batchnorm_identities_at_full_size(shape):
+    b, c, h, w = shape
+    g = torch.Generator(device="cuda").manual_seed(c + 1)
+    mk = lambda: torch.randn(b, c, h, w, device="cuda", generator=g).contiguous(memory_format=torch.channels_last)
+    x, o = torch.relu(mk()), mk()                       # fp32 so that the identities are sharp
+    P, bn = _params(c, 2)
+    rm0, rv0 = bn.running_mean.clone(), bn.running_var.clone()
+    keep = (torch.rand(b, device="cuda", generator=g) > 0.2).float()
+    dp = keep / 0.8
+    out = _tail(x, o, P, bn, True, dp=dp)
+    z = (out - x)[keep.bool()] / (1 / 0.8)              # = BN(m) on the kept images ...
+    zall = (out - x)
+    assert zall[~keep.bool()].abs().max().item() == 0.0  # ... and exactly 0 on the dropped ones
+    # BN(m) over ALL images has mean beta / variance gamma^2; the kept subset is a random 80 % sample of it
+    n_all = b * h * w
+    tol = 6.0 / (0.8 * n_all) ** 0.5
+    mean, var = z.mean(dim=(0, 2, 3)), z.var(dim=(0, 2, 3), unbiased=False)
+    assert ((mean - bn.bias).abs() <= tol * bn.weight.abs() + 1e-4).all()
+    assert ((var / bn.weight ** 2 - 1).abs() <= 12 * tol + 1e-3).all()
+    # running statistics: new = 0.9 * old + 0.1 * batch statistic of m; recover the batch statistics and compare with the
+    # ones implied by `out` (mean of m = save_mean, from BN: m = (z - beta) / gamma * sigma + mu)
+    mu = (bn.running_mean - 0.9 * rm0) / 0.1
+    var_unb = (bn.running_var - 0.9 * rv0) / 0.1
+    assert torch.isfinite(mu).all() and (var_unb > 0).all()
+    from mrla_amd.functional import mrla_light
+    m = mrla_light(x, P["wq"], P["wk"], P["wv"], 32, o_prev=o, lam=P["lam"])        # a*V + lam*o, no BN
+    m_mean, m_var = m.mean(dim=(0, 2, 3)), m.var(dim=(0, 2, 3), unbiased=True)
+    assert (mu - m_mean).abs().max().item() <= 1e-4 * (m_mean.abs().max().item() + 1)
+    assert ((var_unb - m_var).abs() <= 1e-3 * m_var).all()
+
+
+def test_light_tail_lambda_gradient_equals_finite_difference_at_full_size():
+    b, c, h, w = STAGES[1]
+    g = torch.Generator(device="cuda").manual_seed(9)
+    mk = lambda: torch.randn(b, c, h, w, device="cuda", generator=g).contiguous(memory_format=torch.channels_last)
+    x, o, G = torch.relu(mk()), mk(), mk()
+    P, bn = _params(c, 3)
+    lam = P["lam"].clone().requires_grad_(True)
+    Pg = dict(P, lam=lam)
+    (_tail(x, o, Pg, bn, False) * G).sum().backward()
+    direction = torch.randn(c, 1, 1, device="cuda", generator=g)
+    with torch.no_grad():
+        f = lambda t: (_tail(x, o, dict(P, lam=P["lam"] + t * direction), bn, False).double() * G.double()).sum()
+        fd = (f(1.0) - f(-1.0)) / 2.0                    # the loss is affine in lambda_t in eval mode: exact difference
+    an = (lam.grad.double() * direction.double()).sum()
+    assert abs(fd.item() - an.item()) <= 2e-4 * (abs(an.item()) + 1e-3 * G.numel() ** 0.5), (fd.item(), an.item())
+
+
+def test_base_stage3_full_size_slices_equal_small_batches():
+    """resnet101_mrlab stage 3 (b=128, c=1024, 14x14, 23 layers of history), eval-mode fused tails on NHWC rings."""
+    from mrla_amd import _lib as L, functional as Fm
+    b, c, h, w, d, T = 128, 1024, 14, 14, 16, 23
+    g = torch.Generator(device="cuda").manual_seed(5)
+    P, bn = _params(c, 4)
+    xs = [torch.randn(b, c, h, w, device="cuda", generator=g).bfloat16().contiguous(memory_format=torch.channels_last)
+          for _ in range(T)]
+
+    def run(sel):
+        nb = len(range(*sel.indices(b)))
+        stage = Fm.BaseStage(nb, c, h, w, d, torch.bfloat16, torch.device("cuda"), T, L.NHWC)
+        outs = []
+        with torch.no_grad():
+            for x in xs:
+                xi = x[sel].contiguous(memory_format=torch.channels_last)
+                outs.append(Fm.mrla_base(xi, P["wq"], P["wk"], P["wv"], d, stage,
+                                         bn=dict(weight=bn.weight, bias=bn.bias, running_mean=bn.running_mean,
+                                                 running_var=bn.running_var, training=False, momentum=0.1, eps=1e-5)))
+        return outs
+
+    full, part = run(slice(0, b)), run(slice(60, 63))
+    for t in (0, 1, 11, 22):
+        assert same_to_the_last_bit(full[t][60:63], part[t]), t

@@ -217,8 +217,10 @@ __device__ __forceinline__ u32x4 pack16(const float (&v)[16 / sizeof(T)]) {
   return __builtin_bit_cast(u32x4, t);
 }
 
-template <typename T>
-__global__ __launch_bounds__(kThreads) void base_attend_bwd_nhwc(
+// OCC: waves per SIMD the register allocation aims at.  3 (<= 168 VGPRs) is faster while the history is short (the
+// dOut / attn / dA phase dominates); with a long history the unconstrained allocation streams the slots faster.
+template <typename T, int OCC>
+__global__ __launch_bounds__(kThreads, OCC) void base_attend_bwd_nhwc(
     const T* __restrict__ dout, const T* __restrict__ attn, const float* __restrict__ sc, const float* __restrict__ sh,
     const float* __restrict__ dp, const float* __restrict__ cb /*[c,3]*/, const T* __restrict__ Vring,
     T* __restrict__ dAring, float* __restrict__ pmom_part, FlatGeo g, int T_, int t) {
@@ -247,34 +249,41 @@ __global__ __launch_bounds__(kThreads) void base_attend_bwd_nhwc(
       e_[k] = sc ? cb[(c0 + k) * 3 + 0] : 1.f; f_[k] = sc ? cb[(c0 + k) * 3 + 1] : 0.f;
       h_[k] = sc ? cb[(c0 + k) * 3 + 2] : 0.f;
     }
-    u32x4 graw[kNV], araw[kNV];
+    // two halves of kNV/2 vectors: enough loads in flight, half the registers
 #pragma unroll
-    for (int i = 0; i < kNV; ++i) {
-      graw[i] = (u32x4){0u, 0u, 0u, 0u};
-      araw[i] = (u32x4){0u, 0u, 0u, 0u};
-      if (tid + i * kThreads < g.nvec) {
-        graw[i] = ldraw<T>(dout + base + (size_t)i * kThreads * VEC);
-        if (attn) araw[i] = ldraw<T>(attn + base + (size_t)i * kThreads * VEC);
+    for (int half = 0; half < 2; ++half) {
+      constexpr int HV = kNV / 2;
+      u32x4 graw[HV], araw[HV];
+#pragma unroll
+      for (int k = 0; k < HV; ++k) {
+        const int i = half * HV + k;
+        graw[k] = (u32x4){0u, 0u, 0u, 0u};
+        araw[k] = (u32x4){0u, 0u, 0u, 0u};
+        if (tid + i * kThreads < g.nvec) {
+          graw[k] = ldraw<T>(dout + base + (size_t)i * kThreads * VEC);
+          if (attn) araw[k] = ldraw<T>(attn + base + (size_t)i * kThreads * VEC);
+        }
       }
-    }
-    issue(0);                                    // V_0 is on its way while dA_t is formed
 #pragma unroll
-    for (int i = 0; i < kNV; ++i) {
-      float gv[VEC], av[VEC], r[VEC];
-      unpack<T>(graw[i], gv);
-      unpack<T>(araw[i], av);
+      for (int k = 0; k < HV; ++k) {
+        const int i = half * HV + k;
+        float gv[VEC], av[VEC], r[VEC];
+        unpack<T>(graw[k], gv);
+        unpack<T>(araw[k], av);
 #pragma unroll
-      for (int k = 0; k < VEC; ++k) {
-        const float dz = (fmaf(s[k], av[k], h[k]) > 0.f) ? dpb * gv[k] : 0.f;
-        r[k] = fmaf(e_[k], dz, fmaf(f_[k], av[k], h_[k]));
+        for (int q = 0; q < VEC; ++q) {
+          const float dz = (fmaf(s[q], av[q], h[q]) > 0.f) ? dpb * gv[q] : 0.f;
+          r[q] = fmaf(e_[q], dz, fmaf(f_[q], av[q], h_[q]));
+        }
+        da[i] = pack16<T>(r);
+        if (tid + i * kThreads < g.nvec)
+          *reinterpret_cast<u32x4*>(dAring + (size_t)(t - 1) * slot + base + (size_t)i * kThreads * VEC) = da[i];
+        else
+          da[i] = (u32x4){0u, 0u, 0u, 0u};
       }
-      da[i] = pack16<T>(r);
-      if (tid + i * kThreads < g.nvec)
-        *reinterpret_cast<u32x4*>(dAring + (size_t)(t - 1) * slot + base + (size_t)i * kThreads * VEC) = da[i];
-      else
-        da[i] = (u32x4){0u, 0u, 0u, 0u};
     }
   }
+  issue(0);
   for (int j = 0; j < t; ++j) {
     u32x4 cur[kNV];
 #pragma unroll
@@ -482,11 +491,13 @@ int launch_base_attend_bwd_nhwc(const void* dout, const void* attn, const float*
                                 int T, int t, int dtype, hipStream_t st) {
   if (!base_nhwc_supported(C, dtype)) return MRLA_EUNSUPPORTED;
   const FlatGeo g = flat_geo(B, C, HW, dtype, kNV);
-#define CALL(TT)                                                                                                  \
-  hipLaunchKernelGGL((base_attend_bwd_nhwc<TT>), dim3(g.tiles, B), dim3(kThreads), 0, st, (const TT*)dout,         \
+#define CALL_O(TT, OCC)                                                                                           \
+  hipLaunchKernelGGL((base_attend_bwd_nhwc<TT, OCC>), dim3(g.tiles, B), dim3(kThreads), 0, st, (const TT*)dout,    \
                      (const TT*)attn, sc, sh, dp, cb, (const TT*)Vring, (TT*)dAring, pmom_part, g, T, t);
+#define CALL(TT) { if (t <= 16) CALL_O(TT, 3) else CALL_O(TT, 1) }
   MRLA_DISPATCH_B(dtype, CALL)
 #undef CALL
+#undef CALL_O
   return hip_status(hipGetLastError());
 }
 

@@ -299,7 +299,7 @@ def gen_det():
     maps = net(T(x_np))
     loss = sum((m * T(g)).mean() for m, g in zip(maps, gs))
     loss.backward()
-    out["train/loss"] = np.array([float(loss)])
+    out["train/loss"] = np.array([loss.item()])
     for i, m in enumerate(maps):
         out[f"train/map{i}_sum"] = np.array([float(m.double().sum()), float(m.double().abs().sum())])
     frozen = []

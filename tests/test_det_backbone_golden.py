@@ -43,7 +43,7 @@ def check_against_golden(net, dev, tol_map, tol_grad, amp=False):
         maps = net(x)
         loss = sum((m.float() * torch.from_numpy(g).to(dev)).mean() for m, g in zip(maps, gs))
     loss.backward()
-    assert abs(float(loss) - float(G["train/loss"][0])) < tol_map * max(1.0, abs(float(G["train/loss"][0])))
+    assert abs(loss.item() - float(G["train/loss"][0])) < tol_map * max(1.0, abs(float(G["train/loss"][0])))
     frozen = sorted(k for k, p in net.named_parameters() if p.grad is None)
     assert frozen == list(G["train/frozen"])
     n = 0
@@ -72,7 +72,7 @@ def test_product_det_backbone_surface():
     net = mb.ResNet_mrlal(frozen_stages=1, norm_eval=True, style="pytorch", drop_path=0.1,
                           init_cfg=None)
     assert sorted(net.state_dict().keys()) == list(G["state_keys"])
-    assert all(float(m.bn3.weight.abs().sum()) == 0.0 for m in net.modules() if isinstance(m, mb.MRLA_Bottleneck))
+    assert all(m.bn3.weight.detach().abs().sum().item() == 0.0 for m in net.modules() if isinstance(m, mb.MRLA_Bottleneck))
     assert not any(isinstance(m.drop_path, type(net.layer1[0].mrla)) for m in net.layer1)      # no DropPath module in use
     assert all(isinstance(m.drop_path, torch.nn.Identity) for m in net.modules() if isinstance(m, mb.MRLA_Bottleneck))
     net.train()

@@ -512,7 +512,7 @@ int launch_base_value_bwd_nhwc(const void* dout, const void* x, const float* wv,
                                hipStream_t st) {
   const int nstrips = (W + kS - 1) / kS;
   const int nwaves = std::min(nstrips, kMaxStrips);
-  const int BG = nhwc_images_per_group(B, C);
+  const int BG = nhwc_images_per_group(B, C, W);
   const dim3 grid((C + kWave - 1) / kWave, (B + BG - 1) / BG), block(nwaves * kWave);
   const bool wide = (C % kWave) == 0;
   const size_t tb = dtype == MRLA_F32 ? scratch_bytes<float>() : scratch_bytes<bf16_t>();

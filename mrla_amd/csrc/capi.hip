@@ -67,7 +67,7 @@ int mrla_abi_version(void) { return 1; }
 
 int mrla_light_wgrad_rows(int b, int c, int h, int w, int dtype, int layout) {
   if (bad_dims(b, c, h, w) || bad_dtype(dtype)) return MRLA_EINVAL;
-  if (layout == MRLA_NHWC) { const int bg = nhwc_images_per_group(b, c); return (b + bg - 1) / bg; }
+  if (layout == MRLA_NHWC) { const int bg = nhwc_images_per_group(b, c, w); return (b + bg - 1) / bg; }
   if (layout != MRLA_NCHW) return MRLA_EINVAL;
   SlabGeo g;
   const int rc = light_geo(&g, b, c, h, w, dtype);

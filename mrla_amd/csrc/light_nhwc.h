@@ -198,7 +198,7 @@ static NhwcLaunch nhwc_launch(int B, int C, int W, int nred, int dtype) {
   NhwcLaunch L;
   const int nstrips = (W + kS - 1) / kS;
   const int nwaves = std::min(nstrips, kMaxStrips);
-  L.BG = nhwc_images_per_group(B, C);
+  L.BG = nhwc_images_per_group(B, C, 0);
   L.grid = dim3((C + kWave - 1) / kWave, (B + L.BG - 1) / L.BG);
   L.block = dim3(nwaves * kWave);
   L.wide = (C % kWave) == 0;

@@ -129,7 +129,7 @@ int launch_affine_act(const void* x, const void* dy, const float* a, const float
 
 
 // light_nhwc.hip / bnact_nhwc.hip -- channels_last variants
-int nhwc_images_per_group(int B, int C);
+int nhwc_images_per_group(int B, int C, int W);
 int launch_light_stats_fwd_nhwc(const void* x, const void* o, const float* wv, float* mom, void* xout,
                                 const float* psc, const float* psh, void* vout, int B, int C, int H, int W, int dtype,
                                 int act, hipStream_t st);

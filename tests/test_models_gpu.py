@@ -101,3 +101,34 @@ def test_state_dict_roundtrip_and_api_surface():
     sd = em.eager_resnet50_mrlal(num_classes=10).state_dict()
     assert set(net.state_dict().keys()) == set(sd.keys())
     assert sum(p.numel() for p in models.resnet50_mrlal().parameters()) == 25_738_452
+
+
+@pytest.mark.parametrize("arch", ["resnet50_mrlal", "resnet50_mrlab"])
+def test_five_sgd_steps_track_the_eager_restatement(arch):
+    """Same initial weights, same batches, SGD(momentum, weight decay) as resnet/train.py:199-201, fp32, no stochastic depth:
+    the loss trajectory and the BatchNorm running statistics of the product follow the eager restatement step by step."""
+    from mrla_amd import models
+    net, ref = getattr(models, arch)().cuda(), getattr(em, "eager_" + arch)().cuda()
+    load_det(net)
+    ref.load_state_dict(net.state_dict())
+    net.train(); ref.train()
+    opt_a = torch.optim.SGD(net.parameters(), lr=0.001, momentum=0.9, weight_decay=1e-4)
+    opt_b = torch.optim.SGD(ref.parameters(), lr=0.001, momentum=0.9, weight_decay=1e-4)
+    g = torch.Generator(device="cuda").manual_seed(0)
+    la, lb = [], []
+    for step in range(5):
+        x = torch.randn(8, 3, 224, 224, device="cuda", generator=g)
+        y = torch.randint(0, 1000, (8,), device="cuda", generator=g)
+        for model, opt, losses in ((net, opt_a, la), (ref, opt_b, lb)):
+            loss = torch.nn.functional.cross_entropy(model(x), y)
+            opt.zero_grad(set_to_none=True)
+            loss.backward()
+            opt.step()
+            losses.append(loss.item())
+    for a, b in zip(la, lb):
+        assert abs(a - b) <= 2e-3 * abs(b) + 1e-4, (la, lb)
+    sa, sb = net.state_dict(), ref.state_dict()
+    for k in sa:
+        if k.endswith("running_var") or k.endswith("running_mean"):
+            assert rel(sa[k].float().cpu().numpy(), sb[k].float().cpu().numpy()) < 2e-2, k     # 5 steps of rounding drift
+    assert int(sa["bn1.num_batches_tracked"]) == 5

@@ -72,10 +72,34 @@ __device__ __forceinline__ double wave_sum(double v) {
   return v;
 }
 
-__device__ __forceinline__ float gelu_f(float u) { return 0.5f * u * (1.0f + erff(u * 0.70710678118654752440f)); }
+// erf to < 1 ulp without the library call: two minimax polynomials (|a| <= 0.927734375: a + a*P(a^2); beyond:
+// 1 - exp(Q(|a|))), both evaluated and selected -- lanes of a wave straddle the boundary anyway.  ~22 VALU instructions
+// where ocml's erff + expf cost the token kernels >100 per GELU (they were the bulk of those kernels' instruction count).
+__device__ __forceinline__ float erf_f(float a) {
+  const float t = fminf(fabsf(a), 10.0f), s = t * t;       // erf(10) == 1 in fp32
+  float r = fmaf(-1.72853470e-5f, t, 3.83197126e-4f);
+  const float q = fmaf(-3.88396438e-3f, t, 2.42546219e-2f);
+  r = fmaf(r, s, q);
+  r = fmaf(r, t, -1.06777877e-1f);
+  r = fmaf(r, t, -6.34846687e-1f);
+  r = fmaf(r, t, -1.28717512e-1f);
+  r = fmaf(r, t, -t);
+  const float big = copysignf(1.0f - __expf(r), a);
+  float p = -5.96761703e-4f;
+  p = fmaf(p, s, 4.99119423e-3f);
+  p = fmaf(p, s, -2.67681349e-2f);
+  p = fmaf(p, s, 1.12819925e-1f);
+  p = fmaf(p, s, -3.76125336e-1f);
+  p = fmaf(p, s, 1.28379166e-1f);
+  const float small = fmaf(p, a, a);
+  return t > 0.927734375f ? big : small;
+}
+
+// exact (erf) GELU of nn.GELU() and its derivative
+__device__ __forceinline__ float gelu_f(float u) { return 0.5f * u * (1.0f + erf_f(u * 0.70710678118654752440f)); }
 __device__ __forceinline__ float gelu_grad_f(float u) {
-  const float cdf = 0.5f * (1.0f + erff(u * 0.70710678118654752440f));
-  const float pdf = 0.39894228040143267794f * expf(-0.5f * u * u);
+  const float cdf = 0.5f * (1.0f + erf_f(u * 0.70710678118654752440f));
+  const float pdf = 0.39894228040143267794f * __expf(-0.5f * u * u);
   return cdf + u * pdf;
 }
 

@@ -84,6 +84,18 @@ int launch_base_value_bwd(const void* dout, const void* x, const float* wv, cons
                           int res, int dtype, hipStream_t st);
 
 
+// tokens_nhwc.hip -- row-marching token map kernels (C % 64 == 0)
+bool token_nhwc_applies(int C);
+int launch_token_apply_fwd_nhwc(const void* x, const void* o, const float* stats, const float* wx, const float* bx,
+                                const float* wo, const float* bo, const float* wv, const float* gate, const float* lam,
+                                void* out, int B, int n, int C, int side, int d, int res, int dtype, hipStream_t st);
+int launch_token_stats_bwd_nhwc(const void* dout, const void* x, const float* stats, const float* wx, const float* bx,
+                                const float* wv, float* bmom, int B, int n, int C, int side, int dtype, hipStream_t st);
+int launch_token_apply_bwd_nhwc(const void* dout, const void* x, const void* o, const float* stats, const float* wx,
+                                const float* bx, const float* wo, const float* bo, const float* wv, const float* gate,
+                                const float* lam, const float* dyx, float* dxn, float* part, int B, int n, int C,
+                                int side, int d, int dtype, hipStream_t st);
+
 // base_nhwc.hip -- MRLA-base for channels_last activations; rings are slot-major [T][b,h,w,c]
 bool base_nhwc_supported(int C, int dtype);
 int base_nhwc_tiles(int B, int C, int HW, int dtype);

@@ -1,0 +1,410 @@
+// MRLA-light on token sequences, map kernels in the row-marching LANE = CHANNEL form of light_nhwc.hip.
+//
+// The map tokens x[b, 1 + r*side + col, c] ARE a channels_last image (pixel pitch C, row pitch side*C, image pitch n*C,
+// first pixel at offset C), so the strips / rolling row windows / 16-byte row gathers of light_nhwc.h apply unchanged;
+// what is token-specific is the LayerNorm applied to every fetched pixel (its (mean, rstd) are wave-uniform and come
+// through the scalar cache) and the exact-GELU on V.  Used when C % 64 == 0 (DeiT widths 192 / 384 / 768); tokens.hip
+// keeps the LDS-tile kernels for other widths, the LayerNorm statistics / pooling and the LayerNorm backward.
+//   forward : out[b,i>=1] = res*x + a*gelu(dwconv3x3(LN_x(x) map)) + lam*LN_o(o_prev)      (the cls row: token_cls_fwd)
+//   backward: bmom = sum dOut*gelu(U);  dxn = dwconv3x3^T(a*dOut*gelu'(U)) + dy (fp32), 14 parameter partials / channel
+// Reference: deit/deit_mrla_light.py:157-180,194-209,234.
+#include <algorithm>
+
+#include "light_nhwc.h"
+
+namespace mrla {
+
+enum { TS_MX = 0, TS_RX = 1, TS_MO = 2, TS_RO = 3, TS_N = 4 };
+enum { TQ_WV = 0, TQ_LAM = 9, TQ_LNXW = 10, TQ_LNXB = 11, TQ_LNOW = 12, TQ_LNOB = 13, TQ_N = 14 };
+
+// (mean, rstd) of LN_x (which = 0) or LN_o (which = 2) of the map pixel (r, col) of image b: wave-uniform -> scalar load
+__device__ __forceinline__ float2 tok_stat(const float* __restrict__ stats, int tok0, int side, int r, int col, int which) {
+  const int idx = __builtin_amdgcn_readfirstlane((tok0 + r * side + col) * TS_N + which);
+  return *reinterpret_cast<const float2*>(stats + idx);
+}
+
+// raw row -> LN_x(x) row on window columns col0 .. col0+NPX-1 of map row r (0 outside the map)
+template <int NPX>
+__device__ __forceinline__ void normalise_row(float (&v)[NPX], const float* __restrict__ stats, int tok0, int side, int r,
+                                              int col0, float wxc, float bxc) {
+  const bool rowok = r >= 0 && r < side;
+#pragma unroll
+  for (int j = 0; j < NPX; ++j) {
+    const int col = col0 + j;
+    if (rowok && col >= 0 && col < side) {                         // wave-uniform
+      const float2 s = tok_stat(stats, tok0, side, r, col, TS_MX);
+      v[j] = fmaf((v[j] - s.x) * s.y, wxc, bxc);
+    } else {
+      v[j] = 0.f;
+    }
+  }
+}
+
+// same, and hat[j] = the normalised value before the affine (what the LayerNorm weight gradient multiplies)
+template <int NPX>
+__device__ __forceinline__ void normalise_row_hat(float (&v)[NPX], float (&hat)[NPX], const float* __restrict__ stats,
+                                                  int tok0, int side, int r, int col0, float wxc, float bxc) {
+  const bool rowok = r >= 0 && r < side;
+#pragma unroll
+  for (int j = 0; j < NPX; ++j) {
+    const int col = col0 + j;
+    if (rowok && col >= 0 && col < side) {
+      const float2 s = tok_stat(stats, tok0, side, r, col, TS_MX);
+      hat[j] = (v[j] - s.x) * s.y;
+      v[j] = fmaf(hat[j], wxc, bxc);
+    } else {
+      hat[j] = 0.f;
+      v[j] = 0.f;
+    }
+  }
+}
+
+#define MRLA_TOK_PROLOGUE(NRED)                                                                           \
+  extern __shared__ __align__(16) unsigned char smem_raw[];                                               \
+  const int lane = threadIdx.x & (kWave - 1), wave = threadIdx.x / kWave, nwaves = blockDim.x / kWave;    \
+  float* red = reinterpret_cast<float*>(smem_raw);                                                        \
+  constexpr int SB = scratch_bytes<float>();          /* every buffer is sized for fp32 rows */             \
+  unsigned char* my = smem_raw + (size_t)nwaves * (NRED) * kWave * sizeof(float) + (size_t)wave * 2 * SB;  \
+  T* scrT = reinterpret_cast<T*>(my);                 /* gathers */                                        \
+  unsigned char* scrS = my + SB;                      /* scatters */                                       \
+  const int cbase = blockIdx.x * kWave, c = cbase + lane;                                                 \
+  const int b = blockIdx.y, W = side, H = side;                                                           \
+  const int nstrips = (W + kS - 1) / kS;                                                                  \
+  const int tok0 = b * n + 1;                         /* token index of map pixel (0, 0) */                \
+  const size_t ioff = (size_t)tok0 * C;                                                                   \
+  (void)red; (void)scrS;
+
+// ------------------------------------------------------------------------------------------------
+// forward apply (map rows); grid (C/64, b)
+// ------------------------------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(kMaxStrips * kWave) void token_apply_fwd_nhwc(
+    const T* __restrict__ x, const T* __restrict__ o, const float* __restrict__ stats, const float* __restrict__ wx,
+    const float* __restrict__ bx, const float* __restrict__ wo, const float* __restrict__ bo,
+    const float* __restrict__ wv, const float* __restrict__ gate, const float* __restrict__ lam, T* __restrict__ out,
+    int n, int C, int side, int d, int res) {
+  MRLA_TOK_PROLOGUE(0)
+  float w[9];
+#pragma unroll
+  for (int k = 0; k < 9; ++k) w[k] = wv[c * 9 + k];
+  const float a = gate[(size_t)b * (C / d) + c / d];
+  const float lm = lam[c], wxc = wx[c], bxc = bx[c], woc = wo[c], boc = bo[c];
+  const float resf = res ? 1.f : 0.f;
+  const T* xi = x + ioff;
+  const T* oi = o + ioff;
+  T* yo = out + ioff;
+  for (int s = wave; s < nstrips; s += nwaves) {
+    const int s0 = s * kS, nc = min(kS, W - s0);
+    float ra[kS + 2], rb[kS + 2], rc[kS + 2], xraw[kS], xnext[kS];
+    RowLoad<T, kS + 2> qx;
+    RowLoad<T, kS> qo;
+    RowAddr<T, kS + 2> ax;
+    RowAddr<T, kS> ao;
+    make_row_addr<T, kS + 2>(ax, s0 - 1, W, C, cbase, lane);
+    make_row_addr<T, kS>(ao, s0, W, C, cbase, lane);
+#pragma unroll
+    for (int j = 0; j < kS + 2; ++j) ra[j] = 0.f;
+    read_row<T, true, kS + 2>(xi, 0, s0 - 1, H, W, C, cbase, c, lane, scrT, rb);
+#pragma unroll
+    for (int j = 0; j < kS; ++j) xraw[j] = rb[j + 1];
+    normalise_row<kS + 2>(rb, stats, tok0, side, 0, s0 - 1, wxc, bxc);
+    issue_row<T, kS + 2>(qx, xi, 1, H, W * C, ax);
+    issue_row<T, kS>(qo, oi, 0, H, W * C, ao);
+    for (int r = 0; r < H; ++r) {
+      float ov[kS], y[kS];
+      finish_row<T, kS + 2>(qx, lane, scrT, rc);
+      finish_row<T, kS>(qo, lane, scrT, ov);
+      issue_row<T, kS + 2>(qx, xi, r + 2, H, W * C, ax);
+      issue_row<T, kS>(qo, oi, r + 1, H, W * C, ao);
+#pragma unroll
+      for (int j = 0; j < kS; ++j) xnext[j] = rc[j + 1];
+      normalise_row<kS + 2>(rc, stats, tok0, side, r + 1, s0 - 1, wxc, bxc);
+#pragma unroll
+      for (int j = 0; j < kS; ++j) {
+        float on = 0.f;
+        if (j < nc) {
+          const float2 so = tok_stat(stats, tok0, side, r, s0 + j, TS_MO);
+          on = fmaf((ov[j] - so.x) * so.y, woc, boc);
+        }
+        y[j] = fmaf(a, gelu_f(conv_at(w, ra, rb, rc, j)), fmaf(lm, on, resf * xraw[j]));
+      }
+      write_row<T, true, kS>(yo, r, s0, nc, W, C, cbase, c, true, lane, reinterpret_cast<T*>(scrS), y);
+#pragma unroll
+      for (int j = 0; j < kS + 2; ++j) { ra[j] = rb[j]; rb[j] = rc[j]; }
+#pragma unroll
+      for (int j = 0; j < kS; ++j) xraw[j] = xnext[j];
+    }
+  }
+}
+
+// cls row: out[b, 0, :] = res*x + LN_x(x)   (one thread per channel; grid (ceil(C/256), b))
+template <typename T>
+__global__ __launch_bounds__(kThreads) void token_cls_fwd_kernel(const T* __restrict__ x, const float* __restrict__ stats,
+                                                                 const float* __restrict__ wx, const float* __restrict__ bx,
+                                                                 T* __restrict__ out, int n, int C, int res) {
+  const int b = blockIdx.y, c = blockIdx.x * kThreads + threadIdx.x;
+  if (c >= C) return;
+  const size_t g = (size_t)b * n * C + c;
+  const float* s = stats + (size_t)b * n * TS_N;
+  const float xv = to_f(x[g]);
+  float y = fmaf((xv - s[TS_MX]) * s[TS_RX], wx[c], bx[c]);
+  if (res) y += xv;
+  out[g] = from_f<T>(y);
+}
+
+// ------------------------------------------------------------------------------------------------
+// backward statistics: bmom[b,c,D_DV] = sum_i dOut * gelu(U)
+// ------------------------------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(kMaxStrips * kWave) void token_stats_bwd_nhwc(
+    const T* __restrict__ dout, const T* __restrict__ x, const float* __restrict__ stats, const float* __restrict__ wx,
+    const float* __restrict__ bx, const float* __restrict__ wv, float* __restrict__ bmom, int n, int C, int side) {
+  MRLA_TOK_PROLOGUE(1)
+  float w[9];
+#pragma unroll
+  for (int k = 0; k < 9; ++k) w[k] = wv[c * 9 + k];
+  const float wxc = wx[c], bxc = bx[c];
+  const T* xi = x + ioff;
+  const T* gi = dout + ioff;
+  float acc[1] = {0.f};
+  for (int s = wave; s < nstrips; s += nwaves) {
+    const int s0 = s * kS, nc = min(kS, W - s0);
+    float ra[kS + 2], rb[kS + 2], rc[kS + 2];
+    RowLoad<T, kS + 2> qx;
+    RowLoad<T, kS> qg;
+    RowAddr<T, kS + 2> ax;
+    RowAddr<T, kS> ag;
+    make_row_addr<T, kS + 2>(ax, s0 - 1, W, C, cbase, lane);
+    make_row_addr<T, kS>(ag, s0, W, C, cbase, lane);
+#pragma unroll
+    for (int j = 0; j < kS + 2; ++j) ra[j] = 0.f;
+    read_row<T, true, kS + 2>(xi, 0, s0 - 1, H, W, C, cbase, c, lane, scrT, rb);
+    normalise_row<kS + 2>(rb, stats, tok0, side, 0, s0 - 1, wxc, bxc);
+    issue_row<T, kS + 2>(qx, xi, 1, H, W * C, ax);
+    issue_row<T, kS>(qg, gi, 0, H, W * C, ag);
+    for (int r = 0; r < H; ++r) {
+      float gv[kS];
+      finish_row<T, kS + 2>(qx, lane, scrT, rc);
+      finish_row<T, kS>(qg, lane, scrT, gv);
+      issue_row<T, kS + 2>(qx, xi, r + 2, H, W * C, ax);
+      issue_row<T, kS>(qg, gi, r + 1, H, W * C, ag);
+      normalise_row<kS + 2>(rc, stats, tok0, side, r + 1, s0 - 1, wxc, bxc);
+#pragma unroll
+      for (int j = 0; j < kS; ++j)
+        if (j < nc) acc[0] = fmaf(gv[j], gelu_f(conv_at(w, ra, rb, rc, j)), acc[0]);
+#pragma unroll
+      for (int j = 0; j < kS + 2; ++j) { ra[j] = rb[j]; rb[j] = rc[j]; }
+    }
+  }
+  wg_reduce<1>(acc, red, lane, wave, nwaves);
+  if (wave == 0) {
+    float* bm = bmom + ((size_t)b * C + c) * D_N;
+    bm[D_D] = 0.f; bm[D_DV] = acc[0]; bm[D_DO] = 0.f;
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// backward apply: dxn (fp32, map rows and the cls row) and the 14 parameter partials per (image, channel)
+//   dU[i]  = a * dOut[i] * gelu'(U[i])            (zero outside the map)
+//   dxn[i] = sum_{di,dj} wv[di][dj] * dU[i - (di,dj)] + dy
+// Windows per strip: xn rows rr-1..rr+1 on columns s0-2..s0+kS+1; dU rows rr-2..rr on columns s0-1..s0+kS.
+// ------------------------------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(kMaxStrips * kWave) void token_apply_bwd_nhwc(
+    const T* __restrict__ dout, const T* __restrict__ x, const T* __restrict__ o, const float* __restrict__ stats,
+    const float* __restrict__ wx, const float* __restrict__ bx, const float* __restrict__ wo,
+    const float* __restrict__ bo, const float* __restrict__ wv, const float* __restrict__ gate,
+    const float* __restrict__ lam, const float* __restrict__ dyx, float* __restrict__ dxn, float* __restrict__ part,
+    int n, int C, int side, int d) {
+  MRLA_TOK_PROLOGUE(TQ_N)
+  float w[9];
+#pragma unroll
+  for (int k = 0; k < 9; ++k) w[k] = wv[c * 9 + k];
+  const float a = gate[(size_t)b * (C / d) + c / d];
+  const float lm = lam[c], wxc = wx[c], bxc = bx[c], woc = wo[c], boc = bo[c];
+  const float dy = dyx[(size_t)b * C + c];
+  const T* xi = x + ioff;
+  const T* gi = dout + ioff;
+  const T* oi = o + ioff;
+  float* dxo = dxn + ioff;
+  float q[TQ_N];
+#pragma unroll
+  for (int k = 0; k < TQ_N; ++k) q[k] = 0.f;
+  for (int s = wave; s < nstrips; s += nwaves) {
+    const int s0 = s * kS, nc = min(kS, W - s0);
+    float xa[kS + 4], xb[kS + 4], xc[kS + 4];        // xn rows rr-1, rr, rr+1
+    float ua[kS + 2], ub[kS + 2], uc[kS + 2];        // dU rows rr-2, rr-1, rr
+    float h0[kS], h1[kS], h2[kS];                    // xhat (LN_x before its affine) of the owned pixels, rows rr-1..rr+1
+    RowLoad<T, kS + 4> qx;
+    RowLoad<T, kS + 2> qg;
+    RowLoad<T, kS> qo;
+    RowAddr<T, kS + 4> ax;
+    RowAddr<T, kS + 2> ag;
+    RowAddr<T, kS> ao;
+    make_row_addr<T, kS + 4>(ax, s0 - 2, W, C, cbase, lane);
+    make_row_addr<T, kS + 2>(ag, s0 - 1, W, C, cbase, lane);
+    make_row_addr<T, kS>(ao, s0, W, C, cbase, lane);
+#pragma unroll
+    for (int j = 0; j < kS + 4; ++j) xa[j] = 0.f;
+#pragma unroll
+    for (int j = 0; j < kS + 2; ++j) { ua[j] = 0.f; ub[j] = 0.f; }
+    read_row<T, true, kS + 4>(xi, 0, s0 - 2, H, W, C, cbase, c, lane, scrT, xb);
+    {
+      float hat[kS + 4];
+      normalise_row_hat<kS + 4>(xb, hat, stats, tok0, side, 0, s0 - 2, wxc, bxc);
+#pragma unroll
+      for (int j = 0; j < kS; ++j) { h0[j] = 0.f; h1[j] = hat[j + 2]; }
+    }
+    issue_row<T, kS + 4>(qx, xi, 1, H, W * C, ax);
+    issue_row<T, kS + 2>(qg, gi, 0, H, W * C, ag);
+    issue_row<T, kS>(qo, oi, 0, H, W * C, ao);
+    for (int rr = 0; rr <= H; ++rr) {
+      float gv[kS + 2], ov[kS];
+      finish_row<T, kS + 4>(qx, lane, scrT, xc);
+      finish_row<T, kS + 2>(qg, lane, scrT, gv);
+      finish_row<T, kS>(qo, lane, scrT, ov);
+      issue_row<T, kS + 4>(qx, xi, rr + 2, H, W * C, ax);
+      issue_row<T, kS + 2>(qg, gi, rr + 1, H, W * C, ag);
+      issue_row<T, kS>(qo, oi, rr + 1, H, W * C, ao);
+      {
+        float hat[kS + 4];
+        normalise_row_hat<kS + 4>(xc, hat, stats, tok0, side, rr + 1, s0 - 2, wxc, bxc);
+#pragma unroll
+        for (int j = 0; j < kS; ++j) h2[j] = hat[j + 2];
+      }
+      if (rr >= H) {
+#pragma unroll
+        for (int j = 0; j < kS + 2; ++j) uc[j] = 0.f;
+      } else {
+#pragma unroll
+        for (int j = 0; j < kS + 2; ++j) {
+          const int col = s0 - 1 + j;
+          const bool in = col >= 0 && col < W;                              // wave-uniform
+          const float u = conv_at(w, xa, xb, xc, j);
+          const float du = in ? a * gv[j] * gelu_grad_f(u) : 0.f;
+          uc[j] = du;
+          if (j >= 1 && j <= kS && j - 1 < nc) {
+            const float go = gv[j];
+            const float2 so = tok_stat(stats, tok0, side, rr, col, TS_MO);
+            const float ohat = (ov[j - 1] - so.x) * so.y;
+            q[TQ_LAM] = fmaf(go, fmaf(ohat, woc, boc), q[TQ_LAM]);
+            q[TQ_LNOW] = fmaf(lm * go, ohat, q[TQ_LNOW]);
+            q[TQ_LNOB] = fmaf(lm, go, q[TQ_LNOB]);
+            // dWv[i][k] += dU[rr][col] * xn[rr+i-1][col+k-1]   (window index of col+k-1 in the xn arrays: j+k)
+            q[0] = fmaf(du, xa[j], q[0]); q[1] = fmaf(du, xa[j + 1], q[1]); q[2] = fmaf(du, xa[j + 2], q[2]);
+            q[3] = fmaf(du, xb[j], q[3]); q[4] = fmaf(du, xb[j + 1], q[4]); q[5] = fmaf(du, xb[j + 2], q[5]);
+            q[6] = fmaf(du, xc[j], q[6]); q[7] = fmaf(du, xc[j + 1], q[7]); q[8] = fmaf(du, xc[j + 2], q[8]);
+          }
+        }
+      }
+      if (rr >= 1) {
+        const int ro = rr - 1;
+        float yrow[kS];
+#pragma unroll
+        for (int j = 0; j < kS; ++j) {
+          float s9 = w[0] * uc[j + 2];
+          s9 = fmaf(w[1], uc[j + 1], s9); s9 = fmaf(w[2], uc[j], s9);
+          s9 = fmaf(w[3], ub[j + 2], s9); s9 = fmaf(w[4], ub[j + 1], s9); s9 = fmaf(w[5], ub[j], s9);
+          s9 = fmaf(w[6], ua[j + 2], s9); s9 = fmaf(w[7], ua[j + 1], s9); s9 = fmaf(w[8], ua[j], s9);
+          s9 += dy;
+          yrow[j] = s9;
+          if (j < nc) {
+            q[TQ_LNXW] = fmaf(s9, h0[j], q[TQ_LNXW]);
+            q[TQ_LNXB] += s9;
+          }
+        }
+        write_row<float, true, kS>(dxo, ro, s0, nc, W, C, cbase, c, true, lane, reinterpret_cast<float*>(scrS), yrow);
+      }
+#pragma unroll
+      for (int j = 0; j < kS + 4; ++j) { xa[j] = xb[j]; xb[j] = xc[j]; }
+#pragma unroll
+      for (int j = 0; j < kS + 2; ++j) { ua[j] = ub[j]; ub[j] = uc[j]; }
+#pragma unroll
+      for (int j = 0; j < kS; ++j) { h0[j] = h1[j]; h1[j] = h2[j]; }
+    }
+  }
+  wg_reduce<TQ_N>(q, red, lane, wave, nwaves);
+  if (wave == 0) {
+    // cls row: the module output there is LN_x(x) itself
+    const size_t g = (size_t)b * n * C + c;
+    const float* s = stats + (size_t)b * n * TS_N;
+    const float dn = to_f(dout[g]);
+    dxn[g] = dn;
+    q[TQ_LNXW] = fmaf(dn, (to_f(x[g]) - s[TS_MX]) * s[TS_RX], q[TQ_LNXW]);
+    q[TQ_LNXB] += dn;
+#pragma unroll
+    for (int k = 0; k < TQ_N; ++k) part[((size_t)b * C + c) * TQ_N + k] = q[k];
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// launchers (C % 64 == 0)
+// ------------------------------------------------------------------------------------------------
+#define MRLA_DISPATCH_TN(DT, CALL)       \
+  switch (DT) {                          \
+    case MRLA_F32:  CALL(float); break;  \
+    case MRLA_BF16: CALL(bf16_t); break; \
+    case MRLA_F16:  CALL(f16_t); break;  \
+    default: return MRLA_EINVAL;         \
+  }
+
+bool token_nhwc_applies(int C) { return C % kWave == 0; }
+
+static size_t tok_lds(int nwaves, int nred) {
+  return (size_t)nwaves * nred * kWave * sizeof(float) + (size_t)nwaves * 2 * scratch_bytes<float>();
+}
+
+int launch_token_apply_fwd_nhwc(const void* x, const void* o, const float* stats, const float* wx, const float* bx,
+                                const float* wo, const float* bo, const float* wv, const float* gate, const float* lam,
+                                void* out, int B, int n, int C, int side, int d, int res, int dtype, hipStream_t st) {
+  const int nwaves = std::min((side + kS - 1) / kS, kMaxStrips);
+  const dim3 grid(C / kWave, B), block(nwaves * kWave);
+  const size_t lds = tok_lds(nwaves, 0);
+#define CALL(TT)                                                                                                    \
+  {                                                                                                                 \
+    if (set_lds_n(token_apply_fwd_nhwc<TT>, lds) != hipSuccess) return MRLA_EHIP;                                     \
+    hipLaunchKernelGGL((token_apply_fwd_nhwc<TT>), grid, block, lds, st, (const TT*)x, (const TT*)o, stats, wx, bx, wo, \
+                       bo, wv, gate, lam, (TT*)out, n, C, side, d, res);                                            \
+    hipLaunchKernelGGL((token_cls_fwd_kernel<TT>), dim3((C + kThreads - 1) / kThreads, B), dim3(kThreads), 0, st,    \
+                       (const TT*)x, stats, wx, bx, (TT*)out, n, C, res);                                           \
+  }
+  MRLA_DISPATCH_TN(dtype, CALL)
+#undef CALL
+  return hip_status(hipGetLastError());
+}
+
+int launch_token_stats_bwd_nhwc(const void* dout, const void* x, const float* stats, const float* wx, const float* bx,
+                                const float* wv, float* bmom, int B, int n, int C, int side, int dtype, hipStream_t st) {
+  const int nwaves = std::min((side + kS - 1) / kS, kMaxStrips);
+  const dim3 grid(C / kWave, B), block(nwaves * kWave);
+  const size_t lds = tok_lds(nwaves, 1);
+#define CALL(TT)                                                                                                  \
+  {                                                                                                               \
+    if (set_lds_n(token_stats_bwd_nhwc<TT>, lds) != hipSuccess) return MRLA_EHIP;                                   \
+    hipLaunchKernelGGL((token_stats_bwd_nhwc<TT>), grid, block, lds, st, (const TT*)dout, (const TT*)x, stats, wx, bx, \
+                       wv, bmom, n, C, side);                                                                     \
+  }
+  MRLA_DISPATCH_TN(dtype, CALL)
+#undef CALL
+  return hip_status(hipGetLastError());
+}
+
+int launch_token_apply_bwd_nhwc(const void* dout, const void* x, const void* o, const float* stats, const float* wx,
+                                const float* bx, const float* wo, const float* bo, const float* wv, const float* gate,
+                                const float* lam, const float* dyx, float* dxn, float* part, int B, int n, int C,
+                                int side, int d, int dtype, hipStream_t st) {
+  const int nwaves = std::min((side + kS - 1) / kS, kMaxStrips);
+  const dim3 grid(C / kWave, B), block(nwaves * kWave);
+  const size_t lds = tok_lds(nwaves, TQ_N);
+#define CALL(TT)                                                                                                   \
+  {                                                                                                                \
+    if (set_lds_n(token_apply_bwd_nhwc<TT>, lds) != hipSuccess) return MRLA_EHIP;                                    \
+    hipLaunchKernelGGL((token_apply_bwd_nhwc<TT>), grid, block, lds, st, (const TT*)dout, (const TT*)x, (const TT*)o, \
+                       stats, wx, bx, wo, bo, wv, gate, lam, dyx, dxn, part, n, C, side, d);                       \
+  }
+  MRLA_DISPATCH_TN(dtype, CALL)
+#undef CALL
+  return hip_status(hipGetLastError());
+}
+
+}  // namespace mrla

@@ -14,7 +14,6 @@
 // lanes = channels so the 3x3 neighbours are plain LDS reads), token_ln_bwd (per token: both LayerNorm backward
 // passes).  The permutes / split / cat of the reference never touch memory: they are index arithmetic here.
 #include <algorithm>
-#include <cstdlib>
 
 #include "mrla_device.h"
 #include "mrla_kernels.h"
@@ -404,7 +403,7 @@ int launch_token_norm_pool(const void* x, const void* o, const float* wx, const 
 int launch_token_apply_fwd(const void* x, const void* o, const float* stats, const float* wx, const float* bx,
                            const float* wo, const float* bo, const float* wv, const float* gate, const float* lam,
                            void* out, int B, int n, int C, int side, int d, int res, int dtype, hipStream_t st) {
-  if (token_nhwc_applies(C) && !getenv("MRLA_TOK_TILES"))      // row-marching kernels (tokens_nhwc.hip)
+  if (token_nhwc_applies(C))                                   // row-marching kernels (tokens_nhwc.hip)
     return launch_token_apply_fwd_nhwc(x, o, stats, wx, bx, wo, bo, wv, gate, lam, out, B, n, C, side, d, res, dtype, st);
   const int CC = chunk_for(C);
   if (!CC) return MRLA_EUNSUPPORTED;
@@ -424,7 +423,7 @@ int launch_token_apply_fwd(const void* x, const void* o, const float* stats, con
 
 int launch_token_stats_bwd(const void* dout, const void* x, const float* stats, const float* wx, const float* bx,
                            const float* wv, float* bmom, int B, int n, int C, int side, int dtype, hipStream_t st) {
-  if (token_nhwc_applies(C) && !getenv("MRLA_TOK_TILES"))      // row-marching kernels (tokens_nhwc.hip)
+  if (token_nhwc_applies(C))                                   // row-marching kernels (tokens_nhwc.hip)
     return launch_token_stats_bwd_nhwc(dout, x, stats, wx, bx, wv, bmom, B, n, C, side, dtype, st);
   const int CC = chunk_for(C);
   if (!CC) return MRLA_EUNSUPPORTED;
@@ -446,7 +445,7 @@ int launch_token_apply_bwd(const void* dout, const void* x, const void* o, const
                            const float* bx, const float* wo, const float* bo, const float* wv, const float* gate,
                            const float* lam, const float* dyx, float* dxn, float* part, int B, int n, int C, int side,
                            int d, int dtype, hipStream_t st) {
-  if (token_nhwc_applies(C) && !getenv("MRLA_TOK_TILES"))      // row-marching kernels (tokens_nhwc.hip)
+  if (token_nhwc_applies(C))                                   // row-marching kernels (tokens_nhwc.hip)
     return launch_token_apply_bwd_nhwc(dout, x, o, stats, wx, bx, wo, bo, wv, gate, lam, dyx, dxn, part, B, n, C, side, d, dtype, st);
   const int CC = chunk_for(C);
   if (!CC) return MRLA_EUNSUPPORTED;

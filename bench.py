@@ -227,7 +227,9 @@ def main():
         roofline = None
         if dom:
             ach = dom["bytes"] / (dom["ms"] * 1e-3) / 1e9
-            roofline = {"bound": "hbm", "kernel": dom_name + "<bf16>", "achieved": round(ach, 1),
+            # DeiT keeps its residual stream (and therefore the token MRLA kernels) in fp32 under autocast, as the reference does
+            kdt = "fp32" if args.arch.startswith("deit") else "bf16"
+            roofline = {"bound": "hbm", "kernel": f"{dom_name}<{kdt}>", "achieved": round(ach, 1),
                         "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4),
                         "traffic": pmc_traffic(args, dom_name),
                         "launches": dom["launches"], "avg_launch_us": round(1e3 * dom["ms"] / dom["launches"], 2),

@@ -29,6 +29,19 @@ def test_argument_validation_without_a_gpu():
     assert lib.mrla_light_wgrad_rows(256, 256, 56, 56, _lib.BF16, _lib.NCHW) > 0
     assert lib.mrla_light_stats_fwd(None, None, None, None, 1, 32, 4, 4, _lib.F32, _lib.NCHW, 0, None) == _lib.EINVAL
     assert lib.mrla_light_gate_fwd(None, None, None, 4, None, 1, 32, 16, 32, None) == _lib.EINVAL
+    # channels_last MRLA-base geometry: rows of the partial buffers, supported widths, argument checks
+    assert lib.mrla_base_tile_rows(128, 1024, 14, 14, _lib.BF16, _lib.NHWC) == 128 * 28     # 7-pixel tiles
+    assert lib.mrla_base_pmom_rows(128, 1024, 14, 14, _lib.BF16, _lib.NHWC) == 128 * 14     # 14-pixel tiles
+    assert lib.mrla_base_tile_rows(4, 256, 56, 56, _lib.F32, _lib.NCHW) == 4
+    assert lib.mrla_base_tile_rows(4, 192, 14, 14, _lib.BF16, _lib.NHWC) == _lib.EUNSUPPORTED   # 24 vectors per pixel
+    assert lib.mrla_base_tile_rows(4, 2048, 7, 7, _lib.F32, _lib.NHWC) == _lib.EUNSUPPORTED    # 512 fp32 vectors per pixel
+    assert lib.mrla_base_tile_rows(0, 256, 7, 7, _lib.BF16, _lib.NHWC) == _lib.EINVAL
+    assert lib.mrla_base_pool_value_fwd(None, None, None, None, None, None, None, None, 1, 64, 4, 4, _lib.BF16, _lib.NHWC,
+                                        None) == _lib.EINVAL
+    assert lib.mrla_base_dv_combine(None, None, None, 1, 64, 4, 4, 16, 3, 1, 3, _lib.BF16, _lib.NHWC, None) == _lib.EINVAL
+    assert lib.mrla_base_pmom_reduce(None, None, 2, 64, 3, 4, None) == _lib.EINVAL
+    assert lib.mrla_light_pool_fused(None, None, None, None, None, None, 1, 64, 4, 4, _lib.BF16, _lib.NHWC, None) == _lib.EINVAL
+    assert lib.mrla_bn_moment_rows(256, 256, 56, 56, _lib.NHWC) == 256 * 4 and lib.mrla_bn_moment_rows(8, 64, 7, 7, _lib.NCHW) == 8
 
 
 def test_model_surface_matches_reference_names():

@@ -218,13 +218,14 @@ int mrla_base_pool_value_fwd(const void* x, const float* pre_sc, const float* pr
 /* pmom[b, c, t] <- sum over the rows/b tiles of an image of part[rows, t, c]. */
 int mrla_base_pmom_reduce(const float* part, float* pmom, int b, int c, int t, int rows, void* stream);
 
-/* dv[b,h,w,c] (float32) <- dV_t = sum_{t'=t..Tc} p_all[b,g,t'-1,t-1] * dA_t'. */
-int mrla_base_dv_combine(const void* da_ring, const float* p_all, float* dv, int b, int c, int h, int w, int d, int T,
+/* dv[b,h,w,c] (activation dtype, as autograd stores the gradient of a 16-bit V) <- dV_t =
+ * sum_{t'=t..Tc} p_all[b,g,t'-1,t-1] * dA_t', accumulated in fp32. */
+int mrla_base_dv_combine(const void* da_ring, const float* p_all, void* dv, int b, int c, int h, int w, int d, int T,
                          int t, int Tc, int dtype, int layout, void* stream);
 
 /* dx = [x > 0 if res bit 1] * ((res bit 0) * dOut + dwconv3x3^T(dv) + dyx);  dwv_part[rows, c, 9]
  * (rows = mrla_light_wgrad_rows()). */
-int mrla_base_value_bwd_dv(const void* dout, const void* x, const float* wv, const float* dv, const float* dyx, void* dx,
+int mrla_base_value_bwd_dv(const void* dout, const void* x, const float* wv, const void* dv, const float* dyx, void* dx,
                            float* dwv_part, int b, int c, int h, int w, int res, int dtype, int layout, void* stream);
 
 /* =====================================================================================================

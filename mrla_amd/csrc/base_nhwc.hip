@@ -13,7 +13,7 @@
 //
 //   forward : pool+value (light_nhwc.hip) -> gate (base_nchw.hip) -> base_combine<0> (attn, moments) -> tail
 //   backward: tail statistics (bnact_nhwc.hip moments with dp) -> base_attend_bwd (dA -> ring, <dA, V_j> partials)
-//             -> pmom reduce -> gate bwd -> base_combine<1> (dV_t, fp32) -> base_value_bwd (transposed 3x3, dWv)
+//             -> pmom reduce -> gate bwd -> base_combine<1> (dV_t) -> base_value_bwd (transposed 3x3, dWv)
 #include <algorithm>
 
 #include "light_nhwc.h"
@@ -93,7 +93,7 @@ __device__ __forceinline__ void reduce_same_channels(const float (&s)[VEC], floa
 // ------------------------------------------------------------------------------------------------
 // MODE 0 (attend forward):  out = sum_{j<t} P[b,g,t-1,j] * V_j   (slot t-1 first, then j = 0..t-2, as base_nchw.hip),
 //                           out rounded to T; amom_part[b*tiles + tile, c, 2] = (sum out, sum out^2) of the tile.
-// MODE 1 (value gradient):  out = sum_{l=0..Tc-t} P[b,g,t-1+l,t-1] * dA_{t+l}   kept in fp32 (OUT = float).
+// MODE 1 (value gradient):  out = sum_{l=0..Tc-t} P[b,g,t-1+l,t-1] * dA_{t+l}   stored in T (as autograd stores dV).
 // grid: (tiles, B)
 // ------------------------------------------------------------------------------------------------
 template <typename T, typename OUT, int MODE, int NV>
@@ -157,10 +157,7 @@ __global__ __launch_bounds__(kThreads) void base_combine_nhwc(const T* __restric
           s2[k] = fmaf(a, a, s2[k]);
         }
       } else {
-        float* o = reinterpret_cast<float*>(out) + base + (size_t)i * kThreads * VEC;
-#pragma unroll
-        for (int k = 0; k < VEC; k += 4)
-          *reinterpret_cast<float4*>(o + k) = make_float4(acc[i][k], acc[i][k + 1], acc[i][k + 2], acc[i][k + 3]);
+        stv<T>(reinterpret_cast<T*>(out) + base + (size_t)i * kThreads * VEC, acc[i]);
       }
     }
   }
@@ -320,21 +317,21 @@ __global__ __launch_bounds__(kThreads) void base_pmom_reduce_kernel(const float*
 
 // ------------------------------------------------------------------------------------------------
 // value backward: dx = [x > 0 if res&2] * ((res&1) * dOut + dwconv3x3^T(dV) + dyx);  dWv partials.
-// Row-marching stencil kernel, lane = channel, as light_nhwc.hip; dV arrives in fp32 from base_combine<1>.
+// Row-marching stencil kernel, lane = channel, as light_nhwc.hip; dV arrives in the storage type from base_combine<1>.
 //   dx[r][col]  = sum_{i,k} w[i][k] * dV[r-i+1][col-k+1]
 //   dWv[i][k]  += x[r][col] * dV[r-i+1][col-k+1]      (the same window, centred on x)
 // ------------------------------------------------------------------------------------------------
 template <typename T, bool WIDE>
 __global__ __launch_bounds__(kMaxStrips * kWave) void base_value_bwd_nhwc(
-    const T* __restrict__ dout, const T* __restrict__ x, const float* __restrict__ wv, const float* __restrict__ dv,
+    const T* __restrict__ dout, const T* __restrict__ x, const float* __restrict__ wv, const T* __restrict__ dv,
     const float* __restrict__ dyx, T* __restrict__ dx, float* __restrict__ dwv_part, int B, int C, int H, int W, int BG,
     int res) {
   extern __shared__ __align__(16) unsigned char smem_raw[];
   const int lane = threadIdx.x & (kWave - 1), wave = threadIdx.x / kWave, nwaves = blockDim.x / kWave;
   float* red = reinterpret_cast<float*>(smem_raw);
-  constexpr int FB = scratch_bytes<float>(), TB = scratch_bytes<T>();
+  constexpr int FB = scratch_bytes<T>(), TB = scratch_bytes<T>();
   unsigned char* my = smem_raw + (size_t)nwaves * 9 * kWave * sizeof(float) + (size_t)wave * (FB + 2 * TB);
-  float* scrF = reinterpret_cast<float*>(my);              // dV gathers
+  T* scrF = reinterpret_cast<T*>(my);                      // dV gathers
   T* scrT = reinterpret_cast<T*>(my + FB);                 // x / dOut gathers
   T* scrS = reinterpret_cast<T*>(my + FB + TB);            // dx scatters
   const int cbase = blockIdx.x * kWave, c = cbase + lane;
@@ -352,7 +349,7 @@ __global__ __launch_bounds__(kMaxStrips * kWave) void base_value_bwd_nhwc(
     const size_t ioff = (size_t)b * H * W * C;
     const T* xi = x + ioff;
     const T* gi = dout + ioff;
-    const float* ui = dv + ioff;
+    const T* ui = dv + ioff;
     T* dxo = dx + ioff;
     const float dy = dyx[(size_t)b * C + cc];
     for (int s = wave; s < nstrips; s += nwaves) {
@@ -360,29 +357,29 @@ __global__ __launch_bounds__(kMaxStrips * kWave) void base_value_bwd_nhwc(
       float ua[kS + 2], ub[kS + 2], uc[kS + 2];                 // dV rows r-1, r, r+1 on columns s0-1 .. s0+kS
 #pragma unroll
       for (int j = 0; j < kS + 2; ++j) ua[j] = 0.f;
-      read_row<float, WIDE, kS + 2>(ui, 0, s0 - 1, H, W, C, cbase, cc, lane, scrF, ub);
-      RowLoad<float, kS + 2> qu;
+      read_row<T, WIDE, kS + 2>(ui, 0, s0 - 1, H, W, C, cbase, cc, lane, scrF, ub);
+      RowLoad<T, kS + 2> qu;
       RowLoad<T, kS> qx, qg;
-      RowAddr<float, kS + 2> au;
+      RowAddr<T, kS + 2> au;
       RowAddr<T, kS> ax;
       if (WIDE) {
-        make_row_addr<float, kS + 2>(au, s0 - 1, W, C, cbase, lane);
+        make_row_addr<T, kS + 2>(au, s0 - 1, W, C, cbase, lane);
         make_row_addr<T, kS>(ax, s0, W, C, cbase, lane);
-        issue_row<float, kS + 2>(qu, ui, 1, H, W * C, au);
+        issue_row<T, kS + 2>(qu, ui, 1, H, W * C, au);
         issue_row<T, kS>(qx, xi, 0, H, W * C, ax);
         issue_row<T, kS>(qg, gi, 0, H, W * C, ax);
       }
       for (int r = 0; r < H; ++r) {
         float xr[kS], gr[kS];
         if (WIDE) {
-          finish_row<float, kS + 2>(qu, lane, scrF, uc);
+          finish_row<T, kS + 2>(qu, lane, scrF, uc);
           finish_row<T, kS>(qx, lane, scrT, xr);
           finish_row<T, kS>(qg, lane, scrT, gr);
-          issue_row<float, kS + 2>(qu, ui, r + 2, H, W * C, au);
+          issue_row<T, kS + 2>(qu, ui, r + 2, H, W * C, au);
           issue_row<T, kS>(qx, xi, r + 1, H, W * C, ax);
           issue_row<T, kS>(qg, gi, r + 1, H, W * C, ax);
         } else {
-          read_row<float, false, kS + 2>(ui, r + 1, s0 - 1, H, W, C, cbase, cc, lane, scrF, uc);
+          read_row<T, false, kS + 2>(ui, r + 1, s0 - 1, H, W, C, cbase, cc, lane, scrF, uc);
           read_row<T, false, kS>(xi, r, s0, H, W, C, cbase, cc, lane, scrT, xr);
           read_row<T, false, kS>(gi, r, s0, H, W, C, cbase, cc, lane, scrT, gr);
         }
@@ -462,13 +459,13 @@ int launch_base_attend_fwd_nhwc(const void* Vring, const float* Pall, void* attn
   return hip_status(hipGetLastError());
 }
 
-int launch_base_dv_combine_nhwc(const void* dAring, const float* Pall, float* dv, int B, int C, int HW, int d, int T,
+int launch_base_dv_combine_nhwc(const void* dAring, const float* Pall, void* dv, int B, int C, int HW, int d, int T,
                                 int t, int Tc, int dtype, hipStream_t st) {
   if (!base_nhwc_supported(C, dtype)) return MRLA_EUNSUPPORTED;
   const FlatGeo g = flat_geo(B, C, HW, dtype, kNVc);
 #define CALL(TT)                                                                                                     \
-  hipLaunchKernelGGL((base_combine_nhwc<TT, float, 1, kNVc>), dim3(g.tiles, B), dim3(kThreads), 0, st, (const TT*)dAring, \
-                     Pall, dv, (float*)nullptr, g, d, T, t, Tc);
+  hipLaunchKernelGGL((base_combine_nhwc<TT, TT, 1, kNVc>), dim3(g.tiles, B), dim3(kThreads), 0, st, (const TT*)dAring, \
+                     Pall, (TT*)dv, (float*)nullptr, g, d, T, t, Tc);
   MRLA_DISPATCH_B(dtype, CALL)
 #undef CALL
   return hip_status(hipGetLastError());
@@ -507,7 +504,7 @@ int launch_base_pmom_reduce(const float* part, float* pmom, int B, int C, int t,
   return hip_status(hipGetLastError());
 }
 
-int launch_base_value_bwd_nhwc(const void* dout, const void* x, const float* wv, const float* dv, const float* dyx,
+int launch_base_value_bwd_nhwc(const void* dout, const void* x, const float* wv, const void* dv, const float* dyx,
                                void* dx, float* dwv_part, int B, int C, int H, int W, int res, int dtype,
                                hipStream_t st) {
   const int nstrips = (W + kS - 1) / kS;
@@ -516,12 +513,12 @@ int launch_base_value_bwd_nhwc(const void* dout, const void* x, const float* wv,
   const dim3 grid((C + kWave - 1) / kWave, (B + BG - 1) / BG), block(nwaves * kWave);
   const bool wide = (C % kWave) == 0;
   const size_t tb = dtype == MRLA_F32 ? scratch_bytes<float>() : scratch_bytes<bf16_t>();
-  const size_t lds = (size_t)nwaves * 9 * kWave * sizeof(float) + (size_t)nwaves * (scratch_bytes<float>() + 2 * tb);
+  const size_t lds = (size_t)nwaves * 9 * kWave * sizeof(float) + (size_t)nwaves * 3 * tb;
 #define CALL_W(TT, WD)                                                                                              \
   {                                                                                                                 \
     if (set_lds_n(base_value_bwd_nhwc<TT, WD>, lds) != hipSuccess) return MRLA_EHIP;                                  \
-    hipLaunchKernelGGL((base_value_bwd_nhwc<TT, WD>), grid, block, lds, st, (const TT*)dout, (const TT*)x, wv, dv, dyx, \
-                       (TT*)dx, dwv_part, B, C, H, W, BG, res);                                                     \
+    hipLaunchKernelGGL((base_value_bwd_nhwc<TT, WD>), grid, block, lds, st, (const TT*)dout, (const TT*)x, wv, (const TT*)dv, \
+                       dyx, (TT*)dx, dwv_part, B, C, H, W, BG, res);                                                     \
   }
 #define CALL(TT) { if (wide) CALL_W(TT, true) else CALL_W(TT, false) }
   MRLA_DISPATCH_B(dtype, CALL)

@@ -350,7 +350,7 @@ int mrla_base_pmom_reduce(const float* part, float* pmom, int b, int c, int t, i
   return launch_base_pmom_reduce(part, pmom, b, c, t, rows / b, (hipStream_t)stream);
 }
 
-int mrla_base_dv_combine(const void* da_ring, const float* p_all, float* dv, int b, int c, int h, int w, int d, int T,
+int mrla_base_dv_combine(const void* da_ring, const float* p_all, void* dv, int b, int c, int h, int w, int d, int T,
                          int t, int Tc, int dtype, int layout, void* stream) {
   if (!da_ring || !p_all || !dv || bad_dims(b, c, h, w) || bad_dtype(dtype) || d <= 0 || c % d || bad_ring(T, t) ||
       Tc < t || Tc > T)
@@ -359,7 +359,7 @@ int mrla_base_dv_combine(const void* da_ring, const float* p_all, float* dv, int
   return launch_base_dv_combine_nhwc(da_ring, p_all, dv, b, c, h * w, d, T, t, Tc, dtype, (hipStream_t)stream);
 }
 
-int mrla_base_value_bwd_dv(const void* dout, const void* x, const float* wv, const float* dv, const float* dyx, void* dx,
+int mrla_base_value_bwd_dv(const void* dout, const void* x, const float* wv, const void* dv, const float* dyx, void* dx,
                            float* dwv_part, int b, int c, int h, int w, int res, int dtype, int layout, void* stream) {
   if (!dout || !x || !wv || !dv || !dyx || !dx || !dwv_part || bad_dims(b, c, h, w) || bad_dtype(dtype))
     return MRLA_EINVAL;

@@ -102,7 +102,7 @@ int base_nhwc_tiles(int B, int C, int HW, int dtype);
 int base_nhwc_pmom_tiles(int B, int C, int HW, int dtype);
 int launch_base_attend_fwd_nhwc(const void* Vring, const float* Pall, void* attn, float* amom_part, int B, int C, int HW,
                                 int d, int T, int t, int dtype, hipStream_t st);
-int launch_base_dv_combine_nhwc(const void* dAring, const float* Pall, float* dv, int B, int C, int HW, int d, int T,
+int launch_base_dv_combine_nhwc(const void* dAring, const float* Pall, void* dv, int B, int C, int HW, int d, int T,
                                 int t, int Tc, int dtype, hipStream_t st);
 int launch_base_tail_fwd_nhwc(const void* x, const void* attn, const float* sc, const float* sh, const float* dp,
                               void* out, int B, int C, int HW, int dtype, hipStream_t st);
@@ -110,7 +110,7 @@ int launch_base_attend_bwd_nhwc(const void* dout, const void* attn, const float*
                                 const float* cb, const void* Vring, void* dAring, float* pmom_part, int B, int C, int HW,
                                 int T, int t, int dtype, hipStream_t st);
 int launch_base_pmom_reduce(const float* part, float* pmom, int B, int C, int t, int tiles, hipStream_t st);
-int launch_base_value_bwd_nhwc(const void* dout, const void* x, const float* wv, const float* dv, const float* dyx,
+int launch_base_value_bwd_nhwc(const void* dout, const void* x, const float* wv, const void* dv, const float* dyx,
                                void* dx, float* dwv_part, int B, int C, int H, int W, int res, int dtype,
                                hipStream_t st);
 

@@ -469,11 +469,11 @@ class _BaseFn(torch.autograd.Function):
         dwv_part = torch.empty((rows, c * 9), dtype=torch.float32, device=dev)
         dx = torch.empty_like(xc)
         res = int(cfg.tail) | (2 if cfg.fuse else 0)
-        if nhwc:                # dV_t (fp32) from the dA slots t..Tc, then the transposed 3x3 pass
-            dv = torch.empty((b, h, w, c), dtype=torch.float32, device=dev)
-            _call("mrla_base_dv_combine", xc.numel() * (es * (Tc - t + 1) + 4), _ptr(stage.dA), _ptr(stage.P), _ptr(dv),
+        if nhwc:                # dV_t from the dA slots t..Tc, then the transposed 3x3 pass
+            dv = torch.empty((b, h, w, c), dtype=xc.dtype, device=dev)
+            _call("mrla_base_dv_combine", xc.numel() * es * (Tc - t + 2), _ptr(stage.dA), _ptr(stage.P), _ptr(dv),
                   b, c, h, w, d, T, t, Tc, dt, layout, st)
-            _call("mrla_base_value_bwd_dv", xc.numel() * (es * 3 + 4), _ptr(dout), _ptr(xc), _ptr(wv32), _ptr(dv),
+            _call("mrla_base_value_bwd_dv", xc.numel() * es * 4, _ptr(dout), _ptr(xc), _ptr(wv32), _ptr(dv),
                   _ptr(dyx), _ptr(dx), _ptr(dwv_part), b, c, h, w, res, dt, layout, st)
         else:
             _call("mrla_base_value_bwd", xc.numel() * es * (Tc - t + 4), _ptr(dout), _ptr(xc), _ptr(wv32),

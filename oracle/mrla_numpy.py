@@ -244,7 +244,7 @@ def _ident(a):
     return a
 
 
-def base_layer_fwd(x, wq, wk, wv, d, K_prev=None, V_prev=None, rnd=_ident):
+def base_layer_fwd(x, wq, wk, wv, d, K_prev=None, V_prev=None, rnd=_ident, rnd_dv=_ident):
     """K_prev [b,t-1,c] / V_prev [b,t-1,c,h,w] or None (init_cell).  Returns (out, K, V, cache).
     `rnd` models the storage dtype of the HIP path (identity for fp32; round-to-bf16 for bf16 activations):
     it is applied where that path stores an activation-sized tensor (v_t, attn)."""
@@ -267,7 +267,7 @@ def base_layer_fwd(x, wq, wk, wv, d, K_prev=None, V_prev=None, rnd=_ident):
     e = np.exp(logits)
     P = e / e.sum(axis=-1, keepdims=True)                       # [b,g,t]
     out = rnd(np.einsum("bgt,btgdhw->bgdhw", P, V.reshape(b, t, g, d, h, w)).reshape(b, c, h, w))
-    cache = dict(x=x, wq=wq, wk=wk, wv=wv, d=d, s=s, y=y, q=q, K=K, V=V, P=P, rnd=rnd)
+    cache = dict(x=x, wq=wq, wk=wk, wv=wv, d=d, s=s, y=y, q=q, K=K, V=V, P=P, rnd=rnd, rnd_dv=rnd_dv)
     return out, K, V, cache
 
 
@@ -287,7 +287,7 @@ def base_layer_bwd(dout, dK, dV, cache):
     dq = np.einsum("bgt,btgd->bgd", dlog, K.reshape(b, t, g, d)).reshape(b, c)
     dKtot = dK + np.einsum("bgt,bgd->btgd", dlog, q.reshape(b, g, d)).reshape(b, t, c)
     dkt = dKtot[:, -1]
-    dvt = dVtot[:, -1]
+    dvt = cache.get("rnd_dv", _ident)(dVtot[:, -1])            # dV_t as the channels_last path stores it between its two kernels
     dwq = corr1d_wgrad(dq, y, wq.shape[0])
     dwk = corr1d_wgrad(dkt, y, wk.shape[0])
     dy = corr1d_T(dq, wq) + corr1d_T(dkt, wk)
@@ -301,8 +301,8 @@ def base_layer_bwd(dout, dK, dV, cache):
 # a5: base block tail   out = x + dp[b] * relu(BN(attn))
 # ----------------------------------------------------------------------------------------------
 def base_tail_fwd(x, wq, wk, wv, gamma, beta, run_mean, run_var, d, K_prev=None, V_prev=None,
-                  training=True, dp=None, eps=1e-5, momentum=0.1, rnd=_ident):
-    attn, K, V, c1 = base_layer_fwd(x, wq, wk, wv, d, K_prev, V_prev, rnd)
+                  training=True, dp=None, eps=1e-5, momentum=0.1, rnd=_ident, rnd_dv=_ident):
+    attn, K, V, c1 = base_layer_fwd(x, wq, wk, wv, d, K_prev, V_prev, rnd, rnd_dv)
     z, c2 = bn_fwd(attn, gamma, beta, run_mean, run_var, training, eps, momentum)
     r = np.maximum(z, 0)
     dpv = np.ones(x.shape[0], dtype=x.dtype) if dp is None else dp.astype(x.dtype)

@@ -35,7 +35,7 @@ for c, hw, T, ts in ((256, 56, 3, (1, 3)), (512, 28, 4, (1, 4)), (1024, 14, 23, 
     x = torch.randn(B, hw, hw, c, device="cuda").bfloat16()
     g = torch.randn_like(x)
     attn, out, dx = torch.empty_like(x), torch.empty_like(x), torch.empty_like(x)
-    dv = torch.empty(B, hw, hw, c, device="cuda")
+    dv = torch.empty(B, hw, hw, c, device="cuda").bfloat16()
     rows = lib.mrla_base_tile_rows(B, c, hw, hw, L.BF16, L.NHWC)
     amom = torch.empty(rows, c, 2, device="cuda")
     sc, sh, cb = torch.ones(c, device="cuda"), torch.zeros(c, device="cuda"), torch.randn(c, 3, device="cuda")
@@ -50,11 +50,11 @@ for c, hw, T, ts in ((256, 56, 3, (1, 3)), (512, 28, 4, (1, 4)), (1024, 14, 23, 
     t0 = timeit(lambda: lib.mrla_base_tail_fwd(P(x), P(attn), P(sc), P(sh), None, P(out), B, c, hw, hw, L.BF16, L.NHWC, st))
     print(f"   tail_fwd            {t0 * 1e6:8.1f} us  {3 * n * 2 / t0 / 1e12:5.2f} TB/s")
     t0 = timeit(lambda: lib.mrla_base_value_bwd_dv(P(g), P(x), P(wv), P(dv), P(dyx), P(dx), P(dwv), B, c, hw, hw, 3, L.BF16, L.NHWC, st))
-    print(f"   value_bwd_dv        {t0 * 1e6:8.1f} us  {n * (3 * 2 + 4) / t0 / 1e12:5.2f} TB/s")
+    print(f"   value_bwd_dv        {t0 * 1e6:8.1f} us  {n * 4 * 2 / t0 / 1e12:5.2f} TB/s")
     for t in ts:
         part = torch.empty(lib.mrla_base_pmom_rows(B, c, hw, hw, L.BF16, L.NHWC), t, c, device="cuda")
         ta = timeit(lambda: lib.mrla_base_attend_fwd(None, P(wv), P(ring), P(Pall), P(attn), P(amom), B, c, hw, hw, d, T, t, L.BF16, L.NHWC, st))
         tb = timeit(lambda: lib.mrla_base_attend_bwd(P(g), P(attn), P(sc), P(sh), None, P(cb), P(ring), P(dA), P(part), B, c, hw, hw, T, t, L.BF16, L.NHWC, st))
         tc = timeit(lambda: lib.mrla_base_dv_combine(P(dA), P(Pall), P(dv), B, c, hw, hw, d, T, T - t + 1, T, L.BF16, L.NHWC, st))
         print(f"   t={t:2d} attend_fwd {ta * 1e6:8.1f} us {(t + 1) * n * 2 / ta / 1e12:5.2f} TB/s | attend_bwd {tb * 1e6:8.1f} us "
-              f"{(t + 3) * n * 2 / tb / 1e12:5.2f} TB/s | dv_combine({t} slots) {tc * 1e6:8.1f} us {n * (t * 2 + 4) / tc / 1e12:5.2f} TB/s")
+              f"{(t + 3) * n * 2 / tb / 1e12:5.2f} TB/s | dv_combine({t} slots) {tc * 1e6:8.1f} us {n * (t + 1) * 2 / tc / 1e12:5.2f} TB/s")

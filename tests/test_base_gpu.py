@@ -111,7 +111,8 @@ def test_base_chain_fp32_vs_oracle_and_reference(case, mode, cl):
         assert relmax(got[t]["grad/mrla.mrla.Wv.weight"], G[key + "grad/mrla.mrla.Wv.weight"]) < 2e-4
 
 
-@pytest.mark.parametrize("shape", [(3, 256, 56, 56, 16, 3), (2, 1024, 14, 14, 16, 6), (2, 2048, 7, 7, 16, 3)],
+@pytest.mark.parametrize("shape", [(3, 256, 56, 56, 16, 3), (2, 1024, 14, 14, 16, 6), (2, 2048, 7, 7, 16, 3),
+                                   (2, 256, 7, 7, 1, 3)],         # last: channel_wise_mrla (one head per channel)
                          ids=lambda s: "x".join(map(str, s)))
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16], ids=["fp32", "bf16"])
 @pytest.mark.parametrize("cl", [False, True], ids=["nchw", "nhwc"])

@@ -85,7 +85,7 @@ def test_light_tail_fp32_vs_oracle_and_reference(case, mode, cl):
     assert relmax(got["rv"], cache["bn"]["new_rv"]) < ACT_TOL
     for ours, theirs in (("mrla.mrla.Wq.weight", "dwq"), ("mrla.mrla.Wk.weight", "dwk"), ("mrla.mrla.Wv.weight", "dwv"),
                          ("mrla.lambda_t", "dlam"), ("bn_mrla.weight", "dgamma"), ("bn_mrla.bias", "dbeta")):
-        assert relmax(got["grad/" + ours].ravel(), np.asarray(g[theirs]).ravel()) < PAR_TOL, ours
+        assert relmax(got["grad/" + ours].ravel(), np.asarray(g[theirs]).ravel()) < (2e-2 if (dtype != torch.float32 and b * h * w <= 9) else ptol), ours
     # and directly against what the reference itself produced (fp32, so its own rounding is in the budget)
     sub = (lambda a: a[:, ::8]) if name == "s2048" else (lambda a: a)
     assert relmax(sub(got["out"]), G[key + "out"]) < 2e-5
@@ -108,8 +108,10 @@ def assert_bf16_close(got, want64, what):
 
 # (17, 256, 56, 56): 4352 slabs -> workgroups loop over 2 images each, ragged last group;
 # (3, 2048, 7, 7): 2048 channels do not divide into 72-plane slabs -> ragged last slab.
+# (2, 64, 1, 1) / (3, 64, 1, 3) / (2, 128, 3, 1): degenerate maps -- every tap but the centre (or a row / column of
+# taps) falls into the padding; (1, 256, 9, 9): a single image (BatchNorm over h*w only), 2 strips with a ragged one.
 STAGE_SHAPES = [(4, 256, 56, 56, 32), (4, 512, 28, 28, 32), (4, 1024, 14, 14, 32), (3, 2048, 7, 7, 32),
-                (17, 256, 56, 56, 32)]
+                (17, 256, 56, 56, 32), (2, 64, 1, 1, 32), (3, 64, 1, 3, 32), (2, 128, 3, 1, 32), (1, 256, 9, 9, 32)]
 
 
 @pytest.mark.parametrize("shape", STAGE_SHAPES, ids=lambda s: "x".join(map(str, s[:4])))
@@ -128,17 +130,22 @@ def test_light_tail_resnet50_stage_shapes(shape, dtype, cl):
         x, o, gup = bf16_round(x), bf16_round(o), bf16_round(gup)
     got = run_light(x, o, P, d, "train", mask, 0.2, gup, dtype, cl=cl)
     out, cache, g = oracle_light(x, o, P, d, "train", mask, 0.2, gup)
+    # BatchNorm over a handful of values (b*h*w <= 9) is ill-conditioned: 1/sigma amplifies the fp32 input rounding
+    tol, ptol = (ACT_TOL, PAR_TOL) if b * h * w > 9 else (20 * ACT_TOL, 20 * PAR_TOL)
     if dtype == torch.float32:
-        assert relmax(got["out"], out) < ACT_TOL
-        assert relmax(got["dx"], g["dx"]) < ACT_TOL
-        assert relmax(got["do"], g["do_prev"]) < ACT_TOL
+        assert relmax(got["out"], out) < tol
+        assert relmax(got["dx"], g["dx"]) < tol
+        assert relmax(got["do"], g["do_prev"]) < tol
+    elif b * h * w <= 9:
+        for k, want in (("out", out), ("dx", g["dx"]), ("do", g["do_prev"])):
+            assert relmax(got[k], want) < 2.0 ** -6, k
     else:
         assert_bf16_close(got["out"], out, "out")
         assert_bf16_close(got["dx"], g["dx"], "dx")
         assert_bf16_close(got["do"], g["do_prev"], "do")
     for ours, theirs in (("mrla.mrla.Wq.weight", "dwq"), ("mrla.mrla.Wk.weight", "dwk"), ("mrla.mrla.Wv.weight", "dwv"),
                          ("mrla.lambda_t", "dlam"), ("bn_mrla.weight", "dgamma"), ("bn_mrla.bias", "dbeta")):
-        assert relmax(got["grad/" + ours].ravel(), np.asarray(g[theirs]).ravel()) < PAR_TOL, ours
+        assert relmax(got["grad/" + ours].ravel(), np.asarray(g[theirs]).ravel()) < (2e-2 if (dtype != torch.float32 and b * h * w <= 9) else ptol), ours
 
 
 def test_fused_relu_add_producer_fp32_and_bf16():

@@ -85,7 +85,7 @@ def test_light_tail_fp32_vs_oracle_and_reference(case, mode, cl):
     assert relmax(got["rv"], cache["bn"]["new_rv"]) < ACT_TOL
     for ours, theirs in (("mrla.mrla.Wq.weight", "dwq"), ("mrla.mrla.Wk.weight", "dwk"), ("mrla.mrla.Wv.weight", "dwv"),
                          ("mrla.lambda_t", "dlam"), ("bn_mrla.weight", "dgamma"), ("bn_mrla.bias", "dbeta")):
-        assert relmax(got["grad/" + ours].ravel(), np.asarray(g[theirs]).ravel()) < (2e-2 if (dtype != torch.float32 and b * h * w <= 9) else ptol), ours
+        assert relmax(got["grad/" + ours].ravel(), np.asarray(g[theirs]).ravel()) < PAR_TOL, ours
     # and directly against what the reference itself produced (fp32, so its own rounding is in the budget)
     sub = (lambda a: a[:, ::8]) if name == "s2048" else (lambda a: a)
     assert relmax(sub(got["out"]), G[key + "out"]) < 2e-5

@@ -83,3 +83,25 @@ def test_product_det_backbone_surface():
     net2 = mb.ResNet_mrlal(norm_eval=False, frozen_stages=-1).train()
     assert all(m.training for m in net2.modules() if isinstance(m, torch.nn.BatchNorm2d))
     assert all(p.requires_grad for p in net2.parameters())
+
+
+def test_product_det_backbone_loads_a_classification_checkpoint(tmp_path):
+    """init_cfg=dict(type='Pretrained', checkpoint=...) as in the reference's mmdet configs: a classification checkpoint
+    written by resnet/train.py (`{'state_dict': {'module.<key>': ...}}`, with fc.*) initialises the backbone."""
+    import io
+    from contextlib import redirect_stdout
+
+    from mrla_amd import mmdet_backbone as mb, models
+    with redirect_stdout(io.StringIO()):
+        cls = models.resnet50_mrlal()
+    with torch.no_grad():
+        for p in cls.parameters():
+            p.add_(0.01)
+    path = tmp_path / "checkpoint.pth.tar"
+    torch.save({"epoch": 1, "arch": "resnet50_mrlal", "state_dict": {"module." + k: v for k, v in cls.state_dict().items()}},
+               path)
+    net = mb.ResNet_mrlal(init_cfg=dict(type="Pretrained", checkpoint=str(path)))
+    sd, ref = net.state_dict(), cls.state_dict()
+    assert "fc.weight" not in sd
+    for k in sd:
+        assert torch.equal(sd[k], ref[k]), k

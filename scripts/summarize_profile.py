@@ -17,7 +17,8 @@ out = sys.argv[2] if len(sys.argv) > 2 else raw
 def short(name):
     for key in ("light_stats_fwd", "light_apply_fwd", "light_stats_bwd", "light_apply_bwd", "plane_moments_small",
                 "plane_moments", "affine_act", "nhwc_moments_flat", "nhwc_affine_flat", "nhwc_moments", "nhwc_affine",
-                "base_combine", "base_attend_fwd", "base_attend_bwd", "base_value_bwd", "base_tail", "base_pmom",
+                "base_combine_nhwcIDF16bDF16bLi0", "base_combine_nhwcIDF16bDF16bLi1", "base_combine", "base_attend_fwd",
+                "base_attend_bwd", "base_value_bwd", "base_tail", "base_pmom",
                 "plain_bn_fwd", "plain_bn_bwd", "reduce_rows"):
         if key in name:
             return key

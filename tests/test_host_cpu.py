@@ -98,3 +98,31 @@ def test_state_dict_layout_equals_reference():
     with redirect_stdout(io.StringIO()):
         net2 = models.resnet50_mrlal()
     net2.load_state_dict({k[len("module."):]: v for k, v in loaded["state_dict"].items()})   # DDP prefix, as train.py saves it
+
+
+@pytest.mark.parametrize("layout_name", ["NCHW", "NHWC"])
+def test_base_stage_ring_bookkeeping(layout_name):
+    """Host logic of the MRLA-base history (mrla_base_module.py:65-70 replaced by rings): the views a layer returns have
+    the reference's shapes K[b,t,c], V[b,t,c,h,w] in both storage orders, growth keeps what was written, and the history
+    may not grow once its backward pass has begun."""
+    from mrla_amd import _lib, functional as Fm
+    layout = getattr(_lib, layout_name)
+    b, c, h, w, d = 2, 64, 3, 5, 16
+    st = Fm.BaseStage(b, c, h, w, d, torch.float32, torch.device("cpu"), 2, layout)
+    assert st.T == 2 and st.V.shape == ((2, b, h, w, c) if layout == _lib.NHWC else (b, 2, c, h, w))
+    for t in range(5):                                       # capacity hint 2: two doublings on the way to 5 layers
+        st.reserve_slot()
+        st.slot(st.V, t).fill_(float(t + 1))
+        st.K[:, t].fill_(float(-(t + 1)))
+        st.t = t + 1
+        K, V = st.views()
+        assert tuple(K.shape) == (b, t + 1, c) and tuple(V.shape) == (b, t + 1, c, h, w)
+        assert K._mrla_stage is st and V._mrla_stage is st
+        for j in range(t + 1):
+            assert float(V[:, j].min()) == float(V[:, j].max()) == j + 1 and float(K[:, j].max()) == -(j + 1)
+    assert st.T == 8
+    assert st.backward_buffers() is True and st.backward_buffers() is False      # first touch reported once
+    assert st.dA.shape == st.V.shape and st.dK.shape == st.K.shape
+    st.t = st.T
+    with pytest.raises(_lib.MrlaHipError):
+        st.reserve_slot()

@@ -126,3 +126,26 @@ def test_base_stage_ring_bookkeeping(layout_name):
     st.t = st.T
     with pytest.raises(_lib.MrlaHipError):
         st.reserve_slot()
+
+
+def test_host_helpers_follow_the_reference_rules():
+    """k_size rule (mrla_light_module.py:40-42), heads from dim_perhead (:33-38), stochastic depth (utils/drop.py:7-24)."""
+    from mrla_amd import functional as Fm, layers
+    from oracle import eager_models as em
+    assert [Fm.k_size_for(c) for c in (64, 128, 192, 256, 512, 1024, 2048)] == [3, 5, 5, 5, 5, 5, 7]
+    assert all(Fm.k_size_for(c) == em.k_size_for(c) for c in (16, 32, 48, 96, 384, 768, 4096))
+    assert layers._heads_and_ksize(256, None, 32, None) == (8, 5) and layers._heads_and_ksize(64, 4, None, 9) == (4, 9)
+    assert layers.drop_path_scale(8, 0.0, True, "cpu") is None and layers.drop_path_scale(8, 0.3, False, "cpu") is None
+    torch.manual_seed(0)
+    s = layers.drop_path_scale(20000, 0.25, True, "cpu")
+    assert set(s.unique().tolist()) == {0.0, 1.0 / 0.75}                       # dropped, or kept and rescaled
+    assert abs(s.mean().item() - 1.0) < 0.02                                    # unbiased in expectation
+    # same draw as the reference formula for the same RNG state
+    torch.manual_seed(3)
+    a = layers.drop_path_scale(64, 0.2, True, "cpu")
+    torch.manual_seed(3)
+    b = torch.floor(0.8 + torch.rand((64,))) / 0.8
+    assert torch.equal(a, b)
+    dp = layers.DropPath(0.2).eval()
+    x = torch.ones(3, 2, 2)
+    assert dp(x) is x

@@ -138,7 +138,7 @@ def test_host_helpers_follow_the_reference_rules():
     assert layers.drop_path_scale(8, 0.0, True, "cpu") is None and layers.drop_path_scale(8, 0.3, False, "cpu") is None
     torch.manual_seed(0)
     s = layers.drop_path_scale(20000, 0.25, True, "cpu")
-    assert set(s.unique().tolist()) == {0.0, 1.0 / 0.75}                       # dropped, or kept and rescaled
+    assert set(s.unique().tolist()) == {0.0, float(torch.tensor(1.0) / 0.75)}   # dropped, or kept and rescaled
     assert abs(s.mean().item() - 1.0) < 0.02                                    # unbiased in expectation
     # same draw as the reference formula for the same RNG state
     torch.manual_seed(3)

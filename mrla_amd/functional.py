@@ -71,6 +71,42 @@ def _f32(t):
     return t.contiguous()
 
 
+def _on_device(fn):
+    """Run a Function.forward / backward body with the tensor argument's device current: the C ABI launches on the current
+    HIP device and on the stream handed over, while the buffers live on x.device (a model on cuda:1 in a process whose
+    current device is cuda:0 would otherwise launch on the wrong device)."""
+    import functools
+
+    @functools.wraps(fn)
+    def wrapped(ctx, x, *args):
+        if isinstance(x, torch.Tensor) and x.is_cuda and x.device.index != torch.cuda.current_device():
+            with torch.cuda.device(x.device):
+                return fn(ctx, x, *args)
+        return fn(ctx, x, *args)
+    return wrapped
+
+
+class _RunningStats:
+    """running_mean / running_var as the contiguous float32 buffers the kernels read and (train mode) update in place.
+    Buffers of another dtype or layout (model.half() / .bfloat16(), as the reference tolerates) go through float32 copies
+    that are written back after the update; a wrong size raises."""
+
+    def __init__(self, rm, rv, c, what):
+        for t in (rm, rv):
+            if t is None or not t.is_cuda or t.numel() != c:
+                raise L.MrlaHipError(f"{what}: running statistics must be CUDA tensors with {c} elements")
+        self.src = (rm, rv)
+        ok = all(t.dtype == torch.float32 and t.is_contiguous() for t in (rm, rv))
+        self.rm, self.rv = (rm, rv) if ok else (rm.detach().float().contiguous(), rv.detach().float().contiguous())
+        self.copy_back = not ok
+
+    def finish(self, updated):
+        if self.copy_back and updated:
+            with torch.no_grad():
+                self.src[0].copy_(self.rm)
+                self.src[1].copy_(self.rv)
+
+
 def _require_cuda(x, what):
     if not x.is_cuda:
         raise L.MrlaHipError(f"{what}: got a {x.device} tensor. mrla_amd runs only on an AMD GPU through libmrla_hip.so; "
@@ -116,11 +152,18 @@ class _LightFn(torch.autograd.Function):
     """
 
     @staticmethod
+    @_on_device
     def forward(ctx, x, o_prev, wq, wk, wv, lam, gamma, beta, running_mean, running_var, dp, cfg):
         _require_cuda(x, "mrla light forward")
         layout, xc = _layout_of(x)
         b, c, h, w = xc.shape
         d = cfg.d
+        # NCHW is the reference's contract for any map size (mmdet: 800x1333); the NCHW slab kernels need a plane row to
+        # fit one wave and a slab to fit the LDS.  Shapes beyond that run on the NHWC kernels through ONE internal
+        # channels_last conversion, and the result goes back to NCHW-contiguous memory.
+        via_nhwc = layout == L.NCHW and L.load().mrla_light_wgrad_rows(b, c, h, w, _DT[xc.dtype], L.NCHW) == L.EUNSUPPORTED
+        if via_nhwc:
+            layout, xc = L.NHWC, xc.contiguous(memory_format=_CL)
         if c % d:
             raise L.MrlaHipError(f"channels ({c}) not divisible by dim_perhead ({d})")
         oc = None
@@ -155,16 +198,17 @@ class _LightFn(torch.autograd.Function):
             bnbuf = None
             if cfg.bn_mode != L.BN_NONE:
                 gamma32, beta32 = _f32(gamma), _f32(beta)
+                rs = _RunningStats(running_mean, running_var, c, "mrla light forward")
                 bnbuf = torch.empty((4, c), dtype=torch.float32, device=dev)
                 L.call("mrla_light_bn_fwd", _ptr(mom), _ptr(gate), _ptr(lam32), _ptr(gamma32), _ptr(beta32),
-                       _ptr(running_mean), _ptr(running_var), cfg.bn_mode, float(cfg.momentum), float(cfg.eps),
+                       _ptr(rs.rm), _ptr(rs.rv), cfg.bn_mode, float(cfg.momentum), float(cfg.eps),
                        _ptr(bnbuf[0]), _ptr(bnbuf[1]), _ptr(bnbuf[2]), _ptr(bnbuf[3]), b, c, h * w, d, st)
             out = torch.empty_like(xc)
             _call("mrla_light_apply_fwd_fused", xc.numel() * xc.element_size() * 3, _ptr(xc), _ptr(psc), _ptr(psh),
                   _ptr(oc), _ptr(wv32), _ptr(gate), _ptr(bnbuf[0]) if bnbuf is not None else None,
                   _ptr(bnbuf[1]) if bnbuf is not None else None, _ptr(lam32), _ptr(dp32), _ptr(out), b, c, h, w, d,
                   cfg.res, dt, layout, st)
-            return out
+            return out.contiguous() if via_nhwc else out
         if cfg.fuse:
             pre, xc = xc, torch.empty_like(xc)
             psc, psh = cfg.pre_affine if cfg.pre_affine is not None else (None, None)
@@ -178,12 +222,12 @@ class _LightFn(torch.autograd.Function):
         bnbuf = gamma32 = None
         if cfg.bn_mode != L.BN_NONE:
             gamma32, beta32 = _f32(gamma), _f32(beta)
-            if running_mean.dtype != torch.float32 or not running_mean.is_contiguous():
-                raise L.MrlaHipError("running statistics must be contiguous float32 buffers")
+            rs = _RunningStats(running_mean, running_var, c, "mrla light forward")
             bnbuf = torch.empty((4, c), dtype=torch.float32, device=dev)       # sc, sh, save_mean, save_inv
             L.call("mrla_light_bn_fwd", _ptr(mom), _ptr(gate), _ptr(lam32), _ptr(gamma32), _ptr(beta32),
-                   _ptr(running_mean), _ptr(running_var), cfg.bn_mode, float(cfg.momentum), float(cfg.eps),
+                   _ptr(rs.rm), _ptr(rs.rv), cfg.bn_mode, float(cfg.momentum), float(cfg.eps),
                    _ptr(bnbuf[0]), _ptr(bnbuf[1]), _ptr(bnbuf[2]), _ptr(bnbuf[3]), b, c, h * w, d, st)
+            rs.finish(cfg.bn_mode == L.BN_TRAIN)
         out = torch.empty_like(xc)
         _call("mrla_light_apply_fwd", xc.numel() * xc.element_size() * (3 if oc is not None else 2), _ptr(xc), _ptr(oc), _ptr(wv32), _ptr(gate),
                _ptr(bnbuf[0]) if bnbuf is not None else None, _ptr(bnbuf[1]) if bnbuf is not None else None,
@@ -195,9 +239,10 @@ class _LightFn(torch.autograd.Function):
         ctx.pdtypes = (wq.dtype, wk.dtype, wv.dtype, lam.dtype if lam is not None else None,
                        gamma.dtype if gamma is not None else None)
         ctx.save_for_backward(xc, oc, wq32, wk32, wv32, lam32, gamma32, dp32, mom, gate, bnbuf)
-        return out
+        return out.contiguous() if via_nhwc else out
 
     @staticmethod
+    @_on_device
     def backward(ctx, dout):
         xc, oc, wq32, wk32, wv32, lam32, gamma32, dp32, mom, gate, bnbuf = ctx.saved_tensors
         cfg, layout, ks = ctx.cfg, ctx.layout, ctx.ks
@@ -293,6 +338,8 @@ class BaseStage:
         self.T = max(1, int(capacity))
         self.t = 0
         self.bwd_started = False
+        self.bwd_last_t = 0       # layer index of the previous backward call (calls of one pass come in decreasing t)
+        self.bwd_top = 0          # deepest layer that took part in the current backward pass
         self.V = torch.empty(self._vshape(self.T), dtype=dtype, device=device)
         self.K = torch.empty((b, self.T, c), dtype=torch.float32, device=device)
         self.P = torch.empty((b, c // d, self.T, self.T), dtype=torch.float32, device=device)
@@ -301,9 +348,15 @@ class BaseStage:
     @staticmethod
     def layout_for(x, d):
         """MRLA_NHWC when `x` is a channels_last tensor the slot-major NHWC kernels handle, else MRLA_NCHW."""
-        if x.dim() == 4 and not x.is_contiguous() and x.is_contiguous(memory_format=_CL) and x.dtype in _DT:
+        if x.dim() == 4 and x.dtype in _DT:
             b, c, h, w = x.shape
-            if L.load().mrla_base_tile_rows(b, c, h, w, _DT[x.dtype], L.NHWC) > 0:
+            lib = L.load()
+            nhwc_ok = lib.mrla_base_tile_rows(b, c, h, w, _DT[x.dtype], L.NHWC) > 0
+            if not x.is_contiguous() and x.is_contiguous(memory_format=_CL) and nhwc_ok:
+                return L.NHWC
+            # NCHW tensors the slab kernels cannot take (plane rows wider than a wave, slabs beyond the LDS) go through one
+            # internal channels_last conversion per layer instead of failing (the reference accepts any map size)
+            if nhwc_ok and lib.mrla_light_wgrad_rows(b, c, h, w, _DT[x.dtype], L.NCHW) == L.EUNSUPPORTED:
                 return L.NHWC
         return L.NCHW
 
@@ -334,12 +387,18 @@ class BaseStage:
         P[:, :, :t, :t].copy_(self.P[:, :, :t, :t])
         self.V, self.K, self.P, self.T = V, K, P, T2
 
-    def backward_buffers(self):
+    def begin_layer_backward(self, t):
+        """Called by layer t's backward.  Returns True on the first call of a backward PASS: then the dK ring is re-zeroed
+        and `bwd_top` (the deepest layer whose dA slot this pass fills) is reset.  A pass is recognised by t not
+        decreasing -- a repeated backward over the same graph (retain_graph=True, two losses) starts again at the top."""
         if self.dA is None:
             self.dA = torch.empty_like(self.V)
             self.dK = torch.empty_like(self.K)
-        first = not self.bwd_started
+        first = (not self.bwd_started) or t >= self.bwd_last_t
         self.bwd_started = True
+        self.bwd_last_t = t
+        if first:
+            self.bwd_top = t
         return first
 
     def views(self):
@@ -363,6 +422,7 @@ class _BaseFn(torch.autograd.Function):
     no tail: out = attn  (bare mrla_base_layer)."""
 
     @staticmethod
+    @_on_device
     def forward(ctx, x, identity, wq, wk, wv, gamma, beta, running_mean, running_var, dp, stage, cfg):
         _require_cuda(x, "mrla base forward")
         layout, xc = _layout_of(x, stage.layout)    # the stage's rings fix the layout (NHWC rings are slot-major)
@@ -413,10 +473,12 @@ class _BaseFn(torch.autograd.Function):
         out = attn
         if cfg.tail:
             gamma32, beta32 = _f32(gamma), _f32(beta)
+            rs = _RunningStats(running_mean, running_var, c, "mrla base forward")
             bnbuf = torch.empty((4, c), dtype=torch.float32, device=dev)
-            L.call("mrla_bn_stats_fwd", _ptr(amom), _ptr(gamma32), _ptr(beta32), _ptr(running_mean), _ptr(running_var),
+            L.call("mrla_bn_stats_fwd", _ptr(amom), _ptr(gamma32), _ptr(beta32), _ptr(rs.rm), _ptr(rs.rv),
                    cfg.bn_mode, float(cfg.momentum), float(cfg.eps), _ptr(bnbuf[0]), _ptr(bnbuf[1]), _ptr(bnbuf[2]),
                    _ptr(bnbuf[3]), arows, c, b * h * w // arows, st)
+            rs.finish(cfg.bn_mode == L.BN_TRAIN)
             out = torch.empty_like(xc)
             _call("mrla_base_tail_fwd", xc.numel() * xc.element_size() * 3, _ptr(xc), _ptr(attn), _ptr(bnbuf[0]),
                   _ptr(bnbuf[1]), _ptr(dp32), _ptr(out), b, c, h, w, dt, layout, st)
@@ -425,20 +487,24 @@ class _BaseFn(torch.autograd.Function):
         ctx.wv_stride = wv.stride()
         ctx.pdtypes = (wq.dtype, wk.dtype, wv.dtype, gamma.dtype if gamma is not None else None)
         ctx.save_for_backward(xc, attn if cfg.tail else None, wq32, wk32, wv32, gamma32, dp32, mom, q, bnbuf)
+        if nhwc and x.is_contiguous() and not x.is_contiguous(memory_format=_CL):
+            return out.contiguous()          # an NCHW caller of an NHWC stage gets NCHW-contiguous memory back
         return out
 
     @staticmethod
+    @_on_device
     def backward(ctx, dout):
         xc, attn, wq32, wk32, wv32, gamma32, dp32, mom, q, bnbuf = ctx.saved_tensors
         cfg, layout, ks, stage, t = ctx.cfg, ctx.layout, ctx.ks, ctx.stage, ctx.t
         b, c, h, w = xc.shape
-        d, T, Tc = cfg.d, stage.T, stage.t
+        d, T = cfg.d, stage.T
         dt, dev, st = _DT[xc.dtype], xc.device, _stream()
         if dout.dtype != xc.dtype:
             dout = dout.to(xc.dtype)
         dout = _layout_of(dout, layout)[1]
         nhwc = layout == L.NHWC
-        first = stage.backward_buffers()
+        first = stage.begin_layer_backward(t)
+        Tc = stage.bwd_top            # later layers that received no gradient in this pass left no dA slot behind
         es = xc.element_size()
 
         cb = dgamma = dbeta = None
@@ -513,6 +579,7 @@ class _TokenLightFn(torch.autograd.Function):
     (deit_mrla_light.py:194-209 and the block residual :234)."""
 
     @staticmethod
+    @_on_device
     def forward(ctx, x, o_prev, lnx_w, lnx_b, lno_w, lno_b, wq, wk, wv, lam, d, eps, res):
         _require_cuda(x, "mrla token forward")
         if x.dim() != 3 or o_prev.shape != x.shape or o_prev.dtype != x.dtype:
@@ -542,6 +609,7 @@ class _TokenLightFn(torch.autograd.Function):
         return out
 
     @staticmethod
+    @_on_device
     def backward(ctx, dout):
         xc, oc, wxw, wxb, wow, wob, wq32, wk32, wv32, lam32, stats, mom, gate = ctx.saved_tensors
         b, n, c = xc.shape
@@ -589,6 +657,7 @@ class _BnActFn(torch.autograd.Function):
     consumer (the fused MRLA producer) to apply.  The backward is the same either way."""
 
     @staticmethod
+    @_on_device
     def forward(ctx, x, gamma, beta, running_mean, running_var, training, momentum, eps, relu, defer=False):
         _require_cuda(x, "fused bn/act forward")
         layout, xc = _layout_of(x)
@@ -597,14 +666,16 @@ class _BnActFn(torch.autograd.Function):
             layout, xc = _layout_of(x, L.NCHW)           # the NHWC passes move 16-byte channel vectors
         dt, dev, st = _DT[xc.dtype], xc.device, _stream()
         gamma32, beta32 = _f32(gamma), _f32(beta)
+        rs = _RunningStats(running_mean, running_var, c, "fused bn/act forward")
         bnbuf = torch.empty((4, c), dtype=torch.float32, device=dev)       # sc, sh, save_mean, save_inv
         rows = L.load().mrla_bn_moment_rows(b, c, h, w, layout)           # partial-sum rows (b, or b*nsplit for NHWC)
         amom = torch.empty((rows, c, 2), dtype=torch.float32, device=dev)
         if training:
             _call("mrla_bn_plane_moments", xc.numel() * xc.element_size(), _ptr(xc), _ptr(amom), b, c, h, w, dt, layout, st)
-        L.call("mrla_bn_stats_fwd", _ptr(amom), _ptr(gamma32), _ptr(beta32), _ptr(running_mean), _ptr(running_var),
+        L.call("mrla_bn_stats_fwd", _ptr(amom), _ptr(gamma32), _ptr(beta32), _ptr(rs.rm), _ptr(rs.rv),
                L.BN_TRAIN if training else L.BN_EVAL, float(momentum), float(eps), _ptr(bnbuf[0]), _ptr(bnbuf[1]),
                _ptr(bnbuf[2]), _ptr(bnbuf[3]), rows, c, b * h * w // rows, st)
+        rs.finish(training)
         ctx.training, ctx.relu, ctx.gdtype, ctx.layout, ctx.rows = training, int(relu), gamma.dtype, layout, rows
         ctx.save_for_backward(xc, gamma32, bnbuf)
         if defer:
@@ -618,6 +689,7 @@ class _BnActFn(torch.autograd.Function):
         return y
 
     @staticmethod
+    @_on_device
     def backward(ctx, dy, _dbuf=None):
         xc, gamma32, bnbuf = ctx.saved_tensors
         b, c, h, w = xc.shape

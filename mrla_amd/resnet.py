@@ -3,8 +3,8 @@ state_dict names, factory names), whose MRLA block tails run on libmrla_hip.so. 
 convolutions / BatchNorms stay stock PyTorch (MIOpen), as in the reference.
 
 Reference counterparts: resnet/models/resnet_mrla_light.py:47-250, resnet/models/resnet_mrla_base.py:55-283.
-SE / ECA options (off in every BASELINE config) are accepted and rejected
-explicitly rather than silently ignored.
+SE / ECA options (off in every BASELINE config) keep their constructor arguments and
+state_dict keys and run as plain eager PyTorch modules on bn3's output (outside the accelerated path).
 """
 import torch
 import torch.nn as nn
@@ -22,14 +22,42 @@ def _conv1x1(cin, cout, stride=1):
     return nn.Conv2d(cin, cout, 1, stride=stride, bias=False)
 
 
+class se_layer(nn.Module):
+    """Squeeze-and-excitation gate (resnet/models/modules/se_module.py:9-24), eager PyTorch: not on the hot path."""
+
+    def __init__(self, channel, reduction=16):
+        super().__init__()
+        self.avg_pool = nn.AdaptiveAvgPool2d(1)
+        self.fc = nn.Sequential(nn.Linear(channel, channel // reduction, bias=False), nn.ReLU(inplace=True),
+                                nn.Linear(channel // reduction, channel, bias=False), nn.Sigmoid())
+
+    def forward(self, x):
+        b, c = x.shape[:2]
+        return x * self.fc(self.avg_pool(x).view(b, c)).view(b, c, 1, 1)
+
+
+class eca_layer(nn.Module):
+    """ECA gate (resnet/models/modules/eca_module.py:8-35), eager PyTorch: not on the hot path."""
+
+    def __init__(self, channel, k_size=None):
+        super().__init__()
+        if k_size is None:
+            k_size = F_.k_size_for(channel)
+        self.avg_pool = nn.AdaptiveAvgPool2d(1)
+        self.conv = nn.Conv1d(1, 1, kernel_size=k_size, padding=(k_size - 1) // 2, bias=False)
+        self.sigmoid = nn.Sigmoid()
+
+    def forward(self, x):
+        y = self.conv(self.avg_pool(x).squeeze(-1).transpose(-1, -2)).transpose(-1, -2).unsqueeze(-1)
+        return x * self.sigmoid(y)
+
+
 class _BottleneckTrunk(nn.Module):
     """conv1x1-bn-relu, conv3x3-bn-relu, conv1x1-bn, shortcut add, relu: everything in front of the MRLA tail."""
     expansion = 4
 
     def __init__(self, inplanes, planes, stride, downsample, SE, ECA_size, groups, base_width, dilation, norm_layer):
         super().__init__()
-        if SE or ECA_size is not None:
-            raise NotImplementedError("SE / ECA channel attention inside MRLA blocks is outside this build's scope")
         norm_layer = norm_layer or nn.BatchNorm2d
         width = int(planes * (base_width / 64.0)) * groups
         self.conv1 = _conv1x1(inplanes, width)
@@ -41,8 +69,8 @@ class _BottleneckTrunk(nn.Module):
         self.relu = nn.ReLU(inplace=True)
         self.downsample = downsample
         self.stride = stride
-        self.se = None
-        self.eca = None
+        self.se = se_layer(planes * self.expansion, reduction=16) if SE else None
+        self.eca = eca_layer(planes * self.expansion, int(ECA_size)) if ECA_size is not None else None
         self._norm = norm_layer
 
     def trunk_pre(self, x, defer_bn3=False):
@@ -53,7 +81,13 @@ class _BottleneckTrunk(nn.Module):
         out = F_.bn_act(self.conv1(x), self.bn1, relu=True)          # fused BatchNorm+ReLU HIP passes
         out = F_.bn_act(self.conv2(out), self.bn2, relu=True)
         out = self.conv3(out)
+        if self.se is not None or self.eca is not None:     # channel attention reads bn3's output: nothing to defer
+            defer_bn3 = False
         out = F_.bn_act(out, self.bn3, relu=False, defer=defer_bn3(out) if callable(defer_bn3) else defer_bn3)
+        if self.se is not None:
+            out = self.se(out)
+        if self.eca is not None:
+            out = self.eca(out)
         if self.downsample is not None:
             ds = self.downsample
             if isinstance(ds, nn.Sequential) and len(ds) == 2 and isinstance(ds[0], nn.Conv2d):

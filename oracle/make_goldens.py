@@ -157,6 +157,7 @@ BASE_CASES = [  # name, b, c, h, w, d, T
     ("chain5", 2, 64, 6, 5, 16, 5),
     ("chain23", 1, 32, 2, 3, 16, 23),
     ("chain3cw", 2, 16, 4, 4, 1, 3),
+    ("chain23n", 1, 64, 3, 4, 16, 23),      # c % 64 == 0: served by the slot-major NHWC rings as well (BASELINE config 5's path)
 ]
 
 
@@ -204,7 +205,9 @@ def gen_base(ref):
 # ------------------------------------------------------------------------------------------------
 # (iii) DeiT token module  -- rows a6, a7, a8
 # ------------------------------------------------------------------------------------------------
-TOKEN_CASES = [("t17", 2, 17, 32, 16), ("t197", 2, 197, 192, 16)]
+TOKEN_CASES = [("t17", 2, 17, 32, 16), ("t197", 2, 197, 192, 16),
+               ("t197s", 1, 197, 384, 16), ("t197b", 1, 197, 768, 16)]      # deit_mrlal_small / base widths
+GELU_LAYER_CASES = [("g64", 2, 64, 6, 5, 16), ("g192", 2, 192, 14, 14, 16)]     # mrlal_layer on a [b,c,h,w] map
 
 
 def token_inputs(name, b, n, c):
@@ -231,8 +234,22 @@ def gen_tokens(deit_light):
         for pn, pv in mod.named_parameters():
             out[k + "grad/" + pn] = N(pv.grad)
     for k in list(out):
-        if k.startswith("t197/") and out[k].ndim == 3:
+        if k.startswith("t197") and out[k].ndim == 3:
             out[k] = out[k][:, ::4].copy()
+    # the stand-alone map form of the layer (deit_mrla_light.py:157-180, GELU on V), forward and gradients
+    for name, b, c, h, w, d in GELU_LAYER_CASES:
+        lay = deit_light.mrlal_layer(c, dim_perhead=d)
+        load_det(lay, salt=4)
+        s_ = detgen.seed_of("gelu/" + name)
+        x = T(detgen.normalish((b, c, h, w), s_)).requires_grad_(True)
+        y = lay(x)
+        (y * T(detgen.normalish((b, c, h, w), s_ + 1))).sum().backward()
+        k = name + "/"
+        sub = (lambda a: a[:, ::4]) if c > 64 else (lambda a: a)
+        out[k + "out"] = sub(N(y)).copy()
+        out[k + "dx"] = sub(N(x.grad)).copy()
+        for pn, pv in lay.named_parameters():
+            out[k + "grad/" + pn] = N(pv.grad)
     np.savez_compressed(os.path.join(OUT, "token_modules.npz"), **out)
     print("token_modules.npz", sum(v.nbytes for v in out.values()) // 1024, "KiB")
 
@@ -421,7 +438,9 @@ def gen_state_dict_layout(ref, deit_light, deit_base):
                           ("resnet101_mrlab", ref["resnet_mrla_base"].resnet101_mrlab),
                           ("deit_mrlal_tiny_patch16_224", deit_light.deit_mrlal_tiny_patch16_224),
                           ("deit_mrlal_small_patch16_224", deit_light.deit_mrlal_small_patch16_224),
-                          ("deit_mrlab_tiny_patch16_224", deit_base.deit_mrlab_tiny_patch16_224)):
+                          ("deit_mrlab_tiny_patch16_224", deit_base.deit_mrlab_tiny_patch16_224),
+                          # the optional channel-attention modules (off in every BASELINE config): key names only
+                          ("resnet50_mrlal+SE+ECA", lambda: ref["resnet_mrla_light"].resnet50_mrlal(SE=True, ECA=[3, 5, 5, 7]))):
         layout[name] = {k: list(v.shape) for k, v in factory().state_dict().items()}
     with open(os.path.join(OUT, "state_dict_layout.json"), "w") as f:
         json.dump(layout, f, separators=(",", ":"))

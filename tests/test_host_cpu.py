@@ -79,7 +79,8 @@ def test_state_dict_layout_equals_reference():
              "resnet50_mrlab": models.resnet50_mrlab, "resnet101_mrlab": models.resnet101_mrlab,
              "deit_mrlal_tiny_patch16_224": vit.deit_mrlal_tiny_patch16_224,
              "deit_mrlal_small_patch16_224": vit.deit_mrlal_small_patch16_224,
-             "deit_mrlab_tiny_patch16_224": vit.deit_mrlab_tiny_patch16_224}
+             "deit_mrlab_tiny_patch16_224": vit.deit_mrlab_tiny_patch16_224,
+             "resnet50_mrlal+SE+ECA": lambda: models.resnet50_mrlal(SE=True, ECA=[3, 5, 5, 7])}
     for name, factory in built.items():
         with redirect_stdout(io.StringIO()):
             sd = factory().state_dict()
@@ -121,7 +122,12 @@ def test_base_stage_ring_bookkeeping(layout_name):
         for j in range(t + 1):
             assert float(V[:, j].min()) == float(V[:, j].max()) == j + 1 and float(K[:, j].max()) == -(j + 1)
     assert st.T == 8
-    assert st.backward_buffers() is True and st.backward_buffers() is False      # first touch reported once
+    # one backward pass visits the layers in decreasing order: only its first call reports "new pass" (dK ring re-zeroed)
+    assert [st.begin_layer_backward(t) for t in (5, 4, 3, 2, 1)] == [True, False, False, False, False] and st.bwd_top == 5
+    # a second pass over the same graph (retain_graph=True) starts at the top again and is recognised as such ...
+    assert st.begin_layer_backward(5) is True and st.begin_layer_backward(4) is False
+    # ... also when its deepest layer got no gradient this time (bwd_top bounds the dA slots the pass may read)
+    assert st.begin_layer_backward(4) is True and st.bwd_top == 4
     assert st.dA.shape == st.V.shape and st.dK.shape == st.K.shape
     st.t = st.T
     with pytest.raises(_lib.MrlaHipError):
@@ -149,3 +155,19 @@ def test_host_helpers_follow_the_reference_rules():
     dp = layers.DropPath(0.2).eval()
     x = torch.ones(3, 2, 2)
     assert dp(x) is x
+
+
+def test_top_level_models_package_serves_train_py_unedited():
+    """resnet/train.py:21-26 does `import models` and lists every lowercase callable of models.__dict__ as an --arch choice;
+    :158 builds `models.__dict__[arch](drop_rate=..., drop_path=...)`.  With the repository root on PYTHONPATH the
+    top-level `models` package makes those lines work as they are."""
+    import io
+    from contextlib import redirect_stdout
+
+    import models
+    names = sorted(n for n in models.__dict__ if n.islower() and not n.startswith("__") and callable(models.__dict__[n]))
+    assert names == ["resnet101_mrlab", "resnet101_mrlal", "resnet50_mrlab", "resnet50_mrlal"]
+    with redirect_stdout(io.StringIO()):
+        net = models.__dict__["resnet50_mrlal"](drop_rate=0.0, drop_path=0.2)
+    from mrla_amd.resnet import ResNet_mrlal
+    assert isinstance(net, ResNet_mrlal) and models.ResNet_mrlal is ResNet_mrlal

@@ -110,8 +110,12 @@ def assert_bf16_close(got, want64, what):
 # (3, 2048, 7, 7): 2048 channels do not divide into 72-plane slabs -> ragged last slab.
 # (2, 64, 1, 1) / (3, 64, 1, 3) / (2, 128, 3, 1): degenerate maps -- every tap but the centre (or a row / column of
 # taps) falls into the padding; (1, 256, 9, 9): a single image (BatchNorm over h*w only), 2 strips with a ragged one.
+# (128, 2048, 7, 7) / (128, 256, 3, 56) / (256, 512, 4, 28): enough waves for the NHWC backward apply pass to walk 2 / 2 / 4
+# images per workgroup (BG > 1: the dWv partial rows and the per-image coefficients change inside a workgroup), with
+# 1 / 8 / 4 strip-waves -- the oracle covers dx, do and every parameter gradient there.
 STAGE_SHAPES = [(4, 256, 56, 56, 32), (4, 512, 28, 28, 32), (4, 1024, 14, 14, 32), (3, 2048, 7, 7, 32),
-                (17, 256, 56, 56, 32), (2, 64, 1, 1, 32), (3, 64, 1, 3, 32), (2, 128, 3, 1, 32), (1, 256, 9, 9, 32)]
+                (17, 256, 56, 56, 32), (2, 64, 1, 1, 32), (3, 64, 1, 3, 32), (2, 128, 3, 1, 32), (1, 256, 9, 9, 32),
+                (128, 2048, 7, 7, 32), (128, 256, 3, 56, 32), (256, 512, 4, 28, 32)]
 
 
 @pytest.mark.parametrize("shape", STAGE_SHAPES, ids=lambda s: "x".join(map(str, s[:4])))
@@ -125,7 +129,11 @@ def test_light_tail_resnet50_stage_shapes(shape, dtype, cl):
     o = detgen.normalish((b, c, h, w), s + 2)
     gup = detgen.normalish((b, c, h, w), s + 3)
     P = cases.block_params(c, 7)
-    mask = np.array(([1, 0, 1, 1] * 5)[:b], dtype=np.float32)
+    mask = np.array(([1, 0, 1, 1] * ((b + 3) // 4))[:b], dtype=np.float32)
+    if b >= 128:
+        from mrla_amd import _lib as L
+        rows = L.load().mrla_light_wgrad_rows(b, c, h, w, L.BF16 if dtype == torch.bfloat16 else L.F32, L.NHWC)
+        assert 0 < rows < b, "this shape is meant to put several images into one workgroup of the NHWC apply_bwd pass"
     if dtype == torch.bfloat16:
         x, o, gup = bf16_round(x), bf16_round(o), bf16_round(gup)
     got = run_light(x, o, P, d, "train", mask, 0.2, gup, dtype, cl=cl)
@@ -247,3 +255,26 @@ def test_fp16_storage_matches_fp32_arithmetic_on_the_same_values(shape, cl):
         tol = 2.0 ** -9 if i < 3 else 2e-3          # stored fp16 tensors: 2 ulps; fp32 parameter gradients: input rounding only
         bad = (a - r).abs() > tol * (r.abs() + 0.05 * r.abs().max())
         assert bad.float().mean().item() < 1e-4, (i, (a - r).abs().max().item())
+
+
+@pytest.mark.parametrize("shape", [(2, 64, 5, 100, 32), (1, 32, 3, 70, 16)], ids=["w100", "w70-c32"])
+def test_wide_nchw_maps_run_through_one_internal_channels_last_conversion(shape):
+    """The reference takes NCHW maps of any size (mmdet: 800x1333 images); the NCHW slab kernels need a plane row to fit
+    one wave (W <= 64).  Wider NCHW inputs go through the NHWC kernels and come back NCHW-contiguous: same numbers, same
+    memory contract (mrla_light_module.py:62-64,72 use .view on the result)."""
+    from mrla_amd import _lib as L
+    b, c, h, w, d = shape
+    assert L.load().mrla_light_wgrad_rows(b, c, h, w, L.F32, L.NCHW) == L.EUNSUPPORTED
+    from oracle import detgen
+    s = detgen.seed_of(f"wide/{w}")
+    x = np.maximum(detgen.normalish((b, c, h, w), s), 0) + 0.1 * detgen.normalish((b, c, h, w), s + 1)
+    o, gup = detgen.normalish((b, c, h, w), s + 2), detgen.normalish((b, c, h, w), s + 3)
+    P = cases.block_params(c, 7)
+    got = run_light(x, o, P, d, "train", None, 0.0, gup)
+    out, cache, g = oracle_light(x, o, P, d, "train", None, 0.0, gup)
+    assert relmax(got["out"], out) < ACT_TOL and relmax(got["dx"], g["dx"]) < ACT_TOL
+    assert relmax(got["do"], g["do_prev"]) < ACT_TOL
+    assert relmax(got["grad/mrla.mrla.Wv.weight"][:, 0], g["dwv"]) < PAR_TOL
+    from mrla_amd.functional import mrla_light
+    y = mrla_light(to_dev(x), to_dev(P["mrla.mrla.Wq.weight"]), to_dev(P["mrla.mrla.Wk.weight"]), to_dev(P["mrla.mrla.Wv.weight"]), d)
+    assert y.is_contiguous() and y.view(b, c // d, d, h, w).shape[1] == c // d

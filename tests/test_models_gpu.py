@@ -54,12 +54,20 @@ def test_resnet50_mrlal_train_step_matches_eager():
     torch.nn.functional.cross_entropy(yr, tgt).backward()
     gp, gr = dict(net.named_parameters()), dict(ref.named_parameters())
     worst, dots = (0.0, ""), np.zeros(3)
+    tight = (0.0, "")
     for k in gp:
         a, b = gp[k].grad.cpu().numpy().ravel().astype(np.float64), gr[k].grad.cpu().numpy().ravel().astype(np.float64)
         if np.abs(b).sum() < 1e-4:
             continue                       # mathematically-zero gradients: noise
-        worst = max(worst, (np.abs(a - b).sum() / np.abs(b).sum(), k))
+        e = np.abs(a - b).sum() / np.abs(b).sum()
+        worst = max(worst, (e, k))
+        # the MRLA / BatchNorm parameters whose gradients are plain sums well above the noise: this is where the deferred
+        # bn3 affine and the fused producer are wired end to end, so these get their own, tight bound
+        if k.endswith(("mrla.mrla.Wv.weight", "mrla.lambda_t", "bn_mrla.weight", "bn_mrla.bias", "bn3.weight", "bn3.bias")):
+            tight = max(tight, (e, k))
         dots += np.array([a @ b, a @ a, b @ b])
+    print("model-level gradient check: worst", worst, "worst of the MRLA / bn3 parameters", tight)
+    assert tight[0] < 2e-2, tight
     # fp32 noise through 16 train-mode BNs + ReLU masks at batch 4 (and MIOpen may pick different conv algorithms for
     # the two models): per-parameter sums of the tiny Wq/Wk gradients are noise-limited, the block-level tests pin every
     # gradient to 5e-5; the whole gradient must still point the same way
@@ -132,3 +140,48 @@ def test_five_sgd_steps_track_the_eager_restatement(arch):
         if k.endswith("running_var") or k.endswith("running_mean"):
             assert rel(sa[k].float().cpu().numpy(), sb[k].float().cpu().numpy()) < 2e-2, k     # 5 steps of rounding drift
     assert int(sa["bn1.num_batches_tracked"]) == 5
+
+
+def test_half_precision_model_runs_and_keeps_its_statistics_dtype():
+    """model.half() (the reference tolerates it): BatchNorm running statistics become 2-byte buffers; the kernels read and
+    update float32, so the wrappers must go through float32 copies and write the update back -- never hand a 2-byte
+    buffer to the C ABI as float*."""
+    from mrla_amd import models
+    net = models.resnet50_mrlal().cuda()
+    load_det(net)
+    x = torch.from_numpy(cases.image_batch(4)).cuda()
+    net.eval()
+    with torch.no_grad():
+        want = net(x)
+    h = models.resnet50_mrlal().cuda()
+    h.load_state_dict(net.state_dict())
+    h.half().eval()
+    assert h.layer1[0].bn_mrla.running_var.dtype == torch.float16
+    with torch.no_grad():
+        got = h(x.half())
+    assert torch.isfinite(got).all()
+    assert rel(got.float().cpu().numpy(), want.cpu().numpy()) < 3e-2          # fp16 storage of every activation
+    h.train()
+    rv0 = h.layer2[1].bn_mrla.running_var.clone()
+    h(x.half()).float().square().mean().backward()
+    rv1 = h.layer2[1].bn_mrla.running_var
+    assert rv1.dtype == torch.float16 and torch.isfinite(rv1).all() and not torch.equal(rv0, rv1)
+    assert h.layer2[1].mrla.lambda_t.grad is not None and torch.isfinite(h.layer2[1].mrla.lambda_t.grad).all()
+
+
+@pytest.mark.skipif(torch.cuda.device_count() < 2, reason="needs two GPUs")
+def test_kernels_launch_on_the_tensor_device_not_the_current_one():
+    from mrla_amd.functional import mrla_light
+    assert torch.cuda.current_device() == 0
+    dev = torch.device("cuda", 1)
+    c = 64
+    x = torch.randn(2, c, 8, 8, device=dev).requires_grad_(True)
+    args = (torch.randn(1, 1, 3, device=dev), torch.randn(1, 1, 3, device=dev), torch.randn(c, 1, 3, 3, device=dev))
+    y1 = mrla_light(x, *args, 32)
+    y1.sum().backward()
+    with torch.cuda.device(1):
+        x2 = x.detach().clone().requires_grad_(True)
+        y2 = mrla_light(x2, *args, 32)
+        y2.sum().backward()
+    torch.cuda.synchronize(1)
+    assert torch.equal(y1, y2) and torch.equal(x.grad, x2.grad)

@@ -51,7 +51,7 @@ def test_token_module_fp32(case, res):
     assert relmax(do, g["dot"]) < 2 * ACT_TOL
     for got, key in zip(pg, ORACLE):
         assert relmax(got.ravel(), np.asarray(g[key]).ravel()) < PAR_TOL, key
-    sub = (lambda a: a[:, ::4]) if name == "t197" else (lambda a: a)
+    sub = (lambda a: a[:, ::4]) if n == 197 else (lambda a: a)
     if res:      # the golden gradients were taken through the block residual x + module(x, o)
         assert relmax(sub(dx), G[name + "/dx"]) < 5e-5
         assert relmax(sub(do), G[name + "/do"]) < 5e-5
@@ -60,9 +60,10 @@ def test_token_module_fp32(case, res):
         assert relmax(sub(out), G[name + "/module_out"]) < 2e-5
 
 
-def test_token_block_bf16_and_batch():
-    b, n, c, d = 5, 197, 192, 16
-    s = detgen.seed_of("tokbig")
+@pytest.mark.parametrize("c", [192, 384, 768], ids=["tiny", "small", "base"])
+def test_token_block_bf16_and_batch(c):
+    b, n, d = 5 if c == 192 else 3, 197, 16
+    s = detgen.seed_of("tokbig" if c == 192 else f"tokbig{c}")
     x = bf16_round(detgen.normalish((b, n, c), s) * 1.3 + 0.2)
     o = bf16_round(detgen.normalish((b, n, c), s + 1))
     gup = bf16_round(detgen.normalish((b, n, c), s + 2))
@@ -74,6 +75,43 @@ def test_token_block_bf16_and_batch():
     assert_bf16_close(do, g["dot"], "do")
     for got, key in zip(pg, ORACLE):
         assert relmax(got.ravel(), np.asarray(g[key]).ravel()) < PAR_TOL, key
+
+
+@pytest.mark.parametrize("case", cases.GELU_LAYER_CASES, ids=lambda c: c[0])
+@pytest.mark.parametrize("cl", [False, True], ids=["nchw", "nhwc"])
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16], ids=["fp32", "bf16"])
+def test_gelu_map_layer_module(case, cl, dtype):
+    """layers.mrlal_layer (MRLA_ACT_GELU branch of the light map kernels, deit_mrla_light.py:157-180) in both layouts vs
+    the oracle and the reference's golden."""
+    from mrla_amd.layers import mrlal_layer
+    name, b, c, h, w, d = case
+    G = cases.golden("token_modules")
+    x, gup = cases.gelu_layer_inputs(name, b, c, h, w)
+    if dtype == torch.bfloat16:
+        x, gup = bf16_round(x), bf16_round(gup)
+    P = cases.gelu_layer_params(c)
+    lay = mrlal_layer(c, dim_perhead=d).cuda()
+    lay.load_state_dict({k: torch.from_numpy(v) for k, v in P.items()})
+    fmt = torch.channels_last if cl else torch.contiguous_format
+    xt = to_dev(x, dtype).contiguous(memory_format=fmt).requires_grad_(True)
+    y = lay(xt)
+    y.backward(to_dev(gup, dtype).contiguous(memory_format=fmt))
+    P64 = {k: v.astype(np.float64) for k, v in P.items()}
+    want, cache = mn.light_layer_fwd(x.astype(np.float64), P64["Wq.weight"].ravel(), P64["Wk.weight"].ravel(),
+                                     P64["Wv.weight"][:, 0], d, act_gelu=True)
+    g = mn.light_layer_bwd(gup.astype(np.float64), cache)
+    out, dx = y.detach().float().cpu().numpy(), xt.grad.float().cpu().numpy()
+    if dtype == torch.float32:
+        assert relmax(out, want) < ACT_TOL and relmax(dx, g["dx"]) < ACT_TOL
+        sub = (lambda a: a[:, ::4]) if c > 64 else (lambda a: a)
+        assert relmax(sub(out), G[name + "/out"]) < 2e-5 and relmax(sub(dx), G[name + "/dx"]) < 5e-5
+        assert relmax(lay.Wv.weight.grad.cpu().numpy(), G[name + "/grad/Wv.weight"]) < 2e-4
+    else:
+        assert_bf16_close(out, want, "out")
+        assert_bf16_close(dx, g["dx"], "dx")
+    assert relmax(lay.Wv.weight.grad.cpu().numpy()[:, 0], g["dwv"]) < PAR_TOL
+    assert relmax(lay.Wq.weight.grad.cpu().numpy().ravel(), g["dwq"]) < PAR_TOL
+    assert relmax(lay.Wk.weight.grad.cpu().numpy().ravel(), g["dwk"]) < PAR_TOL
 
 
 def test_deit_mrlal_tiny_logits_match_reference_and_eager():

@@ -66,18 +66,22 @@ def test_model_under_ddp_two_ranks_one_gpu(arch, tmp_path):
         for k, v in singles[r]["stats"].items():
             assert torch.allclose(res[r]["stats"][k], v, rtol=1e-4, atol=1e-6), (r, k)
         # gradients: all-reduced average, identical on both ranks
-        dots = np.zeros(3)
+        dots, worst = np.zeros(3), (0.0, "")
         for k, w in want.items():
             a, b = res[r]["grads"][k].double().flatten(), w.double().flatten()
             assert a.shape == b.shape
             dots += np.array([float(a @ b), float(a @ a), float(b @ b)])
-            # the all-reduce itself is exact up to fp32 summation order; the per-rank gradients carry the usual
-            # run-to-run noise of MIOpen's atomically accumulated weight gradients at batch 3
-            scale = b.abs().max().item()
-            noisy = ".Wq." in k or ".Wk." in k       # sums of cancelling terms: noise-limited (tests/test_models_gpu.py)
-            if scale > 1e-6:
-                assert (a - b).abs().max().item() <= (0.5 if noisy else 2e-2) * scale + 1e-7, (r, k)
-        assert dots[0] / np.sqrt(dots[1] * dots[2]) > 0.99999
+            # the all-reduce itself is exact up to fp32 summation order; what differs between a DDP rank and the
+            # single-process run of the same batch is the run-to-run noise of MIOpen's atomically accumulated gradients,
+            # amplified by train-mode BatchNorm over 3 x 7 x 7 values -- a wrong reduction (sum instead of mean, a
+            # parameter left out, stale buckets) would be an O(1) error
+            if b.abs().sum().item() > 1e-4:
+                noisy = ".Wq." in k or ".Wk." in k   # sums of cancelling terms: noise-limited (tests/test_models_gpu.py)
+                e = ((a - b).abs().sum() / b.abs().sum()).item()
+                worst = max(worst, (e, k)) if not noisy else worst
+                assert e < (0.5 if noisy else 0.1), (r, k, e)
+        print(f"rank {r}: worst per-parameter relative L1 difference to the manual average {worst}")
+        assert dots[0] / np.sqrt(dots[1] * dots[2]) > 0.9999
     for k in res[0]["grads"]:
         assert torch.equal(res[0]["grads"][k], res[1]["grads"][k]), k        # both ranks hold the same reduced gradient
     k = next(k for k in res[0]["stats"] if "bn_mrla.running_mean" in k)

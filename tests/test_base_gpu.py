@@ -153,9 +153,9 @@ def test_base_chain_resnet_stage_shapes(shape, dtype, cl):
                 # one flipped ReLU mask moves a channel's dWv / dgamma by one element's worth (b*h*w is only 392 here):
                 # all but a 1e-3 fraction of the entries within 2 %, and the whole tensor within 1 % in L2
                 a, r = got[t]["grad/" + ours].ravel().astype(np.float64), np.asarray(grads[t][theirs]).ravel()
-                err = np.abs(a - r) / np.abs(r).max()
+                err = np.abs(a - r) / max(np.abs(r).max(), 1e-12)     # (dWq / dWk of the first layer are exactly zero)
                 assert np.quantile(err, 0.999) < 2e-2 and err.max() < 0.1, (t, ours, err.max())
-                assert np.linalg.norm(a - r) / np.linalg.norm(r) < 1e-2, (t, ours)
+                assert np.linalg.norm(a - r) <= 1e-2 * np.linalg.norm(r) + 1e-12, (t, ours)
 
 
 def test_bare_base_layer_api_matches_reference_attn():

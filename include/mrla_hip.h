@@ -284,6 +284,19 @@ int mrla_bn_plane_dmoments(const void* dy, const void* x, const float* sc, const
 int mrla_bn_act_bwd(const void* dy, const void* x, const float* sc, const float* sh, const float* cb /*[c,3]*/, int relu,
                     void* dx, int b, int c, int h, int w, int dtype, int layout, void* stream);
 
+/* =====================================================================================================
+ * The 1x1 stride-1 convolutions in front of those BatchNorms as an MFMA GEMM whose epilogue takes the BatchNorm
+ * statistics (first half; reference call sites resnet/models/resnet_mrla_light.py:93-94
+ * `conv1 -> bn1` and :100-101 `conv3 -> bn3`, both nn.Conv2d(kernel_size=1, stride=1, bias=False)).
+ *   y[m, n] = sum_k x[m, k] * w[n, k]        x: channels_last activation viewed as [m = b*h*w, k = c_in] (bf16),
+ *                                            w: the conv weight [n = c_out, k] (bf16), y: [m, n] (bf16, fp32 accumulate)
+ *   mom_part[row, n, 0..1] [opt] = partial (sum, sum of squares) over the row's pixels of the ROUNDED outputs:
+ *   exactly what mrla_bn_plane_moments would read back from y -- pass (rows, m / rows) as (b, hw) to mrla_bn_stats_fwd.
+ * MRLA_EUNSUPPORTED for shapes outside k in {64, 128, 256, 512}, n % 64 == 0, m % 32 == 0 and for dtypes other than
+ * MRLA_BF16: the caller keeps using its stock convolution there. */
+int mrla_conv1x1_rows(int m, int k, int n, int dtype);      /* rows of mom_part (> 0), or a negative code */
+int mrla_conv1x1_fwd(const void* x, const void* w, void* y, float* mom_part, int m, int k, int n, int dtype, void* stream);
+
 /* out[n] = sum over rows of in[rows, n] (fixed order, double accumulation). */
 int mrla_reduce_rows(const float* in, float* out, int rows, int n, void* stream);
 

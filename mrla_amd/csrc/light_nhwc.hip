@@ -11,6 +11,8 @@
 //     workgroup through LDS, in a fixed order (bitwise reproducible).
 // A workgroup = (image group, 64-channel chunk); its waves = column strips.  ResNet stage widths 56/28/14/7 give
 // 8/4/2/1 strips of exactly 7 columns.
+#include <cstdlib>
+
 #include "light_nhwc.h"
 
 namespace mrla {
@@ -349,6 +351,8 @@ int launch_light_stats_fwd_nhwc(const void* x, const void* o, const float* wv, f
                                 const float* psc, const float* psh, void* vout, int B, int C, int H, int W, int dtype,
                                 int act, hipStream_t st) {
   const NhwcLaunch L = nhwc_launch(B, C, W, M_N, dtype);
+  if (L.wide && !getenv("MRLA_NHWC_OLD"))
+    return launch_light_stats_fwd_wide(x, o, wv, mom, xout, psc, psh, vout, B, C, H, W, dtype, act, st);
 #define CALL_W(T, A, O, F, WD)                                                                                       \
   {                                                                                                                  \
     if (set_lds_n(light_stats_fwd_nhwc<T, A, O, F, WD>, L.lds) != hipSuccess) return MRLA_EHIP;                        \
@@ -372,6 +376,8 @@ int launch_light_apply_fwd_nhwc(const void* x, const void* o, const float* wv, c
                                 const float* sh, const float* lam, const float* dp, void* out, int B, int C, int H,
                                 int W, int d, int res, int dtype, int act, hipStream_t st) {
   const NhwcLaunch L = nhwc_launch(B, C, W, 0, dtype);
+  if (L.wide && !getenv("MRLA_NHWC_OLD"))
+    return launch_light_apply_fwd_wide(x, o, wv, gate, sc, sh, lam, dp, out, B, C, H, W, d, res, dtype, act, st);
 #define CALL_W(T, A, O, WD)                                                                                          \
   {                                                                                                                  \
     if (set_lds_n(light_apply_fwd_nhwc<T, A, O, WD>, L.lds) != hipSuccess) return MRLA_EHIP;                           \
@@ -390,6 +396,8 @@ int launch_light_apply_fwd_pre_nhwc(const void* pre, const void* o, const float*
                                     const float* dp, void* out, int B, int C, int H, int W, int d, int res, int dtype,
                                     hipStream_t st) {
   const NhwcLaunch L = nhwc_launch(B, C, W, 0, dtype);
+  if (L.wide && !getenv("MRLA_NHWC_OLD"))
+    return launch_light_apply_fwd_pre_wide(pre, o, psc, psh, wv, gate, sc, sh, lam, dp, out, B, C, H, W, d, res, dtype, st);
 #define CALL_W(T, WD)                                                                                                 \
   {                                                                                                                   \
     if (set_lds_n(light_apply_fwd_pre_nhwc<T, WD>, L.lds) != hipSuccess) return MRLA_EHIP;                              \
@@ -411,6 +419,7 @@ int launch_light_apply_fwd_pre_nhwc(const void* pre, const void* o, const float*
 int launch_light_stats_bwd_nhwc(const void* dout, const void* x, const void* o, const float* wv, float* bmom, int B,
                                 int C, int H, int W, int dtype, int act, hipStream_t st) {
   const NhwcLaunch L = nhwc_launch(B, C, W, D_N, dtype);
+  if (L.wide && !getenv("MRLA_NHWC_OLD")) return launch_light_stats_bwd_wide(dout, x, o, wv, bmom, B, C, H, W, dtype, act, st);
 #define CALL_W(T, A, O, WD)                                                                                          \
   {                                                                                                                  \
     if (set_lds_n(light_stats_bwd_nhwc<T, A, O, WD>, L.lds) != hipSuccess) return MRLA_EHIP;                           \

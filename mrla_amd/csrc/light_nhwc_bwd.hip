@@ -2,6 +2,8 @@
 // A translation unit of its own: this kernel is register-bound, and pairing its FMAs into v_pk_fma_f32 (the SLP
 // vectoriser) costs it ~40 VGPRs and a move per pair, so the Makefile compiles this file with -fno-slp-vectorize;
 // the lighter passes in light_nhwc.hip gain from the pairing and keep it.
+#include <cstdlib>
+
 #include "light_nhwc.h"
 
 namespace mrla {
@@ -176,6 +178,9 @@ int launch_light_apply_bwd_nhwc(const void* dout, const void* x, const void* o, 
                                 void* dprev, float* dwv_part, int B, int C, int H, int W, int d, int res, int relu,
                                 int dtype, int act, hipStream_t st) {
   NhwcLaunch L = nhwc_launch(B, C, W, 9, dtype);
+  if (L.wide && !getenv("MRLA_NHWC_OLD"))
+    return launch_light_apply_bwd_wide(dout, x, o, wv, gate, cb, lam, dp, dyx, dx, dprev, dwv_part, B, C, H, W, d, res,
+                                       relu, dtype, act, st);
   L.BG = nhwc_images_per_group(B, C, W);                  // = the rows mrla_light_wgrad_rows() promised
   L.grid = dim3(L.grid.x, (B + L.BG - 1) / L.BG);
 #define CALL_W(T, A, O, R, WD)                                                                                       \

@@ -1,0 +1,740 @@
+// MRLA-light streaming kernels for channels_last activations with C % 64 == 0 -- every stage of the networks here --
+// on the LDS-DMA row pipeline of nhwc_rows.h.  Same passes and math as light_nhwc.hip (which keeps serving other channel
+// counts with plain per-lane accesses); reference: resnet/models/modules/mrla_light_module.py:52-74,
+// resnet/models/resnet_mrla_light.py:40-43,113-116.
+//
+// These kernels are bound by vector-instruction issue, not by HBM (profiles/r02_notes.md), so the loops are written
+// for instruction count: row windows rotate by NAME (three steps per trip, no register copies), everything outside the
+// image arrives as zeros from the buffer bounds check (no predicates in the arithmetic), bf16 rows need no conversion
+// instruction, and the file is compiled without the SLP vectoriser (its v_pk_fma_f32 pairs cost more moves than they save).
+#include "light_nhwc.h"
+#include "nhwc_rows.h"
+
+namespace mrla {
+
+// Per-wave LDS row buffers follow the cross-wave reduction area.
+#define MRLA_WIDE_PROLOGUE(NRED, WAVE_BYTES)                                                              \
+  extern __shared__ __align__(16) unsigned char smem_raw[];                                               \
+  const int lane = threadIdx.x & (kWave - 1), wave = threadIdx.x / kWave, nwaves = blockDim.x / kWave;    \
+  float* red = reinterpret_cast<float*>(smem_raw);                                                        \
+  unsigned char* wbuf = smem_raw + (size_t)nwaves * (NRED) * kWave * sizeof(float) + (size_t)wave * (WAVE_BYTES); \
+  const int cbase = blockIdx.x * kWave;                                                                   \
+  const int c = cbase + lane;                                                                             \
+  const int nstrips = (W + kS - 1) / kS;                                                                  \
+  const int rowelems = W * C;                                                                             \
+  (void)red;
+
+// Runs step(r, A, B, C) for r = 0 .. n-1 with the three row windows rotating by name.
+#define MRLA_ROTATE3(n, step, A, B, C)                       \
+  {                                                          \
+    int r_ = 0;                                              \
+    for (; r_ + 3 <= (n); r_ += 3) {                         \
+      step(r_, A, B, C);                                     \
+      step(r_ + 1, B, C, A);                                 \
+      step(r_ + 2, C, A, B);                                 \
+    }                                                        \
+    if (r_ < (n)) {                                          \
+      step(r_, A, B, C);                                     \
+      if (r_ + 1 < (n)) step(r_ + 1, B, C, A);               \
+    }                                                        \
+  }
+
+// ------------------------------------------------------------------------------------------------
+// backward statistics: per (image, channel) sums of dOut, dOut*V, dOut*o
+// ------------------------------------------------------------------------------------------------
+template <typename T> constexpr int stats_bwd_wave_bytes() { return RowIO<T, kS + 2>::kBytes + 2 * RowIO<T, kS>::kBytes; }
+
+template <typename T, bool GELU, bool HAS_O>
+__global__ __launch_bounds__(kMaxStrips * kWave) void light_stats_bwd_wide(
+    const T* __restrict__ dout, const T* __restrict__ x, const T* __restrict__ o, const float* __restrict__ wv,
+    float* __restrict__ bmom, int B, int C, int H, int W, int BG) {
+  MRLA_WIDE_PROLOGUE(D_N, stats_bwd_wave_bytes<T>())
+  T* bufX = reinterpret_cast<T*>(wbuf);
+  T* bufG = reinterpret_cast<T*>(wbuf + RowIO<T, kS + 2>::kBytes);
+  T* bufO = reinterpret_cast<T*>(wbuf + RowIO<T, kS + 2>::kBytes + RowIO<T, kS>::kBytes);
+  float w[9];
+#pragma unroll
+  for (int k = 0; k < 9; ++k) w[k] = wv[c * 9 + k];
+  const int b_end = min(B, (int)(blockIdx.y + 1) * BG);
+  for (int b = blockIdx.y * BG; b < b_end; ++b) {
+    const size_t ioff = (size_t)b * H * rowelems;
+    const T* xi = x + ioff;
+    const T* gi = dout + ioff;
+    const T* oi = HAS_O ? o + ioff : nullptr;
+    float acc[D_N] = {0.f, 0.f, 0.f};
+    for (int s = wave; s < nstrips; s += nwaves) {
+      const int s0 = s * kS;
+      RowIO<T, kS + 2> ax;
+      RowIO<T, kS> ag;
+      make_row_io<T, kS + 2>(ax, s0 - 1, kS + 2, W, C, cbase, lane);
+      make_row_io<T, kS>(ag, s0, kS, W, C, cbase, lane);
+      RawRow<kS + 2> xa, xb, xc;                     // x rows r-1, r, r+1 on columns s0-1 .. s0+kS
+      RawRow<kS> gv, ov;
+      xa.clear(); xb.clear(); xc.clear(); gv.clear(); ov.clear();
+      row_fetch<T, kS + 2>(ax, xi, 0, H, rowelems, bufX);
+      rows_landed();
+      row_read<T, kS + 2>(bufX, lane, xb);
+      row_fetch<T, kS + 2>(ax, xi, 1, H, rowelems, bufX);
+      row_fetch<T, kS>(ag, gi, 0, H, rowelems, bufG);
+      if (HAS_O) row_fetch<T, kS>(ag, oi, 0, H, rowelems, bufO);
+      // dOut (and o) are zero beyond the image, so columns of a ragged last strip drop out of every sum by themselves
+      auto step = [&](int r, RawRow<kS + 2>& XA, RawRow<kS + 2>& XB, RawRow<kS + 2>& XC) {
+        rows_landed();
+        row_read<T, kS + 2>(bufX, lane, XC);
+        row_read<T, kS>(bufG, lane, gv);
+        if (HAS_O) row_read<T, kS>(bufO, lane, ov);
+        row_fetch<T, kS + 2>(ax, xi, r + 2, H, rowelems, bufX);
+        row_fetch<T, kS>(ag, gi, r + 1, H, rowelems, bufG);
+        if (HAS_O) row_fetch<T, kS>(ag, oi, r + 1, H, rowelems, bufO);
+#pragma unroll
+        for (int j = 0; j < kS; ++j) {
+          float v = conv_at(w, XA.v, XB.v, XC.v, j);
+          if (GELU) v = gelu_f(v);
+          acc[D_D] += gv.v[j];
+          acc[D_DV] = fmaf(gv.v[j], v, acc[D_DV]);
+          if (HAS_O) acc[D_DO] = fmaf(gv.v[j], ov.v[j], acc[D_DO]);
+        }
+      };
+      MRLA_ROTATE3(H, step, xa, xb, xc)
+      rows_landed();                                 // the look-ahead rows of the last step (zeros) are still in flight
+    }
+    wg_reduce<D_N>(acc, red, lane, wave, nwaves);
+    if (wave == 0) {
+#pragma unroll
+      for (int k = 0; k < D_N; ++k) bmom[((size_t)b * C + c) * D_N + k] = acc[k];
+    }
+  }
+}
+
+
+// ------------------------------------------------------------------------------------------------
+// forward statistics, x given: per (image, channel) sums of x, V, o, V^2, V*o, o^2 (V = act(dwconv3x3(x)));
+// MRLA-base also keeps V (vout = the stage's value-history slot)
+// ------------------------------------------------------------------------------------------------
+template <typename T> constexpr int stats_fwd_wave_bytes() { return RowIO<T, kS + 2>::kBytes + 2 * RowIO<T, kS>::kBytes; }
+
+template <typename T, bool GELU, bool HAS_O, bool RAGGED>
+__global__ __launch_bounds__(kMaxStrips * kWave) void light_stats_fwd_wide(
+    const T* __restrict__ x, const T* __restrict__ o, const float* __restrict__ wv, float* __restrict__ mom,
+    T* __restrict__ vout, int B, int C, int H, int W, int BG) {
+  MRLA_WIDE_PROLOGUE(M_N, stats_fwd_wave_bytes<T>())
+  T* bufX = reinterpret_cast<T*>(wbuf);
+  T* bufO = reinterpret_cast<T*>(wbuf + RowIO<T, kS + 2>::kBytes);
+  T* bufS = reinterpret_cast<T*>(wbuf + RowIO<T, kS + 2>::kBytes + RowIO<T, kS>::kBytes);
+  float w[9];
+#pragma unroll
+  for (int k = 0; k < 9; ++k) w[k] = wv[c * 9 + k];
+  const int b_end = min(B, (int)(blockIdx.y + 1) * BG);
+  for (int b = blockIdx.y * BG; b < b_end; ++b) {
+    const size_t ioff = (size_t)b * H * rowelems;
+    const T* xi = x + ioff;
+    const T* oi = HAS_O ? o + ioff : nullptr;
+    T* vo = vout ? vout + ioff : nullptr;
+    float acc[M_N] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    for (int s = wave; s < nstrips; s += nwaves) {
+      const int s0 = s * kS, nc = min(kS, W - s0);
+      RowIO<T, kS + 2> ax;
+      RowIO<T, kS> ao, as;
+      make_row_io<T, kS + 2>(ax, s0 - 1, kS + 2, W, C, cbase, lane);
+      make_row_io<T, kS>(ao, s0, kS, W, C, cbase, lane);
+      make_row_io<T, kS>(as, s0, nc, W, C, cbase, lane);
+      RawRow<kS + 2> xa, xb, xc;
+      RawRow<kS> ov;
+      xa.clear(); xb.clear(); xc.clear(); ov.clear();
+      row_fetch<T, kS + 2>(ax, xi, 0, H, rowelems, bufX);
+      rows_landed();
+      row_read<T, kS + 2>(bufX, lane, xb);
+      row_fetch<T, kS + 2>(ax, xi, 1, H, rowelems, bufX);
+      if (HAS_O) row_fetch<T, kS>(ao, oi, 0, H, rowelems, bufO);
+      auto step = [&](int r, RawRow<kS + 2>& XA, RawRow<kS + 2>& XB, RawRow<kS + 2>& XC) {
+        rows_landed();
+        row_read<T, kS + 2>(bufX, lane, XC);
+        if (HAS_O) row_read<T, kS>(bufO, lane, ov);
+        row_fetch<T, kS + 2>(ax, xi, r + 2, H, rowelems, bufX);
+        if (HAS_O) row_fetch<T, kS>(ao, oi, r + 1, H, rowelems, bufO);
+        float vrow[kS];
+#pragma unroll
+        for (int j = 0; j < kS; ++j) {
+          float v = conv_at(w, XA.v, XB.v, XC.v, j);
+          if (GELU) v = gelu_f(v);
+          if (RAGGED) v = j < nc ? v : 0.f;          // x and o are zero beyond the image, V is not
+          vrow[j] = v;
+          acc[M_SX] += XB.v[j + 1];
+          acc[M_SV] += v;
+          acc[M_SVV] = fmaf(v, v, acc[M_SVV]);
+          if (HAS_O) {
+            acc[M_SO] += ov.v[j];
+            acc[M_SVO] = fmaf(v, ov.v[j], acc[M_SVO]);
+            acc[M_SOO] = fmaf(ov.v[j], ov.v[j], acc[M_SOO]);
+          }
+        }
+        if (vo) row_store<T, kS>(as, vo, r, rowelems, lane, bufS, vrow);
+      };
+      MRLA_ROTATE3(H, step, xa, xb, xc)
+      rows_landed();
+    }
+    wg_reduce<M_N>(acc, red, lane, wave, nwaves);
+    if (wave == 0) {
+#pragma unroll
+      for (int k = 0; k < M_N; ++k) mom[((size_t)b * C + c) * M_N + k] = acc[k];
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// The fused producer: x_t = relu(round(round(psc*pre + psh) + o)) formed from conv3's output and the shortcut
+// (resnet_mrla_light.py:101-114; AFF = bn3's affine handed over instead of applied in a pass of its own).
+// `pre` and `o` arrive as zeros outside the image; the shift is masked there so that the padding of the 3x3 stays zero.
+// ------------------------------------------------------------------------------------------------
+template <typename T, bool AFF>
+__device__ __forceinline__ void form_x_row(const RawRow<kS + 2>& pre, const RawRow<kS + 2>& o, float asc,
+                                           const float (&shj)[kS + 2], float (&dst)[kS + 2]) {
+#pragma unroll
+  for (int j = 0; j < kS + 2; ++j) {
+    const float z = AFF ? to_f(from_f<T>(fmaf(asc, pre.v[j], shj[j]))) : pre.v[j];
+    dst[j] = fmaxf(to_f(from_f<T>(z + o.v[j])), 0.f);
+  }
+}
+__device__ __forceinline__ void column_shifts(float ash, int s0, int W, float (&shj)[kS + 2]) {
+#pragma unroll
+  for (int j = 0; j < kS + 2; ++j) {
+    const int col = s0 - 1 + j;
+    shj[j] = (col >= 0 && col < W) ? ash : 0.f;      // wave-uniform predicate
+  }
+}
+
+// per wave: pre row, two o rows (row r is read again when V[r] is paired with it), one store buffer
+template <typename T> constexpr int fused_wave_bytes() { return 3 * RowIO<T, kS + 2>::kBytes + RowIO<T, kS>::kBytes; }
+
+template <typename T, bool AFF, bool RAGGED>
+__global__ __launch_bounds__(kMaxStrips * kWave) void light_stats_fwd_fused_wide(
+    const T* __restrict__ pre, const T* __restrict__ o, const float* __restrict__ wv, float* __restrict__ mom,
+    T* __restrict__ xout, const float* __restrict__ psc, const float* __restrict__ psh, T* __restrict__ vout, int B,
+    int C, int H, int W, int BG) {
+  MRLA_WIDE_PROLOGUE(M_N, fused_wave_bytes<T>())
+  constexpr int RB = RowIO<T, kS + 2>::kBytes;
+  T* bufP = reinterpret_cast<T*>(wbuf);
+  unsigned char* bufO2 = wbuf + RB;                  // o row r lives in half (r & 1)
+  T* bufS = reinterpret_cast<T*>(wbuf + 3 * RB);
+  float w[9];
+#pragma unroll
+  for (int k = 0; k < 9; ++k) w[k] = wv[c * 9 + k];
+  const float asc = AFF ? psc[c] : 1.f, ash = AFF ? psh[c] : 0.f;
+  const int b_end = min(B, (int)(blockIdx.y + 1) * BG);
+  for (int b = blockIdx.y * BG; b < b_end; ++b) {
+    const size_t ioff = (size_t)b * H * rowelems;
+    const T* pi = pre + ioff;
+    const T* oi = o + ioff;
+    T* xo = xout + ioff;
+    T* vo = vout ? vout + ioff : nullptr;
+    float acc[M_N] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    for (int s = wave; s < nstrips; s += nwaves) {
+      const int s0 = s * kS, nc = min(kS, W - s0);
+      RowIO<T, kS + 2> ax;
+      RowIO<T, kS> as;
+      make_row_io<T, kS + 2>(ax, s0 - 1, kS + 2, W, C, cbase, lane);
+      make_row_io<T, kS>(as, s0, nc, W, C, cbase, lane);
+      float shj[kS + 2];
+      column_shifts(ash, s0, W, shj);
+      RawRow<kS + 2> praw, oraw;
+      RawRow<kS> ov;
+      praw.clear(); oraw.clear(); ov.clear();
+      float xa[kS + 2], xb[kS + 2], xc[kS + 2];      // x_t rows r-1, r, r+1 on columns s0-1 .. s0+kS
+      auto obuf = [&](int r) { return reinterpret_cast<T*>(bufO2 + (r & 1) * RB); };
+      auto store_owned = [&](T* dst, int r, const float (&row)[kS + 2]) {
+        float own[kS];
+#pragma unroll
+        for (int j = 0; j < kS; ++j) own[j] = row[j + 1];
+        row_store<T, kS>(as, dst, r, rowelems, lane, bufS, own);
+      };
+#pragma unroll
+      for (int j = 0; j < kS + 2; ++j) xa[j] = 0.f;
+      row_fetch<T, kS + 2>(ax, pi, 0, H, rowelems, bufP);
+      row_fetch<T, kS + 2>(ax, oi, 0, H, rowelems, obuf(0));
+      rows_landed();
+      row_read<T, kS + 2>(bufP, lane, praw);
+      row_read<T, kS + 2>(obuf(0), lane, oraw);
+      row_fetch<T, kS + 2>(ax, pi, 1, H, rowelems, bufP);
+      row_fetch<T, kS + 2>(ax, oi, 1, H, rowelems, obuf(1));
+      form_x_row<T, AFF>(praw, oraw, asc, shj, xb);
+      store_owned(xo, 0, xb);
+      auto step = [&](int r, float (&XA)[kS + 2], float (&XB)[kS + 2], float (&XC)[kS + 2]) {
+        rows_landed();
+        row_read<T, kS + 2>(bufP, lane, praw);               // row r+1
+        row_read<T, kS + 2>(obuf(r + 1), lane, oraw);
+        row_read<T, kS>(obuf(r), lane, ov, 1);               // owned pixels of row r
+        row_fetch<T, kS + 2>(ax, pi, r + 2, H, rowelems, bufP);
+        row_fetch<T, kS + 2>(ax, oi, r + 2, H, rowelems, obuf(r));
+        if (r + 1 < H) {
+          form_x_row<T, AFF>(praw, oraw, asc, shj, XC);
+          store_owned(xo, r + 1, XC);
+        } else {
+#pragma unroll
+          for (int j = 0; j < kS + 2; ++j) XC[j] = 0.f;
+        }
+        float vrow[kS];
+#pragma unroll
+        for (int j = 0; j < kS; ++j) {
+          float v = conv_at(w, XA, XB, XC, j);
+          if (RAGGED) v = j < nc ? v : 0.f;
+          vrow[j] = v;
+          acc[M_SX] += XB[j + 1];
+          acc[M_SV] += v;
+          acc[M_SVV] = fmaf(v, v, acc[M_SVV]);
+          acc[M_SO] += ov.v[j];
+          acc[M_SVO] = fmaf(v, ov.v[j], acc[M_SVO]);
+          acc[M_SOO] = fmaf(ov.v[j], ov.v[j], acc[M_SOO]);
+        }
+        if (vo) row_store<T, kS>(as, vo, r, rowelems, lane, bufS, vrow);
+      };
+      MRLA_ROTATE3(H, step, xa, xb, xc)
+      rows_landed();
+    }
+    wg_reduce<M_N>(acc, red, lane, wave, nwaves);
+    if (wave == 0) {
+#pragma unroll
+      for (int k = 0; k < M_N; ++k) mom[((size_t)b * C + c) * M_N + k] = acc[k];
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// forward apply:  out = res*x + A*V + B*o + C   (A, B, C per (image, channel); the gate, the BatchNorm scale and the
+// residual are folded into the nine taps)
+// ------------------------------------------------------------------------------------------------
+template <typename T> constexpr int apply_fwd_wave_bytes() { return RowIO<T, kS + 2>::kBytes + 2 * RowIO<T, kS>::kBytes; }
+
+template <typename T, bool GELU, bool HAS_O>
+__global__ __launch_bounds__(kMaxStrips * kWave) void light_apply_fwd_wide(
+    const T* __restrict__ x, const T* __restrict__ o, const float* __restrict__ wv, const float* __restrict__ gate,
+    const float* __restrict__ sc, const float* __restrict__ sh, const float* __restrict__ lam,
+    const float* __restrict__ dp, T* __restrict__ out, int B, int C, int H, int W, int BG, int d, int res) {
+  MRLA_WIDE_PROLOGUE(0, apply_fwd_wave_bytes<T>())
+  T* bufX = reinterpret_cast<T*>(wbuf);
+  T* bufO = reinterpret_cast<T*>(wbuf + RowIO<T, kS + 2>::kBytes);
+  T* bufS = reinterpret_cast<T*>(wbuf + RowIO<T, kS + 2>::kBytes + RowIO<T, kS>::kBytes);
+  const int G = C / d;
+  float w0[9];
+#pragma unroll
+  for (int k = 0; k < 9; ++k) w0[k] = wv[c * 9 + k];
+  const float scc = sc ? sc[c] : 1.f, shc = sh ? sh[c] : 0.f, lmc = (HAS_O && lam) ? lam[c] : 0.f;
+  const float resf = res ? 1.f : 0.f;
+  const int b_end = min(B, (int)(blockIdx.y + 1) * BG);
+  for (int b = blockIdx.y * BG; b < b_end; ++b) {
+    const size_t ioff = (size_t)b * H * rowelems;
+    const T* xi = x + ioff;
+    const T* oi = HAS_O ? o + ioff : nullptr;
+    T* yo = out + ioff;
+    const float dpb = dp ? dp[b] : 1.f;
+    const float scale = dpb * scc;
+    const float A = scale * gate[(size_t)b * G + c / d];
+    const float Bc = scale * lmc, Cc = dpb * shc;
+    float w[9];
+#pragma unroll
+    for (int k = 0; k < 9; ++k) w[k] = GELU ? w0[k] : w0[k] * A;
+    if (!GELU) w[4] += resf;
+    for (int s = wave; s < nstrips; s += nwaves) {
+      const int s0 = s * kS, nc = min(kS, W - s0);
+      RowIO<T, kS + 2> ax;
+      RowIO<T, kS> ao, as;
+      make_row_io<T, kS + 2>(ax, s0 - 1, kS + 2, W, C, cbase, lane);
+      make_row_io<T, kS>(ao, s0, kS, W, C, cbase, lane);
+      make_row_io<T, kS>(as, s0, nc, W, C, cbase, lane);
+      RawRow<kS + 2> xa, xb, xc;
+      RawRow<kS> ov;
+      xa.clear(); xb.clear(); xc.clear(); ov.clear();
+      row_fetch<T, kS + 2>(ax, xi, 0, H, rowelems, bufX);
+      rows_landed();
+      row_read<T, kS + 2>(bufX, lane, xb);
+      row_fetch<T, kS + 2>(ax, xi, 1, H, rowelems, bufX);
+      if (HAS_O) row_fetch<T, kS>(ao, oi, 0, H, rowelems, bufO);
+      auto step = [&](int r, RawRow<kS + 2>& XA, RawRow<kS + 2>& XB, RawRow<kS + 2>& XC) {
+        rows_landed();
+        row_read<T, kS + 2>(bufX, lane, XC);
+        if (HAS_O) row_read<T, kS>(bufO, lane, ov);
+        row_fetch<T, kS + 2>(ax, xi, r + 2, H, rowelems, bufX);
+        if (HAS_O) row_fetch<T, kS>(ao, oi, r + 1, H, rowelems, bufO);
+        float y[kS];
+#pragma unroll
+        for (int j = 0; j < kS; ++j) {
+          if (GELU) y[j] = fmaf(A, gelu_f(conv_at(w, XA.v, XB.v, XC.v, j)), fmaf(resf, XB.v[j + 1], Cc));
+          else      y[j] = conv_at(w, XA.v, XB.v, XC.v, j) + Cc;
+          if (HAS_O) y[j] = fmaf(Bc, ov.v[j], y[j]);
+        }
+        row_store<T, kS>(as, yo, r, rowelems, lane, bufS, y);
+      };
+      MRLA_ROTATE3(H, step, xa, xb, xc)
+      rows_landed();
+    }
+  }
+}
+
+// Inference form of the apply pass: x_t is re-formed from conv3's output and the shortcut while it is convolved (it is
+// neither needed again nor saved when nothing is differentiated): the block tail moves 5N instead of 6N elements.
+template <typename T, bool AFF>
+__global__ __launch_bounds__(kMaxStrips * kWave) void light_apply_fwd_pre_wide(
+    const T* __restrict__ pre, const T* __restrict__ o, const float* __restrict__ psc, const float* __restrict__ psh,
+    const float* __restrict__ wv, const float* __restrict__ gate, const float* __restrict__ sc,
+    const float* __restrict__ sh, const float* __restrict__ lam, const float* __restrict__ dp, T* __restrict__ out, int B,
+    int C, int H, int W, int BG, int d, int res) {
+  MRLA_WIDE_PROLOGUE(0, fused_wave_bytes<T>())
+  constexpr int RB = RowIO<T, kS + 2>::kBytes;
+  T* bufP = reinterpret_cast<T*>(wbuf);
+  unsigned char* bufO2 = wbuf + RB;
+  T* bufS = reinterpret_cast<T*>(wbuf + 3 * RB);
+  const int G = C / d;
+  float w0[9];
+#pragma unroll
+  for (int k = 0; k < 9; ++k) w0[k] = wv[c * 9 + k];
+  const float scc = sc ? sc[c] : 1.f, shc = sh ? sh[c] : 0.f, lmc = lam ? lam[c] : 0.f;
+  const float resf = res ? 1.f : 0.f;
+  const float asc = AFF ? psc[c] : 1.f, ash = AFF ? psh[c] : 0.f;
+  const int b_end = min(B, (int)(blockIdx.y + 1) * BG);
+  for (int b = blockIdx.y * BG; b < b_end; ++b) {
+    const size_t ioff = (size_t)b * H * rowelems;
+    const T* pi = pre + ioff;
+    const T* oi = o + ioff;
+    T* yo = out + ioff;
+    const float dpb = dp ? dp[b] : 1.f;
+    const float scale = dpb * scc;
+    const float A = scale * gate[(size_t)b * G + c / d];
+    const float Bc = scale * lmc, Cc = dpb * shc;
+    float w[9];
+#pragma unroll
+    for (int k = 0; k < 9; ++k) w[k] = w0[k] * A;
+    w[4] += resf;
+    for (int s = wave; s < nstrips; s += nwaves) {
+      const int s0 = s * kS, nc = min(kS, W - s0);
+      RowIO<T, kS + 2> ax;
+      RowIO<T, kS> as;
+      make_row_io<T, kS + 2>(ax, s0 - 1, kS + 2, W, C, cbase, lane);
+      make_row_io<T, kS>(as, s0, nc, W, C, cbase, lane);
+      float shj[kS + 2];
+      column_shifts(ash, s0, W, shj);
+      RawRow<kS + 2> praw, oraw;
+      RawRow<kS> ov;
+      praw.clear(); oraw.clear(); ov.clear();
+      float xa[kS + 2], xb[kS + 2], xc[kS + 2];
+      auto obuf = [&](int r) { return reinterpret_cast<T*>(bufO2 + (r & 1) * RB); };
+#pragma unroll
+      for (int j = 0; j < kS + 2; ++j) xa[j] = 0.f;
+      row_fetch<T, kS + 2>(ax, pi, 0, H, rowelems, bufP);
+      row_fetch<T, kS + 2>(ax, oi, 0, H, rowelems, obuf(0));
+      rows_landed();
+      row_read<T, kS + 2>(bufP, lane, praw);
+      row_read<T, kS + 2>(obuf(0), lane, oraw);
+      row_fetch<T, kS + 2>(ax, pi, 1, H, rowelems, bufP);
+      row_fetch<T, kS + 2>(ax, oi, 1, H, rowelems, obuf(1));
+      form_x_row<T, AFF>(praw, oraw, asc, shj, xb);
+      auto step = [&](int r, float (&XA)[kS + 2], float (&XB)[kS + 2], float (&XC)[kS + 2]) {
+        rows_landed();
+        row_read<T, kS + 2>(bufP, lane, praw);
+        row_read<T, kS + 2>(obuf(r + 1), lane, oraw);
+        row_read<T, kS>(obuf(r), lane, ov, 1);
+        row_fetch<T, kS + 2>(ax, pi, r + 2, H, rowelems, bufP);
+        row_fetch<T, kS + 2>(ax, oi, r + 2, H, rowelems, obuf(r));
+        if (r + 1 < H) {
+          form_x_row<T, AFF>(praw, oraw, asc, shj, XC);
+        } else {
+#pragma unroll
+          for (int j = 0; j < kS + 2; ++j) XC[j] = 0.f;
+        }
+        float y[kS];
+#pragma unroll
+        for (int j = 0; j < kS; ++j) y[j] = fmaf(Bc, ov.v[j], conv_at(w, XA, XB, XC, j) + Cc);
+        row_store<T, kS>(as, yo, r, rowelems, lane, bufS, y);
+      };
+      MRLA_ROTATE3(H, step, xa, xb, xc)
+      rows_landed();
+    }
+  }
+}
+
+
+// ------------------------------------------------------------------------------------------------
+// backward apply:  dm = E*dOut + F*V + G*o + H (BatchNorm backward in closed form), dU = a*dm*act'(U),
+//   dx = dwconv3x3^T(dU) + res*dOut + dy/(hw)   [RELU: masked by x > 0 -- the fused relu(pre + o) producer],
+//   do = lam*dm  [RELU: + dx],   dWv partial sums per image group.
+// Strip-local windows (columns relative to s0): x rows rr-1..rr+1 over cols -2..kS+1 (kS+4 wide), dU rows rr-2..rr over
+// cols -1..kS (kS+2 wide).  Step rr: U[rr] on cols -1..kS -> dU[rr]; then dx[rr-1] on the owned cols from dU rows
+// rr-2..rr.  dOut of row rr-1 is read a second time from LDS (two dOut row buffers) instead of being kept in registers.
+// ------------------------------------------------------------------------------------------------
+template <typename T> constexpr int apply_bwd_wave_bytes() {
+  return RowIO<T, kS + 4>::kBytes + 3 * RowIO<T, kS + 2>::kBytes + 2 * RowIO<T, kS>::kBytes;
+}
+
+template <typename T, bool GELU, bool HAS_O, bool RELU, bool RAGGED>
+__global__ __launch_bounds__(kMaxStrips * kWave) void light_apply_bwd_wide(
+    const T* __restrict__ dout, const T* __restrict__ x, const T* __restrict__ o, const float* __restrict__ wv,
+    const float* __restrict__ gate, const float* __restrict__ cb, const float* __restrict__ lam,
+    const float* __restrict__ dp, const float* __restrict__ dyx, T* __restrict__ dx, T* __restrict__ dprev,
+    float* __restrict__ dwv_part, int B, int C, int H, int W, int BG, int d, int res) {
+  MRLA_WIDE_PROLOGUE(9, apply_bwd_wave_bytes<T>())
+  constexpr int XB_ = RowIO<T, kS + 4>::kBytes, GB = RowIO<T, kS + 2>::kBytes, SB = RowIO<T, kS>::kBytes;
+  T* bufX = reinterpret_cast<T*>(wbuf);
+  unsigned char* bufG2 = wbuf + XB_;                 // dOut row rr lives in half (rr & 1)
+  T* bufO = reinterpret_cast<T*>(wbuf + XB_ + 2 * GB);
+  T* bufS1 = reinterpret_cast<T*>(wbuf + XB_ + 3 * GB);
+  T* bufS2 = reinterpret_cast<T*>(wbuf + XB_ + 3 * GB + SB);
+  const int G = C / d;
+  float w[9];
+#pragma unroll
+  for (int k = 0; k < 9; ++k) w[k] = wv[c * 9 + k];
+  const float e_ = cb ? cb[c * 4 + 0] : 1.f, f_ = cb ? cb[c * 4 + 1] : 0.f;
+  const float Gc = cb ? cb[c * 4 + 2] : 0.f, Hc = cb ? cb[c * 4 + 3] : 0.f;
+  const float lm = (HAS_O && lam) ? lam[c] : 1.f;
+  const float resf = res ? 1.f : 0.f;
+  float wg[9] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  const int b_end = min(B, (int)(blockIdx.y + 1) * BG);
+  for (int b = blockIdx.y * BG; b < b_end; ++b) {
+    const size_t ioff = (size_t)b * H * rowelems;
+    const T* xi = x + ioff;
+    const T* gi = dout + ioff;
+    const T* oi = HAS_O ? o + ioff : nullptr;
+    T* dxo = dx + ioff;
+    T* doo = HAS_O ? dprev + ioff : nullptr;
+    const float dpb = dp ? dp[b] : 1.f;
+    const float a = gate[(size_t)b * G + c / d];
+    const float E = e_ * dpb, F = f_ * a;
+    const float dy = dyx[(size_t)b * C + c];
+    for (int s = wave; s < nstrips; s += nwaves) {
+      const int s0 = s * kS, nc = min(kS, W - s0);
+      RowIO<T, kS + 4> ax;
+      RowIO<T, kS + 2> ag;
+      RowIO<T, kS> as;
+      make_row_io<T, kS + 4>(ax, s0 - 2, kS + 4, W, C, cbase, lane);
+      make_row_io<T, kS + 2>(ag, s0 - 1, kS + 2, W, C, cbase, lane);
+      make_row_io<T, kS>(as, s0, nc, W, C, cbase, lane);
+      RawRow<kS + 4> xa, xb, xc;                     // x rows rr-1, rr, rr+1
+      RawRow<kS + 2> gv, ov;                         // dOut / o of row rr on columns -1 .. kS
+      RawRow<kS> gp;                                 // dOut of row rr-1 on the owned columns
+      xa.clear(); xb.clear(); xc.clear(); gv.clear(); ov.clear(); gp.clear();
+      float ua[kS + 2], ub[kS + 2], uc[kS + 2];      // dU rows rr-2, rr-1, rr
+      float d0[kS], d1[kS], d2[kS];                  // lam*dm of rows rr-1 / rr (RELU: do = lam*dm + dx one step later)
+#pragma unroll
+      for (int j = 0; j < kS + 2; ++j) { ua[j] = 0.f; ub[j] = 0.f; }
+#pragma unroll
+      for (int j = 0; j < kS; ++j) d0[j] = 0.f;
+      auto gbuf = [&](int r) { return reinterpret_cast<T*>(bufG2 + (r & 1) * GB); };
+      row_fetch<T, kS + 4>(ax, xi, 0, H, rowelems, bufX);
+      rows_landed();
+      row_read<T, kS + 4>(bufX, lane, xb);
+      row_fetch<T, kS + 4>(ax, xi, 1, H, rowelems, bufX);
+      row_fetch<T, kS + 2>(ag, gi, 0, H, rowelems, gbuf(0));
+      if (HAS_O) row_fetch<T, kS + 2>(ag, oi, 0, H, rowelems, bufO);
+      auto step = [&](int rr, RawRow<kS + 4>& XA, RawRow<kS + 4>& XB, RawRow<kS + 4>& XC, float (&UA)[kS + 2],
+                      float (&UB)[kS + 2], float (&UC)[kS + 2], float (&DP)[kS], float (&DC)[kS]) {
+        rows_landed();
+        row_read<T, kS + 4>(bufX, lane, XC);
+        row_read<T, kS + 2>(gbuf(rr), lane, gv);
+        if (HAS_O) row_read<T, kS + 2>(bufO, lane, ov);
+        if (rr >= 1) row_read<T, kS>(gbuf(rr + 1), lane, gp, 1);      // row rr-1, owned pixels
+        row_fetch<T, kS + 4>(ax, xi, rr + 2, H, rowelems, bufX);
+        row_fetch<T, kS + 2>(ag, gi, rr + 1, H, rowelems, gbuf(rr + 1));
+        if (HAS_O) row_fetch<T, kS + 2>(ag, oi, rr + 1, H, rowelems, bufO);
+        float dorow[kS];
+        if (rr >= H) {             // the step past the last row only finishes dx[H-1]
+#pragma unroll
+          for (int j = 0; j < kS + 2; ++j) UC[j] = 0.f;
+#pragma unroll
+          for (int j = 0; j < kS; ++j) { DC[j] = 0.f; dorow[j] = 0.f; }
+        } else {
+#pragma unroll
+          for (int j = 0; j < kS + 2; ++j) {
+            const int col = s0 - 1 + j;
+            // dU exists inside the image only (wave-uniform; for whole strips only the two halo columns can be outside)
+            const bool in = RAGGED ? (col >= 0 && col < W) : (j == 0 ? s0 > 0 : (j == kS + 1 ? s0 + kS < W : true));
+            const float u = conv_at(w, XA.v, XB.v, XC.v, j);             // window cols j..j+2 <-> image cols col-1..col+1
+            const float v = GELU ? gelu_f(u) : u;
+            float dm = fmaf(E, gv.v[j], Hc);
+            dm = fmaf(F, v, dm);
+            if (HAS_O) dm = fmaf(Gc, ov.v[j], dm);
+            float du = a * dm;
+            if (GELU) du *= gelu_grad_f(u);
+            if (RAGGED || j == 0 || j == kS + 1) du = in ? du : 0.f;
+            if (j >= 1 && j <= kS) {                                        // owned column (compile-time after unroll)
+              DC[j - 1] = lm * dm;                   // (columns beyond the image are dropped by the store)
+              dorow[j - 1] = DC[j - 1];
+              // dWv[i][k] += dU[rr][col] * x[rr+i-1][col+k-1]
+              wg[0] = fmaf(du, XA.v[j], wg[0]); wg[1] = fmaf(du, XA.v[j + 1], wg[1]); wg[2] = fmaf(du, XA.v[j + 2], wg[2]);
+              wg[3] = fmaf(du, XB.v[j], wg[3]); wg[4] = fmaf(du, XB.v[j + 1], wg[4]); wg[5] = fmaf(du, XB.v[j + 2], wg[5]);
+              wg[6] = fmaf(du, XC.v[j], wg[6]); wg[7] = fmaf(du, XC.v[j + 1], wg[7]); wg[8] = fmaf(du, XC.v[j + 2], wg[8]);
+            }
+            UC[j] = du;
+          }
+          if (HAS_O && !RELU) row_store<T, kS>(as, doo, rr, rowelems, lane, bufS2, dorow);
+        }
+        // dx[rr-1] on the owned columns:  dx[ro][col] = sum_{i,k} w[i][k] * dU[ro-i+1][col-k+1]
+        if (rr >= 1) {
+          float yrow[kS], dsum[kS];
+#pragma unroll
+          for (int j = 0; j < kS; ++j) {
+            // window index of column (col + 1 - k) in the dU arrays (which start at col -1): j + 2 - k
+            float s9 = w[0] * UC[j + 2];
+            s9 = fmaf(w[1], UC[j + 1], s9); s9 = fmaf(w[2], UC[j], s9);
+            s9 = fmaf(w[3], UB[j + 2], s9); s9 = fmaf(w[4], UB[j + 1], s9); s9 = fmaf(w[5], UB[j], s9);
+            s9 = fmaf(w[6], UA[j + 2], s9); s9 = fmaf(w[7], UA[j + 1], s9); s9 = fmaf(w[8], UA[j], s9);
+            float y = fmaf(resf, gp.v[j], s9 + dy);
+            if (RELU) y = (XA.v[j + 2] > 0.f) ? y : 0.f;                  // XA = x[rr-1]; owned col j <-> window j+2
+            yrow[j] = y;
+            dsum[j] = DP[j] + y;
+          }
+          row_store<T, kS>(as, dxo, rr - 1, rowelems, lane, bufS1, yrow);
+          if (RELU && HAS_O) row_store<T, kS>(as, doo, rr - 1, rowelems, lane, bufS2, dsum);
+        }
+      };
+      // steps rr = 0 .. H; after three steps every array is back in its starting role
+      int rr = 0;
+      for (; rr + 2 <= H; rr += 3) {
+        step(rr,     xa, xb, xc, ua, ub, uc, d0, d1);
+        step(rr + 1, xb, xc, xa, ub, uc, ua, d1, d2);
+        step(rr + 2, xc, xa, xb, uc, ua, ub, d2, d0);
+      }
+      if (rr <= H) {
+        step(rr, xa, xb, xc, ua, ub, uc, d0, d1);
+        if (rr + 1 <= H) step(rr + 1, xb, xc, xa, ub, uc, ua, d1, d2);
+      }
+      rows_landed();
+    }
+  }
+  wg_reduce<9>(wg, red, lane, wave, nwaves);
+  if (wave == 0) {
+#pragma unroll
+    for (int k = 0; k < 9; ++k) dwv_part[((size_t)blockIdx.y * C + c) * 9 + k] = wg[k];
+  }
+}
+
+struct WideLaunch { dim3 grid, block; size_t lds; int BG; };
+static WideLaunch wide_launch(int B, int C, int W, int nred, size_t wave_bytes, int bg) {
+  WideLaunch L;
+  const int nwaves = std::min((W + kS - 1) / kS, kMaxStrips);
+  L.BG = bg;
+  L.grid = dim3(C / kWave, (B + bg - 1) / bg);
+  L.block = dim3(nwaves * kWave);
+  L.lds = (size_t)nwaves * nred * kWave * sizeof(float) + (size_t)nwaves * wave_bytes;
+  return L;
+}
+
+
+int launch_light_stats_fwd_wide(const void* x, const void* o, const float* wv, float* mom, void* xout, const float* psc,
+                                const float* psh, void* vout, int B, int C, int H, int W, int dtype, int act,
+                                hipStream_t st) {
+  const bool ragged = (W % kS) != 0;
+  const int bg = nhwc_images_per_group(B, C, 0);
+  if (xout) {                     // the fused producer (needs o, no activation on V)
+    if (!o || act) return MRLA_EINVAL;
+#define CALL_R(T, AF, RG)                                                                                           \
+  {                                                                                                                 \
+    const WideLaunch L = wide_launch(B, C, W, M_N, fused_wave_bytes<T>(), bg);                                       \
+    if (set_lds_n(light_stats_fwd_fused_wide<T, AF, RG>, L.lds) != hipSuccess) return MRLA_EHIP;                      \
+    hipLaunchKernelGGL((light_stats_fwd_fused_wide<T, AF, RG>), L.grid, L.block, L.lds, st, (const T*)x, (const T*)o, \
+                       wv, mom, (T*)xout, psc, psh, (T*)vout, B, C, H, W, L.BG);                                    \
+  }
+#define CALL_A(T, AF) { if (ragged) CALL_R(T, AF, true) else CALL_R(T, AF, false) }
+#define CALL(T) { if (psc) CALL_A(T, true) else CALL_A(T, false) }
+    switch (dtype) {
+      case MRLA_F32:  CALL(float) break;
+      case MRLA_BF16: CALL(bf16_t) break;
+      case MRLA_F16:  CALL(f16_t) break;
+      default: return MRLA_EINVAL;
+    }
+#undef CALL
+#undef CALL_A
+#undef CALL_R
+    return hip_status(hipGetLastError());
+  }
+#define CALL_R(T, A, O, RG)                                                                                         \
+  {                                                                                                                 \
+    const WideLaunch L = wide_launch(B, C, W, M_N, stats_fwd_wave_bytes<T>(), bg);                                   \
+    if (set_lds_n(light_stats_fwd_wide<T, A, O, RG>, L.lds) != hipSuccess) return MRLA_EHIP;                          \
+    hipLaunchKernelGGL((light_stats_fwd_wide<T, A, O, RG>), L.grid, L.block, L.lds, st, (const T*)x, (const T*)o, wv, \
+                       mom, (T*)vout, B, C, H, W, L.BG);                                                            \
+  }
+#define CALL(T, A, O) { if (ragged) CALL_R(T, A, O, true) else CALL_R(T, A, O, false) }
+  MRLA_DISPATCH_T_N(dtype, act, o != nullptr, CALL)
+#undef CALL
+#undef CALL_R
+  return hip_status(hipGetLastError());
+}
+
+int launch_light_apply_fwd_wide(const void* x, const void* o, const float* wv, const float* gate, const float* sc,
+                                const float* sh, const float* lam, const float* dp, void* out, int B, int C, int H,
+                                int W, int d, int res, int dtype, int act, hipStream_t st) {
+#define CALL(T, A, O)                                                                                              \
+  {                                                                                                                \
+    const WideLaunch L = wide_launch(B, C, W, 0, apply_fwd_wave_bytes<T>(), nhwc_images_per_group(B, C, 0));        \
+    if (set_lds_n(light_apply_fwd_wide<T, A, O>, L.lds) != hipSuccess) return MRLA_EHIP;                            \
+    hipLaunchKernelGGL((light_apply_fwd_wide<T, A, O>), L.grid, L.block, L.lds, st, (const T*)x, (const T*)o, wv,   \
+                       gate, sc, sh, lam, dp, (T*)out, B, C, H, W, L.BG, d, res);                                  \
+  }
+  MRLA_DISPATCH_T_N(dtype, act, o != nullptr, CALL)
+#undef CALL
+  return hip_status(hipGetLastError());
+}
+
+int launch_light_apply_fwd_pre_wide(const void* pre, const void* o, const float* psc, const float* psh, const float* wv,
+                                    const float* gate, const float* sc, const float* sh, const float* lam,
+                                    const float* dp, void* out, int B, int C, int H, int W, int d, int res, int dtype,
+                                    hipStream_t st) {
+#define CALL_A(T, AF)                                                                                                \
+  {                                                                                                                  \
+    const WideLaunch L = wide_launch(B, C, W, 0, fused_wave_bytes<T>(), nhwc_images_per_group(B, C, 0));              \
+    if (set_lds_n(light_apply_fwd_pre_wide<T, AF>, L.lds) != hipSuccess) return MRLA_EHIP;                            \
+    hipLaunchKernelGGL((light_apply_fwd_pre_wide<T, AF>), L.grid, L.block, L.lds, st, (const T*)pre, (const T*)o, psc, \
+                       psh, wv, gate, sc, sh, lam, dp, (T*)out, B, C, H, W, L.BG, d, res);                           \
+  }
+#define CALL(T) { if (psc) CALL_A(T, true) else CALL_A(T, false) }
+  switch (dtype) {
+    case MRLA_F32:  CALL(float) break;
+    case MRLA_BF16: CALL(bf16_t) break;
+    case MRLA_F16:  CALL(f16_t) break;
+    default: return MRLA_EINVAL;
+  }
+#undef CALL
+#undef CALL_A
+  return hip_status(hipGetLastError());
+}
+
+
+int launch_light_apply_bwd_wide(const void* dout, const void* x, const void* o, const float* wv, const float* gate,
+                                const float* cb, const float* lam, const float* dp, const float* dyx, void* dx,
+                                void* dprev, float* dwv_part, int B, int C, int H, int W, int d, int res, int relu,
+                                int dtype, int act, hipStream_t st) {
+  const bool ragged = (W % kS) != 0;
+  const int bg = nhwc_images_per_group(B, C, W);          // = the rows mrla_light_wgrad_rows() promised
+#define CALL_G(T, A, O, R, RG)                                                                                       \
+  {                                                                                                                  \
+    const WideLaunch L = wide_launch(B, C, W, 9, apply_bwd_wave_bytes<T>(), bg);                                      \
+    if (set_lds_n(light_apply_bwd_wide<T, A, O, R, RG>, L.lds) != hipSuccess) return MRLA_EHIP;                        \
+    hipLaunchKernelGGL((light_apply_bwd_wide<T, A, O, R, RG>), L.grid, L.block, L.lds, st, (const T*)dout,            \
+                       (const T*)x, (const T*)o, wv, gate, cb, lam, dp, dyx, (T*)dx, (T*)dprev, dwv_part, B, C, H, W, \
+                       L.BG, d, res);                                                                                \
+  }
+#define CALL_R(T, A, O, R) { if (ragged) CALL_G(T, A, O, R, true) else CALL_G(T, A, O, R, false) }
+#define CALL(T, A, O)                                                                        \
+  {                                                                                          \
+    if (relu) { if (O && !(A)) CALL_R(T, false, true, true) else return MRLA_EINVAL; }       \
+    else CALL_R(T, A, O, false)                                                              \
+  }
+  MRLA_DISPATCH_T_N(dtype, act, o != nullptr, CALL)
+#undef CALL
+#undef CALL_R
+#undef CALL_G
+  return hip_status(hipGetLastError());
+}
+
+int launch_light_stats_bwd_wide(const void* dout, const void* x, const void* o, const float* wv, float* bmom, int B,
+                                int C, int H, int W, int dtype, int act, hipStream_t st) {
+#define CALL(T, A, O)                                                                                              \
+  {                                                                                                                \
+    const WideLaunch L = wide_launch(B, C, W, D_N, stats_bwd_wave_bytes<T>(), nhwc_images_per_group(B, C, 0));     \
+    if (set_lds_n(light_stats_bwd_wide<T, A, O>, L.lds) != hipSuccess) return MRLA_EHIP;                            \
+    hipLaunchKernelGGL((light_stats_bwd_wide<T, A, O>), L.grid, L.block, L.lds, st, (const T*)dout, (const T*)x,    \
+                       (const T*)o, wv, bmom, B, C, H, W, L.BG);                                                   \
+  }
+  MRLA_DISPATCH_T_N(dtype, act, o != nullptr, CALL)
+#undef CALL
+  return hip_status(hipGetLastError());
+}
+
+}  // namespace mrla

@@ -142,6 +142,26 @@ int launch_affine_act(const void* x, const void* dy, const float* a, const float
 
 // light_nhwc.hip / bnact_nhwc.hip -- channels_last variants
 int nhwc_images_per_group(int B, int C, int W);
+// conv1x1.hip -- 1x1 convolution as an MFMA GEMM with a BatchNorm-moments epilogue (bf16)
+int conv1x1_rows(int M, int K, int N);
+int launch_conv1x1_fwd(const void* x, const void* w, void* y, float* part, int M, int K, int N, hipStream_t st);
+// light_nhwc_wide.hip -- the C % 64 == 0 forms on the LDS-DMA row pipeline (nhwc_rows.h)
+int launch_light_stats_fwd_wide(const void* x, const void* o, const float* wv, float* mom, void* xout, const float* psc,
+                                const float* psh, void* vout, int B, int C, int H, int W, int dtype, int act,
+                                hipStream_t st);
+int launch_light_apply_fwd_wide(const void* x, const void* o, const float* wv, const float* gate, const float* sc,
+                                const float* sh, const float* lam, const float* dp, void* out, int B, int C, int H,
+                                int W, int d, int res, int dtype, int act, hipStream_t st);
+int launch_light_apply_fwd_pre_wide(const void* pre, const void* o, const float* psc, const float* psh, const float* wv,
+                                    const float* gate, const float* sc, const float* sh, const float* lam,
+                                    const float* dp, void* out, int B, int C, int H, int W, int d, int res, int dtype,
+                                    hipStream_t st);
+int launch_light_apply_bwd_wide(const void* dout, const void* x, const void* o, const float* wv, const float* gate,
+                                const float* cb, const float* lam, const float* dp, const float* dyx, void* dx,
+                                void* dprev, float* dwv_part, int B, int C, int H, int W, int d, int res, int relu,
+                                int dtype, int act, hipStream_t st);
+int launch_light_stats_bwd_wide(const void* dout, const void* x, const void* o, const float* wv, float* bmom, int B,
+                                int C, int H, int W, int dtype, int act, hipStream_t st);
 int launch_light_stats_fwd_nhwc(const void* x, const void* o, const float* wv, float* mom, void* xout,
                                 const float* psc, const float* psh, void* vout, int B, int C, int H, int W, int dtype,
                                 int act, hipStream_t st);

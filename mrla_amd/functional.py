@@ -658,7 +658,8 @@ class _BnActFn(torch.autograd.Function):
 
     @staticmethod
     @_on_device
-    def forward(ctx, x, gamma, beta, running_mean, running_var, training, momentum, eps, relu, defer=False):
+    def forward(ctx, x, gamma, beta, running_mean, running_var, training, momentum, eps, relu, defer=False,
+                pre_moments=None):
         _require_cuda(x, "fused bn/act forward")
         layout, xc = _layout_of(x)
         b, c, h, w = xc.shape
@@ -669,12 +670,18 @@ class _BnActFn(torch.autograd.Function):
         rs = _RunningStats(running_mean, running_var, c, "fused bn/act forward")
         bnbuf = torch.empty((4, c), dtype=torch.float32, device=dev)       # sc, sh, save_mean, save_inv
         rows = L.load().mrla_bn_moment_rows(b, c, h, w, layout)           # partial-sum rows (b, or b*nsplit for NHWC)
-        amom = torch.empty((rows, c, 2), dtype=torch.float32, device=dev)
-        if training:
-            _call("mrla_bn_plane_moments", xc.numel() * xc.element_size(), _ptr(xc), _ptr(amom), b, c, h, w, dt, layout, st)
+        frows = rows
+        if training and pre_moments is not None:      # the producer (the 1x1 convolution GEMM) already took them
+            amom, frows = pre_moments, pre_moments.shape[0]
+            if tuple(amom.shape) != (frows, c, 2) or amom.dtype != torch.float32 or (b * h * w) % frows:
+                raise L.MrlaHipError("pre_moments must be float32 [rows, c, 2] with rows dividing b*h*w")
+        else:
+            amom = torch.empty((rows, c, 2), dtype=torch.float32, device=dev)
+            if training:
+                _call("mrla_bn_plane_moments", xc.numel() * xc.element_size(), _ptr(xc), _ptr(amom), b, c, h, w, dt, layout, st)
         L.call("mrla_bn_stats_fwd", _ptr(amom), _ptr(gamma32), _ptr(beta32), _ptr(rs.rm), _ptr(rs.rv),
                L.BN_TRAIN if training else L.BN_EVAL, float(momentum), float(eps), _ptr(bnbuf[0]), _ptr(bnbuf[1]),
-               _ptr(bnbuf[2]), _ptr(bnbuf[3]), rows, c, b * h * w // rows, st)
+               _ptr(bnbuf[2]), _ptr(bnbuf[3]), frows, c, b * h * w // frows, st)
         rs.finish(training)
         ctx.training, ctx.relu, ctx.gdtype, ctx.layout, ctx.rows = training, int(relu), gamma.dtype, layout, rows
         ctx.save_for_backward(xc, gamma32, bnbuf)
@@ -710,10 +717,10 @@ class _BnActFn(torch.autograd.Function):
         dx = torch.empty_like(xc)
         _call("mrla_bn_act_bwd", xc.numel() * es * 3, _ptr(dy), _ptr(xc), _ptr(bnbuf[0]), _ptr(bnbuf[1]), _ptr(cb), ctx.relu,
               _ptr(dx), b, c, h, w, dt, layout, st)
-        return dx, small[3].to(ctx.gdtype), small[4].to(ctx.gdtype), None, None, None, None, None, None, None
+        return dx, small[3].to(ctx.gdtype), small[4].to(ctx.gdtype), None, None, None, None, None, None, None, None
 
 
-def bn_act(x, bn, relu, defer=False):
+def bn_act(x, bn, relu, defer=False, pre_moments=None):
     """relu?(bn(x)) for an nn.BatchNorm2d module `bn` on the fused HIP passes; any other norm layer (or a layout /
     device the kernels do not handle) runs as the caller's module followed by torch.relu.
     defer=True (relu must be False): only the statistics are taken; the returned tensor aliases x and carries the
@@ -728,10 +735,75 @@ def bn_act(x, bn, relu, defer=False):
                 momentum = 1.0 / float(bn.num_batches_tracked)
         if defer:
             y, buf = _BnActFn.apply(x, bn.weight, bn.bias, bn.running_mean, bn.running_var, training, momentum or 0.0,
-                                    bn.eps, False, True)
+                                    bn.eps, False, True, pre_moments)
             y._mrla_affine = (buf[0], buf[1])
             return y
         return _BnActFn.apply(x, bn.weight, bn.bias, bn.running_mean, bn.running_var, training, momentum or 0.0, bn.eps,
-                              relu)
+                              relu, False, pre_moments)
     y = bn(x)
     return torch.relu(y) if relu else y
+
+
+# ======================================================================================================
+# 1x1 stride-1 convolution as an MFMA GEMM with the BatchNorm statistics in its epilogue
+# ======================================================================================================
+class _Conv1x1Fn(torch.autograd.Function):
+    """y = conv2d(x, w) for a bias-free 1x1 stride-1 convolution of a channels_last bf16 tensor (mrla_conv1x1_fwd), plus the
+    partial (sum, sum^2) rows of y the following BatchNorm needs.  Backward is the stock convolution backward."""
+
+    @staticmethod
+    @_on_device
+    def forward(ctx, x, w, want_moments):
+        b, k, h, wd = x.shape
+        n = w.shape[0]
+        m = b * h * wd
+        dev, st = x.device, _stream()
+        y = torch.empty((b, n, h, wd), dtype=x.dtype, device=dev, memory_format=_CL)
+        part = None
+        if want_moments:
+            rows = L.load().mrla_conv1x1_rows(m, k, n, _DT[x.dtype])
+            L.check(min(rows, 0), "mrla_conv1x1_rows")
+            part = torch.empty((rows, n, 2), dtype=torch.float32, device=dev)
+        _call("mrla_conv1x1_fwd", (x.numel() + y.numel()) * x.element_size(), _ptr(x), _ptr(w), _ptr(y), _ptr(part), m, k, n,
+              _DT[x.dtype], st)
+        ctx.save_for_backward(x, w)
+        if part is None:
+            part = torch.empty(0, device=dev)
+        ctx.mark_non_differentiable(part)
+        return y, part
+
+    @staticmethod
+    @_on_device
+    def backward(ctx, dy, _dpart=None):
+        x, w = ctx.saved_tensors
+        dy = dy.contiguous(memory_format=_CL)
+        gx, gw, _ = torch.ops.aten.convolution_backward(dy, x, w, None, (1, 1), (0, 0), (1, 1), False, (0, 0), 1,
+                                                       [ctx.needs_input_grad[0], ctx.needs_input_grad[1], False])
+        return gx, gw, None
+
+
+def conv1x1_applies(conv, x):
+    """True when `conv(x)` can run on the MFMA GEMM: nn.Conv2d 1x1 / stride 1 / no bias, channels_last bf16 input, and a
+    shape the kernel takes (mrla_conv1x1_rows)."""
+    if not (type(conv) is torch.nn.Conv2d and conv.kernel_size == (1, 1) and conv.stride == (1, 1)
+            and conv.padding == (0, 0) and conv.dilation == (1, 1) and conv.groups == 1 and conv.bias is None):
+        return False
+    if not (x.is_cuda and x.dim() == 4 and x.dtype == torch.bfloat16 and x.is_contiguous(memory_format=_CL)):
+        return False
+    b, k, h, w = x.shape
+    return k == conv.in_channels and L.load().mrla_conv1x1_rows(b * h * w, k, conv.out_channels, L.BF16) > 0
+
+
+def conv_bn_act(x, conv, bn, relu, defer=False):
+    """relu?(bn(conv(x))) -- resnet_mrla_light.py:93-94,100-101.  Eligible 1x1 convolutions run on the HIP GEMM, whose
+    epilogue hands the train-mode BatchNorm its statistics (the moments pass over the output disappears); everything
+    else is `bn_act(conv(x), ...)` with the stock convolution."""
+    fused_bn = (type(bn) is torch.nn.BatchNorm2d and bn.affine and bn.track_running_stats)
+    if conv1x1_applies(conv, x):
+        wt = conv.weight
+        if wt.dtype != x.dtype:
+            wt = wt.to(x.dtype)                      # what autocast does for the stock convolution (differentiable)
+        wt = wt.reshape(conv.out_channels, conv.in_channels)
+        y, part = _Conv1x1Fn.apply(x, wt, bool(fused_bn and bn.training))
+        return bn_act(y, bn, relu, defer, pre_moments=part if part.numel() else None)
+    return bn_act(conv(x), bn, relu, defer)

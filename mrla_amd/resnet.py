@@ -78,12 +78,17 @@ class _BottleneckTrunk(nn.Module):
         defer_bn3 (bool, or a predicate on conv3's output): only bn3's statistics are taken here; its affine is applied
         by the consumer's first pass."""
         identity = x
-        out = F_.bn_act(self.conv1(x), self.bn1, relu=True)          # fused BatchNorm+ReLU HIP passes
+        # 1x1 convolutions: HIP MFMA GEMM with the BatchNorm statistics in its epilogue when eligible (bf16, channels_last)
+        out = F_.conv_bn_act(x, self.conv1, self.bn1, relu=True)     # fused BatchNorm+ReLU HIP passes
         out = F_.bn_act(self.conv2(out), self.bn2, relu=True)
-        out = self.conv3(out)
         if self.se is not None or self.eca is not None:     # channel attention reads bn3's output: nothing to defer
             defer_bn3 = False
-        out = F_.bn_act(out, self.bn3, relu=False, defer=defer_bn3(out) if callable(defer_bn3) else defer_bn3)
+        if callable(defer_bn3):                              # the predicate looks at conv3's output shape / layout only
+            b_, _, h_, w_ = out.shape
+            cl = out.is_contiguous(memory_format=torch.channels_last) and not out.is_contiguous()
+            defer_bn3 = defer_bn3(torch.empty((b_, self.conv3.out_channels, h_, w_), dtype=out.dtype, device="meta",
+                                              memory_format=torch.channels_last if cl else torch.contiguous_format))
+        out = F_.conv_bn_act(out, self.conv3, self.bn3, relu=False, defer=defer_bn3)
         if self.se is not None:
             out = self.se(out)
         if self.eca is not None:
@@ -91,7 +96,7 @@ class _BottleneckTrunk(nn.Module):
         if self.downsample is not None:
             ds = self.downsample
             if isinstance(ds, nn.Sequential) and len(ds) == 2 and isinstance(ds[0], nn.Conv2d):
-                identity = F_.bn_act(ds[0](x), ds[1], relu=False)
+                identity = F_.conv_bn_act(x, ds[0], ds[1], relu=False)
             else:
                 identity = ds(x)
         return out, identity

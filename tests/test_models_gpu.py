@@ -185,3 +185,39 @@ def test_kernels_launch_on_the_tensor_device_not_the_current_one():
         y2.sum().backward()
     torch.cuda.synchronize(1)
     assert torch.equal(y1, y2) and torch.equal(x.grad, x2.grad)
+
+
+@pytest.mark.parametrize("arch", ["resnet50_mrlal", "resnet50_mrlab"])
+def test_bf16_autocast_train_step_tracks_the_eager_restatement(arch):
+    """The configuration bench.py times (bf16 autocast, channels_last): the 1x1 convolutions then run on the MFMA GEMM with
+    the BatchNorm statistics in its epilogue.  One training step vs the eager restatement under the same autocast: logits
+    and loss agree to bf16 accuracy, every gradient is finite and the whole gradient points the same way."""
+    from mrla_amd import functional as Fm, models
+    net, ref = getattr(models, arch)().cuda(), getattr(em, "eager_" + arch)().cuda()
+    load_det(net)
+    ref.load_state_dict(net.state_dict())
+    net.train(); ref.train()
+    x = torch.from_numpy(cases.image_batch(8, "img-train")).cuda()
+    tgt = (torch.arange(8) * 37 % 1000).cuda()
+    used = []
+    orig = Fm._Conv1x1Fn.apply
+    try:
+        Fm._Conv1x1Fn.apply = staticmethod(lambda *a: (used.append(1), orig(*a))[1])
+        with torch.autocast("cuda", dtype=torch.bfloat16):
+            y = net(x)
+    finally:
+        Fm._Conv1x1Fn.apply = orig
+    assert len(used) >= 20, "the MFMA GEMM path was not taken under autocast"
+    with torch.autocast("cuda", dtype=torch.bfloat16):
+        yr = ref(x)
+    la = torch.nn.functional.cross_entropy(y.float(), tgt)
+    lb = torch.nn.functional.cross_entropy(yr.float(), tgt)
+    assert abs(la.item() - lb.item()) < 3e-2 * abs(lb.item())
+    assert rel(y.detach().float().cpu().numpy(), yr.detach().float().cpu().numpy()) < 6e-2
+    la.backward(); lb.backward()
+    dots = np.zeros(3)
+    for (k, pa), (_, pb) in zip(net.named_parameters(), ref.named_parameters()):
+        assert torch.isfinite(pa.grad).all(), k
+        a, b = pa.grad.double().flatten(), pb.grad.double().flatten()
+        dots += np.array([float(a @ b), float(a @ a), float(b @ b)])
+    assert dots[0] / np.sqrt(dots[1] * dots[2]) > 0.99

@@ -13,8 +13,9 @@
 //   * the W slice of the workgroup stays in LDS for the whole kernel (rows padded by 16 B: conflict-free b128 reads);
 //     a workgroup is persistent over pixel blocks, its 8 waves split (pixel blocks) x (64-channel pairs);
 //   * the accumulator tile has the pixel on the lane and 16 channels in registers; after rounding to bf16 a
-//     v_permlane32_swap between the two half-waves leaves every lane with 2 x 16 contiguous bytes of its pixel's
-//     output row: 16-byte stores without an LDS round trip;
+//     v_permlane32_swap between the two half-waves leaves every lane with 16-byte pieces of its pixel's output row;
+//     a wave-private LDS tile [32 pixels][64 channels] then turns them into stores of whole 128-byte lines (8 lanes
+//     per pixel) -- 32-byte fragments per pixel straight from the lanes cost the L2 four requests per line;
 //   * the BatchNorm moments are per-lane running sums over the wave's pixels (register = channel), reduced across
 //     lanes once at the end of the kernel and written as one partial row per (workgroup, pixel-wave).
 #include <algorithm>
@@ -27,31 +28,33 @@ namespace mrla {
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
-constexpr int kGemmWaves = 8;
+constexpr int kOutRowB = 64 * 2 + 16;               // padded row of the per-wave output tile (64 channels of one pixel)
+constexpr int kOutTileB = 32 * kOutRowB;
 
 // channel of accumulator register `reg` inside its 32-channel tile, for lane half h
 __device__ __forceinline__ int acc_channel(int reg, int h) { return (reg & 3) + 8 * (reg >> 2) + 4 * h; }
 
-template <int KS, bool MOM>
-__global__ __launch_bounds__(kGemmWaves * kWave) void conv1x1_fwd_kernel(
+template <int KS, bool MOM, int NW>
+__global__ __launch_bounds__(NW * kWave) void conv1x1_fwd_kernel(
     const bf16_t* __restrict__ X, const bf16_t* __restrict__ W, bf16_t* __restrict__ Y, float* __restrict__ part,
-    int M, int N, int NS, int WN) {
+    int M, int N, int NS, int WN, int rows_total) {
   constexpr int K = KS * 16;
   constexpr int ROWB = K * 2 + 16;                   // padded LDS row of W, bytes
   constexpr int KC = KS < 16 ? KS : 16;              // k-steps whose X fragments are in registers at a time
   constexpr int NCH = KS / KC;
-  constexpr bool DB = KS <= 4;                       // double-buffer the X fragments when they are small
+  constexpr bool DB = KS <= 16;                      // the next pixel block's X fragments are fetched during this one's MFMAs
   extern __shared__ __align__(16) unsigned char smem_raw[];
   const int lane = threadIdx.x & (kWave - 1), wave = threadIdx.x / kWave;
   const int r = lane & 31, h = lane >> 5;
-  const int WM = kGemmWaves / WN, wn = wave % WN, wm = wave / WN;
+  const int WM = NW / WN, wn = wave % WN, wm = wave / WN;
   const int n_slice0 = blockIdx.y * NS;
+  unsigned char* otile = smem_raw + (size_t)NS * ROWB + (size_t)wave * kOutTileB;      // after the W slice
 
   // stage the W slice [NS][K] into LDS (16-byte pieces, coalesced)
   {
     constexpr int PPR = K / 8;                       // 16-byte pieces per row
     const u32x4* wsrc = reinterpret_cast<const u32x4*>(W + (size_t)n_slice0 * K);
-    for (int i = threadIdx.x; i < NS * PPR; i += kGemmWaves * kWave) {
+    for (int i = threadIdx.x; i < NS * PPR; i += NW * kWave) {
       const int row = i / PPR, pc = i - row * PPR;
       *reinterpret_cast<u32x4*>(smem_raw + (size_t)row * ROWB + pc * 16) = wsrc[i];
     }
@@ -64,13 +67,14 @@ __global__ __launch_bounds__(kGemmWaves * kWave) void conv1x1_fwd_kernel(
 #pragma unroll
     for (int i = 0; i < 16; ++i) { s1[t][i] = 0.f; s2[t][i] = 0.f; }
 
-  const int nblk = M / 32;
+  const int nblk = (M + 31) / 32;
   const int stride = gridDim.x * WM;
   int blk = blockIdx.x * WM + wm;
   u32x4 xf[KC], xn[DB ? KC : 1];
   // K chunk `kc` (KC k-steps) of the X fragments of pixel block b_
   auto load_x = [&](u32x4 (&dst)[KC], int b_, int kc) {
-    const u32x4* xp = reinterpret_cast<const u32x4*>(X + ((size_t)b_ * 32 + r) * K + kc * KC * 16 + h * 8);
+    const int row = min(b_ * 32 + r, M - 1);        // (rows past the end are loaded clamped and never used)
+    const u32x4* xp = reinterpret_cast<const u32x4*>(X + (size_t)row * K + kc * KC * 16 + h * 8);
 #pragma unroll
     for (int ks = 0; ks < KC; ++ks) dst[ks] = xp[ks * 2];
   };
@@ -79,7 +83,7 @@ __global__ __launch_bounds__(kGemmWaves * kWave) void conv1x1_fwd_kernel(
     if constexpr (DB) {
       if (blk + stride < nblk) load_x(reinterpret_cast<u32x4(&)[KC]>(xn), blk + stride, 0);
     }
-    const size_t m = (size_t)blk * 32 + r;
+    const float live = (blk * 32 + r < M) ? 1.f : 0.f;       // this lane's pixel exists (ragged last block)
     f32x16 acc[2];
 #pragma unroll
     for (int t = 0; t < 2; ++t)
@@ -112,7 +116,7 @@ __global__ __launch_bounds__(kGemmWaves * kWave) void conv1x1_fwd_kernel(
         pr[1] = from_f<bf16_t>(acc[t][2 * i + 1]);
         p[i] = __builtin_bit_cast(unsigned, pr);
         if (MOM) {
-          const float lo = __uint_as_float(p[i] << 16), hi = __uint_as_float(p[i] & 0xffff0000u);
+          const float lo = live * __uint_as_float(p[i] << 16), hi = live * __uint_as_float(p[i] & 0xffff0000u);
           s1[t][2 * i] += lo;     s2[t][2 * i] = fmaf(lo, lo, s2[t][2 * i]);
           s1[t][2 * i + 1] += hi; s2[t][2 * i + 1] = fmaf(hi, hi, s2[t][2 * i + 1]);
         }
@@ -130,9 +134,21 @@ __global__ __launch_bounds__(kGemmWaves * kWave) void conv1x1_fwd_kernel(
         }
       }
 #endif
-      bf16_t* yp = Y + m * N + n_slice0 + nloc + h * 8;
-      *reinterpret_cast<u32x4*>(yp) = (u32x4){p[0], p[1], p[2], p[3]};
-      *reinterpret_cast<u32x4*>(yp + 16) = (u32x4){p[4], p[5], p[6], p[7]};
+      // this lane's pieces of its pixel's row in the wave's output tile: channels t*32 + h*8 .. and t*32 + 16 + h*8 ..
+      unsigned char* orow = otile + r * kOutRowB + (t * 32 + h * 8) * 2;
+      *reinterpret_cast<u32x4*>(orow) = (u32x4){p[0], p[1], p[2], p[3]};
+      *reinterpret_cast<u32x4*>(orow + 32) = (u32x4){p[4], p[5], p[6], p[7]};
+    }
+    // whole lines out: 8 lanes per pixel (64 channels = 128 bytes), 8 pixels per store instruction
+    {
+      const int px = lane >> 3, piece = lane & 7;
+      bf16_t* ybase = Y + (size_t)blk * 32 * N + n_slice0 + wn * 64 + piece * 8;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int pr = i * 8 + px;
+        const u32x4 v = *reinterpret_cast<const u32x4*>(otile + pr * kOutRowB + piece * 16);
+        if (blk * 32 + pr < M) *reinterpret_cast<u32x4*>(ybase + (size_t)pr * N) = v;
+      }
     }
     if constexpr (DB) {
 #pragma unroll
@@ -143,6 +159,14 @@ __global__ __launch_bounds__(kGemmWaves * kWave) void conv1x1_fwd_kernel(
   }
 
   if (MOM) {
+    // rows beyond the active (workgroup, pixel-wave) pairs only exist to make the row count divide M: zeros
+    if (blockIdx.x == 0) {
+      const int active = gridDim.x * WM;
+      for (int i = threadIdx.x; i < (rows_total - active) * NS * 2; i += NW * kWave) {
+        const int row = active + i / (NS * 2), j = i % (NS * 2);
+        part[((size_t)row * N + n_slice0) * 2 + j] = 0.f;
+      }
+    }
     // sum over the 32 pixel-lanes of each half (fixed order), one partial row per (workgroup, pixel-wave)
     float* dst = part + ((size_t)(blockIdx.x * WM + wm) * N + n_slice0 + wn * 64) * 2;
 #pragma unroll
@@ -167,27 +191,37 @@ __global__ __launch_bounds__(kGemmWaves * kWave) void conv1x1_fwd_kernel(
 // ------------------------------------------------------------------------------------------------
 // geometry: N slice per workgroup (LDS), waves along N, persistent grid
 // ------------------------------------------------------------------------------------------------
-struct GemmGeo { int NS, WN, WM, gx, gy, rows; size_t lds; };
+struct GemmGeo { int NS, WN, WM, NW, gx, gy, rows; size_t lds; };
 
 static bool conv1x1_geo(GemmGeo* g, int M, int K, int N) {
-  if (K != 64 && K != 128 && K != 256 && K != 512) return false;
-  if (N % 64 || M % 32 || M <= 0) return false;
+  // K = 512 (two fragment chunks per pixel block, no prefetch across them) is slower than the stock convolution: not taken
+  if (K != 64 && K != 128 && K != 256) return false;
+  if (N % 64 || M <= 0) return false;
   const int rowb = K * 2 + 16;
-  int ns = std::min(N, (80 * 1024 / rowb) / 64 * 64);
-  ns = std::min(ns, 256);                            // at most 4 channel pairs per workgroup (8 waves: >= 2 pixel waves)
-  while (ns > 64 && (N % ns || (ns / 64 != 1 && ns / 64 != 2 && ns / 64 != 4))) ns -= 64;
+  int ns = std::min(N, 256);                         // at most 4 channel pairs (= waves along N) per workgroup
+  while (ns > 64 && (N % ns || (ns / 64 != 1 && ns / 64 != 2 && ns / 64 != 4) || (size_t)ns * rowb > 72 * 1024)) ns -= 64;
   if (N % ns) return false;
   g->NS = ns;
   g->WN = ns / 64;
-  g->WM = kGemmWaves / g->WN;
+  // 4-wave workgroups while the X fragments are small (more workgroups per CU under the register budget), else 8
+  g->NW = K <= 128 ? 4 : 8;
+  if (g->NW < g->WN) g->NW = g->WN;
+  g->WM = g->NW / g->WN;
   g->gy = N / ns;
-  g->lds = (size_t)ns * rowb;
-  const int nblk = M / 32;
-  // persistent workgroups: about two per CU over the whole grid; rows must divide M for the statistics kernel
-  int gx = std::max(1, std::min((nblk + g->WM - 1) / g->WM, 512 / g->gy > 0 ? 512 / g->gy : 1));
-  while (gx > 1 && (M % (gx * g->WM)) != 0) --gx;
+  g->lds = (size_t)ns * rowb + (size_t)g->NW * kOutTileB;
+  const int nblk = (M + 31) / 32;
+  // persistent workgroups: a few per CU over the whole grid; rows must divide M for the statistics kernel
+  const int want = std::max(1, (256 * (g->NW == 4 ? 3 : 2)) / g->gy);
+  int gx = std::max(1, std::min((nblk + g->WM - 1) / g->WM, want));
+  // the statistics kernel takes (rows, M / rows): prefer a grid whose (workgroup, pixel-wave) count divides M, else pad
+  // the partial buffer with zero rows up to the next divisor of M
+  for (int t = gx; t >= std::max(1, gx - gx / 4); --t)
+    if (M % (t * g->WM) == 0) { gx = t; break; }
+  int rows = gx * g->WM;
+  while (rows <= 2 * gx * g->WM + 64 && M % rows) ++rows;
+  if (M % rows) return false;
   g->gx = gx;
-  g->rows = gx * g->WM;
+  g->rows = rows;
   return true;
 }
 
@@ -199,26 +233,27 @@ int conv1x1_rows(int M, int K, int N) {
 int launch_conv1x1_fwd(const void* x, const void* w, void* y, float* part, int M, int K, int N, hipStream_t st) {
   GemmGeo g;
   if (!conv1x1_geo(&g, M, K, N)) return MRLA_EUNSUPPORTED;
-  const dim3 grid(g.gx, g.gy), block(kGemmWaves * kWave);
-#define CALL_M(KS, MO)                                                                                           \
-  {                                                                                                              \
-    if (g.lds > 48 * 1024 &&                                                                                     \
-        hipFuncSetAttribute(reinterpret_cast<const void*>(conv1x1_fwd_kernel<KS, MO>),                           \
-                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)g.lds) != hipSuccess)               \
-      return MRLA_EHIP;                                                                                          \
-    hipLaunchKernelGGL((conv1x1_fwd_kernel<KS, MO>), grid, block, g.lds, st, (const bf16_t*)x, (const bf16_t*)w, \
-                       (bf16_t*)y, part, M, N, g.NS, g.WN);                                                      \
+  const dim3 grid(g.gx, g.gy), block(g.NW * kWave);
+#define CALL_W(KS, MO, NWV)                                                                                          \
+  {                                                                                                                  \
+    if (g.lds > 48 * 1024 &&                                                                                         \
+        hipFuncSetAttribute(reinterpret_cast<const void*>(conv1x1_fwd_kernel<KS, MO, NWV>),                          \
+                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)g.lds) != hipSuccess)                   \
+      return MRLA_EHIP;                                                                                              \
+    hipLaunchKernelGGL((conv1x1_fwd_kernel<KS, MO, NWV>), grid, block, g.lds, st, (const bf16_t*)x, (const bf16_t*)w, \
+                       (bf16_t*)y, part, M, N, g.NS, g.WN, g.rows);                                                  \
   }
+#define CALL_M(KS, MO) { if (g.NW == 4) CALL_W(KS, MO, 4) else CALL_W(KS, MO, 8) }
 #define CALL(KS) { if (part) CALL_M(KS, true) else CALL_M(KS, false) }
   switch (K) {
     case 64:  CALL(4) break;
     case 128: CALL(8) break;
     case 256: CALL(16) break;
-    case 512: CALL(32) break;
     default: return MRLA_EUNSUPPORTED;
   }
 #undef CALL
 #undef CALL_M
+#undef CALL_W
   return hip_status(hipGetLastError());
 }
 

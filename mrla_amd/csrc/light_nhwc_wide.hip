@@ -463,8 +463,11 @@ template <typename T> constexpr int apply_bwd_wave_bytes() {
   return RowIO<T, kS + 4>::kBytes + 3 * RowIO<T, kS + 2>::kBytes + 2 * RowIO<T, kS>::kBytes;
 }
 
+// Workgroups of at most 4 waves (a wave walks several strips of a wide image) and a register budget of 168: three waves
+// per SIMD instead of the two an 8-wave workgroup at ~170 registers allows -- the pass is bound by vector issue.
+constexpr int kBwdWaves = 4;
 template <typename T, bool GELU, bool HAS_O, bool RELU, bool RAGGED>
-__global__ __launch_bounds__(kMaxStrips * kWave) void light_apply_bwd_wide(
+__global__ __launch_bounds__(kBwdWaves * kWave, 3) void light_apply_bwd_wide(
     const T* __restrict__ dout, const T* __restrict__ x, const T* __restrict__ o, const float* __restrict__ wv,
     const float* __restrict__ gate, const float* __restrict__ cb, const float* __restrict__ lam,
     const float* __restrict__ dp, const float* __restrict__ dyx, T* __restrict__ dx, T* __restrict__ dprev,
@@ -605,9 +608,9 @@ __global__ __launch_bounds__(kMaxStrips * kWave) void light_apply_bwd_wide(
 }
 
 struct WideLaunch { dim3 grid, block; size_t lds; int BG; };
-static WideLaunch wide_launch(int B, int C, int W, int nred, size_t wave_bytes, int bg) {
+static WideLaunch wide_launch(int B, int C, int W, int nred, size_t wave_bytes, int bg, int max_waves = kMaxStrips) {
   WideLaunch L;
-  const int nwaves = std::min((W + kS - 1) / kS, kMaxStrips);
+  const int nwaves = std::min((W + kS - 1) / kS, max_waves);
   L.BG = bg;
   L.grid = dim3(C / kWave, (B + bg - 1) / bg);
   L.block = dim3(nwaves * kWave);
@@ -704,7 +707,7 @@ int launch_light_apply_bwd_wide(const void* dout, const void* x, const void* o, 
   const int bg = nhwc_images_per_group(B, C, W);          // = the rows mrla_light_wgrad_rows() promised
 #define CALL_G(T, A, O, R, RG)                                                                                       \
   {                                                                                                                  \
-    const WideLaunch L = wide_launch(B, C, W, 9, apply_bwd_wave_bytes<T>(), bg);                                      \
+    const WideLaunch L = wide_launch(B, C, W, 9, apply_bwd_wave_bytes<T>(), bg, kBwdWaves);                           \
     if (set_lds_n(light_apply_bwd_wide<T, A, O, R, RG>, L.lds) != hipSuccess) return MRLA_EHIP;                        \
     hipLaunchKernelGGL((light_apply_bwd_wide<T, A, O, R, RG>), L.grid, L.block, L.lds, st, (const T*)dout,            \
                        (const T*)x, (const T*)o, wv, gate, cb, lam, dp, dyx, (T*)dx, (T*)dprev, dwv_part, B, C, H, W, \

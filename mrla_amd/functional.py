@@ -777,9 +777,10 @@ class _Conv1x1Fn(torch.autograd.Function):
     def backward(ctx, dy, _dpart=None):
         x, w = ctx.saved_tensors
         dy = dy.contiguous(memory_format=_CL)
-        gx, gw, _ = torch.ops.aten.convolution_backward(dy, x, w, None, (1, 1), (0, 0), (1, 1), False, (0, 0), 1,
+        gx, gw, _ = torch.ops.aten.convolution_backward(dy, x, w.view(w.shape[0], w.shape[1], 1, 1), None, (1, 1), (0, 0),
+                                                       (1, 1), False, (0, 0), 1,
                                                        [ctx.needs_input_grad[0], ctx.needs_input_grad[1], False])
-        return gx, gw, None
+        return gx, gw.view(w.shape) if gw is not None else None, None
 
 
 def conv1x1_applies(conv, x):

@@ -28,8 +28,8 @@ def timeit(fn):
 
 
 tot = [0.0, 0.0, 0.0, 0.0]
-for (cin, cout, hw, n) in [(64, 64, 56, 1), (64, 256, 56, 4), (256, 64, 56, 2), (256, 128, 56, 1), (128, 512, 28, 4), (512, 128, 28, 3),
-                           (512, 256, 28, 1), (256, 1024, 14, 6), (512, 2048, 7, 3)]:
+for (cin, cout, hw, n) in [(64, 64, 56, 1), (64, 256, 56, 4), (256, 64, 56, 2), (256, 128, 56, 1), (128, 512, 28, 4),
+                           (256, 1024, 14, 6)]:
     x = torch.randn(B, cin, hw, hw, device="cuda").bfloat16().contiguous(memory_format=torch.channels_last)
     w = (torch.randn(cout, cin, 1, 1, device="cuda") * 0.05).bfloat16().contiguous(memory_format=torch.channels_last)
     w2 = w.view(cout, cin)

@@ -15,7 +15,7 @@ out = sys.argv[2] if len(sys.argv) > 2 else raw
 
 
 def short(name):
-    for key in ("light_stats_fwd", "light_apply_fwd", "light_stats_bwd", "light_apply_bwd", "plane_moments_small",
+    for key in ("light_stats_fwd_fused", "conv1x1_fwd", "light_stats_fwd", "light_apply_fwd_pre", "light_apply_fwd", "light_stats_bwd", "light_apply_bwd", "plane_moments_small",
                 "plane_moments", "affine_act", "nhwc_moments_flat", "nhwc_affine_flat", "nhwc_moments", "nhwc_affine",
                 "base_combine_nhwcIDF16bDF16bLi0", "base_combine_nhwcIDF16bDF16bLi1", "base_combine", "base_attend_fwd",
                 "base_attend_bwd", "base_value_bwd", "base_tail", "base_pmom",
@@ -33,6 +33,8 @@ def pmc(kind, counter):
     for r in csv.DictReader(open(f[0])):
         if "mrla" in r["Kernel_Name"] and r["Counter_Name"] == counter:
             agg[short(r["Kernel_Name"])].append(float(r["Counter_Value"]))
+            if "conv1x1" in r["Kernel_Name"]:       # per shape as well (grid size identifies it)
+                agg[short(r["Kernel_Name"]) + "/grid" + r.get("Grid_Size", "")].append(float(r["Counter_Value"]))
     return agg
 
 

@@ -207,7 +207,7 @@ def test_bf16_autocast_train_step_tracks_the_eager_restatement(arch):
             y = net(x)
     finally:
         Fm._Conv1x1Fn.apply = orig
-    assert len(used) >= 20, "the MFMA GEMM path was not taken under autocast"
+    assert len(used) >= 18, "the MFMA GEMM path was not taken under autocast"   # 13 conv3 + 4 conv1 + 1 downsample (k <= 256)
     with torch.autocast("cuda", dtype=torch.bfloat16):
         yr = ref(x)
     la = torch.nn.functional.cross_entropy(y.float(), tgt)

@@ -463,11 +463,11 @@ template <typename T> constexpr int apply_bwd_wave_bytes() {
   return RowIO<T, kS + 4>::kBytes + 3 * RowIO<T, kS + 2>::kBytes + 2 * RowIO<T, kS>::kBytes;
 }
 
-// Workgroups of at most 4 waves (a wave walks several strips of a wide image) and a register budget of 168: three waves
-// per SIMD instead of the two an 8-wave workgroup at ~170 registers allows -- the pass is bound by vector issue.
-constexpr int kBwdWaves = 4;
+// (4-wave workgroups under a 168-register budget -- three waves per SIMD, a wave walking two strips of the 56-wide stage --
+// measured 25 % SLOWER than one strip per wave at two waves per SIMD: profiles/r02_notes.md.)
+constexpr int kBwdWaves = kMaxStrips;
 template <typename T, bool GELU, bool HAS_O, bool RELU, bool RAGGED>
-__global__ __launch_bounds__(kBwdWaves * kWave, 3) void light_apply_bwd_wide(
+__global__ __launch_bounds__(kBwdWaves * kWave) void light_apply_bwd_wide(
     const T* __restrict__ dout, const T* __restrict__ x, const T* __restrict__ o, const float* __restrict__ wv,
     const float* __restrict__ gate, const float* __restrict__ cb, const float* __restrict__ lam,
     const float* __restrict__ dp, const float* __restrict__ dyx, T* __restrict__ dx, T* __restrict__ dprev,

@@ -156,8 +156,10 @@ int mrla_base_attend_fwd(const void* x, const float* wv, void* v_ring, const flo
                          int b, int c, int h, int w, int d, int T, int t, int dtype, int layout, void* stream);
 
 /* BatchNorm statistics from per-(image, channel) (sum, sum of squares): sc, sh, save_mean, save_inv; running
- * statistics updated in place in TRAIN mode.  Replaces the statistics half of bn_mrla (resnet_mrla_base.py:125). */
-int mrla_bn_stats_fwd(const float* amom, const float* gamma, const float* beta, float* running_mean,
+ * statistics updated in place in TRAIN mode.  Replaces the statistics half of bn_mrla (resnet_mrla_base.py:125).
+ * pivot [opt, c]: the sums are of (x - pivot[c]) (as mrla_bn_plane_moments produces them when given a pivot buffer): the
+ * one-pass variance E[d^2] - E[d]^2 then stays well conditioned for channels with |mean| >> sigma. */
+int mrla_bn_stats_fwd(const float* amom, const float* pivot, const float* gamma, const float* beta, float* running_mean,
                       float* running_var, int bn_mode, float momentum, float eps, float* sc, float* sh,
                       float* save_mean, float* save_inv, int b, int c, int hw, void* stream);
 
@@ -274,8 +276,10 @@ int mrla_token_ln_bwd(const void* dout, const void* x, const void* o_prev, const
 /* Rows of the partial-moment buffers written by mrla_bn_plane_moments / _dmoments: b for NCHW, b*nsplit for NHWC
  * (pixels of an image are split over nsplit workgroups).  Pass (rows, b*h*w/rows) as (b, hw) to mrla_bn_stats_*. */
 int mrla_bn_moment_rows(int b, int c, int h, int w, int layout);
-int mrla_bn_plane_moments(const void* x, float* amom /*[rows,c,2]: sum x, sum x^2*/, int b, int c, int h, int w, int dtype,
-                          int layout, void* stream);
+/* pivot [opt, c floats, OUTPUT]: when given, the kernel records p[c] = x[0, c, 0, 0] there and accumulates sums of
+ * (x - p[c]) and (x - p[c])^2 instead of raw moments (hand the same buffer to mrla_bn_stats_fwd). */
+int mrla_bn_plane_moments(const void* x, float* amom /*[rows,c,2]: sum x, sum x^2*/, float* pivot, int b, int c, int h, int w,
+                          int dtype, int layout, void* stream);
 int mrla_bn_act_fwd(const void* x, const float* sc, const float* sh, int relu, void* y, int b, int c, int h, int w,
                     int dtype, int layout, void* stream);
 int mrla_bn_plane_dmoments(const void* dy, const void* x, const float* sc, const float* sh, int relu,

@@ -45,7 +45,7 @@ SIGNATURES = {
     "mrla_base_value_bwd_dv": [_P] * 7 + [_I] * 7 + [_P],
     "mrla_base_gate_fwd": [_P, _P, _P, _I, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P],
     "mrla_base_attend_fwd": [_P, _P, _P, _P, _P, _P] + [_I] * 9 + [_P],
-    "mrla_bn_stats_fwd": [_P, _P, _P, _P, _P, _I, _F, _F, _P, _P, _P, _P, _I, _I, _I, _P],
+    "mrla_bn_stats_fwd": [_P, _P, _P, _P, _P, _P, _I, _F, _F, _P, _P, _P, _P, _I, _I, _I, _P],
     "mrla_base_tail_fwd": [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P],
     "mrla_base_tail_stats_bwd": [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P],
     "mrla_bn_stats_bwd": [_P, _P, _P, _P, _I, _P, _P, _P, _I, _I, _I, _P],
@@ -58,7 +58,7 @@ SIGNATURES = {
     "mrla_token_apply_bwd": [_P] * 14 + [_I] * 5 + [_P],
     "mrla_token_ln_bwd": [_P] * 10 + [_I] * 5 + [_P],
     "mrla_bn_moment_rows": [_I] * 5,
-    "mrla_bn_plane_moments": [_P, _P, _I, _I, _I, _I, _I, _I, _P],
+    "mrla_bn_plane_moments": [_P, _P, _P, _I, _I, _I, _I, _I, _I, _P],
     "mrla_bn_act_fwd": [_P, _P, _P, _I, _P, _I, _I, _I, _I, _I, _I, _P],
     "mrla_bn_plane_dmoments": [_P, _P, _P, _P, _I, _P, _I, _I, _I, _I, _I, _I, _P],
     "mrla_bn_act_bwd": [_P, _P, _P, _P, _P, _I, _P, _I, _I, _I, _I, _I, _I, _P],

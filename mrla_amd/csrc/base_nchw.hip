@@ -244,7 +244,7 @@ __global__ __launch_bounds__(kThreads) void plain_bn_fwd_kernel(
     const float* __restrict__ amom, const float* __restrict__ gamma, const float* __restrict__ beta,
     float* __restrict__ run_mean, float* __restrict__ run_var, int training, float momentum, float eps,
     float* __restrict__ sc, float* __restrict__ sh, float* __restrict__ save_mean, float* __restrict__ save_inv,
-    int B, int C, int HW) {
+    const float* __restrict__ pivot, int B, int C, int HW) {
   __shared__ double r1[kBnLanes2][kBnCh2], r2[kBnLanes2][kBnCh2];
   const int cc = threadIdx.x % kBnCh2, bl = threadIdx.x / kBnCh2;
   const int c = blockIdx.x * kBnCh2 + cc;
@@ -263,9 +263,11 @@ __global__ __launch_bounds__(kThreads) void plain_bn_fwd_kernel(
     s1 = 0.0; s2 = 0.0;
     for (int i = 0; i < kBnLanes2; ++i) { s1 += r1[i][cc]; s2 += r2[i][cc]; }
     const double M = (double)B * HW;
+    // the sums are of (x - pivot[c]) when the producer shifted them: the variance is shift-invariant, the mean is not
     mean = s1 / M;
     var = s2 / M - mean * mean;
     if (var < 0.0) var = 0.0;
+    if (pivot) mean += (double)pivot[c];
     run_mean[c] = (float)((1.0 - momentum) * run_mean[c] + momentum * mean);
     run_var[c] = (float)((1.0 - momentum) * run_var[c] + momentum * var * (M / (M > 1.0 ? M - 1.0 : 1.0)));
   } else {
@@ -721,9 +723,9 @@ int launch_base_attend_fwd(const void* x, const float* wv, void* Vring, const fl
 
 int launch_plain_bn_fwd(const float* amom, const float* gamma, const float* beta, float* run_mean, float* run_var,
                         int training, float momentum, float eps, float* sc, float* sh, float* save_mean,
-                        float* save_inv, int B, int C, int HW, hipStream_t st) {
+                        float* save_inv, const float* pivot, int B, int C, int HW, hipStream_t st) {
   hipLaunchKernelGGL(plain_bn_fwd_kernel, dim3((C + kBnCh2 - 1) / kBnCh2), dim3(kThreads), 0, st, amom, gamma, beta,
-                     run_mean, run_var, training, momentum, eps, sc, sh, save_mean, save_inv, B, C, HW);
+                     run_mean, run_var, training, momentum, eps, sc, sh, save_mean, save_inv, pivot, B, C, HW);
   return hip_status(hipGetLastError());
 }
 

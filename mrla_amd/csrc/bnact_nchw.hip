@@ -47,13 +47,13 @@ template <typename T> __device__ __forceinline__ bool al16(const T* p) { return 
 // ------------------------------------------------------------------------------------------------
 template <typename T, int MODE, int VW>
 __device__ __forceinline__ void plane_sums(const T* __restrict__ xp, const T* __restrict__ gp, int HW, int lane, float s,
-                                           float h, bool relu, float& s1, float& s2) {
+                                           float h, bool relu, float pv, float& s1, float& s2) {
   for (int e = lane * VW; e < HW; e += kWave * VW) {
     float xv[VW];
     ldv<T, VW>(xp + e, xv);
     if (MODE == 0) {
 #pragma unroll
-      for (int i = 0; i < VW; ++i) { s1 += xv[i]; s2 = fmaf(xv[i], xv[i], s2); }
+      for (int i = 0; i < VW; ++i) { const float d = xv[i] - pv; s1 += d; s2 = fmaf(d, d, s2); }
     } else {
       float gv[VW];
       ldv<T, VW>(gp + e, gv);
@@ -71,7 +71,7 @@ template <typename T, int MODE>
 __global__ __launch_bounds__(kThreads) void plane_moments_kernel(const T* __restrict__ x, const T* __restrict__ dy,
                                                                  const float* __restrict__ sc, const float* __restrict__ sh,
                                                                  int relu, float* __restrict__ out /*[planes,2]*/,
-                                                                 int planes, int C, int HW) {
+                                                                 float* __restrict__ pivot, int planes, int C, int HW) {
   const int lane = threadIdx.x & (kWave - 1), wave = threadIdx.x / kWave;
   constexpr int VEC = 16 / sizeof(T);
   const bool vec_ok = (HW % VEC == 0) && al16(x) && (MODE == 0 || al16(dy));
@@ -81,8 +81,11 @@ __global__ __launch_bounds__(kThreads) void plane_moments_kernel(const T* __rest
     const int c = p % C;
     const float s = (MODE && relu) ? sc[c] : 0.f, h = (MODE && relu) ? sh[c] : 0.f;
     float s1 = 0.f, s2 = 0.f;
-    if (vec_ok) plane_sums<T, MODE, VEC>(xp, gp, HW, lane, s, h, relu != 0, s1, s2);
-    else        plane_sums<T, MODE, 1>(xp, gp, HW, lane, s, h, relu != 0, s1, s2);
+    // MODE 0 with `pivot`: sums of (x - p), p = the channel's first element of the first image (see bnact_nhwc.hip)
+    const float pv = (MODE == 0 && pivot) ? to_f(x[(size_t)c * HW]) : 0.f;
+    if (MODE == 0 && pivot && p < C && lane == 0) pivot[c] = pv;
+    if (vec_ok) plane_sums<T, MODE, VEC>(xp, gp, HW, lane, s, h, relu != 0, pv, s1, s2);
+    else        plane_sums<T, MODE, 1>(xp, gp, HW, lane, s, h, relu != 0, pv, s1, s2);
     s1 = wave_sum(s1);
     s2 = wave_sum(s2);
     if (lane == 0) { out[(size_t)p * 2] = s1; out[(size_t)p * 2 + 1] = s2; }
@@ -95,7 +98,8 @@ template <typename T, int MODE>
 __global__ __launch_bounds__(kThreads) void plane_moments_small_kernel(const T* __restrict__ x, const T* __restrict__ dy,
                                                                        const float* __restrict__ sc,
                                                                        const float* __restrict__ sh, int relu,
-                                                                       float* __restrict__ out, int planes, int C, int HW,
+                                                                       float* __restrict__ out, float* __restrict__ pivot,
+                                                                       int planes, int C, int HW,
                                                                        int PP /*planes per workgroup chunk*/) {
   extern __shared__ __align__(16) unsigned char smem[];
   T* xs = reinterpret_cast<T*>(smem);
@@ -113,9 +117,11 @@ __global__ __launch_bounds__(kThreads) void plane_moments_small_kernel(const T* 
       const int c = (p0 + q) % C;
       const float s = (MODE && relu) ? sc[c] : 0.f, h = (MODE && relu) ? sh[c] : 0.f;
       float s1 = 0.f, s2 = 0.f;
+      const float pv = (MODE == 0 && pivot) ? to_f(x[(size_t)c * HW]) : 0.f;
+      if (MODE == 0 && pivot && p0 + q < C && l16 == 0) pivot[c] = pv;
       for (int e = l16; e < HW; e += 16) {
         const float xv = to_f(xs[q * HW + e]);
-        if (MODE == 0) { s1 += xv; s2 = fmaf(xv, xv, s2); }
+        if (MODE == 0) { const float d = xv - pv; s1 += d; s2 = fmaf(d, d, s2); }
         else {
           const float dz = (!relu || fmaf(s, xv, h) > 0.f) ? to_f(gs[q * HW + e]) : 0.f;
           s1 += dz;
@@ -184,17 +190,17 @@ __global__ __launch_bounds__(kThreads) void affine_act_kernel(const T* __restric
     default: return MRLA_EINVAL;         \
   }
 
-static int launch_moments(const void* x, const void* dy, const float* sc, const float* sh, int relu, float* out, int B,
-                          int C, int HW, int dtype, int mode, hipStream_t st) {
+static int launch_moments(const void* x, const void* dy, const float* sc, const float* sh, int relu, float* out,
+                          float* pivot, int B, int C, int HW, int dtype, int mode, hipStream_t st) {
   const int planes = B * C;
   const size_t es = dtype_size(dtype);
   if (HW >= 512) {
     const int grid = std::max(1, std::min((planes + kWaves - 1) / kWaves, 256 * 8));
 #define CALL(TT)                                                                                                  \
   if (mode) hipLaunchKernelGGL((plane_moments_kernel<TT, 1>), dim3(grid), dim3(kThreads), 0, st, (const TT*)x,   \
-                               (const TT*)dy, sc, sh, relu, out, planes, C, HW);                                  \
+                               (const TT*)dy, sc, sh, relu, out, pivot, planes, C, HW);                           \
   else      hipLaunchKernelGGL((plane_moments_kernel<TT, 0>), dim3(grid), dim3(kThreads), 0, st, (const TT*)x,   \
-                               (const TT*)dy, sc, sh, relu, out, planes, C, HW);
+                               (const TT*)dy, sc, sh, relu, out, pivot, planes, C, HW);
     MRLA_DISPATCH_B(dtype, CALL)
 #undef CALL
   } else {
@@ -204,22 +210,22 @@ static int launch_moments(const void* x, const void* dy, const float* sc, const 
     const int grid = std::max(1, std::min((planes + PP - 1) / PP, 256 * 8));
 #define CALL(TT)                                                                                                      \
   if (mode) hipLaunchKernelGGL((plane_moments_small_kernel<TT, 1>), dim3(grid), dim3(kThreads), lds, st, (const TT*)x, \
-                               (const TT*)dy, sc, sh, relu, out, planes, C, HW, PP);                                  \
+                               (const TT*)dy, sc, sh, relu, out, pivot, planes, C, HW, PP);                           \
   else      hipLaunchKernelGGL((plane_moments_small_kernel<TT, 0>), dim3(grid), dim3(kThreads), lds, st, (const TT*)x, \
-                               (const TT*)dy, sc, sh, relu, out, planes, C, HW, PP);
+                               (const TT*)dy, sc, sh, relu, out, pivot, planes, C, HW, PP);
     MRLA_DISPATCH_B(dtype, CALL)
 #undef CALL
   }
   return hip_status(hipGetLastError());
 }
 
-int launch_plane_moments(const void* x, float* amom, int B, int C, int HW, int dtype, hipStream_t st) {
-  return launch_moments(x, nullptr, nullptr, nullptr, 0, amom, B, C, HW, dtype, 0, st);
+int launch_plane_moments(const void* x, float* amom, float* pivot, int B, int C, int HW, int dtype, hipStream_t st) {
+  return launch_moments(x, nullptr, nullptr, nullptr, 0, amom, pivot, B, C, HW, dtype, 0, st);
 }
 
 int launch_plane_dmoments(const void* dy, const void* x, const float* sc, const float* sh, int relu, float* tmom, int B,
                           int C, int HW, int dtype, hipStream_t st) {
-  return launch_moments(x, dy, sc, sh, relu, tmom, B, C, HW, dtype, 1, st);
+  return launch_moments(x, dy, sc, sh, relu, tmom, nullptr, B, C, HW, dtype, 1, st);
 }
 
 int launch_affine_act(const void* x, const void* dy, const float* a, const float* sc, const float* sh, int relu,

@@ -33,7 +33,7 @@ template <typename T, int MODE>
 __global__ __launch_bounds__(kThreads) void nhwc_moments_kernel(const T* __restrict__ x, const T* __restrict__ dy,
                                                                 const float* __restrict__ sc, const float* __restrict__ sh,
                                                                 int relu, float* __restrict__ out /*[b*nsplit, c, 2]*/,
-                                                                int C, int HW, int nsplit) {
+                                                                float* __restrict__ pivot, int C, int HW, int nsplit) {
   constexpr int VEC = 16 / sizeof(T);
   constexpr int LPC = 64 / VEC;                  // lanes per 64-channel row (8 for 16-bit types, 16 for fp32)
   constexpr int PPW = kWave / LPC;               // pixels per wave-instruction
@@ -48,16 +48,25 @@ __global__ __launch_bounds__(kThreads) void nhwc_moments_kernel(const T* __restr
   float scv[VEC], shv[VEC];
 #pragma unroll
   for (int i = 0; i < VEC; ++i) { scv[i] = (MODE && relu && cv) ? sc[c0 + i] : 0.f; shv[i] = (MODE && relu && cv) ? sh[c0 + i] : 0.f; }
-  float s1[VEC], s2[VEC];
+  float s1[VEC], s2[VEC], pv[VEC];
 #pragma unroll
-  for (int i = 0; i < VEC; ++i) { s1[i] = 0.f; s2[i] = 0.f; }
+  for (int i = 0; i < VEC; ++i) { s1[i] = 0.f; s2[i] = 0.f; pv[i] = 0.f; }
+  // MODE 0 with `pivot`: sums of (x - p), p = the channel's value at the first pixel of the first image -- a sample of
+  // the distribution, so the second moment does not cancel when |mean| >> sigma
+  if (MODE == 0 && pivot && cv) {
+    ld16<T>(x + c0, pv);
+    if (bs == 0 && wave == 0 && lane < LPC) {
+#pragma unroll
+      for (int i = 0; i < VEC; ++i) pivot[c0 + i] = pv[i];
+    }
+  }
   if (cv) {
     for (int p = wave * PPW + lane / LPC; p < npix; p += kWaves * PPW) {
       float xv[VEC];
       ld16<T>(x + base + (size_t)p * C + c0, xv);
       if (MODE == 0) {
 #pragma unroll
-        for (int i = 0; i < VEC; ++i) { s1[i] += xv[i]; s2[i] = fmaf(xv[i], xv[i], s2[i]); }
+        for (int i = 0; i < VEC; ++i) { const float d = xv[i] - pv[i]; s1[i] += d; s2[i] = fmaf(d, d, s2[i]); }
       } else {
         float gv[VEC];
         ld16<T>(dy + base + (size_t)p * C + c0, gv);
@@ -155,8 +164,8 @@ __global__ __launch_bounds__(kThreads) void nhwc_moments_flat_kernel(const T* __
                                                                      const float* __restrict__ sc,
                                                                      const float* __restrict__ sh, int relu,
                                                                      const float* __restrict__ dp /*[b] or null*/,
-                                                                     float* __restrict__ out, int C, int HW, int nsplit,
-                                                                     int CW) {
+                                                                     float* __restrict__ out, float* __restrict__ pivot,
+                                                                     int C, int HW, int nsplit, int CW) {
   constexpr int VEC = 16 / sizeof(T);
   __shared__ float red[2][kThreads * VEC];
   const int t = threadIdx.x;
@@ -175,13 +184,20 @@ __global__ __launch_bounds__(kThreads) void nhwc_moments_flat_kernel(const T* __
 #pragma unroll
     for (int i = 0; i < VEC; ++i) { scv[i] = 0.f; shv[i] = 0.f; }
   }
-  float s1[VEC], s2[VEC];
+  float s1[VEC], s2[VEC], pv[VEC];
 #pragma unroll
-  for (int i = 0; i < VEC; ++i) { s1[i] = 0.f; s2[i] = 0.f; }
+  for (int i = 0; i < VEC; ++i) { s1[i] = 0.f; s2[i] = 0.f; pv[i] = 0.f; }
+  if (MODE == 0 && pivot) {                      // shifted sums, see nhwc_moments_kernel
+    ld16<T>(x + c0, pv);
+    if (bs == 0 && ps == 0) {
+#pragma unroll
+      for (int i = 0; i < VEC; ++i) pivot[c0 + i] = pv[i];
+    }
+  }
   auto accumulate = [&](const float (&xv)[VEC], const float (&gv)[VEC]) {
 #pragma unroll
     for (int i = 0; i < VEC; ++i) {
-      if (MODE == 0) { s1[i] += xv[i]; s2[i] = fmaf(xv[i], xv[i], s2[i]); }
+      if (MODE == 0) { const float d = xv[i] - pv[i]; s1[i] += d; s2[i] = fmaf(d, d, s2[i]); }
       else if (MODE == 2) {     // pooling of x_t = relu(round(sc*pre + sh) + o) for the inference path (x = pre, dy = o)
         const float z = sc ? to_f(from_f<T>(fmaf(scv[i], xv[i], shv[i]))) : xv[i];
         s1[i] += fmaxf(to_f(from_f<T>(z + gv[i])), 0.f);
@@ -312,7 +328,7 @@ static int flat_cw(int C, int vec) {
   }
 
 int launch_nhwc_moments(const void* x, const void* dy, const float* sc, const float* sh, int relu, const float* dp,
-                        float* out, int B, int C, int HW, int dtype, int mode, hipStream_t st) {
+                        float* out, float* pivot, int B, int C, int HW, int dtype, int mode, hipStream_t st) {
   const int vec = 16 / (int)dtype_size(dtype);
   if (C % vec) return MRLA_EUNSUPPORTED;
   const int ns = nhwc_bn_splits(B, C, HW);
@@ -321,9 +337,9 @@ int launch_nhwc_moments(const void* x, const void* dy, const float* sc, const fl
     const dim3 fgrid(C / cw, B * ns);
 #define CALL(TT)                                                                                                       \
   if (mode) hipLaunchKernelGGL((nhwc_moments_flat_kernel<TT, 1>), fgrid, dim3(kThreads), 0, st, (const TT*)x,          \
-                               (const TT*)dy, sc, sh, relu, dp, out, C, HW, ns, cw);                                   \
+                               (const TT*)dy, sc, sh, relu, dp, out, pivot, C, HW, ns, cw);                            \
   else      hipLaunchKernelGGL((nhwc_moments_flat_kernel<TT, 0>), fgrid, dim3(kThreads), 0, st, (const TT*)x,          \
-                               (const TT*)dy, sc, sh, relu, dp, out, C, HW, ns, cw);
+                               (const TT*)dy, sc, sh, relu, dp, out, pivot, C, HW, ns, cw);
     MRLA_DISPATCH_N(dtype, CALL)
 #undef CALL
     return hip_status(hipGetLastError());
@@ -332,9 +348,9 @@ int launch_nhwc_moments(const void* x, const void* dy, const float* sc, const fl
   const dim3 grid((C + 63) / 64, B * ns);
 #define CALL(TT)                                                                                                     \
   if (mode) hipLaunchKernelGGL((nhwc_moments_kernel<TT, 1>), grid, dim3(kThreads), 0, st, (const TT*)x, (const TT*)dy, \
-                               sc, sh, relu, out, C, HW, ns);                                                        \
+                               sc, sh, relu, out, pivot, C, HW, ns);                                                 \
   else      hipLaunchKernelGGL((nhwc_moments_kernel<TT, 0>), grid, dim3(kThreads), 0, st, (const TT*)x, (const TT*)dy, \
-                               sc, sh, relu, out, C, HW, ns);
+                               sc, sh, relu, out, pivot, C, HW, ns);
   MRLA_DISPATCH_N(dtype, CALL)
 #undef CALL
   return hip_status(hipGetLastError());
@@ -350,7 +366,7 @@ int launch_nhwc_pool_fused(const void* pre, const float* sc, const float* sh, co
   const dim3 fgrid(C / cw, B * ns);
 #define CALL(TT)                                                                                                 \
   hipLaunchKernelGGL((nhwc_moments_flat_kernel<TT, 2>), fgrid, dim3(kThreads), 0, st, (const TT*)pre, (const TT*)o, \
-                     sc, sh, 0, (const float*)nullptr, part, C, HW, ns, cw);
+                     sc, sh, 0, (const float*)nullptr, part, (float*)nullptr, C, HW, ns, cw);
   MRLA_DISPATCH_N(dtype, CALL)
 #undef CALL
   hipLaunchKernelGGL(nhwc_pool_finish_kernel, dim3((B * C + kThreads - 1) / kThreads), dim3(kThreads), 0, st, part, mom,

@@ -236,14 +236,14 @@ int mrla_base_attend_fwd(const void* x, const float* wv, void* v_ring, const flo
   return launch_base_attend_fwd(x, wv, v_ring, p_all, attn, amom, g, d, T, t, dtype, (hipStream_t)stream);
 }
 
-int mrla_bn_stats_fwd(const float* amom, const float* gamma, const float* beta, float* running_mean,
+int mrla_bn_stats_fwd(const float* amom, const float* pivot, const float* gamma, const float* beta, float* running_mean,
                       float* running_var, int bn_mode, float momentum, float eps, float* sc, float* sh,
                       float* save_mean, float* save_inv, int b, int c, int hw, void* stream) {
   if (!amom || !gamma || !beta || !running_mean || !running_var || !sc || !sh || !save_mean || !save_inv || b <= 0 ||
       c <= 0 || hw <= 0 || (bn_mode != MRLA_BN_TRAIN && bn_mode != MRLA_BN_EVAL))
     return MRLA_EINVAL;
   return launch_plain_bn_fwd(amom, gamma, beta, running_mean, running_var, bn_mode == MRLA_BN_TRAIN, momentum, eps, sc,
-                             sh, save_mean, save_inv, b, c, hw, (hipStream_t)stream);
+                             sh, save_mean, save_inv, pivot, b, c, hw, (hipStream_t)stream);
 }
 
 int mrla_base_tail_fwd(const void* x, const void* attn, const float* sc, const float* sh, const float* dp, void* out,
@@ -259,7 +259,7 @@ int mrla_base_tail_stats_bwd(const void* dout, const void* attn, const float* sc
                              float* tmom, int b, int c, int h, int w, int dtype, int layout, void* stream) {
   if (!dout || !attn || !sc || !sh || !tmom || bad_dims(b, c, h, w) || bad_dtype(dtype)) return MRLA_EINVAL;
   if (layout == MRLA_NHWC)      // tmom then has mrla_bn_moment_rows() rows
-    return launch_nhwc_moments(attn, dout, sc, sh, 1, dp, tmom, b, c, h * w, dtype, 1, (hipStream_t)stream);
+    return launch_nhwc_moments(attn, dout, sc, sh, 1, dp, tmom, nullptr, b, c, h * w, dtype, 1, (hipStream_t)stream);
   if (layout != MRLA_NCHW) return MRLA_EINVAL;
   SlabGeo g;
   const int rc = light_geo(&g, b, c, h, w, dtype);
@@ -422,12 +422,14 @@ int mrla_token_ln_bwd(const void* dout, const void* x, const void* o_prev, const
                              (hipStream_t)stream);
 }
 
-int mrla_bn_plane_moments(const void* x, float* amom, int b, int c, int h, int w, int dtype, int layout, void* stream) {
+int mrla_bn_plane_moments(const void* x, float* amom, float* pivot, int b, int c, int h, int w, int dtype, int layout,
+                          void* stream) {
   if (!x || !amom || bad_dims(b, c, h, w) || bad_dtype(dtype)) return MRLA_EINVAL;
   if (layout == MRLA_NHWC)
-    return launch_nhwc_moments(x, nullptr, nullptr, nullptr, 0, nullptr, amom, b, c, h * w, dtype, 0, (hipStream_t)stream);
+    return launch_nhwc_moments(x, nullptr, nullptr, nullptr, 0, nullptr, amom, pivot, b, c, h * w, dtype, 0,
+                               (hipStream_t)stream);
   if (layout != MRLA_NCHW) return MRLA_EINVAL;
-  return launch_plane_moments(x, amom, b, c, h * w, dtype, (hipStream_t)stream);
+  return launch_plane_moments(x, amom, pivot, b, c, h * w, dtype, (hipStream_t)stream);
 }
 
 int mrla_bn_act_fwd(const void* x, const float* sc, const float* sh, int relu, void* y, int b, int c, int h, int w,
@@ -443,7 +445,7 @@ int mrla_bn_plane_dmoments(const void* dy, const void* x, const float* sc, const
                            int c, int h, int w, int dtype, int layout, void* stream) {
   if (!dy || !x || !sc || !sh || !tmom || bad_dims(b, c, h, w) || bad_dtype(dtype)) return MRLA_EINVAL;
   if (layout == MRLA_NHWC)
-    return launch_nhwc_moments(x, dy, sc, sh, relu, nullptr, tmom, b, c, h * w, dtype, 1, (hipStream_t)stream);
+    return launch_nhwc_moments(x, dy, sc, sh, relu, nullptr, tmom, nullptr, b, c, h * w, dtype, 1, (hipStream_t)stream);
   if (layout != MRLA_NCHW) return MRLA_EINVAL;
   return launch_plane_dmoments(dy, x, sc, sh, relu, tmom, b, c, h * w, dtype, (hipStream_t)stream);
 }

@@ -66,7 +66,7 @@ int launch_base_attend_fwd(const void* x, const float* wv, void* Vring, const fl
                            const SlabGeo& g, int d, int T, int t, int dtype, hipStream_t st);
 int launch_plain_bn_fwd(const float* amom, const float* gamma, const float* beta, float* run_mean, float* run_var,
                         int training, float momentum, float eps, float* sc, float* sh, float* save_mean,
-                        float* save_inv, int B, int C, int HW, hipStream_t st);
+                        float* save_inv, const float* pivot, int B, int C, int HW, hipStream_t st);
 int launch_plain_bn_bwd(const float* tmom, const float* gamma, const float* save_mean, const float* save_inv,
                         int training, float* cb, float* dgamma, float* dbeta, int B, int C, int HW, hipStream_t st);
 int launch_base_tail_fwd(const void* x, const void* attn, const float* sc, const float* sh, const float* dp, void* out,
@@ -133,7 +133,7 @@ int launch_token_ln_bwd(const void* dout, const void* x, const void* o, const fl
 
 
 // bnact_nchw.hip -- fused BatchNorm2d (+ReLU) passes
-int launch_plane_moments(const void* x, float* amom, int B, int C, int HW, int dtype, hipStream_t st);
+int launch_plane_moments(const void* x, float* amom, float* pivot, int B, int C, int HW, int dtype, hipStream_t st);
 int launch_plane_dmoments(const void* dy, const void* x, const float* sc, const float* sh, int relu, float* tmom, int B,
                           int C, int HW, int dtype, hipStream_t st);
 int launch_affine_act(const void* x, const void* dy, const float* a, const float* sc, const float* sh, int relu,
@@ -182,7 +182,7 @@ int launch_light_apply_fwd_pre_nhwc(const void* pre, const void* o, const float*
                                     const float* dp, void* out, int B, int C, int H, int W, int d, int res, int dtype,
                                     hipStream_t st);
 int launch_nhwc_moments(const void* x, const void* dy, const float* sc, const float* sh, int relu, const float* dp,
-                        float* out, int B, int C, int HW, int dtype, int mode, hipStream_t st);
+                        float* out, float* pivot, int B, int C, int HW, int dtype, int mode, hipStream_t st);
 int launch_nhwc_affine(const void* x, const void* dy, const float* a, const float* sc, const float* sh, int relu,
                        void* out, int B, int C, int HW, int dtype, int bwd, hipStream_t st);
 

@@ -475,7 +475,7 @@ class _BaseFn(torch.autograd.Function):
             gamma32, beta32 = _f32(gamma), _f32(beta)
             rs = _RunningStats(running_mean, running_var, c, "mrla base forward")
             bnbuf = torch.empty((4, c), dtype=torch.float32, device=dev)
-            L.call("mrla_bn_stats_fwd", _ptr(amom), _ptr(gamma32), _ptr(beta32), _ptr(rs.rm), _ptr(rs.rv),
+            L.call("mrla_bn_stats_fwd", _ptr(amom), None, _ptr(gamma32), _ptr(beta32), _ptr(rs.rm), _ptr(rs.rv),
                    cfg.bn_mode, float(cfg.momentum), float(cfg.eps), _ptr(bnbuf[0]), _ptr(bnbuf[1]), _ptr(bnbuf[2]),
                    _ptr(bnbuf[3]), arows, c, b * h * w // arows, st)
             rs.finish(cfg.bn_mode == L.BN_TRAIN)
@@ -670,16 +670,18 @@ class _BnActFn(torch.autograd.Function):
         rs = _RunningStats(running_mean, running_var, c, "fused bn/act forward")
         bnbuf = torch.empty((4, c), dtype=torch.float32, device=dev)       # sc, sh, save_mean, save_inv
         rows = L.load().mrla_bn_moment_rows(b, c, h, w, layout)           # partial-sum rows (b, or b*nsplit for NHWC)
-        frows = rows
+        frows, pivot = rows, None
         if training and pre_moments is not None:      # the producer (the 1x1 convolution GEMM) already took them
             amom, frows = pre_moments, pre_moments.shape[0]
             if tuple(amom.shape) != (frows, c, 2) or amom.dtype != torch.float32 or (b * h * w) % frows:
                 raise L.MrlaHipError("pre_moments must be float32 [rows, c, 2] with rows dividing b*h*w")
         else:
             amom = torch.empty((rows, c, 2), dtype=torch.float32, device=dev)
-            if training:
-                _call("mrla_bn_plane_moments", xc.numel() * xc.element_size(), _ptr(xc), _ptr(amom), b, c, h, w, dt, layout, st)
-        L.call("mrla_bn_stats_fwd", _ptr(amom), _ptr(gamma32), _ptr(beta32), _ptr(rs.rm), _ptr(rs.rv),
+            if training:           # sums about a per-channel pivot (a sample of the channel): robust for |mean| >> sigma
+                pivot = torch.empty((c,), dtype=torch.float32, device=dev)
+                _call("mrla_bn_plane_moments", xc.numel() * xc.element_size(), _ptr(xc), _ptr(amom), _ptr(pivot), b, c, h, w,
+                      dt, layout, st)
+        L.call("mrla_bn_stats_fwd", _ptr(amom), _ptr(pivot), _ptr(gamma32), _ptr(beta32), _ptr(rs.rm), _ptr(rs.rv),
                L.BN_TRAIN if training else L.BN_EVAL, float(momentum), float(eps), _ptr(bnbuf[0]), _ptr(bnbuf[1]),
                _ptr(bnbuf[2]), _ptr(bnbuf[3]), frows, c, b * h * w // frows, st)
         rs.finish(training)

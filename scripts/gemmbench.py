@@ -43,7 +43,7 @@ for (cin, cout, hw, n) in [(64, 64, 56, 1), (64, 256, 56, 4), (256, 64, 56, 2), 
         t_conv = timeit(lambda: F.conv2d(x, w))
         t_gemm = timeit(lambda: Fm._Conv1x1Fn.apply(x, w2, False))
         t_gemm_m = timeit(lambda: Fm._Conv1x1Fn.apply(x, w2, True))
-        t_mom = timeit(lambda: L.call("mrla_bn_plane_moments", Fm._ptr(y), Fm._ptr(amom), B, cout, hw, hw, L.BF16, L.NHWC, st))
+        t_mom = timeit(lambda: L.call("mrla_bn_plane_moments", Fm._ptr(y), Fm._ptr(amom), None, B, cout, hw, hw, L.BF16, L.NHWC, st))
     gb = (x.numel() + y.numel()) * 2 / 1e9
     for i, t in enumerate((t_conv, t_gemm, t_gemm_m, t_mom)):
         tot[i] += t * n

@@ -163,3 +163,33 @@ def test_inference_form_of_the_fused_tail_matches_the_training_form(shape, dtype
     else:
         bad = (a - r).abs() > 2.0 ** -7 * (r.abs() + 0.05 * r.abs().max())
         assert bad.float().mean().item() < 1e-4
+
+
+@pytest.mark.parametrize("cl", [False, True], ids=["nchw", "nhwc"])
+@pytest.mark.parametrize("shape", [(8, 64, 28, 28), (4, 256, 56, 56), (6, 24, 5, 3)], ids=lambda s: "x".join(map(str, s)))
+@pytest.mark.parametrize("ratio", [100.0, 1000.0])
+def test_batchnorm_statistics_stay_accurate_when_the_mean_dwarfs_sigma(cl, shape, ratio):
+    """Channels with |mean| / sigma ~ 1e3 (the one-pass E[x^2] - E[x]^2 on raw fp32 sums would lose ~ eps * ratio^2 = 6 %
+    of the variance; torch uses Welford): the moments pass accumulates about a per-channel pivot, so the batch variance,
+    the running statistics and the gradients keep fp32 accuracy."""
+    from mrla_amd.functional import bn_act
+    torch.manual_seed(3)
+    b, c, h, w = shape
+    fmt = torch.channels_last if cl else torch.contiguous_format
+    sigma = 0.5 + torch.rand(1, c, 1, 1, device="cuda")
+    sign = torch.where(torch.arange(c, device="cuda") % 2 == 0, 1.0, -1.0).view(1, c, 1, 1)
+    x = (sigma * (torch.randn(shape, device="cuda") + ratio * sign)).contiguous(memory_format=fmt)
+    g = torch.randn(shape, device="cuda").contiguous(memory_format=fmt)
+    bn = torch.nn.BatchNorm2d(c).cuda()
+    ref = torch.nn.BatchNorm2d(c).cuda().double()
+    xa, xr = x.clone().requires_grad_(True), x.double().requires_grad_(True)
+    y, yr = bn_act(xa, bn, False), ref(xr)
+    y.backward(g); yr.backward(g.double())
+    # variance to 1e-5 (raw sums: off by percents at ratio 1e3); the mean is trivially right either way
+    assert relmax(bn.running_var.cpu().numpy(), ref.running_var.cpu().numpy()) < 1e-5
+    assert relmax(bn.running_mean.cpu().numpy(), ref.running_mean.cpu().numpy()) < 1e-6
+    # y = sc*x + sh is evaluated in fp32 on x ~ ratio*sigma: its rounding is eps*ratio of a unit-variance output
+    tol = 4e-7 * ratio
+    assert relmax(y.detach().cpu().numpy(), yr.detach().cpu().numpy()) < tol
+    assert relmax(xa.grad.cpu().numpy(), xr.grad.cpu().numpy()) < 4 * tol
+    assert relmax(bn.weight.grad.cpu().numpy(), ref.weight.grad.cpu().numpy()) < 4 * tol

@@ -278,3 +278,22 @@ def test_wide_nchw_maps_run_through_one_internal_channels_last_conversion(shape)
     from mrla_amd.functional import mrla_light
     y = mrla_light(to_dev(x), to_dev(P["mrla.mrla.Wq.weight"]), to_dev(P["mrla.mrla.Wk.weight"]), to_dev(P["mrla.mrla.Wv.weight"]), d)
     assert y.is_contiguous() and y.view(b, c // d, d, h, w).shape[1] == c // d
+
+
+@pytest.mark.parametrize("cl", [False, True], ids=["nchw", "nhwc"])
+def test_closed_form_bn_mrla_statistics_with_offset_inputs(cl):
+    """bn_mrla's batch statistics come in closed form from per-(image, channel) moments of V and o_{t-1}.  With
+    |mean| / sigma = 30 in o (and, through the 3x3 taps, in V) the fp32 raw moments still carry the variance to ~1e-4;
+    the fused tail must match the fp64 oracle at that level (conditioning bound: eps * ratio^2, documented in DESIGN.md)."""
+    from oracle import detgen
+    b, c, h, w, d = 4, 64, 14, 14, 32
+    s = detgen.seed_of("cond")
+    x = np.maximum(detgen.normalish((b, c, h, w), s) + 30.0, 0)
+    o = detgen.normalish((b, c, h, w), s + 1) - 30.0
+    gup = detgen.normalish((b, c, h, w), s + 2)
+    P = cases.block_params(c, 11)
+    got = run_light(x, o, P, d, "train", None, 0.0, gup, cl=cl)
+    out, cache, g = oracle_light(x, o, P, d, "train", None, 0.0, gup)
+    assert relmax(got["rv"], cache["bn"]["new_rv"]) < 2e-3
+    assert relmax(got["out"] - x, out - x) < 2e-3         # the normalised branch (x itself is ~30)
+    assert relmax(got["dx"], g["dx"]) < 5e-3

@@ -76,14 +76,15 @@ __device__ __forceinline__ void load_coef(const float* __restrict__ Pall, int b,
 
 // Sum per-thread channel partials over the threads of the workgroup that own the same channels (thread k owns channel
 // vector k % (C/VEC)); `out[ch]` for ch < C is written by the first C threads' worth of work.  red: [kThreads * VEC].
+// The workgroup size is the largest multiple of C/VEC up to 256 (240 threads for the 192 channels of DeiT-tiny in fp32).
 template <int VEC, typename F>
 __device__ __forceinline__ void reduce_same_channels(const float (&s)[VEC], float* __restrict__ red, int C, F&& emit) {
-  const int t = threadIdx.x;
+  const int t = threadIdx.x, nt = blockDim.x;
 #pragma unroll
   for (int i = 0; i < VEC; ++i) red[t * VEC + i] = s[i];
   __syncthreads();
-  const int reps = (kThreads * VEC) / C;
-  for (int ch = t; ch < C; ch += kThreads) {
+  const int reps = (nt * VEC) / C;
+  for (int ch = t; ch < C; ch += nt) {
     float sum = 0.f;
     for (int r = 0; r < reps; ++r) sum += red[r * C + ch];
     emit(ch, sum);
@@ -102,7 +103,7 @@ __global__ __launch_bounds__(kThreads) void base_combine_nhwc(const T* __restric
                                                               FlatGeo g, int d, int T_, int t, int Tc) {
   constexpr int VEC = 16 / sizeof(T);
   __shared__ float red[2][kThreads * VEC];
-  const int tid = threadIdx.x, b = blockIdx.y, tile = blockIdx.x;
+  const int tid = threadIdx.x, b = blockIdx.y, tile = blockIdx.x, NT = blockDim.x;
   const int G = g.C / d;
   const int c0 = (tid * VEC) % g.C;
   const size_t slot = (size_t)g.B * g.HW * g.C;
@@ -121,7 +122,7 @@ __global__ __launch_bounds__(kThreads) void base_combine_nhwc(const T* __restric
 #pragma unroll
     for (int i = 0; i < NV; ++i) {
       raw[i] = (u32x4){0u, 0u, 0u, 0u};
-      if (tid + i * kThreads < g.nvec) raw[i] = ldraw<T>(src + (size_t)i * kThreads * VEC);
+      if (tid + i * NT < g.nvec) raw[i] = ldraw<T>(src + (size_t)i * NT * VEC);
     }
   };
   issue(0);
@@ -147,9 +148,9 @@ __global__ __launch_bounds__(kThreads) void base_combine_nhwc(const T* __restric
   for (int k = 0; k < VEC; ++k) { s1[k] = 0.f; s2[k] = 0.f; }
 #pragma unroll
   for (int i = 0; i < NV; ++i) {
-    if (tid + i * kThreads < g.nvec) {
+    if (tid + i * NT < g.nvec) {
       if constexpr (MODE == 0) {
-        stv<T>(reinterpret_cast<T*>(out) + base + (size_t)i * kThreads * VEC, acc[i]);
+        stv<T>(reinterpret_cast<T*>(out) + base + (size_t)i * NT * VEC, acc[i]);
 #pragma unroll
         for (int k = 0; k < VEC; ++k) {
           const float a = to_f(from_f<T>(acc[i][k]));       // statistics of the rounded values the tail reads back
@@ -157,7 +158,7 @@ __global__ __launch_bounds__(kThreads) void base_combine_nhwc(const T* __restric
           s2[k] = fmaf(a, a, s2[k]);
         }
       } else {
-        stv<T>(reinterpret_cast<T*>(out) + base + (size_t)i * kThreads * VEC, acc[i]);
+        stv<T>(reinterpret_cast<T*>(out) + base + (size_t)i * NT * VEC, acc[i]);
       }
     }
   }
@@ -177,7 +178,7 @@ __global__ __launch_bounds__(kThreads) void base_tail_fwd_nhwc(const T* __restri
                                                                const float* __restrict__ dp, T* __restrict__ out,
                                                                FlatGeo g) {
   constexpr int VEC = 16 / sizeof(T);
-  const int tid = threadIdx.x, b = blockIdx.y;
+  const int tid = threadIdx.x, b = blockIdx.y, NT = blockDim.x;
   const int c0 = (tid * VEC) % g.C;
   const size_t base = ((size_t)b * g.HW + (size_t)blockIdx.x * g.R) * g.C + (size_t)tid * VEC;
   const float dpb = dp ? dp[b] : 1.f;
@@ -187,17 +188,17 @@ __global__ __launch_bounds__(kThreads) void base_tail_fwd_nhwc(const T* __restri
   float xv[kNV][VEC], av[kNV][VEC];
 #pragma unroll
   for (int i = 0; i < kNV; ++i)
-    if (tid + i * kThreads < g.nvec) {
-      ldv<T>(x + base + (size_t)i * kThreads * VEC, xv[i]);
-      ldv<T>(attn + base + (size_t)i * kThreads * VEC, av[i]);
+    if (tid + i * NT < g.nvec) {
+      ldv<T>(x + base + (size_t)i * NT * VEC, xv[i]);
+      ldv<T>(attn + base + (size_t)i * NT * VEC, av[i]);
     }
 #pragma unroll
   for (int i = 0; i < kNV; ++i)
-    if (tid + i * kThreads < g.nvec) {
+    if (tid + i * NT < g.nvec) {
       float y[VEC];
 #pragma unroll
       for (int k = 0; k < VEC; ++k) y[k] = fmaf(dpb, fmaxf(fmaf(s[k], av[i][k], h[k]), 0.f), xv[i][k]);
-      stv<T>(out + base + (size_t)i * kThreads * VEC, y);
+      stv<T>(out + base + (size_t)i * NT * VEC, y);
     }
 }
 
@@ -223,7 +224,7 @@ __global__ __launch_bounds__(kThreads, OCC) void base_attend_bwd_nhwc(
     T* __restrict__ dAring, float* __restrict__ pmom_part, FlatGeo g, int T_, int t) {
   constexpr int VEC = 16 / sizeof(T);
   __shared__ float red[2][kThreads * VEC];
-  const int tid = threadIdx.x, b = blockIdx.y, tile = blockIdx.x;
+  const int tid = threadIdx.x, b = blockIdx.y, tile = blockIdx.x, NT = blockDim.x;
   const int c0 = (tid * VEC) % g.C;
   const size_t slot = (size_t)g.B * g.HW * g.C;
   const size_t base = ((size_t)b * g.HW + (size_t)tile * g.R) * g.C + (size_t)tid * VEC;
@@ -234,7 +235,7 @@ __global__ __launch_bounds__(kThreads, OCC) void base_attend_bwd_nhwc(
 #pragma unroll
     for (int i = 0; i < kNV; ++i) {
       raw[i] = (u32x4){0u, 0u, 0u, 0u};
-      if (tid + i * kThreads < g.nvec) raw[i] = ldraw<T>(src + (size_t)i * kThreads * VEC);
+      if (tid + i * NT < g.nvec) raw[i] = ldraw<T>(src + (size_t)i * NT * VEC);
     }
   };
   {
@@ -256,9 +257,9 @@ __global__ __launch_bounds__(kThreads, OCC) void base_attend_bwd_nhwc(
         const int i = half * HV + k;
         graw[k] = (u32x4){0u, 0u, 0u, 0u};
         araw[k] = (u32x4){0u, 0u, 0u, 0u};
-        if (tid + i * kThreads < g.nvec) {
-          graw[k] = ldraw<T>(dout + base + (size_t)i * kThreads * VEC);
-          if (attn) araw[k] = ldraw<T>(attn + base + (size_t)i * kThreads * VEC);
+        if (tid + i * NT < g.nvec) {
+          graw[k] = ldraw<T>(dout + base + (size_t)i * NT * VEC);
+          if (attn) araw[k] = ldraw<T>(attn + base + (size_t)i * NT * VEC);
         }
       }
 #pragma unroll
@@ -273,8 +274,8 @@ __global__ __launch_bounds__(kThreads, OCC) void base_attend_bwd_nhwc(
           r[q] = fmaf(e_[q], dz, fmaf(f_[q], av[q], h_[q]));
         }
         da[i] = pack16<T>(r);
-        if (tid + i * kThreads < g.nvec)
-          *reinterpret_cast<u32x4*>(dAring + (size_t)(t - 1) * slot + base + (size_t)i * kThreads * VEC) = da[i];
+        if (tid + i * NT < g.nvec)
+          *reinterpret_cast<u32x4*>(dAring + (size_t)(t - 1) * slot + base + (size_t)i * NT * VEC) = da[i];
         else
           da[i] = (u32x4){0u, 0u, 0u, 0u};
       }
@@ -417,16 +418,21 @@ __global__ __launch_bounds__(kMaxStrips * kWave) void base_value_bwd_nhwc(
 // ------------------------------------------------------------------------------------------------
 // geometry + launchers
 // ------------------------------------------------------------------------------------------------
-// The flat kernels need every thread to keep its channels: 256 % (C / VEC) == 0.
+// The flat kernels need every thread to keep its channels from vector to vector: the workgroup size is the largest
+// multiple of C / VEC up to 256 (256 for the power-of-two ResNet widths, 240 / 192 for DeiT's 192 / 384 / 768).
 bool base_nhwc_supported(int C, int dtype) {
   const int vec = 16 / (int)dtype_size(dtype);
-  return C % 64 == 0 && (kThreads % (C / vec)) == 0;
+  return C % 64 == 0 && C / vec <= kThreads;
+}
+static int flat_threads(int C, int dtype) {
+  const int lpp = C / (16 / (int)dtype_size(dtype));            // lanes (16-byte vectors) per pixel
+  return (kThreads / lpp) * lpp;
 }
 
 // nv: 16-byte vectors per thread the kernel holds (kNVc for the history-combining kernels, kNV for the others)
 static FlatGeo flat_geo(int B, int C, int HW, int dtype, int nv) {
   const int vec = 16 / (int)dtype_size(dtype);
-  const int limit = std::max(1, nv * kThreads * vec / C);      // pixels that fit one tile
+  const int limit = std::max(1, nv * flat_threads(C, dtype) * vec / C);      // pixels that fit one tile
   int R = 1;
   for (int r = 1; r <= std::min(limit, HW); ++r)
     if (HW % r == 0) R = r;
@@ -452,7 +458,7 @@ int launch_base_attend_fwd_nhwc(const void* Vring, const float* Pall, void* attn
   if (!base_nhwc_supported(C, dtype)) return MRLA_EUNSUPPORTED;
   const FlatGeo g = flat_geo(B, C, HW, dtype, kNVc);
 #define CALL(TT)                                                                                                         \
-  hipLaunchKernelGGL((base_combine_nhwc<TT, TT, 0, kNVc>), dim3(g.tiles, B), dim3(kThreads), 0, st, (const TT*)Vring, Pall, \
+  hipLaunchKernelGGL((base_combine_nhwc<TT, TT, 0, kNVc>), dim3(g.tiles, B), dim3(flat_threads(C, dtype)), 0, st, (const TT*)Vring, Pall, \
                      (TT*)attn, amom_part, g, d, T, t, t);
   MRLA_DISPATCH_B(dtype, CALL)
 #undef CALL
@@ -464,7 +470,7 @@ int launch_base_dv_combine_nhwc(const void* dAring, const float* Pall, void* dv,
   if (!base_nhwc_supported(C, dtype)) return MRLA_EUNSUPPORTED;
   const FlatGeo g = flat_geo(B, C, HW, dtype, kNVc);
 #define CALL(TT)                                                                                                     \
-  hipLaunchKernelGGL((base_combine_nhwc<TT, TT, 1, kNVc>), dim3(g.tiles, B), dim3(kThreads), 0, st, (const TT*)dAring, \
+  hipLaunchKernelGGL((base_combine_nhwc<TT, TT, 1, kNVc>), dim3(g.tiles, B), dim3(flat_threads(C, dtype)), 0, st, (const TT*)dAring, \
                      Pall, (TT*)dv, (float*)nullptr, g, d, T, t, Tc);
   MRLA_DISPATCH_B(dtype, CALL)
 #undef CALL
@@ -476,7 +482,7 @@ int launch_base_tail_fwd_nhwc(const void* x, const void* attn, const float* sc, 
   if (!base_nhwc_supported(C, dtype)) return MRLA_EUNSUPPORTED;
   const FlatGeo g = flat_geo(B, C, HW, dtype, kNV);
 #define CALL(TT)                                                                                                    \
-  hipLaunchKernelGGL((base_tail_fwd_nhwc<TT>), dim3(g.tiles, B), dim3(kThreads), 0, st, (const TT*)x, (const TT*)attn, \
+  hipLaunchKernelGGL((base_tail_fwd_nhwc<TT>), dim3(g.tiles, B), dim3(flat_threads(C, dtype)), 0, st, (const TT*)x, (const TT*)attn, \
                      sc, sh, dp, (TT*)out, g);
   MRLA_DISPATCH_B(dtype, CALL)
 #undef CALL
@@ -489,7 +495,7 @@ int launch_base_attend_bwd_nhwc(const void* dout, const void* attn, const float*
   if (!base_nhwc_supported(C, dtype)) return MRLA_EUNSUPPORTED;
   const FlatGeo g = flat_geo(B, C, HW, dtype, kNV);
 #define CALL_O(TT, OCC)                                                                                           \
-  hipLaunchKernelGGL((base_attend_bwd_nhwc<TT, OCC>), dim3(g.tiles, B), dim3(kThreads), 0, st, (const TT*)dout,    \
+  hipLaunchKernelGGL((base_attend_bwd_nhwc<TT, OCC>), dim3(g.tiles, B), dim3(flat_threads(C, dtype)), 0, st, (const TT*)dout,    \
                      (const TT*)attn, sc, sh, dp, cb, (const TT*)Vring, (TT*)dAring, pmom_part, g, T, t);
 #define CALL(TT) { if (t <= 16) CALL_O(TT, 3) else CALL_O(TT, 1) }
   MRLA_DISPATCH_B(dtype, CALL)

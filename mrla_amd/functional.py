@@ -354,6 +354,10 @@ class BaseStage:
             nhwc_ok = lib.mrla_base_tile_rows(b, c, h, w, _DT[x.dtype], L.NHWC) > 0
             if not x.is_contiguous() and x.is_contiguous(memory_format=_CL) and nhwc_ok:
                 return L.NHWC
+            # channel-contiguous views that are not dense (DeiT's map tokens x[:, 1:] seen as [b, c, 14, 14]): one dense
+            # NHWC copy is cheaper than the transposing copy the NCHW kernels would need
+            if nhwc_ok and c > 1 and x.stride(1) == 1 and not x.is_contiguous():
+                return L.NHWC
             # NCHW tensors the slab kernels cannot take (plane rows wider than a wave, slabs beyond the LDS) go through one
             # internal channels_last conversion per layer instead of failing (the reference accepts any map size)
             if nhwc_ok and lib.mrla_light_wgrad_rows(b, c, h, w, _DT[x.dtype], L.NCHW) == L.EUNSUPPORTED:

@@ -282,6 +282,9 @@ class mrlab_module(nn.Module):
         side = math.isqrt(n - 1)
         if side * side != n - 1:
             raise MrlaHipError(f"mrlab_module: {n - 1} map tokens do not form a square map")
-        fmap = xt[:, 1:].reshape(b, side, side, c).permute(0, 3, 1, 2).contiguous()
+        # the map tokens ARE a channels_last image (pixel pitch c): no token <-> NCHW transposes; the stage's history
+        # lives in slot-major NHWC rings and the layer's output comes back as a view of map tokens
+        fmap = xt[:, 1:].reshape(b, side, side, c).permute(0, 3, 1, 2)
         out, kt, vt = self.mrla(fmap, prev_k, prev_v)
-        return torch.cat((xt[:, :1], out.flatten(2).transpose(1, 2)), dim=1), kt, vt
+        tokens = out.permute(0, 2, 3, 1).reshape(b, n - 1, c)
+        return torch.cat((xt[:, :1], tokens), dim=1), kt, vt

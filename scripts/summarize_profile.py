@@ -17,7 +17,9 @@ out = sys.argv[2] if len(sys.argv) > 2 else raw
 def short(name):
     for key in ("light_stats_fwd_fused", "conv1x1_fwd", "light_stats_fwd", "light_apply_fwd_pre", "light_apply_fwd", "light_stats_bwd", "light_apply_bwd", "plane_moments_small",
                 "plane_moments", "affine_act", "nhwc_moments_flat", "nhwc_affine_flat", "nhwc_moments", "nhwc_affine",
-                "base_combine_nhwcIDF16bDF16bLi0", "base_combine_nhwcIDF16bDF16bLi1", "base_combine", "base_attend_fwd",
+                "base_combine_nhwcIDF16bDF16bLi0", "base_combine_nhwcIDF16bDF16bLi1", "base_combine_nhwcIffLi0",
+                "base_combine_nhwcIffLi1", "base_combine", "base_attend_fwd", "token_apply_fwd", "token_apply_bwd",
+                "token_stats_bwd", "token_ln_bwd", "token_norm_pool", "token_ln",
                 "base_attend_bwd", "base_value_bwd", "base_tail", "base_pmom",
                 "plain_bn_fwd", "plain_bn_bwd", "reduce_rows"):
         if key in name:
@@ -52,7 +54,10 @@ json.dump(traffic, open(os.path.join(out, "summary_traffic.json"), "w"), indent=
 f = glob.glob(os.path.join(raw, "trace", "*", "*_kernel_trace.csv"))
 if f:
     rows = sorted(csv.DictReader(open(f[0])), key=lambda r: int(r["Start_Timestamp"]))
-    marks = [i for i, r in enumerate(rows) if "max_pool_backward" in r["Kernel_Name"]]
+    # one launch per training step: the loss kernel (any architecture), else ResNet's max-pool backward
+    marks = [i for i, r in enumerate(rows) if "nll_loss_forward" in r["Kernel_Name"]]
+    if len(marks) < 5:
+        marks = [i for i, r in enumerate(rows) if "max_pool_backward" in r["Kernel_Name"]]
     if len(marks) >= 5:
         sel, steps = rows[marks[-5]:marks[-1]], 4
         agg = collections.defaultdict(lambda: [0, 0.0])

@@ -33,7 +33,8 @@ def test_argument_validation_without_a_gpu():
     assert lib.mrla_base_tile_rows(128, 1024, 14, 14, _lib.BF16, _lib.NHWC) == 128 * 28     # 7-pixel tiles
     assert lib.mrla_base_pmom_rows(128, 1024, 14, 14, _lib.BF16, _lib.NHWC) == 128 * 14     # 14-pixel tiles
     assert lib.mrla_base_tile_rows(4, 256, 56, 56, _lib.F32, _lib.NCHW) == 4
-    assert lib.mrla_base_tile_rows(4, 192, 14, 14, _lib.BF16, _lib.NHWC) == _lib.EUNSUPPORTED   # 24 vectors per pixel
+    assert lib.mrla_base_tile_rows(4, 192, 14, 14, _lib.BF16, _lib.NHWC) > 0       # DeiT widths: 240-thread workgroups
+    assert lib.mrla_base_tile_rows(4, 192, 14, 14, _lib.F32, _lib.NHWC) > 0 and lib.mrla_base_tile_rows(4, 768, 14, 14, _lib.F32, _lib.NHWC) > 0
     assert lib.mrla_base_tile_rows(4, 2048, 7, 7, _lib.F32, _lib.NHWC) == _lib.EUNSUPPORTED    # 512 fp32 vectors per pixel
     assert lib.mrla_base_tile_rows(0, 256, 7, 7, _lib.BF16, _lib.NHWC) == _lib.EINVAL
     assert lib.mrla_base_pool_value_fwd(None, None, None, None, None, None, None, None, 1, 64, 4, 4, _lib.BF16, _lib.NHWC,

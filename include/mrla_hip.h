@@ -40,7 +40,9 @@ enum { MRLA_ACT_NONE = 0, MRLA_ACT_GELU = 1 };
 enum { MRLA_BN_NONE = 0, MRLA_BN_TRAIN = 1, MRLA_BN_EVAL = 2 };
 
 /* Moment record sizes (floats per (image, channel)). */
-#define MRLA_FWD_MOMENTS 6 /* sum x, sum V, sum o, sum V^2, sum V*o, sum o^2 */
+#define MRLA_FWD_MOMENTS 8 /* sum x, sum V', sum o', sum V'^2, sum V'*o', sum o'^2, pV, po  with V' = V - pV, o' = o - po:
+                              the second moments are taken about per-plane pivots (samples of V / o; 0 where a producer
+                              does not shift) so that they stay well conditioned when |mean| >> sigma */
 #define MRLA_BWD_MOMENTS 3 /* sum dOut, sum dOut*V, sum dOut*o */
 
 int mrla_abi_version(void);
@@ -111,16 +113,19 @@ int mrla_light_stats_bwd(const void* dout, const void* x, const void* o_prev, co
 
 /* ---- BatchNorm backward constants + dgamma, dbeta, dlambda ---------------------------------------
  * cb[c, 4] = (e, f, G, H) such that dm = e*dp[b]*dOut + f*a[b,g]*V + G*o_prev + H.
+ * cb_lo[c, 4] [opt, OUTPUT]: the float remainders of the four constants (they are computed in double; the closed-form
+ * gate gradient of mrla_light_gate_bwd cancels large terms and wants them beyond fp32 when |mean| >> sigma).
  * gamma [opt]: null = no BatchNorm (e = 1, f = G = H = 0; dgamma/dbeta untouched).
  * lam, dp, dlam [opt]. */
 int mrla_light_bn_bwd(const float* mom, const float* bmom, const float* gate, const float* lam, const float* gamma,
                       const float* dp, const float* save_mean, const float* save_inv, int bn_mode, float* cb,
-                      float* dgamma, float* dbeta, float* dlam, int b, int c, int hw, int d, void* stream);
+                      float* cb_lo, float* dgamma, float* dbeta, float* dlam, int b, int c, int hw, int d, void* stream);
 
 /* ---- gate backward -------------------------------------------------------------------------------
  * dyx[b, c] = (gradient wrt the pooled descriptor y) / hw ; dwqk_part[b, 2*ksize] = per-image partial
- * sums of dWq (first ksize) and dWk.  cb, dp [opt]. */
-int mrla_light_gate_bwd(const float* mom, const float* bmom, const float* gate, const float* cb, const float* dp,
+ * sums of dWq (first ksize) and dWk.  cb, cb_lo, dp [opt]. */
+int mrla_light_gate_bwd(const float* mom, const float* bmom, const float* gate, const float* cb, const float* cb_lo,
+                        const float* dp,
                         const float* wq, const float* wk, int ksize, float* dyx, float* dwqk_part, int b, int c,
                         int hw, int d, void* stream);
 

@@ -14,7 +14,7 @@ F32, BF16, F16 = 0, 1, 2
 NCHW, NHWC = 0, 1
 ACT_NONE, ACT_GELU = 0, 1
 BN_NONE, BN_TRAIN, BN_EVAL = 0, 1, 2
-FWD_MOMENTS, BWD_MOMENTS, TOKEN_PARTIALS = 6, 3, 14
+FWD_MOMENTS, BWD_MOMENTS, TOKEN_PARTIALS = 8, 3, 14
 
 _ERR = {EINVAL: "invalid argument", EUNSUPPORTED: "unsupported shape/layout for the HIP kernels",
         EHIP: "HIP runtime error at kernel launch"}
@@ -31,8 +31,8 @@ SIGNATURES = {
     "mrla_light_bn_fwd": [_P, _P, _P, _P, _P, _P, _P, _I, _F, _F, _P, _P, _P, _P, _I, _I, _I, _I, _P],
     "mrla_light_apply_fwd": [_P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P],
     "mrla_light_stats_bwd": [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P],
-    "mrla_light_bn_bwd": [_P, _P, _P, _P, _P, _P, _P, _P, _I, _P, _P, _P, _P, _I, _I, _I, _I, _P],
-    "mrla_light_gate_bwd": [_P, _P, _P, _P, _P, _P, _P, _I, _P, _P, _I, _I, _I, _I, _P],
+    "mrla_light_bn_bwd": [_P, _P, _P, _P, _P, _P, _P, _P, _I, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P],
+    "mrla_light_gate_bwd": [_P, _P, _P, _P, _P, _P, _P, _P, _I, _P, _P, _I, _I, _I, _I, _P],
     "mrla_light_apply_bwd": [_P] * 12 + [_I] * 10 + [_P],
     "mrla_light_pool_fused": [_P] * 6 + [_I] * 6 + [_P],
     "mrla_light_apply_fwd_fused": [_P] * 11 + [_I] * 8 + [_P],

@@ -84,7 +84,7 @@ __global__ __launch_bounds__(kThreads) void base_gate_fwd_kernel(
   const float inv_hw = 1.0f / (float)HW;
   for (int i = tid; i < C + 2 * p; i += kThreads) {
     const int c = i - p;
-    ys[i] = (c >= 0 && c < C) ? mom[((size_t)b * C + c) * M_N + M_SX] * inv_hw : 0.f;
+    ys[i] = (c >= 0 && c < C) ? mom[((size_t)b * C + c) * M_REC + M_SX] * inv_hw : 0.f;
   }
   __syncthreads();
   float* Kb = Kring + (size_t)b * T * C;
@@ -488,7 +488,7 @@ __global__ __launch_bounds__(kThreads) void base_gate_bwd_kernel(
   const float s = rsqrtf((float)d);
   for (int i = tid; i < CPD; i += kThreads) {
     const int c = i - p;
-    ys[i] = (c >= 0 && c < C) ? mom[((size_t)b * C + c) * M_N + M_SX] * inv_hw : 0.f;
+    ys[i] = (c >= 0 && c < C) ? mom[((size_t)b * C + c) * M_REC + M_SX] * inv_hw : 0.f;
     dqs[i] = 0.f;
     dks[i] = 0.f;
   }

@@ -240,14 +240,14 @@ __global__ __launch_bounds__(kThreads) void nhwc_moments_flat_kernel(const T* __
 
 // mom[b, c, slot 0 of 6] = sum over the nsplit partial rows of an image (the pooled x_t of the inference path)
 __global__ __launch_bounds__(kThreads) void nhwc_pool_finish_kernel(const float* __restrict__ part /*[b*ns, c, 2]*/,
-                                                                    float* __restrict__ mom /*[b, c, 6]*/, int BC, int C,
+                                                                    float* __restrict__ mom /*[b, c, M_REC]*/, int BC, int C,
                                                                     int ns) {
   const int i = blockIdx.x * kThreads + threadIdx.x;
   if (i >= BC) return;
   const int b = i / C, c = i - b * C;
   float s = 0.f;
   for (int k = 0; k < ns; ++k) s += part[(((size_t)b * ns + k) * C + c) * 2];
-  mom[(size_t)i * 6] = s;
+  mom[(size_t)i * M_REC] = s;
 }
 
 // Elementwise over the flat tensor; requires (kThreads * VEC) % C == 0 (then a thread's channels never change).

@@ -176,21 +176,21 @@ int mrla_light_stats_bwd(const void* dout, const void* x, const void* o_prev, co
 
 int mrla_light_bn_bwd(const float* mom, const float* bmom, const float* gate, const float* lam, const float* gamma,
                       const float* dp, const float* save_mean, const float* save_inv, int bn_mode, float* cb,
-                      float* dgamma, float* dbeta, float* dlam, int b, int c, int hw, int d, void* stream) {
+                      float* cb_lo, float* dgamma, float* dbeta, float* dlam, int b, int c, int hw, int d, void* stream) {
   if (!mom || !bmom || !gate || !cb || b <= 0 || c <= 0 || hw <= 0 || d <= 0 || c % d) return MRLA_EINVAL;
   if (gamma && (!save_mean || !save_inv || !dgamma || !dbeta)) return MRLA_EINVAL;
   if (dlam && !lam) return MRLA_EINVAL;
-  return launch_bn_bwd(mom, bmom, gate, lam, gamma, dp, save_mean, save_inv, bn_mode == MRLA_BN_TRAIN, cb, dgamma,
+  return launch_bn_bwd(mom, bmom, gate, lam, gamma, dp, save_mean, save_inv, bn_mode == MRLA_BN_TRAIN, cb, cb_lo, dgamma,
                        dbeta, dlam, b, c, hw, d, (hipStream_t)stream);
 }
 
-int mrla_light_gate_bwd(const float* mom, const float* bmom, const float* gate, const float* cb, const float* dp,
-                        const float* wq, const float* wk, int ksize, float* dyx, float* dwqk_part, int b, int c,
+int mrla_light_gate_bwd(const float* mom, const float* bmom, const float* gate, const float* cb, const float* cb_lo,
+                        const float* dp, const float* wq, const float* wk, int ksize, float* dyx, float* dwqk_part, int b, int c,
                         int hw, int d, void* stream) {
   if (!mom || !bmom || !gate || !wq || !wk || !dyx || !dwqk_part || b <= 0 || c <= 0 || hw <= 0 || d <= 0 || c % d ||
       ksize <= 0 || !(ksize & 1))
     return MRLA_EINVAL;
-  return launch_gate_bwd(mom, bmom, gate, cb, dp, wq, wk, ksize, dyx, dwqk_part, b, c, hw, d, (hipStream_t)stream);
+  return launch_gate_bwd(mom, bmom, gate, cb, cb_lo, dp, wq, wk, ksize, dyx, dwqk_part, b, c, hw, d, (hipStream_t)stream);
 }
 
 int mrla_light_apply_bwd(const void* dout, const void* x, const void* o_prev, const float* wv, const float* gate,

@@ -28,7 +28,7 @@ __global__ __launch_bounds__(kThreads) void gate_fwd_kernel(const float* __restr
   const float inv_hw = 1.0f / (float)HW;
   for (int i = tid; i < C + 2 * p; i += kThreads) {
     const int c = i - p;
-    ys[i] = (c >= 0 && c < C) ? mom[((size_t)b * C + c) * M_N + M_SX] * inv_hw : 0.f;
+    ys[i] = (c >= 0 && c < C) ? mom[((size_t)b * C + c) * M_REC + M_SX] * inv_hw : 0.f;
   }
   __syncthreads();
   for (int c = tid; c < C; c += kThreads) {
@@ -68,10 +68,11 @@ __global__ __launch_bounds__(kThreads) void bn_fwd_kernel(
     if (live) {
       const float l = lam ? lam[c] : 0.f;
       for (int b = bl; b < B; b += kBnLanes) {
-        const float* m = mom + ((size_t)b * C + c) * M_N;
-        const float a = gate[(size_t)b * G + c / d];
-        s1 += (double)a * m[M_SV] + (double)l * m[M_SO];
-        s2 += (double)a * a * m[M_SVV] + 2.0 * a * l * m[M_SVO] + (double)l * l * m[M_SOO];
+        const float* m = mom + ((size_t)b * C + c) * M_REC;
+        const double a = gate[(size_t)b * G + c / d];
+        const RawMoments r = raw_moments(m, (double)HW);
+        s1 += a * r.sv + (double)l * r.so;
+        s2 += a * a * r.svv + 2.0 * a * l * r.svo + (double)l * l * r.soo;
       }
     }
     r1[bl][cc] = s1; r2[bl][cc] = s2;
@@ -108,9 +109,10 @@ __global__ __launch_bounds__(kThreads) void bn_bwd_kernel(
     const float* __restrict__ mom, const float* __restrict__ bmom, const float* __restrict__ gate,
     const float* __restrict__ lam, const float* __restrict__ gamma, const float* __restrict__ dp,
     const float* __restrict__ save_mean, const float* __restrict__ save_inv, int training, float* __restrict__ cb,
-    float* __restrict__ dgamma, float* __restrict__ dbeta, float* __restrict__ dlam, int B, int C, int HW, int d) {
+    float* __restrict__ cb_lo, float* __restrict__ dgamma, float* __restrict__ dbeta, float* __restrict__ dlam, int B,
+    int C, int HW, int d) {
   __shared__ double r1[kBnLanes][kBnCh], r2[kBnLanes][kBnCh];
-  __shared__ float coef[4][kBnCh];
+  __shared__ double coef[4][kBnCh];
   const int cc = threadIdx.x % kBnCh, bl = threadIdx.x / kBnCh;
   const int c = blockIdx.x * kBnCh + cc;
   const bool live = c < C;
@@ -147,20 +149,25 @@ __global__ __launch_bounds__(kThreads) void bn_bwd_kernel(
       dgamma[c] = (float)dga;
       dbeta[c] = (float)dbe;
     }
-    coef[0][cc] = (float)e; coef[1][cc] = (float)f; coef[2][cc] = (float)Gc; coef[3][cc] = (float)Hc;
+    coef[0][cc] = e; coef[1][cc] = f; coef[2][cc] = Gc; coef[3][cc] = Hc;
     cb[c * 4 + 0] = (float)e; cb[c * 4 + 1] = (float)f; cb[c * 4 + 2] = (float)Gc; cb[c * 4 + 3] = (float)Hc;
+    if (cb_lo) {        // the float remainders: the closed-form gate gradient cancels large terms and needs e..H beyond fp32
+      cb_lo[c * 4 + 0] = (float)(e - (double)(float)e);   cb_lo[c * 4 + 1] = (float)(f - (double)(float)f);
+      cb_lo[c * 4 + 2] = (float)(Gc - (double)(float)Gc); cb_lo[c * 4 + 3] = (float)(Hc - (double)(float)Hc);
+    }
   }
   __syncthreads();
   if (!dlam) return;
   double s3 = 0.0;
   if (live) {
-    const float e = coef[0][cc], f = coef[1][cc], Gc = coef[2][cc], Hc = coef[3][cc];
+    const double e = coef[0][cc], f = coef[1][cc], Gc = coef[2][cc], Hc = coef[3][cc];
     for (int b = bl; b < B; b += kBnLanes) {
-      const float* m = mom + ((size_t)b * C + c) * M_N;
+      const float* m = mom + ((size_t)b * C + c) * M_REC;
       const float* bm = bmom + ((size_t)b * C + c) * D_N;
-      const float a = gate[(size_t)b * G + c / d];
+      const double a = gate[(size_t)b * G + c / d];
       const double dpb = dp ? dp[b] : 1.f;
-      s3 += (double)e * dpb * bm[D_DO] + (double)f * a * m[M_SVO] + (double)Gc * m[M_SOO] + (double)Hc * m[M_SO];
+      const RawMoments r = raw_moments(m, (double)HW);
+      s3 += e * dpb * bm[D_DO] + f * a * r.svo + Gc * r.soo + Hc * r.so;
     }
   }
   r1[bl][cc] = s3;
@@ -189,8 +196,9 @@ __device__ __forceinline__ float block_sum(float v, float* scratch /*[kWaves]*/)
 
 __global__ __launch_bounds__(kThreads) void gate_bwd_kernel(
     const float* __restrict__ mom, const float* __restrict__ bmom, const float* __restrict__ gate,
-    const float* __restrict__ cb, const float* __restrict__ dp, const float* __restrict__ wq,
-    const float* __restrict__ wk, int ks, float* __restrict__ dyx, float* __restrict__ dwqk_part, int C, int HW, int d) {
+    const float* __restrict__ cb, const float* __restrict__ cb_lo, const float* __restrict__ dp,
+    const float* __restrict__ wq, const float* __restrict__ wk, int ks, float* __restrict__ dyx,
+    float* __restrict__ dwqk_part, int C, int HW, int d) {
   extern __shared__ float sm[];
   const int p = (ks - 1) / 2;
   const int CPD = C + 2 * p;
@@ -207,7 +215,7 @@ __global__ __launch_bounds__(kThreads) void gate_bwd_kernel(
   const float dpb = dp ? dp[b] : 1.f;
   for (int i = tid; i < CPD; i += kThreads) {
     const int c = i - p;
-    ys[i] = (c >= 0 && c < C) ? mom[((size_t)b * C + c) * M_N + M_SX] * inv_hw : 0.f;
+    ys[i] = (c >= 0 && c < C) ? mom[((size_t)b * C + c) * M_REC + M_SX] * inv_hw : 0.f;
     dqs[i] = 0.f;
     dks[i] = 0.f;
   }
@@ -220,13 +228,15 @@ __global__ __launch_bounds__(kThreads) void gate_bwd_kernel(
     }
     qs[c] = q;
     kk[c] = k;
-    const float* m = mom + ((size_t)b * C + c) * M_N;
+    const float* m = mom + ((size_t)b * C + c) * M_REC;
     const float* bm = bmom + ((size_t)b * C + c) * D_N;
     const float a = gate[(size_t)b * G + c / d];
-    float e = 1.f, f = 0.f, Gc = 0.f, Hc = 0.f;
+    double e = 1.0, f = 0.0, Gc = 0.0, Hc = 0.0;
     if (cb) { e = cb[c * 4 + 0]; f = cb[c * 4 + 1]; Gc = cb[c * 4 + 2]; Hc = cb[c * 4 + 3]; }
+    if (cb && cb_lo) { e += cb_lo[c * 4 + 0]; f += cb_lo[c * 4 + 1]; Gc += cb_lo[c * 4 + 2]; Hc += cb_lo[c * 4 + 3]; }
     // sum_hw dm * V  for this channel
-    dqs[p + c] = e * dpb * bm[D_DV] + f * a * m[M_SVV] + Gc * m[M_SVO] + Hc * m[M_SV];
+    const RawMoments r = raw_moments(m, (double)HW);
+    dqs[p + c] = (float)(e * dpb * bm[D_DV] + f * a * r.svv + Gc * r.svo + Hc * r.sv);
   }
   __syncthreads();
   const float s = rsqrtf((float)d);
@@ -305,20 +315,20 @@ int launch_bn_fwd(const float* mom, const float* gate, const float* lam, const f
 }
 
 int launch_bn_bwd(const float* mom, const float* bmom, const float* gate, const float* lam, const float* gamma,
-                  const float* dp, const float* save_mean, const float* save_inv, int training, float* cb,
+                  const float* dp, const float* save_mean, const float* save_inv, int training, float* cb, float* cb_lo,
                   float* dgamma, float* dbeta, float* dlam, int B, int C, int HW, int d, hipStream_t st) {
   hipLaunchKernelGGL(bn_bwd_kernel, dim3((C + kBnCh - 1) / kBnCh), dim3(kThreads), 0, st, mom, bmom, gate, lam, gamma,
-                     dp, save_mean, save_inv, training, cb, dgamma, dbeta, dlam, B, C, HW, d);
+                     dp, save_mean, save_inv, training, cb, cb_lo, dgamma, dbeta, dlam, B, C, HW, d);
   return hip_status(hipGetLastError());
 }
 
-int launch_gate_bwd(const float* mom, const float* bmom, const float* gate, const float* cb, const float* dp,
-                    const float* wq, const float* wk, int ks, float* dyx, float* dwqk_part, int B, int C, int HW,
+int launch_gate_bwd(const float* mom, const float* bmom, const float* gate, const float* cb, const float* cb_lo,
+                    const float* dp, const float* wq, const float* wk, int ks, float* dyx, float* dwqk_part, int B, int C, int HW,
                     int d, hipStream_t st) {
   const int p = (ks - 1) / 2;
   const size_t lds = (size_t)(3 * (C + 2 * p) + 2 * C + C / d + kWaves) * sizeof(float);
   if (lds > 64 * 1024) return MRLA_EUNSUPPORTED;
-  hipLaunchKernelGGL(gate_bwd_kernel, dim3(B), dim3(kThreads), lds, st, mom, bmom, gate, cb, dp, wq, wk, ks, dyx,
+  hipLaunchKernelGGL(gate_bwd_kernel, dim3(B), dim3(kThreads), lds, st, mom, bmom, gate, cb, cb_lo, dp, wq, wk, ks, dyx,
                      dwqk_part, C, HW, d);
   return hip_status(hipGetLastError());
 }

@@ -171,7 +171,8 @@ __global__ __launch_bounds__(kThreads) void light_stats_fwd_nchw(
       const int grp = p / g.PW, pl = p - grp * g.PW;
       float s = 0.f;
       for (int band = 0; band < g.NB; ++band) s += red[((grp * g.NB + band) * g.PW + pl) * M_N + k];
-      mom[((size_t)b * g.C + c0 + p) * M_N + k] = s;
+      mom[((size_t)b * g.C + c0 + p) * M_REC + k] = s;
+      if (k == 0) { mom[((size_t)b * g.C + c0 + p) * M_REC + M_PV] = 0.f; mom[((size_t)b * g.C + c0 + p) * M_REC + M_PO] = 0.f; }
     }
   }
 }

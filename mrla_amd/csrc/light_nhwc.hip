@@ -117,7 +117,9 @@ __global__ __launch_bounds__(kMaxStrips * kWave) void light_stats_fwd_nhwc(
     wg_reduce<M_N>(acc, red, lane, wave, nwaves);
     if (wave == 0 && cv) {
 #pragma unroll
-      for (int k = 0; k < M_N; ++k) mom[((size_t)b * C + c) * M_N + k] = acc[k];
+      for (int k = 0; k < M_N; ++k) mom[((size_t)b * C + c) * M_REC + k] = acc[k];
+      mom[((size_t)b * C + c) * M_REC + M_PV] = 0.f;          // raw sums (no pivots on this path)
+      mom[((size_t)b * C + c) * M_REC + M_PO] = 0.f;
     }
   }
 }

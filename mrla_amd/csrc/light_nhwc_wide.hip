@@ -40,6 +40,57 @@ namespace mrla {
   }
 
 // ------------------------------------------------------------------------------------------------
+// Pivoted forward moments (mrla_device.h: the M_REC record).  A strip accumulates its sums over V and o about ITS first
+// values (pV, po) -- samples of the plane, so nothing cancels when |mean| >> sigma; strips of a wave and then the waves of
+// the workgroup are merged by re-basing onto the first one's pivots (exact algebra on the shifted sums).
+// ------------------------------------------------------------------------------------------------
+constexpr int kMomRed = M_N + 3;                     // per-wave reduction record: the six sums, pV, po, pixel count
+struct WaveMoments {
+  float s[M_N], pv, po, n;
+  __device__ __forceinline__ void clear() {
+#pragma unroll
+    for (int k = 0; k < M_N; ++k) s[k] = 0.f;
+    pv = 0.f; po = 0.f; n = 0.f;
+  }
+  // fold in `a` (sums about (apv, apo) over an pixels)
+  __device__ __forceinline__ void merge(float (&a)[M_N], float apv, float apo, float an) {
+    if (n == 0.f) { pv = apv; po = apo; }            // (lanes agree: n is wave-uniform)
+    rebase_moments(a, an, apv, apo, pv, po);
+#pragma unroll
+    for (int k = 0; k < M_N; ++k) s[k] += a[k];
+    n += an;
+  }
+};
+// Workgroup reduction in wave order; wave 0 writes the record of (image b, channel c).
+__device__ __forceinline__ void store_moments(WaveMoments& w, float* __restrict__ red, float* __restrict__ mom, int lane,
+                                              int wave, int nwaves) {
+  if (nwaves > 1) {
+    __syncthreads();
+    float* mine = red + (size_t)wave * kMomRed * kWave;
+#pragma unroll
+    for (int k = 0; k < M_N; ++k) mine[k * kWave + lane] = w.s[k];
+    mine[M_N * kWave + lane] = w.pv; mine[(M_N + 1) * kWave + lane] = w.po; mine[(M_N + 2) * kWave + lane] = w.n;
+    __syncthreads();
+    if (wave == 0) {
+      for (int v = 1; v < nwaves; ++v) {
+        const float* o = red + (size_t)v * kMomRed * kWave;
+        float a[M_N];
+#pragma unroll
+        for (int k = 0; k < M_N; ++k) a[k] = o[k * kWave + lane];
+        const float an = o[(M_N + 2) * kWave + lane];
+        if (an > 0.f) w.merge(a, o[M_N * kWave + lane], o[(M_N + 1) * kWave + lane], an);
+      }
+    }
+  }
+  if (wave == 0) {
+#pragma unroll
+    for (int k = 0; k < M_N; ++k) mom[k] = w.s[k];
+    mom[M_PV] = w.pv;
+    mom[M_PO] = w.po;
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
 // backward statistics: per (image, channel) sums of dOut, dOut*V, dOut*o
 // ------------------------------------------------------------------------------------------------
 template <typename T> constexpr int stats_bwd_wave_bytes() { return RowIO<T, kS + 2>::kBytes + 2 * RowIO<T, kS>::kBytes; }
@@ -117,7 +168,7 @@ template <typename T, bool GELU, bool HAS_O, bool RAGGED>
 __global__ __launch_bounds__(kMaxStrips * kWave) void light_stats_fwd_wide(
     const T* __restrict__ x, const T* __restrict__ o, const float* __restrict__ wv, float* __restrict__ mom,
     T* __restrict__ vout, int B, int C, int H, int W, int BG) {
-  MRLA_WIDE_PROLOGUE(M_N, stats_fwd_wave_bytes<T>())
+  MRLA_WIDE_PROLOGUE(kMomRed, stats_fwd_wave_bytes<T>())
   T* bufX = reinterpret_cast<T*>(wbuf);
   T* bufO = reinterpret_cast<T*>(wbuf + RowIO<T, kS + 2>::kBytes);
   T* bufS = reinterpret_cast<T*>(wbuf + RowIO<T, kS + 2>::kBytes + RowIO<T, kS>::kBytes);
@@ -130,8 +181,11 @@ __global__ __launch_bounds__(kMaxStrips * kWave) void light_stats_fwd_wide(
     const T* xi = x + ioff;
     const T* oi = HAS_O ? o + ioff : nullptr;
     T* vo = vout ? vout + ioff : nullptr;
-    float acc[M_N] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    WaveMoments wm;
+    wm.clear();
     for (int s = wave; s < nstrips; s += nwaves) {
+      float acc[M_N] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+      float pV = 0.f, pO = 0.f;                       // this strip's pivots: its first V and o
       const int s0 = s * kS, nc = min(kS, W - s0);
       RowIO<T, kS + 2> ax;
       RowIO<T, kS> ao, as;
@@ -157,27 +211,29 @@ __global__ __launch_bounds__(kMaxStrips * kWave) void light_stats_fwd_wide(
         for (int j = 0; j < kS; ++j) {
           float v = conv_at(w, XA.v, XB.v, XC.v, j);
           if (GELU) v = gelu_f(v);
-          if (RAGGED) v = j < nc ? v : 0.f;          // x and o are zero beyond the image, V is not
           vrow[j] = v;
+        }
+        if (r == 0) { pV = vrow[0]; pO = HAS_O ? ov.v[0] : 0.f; }
+#pragma unroll
+        for (int j = 0; j < kS; ++j) {
+          float dv = vrow[j] - pV, d_o = HAS_O ? ov.v[j] - pO : 0.f;
+          if (RAGGED) { dv = j < nc ? dv : 0.f; d_o = j < nc ? d_o : 0.f; }     // columns beyond the image do not count
           acc[M_SX] += XB.v[j + 1];
-          acc[M_SV] += v;
-          acc[M_SVV] = fmaf(v, v, acc[M_SVV]);
+          acc[M_SV] += dv;
+          acc[M_SVV] = fmaf(dv, dv, acc[M_SVV]);
           if (HAS_O) {
-            acc[M_SO] += ov.v[j];
-            acc[M_SVO] = fmaf(v, ov.v[j], acc[M_SVO]);
-            acc[M_SOO] = fmaf(ov.v[j], ov.v[j], acc[M_SOO]);
+            acc[M_SO] += d_o;
+            acc[M_SVO] = fmaf(dv, d_o, acc[M_SVO]);
+            acc[M_SOO] = fmaf(d_o, d_o, acc[M_SOO]);
           }
         }
         if (vo) row_store<T, kS>(as, vo, r, rowelems, lane, bufS, vrow);
       };
       MRLA_ROTATE3(H, step, xa, xb, xc)
       rows_landed();
+      wm.merge(acc, pV, pO, (float)(H * nc));
     }
-    wg_reduce<M_N>(acc, red, lane, wave, nwaves);
-    if (wave == 0) {
-#pragma unroll
-      for (int k = 0; k < M_N; ++k) mom[((size_t)b * C + c) * M_N + k] = acc[k];
-    }
+    store_moments(wm, red, mom + ((size_t)b * C + c) * M_REC, lane, wave, nwaves);
   }
 }
 
@@ -211,7 +267,7 @@ __global__ __launch_bounds__(kMaxStrips * kWave) void light_stats_fwd_fused_wide
     const T* __restrict__ pre, const T* __restrict__ o, const float* __restrict__ wv, float* __restrict__ mom,
     T* __restrict__ xout, const float* __restrict__ psc, const float* __restrict__ psh, T* __restrict__ vout, int B,
     int C, int H, int W, int BG) {
-  MRLA_WIDE_PROLOGUE(M_N, fused_wave_bytes<T>())
+  MRLA_WIDE_PROLOGUE(kMomRed, fused_wave_bytes<T>())
   constexpr int RB = RowIO<T, kS + 2>::kBytes;
   T* bufP = reinterpret_cast<T*>(wbuf);
   unsigned char* bufO2 = wbuf + RB;                  // o row r lives in half (r & 1)
@@ -227,8 +283,11 @@ __global__ __launch_bounds__(kMaxStrips * kWave) void light_stats_fwd_fused_wide
     const T* oi = o + ioff;
     T* xo = xout + ioff;
     T* vo = vout ? vout + ioff : nullptr;
-    float acc[M_N] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    WaveMoments wm;
+    wm.clear();
     for (int s = wave; s < nstrips; s += nwaves) {
+      float acc[M_N] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+      float pV = 0.f, pO = 0.f;                       // this strip's pivots: its first V and o
       const int s0 = s * kS, nc = min(kS, W - s0);
       RowIO<T, kS + 2> ax;
       RowIO<T, kS> as;
@@ -274,27 +333,26 @@ __global__ __launch_bounds__(kMaxStrips * kWave) void light_stats_fwd_fused_wide
         }
         float vrow[kS];
 #pragma unroll
+        for (int j = 0; j < kS; ++j) vrow[j] = conv_at(w, XA, XB, XC, j);
+        if (r == 0) { pV = vrow[0]; pO = ov.v[0]; }
+#pragma unroll
         for (int j = 0; j < kS; ++j) {
-          float v = conv_at(w, XA, XB, XC, j);
-          if (RAGGED) v = j < nc ? v : 0.f;
-          vrow[j] = v;
+          float dv = vrow[j] - pV, d_o = ov.v[j] - pO;
+          if (RAGGED) { dv = j < nc ? dv : 0.f; d_o = j < nc ? d_o : 0.f; }
           acc[M_SX] += XB[j + 1];
-          acc[M_SV] += v;
-          acc[M_SVV] = fmaf(v, v, acc[M_SVV]);
-          acc[M_SO] += ov.v[j];
-          acc[M_SVO] = fmaf(v, ov.v[j], acc[M_SVO]);
-          acc[M_SOO] = fmaf(ov.v[j], ov.v[j], acc[M_SOO]);
+          acc[M_SV] += dv;
+          acc[M_SVV] = fmaf(dv, dv, acc[M_SVV]);
+          acc[M_SO] += d_o;
+          acc[M_SVO] = fmaf(dv, d_o, acc[M_SVO]);
+          acc[M_SOO] = fmaf(d_o, d_o, acc[M_SOO]);
         }
         if (vo) row_store<T, kS>(as, vo, r, rowelems, lane, bufS, vrow);
       };
       MRLA_ROTATE3(H, step, xa, xb, xc)
       rows_landed();
+      wm.merge(acc, pV, pO, (float)(H * nc));
     }
-    wg_reduce<M_N>(acc, red, lane, wave, nwaves);
-    if (wave == 0) {
-#pragma unroll
-      for (int k = 0; k < M_N; ++k) mom[((size_t)b * C + c) * M_N + k] = acc[k];
-    }
+    store_moments(wm, red, mom + ((size_t)b * C + c) * M_REC, lane, wave, nwaves);
   }
 }
 
@@ -628,7 +686,7 @@ int launch_light_stats_fwd_wide(const void* x, const void* o, const float* wv, f
     if (!o || act) return MRLA_EINVAL;
 #define CALL_R(T, AF, RG)                                                                                           \
   {                                                                                                                 \
-    const WideLaunch L = wide_launch(B, C, W, M_N, fused_wave_bytes<T>(), bg);                                       \
+    const WideLaunch L = wide_launch(B, C, W, kMomRed, fused_wave_bytes<T>(), bg);                                       \
     if (set_lds_n(light_stats_fwd_fused_wide<T, AF, RG>, L.lds) != hipSuccess) return MRLA_EHIP;                      \
     hipLaunchKernelGGL((light_stats_fwd_fused_wide<T, AF, RG>), L.grid, L.block, L.lds, st, (const T*)x, (const T*)o, \
                        wv, mom, (T*)xout, psc, psh, (T*)vout, B, C, H, W, L.BG);                                    \
@@ -648,7 +706,7 @@ int launch_light_stats_fwd_wide(const void* x, const void* o, const float* wv, f
   }
 #define CALL_R(T, A, O, RG)                                                                                         \
   {                                                                                                                 \
-    const WideLaunch L = wide_launch(B, C, W, M_N, stats_fwd_wave_bytes<T>(), bg);                                   \
+    const WideLaunch L = wide_launch(B, C, W, kMomRed, stats_fwd_wave_bytes<T>(), bg);                                   \
     if (set_lds_n(light_stats_fwd_wide<T, A, O, RG>, L.lds) != hipSuccess) return MRLA_EHIP;                          \
     hipLaunchKernelGGL((light_stats_fwd_wide<T, A, O, RG>), L.grid, L.block, L.lds, st, (const T*)x, (const T*)o, wv, \
                        mom, (T*)vout, B, C, H, W, L.BG);                                                            \

@@ -14,10 +14,36 @@ constexpr int kWave = 64;
 constexpr int kThreads = 256;          // 4 waves per workgroup everywhere
 constexpr int kWaves = kThreads / kWave;
 
-// Moment slots written by the forward statistics pass, per (image, channel).
-enum { M_SX = 0, M_SV = 1, M_SO = 2, M_SVV = 3, M_SVO = 4, M_SOO = 5, M_N = 6 };
+// Moment record written by the forward statistics pass, per (image, channel): M_REC floats.  The sums over V and o are
+// taken about the pivots (pV, po) stored beside them -- samples of V / o from the same plane -- so that the second
+// moments do not cancel when |mean| >> sigma; producers without pivots store pV = po = 0 (raw sums).
+//   [M_SX] sum x   [M_SV] sum (V-pV)   [M_SO] sum (o-po)   [M_SVV] sum (V-pV)^2   [M_SVO] sum (V-pV)(o-po)
+//   [M_SOO] sum (o-po)^2   [M_PV] pV   [M_PO] po
+enum { M_SX = 0, M_SV = 1, M_SO = 2, M_SVV = 3, M_SVO = 4, M_SOO = 5, M_N = 6, M_PV = 6, M_PO = 7, M_REC = 8 };
 // Moment slots written by the backward statistics pass.
 enum { D_D = 0, D_DV = 1, D_DO = 2, D_N = 3 };
+
+// Raw moments of V and o over the n pixels of a plane, in double, from a (pivot-shifted) moment record.
+struct RawMoments { double sv, so, svv, svo, soo; };
+__device__ __forceinline__ RawMoments raw_moments(const float* __restrict__ m, double n) {
+  const double pv = m[M_PV], po = m[M_PO], a = m[M_SV], b = m[M_SO];
+  RawMoments r;
+  r.sv = a + n * pv;
+  r.so = b + n * po;
+  r.svv = (double)m[M_SVV] + 2.0 * pv * a + n * pv * pv;
+  r.svo = (double)m[M_SVO] + pv * b + po * a + n * pv * po;
+  r.soo = (double)m[M_SOO] + 2.0 * po * b + n * po * po;
+  return r;
+}
+// sums of a record about (pv, po) over n pixels -> the same sums about (qv, qo)
+__device__ __forceinline__ void rebase_moments(float (&a)[M_N], float n, float pv, float po, float qv, float qo) {
+  const float dv = pv - qv, d_o = po - qo;
+  a[M_SVV] += 2.f * dv * a[M_SV] + n * dv * dv;
+  a[M_SOO] += 2.f * d_o * a[M_SO] + n * d_o * d_o;
+  a[M_SVO] += d_o * a[M_SV] + dv * a[M_SO] + n * dv * d_o;
+  a[M_SV] += n * dv;
+  a[M_SO] += n * d_o;
+}
 
 template <typename T> __device__ __forceinline__ float to_f(T v) { return static_cast<float>(v); }
 template <typename T> __device__ __forceinline__ T from_f(float v) { return static_cast<T>(v); }

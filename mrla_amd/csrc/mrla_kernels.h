@@ -51,10 +51,10 @@ int launch_bn_fwd(const float* mom, const float* gate, const float* lam, const f
                   float* run_mean, float* run_var, int training, float momentum, float eps, float* sc, float* sh,
                   float* save_mean, float* save_inv, int B, int C, int HW, int d, hipStream_t st);
 int launch_bn_bwd(const float* mom, const float* bmom, const float* gate, const float* lam, const float* gamma,
-                  const float* dp, const float* save_mean, const float* save_inv, int training, float* cb,
+                  const float* dp, const float* save_mean, const float* save_inv, int training, float* cb, float* cb_lo,
                   float* dgamma, float* dbeta, float* dlam, int B, int C, int HW, int d, hipStream_t st);
-int launch_gate_bwd(const float* mom, const float* bmom, const float* gate, const float* cb, const float* dp,
-                    const float* wq, const float* wk, int ks, float* dyx, float* dwqk_part, int B, int C, int HW,
+int launch_gate_bwd(const float* mom, const float* bmom, const float* gate, const float* cb, const float* cb_lo,
+                    const float* dp, const float* wq, const float* wk, int ks, float* dyx, float* dwqk_part, int B, int C, int HW,
                     int d, hipStream_t st);
 int launch_reduce_rows(const float* in, float* out, int rows, int n, hipStream_t st);
 

@@ -81,7 +81,8 @@ __global__ __launch_bounds__(kWave) void token_pool_kernel(const T* __restrict__
   }
   for (; i < n; ++i) s0 = fmaf(to_f(xb[(size_t)i * C]) - sb[i * S_N + S_MX], sb[i * S_N + S_RX], s0);
   const float s = (s0 + s1) + (s2 + s3);
-  float* m = mom + ((size_t)b * C + c) * M_N;
+  float* m = mom + ((size_t)b * C + c) * M_REC;
+  m[M_PV] = 0.f; m[M_PO] = 0.f;
   // slot 0 holds hw * y so that the shared gate kernels' y = Sx / hw is the LN-affine pooled value
   m[M_SX] = fmaf(wx[c], s, bx[c] * (float)(n - 1));
   m[M_SV] = 0.f; m[M_SO] = 0.f; m[M_SVV] = 0.f; m[M_SVO] = 0.f; m[M_SOO] = 0.f;

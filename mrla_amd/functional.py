@@ -258,17 +258,17 @@ class _LightFn(torch.autograd.Function):
         bmom = torch.empty((b, c, L.BWD_MOMENTS), dtype=torch.float32, device=dev)
         _call("mrla_light_stats_bwd", xc.numel() * xc.element_size() * (3 if oc is not None else 2), _ptr(dout), _ptr(xc), _ptr(oc), _ptr(wv32), _ptr(bmom), b, c, h, w, dt, layout,
                cfg.act, st)
-        small = torch.empty((7, c), dtype=torch.float32, device=dev)      # cb[c,4] | dgamma | dbeta | dlam
-        cb = small[:4].view(c, 4)
+        small = torch.empty((11, c), dtype=torch.float32, device=dev)     # cb[c,4] | dgamma | dbeta | dlam | cb_lo[c,4]
+        cb, cb_lo = small[:4].view(c, 4), small[7:].view(c, 4)
         has_bn = cfg.bn_mode != L.BN_NONE
         L.call("mrla_light_bn_bwd", _ptr(mom), _ptr(bmom), _ptr(gate), _ptr(lam32), _ptr(gamma32) if has_bn else None,
                _ptr(dp32), _ptr(bnbuf[2]) if has_bn else None, _ptr(bnbuf[3]) if has_bn else None, cfg.bn_mode,
-               _ptr(cb), _ptr(small[4]) if has_bn else None, _ptr(small[5]) if has_bn else None,
+               _ptr(cb), _ptr(cb_lo), _ptr(small[4]) if has_bn else None, _ptr(small[5]) if has_bn else None,
                _ptr(small[6]) if lam32 is not None else None, b, c, h * w, d, st)
         dyx = torch.empty((b, c), dtype=torch.float32, device=dev)
         dwqk_part = torch.empty((b, 2 * ks), dtype=torch.float32, device=dev)
-        L.call("mrla_light_gate_bwd", _ptr(mom), _ptr(bmom), _ptr(gate), _ptr(cb), _ptr(dp32), _ptr(wq32), _ptr(wk32), ks,
-               _ptr(dyx), _ptr(dwqk_part), b, c, h * w, d, st)
+        L.call("mrla_light_gate_bwd", _ptr(mom), _ptr(bmom), _ptr(gate), _ptr(cb), _ptr(cb_lo), _ptr(dp32), _ptr(wq32),
+               _ptr(wk32), ks, _ptr(dyx), _ptr(dwqk_part), b, c, h * w, d, st)
         rows = L.load().mrla_light_wgrad_rows(b, c, h, w, dt, layout)
         L.check(min(rows, 0), "mrla_light_wgrad_rows")
         dwv_part = torch.empty((rows, c * 9), dtype=torch.float32, device=dev)
@@ -628,7 +628,7 @@ class _TokenLightFn(torch.autograd.Function):
               _ptr(wv32), _ptr(bmom), b, n, c, dt, st)
         dyx = torch.empty((b, c), dtype=torch.float32, device=dev)
         dwqk_part = torch.empty((b, 2 * ks), dtype=torch.float32, device=dev)
-        L.call("mrla_light_gate_bwd", _ptr(mom), _ptr(bmom), _ptr(gate), None, None, _ptr(wq32), _ptr(wk32), ks, _ptr(dyx),
+        L.call("mrla_light_gate_bwd", _ptr(mom), _ptr(bmom), _ptr(gate), None, None, None, _ptr(wq32), _ptr(wk32), ks, _ptr(dyx),
                _ptr(dwqk_part), b, c, n - 1, d, st)
         dxn = torch.empty((b, n, c), dtype=torch.float32, device=dev)
         part = torch.empty((b, c * L.TOKEN_PARTIALS), dtype=torch.float32, device=dev)

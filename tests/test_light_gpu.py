@@ -280,20 +280,26 @@ def test_wide_nchw_maps_run_through_one_internal_channels_last_conversion(shape)
     assert y.is_contiguous() and y.view(b, c // d, d, h, w).shape[1] == c // d
 
 
-@pytest.mark.parametrize("cl", [False, True], ids=["nchw", "nhwc"])
-def test_closed_form_bn_mrla_statistics_with_offset_inputs(cl):
-    """bn_mrla's batch statistics come in closed form from per-(image, channel) moments of V and o_{t-1}.  With
-    |mean| / sigma = 30 in o (and, through the 3x3 taps, in V) the fp32 raw moments still carry the variance to ~1e-4;
-    the fused tail must match the fp64 oracle at that level (conditioning bound: eps * ratio^2, documented in DESIGN.md)."""
+@pytest.mark.parametrize("cl,ratio", [(False, 30.0), (True, 30.0), (True, 1000.0)], ids=["nchw-30", "nhwc-30", "nhwc-1000"])
+def test_closed_form_bn_mrla_statistics_with_offset_inputs(cl, ratio):
+    """bn_mrla's batch statistics come in closed form from per-(image, channel) moments of V and o_{t-1}.  The NHWC kernels
+    (the production path) take those moments about per-plane pivots, so |mean| / sigma ~ 1e3 in o and, through the 3x3 taps,
+    in V costs nothing; the NCHW kernels accumulate raw fp32 sums (error ~ eps * ratio^2: checked at ratio 30).  The
+    elementwise passes evaluate affine forms of V and o in fp32, which bounds every output at ~ eps * ratio."""
     from oracle import detgen
     b, c, h, w, d = 4, 64, 14, 14, 32
     s = detgen.seed_of("cond")
-    x = np.maximum(detgen.normalish((b, c, h, w), s) + 30.0, 0)
-    o = detgen.normalish((b, c, h, w), s + 1) - 30.0
+    x = np.maximum(detgen.normalish((b, c, h, w), s) + ratio, 0)
+    o = detgen.normalish((b, c, h, w), s + 1) - ratio
     gup = detgen.normalish((b, c, h, w), s + 2)
     P = cases.block_params(c, 11)
     got = run_light(x, o, P, d, "train", None, 0.0, gup, cl=cl)
     out, cache, g = oracle_light(x, o, P, d, "train", None, 0.0, gup)
-    assert relmax(got["rv"], cache["bn"]["new_rv"]) < 2e-3
-    assert relmax(got["out"] - x, out - x) < 2e-3         # the normalised branch (x itself is ~30)
-    assert relmax(got["dx"], g["dx"]) < 5e-3
+    tol = 2e-3 if not cl else max(2e-4, 1.5e-6 * ratio)
+    assert relmax(got["rv"], cache["bn"]["new_rv"]) < tol
+    assert relmax(got["out"] - x, out - x) < tol          # the normalised branch (x itself is ~ratio)
+    assert relmax(got["dx"], g["dx"]) < 3 * tol
+    assert relmax(got["do"], g["do_prev"]) < 3 * tol
+    for ours, theirs in (("mrla.mrla.Wv.weight", "dwv"), ("mrla.lambda_t", "dlam"), ("bn_mrla.weight", "dgamma"),
+                         ("bn_mrla.bias", "dbeta")):
+        assert relmax(got["grad/" + ours].ravel(), np.asarray(g[theirs]).ravel()) < 10 * tol, ours

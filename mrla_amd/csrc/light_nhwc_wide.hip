@@ -131,9 +131,12 @@ __global__ __launch_bounds__(kMaxStrips * kWave) void light_stats_bwd_wide(
       // dOut (and o) are zero beyond the image, so columns of a ragged last strip drop out of every sum by themselves
       auto step = [&](int r, RawRow<kS + 2>& XA, RawRow<kS + 2>& XB, RawRow<kS + 2>& XC) {
         rows_landed();
-        row_read<T, kS + 2>(bufX, lane, XC);
-        row_read<T, kS>(bufG, lane, gv);
-        if (HAS_O) row_read<T, kS>(bufO, lane, ov);
+        row_read_issue<T, kS + 2>(bufX, lane, XC);
+        row_read_issue<T, kS>(bufG, lane, gv);
+        if (HAS_O) row_read_issue<T, kS>(bufO, lane, ov);
+        row_read_fence(XC, true);
+        row_read_fence(gv, false);
+        if (HAS_O) row_read_fence(ov, false);
         row_fetch<T, kS + 2>(ax, xi, r + 2, H, rowelems, bufX);
         row_fetch<T, kS>(ag, gi, r + 1, H, rowelems, bufG);
         if (HAS_O) row_fetch<T, kS>(ag, oi, r + 1, H, rowelems, bufO);
@@ -202,8 +205,10 @@ __global__ __launch_bounds__(kMaxStrips * kWave) void light_stats_fwd_wide(
       if (HAS_O) row_fetch<T, kS>(ao, oi, 0, H, rowelems, bufO);
       auto step = [&](int r, RawRow<kS + 2>& XA, RawRow<kS + 2>& XB, RawRow<kS + 2>& XC) {
         rows_landed();
-        row_read<T, kS + 2>(bufX, lane, XC);
-        if (HAS_O) row_read<T, kS>(bufO, lane, ov);
+        row_read_issue<T, kS + 2>(bufX, lane, XC);
+        if (HAS_O) row_read_issue<T, kS>(bufO, lane, ov);
+        row_read_fence(XC, true);
+        if (HAS_O) row_read_fence(ov, false);
         row_fetch<T, kS + 2>(ax, xi, r + 2, H, rowelems, bufX);
         if (HAS_O) row_fetch<T, kS>(ao, oi, r + 1, H, rowelems, bufO);
         float vrow[kS];
@@ -318,10 +323,16 @@ __global__ __launch_bounds__(kMaxStrips * kWave) void light_stats_fwd_fused_wide
       form_x_row<T, AFF>(praw, oraw, asc, shj, xb);
       store_owned(xo, 0, xb);
       auto step = [&](int r, float (&XA)[kS + 2], float (&XB)[kS + 2], float (&XC)[kS + 2]) {
-        rows_landed();
-        row_read<T, kS + 2>(bufP, lane, praw);               // row r+1
-        row_read<T, kS + 2>(obuf(r + 1), lane, oraw);
-        row_read<T, kS>(obuf(r), lane, ov, 1);               // owned pixels of row r
+        // step r-1 stored x_t row r (always: r <= H-1) and, for MRLA-base, V row r-1 after its fetches
+        if (r == 0) rows_landed();
+        else if (vo) rows_landed_keep<2 * RowIO<T, kS>::NL>();
+        else rows_landed_keep<RowIO<T, kS>::NL>();
+        row_read_issue<T, kS + 2>(bufP, lane, praw);         // row r+1
+        row_read_issue<T, kS + 2>(obuf(r + 1), lane, oraw);
+        row_read_issue<T, kS>(obuf(r), lane, ov, 1);         // owned pixels of row r
+        row_read_fence(praw, true);
+        row_read_fence(oraw, false);
+        row_read_fence(ov, false);
         row_fetch<T, kS + 2>(ax, pi, r + 2, H, rowelems, bufP);
         row_fetch<T, kS + 2>(ax, oi, r + 2, H, rowelems, obuf(r));
         if (r + 1 < H) {
@@ -407,9 +418,12 @@ __global__ __launch_bounds__(kMaxStrips * kWave) void light_apply_fwd_wide(
       row_fetch<T, kS + 2>(ax, xi, 1, H, rowelems, bufX);
       if (HAS_O) row_fetch<T, kS>(ao, oi, 0, H, rowelems, bufO);
       auto step = [&](int r, RawRow<kS + 2>& XA, RawRow<kS + 2>& XB, RawRow<kS + 2>& XC) {
-        rows_landed();
-        row_read<T, kS + 2>(bufX, lane, XC);
-        if (HAS_O) row_read<T, kS>(bufO, lane, ov);
+        // the previous step's output row (its newest memory instructions) may stay in flight
+        if (r == 0) rows_landed(); else rows_landed_keep<RowIO<T, kS>::NL>();
+        row_read_issue<T, kS + 2>(bufX, lane, XC);
+        if (HAS_O) row_read_issue<T, kS>(bufO, lane, ov);
+        row_read_fence(XC, true);
+        if (HAS_O) row_read_fence(ov, false);
         row_fetch<T, kS + 2>(ax, xi, r + 2, H, rowelems, bufX);
         if (HAS_O) row_fetch<T, kS>(ao, oi, r + 1, H, rowelems, bufO);
         float y[kS];
@@ -485,10 +499,13 @@ __global__ __launch_bounds__(kMaxStrips * kWave) void light_apply_fwd_pre_wide(
       row_fetch<T, kS + 2>(ax, oi, 1, H, rowelems, obuf(1));
       form_x_row<T, AFF>(praw, oraw, asc, shj, xb);
       auto step = [&](int r, float (&XA)[kS + 2], float (&XB)[kS + 2], float (&XC)[kS + 2]) {
-        rows_landed();
-        row_read<T, kS + 2>(bufP, lane, praw);
-        row_read<T, kS + 2>(obuf(r + 1), lane, oraw);
-        row_read<T, kS>(obuf(r), lane, ov, 1);
+        if (r == 0) rows_landed(); else rows_landed_keep<RowIO<T, kS>::NL>();
+        row_read_issue<T, kS + 2>(bufP, lane, praw);
+        row_read_issue<T, kS + 2>(obuf(r + 1), lane, oraw);
+        row_read_issue<T, kS>(obuf(r), lane, ov, 1);
+        row_read_fence(praw, true);
+        row_read_fence(oraw, false);
+        row_read_fence(ov, false);
         row_fetch<T, kS + 2>(ax, pi, r + 2, H, rowelems, bufP);
         row_fetch<T, kS + 2>(ax, oi, r + 2, H, rowelems, obuf(r));
         if (r + 1 < H) {
@@ -585,11 +602,16 @@ __global__ __launch_bounds__(kBwdWaves * kWave) void light_apply_bwd_wide(
       if (HAS_O) row_fetch<T, kS + 2>(ag, oi, 0, H, rowelems, bufO);
       auto step = [&](int rr, RawRow<kS + 4>& XA, RawRow<kS + 4>& XB, RawRow<kS + 4>& XC, float (&UA)[kS + 2],
                       float (&UB)[kS + 2], float (&UC)[kS + 2], float (&DP)[kS], float (&DC)[kS]) {
-        rows_landed();
-        row_read<T, kS + 4>(bufX, lane, XC);
-        row_read<T, kS + 2>(gbuf(rr), lane, gv);
-        if (HAS_O) row_read<T, kS + 2>(bufO, lane, ov);
-        if (rr >= 1) row_read<T, kS>(gbuf(rr + 1), lane, gp, 1);      // row rr-1, owned pixels
+        // steps rr-1 >= 1 stored two rows (dx and do) after their fetches; those may stay in flight
+        if (rr <= 1 || !HAS_O) rows_landed(); else rows_landed_keep<2 * RowIO<T, kS>::NL>();
+        row_read_issue<T, kS + 4>(bufX, lane, XC);
+        row_read_issue<T, kS + 2>(gbuf(rr), lane, gv);
+        if (HAS_O) row_read_issue<T, kS + 2>(bufO, lane, ov);
+        if (rr >= 1) row_read_issue<T, kS>(gbuf(rr + 1), lane, gp, 1);      // row rr-1, owned pixels
+        row_read_fence(XC, true);
+        row_read_fence(gv, false);
+        if (HAS_O) row_read_fence(ov, false);
+        row_read_fence(gp, false);
         row_fetch<T, kS + 4>(ax, xi, rr + 2, H, rowelems, bufX);
         row_fetch<T, kS + 2>(ag, gi, rr + 1, H, rowelems, gbuf(rr + 1));
         if (HAS_O) row_fetch<T, kS + 2>(ag, oi, rr + 1, H, rowelems, bufO);

@@ -67,6 +67,13 @@ __device__ __forceinline__ void row_fetch(const RowIO<T, NPX>& a, const T* img, 
 
 // All DMA rows issued so far have landed (also orders them against the LDS reads below).
 __device__ __forceinline__ void rows_landed() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+// ... except that the NEWEST `KEEP` vector-memory instructions may still be in flight: the row stores a step issued after
+// its fetches.  (gfx9-family vmcnt counts loads and stores in issue order, which is also what the compiler relies on.)
+template <int KEEP>
+__device__ __forceinline__ void rows_landed_keep() {
+  static_assert(KEEP >= 0 && KEEP < 16, "vmcnt immediate");
+  asm volatile("s_waitcnt vmcnt(%0)" ::"n"(KEEP) : "memory");
+}
 
 __device__ __forceinline__ unsigned lds_addr_of(const void* p) { return (unsigned)(size_t)((lds_cchar_ptr)p); }
 
@@ -119,6 +126,52 @@ __device__ __forceinline__ void row_read<bf16_t, 11>(const bf16_t* buf, int lane
                : "+v"(o.v[0]), "+v"(o.v[1]), "+v"(o.v[2]), "+v"(o.v[3]), "+v"(o.v[4]), "+v"(o.v[5]), "+v"(o.v[6]),
                  "+v"(o.v[7]), "+v"(o.v[8]), "+v"(o.v[9]), "+v"(o.v[10])
                : [a] "v"(a) : "memory");
+}
+
+// Split form for several rows per step: issue the reads of all rows first, then fence them -- the first fence waits for
+// every outstanding LDS read, the others only tie their registers to it (one LDS latency per step instead of one per row).
+// For other element types the issue IS the complete (waited-for) read and the fences are no-ops.
+template <typename T, int NPX>
+__device__ __forceinline__ void row_read_issue(const T* buf, int lane, RawRow<NPX>& out, int px0 = 0) {
+  row_read<T, NPX>(buf, lane, out, px0);
+}
+template <int NPX>
+__device__ __forceinline__ void row_read_fence(RawRow<NPX>&, bool) {}
+template <>
+__device__ __forceinline__ void row_read_issue<bf16_t, 7>(const bf16_t* buf, int lane, RawRow<7>& o, int px0) {
+  const unsigned a = lds_addr_of(buf) + (px0 * kWave + lane) * 2;
+  asm volatile(MRLA_D16(0, 0) MRLA_D16(1, 128) MRLA_D16(2, 256) MRLA_D16(3, 384) MRLA_D16(4, 512) MRLA_D16(5, 640) MRLA_D16(6, 768) ""
+               : "+v"(o.v[0]), "+v"(o.v[1]), "+v"(o.v[2]), "+v"(o.v[3]), "+v"(o.v[4]), "+v"(o.v[5]), "+v"(o.v[6])
+               : [a] "v"(a) : "memory");
+}
+template <>
+__device__ __forceinline__ void row_read_fence<7>(RawRow<7>& o, bool wait) {
+  if (wait) asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(o.v[0]), "+v"(o.v[1]), "+v"(o.v[2]), "+v"(o.v[3]), "+v"(o.v[4]), "+v"(o.v[5]), "+v"(o.v[6]) : : "memory");
+  else      asm volatile("" : "+v"(o.v[0]), "+v"(o.v[1]), "+v"(o.v[2]), "+v"(o.v[3]), "+v"(o.v[4]), "+v"(o.v[5]), "+v"(o.v[6]) : : "memory");
+}
+template <>
+__device__ __forceinline__ void row_read_issue<bf16_t, 9>(const bf16_t* buf, int lane, RawRow<9>& o, int px0) {
+  const unsigned a = lds_addr_of(buf) + (px0 * kWave + lane) * 2;
+  asm volatile(MRLA_D16(0, 0) MRLA_D16(1, 128) MRLA_D16(2, 256) MRLA_D16(3, 384) MRLA_D16(4, 512) MRLA_D16(5, 640) MRLA_D16(6, 768) MRLA_D16(7, 896) MRLA_D16(8, 1024) ""
+               : "+v"(o.v[0]), "+v"(o.v[1]), "+v"(o.v[2]), "+v"(o.v[3]), "+v"(o.v[4]), "+v"(o.v[5]), "+v"(o.v[6]), "+v"(o.v[7]), "+v"(o.v[8])
+               : [a] "v"(a) : "memory");
+}
+template <>
+__device__ __forceinline__ void row_read_fence<9>(RawRow<9>& o, bool wait) {
+  if (wait) asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(o.v[0]), "+v"(o.v[1]), "+v"(o.v[2]), "+v"(o.v[3]), "+v"(o.v[4]), "+v"(o.v[5]), "+v"(o.v[6]), "+v"(o.v[7]), "+v"(o.v[8]) : : "memory");
+  else      asm volatile("" : "+v"(o.v[0]), "+v"(o.v[1]), "+v"(o.v[2]), "+v"(o.v[3]), "+v"(o.v[4]), "+v"(o.v[5]), "+v"(o.v[6]), "+v"(o.v[7]), "+v"(o.v[8]) : : "memory");
+}
+template <>
+__device__ __forceinline__ void row_read_issue<bf16_t, 11>(const bf16_t* buf, int lane, RawRow<11>& o, int px0) {
+  const unsigned a = lds_addr_of(buf) + (px0 * kWave + lane) * 2;
+  asm volatile(MRLA_D16(0, 0) MRLA_D16(1, 128) MRLA_D16(2, 256) MRLA_D16(3, 384) MRLA_D16(4, 512) MRLA_D16(5, 640) MRLA_D16(6, 768) MRLA_D16(7, 896) MRLA_D16(8, 1024) MRLA_D16(9, 1152) MRLA_D16(10, 1280) ""
+               : "+v"(o.v[0]), "+v"(o.v[1]), "+v"(o.v[2]), "+v"(o.v[3]), "+v"(o.v[4]), "+v"(o.v[5]), "+v"(o.v[6]), "+v"(o.v[7]), "+v"(o.v[8]), "+v"(o.v[9]), "+v"(o.v[10])
+               : [a] "v"(a) : "memory");
+}
+template <>
+__device__ __forceinline__ void row_read_fence<11>(RawRow<11>& o, bool wait) {
+  if (wait) asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(o.v[0]), "+v"(o.v[1]), "+v"(o.v[2]), "+v"(o.v[3]), "+v"(o.v[4]), "+v"(o.v[5]), "+v"(o.v[6]), "+v"(o.v[7]), "+v"(o.v[8]), "+v"(o.v[9]), "+v"(o.v[10]) : : "memory");
+  else      asm volatile("" : "+v"(o.v[0]), "+v"(o.v[1]), "+v"(o.v[2]), "+v"(o.v[3]), "+v"(o.v[4]), "+v"(o.v[5]), "+v"(o.v[6]), "+v"(o.v[7]), "+v"(o.v[8]), "+v"(o.v[9]), "+v"(o.v[10]) : : "memory");
 }
 #undef MRLA_D16
 

@@ -6,10 +6,15 @@ ImageNet-shaped data (BASELINE.json metric / configs[1]; configs[2] for --gpus N
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
         bench.py --gpus N --steps K --warmup W
 
-A "step" = forward + loss + backward + SGD update on one synthetic batch already resident in HBM.  Rank 0 prints
-ONE JSON line.  Besides the contract keys it carries
+A "step" = forward + loss + backward + SGD update on one synthetic batch already resident in HBM.  On a single GPU the
+timed steps replay the whole step from one HIP graph (`config.launch`; `--graph 0` times PyTorch's kernel-by-kernel
+launches instead, and under torch.distributed that is the default).  Rank 0 prints ONE JSON line.  Besides the contract
+keys it carries
   roofline     -- HBM roofline of the dominant MRLA kernel (mrla_light_apply_bwd), timed live with HIP events on
-                  the launch stream over the timed region; algorithmic bytes = 5*N*sizeof(bf16) per launch;
+                  the launch stream over `steps` steps launched kernel by kernel (the timed region itself when it is not
+                  graph-replayed, else the same steps run once more right after it: events cannot be read out of a
+                  replayed graph; `eager_launch_ms_per_step` is that region's step time); algorithmic bytes =
+                  5*N*sizeof(bf16) per launch;
   cpu_baseline -- the eager CPU restatement (oracle/eager_models.py, kind "port") forward on the host cores,
                   bounded sample, rank 0 at N=1 only;
   eager_rocm   -- the same restatement run eager on this GPU (the north-star's ">=4x" denominator), N=1 only.
@@ -46,7 +51,9 @@ def parse():
     ap.add_argument("--channels-last", type=int, default=-1,
                     help="1 / 0: force torch.channels_last on / off; -1: the model class default (on for resnet*_mrlal)")
     ap.add_argument("--benchmark", type=int, default=0, help="torch.backends.cudnn.benchmark (resnet/train.py:247 sets it)")
-    ap.add_argument("--graph", type=int, default=0, help="1: replay the whole step (fwd+bwd+SGD) from one HIP graph")
+    ap.add_argument("--graph", type=int, default=-1,
+                    help="1: the timed steps replay the whole step (fwd+bwd+SGD) from one HIP graph; 0: launched kernel by "
+                         "kernel; -1 (default): 1 on a single GPU, 0 under torch.distributed")
     ap.add_argument("--backend", default=os.environ.get("MRLA_DIST_BACKEND", "nccl"))
     return ap.parse_args()
 
@@ -210,22 +217,31 @@ def main():
     y = torch.randint(0, 1000, (args.batch,), device="cuda", generator=gy)
     step = make_step(net, sgd(net.parameters()), x, y)
 
-    # warm-up without the timer, then the timed region with HIP-event timing of the dominant kernel
+    # warm-up without the timer
     for _ in range(args.warmup):
         step()
-    if args.graph:
-        # the whole training step is launch-order static (no host sync inside): capture it once, replay it
-        torch.cuda.synchronize()
-        side = torch.cuda.Stream()
-        side.wait_stream(torch.cuda.current_stream())
-        with torch.cuda.stream(side):
-            for _ in range(2):
-                step()
-        torch.cuda.current_stream().wait_stream(side)
-        graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(graph):
-            step()
-        eager_step, step = step, graph.replay
+    eager_step = step
+    use_graph = args.graph == 1 or (args.graph < 0 and not dist_on)
+    launch = "kernel by kernel (PyTorch eager launches)"
+    if use_graph:
+        # the whole training step is launch-order static (no host sync inside): capture it once into a HIP graph and
+        # replay it -- the same kernels on the same buffers, minus ~1 ms/step of launch gaps
+        try:
+            torch.cuda.synchronize()
+            side = torch.cuda.Stream()
+            side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(side):
+                for _ in range(2):
+                    eager_step()
+            torch.cuda.current_stream().wait_stream(side)
+            graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(graph):
+                eager_step()
+            step = graph.replay
+            launch = "one HIP graph per step (captured fwd+loss+bwd+SGD), replayed"
+        except Exception as e:                        # capture not possible here: time the eager launches instead
+            print(f"warning: HIP graph capture failed ({type(e).__name__}: {e}); timing eager launches", file=sys.stderr)
+            step, use_graph = eager_step, False
     timer = Fm.KernelTimer(["mrla_light_apply_bwd", "mrla_light_stats_bwd", "mrla_light_apply_fwd",
                             "mrla_light_stats_fwd", "mrla_base_attend_fwd", "mrla_base_tail_fwd",
                             "mrla_base_tail_stats_bwd", "mrla_base_attend_bwd", "mrla_base_value_bwd",
@@ -233,9 +249,19 @@ def main():
                             "mrla_token_apply_fwd", "mrla_token_stats_bwd", "mrla_token_apply_bwd", "mrla_token_ln_bwd",
                             "mrla_light_stats_fwd_fused", "mrla_light_pool_fused", "mrla_light_apply_fwd_fused", "mrla_bn_plane_moments", "mrla_bn_act_fwd",
                             "mrla_bn_plane_dmoments", "mrla_bn_act_bwd"])
-    Fm.TIMER = timer
-    dt = timed(step, args.steps, 0, dist_on)
-    Fm.TIMER = None
+    # the timed region: exactly `steps` steps between barrier + synchronize
+    if use_graph:
+        dt = timed(step, args.steps, 0, dist_on)
+        # per-kernel HIP events cannot be read out of a replayed graph: the same `steps` steps once more, launched kernel by
+        # kernel with the events on the launch stream (this second region feeds `roofline` / `mrla_kernels` only)
+        Fm.TIMER = timer
+        dt_eager = timed(eager_step, args.steps, 0, dist_on)
+        Fm.TIMER = None
+    else:
+        Fm.TIMER = timer
+        dt = timed(step, args.steps, 0, dist_on)
+        Fm.TIMER = None
+        dt_eager = dt
     ips = world * args.batch * args.steps / dt
 
     if rank == 0:
@@ -258,9 +284,10 @@ def main():
                "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
                "config": {"workload": f"{args.arch} fwd+bwd+SGD, {args.batch} images/GPU of 3x224x224, bf16 autocast, "
                                       f"fp32 master weights, drop_path {args.drop_path}",
-                          "global_batch": world * args.batch, "parallelism": f"dp{world}",
+                          "global_batch": world * args.batch, "parallelism": f"dp{world}", "launch": launch,
                           "path": "eager restatement" if args.eager else
                                   f"mrla_amd (HIP MRLA tails incl. shortcut add+ReLU, HIP BatchNorm+ReLU, stock convolutions; {layout})"},
+               "eager_launch_ms_per_step": round(1e3 * dt_eager / args.steps, 3),
                "roofline": roofline,
                "mrla_kernels": {k: {"launches": v["launches"], "ms_per_step": round(v["ms"] / args.steps, 3),
                                     "GBps": round(v["bytes"] / (v["ms"] * 1e-3) / 1e9, 1)} for k, v in ks.items()}}

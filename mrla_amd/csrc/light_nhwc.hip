@@ -11,8 +11,6 @@
 //     workgroup through LDS, in a fixed order (bitwise reproducible).
 // A workgroup = (image group, 64-channel chunk); its waves = column strips.  ResNet stage widths 56/28/14/7 give
 // 8/4/2/1 strips of exactly 7 columns.
-#include <cstdlib>
-
 #include "light_nhwc.h"
 
 namespace mrla {
@@ -353,7 +351,7 @@ int launch_light_stats_fwd_nhwc(const void* x, const void* o, const float* wv, f
                                 const float* psc, const float* psh, void* vout, int B, int C, int H, int W, int dtype,
                                 int act, hipStream_t st) {
   const NhwcLaunch L = nhwc_launch(B, C, W, M_N, dtype);
-  if (L.wide && !getenv("MRLA_NHWC_OLD"))
+  if (L.wide)          // C % 64 == 0: the LDS-DMA row pipeline (light_nhwc_wide.hip)
     return launch_light_stats_fwd_wide(x, o, wv, mom, xout, psc, psh, vout, B, C, H, W, dtype, act, st);
 #define CALL_W(T, A, O, F, WD)                                                                                       \
   {                                                                                                                  \
@@ -361,7 +359,7 @@ int launch_light_stats_fwd_nhwc(const void* x, const void* o, const float* wv, f
     hipLaunchKernelGGL((light_stats_fwd_nhwc<T, A, O, F, WD>), L.grid, L.block, L.lds, st, (const T*)x, (const T*)o,  \
                        wv, mom, (T*)xout, psc, psh, (T*)vout, B, C, H, W, L.BG);                                     \
   }
-#define CALL_F(T, A, O, F) { if (L.wide) CALL_W(T, A, O, F, true) else CALL_W(T, A, O, F, false) }
+#define CALL_F(T, A, O, F) CALL_W(T, A, O, F, false)
 #define CALL(T, A, O)                                                        \
   {                                                                          \
     if (xout) { if (O) CALL_F(T, A, true, true) else return MRLA_EINVAL; }   \
@@ -378,7 +376,7 @@ int launch_light_apply_fwd_nhwc(const void* x, const void* o, const float* wv, c
                                 const float* sh, const float* lam, const float* dp, void* out, int B, int C, int H,
                                 int W, int d, int res, int dtype, int act, hipStream_t st) {
   const NhwcLaunch L = nhwc_launch(B, C, W, 0, dtype);
-  if (L.wide && !getenv("MRLA_NHWC_OLD"))
+  if (L.wide)          // C % 64 == 0: the LDS-DMA row pipeline (light_nhwc_wide.hip)
     return launch_light_apply_fwd_wide(x, o, wv, gate, sc, sh, lam, dp, out, B, C, H, W, d, res, dtype, act, st);
 #define CALL_W(T, A, O, WD)                                                                                          \
   {                                                                                                                  \
@@ -386,7 +384,7 @@ int launch_light_apply_fwd_nhwc(const void* x, const void* o, const float* wv, c
     hipLaunchKernelGGL((light_apply_fwd_nhwc<T, A, O, WD>), L.grid, L.block, L.lds, st, (const T*)x, (const T*)o, wv, \
                        gate, sc, sh, lam, dp, (T*)out, B, C, H, W, L.BG, d, res);                                    \
   }
-#define CALL(T, A, O) { if (L.wide) CALL_W(T, A, O, true) else CALL_W(T, A, O, false) }
+#define CALL(T, A, O) CALL_W(T, A, O, false)
   MRLA_DISPATCH_T_N(dtype, act, o != nullptr, CALL)
 #undef CALL
 #undef CALL_W
@@ -398,7 +396,7 @@ int launch_light_apply_fwd_pre_nhwc(const void* pre, const void* o, const float*
                                     const float* dp, void* out, int B, int C, int H, int W, int d, int res, int dtype,
                                     hipStream_t st) {
   const NhwcLaunch L = nhwc_launch(B, C, W, 0, dtype);
-  if (L.wide && !getenv("MRLA_NHWC_OLD"))
+  if (L.wide)          // C % 64 == 0: the LDS-DMA row pipeline (light_nhwc_wide.hip)
     return launch_light_apply_fwd_pre_wide(pre, o, psc, psh, wv, gate, sc, sh, lam, dp, out, B, C, H, W, d, res, dtype, st);
 #define CALL_W(T, WD)                                                                                                 \
   {                                                                                                                   \
@@ -406,7 +404,7 @@ int launch_light_apply_fwd_pre_nhwc(const void* pre, const void* o, const float*
     hipLaunchKernelGGL((light_apply_fwd_pre_nhwc<T, WD>), L.grid, L.block, L.lds, st, (const T*)pre, (const T*)o, psc, \
                        psh, wv, gate, sc, sh, lam, dp, (T*)out, B, C, H, W, L.BG, d, res);                            \
   }
-#define CALL(T) { if (L.wide) CALL_W(T, true) else CALL_W(T, false) }
+#define CALL(T) CALL_W(T, false)
   switch (dtype) {
     case MRLA_F32:  CALL(float) break;
     case MRLA_BF16: CALL(bf16_t) break;
@@ -421,14 +419,14 @@ int launch_light_apply_fwd_pre_nhwc(const void* pre, const void* o, const float*
 int launch_light_stats_bwd_nhwc(const void* dout, const void* x, const void* o, const float* wv, float* bmom, int B,
                                 int C, int H, int W, int dtype, int act, hipStream_t st) {
   const NhwcLaunch L = nhwc_launch(B, C, W, D_N, dtype);
-  if (L.wide && !getenv("MRLA_NHWC_OLD")) return launch_light_stats_bwd_wide(dout, x, o, wv, bmom, B, C, H, W, dtype, act, st);
+  if (L.wide) return launch_light_stats_bwd_wide(dout, x, o, wv, bmom, B, C, H, W, dtype, act, st);
 #define CALL_W(T, A, O, WD)                                                                                          \
   {                                                                                                                  \
     if (set_lds_n(light_stats_bwd_nhwc<T, A, O, WD>, L.lds) != hipSuccess) return MRLA_EHIP;                           \
     hipLaunchKernelGGL((light_stats_bwd_nhwc<T, A, O, WD>), L.grid, L.block, L.lds, st, (const T*)dout, (const T*)x,  \
                        (const T*)o, wv, bmom, B, C, H, W, L.BG);                                                     \
   }
-#define CALL(T, A, O) { if (L.wide) CALL_W(T, A, O, true) else CALL_W(T, A, O, false) }
+#define CALL(T, A, O) CALL_W(T, A, O, false)
   MRLA_DISPATCH_T_N(dtype, act, o != nullptr, CALL)
 #undef CALL
 #undef CALL_W

@@ -2,8 +2,6 @@
 // A translation unit of its own: this kernel is register-bound, and pairing its FMAs into v_pk_fma_f32 (the SLP
 // vectoriser) costs it ~40 VGPRs and a move per pair, so the Makefile compiles this file with -fno-slp-vectorize;
 // the lighter passes in light_nhwc.hip gain from the pairing and keep it.
-#include <cstdlib>
-
 #include "light_nhwc.h"
 
 namespace mrla {
@@ -178,7 +176,7 @@ int launch_light_apply_bwd_nhwc(const void* dout, const void* x, const void* o, 
                                 void* dprev, float* dwv_part, int B, int C, int H, int W, int d, int res, int relu,
                                 int dtype, int act, hipStream_t st) {
   NhwcLaunch L = nhwc_launch(B, C, W, 9, dtype);
-  if (L.wide && !getenv("MRLA_NHWC_OLD"))
+  if (L.wide)          // C % 64 == 0: the LDS-DMA row pipeline (light_nhwc_wide.hip)
     return launch_light_apply_bwd_wide(dout, x, o, wv, gate, cb, lam, dp, dyx, dx, dprev, dwv_part, B, C, H, W, d, res,
                                        relu, dtype, act, st);
   L.BG = nhwc_images_per_group(B, C, W);                  // = the rows mrla_light_wgrad_rows() promised
@@ -190,7 +188,7 @@ int launch_light_apply_bwd_nhwc(const void* dout, const void* x, const void* o, 
                        (const T*)x, (const T*)o, wv, gate, cb, lam, dp, dyx, (T*)dx, (T*)dprev, dwv_part, B, C, H, W, \
                        L.BG, d, res);                                                                                \
   }
-#define CALL_R(T, A, O, R) { if (L.wide) CALL_W(T, A, O, R, true) else CALL_W(T, A, O, R, false) }
+#define CALL_R(T, A, O, R) CALL_W(T, A, O, R, false)
 #define CALL(T, A, O)                                                                        \
   {                                                                                          \
     if (relu) { if (O && !(A)) CALL_R(T, false, true, true) else return MRLA_EINVAL; }       \

@@ -248,7 +248,8 @@ def main():
                             "mrla_base_pool_value_fwd", "mrla_base_dv_combine", "mrla_base_value_bwd_dv",
                             "mrla_token_apply_fwd", "mrla_token_stats_bwd", "mrla_token_apply_bwd", "mrla_token_ln_bwd",
                             "mrla_light_stats_fwd_fused", "mrla_light_pool_fused", "mrla_light_apply_fwd_fused", "mrla_bn_plane_moments", "mrla_bn_act_fwd",
-                            "mrla_bn_plane_dmoments", "mrla_bn_act_bwd"])
+                            "mrla_bn_plane_dmoments", "mrla_bn_act_bwd",
+                            "mrla_conv1x1_fwd", "mrla_conv1x1_bwd_data"])
     # the timed region: exactly `steps` steps between barrier + synchronize
     if use_graph:
         dt = timed(step, args.steps, 0, dist_on)
@@ -266,7 +267,7 @@ def main():
 
     if rank == 0:
         ks = timer.summary()
-        path_k = {k: v for k, v in ks.items() if not k.startswith("mrla_bn_")}   # the MRLA path proper
+        path_k = {k: v for k, v in ks.items() if not k.startswith(("mrla_bn_", "mrla_conv1x1"))}   # the MRLA path proper
         dom_name = max(path_k, key=lambda k: path_k[k]["ms"]) if path_k else None  # its kernel with the most time
         dom = ks.get(dom_name)
         roofline = None

@@ -41,16 +41,17 @@ class KernelTimer:
 TIMER = None      # set to a KernelTimer to time launches
 
 
-def _call(name, nbytes, *args):
+def _call(name, nbytes, *args, entry=None):
+    """Launch the C-ABI entry point `entry` (default: `name`); `name` is the label the optional timer records it under."""
     t = TIMER
     if t is not None and name in t.names:
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
-        L.call(name, *args)
+        L.call(entry or name, *args)
         e1.record()
         t.records.append((name, nbytes, e0, e1))
     else:
-        L.call(name, *args)
+        L.call(entry or name, *args)
 
 
 def _ptr(t):
@@ -783,10 +784,22 @@ class _Conv1x1Fn(torch.autograd.Function):
     def backward(ctx, dy, _dpart=None):
         x, w = ctx.saved_tensors
         dy = dy.contiguous(memory_format=_CL)
-        gx, gw, _ = torch.ops.aten.convolution_backward(dy, x, w.view(w.shape[0], w.shape[1], 1, 1), None, (1, 1), (0, 0),
-                                                       (1, 1), False, (0, 0), 1,
-                                                       [ctx.needs_input_grad[0], ctx.needs_input_grad[1], False])
-        return gx, gw.view(w.shape) if gw is not None else None, None
+        n, k = w.shape
+        b, _, h, wd = x.shape
+        m = b * h * wd
+        need_x, need_w = ctx.needs_input_grad[0], ctx.needs_input_grad[1]
+        gx = None
+        # the input gradient is the same GEMM with the transposed weight: dX[m, k] = sum_n dY[m, n] * W^T[k, n]
+        # (no memset of dX, as MIOpen's backward-data solver needs); shapes the kernel does not take stay on MIOpen
+        if need_x and dy.dtype == x.dtype and L.load().mrla_conv1x1_rows(m, n, k, _DT[x.dtype]) > 0:
+            gx = torch.empty_like(x)
+            wt = w.t().contiguous()
+            _call("mrla_conv1x1_bwd_data", (dy.numel() + gx.numel()) * x.element_size(), _ptr(dy), _ptr(wt), _ptr(gx), None,
+                  m, n, k, _DT[x.dtype], _stream(), entry="mrla_conv1x1_fwd")
+            need_x = False
+        gx2, gw, _ = torch.ops.aten.convolution_backward(dy, x, w.view(n, k, 1, 1), None, (1, 1), (0, 0), (1, 1), False, (0, 0),
+                                                        1, [need_x, need_w, False])
+        return (gx if gx is not None else gx2), (gw.view(w.shape) if gw is not None else None), None
 
 
 def conv1x1_applies(conv, x):

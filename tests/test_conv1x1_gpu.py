@@ -100,3 +100,26 @@ def test_conv_bn_act_composite_matches_stock_modules(shape):
     for got, want, tol in ((bn.weight.grad, bn_r.weight.grad, 2e-2), (bn.bias.grad, bn_r.bias.grad, 2e-2),
                            (conv.weight.grad, conv_r.weight.grad, 3e-2), (xt.grad.float(), xr.grad, 3e-2)):
         assert ((got.float() - want).norm() / want.norm()).item() < tol
+
+
+@pytest.mark.parametrize("shape", [(4, 14, 14, 256, 64), (4, 14, 14, 64, 256), (2, 28, 28, 64, 64), (3, 7, 7, 128, 512)],
+                         ids=lambda s: "x".join(map(str, s)))
+def test_input_gradient_is_the_gemm_with_the_transposed_weight(shape):
+    """dX = dY * W (resnet backward of conv1 / conv3) through mrla_conv1x1_fwd on W^T where the kernel takes the shape
+    (c_out in {64, 128, 256}), else through the stock backward: both must equal a float64 product rounded once to bf16."""
+    from mrla_amd import _lib as L, functional as Fm
+    b, h, w, k, n = shape
+    m = b * h * w
+    x, wt = _operands(b, h, w, k, n, salt=2)
+    dy = bf16_round(detgen.normalish((b, h, w, n), detgen.seed_of(f"conv1x1/dy/{k}/{n}")))
+    xt = torch.from_numpy(x).cuda().bfloat16().permute(0, 3, 1, 2).requires_grad_(True)
+    wtt = torch.from_numpy(wt).cuda().bfloat16().requires_grad_(True)
+    y, _ = Fm._Conv1x1Fn.apply(xt, wtt, False)
+    y.backward(torch.from_numpy(dy).cuda().bfloat16().permute(0, 3, 1, 2))
+    own = L.load().mrla_conv1x1_rows(m, n, k, L.BF16) > 0
+    assert own == (n in (64, 128, 256))
+    want_dx = dy.reshape(m, n).astype(np.float64) @ wt.astype(np.float64)
+    got_dx = xt.grad.permute(0, 2, 3, 1).reshape(m, k).float().cpu().numpy()
+    assert_bf16_close(got_dx, want_dx, "dx")
+    want_dw = dy.reshape(m, n).astype(np.float64).T @ x.reshape(m, k).astype(np.float64)
+    assert relmax(wtt.grad.float().cpu().numpy(), want_dw) < 2.0 ** -7

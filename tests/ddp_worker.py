@@ -31,11 +31,13 @@ def rank_batch(rank, batch):
     return torch.from_numpy(x).cuda(), y.cuda()
 
 
-def step(net, x, y):
+def step(net, x, y, amp=False):
+    """One forward/backward; amp: under bf16 autocast, the configuration bench.py times (1x1 convolutions on the MFMA GEMM)."""
     import torch
-    logits = net(x)
-    torch.nn.functional.cross_entropy(logits, y).backward()
-    return logits.detach()
+    with torch.autocast("cuda", dtype=torch.bfloat16, enabled=amp):
+        logits = net(x)
+    torch.nn.functional.cross_entropy(logits.float(), y).backward()
+    return logits.detach().float()
 
 
 def stats_of(module):
@@ -45,6 +47,7 @@ def stats_of(module):
 
 def main():
     arch, rank, world, port, outdir, batch = sys.argv[1], int(sys.argv[2]), int(sys.argv[3]), sys.argv[4], sys.argv[5], int(sys.argv[6])
+    amp = len(sys.argv) > 7 and sys.argv[7] == "amp"
     os.environ.update(RANK=str(rank), LOCAL_RANK="0", WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=port)
     import torch
     from mrla_amd import distributed as D
@@ -53,7 +56,7 @@ def main():
     net = D.wrap_data_parallel(build(arch), device_ids=[0])
     assert isinstance(net, torch.nn.parallel.DistributedDataParallel)
     x, y = rank_batch(rank, batch)
-    logits = step(net, x, y)
+    logits = step(net, x, y, amp)
     torch.cuda.synchronize()
     grads = {k: p.grad.detach().float().cpu().clone() for k, p in net.module.named_parameters()}
     torch.save(dict(grads=grads, logits=logits.float().cpu(), stats=stats_of(net.module)),

@@ -28,13 +28,15 @@ def _free_port():
     return p
 
 
-@pytest.mark.parametrize("arch", ["resnet50_mrlal", "resnet50_mrlab"])
-def test_model_under_ddp_two_ranks_one_gpu(arch, tmp_path):
+@pytest.mark.parametrize("arch,amp", [("resnet50_mrlal", False), ("resnet50_mrlab", False), ("resnet50_mrlal", True)],
+                         ids=["resnet50_mrlal-fp32", "resnet50_mrlab-fp32", "resnet50_mrlal-bf16-autocast"])
+def test_model_under_ddp_two_ranks_one_gpu(arch, amp, tmp_path):
     from tests import ddp_worker as W
     world, batch, port = 2, 3, str(_free_port())
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
     procs = [subprocess.Popen([sys.executable, os.path.join(HERE, "ddp_worker.py"), arch, str(r), str(world), port,
-                               str(tmp_path), str(batch)], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)
+                               str(tmp_path), str(batch)] + (["amp"] if amp else []), env=env, stdout=subprocess.PIPE,
+                              stderr=subprocess.STDOUT)
              for r in range(world)]
     logs = []
     for p in procs:
@@ -53,7 +55,7 @@ def test_model_under_ddp_two_ranks_one_gpu(arch, tmp_path):
     for r in range(world):
         net = W.build(arch)
         x, y = W.rank_batch(r, batch)
-        logits = W.step(net, x, y)
+        logits = W.step(net, x, y, amp)
         torch.cuda.synchronize()
         g = {k: p.grad.detach().float().cpu() for k, p in net.named_parameters()}
         want = g if want is None else {k: want[k] + g[k] for k in g}
@@ -62,9 +64,10 @@ def test_model_under_ddp_two_ranks_one_gpu(arch, tmp_path):
 
     for r in range(world):
         # forward of a rank = the single-process forward on its batch; statistics stayed local to the rank
-        assert torch.allclose(res[r]["logits"], singles[r]["logits"], rtol=1e-4, atol=1e-5), r
+        # (bf16 autocast: the forward is deterministic too -- same kernels, same order -- but leave room for MIOpen)
+        assert torch.allclose(res[r]["logits"], singles[r]["logits"], rtol=2e-2 if amp else 1e-4, atol=2e-2 if amp else 1e-5), r
         for k, v in singles[r]["stats"].items():
-            assert torch.allclose(res[r]["stats"][k], v, rtol=1e-4, atol=1e-6), (r, k)
+            assert torch.allclose(res[r]["stats"][k], v, rtol=2e-2 if amp else 1e-4, atol=1e-3 if amp else 1e-6), (r, k)
         # gradients: all-reduced average, identical on both ranks
         dots, worst = np.zeros(3), (0.0, "")
         for k, w in want.items():
@@ -79,9 +82,9 @@ def test_model_under_ddp_two_ranks_one_gpu(arch, tmp_path):
                 noisy = ".Wq." in k or ".Wk." in k   # sums of cancelling terms: noise-limited (tests/test_models_gpu.py)
                 e = ((a - b).abs().sum() / b.abs().sum()).item()
                 worst = max(worst, (e, k)) if not noisy else worst
-                assert e < (0.5 if noisy else 2e-2), (r, k, e)          # measured: 3e-3
+                assert e < (0.5 if noisy else (0.5 if amp else 2e-2)), (r, k, e)          # measured (fp32): 3e-3
         print(f"rank {r}: worst per-parameter relative L1 difference to the manual average {worst}")
-        assert dots[0] / np.sqrt(dots[1] * dots[2]) > 0.9999
+        assert dots[0] / np.sqrt(dots[1] * dots[2]) > (0.97 if amp else 0.9999)
     for k in res[0]["grads"]:
         assert torch.equal(res[0]["grads"][k], res[1]["grads"][k]), k        # both ranks hold the same reduced gradient
     k = next(k for k in res[0]["stats"] if "bn_mrla.running_mean" in k)

@@ -17,7 +17,7 @@
 //     a wave-private LDS tile [32 pixels][64 channels] then turns them into stores of whole 128-byte lines (8 lanes
 //     per pixel) -- 32-byte fragments per pixel straight from the lanes cost the L2 four requests per line;
 //   * the BatchNorm moments are per-lane running sums over the wave's pixels (register = channel), reduced across
-//     lanes once at the end of the kernel and written as one partial row per (workgroup, pixel-wave).
+//     lanes and pixel-waves once at the end of the kernel and written as one partial row per workgroup.
 #include <algorithm>
 
 #include "mrla_device.h"
@@ -159,16 +159,17 @@ __global__ __launch_bounds__(NW * kWave) void conv1x1_fwd_kernel(
   }
 
   if (MOM) {
-    // rows beyond the active (workgroup, pixel-wave) pairs only exist to make the row count divide M: zeros
+    // rows beyond the active workgroups only exist to make the row count divide M: zeros
     if (blockIdx.x == 0) {
-      const int active = gridDim.x * WM;
-      for (int i = threadIdx.x; i < (rows_total - active) * NS * 2; i += NW * kWave) {
-        const int row = active + i / (NS * 2), j = i % (NS * 2);
+      for (int i = threadIdx.x; i < (rows_total - (int)gridDim.x) * NS * 2; i += NW * kWave) {
+        const int row = gridDim.x + i / (NS * 2), j = i % (NS * 2);
         part[((size_t)row * N + n_slice0) * 2 + j] = 0.f;
       }
     }
-    // sum over the 32 pixel-lanes of each half (fixed order), one partial row per (workgroup, pixel-wave)
-    float* dst = part + ((size_t)(blockIdx.x * WM + wm) * N + n_slice0 + wn * 64) * 2;
+    // sum over the 32 pixel-lanes of each half, then over the workgroup's pixel-waves (fixed order, through the LDS of
+    // the output tiles, which are done with): one partial row per workgroup
+    __syncthreads();
+    float* sums = reinterpret_cast<float*>(smem_raw + (size_t)NS * ROWB);          // [WM][NS][2]
 #pragma unroll
     for (int t = 0; t < 2; ++t)
 #pragma unroll
@@ -180,11 +181,18 @@ __global__ __launch_bounds__(NW * kWave) void conv1x1_fwd_kernel(
           b += __shfl_xor(b, off, kWave);
         }
         if (r == 0) {
-          const int ch = t * 32 + acc_channel(i, h);
-          dst[ch * 2 + 0] = a;
-          dst[ch * 2 + 1] = b;
+          const int ch = wn * 64 + t * 32 + acc_channel(i, h);
+          sums[((size_t)wm * NS + ch) * 2 + 0] = a;
+          sums[((size_t)wm * NS + ch) * 2 + 1] = b;
         }
       }
+    __syncthreads();
+    float* dst = part + ((size_t)blockIdx.x * N + n_slice0) * 2;
+    for (int i = threadIdx.x; i < NS * 2; i += NW * kWave) {
+      float a = 0.f;
+      for (int v = 0; v < WM; ++v) a += sums[(size_t)v * NS * 2 + i];
+      dst[i] = a;
+    }
   }
 }
 
@@ -213,12 +221,12 @@ static bool conv1x1_geo(GemmGeo* g, int M, int K, int N) {
   // persistent workgroups: a few per CU over the whole grid; rows must divide M for the statistics kernel
   const int want = std::max(1, (256 * (g->NW == 4 ? 3 : 2)) / g->gy);
   int gx = std::max(1, std::min((nblk + g->WM - 1) / g->WM, want));
-  // the statistics kernel takes (rows, M / rows): prefer a grid whose (workgroup, pixel-wave) count divides M, else pad
+  // the statistics kernel takes (rows, M / rows): prefer a grid whose workgroup count divides M, else pad
   // the partial buffer with zero rows up to the next divisor of M
   for (int t = gx; t >= std::max(1, gx - gx / 4); --t)
-    if (M % (t * g->WM) == 0) { gx = t; break; }
-  int rows = gx * g->WM;
-  while (rows <= 2 * gx * g->WM + 64 && M % rows) ++rows;
+    if (M % t == 0) { gx = t; break; }
+  int rows = gx;
+  while (rows <= 2 * gx + 64 && M % rows) ++rows;
   if (M % rows) return false;
   g->gx = gx;
   g->rows = rows;

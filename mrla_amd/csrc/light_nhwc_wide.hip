@@ -538,8 +538,9 @@ template <typename T> constexpr int apply_bwd_wave_bytes() {
   return RowIO<T, kS + 4>::kBytes + 3 * RowIO<T, kS + 2>::kBytes + 2 * RowIO<T, kS>::kBytes;
 }
 
-// (4-wave workgroups under a 168-register budget -- three waves per SIMD, a wave walking two strips of the 56-wide stage --
-// measured 25 % SLOWER than one strip per wave at two waves per SIMD: profiles/r02_notes.md.)
+// (Measured and rejected, profiles/r02_notes.md: 4-wave workgroups under a 168-register budget -- three waves per SIMD, a
+// wave walking two strips of the 56-wide stage -- 25 % slower; the 168-register cap alone on these 8-wave workgroups 8 %
+// slower than the 171 registers the compiler picks by itself.)
 constexpr int kBwdWaves = kMaxStrips;
 template <typename T, bool GELU, bool HAS_O, bool RELU, bool RAGGED>
 __global__ __launch_bounds__(kBwdWaves * kWave) void light_apply_bwd_wide(

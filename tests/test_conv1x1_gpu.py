@@ -13,7 +13,7 @@ pytestmark = pytest.mark.gpu
 
 # (b, h, w, k, n): every ResNet-50 shape class the kernel takes (scaled-down batch) + a ragged pixel count + tiny N
 SHAPES = [(2, 56, 56, 64, 256), (2, 56, 56, 256, 64), (2, 56, 56, 64, 64), (2, 56, 56, 256, 128), (3, 28, 28, 128, 512),
-          (4, 14, 14, 256, 1024), (1, 4, 8, 64, 64), (5, 12, 16, 128, 192), (3, 7, 7, 64, 128)]
+          (4, 14, 14, 256, 1024), (1, 4, 8, 64, 64), (5, 12, 16, 128, 192), (3, 7, 7, 64, 128), (1, 1, 1, 256, 64)]
 
 
 def _operands(b, h, w, k, n, salt=0):
@@ -56,7 +56,7 @@ def test_unsupported_shapes_are_reported_not_run():
     assert lib.mrla_conv1x1_rows(64, 1024, 256, L.BF16) == L.EUNSUPPORTED
     assert lib.mrla_conv1x1_rows(64, 512, 128, L.BF16) == L.EUNSUPPORTED       # left to the stock convolution
     assert lib.mrla_conv1x1_rows(48, 64, 64, L.BF16) > 0                       # ragged last pixel block
-    assert lib.mrla_conv1x1_rows(1, 256, 64, L.BF16) == L.EUNSUPPORTED          # fewer pixels than pixel-waves
+    assert lib.mrla_conv1x1_rows(1, 256, 64, L.BF16) == 1                       # a single pixel: one workgroup, one row
     assert lib.mrla_conv1x1_rows(64, 64, 96, L.BF16) == L.EUNSUPPORTED        # n % 64
     assert lib.mrla_conv1x1_rows(64, 64, 64, L.F32) == L.EUNSUPPORTED
     assert lib.mrla_conv1x1_rows(0, 64, 64, L.BF16) == L.EINVAL

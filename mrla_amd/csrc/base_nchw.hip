@@ -101,18 +101,20 @@ __global__ __launch_bounds__(kThreads) void base_gate_fwd_kernel(
   }
   __syncthreads();
   const float s = rsqrtf((float)d);
-  // one thread per head: logits over j, stable softmax (t <= a few dozen)
+  // logits: one (head, slot) pair per thread (G*t pairs: the whole workgroup loads the key history), written to the P row
+  for (int idx = tid; idx < G * t; idx += kThreads) {
+    const int g = idx / t, j = idx - g * t;
+    const float* kj = (j == t - 1) ? kts + g * d : Kb + (size_t)j * C + g * d;
+    float acc = 0.f;
+    for (int i = 0; i < d; ++i) acc = fmaf(qs[g * d + i], kj[i], acc);
+    Pall[(((size_t)b * G + g) * T + (t - 1)) * T + j] = acc * s;
+  }
+  __syncthreads();
+  // one thread per head: stable softmax over the slots (t <= a few dozen)
   for (int g = tid; g < G; g += kThreads) {
     float* Prow = Pall + (((size_t)b * G + g) * T + (t - 1)) * T;
     float mx = -INFINITY;
-    for (int j = 0; j < t; ++j) {
-      float acc = 0.f;
-      if (j == t - 1) { for (int i = 0; i < d; ++i) acc = fmaf(qs[g * d + i], kts[g * d + i], acc); }
-      else            { for (int i = 0; i < d; ++i) acc = fmaf(qs[g * d + i], Kb[(size_t)j * C + g * d + i], acc); }
-      acc *= s;
-      Prow[j] = acc;
-      mx = fmaxf(mx, acc);
-    }
+    for (int j = 0; j < t; ++j) mx = fmaxf(mx, Prow[j]);
     float den = 0.f;
     for (int j = 0; j < t; ++j) {
       const float e = expf(Prow[j] - mx);
@@ -492,16 +494,19 @@ __global__ __launch_bounds__(kThreads) void base_gate_bwd_kernel(
     dqs[i] = 0.f;
     dks[i] = 0.f;
   }
-  // dP[g,j] = sum_{c in g} pmom[b,c,j]; softmax backward
+  // dP[g,j] = sum_{c in g} pmom[b,c,j] (one (head, slot) pair per thread: G*t pairs keep the whole workgroup loading),
+  // then the softmax backward per head
+  for (int idx = tid; idx < G * t; idx += kThreads) {
+    const int g = idx / t, j = idx - g * t;
+    float dP = 0.f;
+    for (int i = 0; i < d; ++i) dP += pmom[((size_t)b * C + g * d + i) * t + j];
+    dlg[idx] = dP;
+  }
+  __syncthreads();
   for (int g = tid; g < G; g += kThreads) {
     const float* Prow = Pall + (((size_t)b * G + g) * T + (t - 1)) * T;
     float dot = 0.f;
-    for (int j = 0; j < t; ++j) {
-      float dP = 0.f;
-      for (int i = 0; i < d; ++i) dP += pmom[((size_t)b * C + g * d + i) * t + j];
-      dlg[g * t + j] = dP;
-      dot = fmaf(Prow[j], dP, dot);
-    }
+    for (int j = 0; j < t; ++j) dot = fmaf(Prow[j], dlg[g * t + j], dot);
     for (int j = 0; j < t; ++j) dlg[g * t + j] = Prow[j] * (dlg[g * t + j] - dot) * s;
   }
   __syncthreads();

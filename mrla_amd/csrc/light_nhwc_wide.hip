@@ -247,20 +247,37 @@ __global__ __launch_bounds__(kMaxStrips * kWave) void light_stats_fwd_wide(
 // (resnet_mrla_light.py:101-114; AFF = bn3's affine handed over instead of applied in a pass of its own).
 // `pre` and `o` arrive as zeros outside the image; the shift is masked there so that the padding of the 3x3 stays zero.
 // ------------------------------------------------------------------------------------------------
-template <typename T, bool AFF>
-__device__ __forceinline__ void form_x_row(const RawRow<kS + 2>& pre, const RawRow<kS + 2>& o, float asc,
-                                           const float (&shj)[kS + 2], float (&dst)[kS + 2]) {
+// The shift per window column: `ash` inside the image, 0 outside.  For whole strips only the two halo columns can be
+// outside, so three values stand for the nine (RAGGED strips keep the full table).
+template <bool RAGGED> struct ColumnShifts;
+template <> struct ColumnShifts<true> {
+  float v[kS + 2];
+  __device__ __forceinline__ void set(float ash, int s0, int W) {
 #pragma unroll
-  for (int j = 0; j < kS + 2; ++j) {
-    const float z = AFF ? to_f(from_f<T>(fmaf(asc, pre.v[j], shj[j]))) : pre.v[j];
-    dst[j] = fmaxf(to_f(from_f<T>(z + o.v[j])), 0.f);
+    for (int j = 0; j < kS + 2; ++j) {
+      const int col = s0 - 1 + j;
+      v[j] = (col >= 0 && col < W) ? ash : 0.f;      // wave-uniform predicate
+    }
   }
-}
-__device__ __forceinline__ void column_shifts(float ash, int s0, int W, float (&shj)[kS + 2]) {
+  __device__ __forceinline__ float at(int j) const { return v[j]; }
+};
+template <> struct ColumnShifts<false> {
+  float first, mid, last;
+  __device__ __forceinline__ void set(float ash, int s0, int W) {
+    first = s0 > 0 ? ash : 0.f;
+    mid = ash;
+    last = s0 + kS < W ? ash : 0.f;
+  }
+  __device__ __forceinline__ float at(int j) const { return j == 0 ? first : (j == kS + 1 ? last : mid); }
+};
+
+template <typename T, bool AFF, bool RAGGED>
+__device__ __forceinline__ void form_x_row(const RawRow<kS + 2>& pre, const RawRow<kS + 2>& o, float asc,
+                                           const ColumnShifts<RAGGED>& sh, float (&dst)[kS + 2]) {
 #pragma unroll
   for (int j = 0; j < kS + 2; ++j) {
-    const int col = s0 - 1 + j;
-    shj[j] = (col >= 0 && col < W) ? ash : 0.f;      // wave-uniform predicate
+    const float z = AFF ? to_f(from_f<T>(fmaf(asc, pre.v[j], sh.at(j)))) : pre.v[j];
+    dst[j] = fmaxf(to_f(from_f<T>(z + o.v[j])), 0.f);
   }
 }
 
@@ -298,8 +315,8 @@ __global__ __launch_bounds__(kMaxStrips * kWave) void light_stats_fwd_fused_wide
       RowIO<T, kS> as;
       make_row_io<T, kS + 2>(ax, s0 - 1, kS + 2, W, C, cbase, lane);
       make_row_io<T, kS>(as, s0, nc, W, C, cbase, lane);
-      float shj[kS + 2];
-      column_shifts(ash, s0, W, shj);
+      ColumnShifts<RAGGED> shj;
+      shj.set(ash, s0, W);
       RawRow<kS + 2> praw, oraw;
       RawRow<kS> ov;
       praw.clear(); oraw.clear(); ov.clear();
@@ -320,7 +337,7 @@ __global__ __launch_bounds__(kMaxStrips * kWave) void light_stats_fwd_fused_wide
       row_read<T, kS + 2>(obuf(0), lane, oraw);
       row_fetch<T, kS + 2>(ax, pi, 1, H, rowelems, bufP);
       row_fetch<T, kS + 2>(ax, oi, 1, H, rowelems, obuf(1));
-      form_x_row<T, AFF>(praw, oraw, asc, shj, xb);
+      form_x_row<T, AFF, RAGGED>(praw, oraw, asc, shj, xb);
       store_owned(xo, 0, xb);
       auto step = [&](int r, float (&XA)[kS + 2], float (&XB)[kS + 2], float (&XC)[kS + 2]) {
         // step r-1 stored x_t row r (always: r <= H-1) and, for MRLA-base, V row r-1 after its fetches
@@ -336,7 +353,7 @@ __global__ __launch_bounds__(kMaxStrips * kWave) void light_stats_fwd_fused_wide
         row_fetch<T, kS + 2>(ax, pi, r + 2, H, rowelems, bufP);
         row_fetch<T, kS + 2>(ax, oi, r + 2, H, rowelems, obuf(r));
         if (r + 1 < H) {
-          form_x_row<T, AFF>(praw, oraw, asc, shj, XC);
+          form_x_row<T, AFF, RAGGED>(praw, oraw, asc, shj, XC);
           store_owned(xo, r + 1, XC);
         } else {
 #pragma unroll
@@ -481,8 +498,8 @@ __global__ __launch_bounds__(kMaxStrips * kWave) void light_apply_fwd_pre_wide(
       RowIO<T, kS> as;
       make_row_io<T, kS + 2>(ax, s0 - 1, kS + 2, W, C, cbase, lane);
       make_row_io<T, kS>(as, s0, nc, W, C, cbase, lane);
-      float shj[kS + 2];
-      column_shifts(ash, s0, W, shj);
+      ColumnShifts<true> shj;
+      shj.set(ash, s0, W);
       RawRow<kS + 2> praw, oraw;
       RawRow<kS> ov;
       praw.clear(); oraw.clear(); ov.clear();
@@ -497,7 +514,7 @@ __global__ __launch_bounds__(kMaxStrips * kWave) void light_apply_fwd_pre_wide(
       row_read<T, kS + 2>(obuf(0), lane, oraw);
       row_fetch<T, kS + 2>(ax, pi, 1, H, rowelems, bufP);
       row_fetch<T, kS + 2>(ax, oi, 1, H, rowelems, obuf(1));
-      form_x_row<T, AFF>(praw, oraw, asc, shj, xb);
+      form_x_row<T, AFF, true>(praw, oraw, asc, shj, xb);
       auto step = [&](int r, float (&XA)[kS + 2], float (&XB)[kS + 2], float (&XC)[kS + 2]) {
         if (r == 0) rows_landed(); else rows_landed_keep<RowIO<T, kS>::NL>();
         row_read_issue<T, kS + 2>(bufP, lane, praw);
@@ -509,7 +526,7 @@ __global__ __launch_bounds__(kMaxStrips * kWave) void light_apply_fwd_pre_wide(
         row_fetch<T, kS + 2>(ax, pi, r + 2, H, rowelems, bufP);
         row_fetch<T, kS + 2>(ax, oi, r + 2, H, rowelems, obuf(r));
         if (r + 1 < H) {
-          form_x_row<T, AFF>(praw, oraw, asc, shj, XC);
+          form_x_row<T, AFF, true>(praw, oraw, asc, shj, XC);
         } else {
 #pragma unroll
           for (int j = 0; j < kS + 2; ++j) XC[j] = 0.f;

@@ -150,8 +150,7 @@ def eager_rocm(arch, batch, drop_path, steps=6):
 def forward_only(net, x, steps=10, graph=True):
     """Inference pass (eval, no_grad, bf16 autocast) of the product network: the numerator of the north-star's
     ">= 4x the eager PyTorch-ROCm forward" target (eager_rocm.fwd_images_per_sec is its denominator).  Timed both as
-    PyTorch launches it and (graph=True) replayed from one HIP graph; `fwd_images_per_sec` is the graph figure when the
-    capture succeeded."""
+    PyTorch launches it and (graph=True) replayed from one HIP graph; `fwd_images_per_sec` is the faster of the two."""
     was = net.training
     net.eval()
     res = {"mode": "eval, no_grad, bf16 autocast"}
@@ -183,8 +182,10 @@ def forward_only(net, x, steps=10, graph=True):
                 torch.cuda.synchronize()
                 fg = (time.perf_counter() - t0) / steps
                 res.update(eager_launch_fwd_images_per_sec=res["fwd_images_per_sec"], eager_launch_ms=res["ms"],
-                           fwd_images_per_sec=round(x.shape[0] / fg, 1), ms=round(1e3 * fg, 3),
-                           launch="one HIP graph, replayed")
+                           graph_fwd_images_per_sec=round(x.shape[0] / fg, 1), graph_ms=round(1e3 * fg, 3))
+                if fg < fw:            # the headline forward figure is the faster way of launching the same kernels
+                    res.update(fwd_images_per_sec=res["graph_fwd_images_per_sec"], ms=res["graph_ms"],
+                               launch="one HIP graph, replayed")
             except Exception as e:
                 print(f"warning: forward HIP graph capture failed ({type(e).__name__}: {e})", file=sys.stderr)
     net.train(was)

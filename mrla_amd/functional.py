@@ -4,7 +4,9 @@ PyTorch is plumbing here: it owns the device buffers and the stream and records 
 arithmetic of the MRLA path happens in libmrla_hip.so.  There is deliberately no fallback: CPU tensors or
 a missing library raise.
 """
+import contextlib
 import ctypes
+import threading
 from math import log
 
 import torch
@@ -56,6 +58,61 @@ def _call(name, nbytes, *args, entry=None):
 
 def _ptr(t):
     return ctypes.c_void_p(t.data_ptr()) if t is not None else None
+
+
+# ------------------------------------------------------------------------------------------------------
+# Per-forward batching of the tiny bookkeeping kernels: 85 `num_batches_tracked += 1` launches and 16 x 4 stochastic-depth
+# mask kernels per resnet50_mrlal step become one _foreach_add_ and one mask table.
+# ------------------------------------------------------------------------------------------------------
+class _Bookkeeping:
+    def __init__(self, n_drop_paths):
+        self.counters, self.n_dp, self.table, self.key, self.next = [], int(n_drop_paths), None, None, 0
+
+    def drop_path_row(self, batch, drop_prob, device):
+        """floor(keep + U[0,1)) / keep for one block: a row of a table drawn once per forward."""
+        key = (batch, float(drop_prob), str(device))
+        if self.table is None or self.key != key or self.next >= self.n_dp:
+            keep = 1.0 - drop_prob
+            self.table = torch.floor(keep + torch.rand((self.n_dp, batch), dtype=torch.float32, device=device)) / keep
+            self.key, self.next = key, 0
+        row = self.table[self.next]
+        self.next += 1
+        return row
+
+
+_TLS = threading.local()
+
+
+def current_bookkeeping():
+    return getattr(_TLS, "book", None)
+
+
+@contextlib.contextmanager
+def batched_bookkeeping(n_drop_paths=0):
+    """Inside: train-mode BatchNorm counters handled by bn_act / the fused tails are collected and bumped with ONE
+    torch._foreach_add_ on exit, and layers.drop_path_scale serves stochastic-depth rows from one table."""
+    prev, book = current_bookkeeping(), _Bookkeeping(n_drop_paths)
+    _TLS.book = book
+    try:
+        yield book
+    finally:
+        _TLS.book = prev
+        if book.counters:
+            torch._foreach_add_(book.counters, 1)
+
+
+def bump_batch_counter(bn):
+    """num_batches_tracked += 1 for a train-mode BatchNorm; returns the momentum to use (handles momentum=None)."""
+    momentum = bn.momentum
+    if bn.num_batches_tracked is not None:
+        book = current_bookkeeping()
+        if book is not None and momentum is not None:
+            book.counters.append(bn.num_batches_tracked)
+        else:
+            bn.num_batches_tracked.add_(1)
+            if momentum is None:
+                momentum = 1.0 / float(bn.num_batches_tracked)
+    return momentum
 
 
 def _stream():
@@ -735,11 +792,7 @@ def bn_act(x, bn, relu, defer=False, pre_moments=None):
     if (type(bn) is torch.nn.BatchNorm2d and bn.affine and bn.track_running_stats and x.is_cuda and x.dim() == 4
             and x.dtype in _DT and (x.is_contiguous() or x.is_contiguous(memory_format=_CL))):
         training = bn.training
-        momentum = bn.momentum
-        if training and bn.num_batches_tracked is not None:
-            bn.num_batches_tracked.add_(1)
-            if momentum is None:
-                momentum = 1.0 / float(bn.num_batches_tracked)
+        momentum = bump_batch_counter(bn) if training else bn.momentum
         if defer:
             y, buf = _BnActFn.apply(x, bn.weight, bn.bias, bn.running_mean, bn.running_var, training, momentum or 0.0,
                                     bn.eps, False, True, pre_moments)

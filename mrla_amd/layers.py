@@ -32,6 +32,9 @@ def drop_path_scale(batch, drop_prob, training, device):
     """Per-sample multiplier of stochastic depth, floor(keep + U[0,1)) / keep, or None when inactive."""
     if drop_prob == 0.0 or not training:
         return None
+    book = F_.current_bookkeeping()
+    if book is not None and book.n_dp > 0:          # one table per forward instead of four tiny kernels per block
+        return book.drop_path_row(batch, drop_prob, device)
     keep = 1.0 - drop_prob
     return torch.floor(keep + torch.rand((batch,), dtype=torch.float32, device=device)) / keep
 
@@ -103,10 +106,8 @@ def _bn_args(bn):
     training = bn.training or bn.running_mean is None
     momentum = bn.momentum
     rm, rv = bn.running_mean, bn.running_var
-    if bn.training and bn.track_running_stats and bn.num_batches_tracked is not None:
-        bn.num_batches_tracked.add_(1)
-        if momentum is None:
-            momentum = 1.0 / float(bn.num_batches_tracked)
+    if bn.training and bn.track_running_stats:
+        momentum = F_.bump_batch_counter(bn)
     if momentum is None:
         momentum = 0.0
     if rm is None:       # statistics not tracked: batch statistics in both modes, nothing to update

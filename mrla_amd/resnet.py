@@ -192,6 +192,12 @@ class _ResNetMRLA(nn.Module):
                 if isinstance(m, _BottleneckTrunk):
                     nn.init.constant_(m.bn3.weight, 0)
 
+    def _stochastic_depth_blocks(self):
+        """Blocks that will draw a stochastic-depth mask in this forward (0: none, each block draws its own)."""
+        if not (self.training and self.drop_path):
+            return 0
+        return sum(1 for m in self.modules() if isinstance(m, _BottleneckTrunk))
+
     def forward(self, x):
         x = self.forward_features(x)
         x = torch.flatten(self.avgpool(x), 1)
@@ -231,8 +237,9 @@ class ResNet_mrlal(_ResNetMRLA):
     def forward_features(self, x):
         if self.channels_last and x.is_cuda:
             x = x.contiguous(memory_format=torch.channels_last)
-        x = self.maxpool(F_.bn_act(self.conv1(x), self.bn1, relu=True))
-        return self.layer4(self.layer3(self.layer2(self.layer1(x))))
+        with F_.batched_bookkeeping(self._stochastic_depth_blocks()):
+            x = self.maxpool(F_.bn_act(self.conv1(x), self.bn1, relu=True))
+            return self.layer4(self.layer3(self.layer2(self.layer1(x))))
 
 
 class ResNet_mrlab(_ResNetMRLA):
@@ -272,11 +279,12 @@ class ResNet_mrlab(_ResNetMRLA):
     def forward_features(self, x):
         if self.channels_last and x.is_cuda:
             x = x.contiguous(memory_format=torch.channels_last)
-        x = self.maxpool(F_.bn_act(self.conv1(x), self.bn1, relu=True))
-        k = v = None
-        for stage in self.stages:
-            for blk in stage:
-                x, k, v = blk(x, k, v)
+        with F_.batched_bookkeeping(self._stochastic_depth_blocks()):
+            x = self.maxpool(F_.bn_act(self.conv1(x), self.bn1, relu=True))
+            k = v = None
+            for stage in self.stages:
+                for blk in stage:
+                    x, k, v = blk(x, k, v)
         return x
 
 

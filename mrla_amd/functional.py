@@ -861,7 +861,8 @@ def conv1x1_applies(conv, x):
     if not (type(conv) is torch.nn.Conv2d and conv.kernel_size == (1, 1) and conv.stride == (1, 1)
             and conv.padding == (0, 0) and conv.dilation == (1, 1) and conv.groups == 1 and conv.bias is None):
         return False
-    if not (x.is_cuda and x.dim() == 4 and x.dtype == torch.bfloat16 and x.is_contiguous(memory_format=_CL)):
+    if not (x.is_cuda and x.dim() == 4 and x.dtype == torch.bfloat16 and x.is_contiguous(memory_format=_CL)
+            and x.data_ptr() % 16 == 0):               # (the kernel moves 16-byte fragments)
         return False
     b, k, h, w = x.shape
     return k == conv.in_channels and L.load().mrla_conv1x1_rows(b * h * w, k, conv.out_channels, L.BF16) > 0

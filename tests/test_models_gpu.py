@@ -244,3 +244,35 @@ def test_bf16_autocast_train_step_tracks_the_eager_restatement(arch):
     print(f"{arch}: gradient cosine vs eager {c_eager:.4f}, GEMM vs stock 1x1 convolutions {c_stock:.4f}; "
           f"logits GEMM vs stock {rel(y.detach().float().cpu().numpy(), y2.detach().float().cpu().numpy()):.3e}")
     assert c_eager > 0.8 and c_stock > 0.8
+
+
+def test_per_forward_bookkeeping_is_batched_but_equivalent():
+    """One training forward bumps every BatchNorm's num_batches_tracked exactly once (collected and applied by one
+    _foreach_add_ at the end of forward_features) and serves every block its own stochastic-depth row from one table."""
+    from mrla_amd import functional as Fm, models
+    net = models.resnet50_mrlal(drop_path=0.5).cuda().train()
+    x = torch.from_numpy(cases.image_batch(8, "img-train")).cuda()
+    seen = []
+    orig = Fm._Bookkeeping.drop_path_row
+
+    def spy(self, batch, p, device):
+        row = orig(self, batch, p, device)
+        seen.append(row)
+        return row
+    try:
+        Fm._Bookkeeping.drop_path_row = spy
+        with torch.autocast("cuda", dtype=torch.bfloat16):
+            net(x).float().sum().backward()
+    finally:
+        Fm._Bookkeeping.drop_path_row = orig
+    counters = [m.num_batches_tracked for m in net.modules() if isinstance(m, torch.nn.BatchNorm2d)]
+    assert len(counters) == 53 + 16 and all(int(c) == 1 for c in counters)
+    assert len(seen) == 16 and all(r.shape == (8,) for r in seen)
+    rows = torch.stack(seen)
+    assert set(rows.unique().tolist()) <= {0.0, 2.0} and rows.float().mean().item() not in (0.0, 2.0)
+    assert len({tuple(r.tolist()) for r in rows}) > 8            # independent rows, not one mask repeated
+    assert Fm.current_bookkeeping() is None
+    # outside a model forward nothing is deferred
+    bn = torch.nn.BatchNorm2d(64).cuda()
+    Fm.bn_act(torch.randn(2, 64, 8, 8, device="cuda"), bn, relu=True)
+    assert int(bn.num_batches_tracked) == 1

@@ -276,7 +276,7 @@ def main():
                             "mrla_token_apply_fwd", "mrla_token_stats_bwd", "mrla_token_apply_bwd", "mrla_token_ln_bwd",
                             "mrla_light_stats_fwd_fused", "mrla_light_pool_fused", "mrla_light_apply_fwd_fused", "mrla_bn_plane_moments", "mrla_bn_act_fwd",
                             "mrla_bn_plane_dmoments", "mrla_bn_act_bwd",
-                            "mrla_conv1x1_fwd", "mrla_conv1x1_bwd_data"])
+                            "mrla_conv1x1_fwd", "mrla_conv1x1_bwd_data", "mrla_conv1x1_wgrad"])
     # the timed region: exactly `steps` steps between barrier + synchronize
     if use_graph:
         dt = timed(step, args.steps, 0, dist_on)

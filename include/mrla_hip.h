@@ -301,10 +301,19 @@ int mrla_bn_act_bwd(const void* dy, const void* x, const float* sc, const float*
  *                                            w: the conv weight [n = c_out, k] (bf16), y: [m, n] (bf16, fp32 accumulate)
  *   mom_part[row, n, 0..1] [opt] = partial (sum, sum of squares) over the row's pixels of the ROUNDED outputs:
  *   exactly what mrla_bn_plane_moments would read back from y -- pass (rows, m / rows) as (b, hw) to mrla_bn_stats_fwd.
- * MRLA_EUNSUPPORTED for shapes outside k in {64, 128, 256, 512}, n % 64 == 0, m % 32 == 0 and for dtypes other than
- * MRLA_BF16: the caller keeps using its stock convolution there. */
+ * MRLA_EUNSUPPORTED for shapes outside k in {64, 128, 256}, n % 64 == 0 and for dtypes other than MRLA_BF16: the caller
+ * keeps using its stock convolution there.  (The input gradient dX = dY * W is the same entry point with w^T.) */
 int mrla_conv1x1_rows(int m, int k, int n, int dtype);      /* rows of mom_part (> 0), or a negative code */
 int mrla_conv1x1_fwd(const void* x, const void* w, void* y, float* mom_part, int m, int k, int n, int dtype, void* stream);
+
+/* Weight gradient of the same convolution (the backward of the reference's nn.Conv2d(kernel_size=1) call sites above,
+ * which the reference leaves to cuDNN):   dw[n, k] = sum_m dy[m, n] * x[m, k]
+ *   dy: [m, n] and x: [m, k] channels_last activations (bf16), dw: [n, k] (bf16, fp32 accumulation),
+ *   part: fp32 workspace [rows, n, k] with rows = mrla_conv1x1_wgrad_rows(m, k, n, dtype): the per-workgroup partial
+ *   tiles of the split over m, summed in a fixed order by a second kernel (no atomics, no memset of dw).
+ * MRLA_EUNSUPPORTED unless n % 64 == 0, k % 64 == 0, dtype MRLA_BF16 and m * max(n, k) * 2 < 2^31. */
+int mrla_conv1x1_wgrad_rows(int m, int k, int n, int dtype);      /* rows of part (> 0), or a negative code */
+int mrla_conv1x1_wgrad(const void* dy, const void* x, float* part, void* dw, int m, int k, int n, int dtype, void* stream);
 
 /* out[n] = sum over rows of in[rows, n] (fixed order, double accumulation). */
 int mrla_reduce_rows(const float* in, float* out, int rows, int n, void* stream);

@@ -471,6 +471,18 @@ int mrla_conv1x1_fwd(const void* x, const void* w, void* y, float* mom_part, int
   return launch_conv1x1_fwd(x, w, y, mom_part, m, k, n, (hipStream_t)stream);
 }
 
+int mrla_conv1x1_wgrad_rows(int m, int k, int n, int dtype) {
+  if (m <= 0 || k <= 0 || n <= 0 || bad_dtype(dtype)) return MRLA_EINVAL;
+  if (dtype != MRLA_BF16) return MRLA_EUNSUPPORTED;
+  return conv1x1_wgrad_rows(m, k, n);
+}
+
+int mrla_conv1x1_wgrad(const void* dy, const void* x, float* part, void* dw, int m, int k, int n, int dtype, void* stream) {
+  if (!dy || !x || !part || !dw || m <= 0 || k <= 0 || n <= 0 || bad_dtype(dtype)) return MRLA_EINVAL;
+  if (dtype != MRLA_BF16) return MRLA_EUNSUPPORTED;
+  return launch_conv1x1_wgrad(dy, x, part, dw, m, k, n, (hipStream_t)stream);
+}
+
 int mrla_reduce_rows(const float* in, float* out, int rows, int n, void* stream) {
   if (!in || !out || rows <= 0 || n <= 0) return MRLA_EINVAL;
   return launch_reduce_rows(in, out, rows, n, (hipStream_t)stream);

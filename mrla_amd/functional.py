@@ -808,8 +808,10 @@ def bn_act(x, bn, relu, defer=False, pre_moments=None):
 # 1x1 stride-1 convolution as an MFMA GEMM with the BatchNorm statistics in its epilogue
 # ======================================================================================================
 class _Conv1x1Fn(torch.autograd.Function):
-    """y = conv2d(x, w) for a bias-free 1x1 stride-1 convolution of a channels_last bf16 tensor (mrla_conv1x1_fwd), plus the
-    partial (sum, sum^2) rows of y the following BatchNorm needs.  Backward is the stock convolution backward."""
+    """y = conv2d(x, w) for a bias-free 1x1 stride-1 convolution of a channels_last bf16 tensor, plus the partial
+    (sum, sum^2) rows of y the following BatchNorm needs (mrla_conv1x1_fwd; shapes that kernel does not take run the
+    stock convolution and return no rows).  Backward: dX through the same GEMM on w^T where it applies, dW through the
+    split-M GEMM mrla_conv1x1_wgrad; what neither takes stays on the stock convolution backward."""
 
     @staticmethod
     @_on_device
@@ -818,14 +820,16 @@ class _Conv1x1Fn(torch.autograd.Function):
         n = w.shape[0]
         m = b * h * wd
         dev, st = x.device, _stream()
-        y = torch.empty((b, n, h, wd), dtype=x.dtype, device=dev, memory_format=_CL)
         part = None
-        if want_moments:
-            rows = L.load().mrla_conv1x1_rows(m, k, n, _DT[x.dtype])
-            L.check(min(rows, 0), "mrla_conv1x1_rows")
-            part = torch.empty((rows, n, 2), dtype=torch.float32, device=dev)
-        _call("mrla_conv1x1_fwd", (x.numel() + y.numel()) * x.element_size(), _ptr(x), _ptr(w), _ptr(y), _ptr(part), m, k, n,
-              _DT[x.dtype], st)
+        if L.load().mrla_conv1x1_rows(m, k, n, _DT[x.dtype]) > 0:
+            y = torch.empty((b, n, h, wd), dtype=x.dtype, device=dev, memory_format=_CL)
+            if want_moments:
+                rows = L.load().mrla_conv1x1_rows(m, k, n, _DT[x.dtype])
+                part = torch.empty((rows, n, 2), dtype=torch.float32, device=dev)
+            _call("mrla_conv1x1_fwd", (x.numel() + y.numel()) * x.element_size(), _ptr(x), _ptr(w), _ptr(y), _ptr(part), m, k,
+                  n, _DT[x.dtype], st)
+        else:
+            y = torch.nn.functional.conv2d(x, w.view(n, k, 1, 1))
         ctx.save_for_backward(x, w)
         if part is None:
             part = torch.empty(0, device=dev)
@@ -840,32 +844,52 @@ class _Conv1x1Fn(torch.autograd.Function):
         n, k = w.shape
         b, _, h, wd = x.shape
         m = b * h * wd
+        lib, dt = L.load(), _DT[x.dtype]
         need_x, need_w = ctx.needs_input_grad[0], ctx.needs_input_grad[1]
-        gx = None
+        gx = gw = None
+        same = dy.dtype == x.dtype and dy.data_ptr() % 16 == 0
         # the input gradient is the same GEMM with the transposed weight: dX[m, k] = sum_n dY[m, n] * W^T[k, n]
         # (no memset of dX, as MIOpen's backward-data solver needs); shapes the kernel does not take stay on MIOpen
-        if need_x and dy.dtype == x.dtype and L.load().mrla_conv1x1_rows(m, n, k, _DT[x.dtype]) > 0:
+        if need_x and same and lib.mrla_conv1x1_rows(m, n, k, dt) > 0:
             gx = torch.empty_like(x)
             wt = w.t().contiguous()
             _call("mrla_conv1x1_bwd_data", (dy.numel() + gx.numel()) * x.element_size(), _ptr(dy), _ptr(wt), _ptr(gx), None,
-                  m, n, k, _DT[x.dtype], _stream(), entry="mrla_conv1x1_fwd")
+                  m, n, k, dt, _stream(), entry="mrla_conv1x1_fwd")
             need_x = False
-        gx2, gw, _ = torch.ops.aten.convolution_backward(dy, x, w.view(n, k, 1, 1), None, (1, 1), (0, 0), (1, 1), False, (0, 0),
-                                                        1, [need_x, need_w, False])
-        return (gx if gx is not None else gx2), (gw.view(w.shape) if gw is not None else None), None
+        # the weight gradient dW[n, k] = sum_m dY[m, n] * X[m, k]: one pass over both activations, per-workgroup partial
+        # tiles summed by a second kernel (MIOpen: memset + atomics into fp32 + a cast kernel)
+        if need_w and same and w.dtype == x.dtype:
+            rows = lib.mrla_conv1x1_wgrad_rows(m, k, n, dt)
+            if rows > 0:
+                part = torch.empty((rows, n, k), dtype=torch.float32, device=x.device)
+                gw = torch.empty((n, k), dtype=w.dtype, device=x.device)
+                _call("mrla_conv1x1_wgrad", (dy.numel() + x.numel()) * x.element_size(), _ptr(dy), _ptr(x), _ptr(part),
+                      _ptr(gw), m, k, n, dt, _stream())
+                need_w = False
+        if need_x or need_w:
+            gx2, gw2, _ = torch.ops.aten.convolution_backward(dy, x, w.view(n, k, 1, 1), None, (1, 1), (0, 0), (1, 1), False,
+                                                              (0, 0), 1, [need_x, need_w, False])
+            gx = gx2 if need_x else gx
+            gw = gw2.view(w.shape) if need_w else gw
+        return gx, gw, None
 
 
 def conv1x1_applies(conv, x):
-    """True when `conv(x)` can run on the MFMA GEMM: nn.Conv2d 1x1 / stride 1 / no bias, channels_last bf16 input, and a
-    shape the kernel takes (mrla_conv1x1_rows)."""
+    """True when `conv(x)` belongs on the HIP GEMMs: nn.Conv2d 1x1 / stride 1 / no bias, channels_last bf16 input, and a
+    shape the forward kernel (mrla_conv1x1_rows) or the weight-gradient kernel (mrla_conv1x1_wgrad_rows) takes."""
     if not (type(conv) is torch.nn.Conv2d and conv.kernel_size == (1, 1) and conv.stride == (1, 1)
             and conv.padding == (0, 0) and conv.dilation == (1, 1) and conv.groups == 1 and conv.bias is None):
         return False
     if not (x.is_cuda and x.dim() == 4 and x.dtype == torch.bfloat16 and x.is_contiguous(memory_format=_CL)
-            and x.data_ptr() % 16 == 0):               # (the kernel moves 16-byte fragments)
+            and x.data_ptr() % 16 == 0):               # (the kernels move 16-byte fragments)
         return False
     b, k, h, w = x.shape
-    return k == conv.in_channels and L.load().mrla_conv1x1_rows(b * h * w, k, conv.out_channels, L.BF16) > 0
+    if k != conv.in_channels:
+        return False
+    lib, m, n = L.load(), b * h * w, conv.out_channels
+    if lib.mrla_conv1x1_rows(m, k, n, L.BF16) > 0:
+        return True
+    return torch.is_grad_enabled() and conv.weight.requires_grad and lib.mrla_conv1x1_wgrad_rows(m, k, n, L.BF16) > 0
 
 
 def conv_bn_act(x, conv, bn, relu, defer=False):

@@ -123,3 +123,87 @@ def test_input_gradient_is_the_gemm_with_the_transposed_weight(shape):
     assert_bf16_close(got_dx, want_dx, "dx")
     want_dw = dy.reshape(m, n).astype(np.float64).T @ x.reshape(m, k).astype(np.float64)
     assert relmax(wtt.grad.float().cpu().numpy(), want_dw) < 2.0 ** -7
+
+
+# (b, h, w, k, n): every tile class (64/128/256 on either side), several tiles per extent, ragged pixel counts (not a
+# multiple of the 32-pixel chunk), fewer chunks than workgroups, a single pixel
+WGRAD_SHAPES = [(2, 56, 56, 64, 64), (2, 56, 56, 64, 256), (2, 56, 56, 256, 64), (2, 28, 28, 256, 128), (2, 28, 28, 512, 128),
+                (2, 28, 28, 128, 512), (2, 14, 14, 1024, 256), (2, 14, 14, 256, 1024), (3, 7, 7, 2048, 512),
+                (3, 7, 7, 512, 2048), (1, 5, 7, 128, 64), (1, 1, 1, 64, 128), (5, 12, 16, 192, 320), (2, 9, 9, 128, 128)]
+
+
+@pytest.mark.parametrize("shape", WGRAD_SHAPES, ids=lambda s: "x".join(map(str, s)))
+def test_weight_gradient_gemm(shape):
+    """dW[n,k] = sum_m dY[m,n] X[m,k] (mrla_conv1x1_wgrad through the C ABI) vs a float64 product of the same bf16 operands
+    rounded once to bf16; workspace rows as the library reports them; poisoned workspace and output (no memset needed)."""
+    import ctypes
+    from mrla_amd import _lib as L
+    b, h, w, k, n = shape
+    m = b * h * w
+    lib = L.load()
+    rows = lib.mrla_conv1x1_wgrad_rows(m, k, n, L.BF16)
+    assert rows > 0
+    x, _ = _operands(b, h, w, k, n, salt=3)
+    dy = bf16_round(detgen.normalish((b, h, w, n), detgen.seed_of(f"conv1x1/wgrad/dy/{m}/{k}/{n}")))
+    xt = torch.from_numpy(x).cuda().bfloat16().reshape(m, k)
+    dyt = torch.from_numpy(dy).cuda().bfloat16().reshape(m, n)
+    part = torch.full((rows, n, k), float("nan"), dtype=torch.float32, device="cuda")
+    dw = torch.full((n, k), float("nan"), dtype=torch.bfloat16, device="cuda")
+    st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+    L.call("mrla_conv1x1_wgrad", ctypes.c_void_p(dyt.data_ptr()), ctypes.c_void_p(xt.data_ptr()),
+           ctypes.c_void_p(part.data_ptr()), ctypes.c_void_p(dw.data_ptr()), m, k, n, L.BF16, st)
+    torch.cuda.synchronize()
+    want = dy.reshape(m, n).astype(np.float64).T @ x.reshape(m, k).astype(np.float64)
+    got = dw.float().cpu().numpy()
+    assert np.isfinite(got).all()
+    assert_bf16_close(got, want, "dw")
+    # the partial tiles themselves: their fp64 sum is the product to fp32 accuracy
+    psum = part.double().sum(0).cpu().numpy()
+    assert relmax(psum, want) < 1e-5
+
+
+def test_weight_gradient_unsupported_shapes_are_reported():
+    from mrla_amd import _lib as L
+    lib = L.load()
+    assert lib.mrla_conv1x1_wgrad_rows(64, 96, 64, L.BF16) == L.EUNSUPPORTED
+    assert lib.mrla_conv1x1_wgrad_rows(64, 64, 32, L.BF16) == L.EUNSUPPORTED
+    assert lib.mrla_conv1x1_wgrad_rows(64, 64, 64, L.F32) == L.EUNSUPPORTED
+    assert lib.mrla_conv1x1_wgrad_rows(1 << 24, 128, 64, L.BF16) == L.EUNSUPPORTED      # 32-bit buffer offsets
+    assert lib.mrla_conv1x1_wgrad_rows(0, 64, 64, L.BF16) == L.EINVAL
+    assert lib.mrla_conv1x1_wgrad_rows(1, 64, 64, L.BF16) == 1
+    assert lib.mrla_conv1x1_wgrad_rows(256 * 56 * 56, 64, 256, L.BF16) == 256           # one workgroup per CU
+
+
+def test_wide_reduction_convolution_takes_the_weight_gradient_gemm():
+    """A 1x1 convolution whose forward the GEMM does not take (c_in = 1024) still goes through _Conv1x1Fn in training so
+    that its weight gradient runs on mrla_conv1x1_wgrad: outputs and gradients agree with the stock modules'."""
+    from mrla_amd import functional as Fm
+    b, h, w, k, n = 4, 14, 14, 1024, 256
+    x, wt = _operands(b, h, w, k, n, salt=4)
+    conv = torch.nn.Conv2d(k, n, 1, bias=False).cuda().to(memory_format=torch.channels_last)
+    bn = torch.nn.BatchNorm2d(n).cuda()
+    with torch.no_grad():
+        conv.weight.copy_(torch.from_numpy(wt).view(n, k, 1, 1))
+    xt = torch.from_numpy(x).cuda().bfloat16().permute(0, 3, 1, 2).requires_grad_(True)
+    assert Fm.conv1x1_applies(conv, xt)
+    with torch.no_grad():
+        assert not Fm.conv1x1_applies(conv, xt)                  # nothing to gain without a backward
+    Fm.TIMER = timer = Fm.KernelTimer(["mrla_conv1x1_wgrad", "mrla_conv1x1_fwd"])
+    try:
+        out = Fm.conv_bn_act(xt, conv, bn, relu=True)
+        gup = torch.from_numpy(bf16_round(detgen.normalish((b, n, h, w), 19))).cuda().bfloat16().contiguous(memory_format=torch.channels_last)
+        out.backward(gup)
+        torch.cuda.synchronize()
+    finally:
+        Fm.TIMER = None
+    assert set(timer.summary()) == {"mrla_conv1x1_wgrad"}
+    conv_r = torch.nn.Conv2d(k, n, 1, bias=False).cuda().to(memory_format=torch.channels_last)
+    bn_r = torch.nn.BatchNorm2d(n).cuda()
+    conv_r.load_state_dict(conv.state_dict())
+    xr = xt.detach().clone().requires_grad_(True)
+    with torch.autocast("cuda", dtype=torch.bfloat16):
+        out_r = Fm.bn_act(conv_r(xr), bn_r, relu=True)
+    out_r.backward(gup)
+    assert ((out.float() - out_r.float()).norm() / out_r.float().norm()).item() < 1e-2       # (the solver may differ)
+    assert ((conv.weight.grad - conv_r.weight.grad).norm() / conv_r.weight.grad.norm()).item() < 1e-2
+    assert ((xt.grad.float() - xr.grad.float()).norm() / xr.grad.float().norm()).item() < 1e-2

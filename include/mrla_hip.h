@@ -306,6 +306,15 @@ int mrla_bn_act_bwd(const void* dy, const void* x, const float* sc, const float*
 int mrla_conv1x1_rows(int m, int k, int n, int dtype);      /* rows of mom_part (> 0), or a negative code */
 int mrla_conv1x1_fwd(const void* x, const void* w, void* y, float* mom_part, int m, int k, int n, int dtype, void* stream);
 
+/* y = x * w^T + addend in one pass (fp32 sum, one rounding).  Used for the input gradient of the bottleneck's conv1
+ * (resnet_mrla_light.py:93) with x = dY, w = W^T and addend = the gradient arriving at the block input through the
+ * shortcut (:110-114), which autograd would otherwise add in a separate elementwise pass.  addend: [m, n] like y; it may
+ * alias y.  Only the wide form (n % 256 == 0, k in {64, 128, 256}): mrla_conv1x1_add_supported returns 1 or
+ * MRLA_EUNSUPPORTED. */
+int mrla_conv1x1_add_supported(int m, int k, int n, int dtype);
+int mrla_conv1x1_fwd_add(const void* x, const void* w, const void* addend, void* y, int m, int k, int n, int dtype,
+                         void* stream);
+
 /* Weight gradient of the same convolution (the backward of the reference's nn.Conv2d(kernel_size=1) call sites above,
  * which the reference leaves to cuDNN):   dw[n, k] = sum_m dy[m, n] * x[m, k]
  *   dy: [m, n] and x: [m, k] channels_last activations (bf16), dw: [n, k] (bf16, fp32 accumulation),

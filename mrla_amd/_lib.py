@@ -64,6 +64,8 @@ SIGNATURES = {
     "mrla_bn_act_bwd": [_P, _P, _P, _P, _P, _I, _P, _I, _I, _I, _I, _I, _I, _P],
     "mrla_conv1x1_rows": [_I] * 4,
     "mrla_conv1x1_fwd": [_P, _P, _P, _P, _I, _I, _I, _I, _P],
+    "mrla_conv1x1_add_supported": [_I] * 4,
+    "mrla_conv1x1_fwd_add": [_P, _P, _P, _P, _I, _I, _I, _I, _P],
     "mrla_conv1x1_wgrad_rows": [_I] * 4,
     "mrla_conv1x1_wgrad": [_P, _P, _P, _P, _I, _I, _I, _I, _P],
     "mrla_reduce_rows": [_P, _P, _I, _I, _P],

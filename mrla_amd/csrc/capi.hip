@@ -471,6 +471,19 @@ int mrla_conv1x1_fwd(const void* x, const void* w, void* y, float* mom_part, int
   return launch_conv1x1_fwd(x, w, y, mom_part, m, k, n, (hipStream_t)stream);
 }
 
+int mrla_conv1x1_add_supported(int m, int k, int n, int dtype) {
+  if (m <= 0 || k <= 0 || n <= 0 || bad_dtype(dtype)) return MRLA_EINVAL;
+  if (dtype != MRLA_BF16) return MRLA_EUNSUPPORTED;
+  return conv1x1_wide_rows(m, k, n) > 0 ? 1 : MRLA_EUNSUPPORTED;
+}
+
+int mrla_conv1x1_fwd_add(const void* x, const void* w, const void* addend, void* y, int m, int k, int n, int dtype,
+                         void* stream) {
+  if (!x || !w || !addend || !y || m <= 0 || k <= 0 || n <= 0 || bad_dtype(dtype)) return MRLA_EINVAL;
+  if (dtype != MRLA_BF16) return MRLA_EUNSUPPORTED;
+  return launch_conv1x1_wide(x, w, addend, y, nullptr, m, k, n, (hipStream_t)stream);
+}
+
 int mrla_conv1x1_wgrad_rows(int m, int k, int n, int dtype) {
   if (m <= 0 || k <= 0 || n <= 0 || bad_dtype(dtype)) return MRLA_EINVAL;
   if (dtype != MRLA_BF16) return MRLA_EUNSUPPORTED;

@@ -234,11 +234,14 @@ static bool conv1x1_geo(GemmGeo* g, int M, int K, int N) {
 }
 
 int conv1x1_rows(int M, int K, int N) {
+  const int wide = conv1x1_wide_rows(M, K, N);                 // N % 256 == 0: the streaming kernel of conv1x1_wide.hip
+  if (wide > 0) return wide;
   GemmGeo g;
   return conv1x1_geo(&g, M, K, N) ? g.rows : MRLA_EUNSUPPORTED;
 }
 
 int launch_conv1x1_fwd(const void* x, const void* w, void* y, float* part, int M, int K, int N, hipStream_t st) {
+  if (conv1x1_wide_rows(M, K, N) > 0) return launch_conv1x1_wide(x, w, nullptr, y, part, M, K, N, st);
   GemmGeo g;
   if (!conv1x1_geo(&g, M, K, N)) return MRLA_EUNSUPPORTED;
   const dim3 grid(g.gx, g.gy), block(g.NW * kWave);

@@ -145,6 +145,10 @@ int nhwc_images_per_group(int B, int C, int W);
 // conv1x1.hip -- 1x1 convolution as an MFMA GEMM with a BatchNorm-moments epilogue (bf16)
 int conv1x1_rows(int M, int K, int N);
 int launch_conv1x1_fwd(const void* x, const void* w, void* y, float* part, int M, int K, int N, hipStream_t st);
+// conv1x1_wide.hip -- the same product for wide outputs (N % 256 == 0): X streamed through LDS, optional addend
+int conv1x1_wide_rows(int M, int K, int N);
+int launch_conv1x1_wide(const void* x, const void* w, const void* addend, void* y, float* part, int M, int K, int N,
+                        hipStream_t st);
 // conv1x1_wgrad.hip -- its weight gradient dW[n,k] = sum_m dY[m,n] X[m,k] as a split-M MFMA GEMM (bf16)
 int conv1x1_wgrad_rows(int M, int K, int N);
 int launch_conv1x1_wgrad(const void* dy, const void* x, float* part, void* dw, int M, int K, int N, hipStream_t st);

@@ -815,7 +815,7 @@ class _Conv1x1Fn(torch.autograd.Function):
 
     @staticmethod
     @_on_device
-    def forward(ctx, x, w, want_moments):
+    def forward(ctx, x, w, want_moments, passthrough=False):
         b, k, h, wd = x.shape
         n = w.shape[0]
         m = b * h * wd
@@ -834,11 +834,13 @@ class _Conv1x1Fn(torch.autograd.Function):
         if part is None:
             part = torch.empty(0, device=dev)
         ctx.mark_non_differentiable(part)
+        if passthrough:             # x itself as a third output: its gradient (the shortcut's) comes back to backward()
+            return y, part, x
         return y, part
 
     @staticmethod
     @_on_device
-    def backward(ctx, dy, _dpart=None):
+    def backward(ctx, dy, _dpart=None, d_through=None):
         x, w = ctx.saved_tensors
         dy = dy.contiguous(memory_format=_CL)
         n, k = w.shape
@@ -850,11 +852,21 @@ class _Conv1x1Fn(torch.autograd.Function):
         same = dy.dtype == x.dtype and dy.data_ptr() % 16 == 0
         # the input gradient is the same GEMM with the transposed weight: dX[m, k] = sum_n dY[m, n] * W^T[k, n]
         # (no memset of dX, as MIOpen's backward-data solver needs); shapes the kernel does not take stay on MIOpen
+        if d_through is not None and (d_through.dtype != x.dtype or not d_through.is_contiguous(memory_format=_CL)
+                                      or d_through.data_ptr() % 16):
+            d_through = d_through.to(x.dtype).contiguous(memory_format=_CL)
         if need_x and same and lib.mrla_conv1x1_rows(m, n, k, dt) > 0:
             gx = torch.empty_like(x)
             wt = w.t().contiguous()
-            _call("mrla_conv1x1_bwd_data", (dy.numel() + gx.numel()) * x.element_size(), _ptr(dy), _ptr(wt), _ptr(gx), None,
-                  m, n, k, dt, _stream(), entry="mrla_conv1x1_fwd")
+            if d_through is not None and lib.mrla_conv1x1_add_supported(m, n, k, dt) == 1:
+                # ... + the shortcut's gradient in the GEMM epilogue (fp32 sum, one rounding) instead of a separate
+                # accumulation pass over the block input's gradient
+                _call("mrla_conv1x1_bwd_data", (dy.numel() + 2 * gx.numel()) * x.element_size(), _ptr(dy), _ptr(wt),
+                      _ptr(d_through), _ptr(gx), m, n, k, dt, _stream(), entry="mrla_conv1x1_fwd_add")
+                d_through = None
+            else:
+                _call("mrla_conv1x1_bwd_data", (dy.numel() + gx.numel()) * x.element_size(), _ptr(dy), _ptr(wt), _ptr(gx),
+                      None, m, n, k, dt, _stream(), entry="mrla_conv1x1_fwd")
             need_x = False
         # the weight gradient dW[n, k] = sum_m dY[m, n] * X[m, k]: one pass over both activations, per-workgroup partial
         # tiles summed by a second kernel (MIOpen: memset + atomics into fp32 + a cast kernel)
@@ -871,7 +883,9 @@ class _Conv1x1Fn(torch.autograd.Function):
                                                               (0, 0), 1, [need_x, need_w, False])
             gx = gx2 if need_x else gx
             gw = gw2.view(w.shape) if need_w else gw
-        return gx, gw, None
+        if d_through is not None and ctx.needs_input_grad[0]:
+            gx = gx + d_through
+        return gx, gw, None, None
 
 
 def conv1x1_applies(conv, x):
@@ -892,16 +906,24 @@ def conv1x1_applies(conv, x):
     return torch.is_grad_enabled() and conv.weight.requires_grad and lib.mrla_conv1x1_wgrad_rows(m, k, n, L.BF16) > 0
 
 
-def conv_bn_act(x, conv, bn, relu, defer=False):
+def conv_bn_act(x, conv, bn, relu, defer=False, passthrough=False):
     """relu?(bn(conv(x))) -- resnet_mrla_light.py:93-94,100-101.  Eligible 1x1 convolutions run on the HIP GEMM, whose
     epilogue hands the train-mode BatchNorm its statistics (the moments pass over the output disappears); everything
-    else is `bn_act(conv(x), ...)` with the stock convolution."""
+    else is `bn_act(conv(x), ...)` with the stock convolution.
+    passthrough=True returns (result, x'), x' being x routed through the convolution's autograd node: a consumer that
+    uses x' as the block's shortcut (resnet_mrla_light.py:91,110-114) gets the shortcut gradient added inside the
+    convolution's input-gradient GEMM instead of by a separate accumulation pass."""
     fused_bn = (type(bn) is torch.nn.BatchNorm2d and bn.affine and bn.track_running_stats)
     if conv1x1_applies(conv, x):
         wt = conv.weight
         if wt.dtype != x.dtype:
             wt = wt.to(x.dtype)                      # what autocast does for the stock convolution (differentiable)
         wt = wt.reshape(conv.out_channels, conv.in_channels)
+        if passthrough and torch.is_grad_enabled() and x.requires_grad:
+            y, part, through = _Conv1x1Fn.apply(x, wt, bool(fused_bn and bn.training), True)
+            return bn_act(y, bn, relu, defer, pre_moments=part if part.numel() else None), through
         y, part = _Conv1x1Fn.apply(x, wt, bool(fused_bn and bn.training))
-        return bn_act(y, bn, relu, defer, pre_moments=part if part.numel() else None)
-    return bn_act(conv(x), bn, relu, defer)
+        out = bn_act(y, bn, relu, defer, pre_moments=part if part.numel() else None)
+        return (out, x) if passthrough else out
+    out = bn_act(conv(x), bn, relu, defer)
+    return (out, x) if passthrough else out

@@ -77,9 +77,13 @@ class _BottleneckTrunk(nn.Module):
         """Everything up to, but not including, the shortcut add + ReLU: (bn3 output, identity).
         defer_bn3 (bool, or a predicate on conv3's output): only bn3's statistics are taken here; its affine is applied
         by the consumer's first pass."""
-        identity = x
-        # 1x1 convolutions: HIP MFMA GEMM with the BatchNorm statistics in its epilogue when eligible (bf16, channels_last)
-        out = F_.conv_bn_act(x, self.conv1, self.bn1, relu=True)     # fused BatchNorm+ReLU HIP passes
+        # 1x1 convolutions: HIP MFMA GEMM with the BatchNorm statistics in its epilogue when eligible (bf16, channels_last).
+        # Without a downsample the shortcut is the block input itself: it is taken through conv1's autograd node so that
+        # its gradient is added in the epilogue of conv1's input-gradient GEMM.
+        if self.downsample is None:
+            out, identity = F_.conv_bn_act(x, self.conv1, self.bn1, relu=True, passthrough=True)
+        else:
+            out, identity = F_.conv_bn_act(x, self.conv1, self.bn1, relu=True), x
         out = F_.bn_act(self.conv2(out), self.bn2, relu=True)
         if self.se is not None or self.eca is not None:     # channel attention reads bn3's output: nothing to defer
             defer_bn3 = False

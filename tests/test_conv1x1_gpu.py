@@ -13,7 +13,8 @@ pytestmark = pytest.mark.gpu
 
 # (b, h, w, k, n): every ResNet-50 shape class the kernel takes (scaled-down batch) + a ragged pixel count + tiny N
 SHAPES = [(2, 56, 56, 64, 256), (2, 56, 56, 256, 64), (2, 56, 56, 64, 64), (2, 56, 56, 256, 128), (3, 28, 28, 128, 512),
-          (4, 14, 14, 256, 1024), (1, 4, 8, 64, 64), (5, 12, 16, 128, 192), (3, 7, 7, 64, 128), (1, 1, 1, 256, 64)]
+          (4, 14, 14, 256, 1024), (1, 4, 8, 64, 64), (5, 12, 16, 128, 192), (3, 7, 7, 64, 128), (1, 1, 1, 256, 64),
+          (1, 5, 7, 64, 256), (3, 7, 7, 256, 512), (2, 9, 9, 128, 256), (1, 1, 1, 256, 256)]   # wide form, ragged pixel counts
 
 
 def _operands(b, h, w, k, n, salt=0):
@@ -207,3 +208,76 @@ def test_wide_reduction_convolution_takes_the_weight_gradient_gemm():
     assert ((out.float() - out_r.float()).norm() / out_r.float().norm()).item() < 1e-2       # (the solver may differ)
     assert ((conv.weight.grad - conv_r.weight.grad).norm() / conv_r.weight.grad.norm()).item() < 1e-2
     assert ((xt.grad.float() - xr.grad.float()).norm() / xr.grad.float().norm()).item() < 1e-2
+
+
+@pytest.mark.parametrize("shape", [(2, 56, 56, 64, 256), (3, 28, 28, 128, 512), (4, 14, 14, 256, 1024), (1, 5, 7, 64, 256),
+                                   (2, 9, 9, 256, 256)], ids=lambda s: "x".join(map(str, s)))
+def test_gemm_with_addend_epilogue(shape):
+    """y = x w^T + addend (mrla_conv1x1_fwd_add): fp32 sum rounded once, vs a float64 product + addend; in place
+    (addend aliasing y) gives the same bits."""
+    import ctypes
+    from mrla_amd import _lib as L
+    b, h, w, k, n = shape
+    m = b * h * w
+    lib = L.load()
+    assert lib.mrla_conv1x1_add_supported(m, k, n, L.BF16) == 1
+    assert lib.mrla_conv1x1_add_supported(m, k, 64, L.BF16) == L.EUNSUPPORTED
+    x, wt = _operands(b, h, w, k, n, salt=5)
+    add = bf16_round(detgen.normalish((m, n), detgen.seed_of(f"conv1x1/add/{m}/{k}/{n}")))
+    xt = torch.from_numpy(x).cuda().bfloat16().reshape(m, k)
+    wtt = torch.from_numpy(wt).cuda().bfloat16()
+    at = torch.from_numpy(add).cuda().bfloat16()
+    y = torch.full((m, n), float("nan"), dtype=torch.bfloat16, device="cuda")
+    st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+    P = lambda t: ctypes.c_void_p(t.data_ptr())
+    L.call("mrla_conv1x1_fwd_add", P(xt), P(wtt), P(at), P(y), m, k, n, L.BF16, st)
+    torch.cuda.synchronize()
+    want = x.reshape(m, k).astype(np.float64) @ wt.astype(np.float64).T + add.astype(np.float64)
+    assert_bf16_close(y.float().cpu().numpy(), want, "y")
+    inplace = at.clone()
+    L.call("mrla_conv1x1_fwd_add", P(xt), P(wtt), P(inplace), P(inplace), m, k, n, L.BF16, st)
+    torch.cuda.synchronize()
+    assert torch.equal(inplace, y)
+
+
+@pytest.mark.parametrize("shape", [(4, 14, 14, 256, 64), (2, 28, 28, 512, 128), (3, 7, 7, 2048, 512)],
+                         ids=lambda s: "x".join(map(str, s)))
+def test_shortcut_gradient_joins_the_input_gradient_gemm(shape):
+    """conv_bn_act(..., passthrough=True): the second result is x routed through the convolution's autograd node; a
+    gradient arriving there (the shortcut's, resnet_mrla_light.py:110-114) must come out as dX + that gradient, whether
+    the GEMM epilogue adds it (c_in % 256 == 0, c_out <= 256) or the fallback does."""
+    from mrla_amd import _lib as L, functional as Fm
+    b, h, w, k, n = shape
+    m = b * h * w
+    x, wt = _operands(b, h, w, k, n, salt=6)
+    conv = torch.nn.Conv2d(k, n, 1, bias=False).cuda().to(memory_format=torch.channels_last)
+    bn = torch.nn.BatchNorm2d(n).cuda()
+    with torch.no_grad():
+        conv.weight.copy_(torch.from_numpy(wt).view(n, k, 1, 1))
+    xt = torch.from_numpy(x).cuda().bfloat16().permute(0, 3, 1, 2).requires_grad_(True)
+    g1 = torch.from_numpy(bf16_round(detgen.normalish((b, n, h, w), 29))).cuda().bfloat16().contiguous(memory_format=torch.channels_last)
+    g2 = torch.from_numpy(bf16_round(detgen.normalish((b, k, h, w), 31))).cuda().bfloat16().contiguous(memory_format=torch.channels_last)
+    Fm.TIMER = timer = Fm.KernelTimer(["mrla_conv1x1_bwd_data"])
+    try:
+        out, through = Fm.conv_bn_act(xt, conv, bn, relu=True, passthrough=True)
+        assert through.data_ptr() == xt.data_ptr() and through.grad_fn is not None
+        torch.autograd.backward([out, through], [g1, g2])
+        torch.cuda.synchronize()
+    finally:
+        Fm.TIMER = None
+    fused = L.load().mrla_conv1x1_add_supported(m, n, k, L.BF16) == 1
+    assert fused == (n <= 256)
+    assert len(timer.records) == (1 if n <= 256 else 0)
+    conv_r = torch.nn.Conv2d(k, n, 1, bias=False).cuda().to(memory_format=torch.channels_last)
+    bn_r = torch.nn.BatchNorm2d(n).cuda()
+    conv_r.load_state_dict(conv.state_dict())
+    xr = xt.detach().clone().requires_grad_(True)
+    with torch.autocast("cuda", dtype=torch.bfloat16):
+        out_r = Fm.bn_act(conv_r(xr), bn_r, relu=True)
+    torch.autograd.backward([out_r, xr * 1.0], [g1, g2])
+    assert ((xt.grad.float() - xr.grad.float()).norm() / xr.grad.float().norm()).item() < 1e-2
+    assert ((conv.weight.grad - conv_r.weight.grad).norm() / conv_r.weight.grad.norm()).item() < 1e-2
+    # without autograd (or for a convolution off the GEMM path) the second result is x itself
+    with torch.no_grad(), torch.autocast("cuda", dtype=torch.bfloat16):
+        o2, t2 = Fm.conv_bn_act(xt, conv, bn, relu=True, passthrough=True)
+    assert t2 is xt

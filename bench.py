@@ -276,7 +276,8 @@ def main():
                             "mrla_token_apply_fwd", "mrla_token_stats_bwd", "mrla_token_apply_bwd", "mrla_token_ln_bwd",
                             "mrla_light_stats_fwd_fused", "mrla_light_pool_fused", "mrla_light_apply_fwd_fused", "mrla_bn_plane_moments", "mrla_bn_act_fwd",
                             "mrla_bn_plane_dmoments", "mrla_bn_act_bwd",
-                            "mrla_conv1x1_fwd", "mrla_conv1x1_bwd_data", "mrla_conv1x1_wgrad"])
+                            "mrla_conv1x1_fwd", "mrla_conv1x1_bwd_data", "mrla_conv1x1_wgrad", "mrla_bn_relu_pool_fwd",
+                            "mrla_bn_relu_pool_dmoments", "mrla_bn_relu_pool_bwd"])
     # the timed region: exactly `steps` steps between barrier + synchronize
     if use_graph:
         dt = timed(step, args.steps, 0, dist_on)
@@ -314,7 +315,8 @@ def main():
                                       f"fp32 master weights, drop_path {args.drop_path}",
                           "global_batch": world * args.batch, "parallelism": f"dp{world}", "launch": launch,
                           "path": "eager restatement" if args.eager else
-                                  f"mrla_amd (HIP MRLA tails incl. shortcut add+ReLU, HIP BatchNorm+ReLU, stock convolutions; {layout})"},
+                                  f"mrla_amd (HIP MRLA tails incl. shortcut add+ReLU, HIP BatchNorm+ReLU(+stem max-pool), HIP MFMA GEMMs for the "
+                                  f"1x1 convolutions fwd / dgrad / wgrad where eligible, stock 3x3 / 7x7 / strided convolutions; {layout})"},
                "eager_launch_ms_per_step": round(1e3 * dt_eager / args.steps, 3),
                "roofline": roofline,
                "mrla_kernels": {k: {"launches": v["launches"], "ms_per_step": round(v["ms"] / args.steps, 3),

@@ -293,6 +293,21 @@ int mrla_bn_plane_dmoments(const void* dy, const void* x, const float* sc, const
 int mrla_bn_act_bwd(const void* dy, const void* x, const float* sc, const float* sh, const float* cb /*[c,3]*/, int relu,
                     void* dx, int b, int c, int h, int w, int dtype, int layout, void* stream);
 
+/* The stem tail maxpool3x3/s2/p1(relu(bn1(x))) (resnet/models/resnet_mrla_light.py:198-201; nn.MaxPool2d(kernel_size=3,
+ * stride=2, padding=1) after bn1/relu) without the full-size BatchNorm+ReLU tensor: MRLA_NHWC, c % 64 == 0.
+ *   forward : mrla_bn_plane_moments -> mrla_bn_stats_fwd -> mrla_bn_relu_pool_fwd   out[b,c,ho,wo], ho = (h-1)/2+1
+ *   backward: mrla_bn_relu_pool_dmoments -> mrla_bn_stats_bwd -> mrla_bn_relu_pool_bwd
+ *             dz = dP[window] at the window's first maximum (ATen's rule, on the values rounded to dtype) when that
+ *             maximum is > 0;  tmom[rows,c,2] = (sum dz, sum dz*x) with rows = mrla_bn_pool_rows();  dx = e*dz + f*x + h.
+ * mrla_bn_pool_rows returns MRLA_EUNSUPPORTED for MRLA_NCHW or c % 64 != 0: the caller keeps bn_act + its own pooling. */
+int mrla_bn_pool_rows(int b, int c, int h, int w, int dtype, int layout);
+int mrla_bn_relu_pool_fwd(const void* x, const float* sc, const float* sh, void* out, int b, int c, int h, int w, int dtype,
+                          int layout, void* stream);
+int mrla_bn_relu_pool_dmoments(const void* dp, const void* x, const float* sc, const float* sh, float* tmom, int b, int c,
+                               int h, int w, int dtype, int layout, void* stream);
+int mrla_bn_relu_pool_bwd(const void* dp, const void* x, const float* sc, const float* sh, const float* cb /*[c,3]*/,
+                          void* dx, int b, int c, int h, int w, int dtype, int layout, void* stream);
+
 /* =====================================================================================================
  * The 1x1 stride-1 convolutions in front of those BatchNorms as an MFMA GEMM whose epilogue takes the BatchNorm
  * statistics (first half; reference call sites resnet/models/resnet_mrla_light.py:93-94

@@ -62,6 +62,10 @@ SIGNATURES = {
     "mrla_bn_act_fwd": [_P, _P, _P, _I, _P, _I, _I, _I, _I, _I, _I, _P],
     "mrla_bn_plane_dmoments": [_P, _P, _P, _P, _I, _P, _I, _I, _I, _I, _I, _I, _P],
     "mrla_bn_act_bwd": [_P, _P, _P, _P, _P, _I, _P, _I, _I, _I, _I, _I, _I, _P],
+    "mrla_bn_pool_rows": [_I] * 6,
+    "mrla_bn_relu_pool_fwd": [_P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P],
+    "mrla_bn_relu_pool_dmoments": [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P],
+    "mrla_bn_relu_pool_bwd": [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P],
     "mrla_conv1x1_rows": [_I] * 4,
     "mrla_conv1x1_fwd": [_P, _P, _P, _P, _I, _I, _I, _I, _P],
     "mrla_conv1x1_add_supported": [_I] * 4,

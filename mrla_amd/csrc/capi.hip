@@ -459,6 +459,33 @@ int mrla_bn_act_bwd(const void* dy, const void* x, const float* sc, const float*
   return launch_affine_act(x, dy, cb, sc, sh, relu, dx, b, c, h * w, dtype, 1, (hipStream_t)stream);
 }
 
+int mrla_bn_pool_rows(int b, int c, int h, int w, int dtype, int layout) {
+  if (bad_dims(b, c, h, w) || bad_dtype(dtype)) return MRLA_EINVAL;
+  if (layout != MRLA_NHWC) return layout == MRLA_NCHW ? MRLA_EUNSUPPORTED : MRLA_EINVAL;
+  return bn_pool_rows(b, c, h, w);
+}
+
+int mrla_bn_relu_pool_fwd(const void* x, const float* sc, const float* sh, void* out, int b, int c, int h, int w, int dtype,
+                          int layout, void* stream) {
+  if (!x || !sc || !sh || !out || bad_dims(b, c, h, w) || bad_dtype(dtype)) return MRLA_EINVAL;
+  if (layout != MRLA_NHWC) return layout == MRLA_NCHW ? MRLA_EUNSUPPORTED : MRLA_EINVAL;
+  return launch_bn_relu_pool_fwd(x, sc, sh, out, b, c, h, w, dtype, (hipStream_t)stream);
+}
+
+int mrla_bn_relu_pool_dmoments(const void* dp, const void* x, const float* sc, const float* sh, float* tmom, int b, int c,
+                               int h, int w, int dtype, int layout, void* stream) {
+  if (!dp || !x || !sc || !sh || !tmom || bad_dims(b, c, h, w) || bad_dtype(dtype)) return MRLA_EINVAL;
+  if (layout != MRLA_NHWC) return layout == MRLA_NCHW ? MRLA_EUNSUPPORTED : MRLA_EINVAL;
+  return launch_bn_relu_pool_dmoments(dp, x, sc, sh, tmom, b, c, h, w, dtype, (hipStream_t)stream);
+}
+
+int mrla_bn_relu_pool_bwd(const void* dp, const void* x, const float* sc, const float* sh, const float* cb, void* dx, int b,
+                          int c, int h, int w, int dtype, int layout, void* stream) {
+  if (!dp || !x || !sc || !sh || !cb || !dx || bad_dims(b, c, h, w) || bad_dtype(dtype)) return MRLA_EINVAL;
+  if (layout != MRLA_NHWC) return layout == MRLA_NCHW ? MRLA_EUNSUPPORTED : MRLA_EINVAL;
+  return launch_bn_relu_pool_bwd(dp, x, sc, sh, cb, dx, b, c, h, w, dtype, (hipStream_t)stream);
+}
+
 int mrla_conv1x1_rows(int m, int k, int n, int dtype) {
   if (m <= 0 || k <= 0 || n <= 0 || bad_dtype(dtype)) return MRLA_EINVAL;
   if (dtype != MRLA_BF16) return MRLA_EUNSUPPORTED;

@@ -105,7 +105,6 @@ __global__ __launch_bounds__(NW * kWave) void conv1x1_fwd_kernel(
     }
 #pragma unroll
     for (int t = 0; t < 2; ++t) {
-      const int nloc = wn * 64 + t * 32;                               // first channel of the tile inside the slice
       // round to bf16 (pairs of neighbouring channels), statistics of the rounded values
       unsigned p[8];
 #pragma unroll

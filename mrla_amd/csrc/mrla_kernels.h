@@ -145,6 +145,14 @@ int nhwc_images_per_group(int B, int C, int W);
 // conv1x1.hip -- 1x1 convolution as an MFMA GEMM with a BatchNorm-moments epilogue (bf16)
 int conv1x1_rows(int M, int K, int N);
 int launch_conv1x1_fwd(const void* x, const void* w, void* y, float* part, int M, int K, int N, hipStream_t st);
+// stem_pool_nhwc.hip -- maxpool3x3/s2/p1(relu(bn(x))) without the intermediate tensor (channels_last, C % 64 == 0)
+int bn_pool_rows(int B, int C, int H, int W);
+int launch_bn_relu_pool_fwd(const void* x, const float* sc, const float* sh, void* out, int B, int C, int H, int W,
+                            int dtype, hipStream_t st);
+int launch_bn_relu_pool_dmoments(const void* dp, const void* x, const float* sc, const float* sh, float* tmom, int B,
+                                 int C, int H, int W, int dtype, hipStream_t st);
+int launch_bn_relu_pool_bwd(const void* dp, const void* x, const float* sc, const float* sh, const float* cb, void* dx,
+                            int B, int C, int H, int W, int dtype, hipStream_t st);
 // conv1x1_wide.hip -- the same product for wide outputs (N % 256 == 0): X streamed through LDS, optional addend
 int conv1x1_wide_rows(int M, int K, int N);
 int launch_conv1x1_wide(const void* x, const void* w, const void* addend, void* y, float* part, int M, int K, int N,

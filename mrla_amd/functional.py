@@ -804,6 +804,86 @@ def bn_act(x, bn, relu, defer=False, pre_moments=None):
     return torch.relu(y) if relu else y
 
 
+class _BnReluPoolFn(torch.autograd.Function):
+    """maxpool3x3/s2/p1(relu(BatchNorm2d(x))) on a channels_last tensor without the full-size intermediate
+    (mrla_bn_relu_pool_*; resnet_mrla_light.py:198-201).  The statistics pass and the running-stat update are
+    _BnActFn's; the window maximum follows ATen's first-maximum rule on the rounded values."""
+
+    @staticmethod
+    @_on_device
+    def forward(ctx, x, gamma, beta, running_mean, running_var, training, momentum, eps):
+        _require_cuda(x, "fused bn/relu/maxpool forward")
+        layout, xc = _layout_of(x, L.NHWC)
+        b, c, h, w = xc.shape
+        dt, dev, st = _DT[xc.dtype], xc.device, _stream()
+        gamma32, beta32 = _f32(gamma), _f32(beta)
+        rs = _RunningStats(running_mean, running_var, c, "fused bn/relu/maxpool forward")
+        bnbuf = torch.empty((4, c), dtype=torch.float32, device=dev)       # sc, sh, save_mean, save_inv
+        rows = L.load().mrla_bn_moment_rows(b, c, h, w, layout)
+        amom = torch.empty((rows, c, 2), dtype=torch.float32, device=dev)
+        pivot = None
+        if training:
+            pivot = torch.empty((c,), dtype=torch.float32, device=dev)
+            _call("mrla_bn_plane_moments", xc.numel() * xc.element_size(), _ptr(xc), _ptr(amom), _ptr(pivot), b, c, h, w, dt,
+                  layout, st)
+        L.call("mrla_bn_stats_fwd", _ptr(amom), _ptr(pivot), _ptr(gamma32), _ptr(beta32), _ptr(rs.rm), _ptr(rs.rv),
+               L.BN_TRAIN if training else L.BN_EVAL, float(momentum), float(eps), _ptr(bnbuf[0]), _ptr(bnbuf[1]),
+               _ptr(bnbuf[2]), _ptr(bnbuf[3]), rows, c, b * h * w // rows, st)
+        rs.finish(training)
+        ho, wo = (h - 1) // 2 + 1, (w - 1) // 2 + 1
+        out = torch.empty((b, c, ho, wo), dtype=xc.dtype, device=dev, memory_format=_CL)
+        _call("mrla_bn_relu_pool_fwd", (xc.numel() + out.numel()) * xc.element_size(), _ptr(xc), _ptr(bnbuf[0]),
+              _ptr(bnbuf[1]), _ptr(out), b, c, h, w, dt, layout, st)
+        ctx.training, ctx.gdtype = training, gamma.dtype
+        ctx.save_for_backward(xc, gamma32, bnbuf)
+        return out
+
+    @staticmethod
+    @_on_device
+    def backward(ctx, dp):
+        xc, gamma32, bnbuf = ctx.saved_tensors
+        b, c, h, w = xc.shape
+        dt, dev, st = _DT[xc.dtype], xc.device, _stream()
+        if dp.dtype != xc.dtype:
+            dp = dp.to(xc.dtype)
+        dp = _layout_of(dp, L.NHWC)[1]
+        es = xc.element_size()
+        rows = L.load().mrla_bn_pool_rows(b, c, h, w, dt, L.NHWC)
+        L.check(min(rows, 0), "mrla_bn_pool_rows")
+        tmom = torch.empty((rows, c, 2), dtype=torch.float32, device=dev)
+        _call("mrla_bn_relu_pool_dmoments", (xc.numel() + dp.numel()) * es, _ptr(dp), _ptr(xc), _ptr(bnbuf[0]), _ptr(bnbuf[1]),
+              _ptr(tmom), b, c, h, w, dt, L.NHWC, st)
+        small = torch.empty((5, c), dtype=torch.float32, device=dev)          # cb[c,3] | dgamma | dbeta
+        cb = small[:3].view(c, 3)
+        L.call("mrla_bn_stats_bwd", _ptr(tmom), _ptr(gamma32), _ptr(bnbuf[2]), _ptr(bnbuf[3]),
+               L.BN_TRAIN if ctx.training else L.BN_EVAL, _ptr(cb), _ptr(small[3]), _ptr(small[4]), rows, c,
+               b * h * w // rows, st)
+        dx = None
+        if ctx.needs_input_grad[0]:
+            dx = torch.empty_like(xc)
+            _call("mrla_bn_relu_pool_bwd", (2 * xc.numel() + dp.numel()) * es, _ptr(dp), _ptr(xc), _ptr(bnbuf[0]),
+                  _ptr(bnbuf[1]), _ptr(cb), _ptr(dx), b, c, h, w, dt, L.NHWC, st)
+        return dx, small[3].to(ctx.gdtype), small[4].to(ctx.gdtype), None, None, None, None, None
+
+
+def bn_relu_maxpool(x, bn, pool):
+    """pool(relu(bn(x))) for the ResNet stem (nn.BatchNorm2d, then nn.MaxPool2d(kernel_size=3, stride=2, padding=1),
+    resnet_mrla_light.py:198-201): one fused pass per direction when x is a channels_last CUDA tensor with c % 64 == 0;
+    any other configuration runs `pool(bn_act(x, bn, relu=True))`."""
+    def _pair(v):
+        return tuple(v) if isinstance(v, (tuple, list)) else (v, v)
+    if (type(bn) is torch.nn.BatchNorm2d and bn.affine and bn.track_running_stats and type(pool) is torch.nn.MaxPool2d
+            and _pair(pool.kernel_size) == (3, 3) and _pair(pool.stride) == (2, 2) and _pair(pool.padding) == (1, 1)
+            and _pair(pool.dilation) == (1, 1) and not pool.ceil_mode and not pool.return_indices
+            and x.is_cuda and x.dim() == 4 and x.dtype in _DT and x.is_contiguous(memory_format=_CL)
+            and x.data_ptr() % 16 == 0
+            and L.load().mrla_bn_pool_rows(x.shape[0], x.shape[1], x.shape[2], x.shape[3], _DT[x.dtype], L.NHWC) > 0):
+        training = bn.training
+        momentum = bump_batch_counter(bn) if training else bn.momentum
+        return _BnReluPoolFn.apply(x, bn.weight, bn.bias, bn.running_mean, bn.running_var, training, momentum or 0.0, bn.eps)
+    return pool(bn_act(x, bn, relu=True))
+
+
 # ======================================================================================================
 # 1x1 stride-1 convolution as an MFMA GEMM with the BatchNorm statistics in its epilogue (SURVEY.md 8f rank 1)
 # ======================================================================================================

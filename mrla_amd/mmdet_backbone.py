@@ -93,7 +93,7 @@ class ResNet_mrlal(_ResNetMRLA):
     def forward_features(self, x):
         if self.channels_last and x.is_cuda:
             x = x.contiguous(memory_format=torch.channels_last)
-        x = self.maxpool(F_.bn_act(self.conv1(x), self.bn1, relu=True))
+        x = F_.bn_relu_maxpool(self.conv1(x), self.bn1, self.maxpool)
         outs = []
         for stage in (self.layer1, self.layer2, self.layer3, self.layer4):
             x = stage(x)

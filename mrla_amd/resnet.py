@@ -242,7 +242,7 @@ class ResNet_mrlal(_ResNetMRLA):
         if self.channels_last and x.is_cuda:
             x = x.contiguous(memory_format=torch.channels_last)
         with F_.batched_bookkeeping(self._stochastic_depth_blocks()):
-            x = self.maxpool(F_.bn_act(self.conv1(x), self.bn1, relu=True))
+            x = F_.bn_relu_maxpool(self.conv1(x), self.bn1, self.maxpool)
             return self.layer4(self.layer3(self.layer2(self.layer1(x))))
 
 
@@ -284,7 +284,7 @@ class ResNet_mrlab(_ResNetMRLA):
         if self.channels_last and x.is_cuda:
             x = x.contiguous(memory_format=torch.channels_last)
         with F_.batched_bookkeeping(self._stochastic_depth_blocks()):
-            x = self.maxpool(F_.bn_act(self.conv1(x), self.bn1, relu=True))
+            x = F_.bn_relu_maxpool(self.conv1(x), self.bn1, self.maxpool)
             k = v = None
             for stage in self.stages:
                 for blk in stage:

@@ -50,7 +50,9 @@ def parse():
     ap.add_argument("--eager", action="store_true", help="time the eager restatement instead (diagnostic)")
     ap.add_argument("--channels-last", type=int, default=-1,
                     help="1 / 0: force torch.channels_last on / off; -1: the model class default (on for resnet*_mrlal)")
-    ap.add_argument("--benchmark", type=int, default=0, help="torch.backends.cudnn.benchmark (resnet/train.py:247 sets it)")
+    ap.add_argument("--benchmark", type=int, default=1,
+                    help="torch.backends.cudnn.benchmark for the timed model: 1 as resnet/train.py:247 sets it (MIOpen picks its "
+                         "solvers by measuring them during the warm-up steps), 0 for MIOpen's immediate-mode choice")
     ap.add_argument("--graph", type=int, default=-1,
                     help="1: the timed steps replay the whole step (fwd+bwd+SGD) from one HIP graph; 0: launched kernel by "
                          "kernel; -1 (default): 1 on a single GPU, 0 under torch.distributed")
@@ -144,7 +146,7 @@ def eager_rocm(arch, batch, drop_path, steps=6):
             "warmup_s_benchmark_false": fwd[False][1], "warmup_s_benchmark_true": fwd[True][1],
             "what": "oracle/eager_models.py (stock ATen/MIOpen ops) on this GPU, same batch/dtype/optimizer; forward "
                     "timed with torch.backends.cudnn.benchmark False and True (resnet/train.py:247), the faster one is "
-                    "fwd_images_per_sec; fwd_bwd with benchmark False"}
+                    f"fwd_images_per_sec; fwd_bwd with the flag as the product run has it ({bool(was)})"}
 
 
 def forward_only(net, x, steps=10, graph=True):

@@ -293,7 +293,7 @@ int mrla_bn_plane_dmoments(const void* dy, const void* x, const float* sc, const
 int mrla_bn_act_bwd(const void* dy, const void* x, const float* sc, const float* sh, const float* cb /*[c,3]*/, int relu,
                     void* dx, int b, int c, int h, int w, int dtype, int layout, void* stream);
 
-/* The stem tail maxpool3x3/s2/p1(relu(bn1(x))) (resnet/models/resnet_mrla_light.py:198-201; nn.MaxPool2d(kernel_size=3,
+/* The stem tail maxpool3x3/s2/p1(relu(bn1(x))) (resnet/models/resnet_mrla_light.py:220-222; nn.MaxPool2d(kernel_size=3,
  * stride=2, padding=1) after bn1/relu) without the full-size BatchNorm+ReLU tensor: MRLA_NHWC, c % 64 == 0.
  *   forward : mrla_bn_plane_moments -> mrla_bn_stats_fwd -> mrla_bn_relu_pool_fwd   out[b,c,ho,wo], ho = (h-1)/2+1
  *   backward: mrla_bn_relu_pool_dmoments -> mrla_bn_stats_bwd -> mrla_bn_relu_pool_bwd

@@ -1,5 +1,5 @@
 // ResNet stem tail  maxpool3x3/s2/p1(relu(bn1(x)))  on a channels_last tensor, C % 64 == 0, without materialising the
-// BatchNorm+ReLU output (resnet/models/resnet_mrla_light.py:198-201: `x = self.bn1(x); x = self.relu(x); x = self.maxpool(x)`
+// BatchNorm+ReLU output (resnet/models/resnet_mrla_light.py:220-222: `x = self.bn1(x); x = self.relu(x); x = self.maxpool(x)`
 // on the 112x112x64 convolution output -- 411 MB at b = 256 in bf16, the largest activation of the network):
 //   forward : out[ho, wo]   = max over the window of a,  a = round_T(relu(sc*x + sh))           (1 read of x, 1/4 write)
 //   moments : tmom[row,c,0] = sum dz, [..,1] = sum dz*x,  dz = dP[window] at the window's first maximum if it is > 0

@@ -806,7 +806,7 @@ def bn_act(x, bn, relu, defer=False, pre_moments=None):
 
 class _BnReluPoolFn(torch.autograd.Function):
     """maxpool3x3/s2/p1(relu(BatchNorm2d(x))) on a channels_last tensor without the full-size intermediate
-    (mrla_bn_relu_pool_*; resnet_mrla_light.py:198-201).  The statistics pass and the running-stat update are
+    (mrla_bn_relu_pool_*; resnet_mrla_light.py:220-222).  The statistics pass and the running-stat update are
     _BnActFn's; the window maximum follows ATen's first-maximum rule on the rounded values."""
 
     @staticmethod
@@ -868,7 +868,7 @@ class _BnReluPoolFn(torch.autograd.Function):
 
 def bn_relu_maxpool(x, bn, pool):
     """pool(relu(bn(x))) for the ResNet stem (nn.BatchNorm2d, then nn.MaxPool2d(kernel_size=3, stride=2, padding=1),
-    resnet_mrla_light.py:198-201): one fused pass per direction when x is a channels_last CUDA tensor with c % 64 == 0;
+    resnet_mrla_light.py:220-222): one fused pass per direction when x is a channels_last CUDA tensor with c % 64 == 0;
     any other configuration runs `pool(bn_act(x, bn, relu=True))`."""
     def _pair(v):
         return tuple(v) if isinstance(v, (tuple, list)) else (v, v)

@@ -78,12 +78,10 @@ class _BottleneckTrunk(nn.Module):
         defer_bn3 (bool, or a predicate on conv3's output): only bn3's statistics are taken here; its affine is applied
         by the consumer's first pass."""
         # 1x1 convolutions: HIP MFMA GEMM with the BatchNorm statistics in its epilogue when eligible (bf16, channels_last).
-        # Without a downsample the shortcut is the block input itself: it is taken through conv1's autograd node so that
-        # its gradient is added in the epilogue of conv1's input-gradient GEMM.
-        if self.downsample is None:
-            out, identity = F_.conv_bn_act(x, self.conv1, self.bn1, relu=True, passthrough=True)
-        else:
-            out, identity = F_.conv_bn_act(x, self.conv1, self.bn1, relu=True), x
+        # The block input's second consumer -- the shortcut itself, or the downsample branch -- takes it through conv1's
+        # autograd node, so that its gradient is added in the epilogue of conv1's input-gradient GEMM instead of by
+        # autograd's accumulation pass.
+        out, identity = F_.conv_bn_act(x, self.conv1, self.bn1, relu=True, passthrough=True)
         out = F_.bn_act(self.conv2(out), self.bn2, relu=True)
         if self.se is not None or self.eca is not None:     # channel attention reads bn3's output: nothing to defer
             defer_bn3 = False
@@ -100,9 +98,9 @@ class _BottleneckTrunk(nn.Module):
         if self.downsample is not None:
             ds = self.downsample
             if isinstance(ds, nn.Sequential) and len(ds) == 2 and isinstance(ds[0], nn.Conv2d):
-                identity = F_.conv_bn_act(x, ds[0], ds[1], relu=False)
+                identity = F_.conv_bn_act(identity, ds[0], ds[1], relu=False)
             else:
-                identity = ds(x)
+                identity = ds(identity)
         return out, identity
 
     def trunk(self, x):

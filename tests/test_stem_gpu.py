@@ -1,4 +1,4 @@
-"""GPU parity of the fused stem tail maxpool3x3/s2/p1(relu(bn1(x))) (mrla_bn_relu_pool_*; resnet_mrla_light.py:198-201)
+"""GPU parity of the fused stem tail maxpool3x3/s2/p1(relu(bn1(x))) (mrla_bn_relu_pool_*; resnet_mrla_light.py:220-222)
 against the stock modules nn.BatchNorm2d -> relu -> nn.MaxPool2d on the same tensors: outputs, running statistics and every
 gradient, train and eval mode, odd / even / ragged spatial sizes, fp32 and bf16."""
 import pytest

@@ -8,6 +8,10 @@
 #include "mrla_device.h"
 #include "mrla_kernels.h"
 
+#ifndef MRLA_REVERSE_AFFINE
+#define MRLA_REVERSE_AFFINE 1
+#endif
+
 namespace mrla {
 
 template <typename T> struct V16 { typedef T type __attribute__((ext_vector_type(16 / sizeof(T)))); };
@@ -264,7 +268,9 @@ __global__ __launch_bounds__(kThreads) void nhwc_affine_flat_kernel(const T* __r
   ldf<VEC>(sc + c0, scv);
   ldf<VEC>(sh + c0, shv);
   if constexpr (BWD) ldf<3 * VEC>(a + (size_t)c0 * 3, cbv);
-  size_t e = (size_t)blockIdx.x * iters * STEP + (size_t)threadIdx.x * VEC;
+  // the workgroups walk the tensor from its END: the statistics pass that ran just before left the end in the cache
+  const size_t bx = MRLA_REVERSE_AFFINE ? gridDim.x - 1 - blockIdx.x : blockIdx.x;
+  size_t e = bx * iters * STEP + (size_t)threadIdx.x * VEC;
   auto one = [&](const float (&xv)[VEC], const float (&gv)[VEC], size_t at) {
     float y[VEC];
 #pragma unroll

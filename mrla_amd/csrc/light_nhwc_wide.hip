@@ -10,6 +10,23 @@
 #include "light_nhwc.h"
 #include "nhwc_rows.h"
 
+#ifndef MRLA_REVERSE_APPLY
+#define MRLA_REVERSE_APPLY 1
+#endif
+#ifndef MRLA_STREAM_MB
+#define MRLA_STREAM_MB 128
+#endif
+// Cache policy of the row fetches (template AUX: 0 = default, 2 = nt / streaming) and image order, measured in the
+// training step (b = 256, same box, GB/s):            stats_fwd_fused  apply_fwd  stats_bwd  apply_bwd
+//   default policy, images in launch order                  4069         4681       4773       4846
+//   nt fetches in the three 3N passes (tensors >= 128 MB)   4273         4789       5034       4636
+//   ... and apply_* walking the images in reverse order     4258         4991       5017       4667
+// `nt` keeps a pass from competing for the Infinity Cache with the write-back of its predecessor's lines (+5 %), and the
+// pass that follows the statistics pass finds the END of the tensors in the cache, so it starts there (apply_fwd +4 %).
+// But apply_bwd loses 4 % when stats_bwd streams (it lives off what stats_bwd leaves behind), and its own 9- / 11-pixel
+// row pieces overlap between neighbouring strips, which `nt` re-fetches from HBM.  Hence: nt for the two FORWARD passes
+// on tensors far beyond the cache, default policy for both backward passes, reverse image order in both apply passes.
+
 namespace mrla {
 
 // Per-wave LDS row buffers follow the cross-wave reduction area.
@@ -95,7 +112,7 @@ __device__ __forceinline__ void store_moments(WaveMoments& w, float* __restrict_
 // ------------------------------------------------------------------------------------------------
 template <typename T> constexpr int stats_bwd_wave_bytes() { return RowIO<T, kS + 2>::kBytes + 2 * RowIO<T, kS>::kBytes; }
 
-template <typename T, bool GELU, bool HAS_O>
+template <typename T, bool GELU, bool HAS_O, int AUX>
 __global__ __launch_bounds__(kMaxStrips * kWave) void light_stats_bwd_wide(
     const T* __restrict__ dout, const T* __restrict__ x, const T* __restrict__ o, const float* __restrict__ wv,
     float* __restrict__ bmom, int B, int C, int H, int W, int BG) {
@@ -122,12 +139,12 @@ __global__ __launch_bounds__(kMaxStrips * kWave) void light_stats_bwd_wide(
       RawRow<kS + 2> xa, xb, xc;                     // x rows r-1, r, r+1 on columns s0-1 .. s0+kS
       RawRow<kS> gv, ov;
       xa.clear(); xb.clear(); xc.clear(); gv.clear(); ov.clear();
-      row_fetch<T, kS + 2>(ax, xi, 0, H, rowelems, bufX);
+      row_fetch<T, kS + 2, AUX>(ax, xi, 0, H, rowelems, bufX);
       rows_landed();
       row_read<T, kS + 2>(bufX, lane, xb);
-      row_fetch<T, kS + 2>(ax, xi, 1, H, rowelems, bufX);
-      row_fetch<T, kS>(ag, gi, 0, H, rowelems, bufG);
-      if (HAS_O) row_fetch<T, kS>(ag, oi, 0, H, rowelems, bufO);
+      row_fetch<T, kS + 2, AUX>(ax, xi, 1, H, rowelems, bufX);
+      row_fetch<T, kS, AUX>(ag, gi, 0, H, rowelems, bufG);
+      if (HAS_O) row_fetch<T, kS, AUX>(ag, oi, 0, H, rowelems, bufO);
       // dOut (and o) are zero beyond the image, so columns of a ragged last strip drop out of every sum by themselves
       auto step = [&](int r, RawRow<kS + 2>& XA, RawRow<kS + 2>& XB, RawRow<kS + 2>& XC) {
         rows_landed();
@@ -137,9 +154,9 @@ __global__ __launch_bounds__(kMaxStrips * kWave) void light_stats_bwd_wide(
         row_read_fence(XC, true);
         row_read_fence(gv, false);
         if (HAS_O) row_read_fence(ov, false);
-        row_fetch<T, kS + 2>(ax, xi, r + 2, H, rowelems, bufX);
-        row_fetch<T, kS>(ag, gi, r + 1, H, rowelems, bufG);
-        if (HAS_O) row_fetch<T, kS>(ag, oi, r + 1, H, rowelems, bufO);
+        row_fetch<T, kS + 2, AUX>(ax, xi, r + 2, H, rowelems, bufX);
+        row_fetch<T, kS, AUX>(ag, gi, r + 1, H, rowelems, bufG);
+        if (HAS_O) row_fetch<T, kS, AUX>(ag, oi, r + 1, H, rowelems, bufO);
 #pragma unroll
         for (int j = 0; j < kS; ++j) {
           float v = conv_at(w, XA.v, XB.v, XC.v, j);
@@ -284,7 +301,7 @@ __device__ __forceinline__ void form_x_row(const RawRow<kS + 2>& pre, const RawR
 // per wave: pre row, two o rows (row r is read again when V[r] is paired with it), one store buffer
 template <typename T> constexpr int fused_wave_bytes() { return 3 * RowIO<T, kS + 2>::kBytes + RowIO<T, kS>::kBytes; }
 
-template <typename T, bool AFF, bool RAGGED>
+template <typename T, bool AFF, bool RAGGED, int AUX>
 __global__ __launch_bounds__(kMaxStrips * kWave) void light_stats_fwd_fused_wide(
     const T* __restrict__ pre, const T* __restrict__ o, const float* __restrict__ wv, float* __restrict__ mom,
     T* __restrict__ xout, const float* __restrict__ psc, const float* __restrict__ psh, T* __restrict__ vout, int B,
@@ -330,13 +347,13 @@ __global__ __launch_bounds__(kMaxStrips * kWave) void light_stats_fwd_fused_wide
       };
 #pragma unroll
       for (int j = 0; j < kS + 2; ++j) xa[j] = 0.f;
-      row_fetch<T, kS + 2>(ax, pi, 0, H, rowelems, bufP);
-      row_fetch<T, kS + 2>(ax, oi, 0, H, rowelems, obuf(0));
+      row_fetch<T, kS + 2, AUX>(ax, pi, 0, H, rowelems, bufP);
+      row_fetch<T, kS + 2, AUX>(ax, oi, 0, H, rowelems, obuf(0));
       rows_landed();
       row_read<T, kS + 2>(bufP, lane, praw);
       row_read<T, kS + 2>(obuf(0), lane, oraw);
-      row_fetch<T, kS + 2>(ax, pi, 1, H, rowelems, bufP);
-      row_fetch<T, kS + 2>(ax, oi, 1, H, rowelems, obuf(1));
+      row_fetch<T, kS + 2, AUX>(ax, pi, 1, H, rowelems, bufP);
+      row_fetch<T, kS + 2, AUX>(ax, oi, 1, H, rowelems, obuf(1));
       form_x_row<T, AFF, RAGGED>(praw, oraw, asc, shj, xb);
       store_owned(xo, 0, xb);
       auto step = [&](int r, float (&XA)[kS + 2], float (&XB)[kS + 2], float (&XC)[kS + 2]) {
@@ -350,8 +367,8 @@ __global__ __launch_bounds__(kMaxStrips * kWave) void light_stats_fwd_fused_wide
         row_read_fence(praw, true);
         row_read_fence(oraw, false);
         row_read_fence(ov, false);
-        row_fetch<T, kS + 2>(ax, pi, r + 2, H, rowelems, bufP);
-        row_fetch<T, kS + 2>(ax, oi, r + 2, H, rowelems, obuf(r));
+        row_fetch<T, kS + 2, AUX>(ax, pi, r + 2, H, rowelems, bufP);
+        row_fetch<T, kS + 2, AUX>(ax, oi, r + 2, H, rowelems, obuf(r));
         if (r + 1 < H) {
           form_x_row<T, AFF, RAGGED>(praw, oraw, asc, shj, XC);
           store_owned(xo, r + 1, XC);
@@ -390,7 +407,7 @@ __global__ __launch_bounds__(kMaxStrips * kWave) void light_stats_fwd_fused_wide
 // ------------------------------------------------------------------------------------------------
 template <typename T> constexpr int apply_fwd_wave_bytes() { return RowIO<T, kS + 2>::kBytes + 2 * RowIO<T, kS>::kBytes; }
 
-template <typename T, bool GELU, bool HAS_O>
+template <typename T, bool GELU, bool HAS_O, int AUX>
 __global__ __launch_bounds__(kMaxStrips * kWave) void light_apply_fwd_wide(
     const T* __restrict__ x, const T* __restrict__ o, const float* __restrict__ wv, const float* __restrict__ gate,
     const float* __restrict__ sc, const float* __restrict__ sh, const float* __restrict__ lam,
@@ -405,8 +422,9 @@ __global__ __launch_bounds__(kMaxStrips * kWave) void light_apply_fwd_wide(
   for (int k = 0; k < 9; ++k) w0[k] = wv[c * 9 + k];
   const float scc = sc ? sc[c] : 1.f, shc = sh ? sh[c] : 0.f, lmc = (HAS_O && lam) ? lam[c] : 0.f;
   const float resf = res ? 1.f : 0.f;
-  const int b_end = min(B, (int)(blockIdx.y + 1) * BG);
-  for (int b = blockIdx.y * BG; b < b_end; ++b) {
+  const int yy = MRLA_REVERSE_APPLY ? (int)(gridDim.y - 1 - blockIdx.y) : (int)blockIdx.y;   // (see the note at the top)
+  const int b_end = min(B, (yy + 1) * BG);
+  for (int b = yy * BG; b < b_end; ++b) {
     const size_t ioff = (size_t)b * H * rowelems;
     const T* xi = x + ioff;
     const T* oi = HAS_O ? o + ioff : nullptr;
@@ -429,11 +447,11 @@ __global__ __launch_bounds__(kMaxStrips * kWave) void light_apply_fwd_wide(
       RawRow<kS + 2> xa, xb, xc;
       RawRow<kS> ov;
       xa.clear(); xb.clear(); xc.clear(); ov.clear();
-      row_fetch<T, kS + 2>(ax, xi, 0, H, rowelems, bufX);
+      row_fetch<T, kS + 2, AUX>(ax, xi, 0, H, rowelems, bufX);
       rows_landed();
       row_read<T, kS + 2>(bufX, lane, xb);
-      row_fetch<T, kS + 2>(ax, xi, 1, H, rowelems, bufX);
-      if (HAS_O) row_fetch<T, kS>(ao, oi, 0, H, rowelems, bufO);
+      row_fetch<T, kS + 2, AUX>(ax, xi, 1, H, rowelems, bufX);
+      if (HAS_O) row_fetch<T, kS, AUX>(ao, oi, 0, H, rowelems, bufO);
       auto step = [&](int r, RawRow<kS + 2>& XA, RawRow<kS + 2>& XB, RawRow<kS + 2>& XC) {
         // the previous step's output row (its newest memory instructions) may stay in flight
         if (r == 0) rows_landed(); else rows_landed_keep<RowIO<T, kS>::NL>();
@@ -441,8 +459,8 @@ __global__ __launch_bounds__(kMaxStrips * kWave) void light_apply_fwd_wide(
         if (HAS_O) row_read_issue<T, kS>(bufO, lane, ov);
         row_read_fence(XC, true);
         if (HAS_O) row_read_fence(ov, false);
-        row_fetch<T, kS + 2>(ax, xi, r + 2, H, rowelems, bufX);
-        if (HAS_O) row_fetch<T, kS>(ao, oi, r + 1, H, rowelems, bufO);
+        row_fetch<T, kS + 2, AUX>(ax, xi, r + 2, H, rowelems, bufX);
+        if (HAS_O) row_fetch<T, kS, AUX>(ao, oi, r + 1, H, rowelems, bufO);
         float y[kS];
 #pragma unroll
         for (int j = 0; j < kS; ++j) {
@@ -581,8 +599,9 @@ __global__ __launch_bounds__(kBwdWaves * kWave) void light_apply_bwd_wide(
   const float lm = (HAS_O && lam) ? lam[c] : 1.f;
   const float resf = res ? 1.f : 0.f;
   float wg[9] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-  const int b_end = min(B, (int)(blockIdx.y + 1) * BG);
-  for (int b = blockIdx.y * BG; b < b_end; ++b) {
+  const int yy = MRLA_REVERSE_APPLY ? (int)(gridDim.y - 1 - blockIdx.y) : (int)blockIdx.y;   // (see the note at the top)
+  const int b_end = min(B, (yy + 1) * BG);
+  for (int b = yy * BG; b < b_end; ++b) {
     const size_t ioff = (size_t)b * H * rowelems;
     const T* xi = x + ioff;
     const T* gi = dout + ioff;
@@ -717,6 +736,11 @@ static WideLaunch wide_launch(int B, int C, int W, int nred, size_t wave_bytes, 
 }
 
 
+// tensors of this size and beyond are fetched `nt` by the 3N passes (see the note at the top of the file)
+static bool stream_fetches(int B, int C, int H, int W, size_t elem) {
+  return (size_t)B * C * H * W * elem >= ((size_t)MRLA_STREAM_MB << 20);
+}
+
 int launch_light_stats_fwd_wide(const void* x, const void* o, const float* wv, float* mom, void* xout, const float* psc,
                                 const float* psh, void* vout, int B, int C, int H, int W, int dtype, int act,
                                 hipStream_t st) {
@@ -724,13 +748,14 @@ int launch_light_stats_fwd_wide(const void* x, const void* o, const float* wv, f
   const int bg = nhwc_images_per_group(B, C, 0);
   if (xout) {                     // the fused producer (needs o, no activation on V)
     if (!o || act) return MRLA_EINVAL;
-#define CALL_R(T, AF, RG)                                                                                           \
+#define CALL_N(T, AF, RG, NT)                                                                                       \
   {                                                                                                                 \
     const WideLaunch L = wide_launch(B, C, W, kMomRed, fused_wave_bytes<T>(), bg);                                       \
-    if (set_lds_n(light_stats_fwd_fused_wide<T, AF, RG>, L.lds) != hipSuccess) return MRLA_EHIP;                      \
-    hipLaunchKernelGGL((light_stats_fwd_fused_wide<T, AF, RG>), L.grid, L.block, L.lds, st, (const T*)x, (const T*)o, \
+    if (set_lds_n(light_stats_fwd_fused_wide<T, AF, RG, NT>, L.lds) != hipSuccess) return MRLA_EHIP;                  \
+    hipLaunchKernelGGL((light_stats_fwd_fused_wide<T, AF, RG, NT>), L.grid, L.block, L.lds, st, (const T*)x, (const T*)o, \
                        wv, mom, (T*)xout, psc, psh, (T*)vout, B, C, H, W, L.BG);                                    \
   }
+#define CALL_R(T, AF, RG) { if (stream_fetches(B, C, H, W, sizeof(T))) CALL_N(T, AF, RG, 2) else CALL_N(T, AF, RG, 0) }
 #define CALL_A(T, AF) { if (ragged) CALL_R(T, AF, true) else CALL_R(T, AF, false) }
 #define CALL(T) { if (psc) CALL_A(T, true) else CALL_A(T, false) }
     switch (dtype) {
@@ -742,6 +767,7 @@ int launch_light_stats_fwd_wide(const void* x, const void* o, const float* wv, f
 #undef CALL
 #undef CALL_A
 #undef CALL_R
+#undef CALL_N
     return hip_status(hipGetLastError());
   }
 #define CALL_R(T, A, O, RG)                                                                                         \
@@ -761,15 +787,17 @@ int launch_light_stats_fwd_wide(const void* x, const void* o, const float* wv, f
 int launch_light_apply_fwd_wide(const void* x, const void* o, const float* wv, const float* gate, const float* sc,
                                 const float* sh, const float* lam, const float* dp, void* out, int B, int C, int H,
                                 int W, int d, int res, int dtype, int act, hipStream_t st) {
-#define CALL(T, A, O)                                                                                              \
+#define CALL(T, A, O) { if (stream_fetches(B, C, H, W, sizeof(T))) CALL_N(T, A, O, 2) else CALL_N(T, A, O, 0) }
+#define CALL_N(T, A, O, NT)                                                                                        \
   {                                                                                                                \
     const WideLaunch L = wide_launch(B, C, W, 0, apply_fwd_wave_bytes<T>(), nhwc_images_per_group(B, C, 0));        \
-    if (set_lds_n(light_apply_fwd_wide<T, A, O>, L.lds) != hipSuccess) return MRLA_EHIP;                            \
-    hipLaunchKernelGGL((light_apply_fwd_wide<T, A, O>), L.grid, L.block, L.lds, st, (const T*)x, (const T*)o, wv,   \
+    if (set_lds_n(light_apply_fwd_wide<T, A, O, NT>, L.lds) != hipSuccess) return MRLA_EHIP;                        \
+    hipLaunchKernelGGL((light_apply_fwd_wide<T, A, O, NT>), L.grid, L.block, L.lds, st, (const T*)x, (const T*)o, wv,   \
                        gate, sc, sh, lam, dp, (T*)out, B, C, H, W, L.BG, d, res);                                  \
   }
   MRLA_DISPATCH_T_N(dtype, act, o != nullptr, CALL)
 #undef CALL
+#undef CALL_N
   return hip_status(hipGetLastError());
 }
 
@@ -826,15 +854,17 @@ int launch_light_apply_bwd_wide(const void* dout, const void* x, const void* o, 
 
 int launch_light_stats_bwd_wide(const void* dout, const void* x, const void* o, const float* wv, float* bmom, int B,
                                 int C, int H, int W, int dtype, int act, hipStream_t st) {
-#define CALL(T, A, O)                                                                                              \
+#define CALL(T, A, O) CALL_N(T, A, O, 0)      /* default policy: apply_bwd re-reads these tensors right after */
+#define CALL_N(T, A, O, NT)                                                                                        \
   {                                                                                                                \
     const WideLaunch L = wide_launch(B, C, W, D_N, stats_bwd_wave_bytes<T>(), nhwc_images_per_group(B, C, 0));     \
-    if (set_lds_n(light_stats_bwd_wide<T, A, O>, L.lds) != hipSuccess) return MRLA_EHIP;                            \
-    hipLaunchKernelGGL((light_stats_bwd_wide<T, A, O>), L.grid, L.block, L.lds, st, (const T*)dout, (const T*)x,    \
+    if (set_lds_n(light_stats_bwd_wide<T, A, O, NT>, L.lds) != hipSuccess) return MRLA_EHIP;                        \
+    hipLaunchKernelGGL((light_stats_bwd_wide<T, A, O, NT>), L.grid, L.block, L.lds, st, (const T*)dout, (const T*)x,    \
                        (const T*)o, wv, bmom, B, C, H, W, L.BG);                                                   \
   }
   MRLA_DISPATCH_T_N(dtype, act, o != nullptr, CALL)
 #undef CALL
+#undef CALL_N
   return hip_status(hipGetLastError());
 }
 

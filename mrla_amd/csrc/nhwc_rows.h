@@ -19,6 +19,13 @@
 #pragma once
 #include "mrla_device.h"
 
+#ifndef MRLA_ROW_LOAD_AUX
+#define MRLA_ROW_LOAD_AUX 0
+#endif
+#ifndef MRLA_ROW_STORE_AUX
+#define MRLA_ROW_STORE_AUX 0
+#endif
+
 namespace mrla {
 
 constexpr unsigned kRowOob = 0x80000000u;          // byte offset no row reaches: the buffer bounds check yields zeros
@@ -52,7 +59,7 @@ __device__ __forceinline__ void make_row_io(RowIO<T, NPX>& a, int col0, int npx,
 // (The buffer builtins exist in the device pass only; the host pass of hipcc sees empty bodies.)
 // Start the DMA of row r into the LDS row buffer `buf` (wave-private, RowIO::kBytes).  The buffer descriptor of a row
 // outside [0, H) has num_records = 0: every access is out of range and delivers zeros.
-template <typename T, int NPX>
+template <typename T, int NPX, int AUX = MRLA_ROW_LOAD_AUX>
 __device__ __forceinline__ void row_fetch(const RowIO<T, NPX>& a, const T* img, int r, int H, int rowelems, T* buf) {
 #if defined(__HIP_DEVICE_COMPILE__)
   typedef RowIO<T, NPX> Q;
@@ -61,7 +68,7 @@ __device__ __forceinline__ void row_fetch(const RowIO<T, NPX>& a, const T* img, 
                                                     live ? rowelems * (int)sizeof(T) : 0, kBufFlags);
 #pragma unroll
   for (int l = 0; l < Q::NL; ++l)
-    __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_void_ptr)(reinterpret_cast<char*>(buf) + l * 1024), 16, a.voff[l], 0, 0, 0);
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_void_ptr)(reinterpret_cast<char*>(buf) + l * 1024), 16, a.voff[l], 0, 0, AUX);
 #endif
 }
 
@@ -191,7 +198,7 @@ __device__ __forceinline__ void row_store(const RowIO<T, NPX>& a, T* img, int r,
   typedef __attribute__((address_space(3))) const u32x4* lds_v4_ptr;
   lds_v4_ptr s4 = (lds_v4_ptr)buf + lane;
 #pragma unroll
-  for (int l = 0; l < Q::NL; ++l) __builtin_amdgcn_raw_buffer_store_b128(s4[l * kWave], rs, a.voff[l], 0, 0);
+  for (int l = 0; l < Q::NL; ++l) __builtin_amdgcn_raw_buffer_store_b128(s4[l * kWave], rs, a.voff[l], 0, MRLA_ROW_STORE_AUX);
 #endif
 }
 

@@ -261,7 +261,9 @@ int mrla_token_apply_fwd(const void* x, const void* o_prev, const float* stats, 
 int mrla_token_stats_bwd(const void* dout, const void* x, const float* stats, const float* lnx_w, const float* lnx_b,
                          const float* wv, float* bmom, int b, int n, int c, int dtype, void* stream);
 
-/* dxn[b,n,c] (float32) = gradient wrt LN_x(x) incl. the cls row; part[b,c,14] parameter-gradient partials. */
+/* dxn[b,n,c] (float32) = gradient wrt LN_x(x) incl. the cls row; part[rows,c,14] parameter-gradient partials with
+ * rows = mrla_token_part_rows(b, n, c, dtype) (>= b: the map rows of an image may be split over several workgroups). */
+int mrla_token_part_rows(int b, int n, int c, int dtype);
 int mrla_token_apply_bwd(const void* dout, const void* x, const void* o_prev, const float* stats, const float* lnx_w,
                          const float* lnx_b, const float* lno_w, const float* lno_b, const float* wv,
                          const float* gate, const float* lam, const float* dyx, float* dxn, float* part, int b, int n,

@@ -55,6 +55,7 @@ SIGNATURES = {
     "mrla_token_norm_pool": [_P, _P, _P, _P, _F, _P, _P, _I, _I, _I, _I, _P],
     "mrla_token_apply_fwd": [_P] * 11 + [_I] * 6 + [_P],
     "mrla_token_stats_bwd": [_P] * 7 + [_I] * 4 + [_P],
+    "mrla_token_part_rows": [_I] * 4,
     "mrla_token_apply_bwd": [_P] * 14 + [_I] * 5 + [_P],
     "mrla_token_ln_bwd": [_P] * 10 + [_I] * 5 + [_P],
     "mrla_bn_moment_rows": [_I] * 5,

@@ -401,6 +401,11 @@ int mrla_token_stats_bwd(const void* dout, const void* x, const float* stats, co
                                 (hipStream_t)stream);
 }
 
+int mrla_token_part_rows(int b, int n, int c, int dtype) {
+  if (b <= 0 || c <= 0 || bad_dtype(dtype) || !token_side(n)) return MRLA_EINVAL;
+  return b * token_bands_bwd(b, c, token_side(n));
+}
+
 int mrla_token_apply_bwd(const void* dout, const void* x, const void* o_prev, const float* stats, const float* lnx_w,
                          const float* lnx_b, const float* lno_w, const float* lno_b, const float* wv,
                          const float* gate, const float* lam, const float* dyx, float* dxn, float* part, int b, int n,

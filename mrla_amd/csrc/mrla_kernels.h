@@ -86,6 +86,8 @@ int launch_base_value_bwd(const void* dout, const void* x, const float* wv, cons
 
 // tokens_nhwc.hip -- row-marching token map kernels (C % 64 == 0)
 bool token_nhwc_applies(int C);
+int token_bands(int B, int C, int side);       // row bands of the NHWC forward apply kernel
+int token_bands_bwd(int B, int C, int side);   // ... of the backward apply kernel (= rows of `part` per image)
 int launch_token_apply_fwd_nhwc(const void* x, const void* o, const float* stats, const float* wx, const float* bx,
                                 const float* wo, const float* bo, const float* wv, const float* gate, const float* lam,
                                 void* out, int B, int n, int C, int side, int d, int res, int dtype, hipStream_t st);

@@ -72,7 +72,9 @@ __device__ __forceinline__ void normalise_row_hat(float (&v)[NPX], float (&hat)[
   const int nstrips = (W + kS - 1) / kS;                                                                  \
   const int tok0 = b * n + 1;                         /* token index of map pixel (0, 0) */                \
   const size_t ioff = (size_t)tok0 * C;                                                                   \
-  (void)red; (void)scrS;
+  /* row band of this workgroup (grid.z bands; 1 band = the whole map) */                                 \
+  const int r0 = (int)((H * blockIdx.z) / gridDim.z), r1 = (int)((H * (blockIdx.z + 1)) / gridDim.z);     \
+  (void)red; (void)scrS; (void)r0; (void)r1;
 
 // ------------------------------------------------------------------------------------------------
 // forward apply (map rows); grid (C/64, b)
@@ -102,15 +104,15 @@ __global__ __launch_bounds__(kMaxStrips * kWave) void token_apply_fwd_nhwc(
     RowAddr<T, kS> ao;
     make_row_addr<T, kS + 2>(ax, s0 - 1, W, C, cbase, lane);
     make_row_addr<T, kS>(ao, s0, W, C, cbase, lane);
-#pragma unroll
-    for (int j = 0; j < kS + 2; ++j) ra[j] = 0.f;
-    read_row<T, true, kS + 2>(xi, 0, s0 - 1, H, W, C, cbase, c, lane, scrT, rb);
+    read_row<T, true, kS + 2>(xi, r0 - 1, s0 - 1, H, W, C, cbase, c, lane, scrT, ra);      // (zeros above the map)
+    normalise_row<kS + 2>(ra, stats, tok0, side, r0 - 1, s0 - 1, wxc, bxc);
+    read_row<T, true, kS + 2>(xi, r0, s0 - 1, H, W, C, cbase, c, lane, scrT, rb);
 #pragma unroll
     for (int j = 0; j < kS; ++j) xraw[j] = rb[j + 1];
-    normalise_row<kS + 2>(rb, stats, tok0, side, 0, s0 - 1, wxc, bxc);
-    issue_row<T, kS + 2>(qx, xi, 1, H, W * C, ax);
-    issue_row<T, kS>(qo, oi, 0, H, W * C, ao);
-    for (int r = 0; r < H; ++r) {
+    normalise_row<kS + 2>(rb, stats, tok0, side, r0, s0 - 1, wxc, bxc);
+    issue_row<T, kS + 2>(qx, xi, r0 + 1, H, W * C, ax);
+    issue_row<T, kS>(qo, oi, r0, H, W * C, ao);
+    for (int r = r0; r < r1; ++r) {
       float ov[kS], y[kS];
       finish_row<T, kS + 2>(qx, lane, scrT, rc);
       finish_row<T, kS>(qo, lane, scrT, ov);
@@ -245,20 +247,25 @@ __global__ __launch_bounds__(kMaxStrips * kWave) void token_apply_bwd_nhwc(
     make_row_addr<T, kS + 2>(ag, s0 - 1, W, C, cbase, lane);
     make_row_addr<T, kS>(ao, s0, W, C, cbase, lane);
 #pragma unroll
-    for (int j = 0; j < kS + 4; ++j) xa[j] = 0.f;
-#pragma unroll
     for (int j = 0; j < kS + 2; ++j) { ua[j] = 0.f; ub[j] = 0.f; }
-    read_row<T, true, kS + 4>(xi, 0, s0 - 2, H, W, C, cbase, c, lane, scrT, xb);
+    // the band r0 .. r1-1 of output rows needs dU rows r0-1 .. r1: the walk starts one row early and ends one row late
+    const int rs = r0 - 1;
     {
       float hat[kS + 4];
-      normalise_row_hat<kS + 4>(xb, hat, stats, tok0, side, 0, s0 - 2, wxc, bxc);
+      read_row<T, true, kS + 4>(xi, rs - 1, s0 - 2, H, W, C, cbase, c, lane, scrT, xa);
+      normalise_row_hat<kS + 4>(xa, hat, stats, tok0, side, rs - 1, s0 - 2, wxc, bxc);
 #pragma unroll
-      for (int j = 0; j < kS; ++j) { h0[j] = 0.f; h1[j] = hat[j + 2]; }
+      for (int j = 0; j < kS; ++j) h0[j] = hat[j + 2];
+      read_row<T, true, kS + 4>(xi, rs, s0 - 2, H, W, C, cbase, c, lane, scrT, xb);
+      normalise_row_hat<kS + 4>(xb, hat, stats, tok0, side, rs, s0 - 2, wxc, bxc);
+#pragma unroll
+      for (int j = 0; j < kS; ++j) h1[j] = hat[j + 2];
     }
-    issue_row<T, kS + 4>(qx, xi, 1, H, W * C, ax);
-    issue_row<T, kS + 2>(qg, gi, 0, H, W * C, ag);
-    issue_row<T, kS>(qo, oi, 0, H, W * C, ao);
-    for (int rr = 0; rr <= H; ++rr) {
+    issue_row<T, kS + 4>(qx, xi, rs + 1, H, W * C, ax);
+    issue_row<T, kS + 2>(qg, gi, rs, H, W * C, ag);
+    issue_row<T, kS>(qo, oi, rs, H, W * C, ao);
+    for (int rr = rs; rr <= r1; ++rr) {
+      const bool own = rr >= r0 && rr < r1;          // parameter partials are taken on the band's own rows only
       float gv[kS + 2], ov[kS];
       finish_row<T, kS + 4>(qx, lane, scrT, xc);
       finish_row<T, kS + 2>(qg, lane, scrT, gv);
@@ -272,7 +279,7 @@ __global__ __launch_bounds__(kMaxStrips * kWave) void token_apply_bwd_nhwc(
 #pragma unroll
         for (int j = 0; j < kS; ++j) h2[j] = hat[j + 2];
       }
-      if (rr >= H) {
+      if (rr < 0 || rr >= H) {
 #pragma unroll
         for (int j = 0; j < kS + 2; ++j) uc[j] = 0.f;
       } else {
@@ -283,7 +290,7 @@ __global__ __launch_bounds__(kMaxStrips * kWave) void token_apply_bwd_nhwc(
           const float u = conv_at(w, xa, xb, xc, j);
           const float du = in ? a * gv[j] * gelu_grad_f(u) : 0.f;
           uc[j] = du;
-          if (j >= 1 && j <= kS && j - 1 < nc) {
+          if (own && j >= 1 && j <= kS && j - 1 < nc) {
             const float go = gv[j];
             const float2 so = tok_stat(stats, tok0, side, rr, col, TS_MO);
             const float ohat = (ov[j - 1] - so.x) * so.y;
@@ -297,7 +304,7 @@ __global__ __launch_bounds__(kMaxStrips * kWave) void token_apply_bwd_nhwc(
           }
         }
       }
-      if (rr >= 1) {
+      if (rr - 1 >= r0) {
         const int ro = rr - 1;
         float yrow[kS];
 #pragma unroll
@@ -325,15 +332,18 @@ __global__ __launch_bounds__(kMaxStrips * kWave) void token_apply_bwd_nhwc(
   }
   wg_reduce<TQ_N>(q, red, lane, wave, nwaves);
   if (wave == 0) {
-    // cls row: the module output there is LN_x(x) itself
-    const size_t g = (size_t)b * n * C + c;
-    const float* s = stats + (size_t)b * n * TS_N;
-    const float dn = to_f(dout[g]);
-    dxn[g] = dn;
-    q[TQ_LNXW] = fmaf(dn, (to_f(x[g]) - s[TS_MX]) * s[TS_RX], q[TQ_LNXW]);
-    q[TQ_LNXB] += dn;
+    if (blockIdx.z == 0) {
+      // cls row: the module output there is LN_x(x) itself
+      const size_t g = (size_t)b * n * C + c;
+      const float* s = stats + (size_t)b * n * TS_N;
+      const float dn = to_f(dout[g]);
+      dxn[g] = dn;
+      q[TQ_LNXW] = fmaf(dn, (to_f(x[g]) - s[TS_MX]) * s[TS_RX], q[TQ_LNXW]);
+      q[TQ_LNXB] += dn;
+    }
+    // one partial row per (band, image)
 #pragma unroll
-    for (int k = 0; k < TQ_N; ++k) part[((size_t)b * C + c) * TQ_N + k] = q[k];
+    for (int k = 0; k < TQ_N; ++k) part[(((size_t)blockIdx.z * gridDim.y + b) * C + c) * TQ_N + k] = q[k];
   }
 }
 
@@ -350,6 +360,19 @@ __global__ __launch_bounds__(kMaxStrips * kWave) void token_apply_bwd_nhwc(
 
 bool token_nhwc_applies(int C) { return C % kWave == 0; }
 
+// Row bands of the forward apply kernel: a 14 x 14 map gives a wave only 14 dependent row steps and the grid only
+// (C/64) * B two-wave workgroups; splitting the rows (one halo row of recompute) doubles the waves in flight: 0.59 ->
+// 0.45 ms per step on deit_mrlal_tiny.  The backward kernel supports bands as well but is bound by its arithmetic
+// (exact GELU and its derivative per pixel): the two halo rows per band made it 7 % slower, so it runs unbanded.
+int token_bands_bwd(int, int, int) { return 1; }
+int token_bands(int B, int C, int side) {
+  if (!token_nhwc_applies(C)) return 1;
+  const int wgs = (C / kWave) * B;
+  int bands = 1;
+  while (bands < 4 && wgs * bands < 1536 && side / (bands * 2) >= 4) bands *= 2;
+  return bands;
+}
+
 static size_t tok_lds(int nwaves, int nred) {
   return (size_t)nwaves * nred * kWave * sizeof(float) + (size_t)nwaves * 2 * scratch_bytes<float>();
 }
@@ -358,7 +381,7 @@ int launch_token_apply_fwd_nhwc(const void* x, const void* o, const float* stats
                                 const float* wo, const float* bo, const float* wv, const float* gate, const float* lam,
                                 void* out, int B, int n, int C, int side, int d, int res, int dtype, hipStream_t st) {
   const int nwaves = std::min((side + kS - 1) / kS, kMaxStrips);
-  const dim3 grid(C / kWave, B), block(nwaves * kWave);
+  const dim3 grid(C / kWave, B, token_bands(B, C, side)), block(nwaves * kWave);
   const size_t lds = tok_lds(nwaves, 0);
 #define CALL(TT)                                                                                                    \
   {                                                                                                                 \
@@ -394,7 +417,7 @@ int launch_token_apply_bwd_nhwc(const void* dout, const void* x, const void* o, 
                                 const float* lam, const float* dyx, float* dxn, float* part, int B, int n, int C,
                                 int side, int d, int dtype, hipStream_t st) {
   const int nwaves = std::min((side + kS - 1) / kS, kMaxStrips);
-  const dim3 grid(C / kWave, B), block(nwaves * kWave);
+  const dim3 grid(C / kWave, B, token_bands_bwd(B, C, side)), block(nwaves * kWave);
   const size_t lds = tok_lds(nwaves, TQ_N);
 #define CALL(TT)                                                                                                   \
   {                                                                                                                \

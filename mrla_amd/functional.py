@@ -689,7 +689,9 @@ class _TokenLightFn(torch.autograd.Function):
         L.call("mrla_light_gate_bwd", _ptr(mom), _ptr(bmom), _ptr(gate), None, None, None, _ptr(wq32), _ptr(wk32), ks, _ptr(dyx),
                _ptr(dwqk_part), b, c, n - 1, d, st)
         dxn = torch.empty((b, n, c), dtype=torch.float32, device=dev)
-        part = torch.empty((b, c * L.TOKEN_PARTIALS), dtype=torch.float32, device=dev)
+        prow = L.load().mrla_token_part_rows(b, n, c, dt)
+        L.check(min(prow, 0), "mrla_token_part_rows")
+        part = torch.empty((prow, c * L.TOKEN_PARTIALS), dtype=torch.float32, device=dev)
         _call("mrla_token_apply_bwd", xc.numel() * es * 3 + dxn.numel() * 4, _ptr(dout), _ptr(xc), _ptr(oc), _ptr(stats),
               _ptr(wxw), _ptr(wxb), _ptr(wow), _ptr(wob), _ptr(wv32), _ptr(gate), _ptr(lam32), _ptr(dyx), _ptr(dxn),
               _ptr(part), b, n, c, d, dt, st)
@@ -697,7 +699,7 @@ class _TokenLightFn(torch.autograd.Function):
         _call("mrla_token_ln_bwd", xc.numel() * es * 5 + dxn.numel() * 4, _ptr(dout), _ptr(xc), _ptr(oc), _ptr(dxn),
               _ptr(stats), _ptr(wxw), _ptr(wow), _ptr(lam32), _ptr(dx), _ptr(do), b, n, c, res, dt, st)
         sums = torch.empty((c * L.TOKEN_PARTIALS + 2 * ks,), dtype=torch.float32, device=dev)
-        L.call("mrla_reduce_rows", _ptr(part), _ptr(sums), b, c * L.TOKEN_PARTIALS, st)
+        L.call("mrla_reduce_rows", _ptr(part), _ptr(sums), prow, c * L.TOKEN_PARTIALS, st)
         L.call("mrla_reduce_rows", _ptr(dwqk_part), _ptr(sums[c * L.TOKEN_PARTIALS:]), b, 2 * ks, st)
         pc = sums[:c * L.TOKEN_PARTIALS].view(c, L.TOKEN_PARTIALS)
         dwqk = sums[c * L.TOKEN_PARTIALS:]

@@ -902,6 +902,10 @@ class _Conv1x1Fn(torch.autograd.Function):
         n = w.shape[0]
         m = b * h * wd
         dev, st = x.device, _stream()
+        ctx.wshape, ctx.wstride = w.shape, w.stride()     # [n, k] or the module's [n, k, 1, 1] (any dense strides)
+        w = w.reshape(n, k)                                # (a view: the 1x1 taps carry no data)
+        if not w.is_contiguous():
+            w = w.contiguous()
         part = None
         if L.load().mrla_conv1x1_rows(m, k, n, _DT[x.dtype]) > 0:
             y = torch.empty((b, n, h, wd), dtype=x.dtype, device=dev, memory_format=_CL)
@@ -964,9 +968,11 @@ class _Conv1x1Fn(torch.autograd.Function):
             gx2, gw2, _ = torch.ops.aten.convolution_backward(dy, x, w.view(n, k, 1, 1), None, (1, 1), (0, 0), (1, 1), False,
                                                               (0, 0), 1, [need_x, need_w, False])
             gx = gx2 if need_x else gx
-            gw = gw2.view(w.shape) if need_w else gw
+            gw = gw2.reshape(n, k) if need_w else gw
         if d_through is not None and ctx.needs_input_grad[0]:
             gx = gx + d_through
+        if gw is not None:          # the weight's own shape AND strides (autograd's / DDP's gradient layout contract)
+            gw = gw.contiguous().as_strided(ctx.wshape, ctx.wstride)
         return gx, gw, None, None
 
 
@@ -1000,7 +1006,6 @@ def conv_bn_act(x, conv, bn, relu, defer=False, passthrough=False):
         wt = conv.weight
         if wt.dtype != x.dtype:
             wt = wt.to(x.dtype)                      # what autocast does for the stock convolution (differentiable)
-        wt = wt.reshape(conv.out_channels, conv.in_channels)
         if passthrough and torch.is_grad_enabled() and x.requires_grad:
             y, part, through = _Conv1x1Fn.apply(x, wt, bool(fused_bn and bn.training), True)
             return bn_act(y, bn, relu, defer, pre_moments=part if part.numel() else None), through

@@ -46,6 +46,11 @@ __device__ __forceinline__ void stv(T* __restrict__ p, const float (&v)[16 / siz
 // tile slice that waits for its use)
 template <typename T>
 __device__ __forceinline__ u32x4 ldraw(const T* __restrict__ p) { return *reinterpret_cast<const u32x4*>(p); }
+// the same with the streaming (nt) cache policy: history slots, far larger than the caches and read once per kernel
+template <typename T>
+__device__ __forceinline__ u32x4 ldraw_stream(const T* __restrict__ p) {
+  return __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(p));
+}
 template <typename T>
 __device__ __forceinline__ void unpack(const u32x4& r, float (&v)[16 / sizeof(T)]) {
   typedef typename Vec16<T>::type VT;
@@ -122,7 +127,7 @@ __global__ __launch_bounds__(kThreads) void base_combine_nhwc(const T* __restric
 #pragma unroll
     for (int i = 0; i < NV; ++i) {
       raw[i] = (u32x4){0u, 0u, 0u, 0u};
-      if (tid + i * NT < g.nvec) raw[i] = ldraw<T>(src + (size_t)i * NT * VEC);
+      if (tid + i * NT < g.nvec) raw[i] = ldraw_stream<T>(src + (size_t)i * NT * VEC);
     }
   };
   issue(0);
@@ -235,7 +240,7 @@ __global__ __launch_bounds__(kThreads, OCC) void base_attend_bwd_nhwc(
 #pragma unroll
     for (int i = 0; i < kNV; ++i) {
       raw[i] = (u32x4){0u, 0u, 0u, 0u};
-      if (tid + i * NT < g.nvec) raw[i] = ldraw<T>(src + (size_t)i * NT * VEC);
+      if (tid + i * NT < g.nvec) raw[i] = ldraw_stream<T>(src + (size_t)i * NT * VEC);
     }
   };
   {

@@ -198,7 +198,11 @@ class _ResNetMRLA(nn.Module):
         """Blocks that will draw a stochastic-depth mask in this forward (0: none, each block draws its own)."""
         if not (self.training and self.drop_path):
             return 0
-        return sum(1 for m in self.modules() if isinstance(m, _BottleneckTrunk))
+        n = self.__dict__.get("_n_trunks")
+        if n is None:                      # (the block list is fixed after construction; counted once)
+            n = sum(1 for m in self.modules() if isinstance(m, _BottleneckTrunk))
+            self.__dict__["_n_trunks"] = n
+        return n
 
     def forward(self, x):
         x = self.forward_features(x)

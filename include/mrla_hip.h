@@ -45,6 +45,12 @@ enum { MRLA_BN_NONE = 0, MRLA_BN_TRAIN = 1, MRLA_BN_EVAL = 2 };
                               does not shift) so that they stay well conditioned when |mean| >> sigma */
 #define MRLA_BWD_MOMENTS 3 /* sum dOut, sum dOut*V, sum dOut*o */
 
+/* ABI version of this header.  Bumped whenever an existing entry point changes its arguments or a record changes size:
+ *   1 -> 2: mrla_light_bn_bwd / mrla_light_gate_bwd gained cb_lo, mrla_bn_stats_fwd / mrla_bn_plane_moments gained pivot,
+ *           MRLA_FWD_MOMENTS grew from 6 to 8 floats; mrla_conv1x1_plan / mrla_conv1x1_wgrad_plan were added.
+ * A consumer compares mrla_abi_version() (what the loaded library was built from) against this constant before its
+ * first call. */
+#define MRLA_ABI_VERSION 2
 int mrla_abi_version(void);
 
 /* Number of rows of the `dwv_part` scratch that mrla_light_apply_bwd writes for this problem
@@ -321,6 +327,11 @@ int mrla_bn_relu_pool_bwd(const void* dp, const void* x, const float* sc, const 
  * MRLA_EUNSUPPORTED for shapes outside k in {64, 128, 256}, n % 64 == 0 and for dtypes other than MRLA_BF16: the caller
  * keeps using its stock convolution there.  (The input gradient dX = dY * W is the same entry point with w^T.) */
 int mrla_conv1x1_rows(int m, int k, int n, int dtype);      /* rows of mom_part (> 0), or a negative code */
+/* How the launch of this problem is laid out (host-side query, `out` is a HOST array of 4 ints): out[0] = 32-pixel blocks
+ * one workgroup (n % 256 == 0) / one pixel-wave (narrow outputs) walks, out[1] = depth in blocks of its LDS ring / register
+ * prefetch, out[2] = workgroups, out[3] = mrla_conv1x1_rows().  addend != 0: the mrla_conv1x1_fwd_add form.  Lets a
+ * test prove that a case runs the software pipeline in steady state (out[0] >> out[1]). */
+int mrla_conv1x1_plan(int m, int k, int n, int dtype, int addend, int* out);
 int mrla_conv1x1_fwd(const void* x, const void* w, void* y, float* mom_part, int m, int k, int n, int dtype, void* stream);
 
 /* y = x * w^T + addend in one pass (fp32 sum, one rounding).  Used for the input gradient of the bottleneck's conv1
@@ -339,6 +350,9 @@ int mrla_conv1x1_fwd_add(const void* x, const void* w, const void* addend, void*
  *   tiles of the split over m, summed in a fixed order by a second kernel (no atomics, no memset of dw).
  * MRLA_EUNSUPPORTED unless n % 64 == 0, k % 64 == 0, dtype MRLA_BF16 and m * max(n, k) * 2 < 2^31. */
 int mrla_conv1x1_wgrad_rows(int m, int k, int n, int dtype);      /* rows of part (> 0), or a negative code */
+/* Host-side query, `out` is a HOST array of 6 ints: 32-pixel chunks per workgroup, LDS stages, tile n, tile k,
+ * splits (= mrla_conv1x1_wgrad_rows()), output tiles. */
+int mrla_conv1x1_wgrad_plan(int m, int k, int n, int dtype, int* out);
 int mrla_conv1x1_wgrad(const void* dy, const void* x, float* part, void* dw, int m, int k, int n, int dtype, void* stream);
 
 /* out[n] = sum over rows of in[rows, n] (fixed order, double accumulation). */

@@ -9,6 +9,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libmrla_hip.so")
 
+ABI_VERSION = 2          # MRLA_ABI_VERSION of include/mrla_hip.h
 OK, EINVAL, EUNSUPPORTED, EHIP = 0, -1, -2, -3
 F32, BF16, F16 = 0, 1, 2
 NCHW, NHWC = 0, 1
@@ -68,6 +69,8 @@ SIGNATURES = {
     "mrla_bn_relu_pool_dmoments": [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P],
     "mrla_bn_relu_pool_bwd": [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P],
     "mrla_conv1x1_rows": [_I] * 4,
+    "mrla_conv1x1_plan": [_I, _I, _I, _I, _I, _P],
+    "mrla_conv1x1_wgrad_plan": [_I, _I, _I, _I, _P],
     "mrla_conv1x1_fwd": [_P, _P, _P, _P, _I, _I, _I, _I, _P],
     "mrla_conv1x1_add_supported": [_I] * 4,
     "mrla_conv1x1_fwd_add": [_P, _P, _P, _P, _I, _I, _I, _I, _P],
@@ -98,8 +101,9 @@ def load():
         fn = getattr(lib, name)          # AttributeError here = header/library mismatch: fail loudly
         fn.argtypes = argtypes
         fn.restype = ctypes.c_int
-    if lib.mrla_abi_version() != 1:
-        raise MrlaHipError("libmrla_hip.so ABI version mismatch; rebuild it")
+    if lib.mrla_abi_version() != ABI_VERSION:
+        raise MrlaHipError(f"libmrla_hip.so reports ABI version {lib.mrla_abi_version()}, this binding is written against "
+                           f"{ABI_VERSION} (MRLA_ABI_VERSION of include/mrla_hip.h); rebuild it")
     _lib = lib
     return lib
 
@@ -107,6 +111,20 @@ def load():
 def check(rc, what):
     if rc != OK:
         raise MrlaHipError(f"{what}: {_ERR.get(rc, 'error')} (code {rc})")
+
+
+def conv1x1_plan(m, k, n, addend=False):
+    """(pixel blocks per workgroup, pipeline depth, workgroups, moment rows) of mrla_conv1x1_fwd[_add], or None."""
+    out = (ctypes.c_int * 4)()
+    rc = load().mrla_conv1x1_plan(m, k, n, BF16, int(addend), ctypes.cast(out, ctypes.c_void_p))
+    return tuple(out) if rc == OK else None
+
+
+def conv1x1_wgrad_plan(m, k, n):
+    """(chunks per workgroup, LDS stages, tile n, tile k, splits, tiles) of mrla_conv1x1_wgrad, or None."""
+    out = (ctypes.c_int * 6)()
+    rc = load().mrla_conv1x1_wgrad_plan(m, k, n, BF16, ctypes.cast(out, ctypes.c_void_p))
+    return tuple(out) if rc == OK else None
 
 
 def call(name, *args):

@@ -688,8 +688,7 @@ __global__ __launch_bounds__(kThreads) void base_value_bwd_nchw(
 // ------------------------------------------------------------------------------------------------
 template <typename K>
 static hipError_t set_lds2(K kernel, size_t bytes) {
-  if (bytes <= 48 * 1024) return hipSuccess;
-  return hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+  return lds_opt_in(reinterpret_cast<const void*>(kernel), bytes);
 }
 
 #define MRLA_DISPATCH_T(DT, CALL)        \

@@ -1,10 +1,40 @@
 // extern "C" surface of libmrla_hip.so (declared in include/mrla_hip.h): argument validation, slab
 // geometry, dispatch on dtype / layout.  No global state; nothing here allocates or synchronises.
 #include <algorithm>
+#include <atomic>
+#include <mutex>
 
 #include "mrla_kernels.h"
 
 namespace mrla {
+
+// What hipFuncAttributeMaxDynamicSharedMemorySize was last raised to, per (kernel, device): an open-addressed table of
+// atomics read without a lock; raising it (a handful of times per kernel in a process) is serialised by a mutex so
+// that the attribute always equals the largest size ever asked for.  A cache of an idempotent driver call, no
+// behavioural state: a full table degrades to one attribute call per launch.
+hipError_t lds_opt_in(const void* kernel, size_t bytes) {
+  if (bytes <= 48 * 1024) return hipSuccess;
+  constexpr unsigned kSlots = 1024;
+  static std::atomic<uintptr_t> keys[kSlots];
+  static std::atomic<int> granted[kSlots];
+  static std::mutex raise_mutex;
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess) return hipErrorInvalidDevice;
+  const uintptr_t key = reinterpret_cast<uintptr_t>(kernel) ^ ((uintptr_t)(dev + 1) << 52);
+  unsigned i = (unsigned)((key >> 4) * 0x9E3779B1u) % kSlots;
+  int slot = -1;
+  for (unsigned probe = 0; probe < kSlots; ++probe, i = (i + 1) % kSlots) {
+    uintptr_t k = keys[i].load(std::memory_order_acquire);
+    if (k == 0 && keys[i].compare_exchange_strong(k, key, std::memory_order_acq_rel)) k = key;
+    if (k == key) { slot = (int)i; break; }
+  }
+  if (slot >= 0 && granted[slot].load(std::memory_order_acquire) >= (int)bytes) return hipSuccess;
+  std::lock_guard<std::mutex> lock(raise_mutex);
+  if (slot >= 0 && granted[slot].load(std::memory_order_relaxed) >= (int)bytes) return hipSuccess;
+  const hipError_t e = hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+  if (e == hipSuccess && slot >= 0) granted[slot].store((int)bytes, std::memory_order_release);
+  return e;
+}
 
 constexpr int kWavesPerGroup = 4;
 static int gcd_i(int a, int b) { while (b) { int t = a % b; a = b; b = t; } return a; }
@@ -63,7 +93,7 @@ using namespace mrla;
 
 extern "C" {
 
-int mrla_abi_version(void) { return 1; }
+int mrla_abi_version(void) { return MRLA_ABI_VERSION; }
 
 int mrla_light_wgrad_rows(int b, int c, int h, int w, int dtype, int layout) {
   if (bad_dims(b, c, h, w) || bad_dtype(dtype)) return MRLA_EINVAL;
@@ -495,6 +525,18 @@ int mrla_conv1x1_rows(int m, int k, int n, int dtype) {
   if (m <= 0 || k <= 0 || n <= 0 || bad_dtype(dtype)) return MRLA_EINVAL;
   if (dtype != MRLA_BF16) return MRLA_EUNSUPPORTED;
   return conv1x1_rows(m, k, n);
+}
+
+int mrla_conv1x1_plan(int m, int k, int n, int dtype, int addend, int* out) {
+  if (m <= 0 || k <= 0 || n <= 0 || bad_dtype(dtype) || !out) return MRLA_EINVAL;
+  if (dtype != MRLA_BF16) return MRLA_EUNSUPPORTED;
+  return conv1x1_plan(m, k, n, addend, out);
+}
+
+int mrla_conv1x1_wgrad_plan(int m, int k, int n, int dtype, int* out) {
+  if (m <= 0 || k <= 0 || n <= 0 || bad_dtype(dtype) || !out) return MRLA_EINVAL;
+  if (dtype != MRLA_BF16) return MRLA_EUNSUPPORTED;
+  return conv1x1_wgrad_plan(m, k, n, out);
 }
 
 int mrla_conv1x1_fwd(const void* x, const void* w, void* y, float* mom_part, int m, int k, int n, int dtype, void* stream) {

@@ -239,6 +239,19 @@ int conv1x1_rows(int M, int K, int N) {
   return conv1x1_geo(&g, M, K, N) ? g.rows : MRLA_EUNSUPPORTED;
 }
 
+// {32-pixel blocks per workgroup (wide form) / per pixel-wave (narrow form), pipeline depth in blocks, workgroups, rows}
+int conv1x1_plan(int M, int K, int N, int add, int* out) {
+  if (conv1x1_wide_plan(M, K, N, add, out) == MRLA_OK) return MRLA_OK;
+  GemmGeo g;
+  if (add || !conv1x1_geo(&g, M, K, N)) return MRLA_EUNSUPPORTED;
+  const int nblk = (M + 31) / 32;
+  out[0] = (nblk + g.gx * g.WM - 1) / (g.gx * g.WM);
+  out[1] = 2;                               // the next block's X fragments are fetched during this block's MFMAs
+  out[2] = g.gx * g.gy;
+  out[3] = g.rows;
+  return MRLA_OK;
+}
+
 int launch_conv1x1_fwd(const void* x, const void* w, void* y, float* part, int M, int K, int N, hipStream_t st) {
   if (conv1x1_wide_rows(M, K, N) > 0) return launch_conv1x1_wide(x, w, nullptr, y, part, M, K, N, st);
   GemmGeo g;
@@ -246,9 +259,7 @@ int launch_conv1x1_fwd(const void* x, const void* w, void* y, float* part, int M
   const dim3 grid(g.gx, g.gy), block(g.NW * kWave);
 #define CALL_W(KS, MO, NWV)                                                                                          \
   {                                                                                                                  \
-    if (g.lds > 48 * 1024 &&                                                                                         \
-        hipFuncSetAttribute(reinterpret_cast<const void*>(conv1x1_fwd_kernel<KS, MO, NWV>),                          \
-                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)g.lds) != hipSuccess)                   \
+    if (lds_opt_in(reinterpret_cast<const void*>(conv1x1_fwd_kernel<KS, MO, NWV>), g.lds) != hipSuccess)              \
       return MRLA_EHIP;                                                                                              \
     hipLaunchKernelGGL((conv1x1_fwd_kernel<KS, MO, NWV>), grid, block, g.lds, st, (const bf16_t*)x, (const bf16_t*)w, \
                        (bf16_t*)y, part, M, N, g.NS, g.WN, g.rows);                                                  \

@@ -299,10 +299,7 @@ template <int TN, int TK, int ST, int PC>
 int launch_tile(const WgPlan& p, const void* dy, const void* x, float* part, int M, int K, int N, hipStream_t st) {
   typedef WgGeo<TN, TK, PC> G;
   const size_t lds = (size_t)ST * G::SB;
-  if (lds > 48 * 1024 &&
-      hipFuncSetAttribute(reinterpret_cast<const void*>(conv1x1_wgrad_kernel<TN, TK, ST, PC>),
-                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
-    return MRLA_EHIP;
+  if (lds_opt_in(reinterpret_cast<const void*>(conv1x1_wgrad_kernel<TN, TK, ST, PC>), lds) != hipSuccess) return MRLA_EHIP;
   hipLaunchKernelGGL((conv1x1_wgrad_kernel<TN, TK, ST, PC>), dim3((p.tiles * p.splits + 7) / 8 * 8), dim3(kWgWaves * kWave), lds, st,
                      (const bf16_t*)dy, (const bf16_t*)x, part, M, N, K, p.chunks_per_wg, p.splits);
   return MRLA_OK;
@@ -313,6 +310,14 @@ int launch_tile(const WgPlan& p, const void* dy, const void* x, float* part, int
 int conv1x1_wgrad_rows(int M, int K, int N) {
   const WgPlan p = wgrad_plan(M, K, N);
   return p.tiles ? p.splits : MRLA_EUNSUPPORTED;
+}
+
+// {32-pixel chunks per workgroup, LDS stages, tile n, tile k, splits, output tiles}
+int conv1x1_wgrad_plan(int M, int K, int N, int* out) {
+  const WgPlan p = wgrad_plan(M, K, N);
+  if (!p.tiles) return MRLA_EUNSUPPORTED;
+  out[0] = p.chunks_per_wg; out[1] = kWgStages; out[2] = p.tn; out[3] = p.tk; out[4] = p.splits; out[5] = p.tiles;
+  return MRLA_OK;
 }
 
 int launch_conv1x1_wgrad(const void* dy, const void* x, float* part, void* dw, int M, int K, int N, hipStream_t st) {

@@ -328,9 +328,7 @@ template <int KS, bool MOM, bool ADD>
 int cw_launch(const CwPlan& p, const void* x, const void* w, const void* a, void* y, float* part, int M, int N, hipStream_t st) {
   typedef CwGeo<KS, ADD> G;
   static_assert(G::kLds <= 160 * 1024, "LDS");
-  if (hipFuncSetAttribute(reinterpret_cast<const void*>(conv1x1_wide_kernel<KS, MOM, ADD>),
-                          hipFuncAttributeMaxDynamicSharedMemorySize, G::kLds) != hipSuccess)
-    return MRLA_EHIP;
+  if (lds_opt_in(reinterpret_cast<const void*>(conv1x1_wide_kernel<KS, MOM, ADD>), G::kLds) != hipSuccess) return MRLA_EHIP;
   hipLaunchKernelGGL((conv1x1_wide_kernel<KS, MOM, ADD>), dim3((p.groups * p.splits + 7) / 8 * 8), dim3(kCwWaves * kWave),
                      G::kLds, st, (const bf16_t*)x, (const bf16_t*)w, (const bf16_t*)a, (bf16_t*)y, part, M, N,
                      p.units_per_wg, p.splits, p.rows);
@@ -342,6 +340,19 @@ int cw_launch(const CwPlan& p, const void* x, const void* w, const void* a, void
 int conv1x1_wide_rows(int M, int K, int N) {
   const CwPlan p = cw_plan(M, K, N);
   return p.groups ? p.rows : MRLA_EUNSUPPORTED;
+}
+
+// {32-pixel blocks per workgroup, LDS ring depth in blocks, workgroups, moment rows}
+int conv1x1_wide_plan(int M, int K, int N, int add, int* out) {
+  const CwPlan p = cw_plan(M, K, N);
+  if (!p.groups) return MRLA_EUNSUPPORTED;
+  const int ks = K / 16;
+  out[0] = p.units_per_wg;
+  out[1] = add ? (ks == 16 ? CwGeo<16, true>::UST : ks == 8 ? CwGeo<8, true>::UST : CwGeo<4, true>::UST)
+               : (ks == 16 ? CwGeo<16, false>::UST : ks == 8 ? CwGeo<8, false>::UST : CwGeo<4, false>::UST);
+  out[2] = p.groups * p.splits;
+  out[3] = p.rows;
+  return MRLA_OK;
 }
 
 int launch_conv1x1_wide(const void* x, const void* w, const void* addend, void* y, float* part, int M, int K, int N,

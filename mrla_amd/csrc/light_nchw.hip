@@ -514,8 +514,7 @@ constexpr size_t kMaxLds = 150 * 1024;
 
 template <typename K>
 static hipError_t set_lds(K kernel, size_t bytes) {
-  if (bytes <= 48 * 1024) return hipSuccess;
-  return hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+  return lds_opt_in(reinterpret_cast<const void*>(kernel), bytes);
 }
 
 #define MRLA_DISPATCH_AO(TT, ACT, HASO, CALL)                          \

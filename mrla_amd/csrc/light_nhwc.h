@@ -208,8 +208,7 @@ static NhwcLaunch nhwc_launch(int B, int C, int W, int nred, int dtype) {
 }
 template <typename K>
 static hipError_t set_lds_n(K kernel, size_t bytes) {
-  if (bytes <= 48 * 1024) return hipSuccess;
-  return hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+  return lds_opt_in(reinterpret_cast<const void*>(kernel), bytes);
 }
 
 }  // namespace mrla

@@ -28,6 +28,11 @@ inline size_t dtype_size(int dtype) { return dtype == MRLA_F32 ? 4 : 2; }
 
 inline int hip_status(hipError_t e) { return e == hipSuccess ? MRLA_OK : MRLA_EHIP; }
 
+// Opt a kernel in to more than the default 48 KB of dynamic LDS (hipFuncAttributeMaxDynamicSharedMemorySize) -- once per
+// (kernel, device) and size, not on every launch: the attribute call costs host time on a path that issues ~600 launches
+// per training step.  A lock-free lookup of what was granted before; the first call per kernel takes a mutex.  (capi.hip)
+hipError_t lds_opt_in(const void* kernel, size_t bytes);
+
 // Returns MRLA_OK or MRLA_EUNSUPPORTED (plane wider than a wave / slab does not fit LDS).
 int make_slab_geo(SlabGeo* g, int B, int C, int H, int W, int dtype, int arrays, int bg_hint);
 
@@ -146,6 +151,7 @@ int launch_affine_act(const void* x, const void* dy, const float* a, const float
 int nhwc_images_per_group(int B, int C, int W);
 // conv1x1.hip -- 1x1 convolution as an MFMA GEMM with a BatchNorm-moments epilogue (bf16)
 int conv1x1_rows(int M, int K, int N);
+int conv1x1_plan(int M, int K, int N, int add, int* out);
 int launch_conv1x1_fwd(const void* x, const void* w, void* y, float* part, int M, int K, int N, hipStream_t st);
 // stem_pool_nhwc.hip -- maxpool3x3/s2/p1(relu(bn(x))) without the intermediate tensor (channels_last, C % 64 == 0)
 int bn_pool_rows(int B, int C, int H, int W);
@@ -157,10 +163,12 @@ int launch_bn_relu_pool_bwd(const void* dp, const void* x, const float* sc, cons
                             int B, int C, int H, int W, int dtype, hipStream_t st);
 // conv1x1_wide.hip -- the same product for wide outputs (N % 256 == 0): X streamed through LDS, optional addend
 int conv1x1_wide_rows(int M, int K, int N);
+int conv1x1_wide_plan(int M, int K, int N, int add, int* out);
 int launch_conv1x1_wide(const void* x, const void* w, const void* addend, void* y, float* part, int M, int K, int N,
                         hipStream_t st);
 // conv1x1_wgrad.hip -- its weight gradient dW[n,k] = sum_m dY[m,n] X[m,k] as a split-M MFMA GEMM (bf16)
 int conv1x1_wgrad_rows(int M, int K, int N);
+int conv1x1_wgrad_plan(int M, int K, int N, int* out);
 int launch_conv1x1_wgrad(const void* dy, const void* x, float* part, void* dw, int M, int K, int N, hipStream_t st);
 // light_nhwc_wide.hip -- the C % 64 == 0 forms on the LDS-DMA row pipeline (nhwc_rows.h)
 int launch_light_stats_fwd_wide(const void* x, const void* o, const float* wv, float* mom, void* xout, const float* psc,

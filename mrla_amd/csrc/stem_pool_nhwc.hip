@@ -368,8 +368,7 @@ __global__ __launch_bounds__(kPoolWaves* kWave) void bn_relu_pool_bwd_kernel(con
 
 template <typename K>
 hipError_t pool_lds(K kernel, size_t bytes) {
-  if (bytes <= 48 * 1024) return hipSuccess;
-  return hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+  return lds_opt_in(reinterpret_cast<const void*>(kernel), bytes);
 }
 
 constexpr int kPS = 4;

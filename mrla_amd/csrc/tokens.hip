@@ -382,8 +382,7 @@ static int chunk_for(int C) { return C % 16 == 0 ? 16 : 0; }
 
 template <typename K>
 static hipError_t set_lds3(K kernel, size_t bytes) {
-  if (bytes <= 48 * 1024) return hipSuccess;
-  return hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+  return lds_opt_in(reinterpret_cast<const void*>(kernel), bytes);
 }
 
 int launch_token_norm_pool(const void* x, const void* o, const float* wx, const float* bx, float eps, float* stats,

@@ -31,12 +31,13 @@ def init_from_env(backend=None):
     return rank, local, world
 
 
-def wrap_data_parallel(model, device_ids=None, bucket_cap_mb=32):
+def wrap_data_parallel(model, device_ids=None, bucket_cap_mb=32, force=False):
     """DistributedDataParallel tuned for this workload: gradients are views into the flat buckets (no extra copy),
     buckets large enough that the 103 MB of resnet50_mrlal gradients go out as a handful of RCCL all-reduces that
     overlap the rest of backward, static graph (every parameter is used in every step), no buffer broadcast per
-    step (BatchNorm statistics are per-GPU by design)."""
-    if not dist.is_initialized() or dist.get_world_size() == 1:
+    step (BatchNorm statistics are per-GPU by design).  force: wrap even in a one-rank group (diagnostics: the reducer's
+    hooks, bucket views and RCCL calls then run exactly as at N > 1, with nobody to exchange with)."""
+    if not dist.is_initialized() or (dist.get_world_size() == 1 and not force):
         return model
     return torch.nn.parallel.DistributedDataParallel(
         model, device_ids=device_ids, gradient_as_bucket_view=True, bucket_cap_mb=bucket_cap_mb, static_graph=True,

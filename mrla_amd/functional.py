@@ -116,6 +116,12 @@ def bump_batch_counter(bn):
 
 
 _raw_stream = getattr(torch._C, "_cuda_getCurrentRawStream", None)
+_graph_task = getattr(torch._C, "_current_graph_task_id", None)
+
+
+def _graph_task_id():
+    """Id of the autograd engine's running backward pass, -1 outside one (or when this torch has no such query)."""
+    return _graph_task() if _graph_task is not None else -1
 
 
 def _stream():
@@ -134,6 +140,22 @@ def _f32(t):
     if t.dtype != torch.float32:
         t = t.float()
     return t.contiguous()
+
+
+def _grad_like(g, shape, stride):
+    """`g` (any dense tensor with shape.numel() elements in row-major order of `shape`) as a gradient with the
+    parameter's own shape AND strides -- autograd's / DDP's gradient layout contract.  Free (a re-striding view) when the
+    parameter's strides enumerate its elements in row-major order once size-1 dimensions are ignored (contiguous
+    weights, and channels_last [n, k, 1, 1] / [c, 1, 3, 3] ones); any other dense layout gets a strided copy."""
+    g = g.contiguous()
+    dims = [(n, s) for n, s in zip(shape, stride) if n > 1]
+    expect, row_major = 1, True
+    for n, s in reversed(dims):
+        row_major &= s == expect
+        expect *= n
+    if row_major:
+        return g.as_strided(shape, stride)
+    return torch.empty_strided(shape, stride, dtype=g.dtype, device=g.device).copy_(g.view(shape))
 
 
 def _on_device(fn):
@@ -348,7 +370,7 @@ class _LightFn(torch.autograd.Function):
 
         sq, sk, sv, sl = ctx.shapes
         tq, tk, tv, tl, tg = ctx.pdtypes
-        dwv = wsum[:c * 9].view(sv).to(tv).as_strided(sv, ctx.wv_stride)
+        dwv = _grad_like(wsum[:c * 9].to(tv), sv, ctx.wv_stride)
         dwq = wsum[c * 9:c * 9 + ks].view(sq).to(tq)
         dwk = wsum[c * 9 + ks:].view(sk).to(tk)
         dlam = small[6].view(sl).to(tl) if lam32 is not None else None
@@ -403,6 +425,7 @@ class BaseStage:
         self.T = max(1, int(capacity))
         self.t = 0
         self.bwd_started = False
+        self.bwd_task = -1        # autograd graph-task id of the backward pass the dA / dK rings currently belong to
         self.bwd_last_t = 0       # layer index of the previous backward call (calls of one pass come in decreasing t)
         self.bwd_top = 0          # deepest layer that took part in the current backward pass
         self.V = torch.empty(self._vshape(self.T), dtype=dtype, device=device)
@@ -458,13 +481,20 @@ class BaseStage:
 
     def begin_layer_backward(self, t):
         """Called by layer t's backward.  Returns True on the first call of a backward PASS: then the dK ring is re-zeroed
-        and `bwd_top` (the deepest layer whose dA slot this pass fills) is reset.  A pass is recognised by t not
-        decreasing -- a repeated backward over the same graph (retain_graph=True, two losses) starts again at the top."""
+        and `bwd_top` (the deepest layer whose dA slot this pass fills) is reset.  A pass is identified by the autograd
+        engine's graph-task id (a partial pass -- autograd.grad down to layer 3 -- followed by one whose deepest layer is
+        shallower is a new pass although t decreased); outside an engine-driven backward (id -1) a pass is recognised
+        by t not decreasing: a repeated backward over the same graph starts again at the top."""
         if self.dA is None:
             self.dA = torch.empty_like(self.V)
             self.dK = torch.empty_like(self.K)
-        first = (not self.bwd_started) or t >= self.bwd_last_t
+        task = _graph_task_id()
+        if task != -1:
+            first = (not self.bwd_started) or task != self.bwd_task
+        else:
+            first = (not self.bwd_started) or t >= self.bwd_last_t
         self.bwd_started = True
+        self.bwd_task = task
         self.bwd_last_t = t
         if first:
             self.bwd_top = t
@@ -620,7 +650,7 @@ class _BaseFn(torch.autograd.Function):
         sq, sk, sv = ctx.shapes
         tq, tk, tv, _ = ctx.pdtypes
         return (dx, dx if cfg.fuse else None, wsum[c * 9:c * 9 + ks].view(sq).to(tq), wsum[c * 9 + ks:].view(sk).to(tk),
-                wsum[:c * 9].view(sv).to(tv).as_strided(sv, ctx.wv_stride), dgamma, dbeta, None, None, None, None, None)
+                _grad_like(wsum[:c * 9].to(tv), sv, ctx.wv_stride), dgamma, dbeta, None, None, None, None, None)
 
 
 def mrla_base(x, wq, wk, wv, d, stage, bn=None, dp=None, identity=None):
@@ -979,7 +1009,7 @@ class _Conv1x1Fn(torch.autograd.Function):
         if d_through is not None and ctx.needs_input_grad[0]:
             gx = gx + d_through
         if gw is not None:          # the weight's own shape AND strides (autograd's / DDP's gradient layout contract)
-            gw = gw.contiguous().as_strided(ctx.wshape, ctx.wstride)
+            gw = _grad_like(gw, ctx.wshape, ctx.wstride)
         return gx, gw, None, None
 
 

@@ -255,6 +255,19 @@ def test_repeated_backward_over_one_stage_restarts_the_gradient_rings(cl):
     _, _, og, _, _ = oracle_chain(xs64, [g.cpu().numpy() for g in gups[:-1]], params, d, True)
     for t in range(Tn - 1):
         assert relmax(g3[t].cpu().numpy(), og[t]["dx"]) < 2 * ACT_TOL, t
+    # a pass whose deepest layer is SHALLOWER than the previous pass's last layer (t decreases across the pass boundary:
+    # the ordering heuristic alone would take it for a continuation): passes are told apart by the autograd graph-task id
+    shallow = sum((o * g).sum() for o, g in zip(outs[:2], gups[:2]))
+    grads_of(part, True)                                   # ends at layer 1 ...
+    g5 = grads_of(shallow, True)                           # ... and this one starts at layer 2 of 4
+    _, _, og2, _, _ = oracle_chain(xs64[:2], [g.cpu().numpy() for g in gups[:2]], params[:2], d, True)
+    for t in range(2):
+        assert relmax(g5[t].cpu().numpy(), og2[t]["dx"]) < 2 * ACT_TOL, t
+    # and directly after a partial pass that stopped at layer 3 (torch.autograd.grad down to x_3 only)
+    torch.autograd.grad(full, [xs[2]], retain_graph=True)
+    g6 = grads_of(shallow, True)
+    for a, r in zip(g5, g6):
+        assert (a is None and r is None) or torch.equal(a, r)
 
 
 def test_wide_nchw_base_stage_goes_through_nhwc_rings():

@@ -1,0 +1,128 @@
+"""One whole MRLA bottleneck in bf16 (the headline configuration's production path, resnet_mrla_light.py:89-118) against
+a STAGED float64 reference -- the tight statement about the bf16 path that model-level cosine similarities cannot make.
+
+Product: mrla_amd.resnet.MRLA_Bottleneck, channels_last, bf16 autocast, train mode, drop-path mask pinned:
+  conv1 (MFMA GEMM, BatchNorm moments in its epilogue) -> bn1+relu -> stock 3x3 -> bn2+relu -> conv3 (MFMA GEMM) ->
+  deferred bn3 affine + shortcut add + ReLU inside the first MRLA pass -> MRLA tail; backward through the fused
+  passes, the input-gradient GEMMs (conv1's with the shortcut gradient in its epilogue) and the weight-gradient GEMMs.
+Reference: the same block in float64 (oracle/eager_models.py's modules) with a rounding hook at every point where the
+product stores an activation-sized tensor in bf16 -- forward: conv outputs, BatchNorm(+ReLU) outputs, bn3's output, x_t,
+out; backward: the gradients of those same tensors (autograd stores them in the activation type), the shortcut
+gradient rounded once after its two contributions are summed, as the fused kernels do.  The protocol of
+`oracle_chain(rnd=...)` in tests/test_base_gpu.py, applied to the light block.
+
+Bounds asserted: <= 2 bf16 ulps on >= 99.99 % of out and dx (a 1-ulp difference in a stored intermediate can move a
+later rounding), nothing beyond 8 ulps; 2 % L2 on every parameter gradient; BatchNorm running statistics to 1e-3."""
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+
+class _Round(torch.autograd.Function):
+    """bf16 storage point: mode 'both' rounds the value forward and its gradient backward, 'fwd' / 'bwd' one of them."""
+
+    @staticmethod
+    def forward(ctx, x, mode):
+        ctx.mode = mode
+        return x.float().bfloat16().double() if mode in ("both", "fwd") else x.clone()
+
+    @staticmethod
+    def backward(ctx, g):
+        return (g.float().bfloat16().double() if ctx.mode in ("both", "bwd") else g), None
+
+
+def rnd(x, mode="both"):
+    return _Round.apply(x, mode)
+
+
+def _bn(x, bn):
+    """Train-mode BatchNorm2d in float64 on the stored (rounded) input; returns (y, batch mean, biased batch var)."""
+    mean = x.mean(dim=(0, 2, 3))
+    var = x.var(dim=(0, 2, 3), unbiased=False)
+    y = (x - mean[None, :, None, None]) / torch.sqrt(var[None, :, None, None] + bn.eps)
+    return y * bn.weight[None, :, None, None] + bn.bias[None, :, None, None], mean, var
+
+
+def staged_reference(blk, x, dp, wcast):
+    """blk: an EagerLightBottleneck in float64 (fp32 master values); wcast(w): the bf16-rounded convolution weight the
+    autocast product multiplies with.  x: leaf float64 tensor (bf16 values).  Returns (out, {bn name: (mean, var)})."""
+    stats = {}
+    ident = rnd(x, "bwd")                                             # the shortcut branch: its gradient is stored once
+    y1 = rnd(F.conv2d(x, wcast(blk.conv1.weight)))
+    z1, *stats["bn1"] = _bn(y1, blk.bn1)
+    z1 = rnd(torch.relu(z1))
+    y2 = rnd(F.conv2d(z1, wcast(blk.conv2.weight), padding=1))
+    z2, *stats["bn2"] = _bn(y2, blk.bn2)
+    z2 = rnd(torch.relu(z2))
+    y3 = rnd(F.conv2d(z2, wcast(blk.conv3.weight)))
+    pre, *stats["bn3"] = _bn(y3, blk.bn3)
+    pre = rnd(pre)                                                    # bn3's output as the stand-alone pass would store it
+    xt = rnd(torch.relu(pre + ident), "fwd")                          # x_t is stored; its gradient never is
+    m = blk.mrla(xt, ident)
+    z, *stats["bn_mrla"] = _bn(m, blk.bn_mrla)
+    out = rnd(xt + dp[:, None, None, None] * z, "fwd")
+    return out, stats
+
+
+def _ulps(got, want64):
+    """|got - bf16(want)| in bf16 ulps of the value (2^-7 relative), with the repo's floor of 1e-3 of the largest ulp."""
+    want = want64.float().bfloat16().float()
+    unit = want.abs() * 2.0 ** -7 + 1e-3 * want64.abs().max().item() * 2.0 ** -7 + 1e-30
+    return (got.float() - want).abs() / unit
+
+
+@pytest.mark.parametrize("shape", [(64, 256, 64, 56), (64, 1024, 256, 14)], ids=["stage1", "stage3"])
+def test_bf16_bottleneck_against_the_staged_float64_reference(shape, monkeypatch):
+    from mrla_amd import layers, resnet
+    from oracle import eager_models as em
+    b, inplanes, planes, hw = shape
+    p_drop = 0.2
+    torch.manual_seed(1234)
+    blk = resnet.MRLA_Bottleneck(inplanes, planes, drop_path=p_drop)
+    for mod in blk.modules():
+        if isinstance(mod, torch.nn.Conv2d) and mod.groups == 1:
+            torch.nn.init.kaiming_normal_(mod.weight, mode="fan_out", nonlinearity="relu")
+        elif isinstance(mod, torch.nn.BatchNorm2d):          # a trained-looking affine (bn3 is zero-initialised in the model)
+            torch.nn.init.uniform_(mod.weight, 0.6, 1.4)
+            torch.nn.init.uniform_(mod.bias, -0.3, 0.3)
+    blk = blk.cuda().to(memory_format=torch.channels_last).train()
+    ref = em.EagerLightBottleneck(inplanes, planes, drop_path=p_drop).cuda().double().train()
+    ref.load_state_dict({k: v.double() for k, v in blk.state_dict().items()})
+
+    g = torch.Generator(device="cuda").manual_seed(5)
+    x = torch.relu(torch.randn((b, inplanes, hw, hw), device="cuda", generator=g) + 0.3).bfloat16()     # a block input is post-ReLU
+    x = x.contiguous(memory_format=torch.channels_last)
+    gup = (torch.randn((b, inplanes, hw, hw), device="cuda", generator=g) * 0.1).bfloat16().contiguous(memory_format=torch.channels_last)
+    keep = (torch.rand((b,), device="cuda", generator=g) >= p_drop).float()
+    dp = keep / (1.0 - p_drop)
+    assert 0 < keep.sum() < b
+    monkeypatch.setattr(layers, "drop_path_scale", lambda batch, p, training, device: dp)
+
+    xp = x.clone().requires_grad_(True)
+    with torch.autocast("cuda", dtype=torch.bfloat16):
+        out = blk(xp)
+    assert out.dtype == torch.bfloat16
+    out.backward(gup)
+
+    xr = x.double().requires_grad_(True)
+    out_r, stats = staged_reference(ref, xr, dp.double(), lambda w: w.float().bfloat16().double())
+    out_r.backward(gup.double())
+    torch.cuda.synchronize()
+
+    for name, got, want in (("out", out.detach(), out_r.detach()), ("dx", xp.grad, xr.grad)):
+        u = _ulps(got, want)
+        frac = (u > 2.0).float().mean().item()
+        assert frac <= 1e-4, f"{name}: {frac:.2e} of the elements beyond 2 bf16 ulps (worst {u.max().item():.1f})"
+        assert u.max().item() <= 8.0, f"{name}: worst element {u.max().item():.1f} ulps"
+    pref = dict(ref.named_parameters())
+    for name, p in blk.named_parameters():
+        want = pref[name].grad
+        err = ((p.grad.double() - want).norm() / want.norm()).item()
+        assert err < 2e-2, f"grad {name}: relative L2 error {err:.3e}"
+    n = b * hw * hw
+    for name, (mean, var) in stats.items():
+        bn = getattr(blk, name)
+        assert torch.allclose(bn.running_mean.double(), 0.1 * mean, rtol=1e-3, atol=1e-4 * mean.abs().max().item()), name
+        assert torch.allclose(bn.running_var.double(), 0.9 + 0.1 * var * n / (n - 1), rtol=1e-3), name

@@ -98,3 +98,33 @@ def test_model_under_ddp_two_ranks_one_gpu(arch, amp, tmp_path):
         assert torch.equal(res[0]["grads"][k], res[1]["grads"][k]), k        # both ranks hold the same reduced gradient
     k = next(k for k in res[0]["stats"] if "bn_mrla.running_mean" in k)
     assert not torch.allclose(res[0]["stats"][k], res[1]["stats"][k])        # no SyncBN / buffer broadcast
+
+
+def test_bench_py_under_torch_distributed_run_two_ranks_one_gpu():
+    """The exact launch line of the driver's N > 1 runs (`python -m torch.distributed.run --nnodes=1 --nproc-per-node N
+    --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...`, resnet/train.py:133,166-174) with two ranks sharing
+    the one GPU over gloo (MRLA_DIST_BACKEND; RCCL refuses two ranks on one device): the N > 1 code path of bench.py --
+    process-group set-up, DDP wrapper, barrier-bracketed timing, max over ranks, rank-0-only JSON -- must keep producing
+    the contract's line.  Started as a fresh child process, before which nothing of it has touched the GPU."""
+    import json
+    root = os.path.dirname(HERE)
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", MRLA_DIST_BACKEND="gloo", PYTHONPATH=root)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
+           "--batch", "8", "--no-baselines", "--benchmark", "0"]
+    p = subprocess.run(cmd, env=env, cwd=root, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=1200)
+    out, err = p.stdout.decode(errors="replace"), p.stderr.decode(errors="replace")
+    assert p.returncode == 0, (out + err)[-4000:]
+    lines = [ln for ln in out.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, out[-2000:]                    # rank 0 only
+    rec = json.loads(lines[0])
+    assert rec["n_gpus"] == 2 and rec["steps"] == 2 and rec["warmup"] == 1
+    assert rec["config"]["global_batch"] == 16 and rec["config"]["parallelism"] == "dp2"
+    assert rec["scaling"] == "weak" and rec["higher_is_better"] is True and rec["unit"] == "images/sec"
+    assert rec["metric"].startswith("images/sec fwd+bwd resnet50_mrlal") and rec["value"] > 0
+    assert rec["config"]["launch"].startswith(("kernel by kernel", "one HIP graph"))
+    assert rec["roofline"] is not None and rec["roofline"]["bound"] == "hbm" and rec["roofline"]["achieved"] > 0
+    assert rec["roofline"]["kernel"].startswith("mrla_light_apply_bwd")
+    assert "cpu_baseline" not in rec and "forward_only" not in rec            # N = 1 legs only
+    # value is the whole job: 16 images per step over the slowest rank's time
+    assert abs(rec["value"] - 16 * 1e3 / rec["ms_per_step"]) / rec["value"] < 1e-2

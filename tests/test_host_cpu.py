@@ -18,7 +18,9 @@ def test_library_exports_every_declared_symbol():
     assert declared == set(_lib.SIGNATURES), declared ^ set(_lib.SIGNATURES)
     for name in declared:
         assert hasattr(lib, name), name
-    assert lib.mrla_abi_version() == 1
+    # the version the header declares == what the library reports == what the ctypes binding was written against
+    hdr_version = int(re.search(r"#define\s+MRLA_ABI_VERSION\s+(\d+)", hdr).group(1))
+    assert lib.mrla_abi_version() == hdr_version == _lib.ABI_VERSION == 2
 
 
 def test_argument_validation_without_a_gpu():
@@ -180,3 +182,23 @@ def test_top_level_models_package_serves_train_py_unedited():
         net = models.__dict__["resnet50_mrlal"](drop_rate=0.0, drop_path=0.2)
     from mrla_amd.resnet import ResNet_mrlal
     assert isinstance(net, ResNet_mrlal) and models.ResNet_mrlal is ResNet_mrlal
+
+
+def test_parameter_gradient_layout_helper_handles_every_dense_stride_pattern():
+    """_grad_like: a row-major gradient buffer handed back with the parameter's own shape and strides (autograd / DDP
+    contract; resnet/train.py:174): a view for contiguous and channels_last 1x1 / depthwise weights, a strided copy for any
+    other dense layout -- never a silent permutation."""
+    import torch
+    from mrla_amd.functional import _grad_like
+    n, k = 6, 4
+    g = torch.arange(n * k, dtype=torch.float32)
+    for w in (torch.empty(n, k), torch.empty(n, k, 1, 1), torch.empty(n, k, 1, 1).to(memory_format=torch.channels_last),
+              torch.empty(n, 1, 3, 3).to(memory_format=torch.channels_last)):
+        gg = torch.arange(w.numel(), dtype=torch.float32)
+        out = _grad_like(gg, w.shape, w.stride())
+        assert out.shape == w.shape and out.stride() == w.stride()
+        assert torch.equal(out.contiguous().view(-1), gg)
+        assert out.data_ptr() == gg.data_ptr()                          # a view: no copy kernel on the hot path
+    wt = torch.empty(k, n).t()                                          # [n, k] stored column-major: dense, not row-major
+    out = _grad_like(g, wt.shape, wt.stride())
+    assert out.stride() == wt.stride() and torch.equal(out, g.view(n, k))

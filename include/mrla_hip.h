@@ -47,7 +47,8 @@ enum { MRLA_BN_NONE = 0, MRLA_BN_TRAIN = 1, MRLA_BN_EVAL = 2 };
 
 /* ABI version of this header.  Bumped whenever an existing entry point changes its arguments or a record changes size:
  *   1 -> 2: mrla_light_bn_bwd / mrla_light_gate_bwd gained cb_lo, mrla_bn_stats_fwd / mrla_bn_plane_moments gained pivot,
- *           MRLA_FWD_MOMENTS grew from 6 to 8 floats; mrla_conv1x1_plan / mrla_conv1x1_wgrad_plan were added.
+ *           MRLA_FWD_MOMENTS grew from 6 to 8 floats, mrla_light_apply_bwd gained pre / pre_tmom;
+ *           mrla_conv1x1_plan, mrla_conv1x1_wgrad_plan and mrla_light_apply_bwd_pre_sums were added.
  * A consumer compares mrla_abi_version() (what the loaded library was built from) against this constant before its
  * first call. */
 #define MRLA_ABI_VERSION 2
@@ -139,11 +140,18 @@ int mrla_light_gate_bwd(const float* mom, const float* bmom, const float* gate, 
  * dx = res*dOut + dwconv^T(a*dm*act'(U)) + dyx ;  do_prev = lam*dm ;  dwv_part[rows, c, 9] partial sums
  * of dWv over groups of images (rows = mrla_light_wgrad_rows()).  cb, lam, dp, o_prev, do_prev [opt].
  * relu_mask != 0 (fused producer, x_t = relu(pre + o_prev)): dx <- [x_t > 0]*dx is the gradient wrt `pre` and
- * do_prev <- lam*dm + [x_t > 0]*dx the total gradient wrt o_prev (ReLU + shortcut-add backward folded in). */
+ * do_prev <- lam*dm + [x_t > 0]*dx the total gradient wrt o_prev (ReLU + shortcut-add backward folded in).
+ * pre, pre_tmom [opt, both or neither; relu_mask only]: the caller deferred the BatchNorm in front of the fused producer
+ * (bn3, resnet_mrla_light.py:101-102: x_t = relu(bn3(pre) + o_prev)) and its backward needs, per channel, sum(dpre) and
+ * sum(dpre * pre) with dpre = the dx written here.  Given `pre` (conv3's raw output), the kernel takes both sums on the
+ * way: pre_tmom[rows, c, 2] with rows = mrla_light_wgrad_rows(), in the layout mrla_bn_stats_bwd reads
+ * (mrla_bn_plane_dmoments's separate pass over (dpre, pre) is then not needed).  mrla_light_apply_bwd_pre_sums says
+ * whether the kernels of this shape / layout can (1) or not (MRLA_EUNSUPPORTED). */
+int mrla_light_apply_bwd_pre_sums(int b, int c, int h, int w, int dtype, int layout);
 int mrla_light_apply_bwd(const void* dout, const void* x, const void* o_prev, const float* wv, const float* gate,
                          const float* cb, const float* lam, const float* dp, const float* dyx, void* dx,
-                         void* do_prev, float* dwv_part, int b, int c, int h, int w, int d, int res, int relu_mask,
-                         int dtype, int layout, int act, void* stream);
+                         void* do_prev, float* dwv_part, const void* pre, float* pre_tmom, int b, int c, int h, int w,
+                         int d, int res, int relu_mask, int dtype, int layout, int act, void* stream);
 
 /* =====================================================================================================
  * MRLA-base: softmax over the depth of a stage (resnet/models/modules/mrla_base_module.py:54-89 and the

@@ -34,7 +34,8 @@ SIGNATURES = {
     "mrla_light_stats_bwd": [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P],
     "mrla_light_bn_bwd": [_P, _P, _P, _P, _P, _P, _P, _P, _I, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P],
     "mrla_light_gate_bwd": [_P, _P, _P, _P, _P, _P, _P, _P, _I, _P, _P, _I, _I, _I, _I, _P],
-    "mrla_light_apply_bwd": [_P] * 12 + [_I] * 10 + [_P],
+    "mrla_light_apply_bwd_pre_sums": [_I] * 6,
+    "mrla_light_apply_bwd": [_P] * 14 + [_I] * 10 + [_P],
     "mrla_light_pool_fused": [_P] * 6 + [_I] * 6 + [_P],
     "mrla_light_apply_fwd_fused": [_P] * 11 + [_I] * 8 + [_P],
     "mrla_light_stats_fwd_fused": [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P],

@@ -4,6 +4,7 @@
 #include <atomic>
 #include <mutex>
 
+#include "mrla_device.h"
 #include "mrla_kernels.h"
 
 namespace mrla {
@@ -223,19 +224,27 @@ int mrla_light_gate_bwd(const float* mom, const float* bmom, const float* gate, 
   return launch_gate_bwd(mom, bmom, gate, cb, cb_lo, dp, wq, wk, ksize, dyx, dwqk_part, b, c, hw, d, (hipStream_t)stream);
 }
 
+int mrla_light_apply_bwd_pre_sums(int b, int c, int h, int w, int dtype, int layout) {
+  if (bad_dims(b, c, h, w) || bad_dtype(dtype)) return MRLA_EINVAL;
+  if (layout != MRLA_NHWC && layout != MRLA_NCHW) return MRLA_EINVAL;
+  return (layout == MRLA_NHWC && c % kWave == 0) ? 1 : MRLA_EUNSUPPORTED;
+}
+
 int mrla_light_apply_bwd(const void* dout, const void* x, const void* o_prev, const float* wv, const float* gate,
                          const float* cb, const float* lam, const float* dp, const float* dyx, void* dx,
-                         void* do_prev, float* dwv_part, int b, int c, int h, int w, int d, int res, int relu_mask,
-                         int dtype, int layout, int act, void* stream) {
+                         void* do_prev, float* dwv_part, const void* pre, float* pre_tmom, int b, int c, int h, int w,
+                         int d, int res, int relu_mask, int dtype, int layout, int act, void* stream) {
   if (!dout || !x || !wv || !gate || !dyx || !dx || !dwv_part || bad_dims(b, c, h, w) || bad_dtype(dtype) || d <= 0 ||
       c % d)
     return MRLA_EINVAL;
   if (o_prev && (!lam || !do_prev)) return MRLA_EINVAL;
   if (relu_mask && (!o_prev || act != MRLA_ACT_NONE)) return MRLA_EINVAL;
+  if ((pre == nullptr) != (pre_tmom == nullptr) || (pre_tmom && !relu_mask)) return MRLA_EINVAL;
   if (layout == MRLA_NHWC)
-    return launch_light_apply_bwd_nhwc(dout, x, o_prev, wv, gate, cb, lam, dp, dyx, dx, do_prev, dwv_part, b, c, h, w, d,
-                                       res, relu_mask, dtype, act, (hipStream_t)stream);
+    return launch_light_apply_bwd_nhwc(dout, x, o_prev, wv, gate, cb, lam, dp, dyx, dx, do_prev, dwv_part, pre, pre_tmom, b,
+                                       c, h, w, d, res, relu_mask, dtype, act, (hipStream_t)stream);
   if (layout != MRLA_NCHW) return MRLA_EINVAL;
+  if (pre_tmom) return MRLA_EUNSUPPORTED;
   SlabGeo g;
   const int rc = light_geo(&g, b, c, h, w, dtype);
   if (rc != MRLA_OK) return rc;

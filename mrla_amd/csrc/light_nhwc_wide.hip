@@ -569,27 +569,36 @@ __global__ __launch_bounds__(kMaxStrips * kWave) void light_apply_fwd_pre_wide(
 // cols -1..kS (kS+2 wide).  Step rr: U[rr] on cols -1..kS -> dU[rr]; then dx[rr-1] on the owned cols from dU rows
 // rr-2..rr.  dOut of row rr-1 is read a second time from LDS (two dOut row buffers) instead of being kept in registers.
 // ------------------------------------------------------------------------------------------------
-template <typename T> constexpr int apply_bwd_wave_bytes() {
-  return RowIO<T, kS + 4>::kBytes + 3 * RowIO<T, kS + 2>::kBytes + 2 * RowIO<T, kS>::kBytes;
+// PRE (with RELU only): the caller deferred the BatchNorm in front of the fused producer (bn3, resnet_mrla_light.py:101-102)
+// and its backward needs sum(dpre) and sum(dpre * y3) per channel, y3 = conv3's raw output `pre`.  dpre = dx is formed
+// here, so the two sums are taken here as well (one more kS-wide row fetch per step, two accumulators): the separate
+// 2N statistics pass over (dpre, y3) disappears.  y3 cannot be reconstructed from x_t - o instead: bn3's scale is zero
+// at initialisation (zero_init_last_bn) and tiny early in training.
+template <typename T, bool PRE = false> constexpr int apply_bwd_wave_bytes() {
+  return RowIO<T, kS + 4>::kBytes + 3 * RowIO<T, kS + 2>::kBytes + (PRE ? 3 : 2) * RowIO<T, kS>::kBytes;
 }
 
 // (Measured and rejected, profiles/r02_notes.md: 4-wave workgroups under a 168-register budget -- three waves per SIMD, a
 // wave walking two strips of the 56-wide stage -- 25 % slower; the 168-register cap alone on these 8-wave workgroups 8 %
 // slower than the 171 registers the compiler picks by itself.)
 constexpr int kBwdWaves = kMaxStrips;
-template <typename T, bool GELU, bool HAS_O, bool RELU, bool RAGGED>
+template <typename T, bool GELU, bool HAS_O, bool RELU, bool RAGGED, bool PRE>
 __global__ __launch_bounds__(kBwdWaves * kWave) void light_apply_bwd_wide(
     const T* __restrict__ dout, const T* __restrict__ x, const T* __restrict__ o, const float* __restrict__ wv,
     const float* __restrict__ gate, const float* __restrict__ cb, const float* __restrict__ lam,
     const float* __restrict__ dp, const float* __restrict__ dyx, T* __restrict__ dx, T* __restrict__ dprev,
-    float* __restrict__ dwv_part, int B, int C, int H, int W, int BG, int d, int res) {
-  MRLA_WIDE_PROLOGUE(9, apply_bwd_wave_bytes<T>())
+    float* __restrict__ dwv_part, const T* __restrict__ pre, float* __restrict__ pre_tmom, int B, int C, int H, int W,
+    int BG, int d, int res) {
+  static_assert(!PRE || RELU, "the deferred-BatchNorm sums belong to the fused relu(pre + o) producer");
+  MRLA_WIDE_PROLOGUE(9, (apply_bwd_wave_bytes<T, PRE>()))
   constexpr int XB_ = RowIO<T, kS + 4>::kBytes, GB = RowIO<T, kS + 2>::kBytes, SB = RowIO<T, kS>::kBytes;
   T* bufX = reinterpret_cast<T*>(wbuf);
   unsigned char* bufG2 = wbuf + XB_;                 // dOut row rr lives in half (rr & 1)
   T* bufO = reinterpret_cast<T*>(wbuf + XB_ + 2 * GB);
   T* bufS1 = reinterpret_cast<T*>(wbuf + XB_ + 3 * GB);
   T* bufS2 = reinterpret_cast<T*>(wbuf + XB_ + 3 * GB + SB);
+  T* bufP = reinterpret_cast<T*>(wbuf + XB_ + 3 * GB + 2 * SB);      // (PRE) y3 row rr-1 on the owned columns
+  float pm[2] = {0.f, 0.f};                          // (PRE) sum dpre, sum dpre * y3 over this workgroup's images
   const int G = C / d;
   float w[9];
 #pragma unroll
@@ -608,6 +617,7 @@ __global__ __launch_bounds__(kBwdWaves * kWave) void light_apply_bwd_wide(
     const T* oi = HAS_O ? o + ioff : nullptr;
     T* dxo = dx + ioff;
     T* doo = HAS_O ? dprev + ioff : nullptr;
+    const T* pri = PRE ? pre + ioff : nullptr;
     const float dpb = dp ? dp[b] : 1.f;
     const float a = gate[(size_t)b * G + c / d];
     const float E = e_ * dpb, F = f_ * a;
@@ -623,7 +633,8 @@ __global__ __launch_bounds__(kBwdWaves * kWave) void light_apply_bwd_wide(
       RawRow<kS + 4> xa, xb, xc;                     // x rows rr-1, rr, rr+1
       RawRow<kS + 2> gv, ov;                         // dOut / o of row rr on columns -1 .. kS
       RawRow<kS> gp;                                 // dOut of row rr-1 on the owned columns
-      xa.clear(); xb.clear(); xc.clear(); gv.clear(); ov.clear(); gp.clear();
+      RawRow<kS> pv;                                 // (PRE) y3 of row rr-1 on the owned columns
+      xa.clear(); xb.clear(); xc.clear(); gv.clear(); ov.clear(); gp.clear(); pv.clear();
       float ua[kS + 2], ub[kS + 2], uc[kS + 2];      // dU rows rr-2, rr-1, rr
       float d0[kS], d1[kS], d2[kS];                  // lam*dm of rows rr-1 / rr (RELU: do = lam*dm + dx one step later)
 #pragma unroll
@@ -645,13 +656,16 @@ __global__ __launch_bounds__(kBwdWaves * kWave) void light_apply_bwd_wide(
         row_read_issue<T, kS + 2>(gbuf(rr), lane, gv);
         if (HAS_O) row_read_issue<T, kS + 2>(bufO, lane, ov);
         if (rr >= 1) row_read_issue<T, kS>(gbuf(rr + 1), lane, gp, 1);      // row rr-1, owned pixels
+        if (PRE && rr >= 1) row_read_issue<T, kS>(bufP, lane, pv);
         row_read_fence(XC, true);
         row_read_fence(gv, false);
         if (HAS_O) row_read_fence(ov, false);
         row_read_fence(gp, false);
+        if (PRE) row_read_fence(pv, false);
         row_fetch<T, kS + 4>(ax, xi, rr + 2, H, rowelems, bufX);
         row_fetch<T, kS + 2>(ag, gi, rr + 1, H, rowelems, gbuf(rr + 1));
         if (HAS_O) row_fetch<T, kS + 2>(ag, oi, rr + 1, H, rowelems, bufO);
+        if (PRE) row_fetch<T, kS>(as, pri, rr, H, rowelems, bufP);           // for step rr+1 (pixels past the image: zeros)
         float dorow[kS];
         if (rr >= H) {             // the step past the last row only finishes dx[H-1]
 #pragma unroll
@@ -698,6 +712,10 @@ __global__ __launch_bounds__(kBwdWaves * kWave) void light_apply_bwd_wide(
             if (RELU) y = (XA.v[j + 2] > 0.f) ? y : 0.f;                  // XA = x[rr-1]; owned col j <-> window j+2
             yrow[j] = y;
             dsum[j] = DP[j] + y;
+            if (PRE) {             // (columns past the image have x = 0, hence y = 0: nothing to mask)
+              pm[0] += y;
+              pm[1] = fmaf(y, pv.v[j], pm[1]);
+            }
           }
           row_store<T, kS>(as, dxo, rr - 1, rowelems, lane, bufS1, yrow);
           if (RELU && HAS_O) row_store<T, kS>(as, doo, rr - 1, rowelems, lane, bufS2, dsum);
@@ -721,6 +739,13 @@ __global__ __launch_bounds__(kBwdWaves * kWave) void light_apply_bwd_wide(
   if (wave == 0) {
 #pragma unroll
     for (int k = 0; k < 9; ++k) dwv_part[((size_t)blockIdx.y * C + c) * 9 + k] = wg[k];
+  }
+  if (PRE) {
+    wg_reduce<2>(pm, red, lane, wave, nwaves);
+    if (wave == 0) {
+      pre_tmom[((size_t)blockIdx.y * C + c) * 2 + 0] = pm[0];
+      pre_tmom[((size_t)blockIdx.y * C + c) * 2 + 1] = pm[1];
+    }
   }
 }
 
@@ -827,26 +852,31 @@ int launch_light_apply_fwd_pre_wide(const void* pre, const void* o, const float*
 
 int launch_light_apply_bwd_wide(const void* dout, const void* x, const void* o, const float* wv, const float* gate,
                                 const float* cb, const float* lam, const float* dp, const float* dyx, void* dx,
-                                void* dprev, float* dwv_part, int B, int C, int H, int W, int d, int res, int relu,
-                                int dtype, int act, hipStream_t st) {
+                                void* dprev, float* dwv_part, const void* pre, float* pre_tmom, int B, int C, int H,
+                                int W, int d, int res, int relu, int dtype, int act, hipStream_t st) {
   const bool ragged = (W % kS) != 0;
   const int bg = nhwc_images_per_group(B, C, W);          // = the rows mrla_light_wgrad_rows() promised
-#define CALL_G(T, A, O, R, RG)                                                                                       \
+  if (pre_tmom && (!pre || !relu)) return MRLA_EINVAL;
+#define CALL_G(T, A, O, R, RG, PR)                                                                                   \
   {                                                                                                                  \
-    const WideLaunch L = wide_launch(B, C, W, 9, apply_bwd_wave_bytes<T>(), bg, kBwdWaves);                           \
-    if (set_lds_n(light_apply_bwd_wide<T, A, O, R, RG>, L.lds) != hipSuccess) return MRLA_EHIP;                        \
-    hipLaunchKernelGGL((light_apply_bwd_wide<T, A, O, R, RG>), L.grid, L.block, L.lds, st, (const T*)dout,            \
-                       (const T*)x, (const T*)o, wv, gate, cb, lam, dp, dyx, (T*)dx, (T*)dprev, dwv_part, B, C, H, W, \
-                       L.BG, d, res);                                                                                \
+    const WideLaunch L = wide_launch(B, C, W, 9, apply_bwd_wave_bytes<T, PR>(), bg, kBwdWaves);                       \
+    if (set_lds_n(light_apply_bwd_wide<T, A, O, R, RG, PR>, L.lds) != hipSuccess) return MRLA_EHIP;                    \
+    hipLaunchKernelGGL((light_apply_bwd_wide<T, A, O, R, RG, PR>), L.grid, L.block, L.lds, st, (const T*)dout,        \
+                       (const T*)x, (const T*)o, wv, gate, cb, lam, dp, dyx, (T*)dx, (T*)dprev, dwv_part,             \
+                       (const T*)pre, pre_tmom, B, C, H, W, L.BG, d, res);                                           \
   }
-#define CALL_R(T, A, O, R) { if (ragged) CALL_G(T, A, O, R, true) else CALL_G(T, A, O, R, false) }
+#define CALL_R(T, A, O, R) { if (ragged) CALL_G(T, A, O, R, true, false) else CALL_G(T, A, O, R, false, false) }
+#define CALL_P(T) { if (ragged) CALL_G(T, false, true, true, true, true) else CALL_G(T, false, true, true, false, true) }
 #define CALL(T, A, O)                                                                        \
   {                                                                                          \
-    if (relu) { if (O && !(A)) CALL_R(T, false, true, true) else return MRLA_EINVAL; }       \
-    else CALL_R(T, A, O, false)                                                              \
+    if (relu) {                                                                              \
+      if (!(O && !(A))) return MRLA_EINVAL;                                                  \
+      if (pre_tmom) CALL_P(T) else CALL_R(T, false, true, true)                              \
+    } else CALL_R(T, A, O, false)                                                            \
   }
   MRLA_DISPATCH_T_N(dtype, act, o != nullptr, CALL)
 #undef CALL
+#undef CALL_P
 #undef CALL_R
 #undef CALL_G
   return hip_status(hipGetLastError());

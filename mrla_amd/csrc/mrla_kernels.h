@@ -183,8 +183,8 @@ int launch_light_apply_fwd_pre_wide(const void* pre, const void* o, const float*
                                     hipStream_t st);
 int launch_light_apply_bwd_wide(const void* dout, const void* x, const void* o, const float* wv, const float* gate,
                                 const float* cb, const float* lam, const float* dp, const float* dyx, void* dx,
-                                void* dprev, float* dwv_part, int B, int C, int H, int W, int d, int res, int relu,
-                                int dtype, int act, hipStream_t st);
+                                void* dprev, float* dwv_part, const void* pre, float* pre_tmom, int B, int C, int H,
+                                int W, int d, int res, int relu, int dtype, int act, hipStream_t st);
 int launch_light_stats_bwd_wide(const void* dout, const void* x, const void* o, const float* wv, float* bmom, int B,
                                 int C, int H, int W, int dtype, int act, hipStream_t st);
 int launch_light_stats_fwd_nhwc(const void* x, const void* o, const float* wv, float* mom, void* xout,
@@ -197,8 +197,8 @@ int launch_light_stats_bwd_nhwc(const void* dout, const void* x, const void* o, 
                                 int C, int H, int W, int dtype, int act, hipStream_t st);
 int launch_light_apply_bwd_nhwc(const void* dout, const void* x, const void* o, const float* wv, const float* gate,
                                 const float* cb, const float* lam, const float* dp, const float* dyx, void* dx,
-                                void* dprev, float* dwv_part, int B, int C, int H, int W, int d, int res, int relu,
-                                int dtype, int act, hipStream_t st);
+                                void* dprev, float* dwv_part, const void* pre, float* pre_tmom, int B, int C, int H,
+                                int W, int d, int res, int relu, int dtype, int act, hipStream_t st);
 int nhwc_bn_splits(int B, int C, int HW);
 int launch_nhwc_pool_fused(const void* pre, const float* sc, const float* sh, const void* o, float* part, float* mom,
                            int B, int C, int HW, int dtype, hipStream_t st);

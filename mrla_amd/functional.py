@@ -219,14 +219,37 @@ def _layout_of(x, want=None):
     return L.NCHW, x.contiguous()
 
 
+class _DeferredBnBox:
+    """Hand-over between the fused MRLA producer and the deferred BatchNorm in front of it (bn_act(defer=True)): the MRLA
+    backward apply pass forms dpre, the gradient of that BatchNorm's output, and can take the two per-channel sums its
+    backward needs on the way (mrla_light_apply_bwd: pre / pre_tmom).  It leaves them here, tagged with the gradient tensor
+    they belong to; the BatchNorm's backward uses them when exactly that tensor arrives, and runs its own statistics pass
+    otherwise (another consumer added to the gradient, a layout conversion, a path without the fused sums)."""
+    __slots__ = ("ptr", "shape", "tmom", "rows")
+
+    def __init__(self):
+        self.ptr = self.shape = self.tmom = self.rows = None
+
+    def put(self, dpre, tmom, rows):
+        self.ptr, self.shape, self.tmom, self.rows = dpre.data_ptr(), tuple(dpre.shape), tmom, rows
+
+    def take(self, dy):
+        tmom, rows, ok = self.tmom, self.rows, (self.tmom is not None and dy.data_ptr() == self.ptr
+                                               and tuple(dy.shape) == self.shape)
+        self.ptr = self.shape = self.tmom = self.rows = None
+        return (tmom, rows) if ok else None
+
+
 class LightConfig:
     """Static configuration of one MRLA-light call.  fuse: the first tensor argument is the block's pre-activation
     and x_t = relu(pre + o_prev) is formed inside the statistics kernel (resnet_mrla_light.py:113-114 folded in)."""
-    __slots__ = ("d", "bn_mode", "momentum", "eps", "res", "act", "fuse", "pre_affine", "infer")
+    __slots__ = ("d", "bn_mode", "momentum", "eps", "res", "act", "fuse", "pre_affine", "pre_box", "infer")
 
-    def __init__(self, d, bn_mode=L.BN_NONE, momentum=0.1, eps=1e-5, res=0, act=L.ACT_NONE, fuse=False, pre_affine=None):
+    def __init__(self, d, bn_mode=L.BN_NONE, momentum=0.1, eps=1e-5, res=0, act=L.ACT_NONE, fuse=False, pre_affine=None,
+                 pre_box=None):
         self.d, self.bn_mode, self.momentum, self.eps, self.res, self.act = d, bn_mode, momentum, eps, res, act
         self.pre_affine = pre_affine     # (scale[c], shift[c]) fp32 of a deferred BatchNorm in front of the fused producer
+        self.pre_box = pre_box           # its _DeferredBnBox: where the backward leaves that BatchNorm's gradient sums
         self.infer = False               # nothing will be differentiated (set by mrla_light from the autograd state)
         self.fuse = fuse
 
@@ -325,13 +348,16 @@ class _LightFn(torch.autograd.Function):
         ctx.wv_stride = wv.stride()          # gradient layout contract of DDP: same strides as the parameter
         ctx.pdtypes = (wq.dtype, wk.dtype, wv.dtype, lam.dtype if lam is not None else None,
                        gamma.dtype if gamma is not None else None)
-        ctx.save_for_backward(xc, oc, wq32, wk32, wv32, lam32, gamma32, dp32, mom, gate, bnbuf)
+        # conv3's raw output, when the BatchNorm behind it was deferred and its backward sums can ride in apply_bwd
+        keep_pre = (cfg.fuse and cfg.pre_box is not None and not via_nhwc
+                    and L.load().mrla_light_apply_bwd_pre_sums(b, c, h, w, dt, layout) == 1)
+        ctx.save_for_backward(xc, oc, wq32, wk32, wv32, lam32, gamma32, dp32, mom, gate, bnbuf, pre if keep_pre else None)
         return out.contiguous() if via_nhwc else out
 
     @staticmethod
     @_on_device
     def backward(ctx, dout):
-        xc, oc, wq32, wk32, wv32, lam32, gamma32, dp32, mom, gate, bnbuf = ctx.saved_tensors
+        xc, oc, wq32, wk32, wv32, lam32, gamma32, dp32, mom, gate, bnbuf, pre = ctx.saved_tensors
         cfg, layout, ks = ctx.cfg, ctx.layout, ctx.ks
         b, c, h, w = xc.shape
         d = cfg.d
@@ -361,9 +387,18 @@ class _LightFn(torch.autograd.Function):
         dwv_part = torch.empty((rows, c * 9), dtype=torch.float32, device=dev)
         dx = torch.empty_like(xc)
         do = torch.empty_like(oc) if oc is not None else None
-        _call("mrla_light_apply_bwd", xc.numel() * xc.element_size() * (5 if oc is not None else 3), _ptr(dout), _ptr(xc), _ptr(oc), _ptr(wv32), _ptr(gate), _ptr(cb), _ptr(lam32),
-               _ptr(dp32), _ptr(dyx), _ptr(dx), _ptr(do), _ptr(dwv_part), b, c, h, w, d, cfg.res, int(cfg.fuse), dt, layout,
-               cfg.act, st)
+        # the deferred bn3's backward sums (sum dpre, sum dpre*y3) ride in this pass: one more row fetch, no 2N pass
+        pre_tmom = None
+        if pre is not None and (b * h * w) % rows == 0:
+            pre_tmom = torch.empty((rows, c, 2), dtype=torch.float32, device=dev)
+        else:
+            pre = None
+        _call("mrla_light_apply_bwd", xc.numel() * xc.element_size() * ((5 if oc is not None else 3) + (pre is not None)),
+              _ptr(dout), _ptr(xc), _ptr(oc), _ptr(wv32), _ptr(gate), _ptr(cb), _ptr(lam32),
+              _ptr(dp32), _ptr(dyx), _ptr(dx), _ptr(do), _ptr(dwv_part), _ptr(pre), _ptr(pre_tmom), b, c, h, w, d, cfg.res,
+              int(cfg.fuse), dt, layout, cfg.act, st)
+        if pre_tmom is not None:
+            cfg.pre_box.put(dx, pre_tmom, rows)
         wsum = torch.empty((c * 9 + 2 * ks,), dtype=torch.float32, device=dev)
         L.call("mrla_reduce_rows", _ptr(dwv_part), _ptr(wsum), rows, c * 9, st)
         L.call("mrla_reduce_rows", _ptr(dwqk_part), _ptr(wsum[c * 9:]), b, 2 * ks, st)
@@ -388,7 +423,7 @@ def mrla_light(x, wq, wk, wv, d, o_prev=None, lam=None, bn=None, dp=None, res=Fa
     pre_activation: `x` is the block's pre-activation; x_t = relu(x + o_prev) is formed inside the kernels.  When `x`
     came out of `bn_act(..., defer=True)` its BatchNorm affine is applied there too (x then aliases the conv output).
     """
-    pre_affine = getattr(x, "_mrla_affine", None)
+    pre_affine, pre_box = getattr(x, "_mrla_affine", None), getattr(x, "_mrla_bn_box", None)
     if pre_affine is not None and not pre_activation:
         raise L.MrlaHipError("a deferred BatchNorm output can only feed the fused producer (pre_activation=True)")
     tensors = [t for t in (x, o_prev, wq, wk, wv, lam) if t is not None]
@@ -397,11 +432,12 @@ def mrla_light(x, wq, wk, wv, d, o_prev=None, lam=None, bn=None, dp=None, res=Fa
     infer = not (torch.is_grad_enabled() and any(t.requires_grad for t in tensors))
     if bn is None:
         cfg = LightConfig(d, L.BN_NONE, res=int(res), act=L.ACT_GELU if act_gelu else L.ACT_NONE, fuse=pre_activation,
-                          pre_affine=pre_affine)
+                          pre_affine=pre_affine, pre_box=pre_box)
         cfg.infer = infer
         return _LightFn.apply(x, o_prev, wq, wk, wv, lam, None, None, None, None, dp, cfg)
     cfg = LightConfig(d, L.BN_TRAIN if bn["training"] else L.BN_EVAL, bn.get("momentum", 0.1), bn.get("eps", 1e-5),
-                      int(res), L.ACT_GELU if act_gelu else L.ACT_NONE, fuse=pre_activation, pre_affine=pre_affine)
+                      int(res), L.ACT_GELU if act_gelu else L.ACT_NONE, fuse=pre_activation, pre_affine=pre_affine,
+                      pre_box=pre_box)
     cfg.infer = infer
     return _LightFn.apply(x, o_prev, wq, wk, wv, lam, bn["weight"], bn["bias"], bn["running_mean"], bn["running_var"],
                           dp, cfg)
@@ -760,7 +796,7 @@ class _BnActFn(torch.autograd.Function):
     @staticmethod
     @_on_device
     def forward(ctx, x, gamma, beta, running_mean, running_var, training, momentum, eps, relu, defer=False,
-                pre_moments=None):
+                pre_moments=None, box=None):
         _require_cuda(x, "fused bn/act forward")
         layout, xc = _layout_of(x)
         b, c, h, w = xc.shape
@@ -787,6 +823,7 @@ class _BnActFn(torch.autograd.Function):
                _ptr(bnbuf[2]), _ptr(bnbuf[3]), frows, c, b * h * w // frows, st)
         rs.finish(training)
         ctx.training, ctx.relu, ctx.gdtype, ctx.layout, ctx.rows = training, int(relu), gamma.dtype, layout, rows
+        ctx.box = box if defer else None
         ctx.save_for_backward(xc, gamma32, bnbuf)
         if defer:
             if relu:
@@ -807,11 +844,15 @@ class _BnActFn(torch.autograd.Function):
         if dy.dtype != xc.dtype:
             dy = dy.to(xc.dtype)
         layout, rows = ctx.layout, ctx.rows
+        handed = ctx.box.take(dy) if ctx.box is not None else None      # (sum dz, sum dz*x) taken by the producer of dy
         dy = _layout_of(dy, layout)[1]
         es = xc.element_size()
-        tmom = torch.empty((rows, c, 2), dtype=torch.float32, device=dev)
-        _call("mrla_bn_plane_dmoments", xc.numel() * es * 2, _ptr(dy), _ptr(xc), _ptr(bnbuf[0]), _ptr(bnbuf[1]), ctx.relu,
-              _ptr(tmom), b, c, h, w, dt, layout, st)
+        if handed is not None:
+            tmom, rows = handed
+        else:
+            tmom = torch.empty((rows, c, 2), dtype=torch.float32, device=dev)
+            _call("mrla_bn_plane_dmoments", xc.numel() * es * 2, _ptr(dy), _ptr(xc), _ptr(bnbuf[0]), _ptr(bnbuf[1]), ctx.relu,
+                  _ptr(tmom), b, c, h, w, dt, layout, st)
         small = torch.empty((5, c), dtype=torch.float32, device=dev)          # cb[c,3] | dgamma | dbeta
         cb = small[:3].view(c, 3)
         L.call("mrla_bn_stats_bwd", _ptr(tmom), _ptr(gamma32), _ptr(bnbuf[2]), _ptr(bnbuf[3]),
@@ -820,7 +861,7 @@ class _BnActFn(torch.autograd.Function):
         dx = torch.empty_like(xc)
         _call("mrla_bn_act_bwd", xc.numel() * es * 3, _ptr(dy), _ptr(xc), _ptr(bnbuf[0]), _ptr(bnbuf[1]), _ptr(cb), ctx.relu,
               _ptr(dx), b, c, h, w, dt, layout, st)
-        return dx, small[3].to(ctx.gdtype), small[4].to(ctx.gdtype), None, None, None, None, None, None, None, None
+        return dx, small[3].to(ctx.gdtype), small[4].to(ctx.gdtype), None, None, None, None, None, None, None, None, None
 
 
 def bn_act(x, bn, relu, defer=False, pre_moments=None):
@@ -833,9 +874,11 @@ def bn_act(x, bn, relu, defer=False, pre_moments=None):
         training = bn.training
         momentum = bump_batch_counter(bn) if training else bn.momentum
         if defer:
+            box = _DeferredBnBox()
             y, buf = _BnActFn.apply(x, bn.weight, bn.bias, bn.running_mean, bn.running_var, training, momentum or 0.0,
-                                    bn.eps, False, True, pre_moments)
+                                    bn.eps, False, True, pre_moments, box)
             y._mrla_affine = (buf[0], buf[1])
+            y._mrla_bn_box = box
             return y
         return _BnActFn.apply(x, bn.weight, bn.bias, bn.running_mean, bn.running_var, training, momentum or 0.0, bn.eps,
                               relu, False, pre_moments)

@@ -47,8 +47,10 @@ enum { MRLA_BN_NONE = 0, MRLA_BN_TRAIN = 1, MRLA_BN_EVAL = 2 };
 
 /* ABI version of this header.  Bumped whenever an existing entry point changes its arguments or a record changes size:
  *   1 -> 2: mrla_light_bn_bwd / mrla_light_gate_bwd gained cb_lo, mrla_bn_stats_fwd / mrla_bn_plane_moments gained pivot,
- *           MRLA_FWD_MOMENTS grew from 6 to 8 floats, mrla_light_apply_bwd gained pre / pre_tmom;
- *           mrla_conv1x1_plan, mrla_conv1x1_wgrad_plan and mrla_light_apply_bwd_pre_sums were added.
+ *           MRLA_FWD_MOMENTS grew from 6 to 8 floats, mrla_light_apply_bwd gained pre / pre_tmom,
+ *           mrla_conv1x1_wgrad gained dw_dtype;
+ *           mrla_conv1x1_plan, mrla_conv1x1_wgrad_plan, mrla_light_apply_bwd_pre_sums, mrla_reduce_rows2 and
+ *           mrla_weight_bank_refresh were added.
  * A consumer compares mrla_abi_version() (what the loaded library was built from) against this constant before its
  * first call. */
 #define MRLA_ABI_VERSION 2
@@ -361,10 +363,26 @@ int mrla_conv1x1_wgrad_rows(int m, int k, int n, int dtype);      /* rows of par
 /* Host-side query, `out` is a HOST array of 6 ints: 32-pixel chunks per workgroup, LDS stages, tile n, tile k,
  * splits (= mrla_conv1x1_wgrad_rows()), output tiles. */
 int mrla_conv1x1_wgrad_plan(int m, int k, int n, int dtype, int* out);
-int mrla_conv1x1_wgrad(const void* dy, const void* x, float* part, void* dw, int m, int k, int n, int dtype, void* stream);
+/* dw_dtype: MRLA_BF16 (the autocast copy's gradient, as the stock backward produces it) or MRLA_F32 (the fp32 master
+ * weight's gradient directly: the sum over the partial tiles is fp32 anyway, and the cast kernel autograd would append
+ * disappears). */
+int mrla_conv1x1_wgrad(const void* dy, const void* x, float* part, void* dw, int m, int k, int n, int dtype, int dw_dtype,
+                       void* stream);
+
+/* The bf16 working copies of every fp32 convolution weight the GEMMs above multiply with, refreshed in ONE launch per
+ * training step instead of one autocast cast kernel per convolution and forward (and one transposing copy per input
+ * gradient): replaces what torch.autocast does in front of nn.Conv2d (resnet/train.py runs fp32; the bf16 configuration of
+ * BASELINE.json casts each weight per forward).
+ *   table: DEVICE array of `entries` x 4 int64: { src fp32 [n, k] pointer, dst bf16 [n, k] pointer,
+ *          dst_t bf16 [k, n] pointer or 0, (n << 32) | k };  n % 64 == 0, k % 64 == 0.
+ *   max_tiles: the largest (n / 64) * (k / 64) over the entries. */
+int mrla_weight_bank_refresh(const void* table, int entries, int max_tiles, void* stream);
 
 /* out[n] = sum over rows of in[rows, n] (fixed order, double accumulation). */
 int mrla_reduce_rows(const float* in, float* out, int rows, int n, void* stream);
+/* Two such sums in one launch (a block's dWv partials and its dWq / dWk partials). */
+int mrla_reduce_rows2(const float* in1, float* out1, int rows1, int n1, const float* in2, float* out2, int rows2, int n2,
+                      void* stream);
 
 #ifdef __cplusplus
 }

@@ -76,8 +76,10 @@ SIGNATURES = {
     "mrla_conv1x1_add_supported": [_I] * 4,
     "mrla_conv1x1_fwd_add": [_P, _P, _P, _P, _I, _I, _I, _I, _P],
     "mrla_conv1x1_wgrad_rows": [_I] * 4,
-    "mrla_conv1x1_wgrad": [_P, _P, _P, _P, _I, _I, _I, _I, _P],
+    "mrla_conv1x1_wgrad": [_P, _P, _P, _P, _I, _I, _I, _I, _I, _P],
+    "mrla_weight_bank_refresh": [_P, _I, _I, _P],
     "mrla_reduce_rows": [_P, _P, _I, _I, _P],
+    "mrla_reduce_rows2": [_P, _P, _I, _I, _P, _P, _I, _I, _P],
 }
 
 

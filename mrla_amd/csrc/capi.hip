@@ -573,15 +573,28 @@ int mrla_conv1x1_wgrad_rows(int m, int k, int n, int dtype) {
   return conv1x1_wgrad_rows(m, k, n);
 }
 
-int mrla_conv1x1_wgrad(const void* dy, const void* x, float* part, void* dw, int m, int k, int n, int dtype, void* stream) {
+int mrla_conv1x1_wgrad(const void* dy, const void* x, float* part, void* dw, int m, int k, int n, int dtype, int dw_dtype,
+                       void* stream) {
   if (!dy || !x || !part || !dw || m <= 0 || k <= 0 || n <= 0 || bad_dtype(dtype)) return MRLA_EINVAL;
+  if (dw_dtype != MRLA_BF16 && dw_dtype != MRLA_F32) return MRLA_EINVAL;
   if (dtype != MRLA_BF16) return MRLA_EUNSUPPORTED;
-  return launch_conv1x1_wgrad(dy, x, part, dw, m, k, n, (hipStream_t)stream);
+  return launch_conv1x1_wgrad(dy, x, part, dw, dw_dtype == MRLA_F32, m, k, n, (hipStream_t)stream);
+}
+
+int mrla_weight_bank_refresh(const void* table, int entries, int max_tiles, void* stream) {
+  if (!table || entries <= 0 || max_tiles <= 0) return MRLA_EINVAL;
+  return launch_weight_bank_refresh((const long long*)table, entries, max_tiles, (hipStream_t)stream);
 }
 
 int mrla_reduce_rows(const float* in, float* out, int rows, int n, void* stream) {
   if (!in || !out || rows <= 0 || n <= 0) return MRLA_EINVAL;
   return launch_reduce_rows(in, out, rows, n, (hipStream_t)stream);
+}
+
+int mrla_reduce_rows2(const float* in1, float* out1, int rows1, int n1, const float* in2, float* out2, int rows2, int n2,
+                      void* stream) {
+  if (!in1 || !out1 || !in2 || !out2 || rows1 <= 0 || n1 <= 0 || rows2 <= 0 || n2 <= 0) return MRLA_EINVAL;
+  return launch_reduce_rows2(in1, out1, rows1, n1, in2, out2, rows2, n2, (hipStream_t)stream);
 }
 
 }  // extern "C"

@@ -243,7 +243,8 @@ __global__ __launch_bounds__(kWgWaves* kWave) void conv1x1_wgrad_kernel(const bf
 
 // dW[e] = sum over splits of part[s][e] in a fixed order: a workgroup takes 64 outputs, its 16 groups of 16 lanes take
 // every 16th split with 16-byte loads, LDS folds the groups
-__global__ __launch_bounds__(256) void conv1x1_wgrad_reduce_kernel(const float* __restrict__ part, bf16_t* __restrict__ dW,
+template <typename TO>
+__global__ __launch_bounds__(256) void conv1x1_wgrad_reduce_kernel(const float* __restrict__ part, TO* __restrict__ dW,
                                                                    int splits, int NK) {
   __shared__ float4 red[16][16];
   const int q = threadIdx.x & 15, g = threadIdx.x >> 4;
@@ -268,7 +269,7 @@ __global__ __launch_bounds__(256) void conv1x1_wgrad_reduce_kernel(const float* 
     float t = 0.f;
 #pragma unroll
     for (int i = 0; i < 16; ++i) t += reinterpret_cast<const float*>(&red[i][qq])[cc];
-    dW[blockIdx.x * 64 + threadIdx.x] = from_f<bf16_t>(t);
+    dW[blockIdx.x * 64 + threadIdx.x] = from_f<TO>(t);
   }
 }
 
@@ -320,7 +321,8 @@ int conv1x1_wgrad_plan(int M, int K, int N, int* out) {
   return MRLA_OK;
 }
 
-int launch_conv1x1_wgrad(const void* dy, const void* x, float* part, void* dw, int M, int K, int N, hipStream_t st) {
+int launch_conv1x1_wgrad(const void* dy, const void* x, float* part, void* dw, int dw_f32, int M, int K, int N,
+                         hipStream_t st) {
   const WgPlan p = wgrad_plan(M, K, N);
   if (!p.tiles) return MRLA_EUNSUPPORTED;
   int rc = MRLA_EUNSUPPORTED;
@@ -331,7 +333,10 @@ int launch_conv1x1_wgrad(const void* dy, const void* x, float* part, void* dw, i
 #undef MRLA_WG_TILE
   if (rc != MRLA_OK) return rc;
   const int NK = N * K;
-  hipLaunchKernelGGL(conv1x1_wgrad_reduce_kernel, dim3(NK / 64), dim3(256), 0, st, part, (bf16_t*)dw, p.splits, NK);
+  if (dw_f32)      // the fp32 master weight's gradient directly (no cast kernel behind an autocast convolution)
+    hipLaunchKernelGGL(conv1x1_wgrad_reduce_kernel<float>, dim3(NK / 64), dim3(256), 0, st, part, (float*)dw, p.splits, NK);
+  else
+    hipLaunchKernelGGL(conv1x1_wgrad_reduce_kernel<bf16_t>, dim3(NK / 64), dim3(256), 0, st, part, (bf16_t*)dw, p.splits, NK);
   return hip_status(hipGetLastError());
 }
 

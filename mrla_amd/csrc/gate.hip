@@ -295,6 +295,27 @@ __global__ __launch_bounds__(kThreads) void reduce_rows_kernel(const float* __re
   }
 }
 
+// Two independent column sums in one launch (the dWv and the dWq / dWk partials of one block's backward): blocks
+// [0, g1) take the first matrix, the rest the second.
+struct ReduceJob { const float* in; float* out; int rows, n, cpb; };
+__global__ __launch_bounds__(kThreads) void reduce_rows2_kernel(ReduceJob a, ReduceJob b, int g1) {
+  __shared__ double part[kThreads];
+  const bool first = (int)blockIdx.x < g1;
+  const ReduceJob j = first ? a : b;
+  const int blk = first ? (int)blockIdx.x : (int)blockIdx.x - g1;
+  const int cx = threadIdx.x % j.cpb, ry = threadIdx.x / j.cpb, rl = kThreads / j.cpb;
+  const int i = blk * j.cpb + cx;
+  double s = 0.0;
+  if (i < j.n)
+    for (int r = ry; r < j.rows; r += rl) s += j.in[(size_t)r * j.n + i];
+  part[threadIdx.x] = s;
+  __syncthreads();
+  if (ry == 0 && i < j.n) {
+    for (int k = 1; k < rl; ++k) s += part[k * j.cpb + cx];
+    j.out[i] = (float)s;
+  }
+}
+
 // ------------------------------------------------------------------------------------------------
 // launchers
 // ------------------------------------------------------------------------------------------------
@@ -333,11 +354,24 @@ int launch_gate_bwd(const float* mom, const float* bmom, const float* gate, cons
   return hip_status(hipGetLastError());
 }
 
-int launch_reduce_rows(const float* in, float* out, int rows, int n, hipStream_t st) {
+static int reduce_cpb(int rows, int n) {
   int cpb = 64;
   while (cpb > 1 && cpb / 2 >= n) cpb >>= 1;                  // narrow matrices: fewer columns, more row lanes
   if (rows < 16) cpb = 64;
+  return cpb;
+}
+
+int launch_reduce_rows(const float* in, float* out, int rows, int n, hipStream_t st) {
+  const int cpb = reduce_cpb(rows, n);
   hipLaunchKernelGGL(reduce_rows_kernel, dim3((n + cpb - 1) / cpb), dim3(kThreads), 0, st, in, out, rows, n, cpb);
+  return hip_status(hipGetLastError());
+}
+
+int launch_reduce_rows2(const float* in1, float* out1, int rows1, int n1, const float* in2, float* out2, int rows2, int n2,
+                        hipStream_t st) {
+  const ReduceJob a{in1, out1, rows1, n1, reduce_cpb(rows1, n1)}, b{in2, out2, rows2, n2, reduce_cpb(rows2, n2)};
+  const int g1 = (n1 + a.cpb - 1) / a.cpb, g2 = (n2 + b.cpb - 1) / b.cpb;
+  hipLaunchKernelGGL(reduce_rows2_kernel, dim3(g1 + g2), dim3(kThreads), 0, st, a, b, g1);
   return hip_status(hipGetLastError());
 }
 

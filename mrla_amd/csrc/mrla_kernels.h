@@ -62,6 +62,8 @@ int launch_gate_bwd(const float* mom, const float* bmom, const float* gate, cons
                     const float* dp, const float* wq, const float* wk, int ks, float* dyx, float* dwqk_part, int B, int C, int HW,
                     int d, hipStream_t st);
 int launch_reduce_rows(const float* in, float* out, int rows, int n, hipStream_t st);
+int launch_reduce_rows2(const float* in1, float* out1, int rows1, int n1, const float* in2, float* out2, int rows2, int n2,
+                        hipStream_t st);
 
 
 // base_nchw.hip -- MRLA-base (softmax over depth) kernels
@@ -169,7 +171,10 @@ int launch_conv1x1_wide(const void* x, const void* w, const void* addend, void* 
 // conv1x1_wgrad.hip -- its weight gradient dW[n,k] = sum_m dY[m,n] X[m,k] as a split-M MFMA GEMM (bf16)
 int conv1x1_wgrad_rows(int M, int K, int N);
 int conv1x1_wgrad_plan(int M, int K, int N, int* out);
-int launch_conv1x1_wgrad(const void* dy, const void* x, float* part, void* dw, int M, int K, int N, hipStream_t st);
+int launch_conv1x1_wgrad(const void* dy, const void* x, float* part, void* dw, int dw_f32, int M, int K, int N,
+                         hipStream_t st);
+// weight_bank.hip -- all eligible fp32 conv weights -> bf16 copies (+ transposes) in one launch
+int launch_weight_bank_refresh(const long long* table, int entries, int max_tiles, hipStream_t st);
 // light_nhwc_wide.hip -- the C % 64 == 0 forms on the LDS-DMA row pipeline (nhwc_rows.h)
 int launch_light_stats_fwd_wide(const void* x, const void* o, const float* wv, float* mom, void* xout, const float* psc,
                                 const float* psh, void* vout, int B, int C, int H, int W, int dtype, int act,

@@ -65,8 +65,9 @@ def _ptr(t):
 # mask kernels per resnet50_mrlal step become one _foreach_add_ and one mask table.
 # ------------------------------------------------------------------------------------------------------
 class _Bookkeeping:
-    def __init__(self, n_drop_paths):
+    def __init__(self, n_drop_paths, bank=None):
         self.counters, self.n_dp, self.table, self.key, self.next = [], int(n_drop_paths), None, None, 0
+        self.bank = bank           # WeightBank of the model this forward belongs to (or None)
 
     def drop_path_row(self, batch, drop_prob, device):
         """floor(keep + U[0,1)) / keep for one block: a row of a table drawn once per forward."""
@@ -88,10 +89,11 @@ def current_bookkeeping():
 
 
 @contextlib.contextmanager
-def batched_bookkeeping(n_drop_paths=0):
+def batched_bookkeeping(n_drop_paths=0, bank=None):
     """Inside: train-mode BatchNorm counters handled by bn_act / the fused tails are collected and bumped with ONE
-    torch._foreach_add_ on exit, and layers.drop_path_scale serves stochastic-depth rows from one table."""
-    prev, book = current_bookkeeping(), _Bookkeeping(n_drop_paths)
+    torch._foreach_add_ on exit, layers.drop_path_scale serves stochastic-depth rows from one table, and conv_bn_act
+    takes the bf16 working copies of its weights from `bank` (a refreshed WeightBank)."""
+    prev, book = current_bookkeeping(), _Bookkeeping(n_drop_paths, bank)
     _TLS.book = book
     try:
         yield book
@@ -400,8 +402,7 @@ class _LightFn(torch.autograd.Function):
         if pre_tmom is not None:
             cfg.pre_box.put(dx, pre_tmom, rows)
         wsum = torch.empty((c * 9 + 2 * ks,), dtype=torch.float32, device=dev)
-        L.call("mrla_reduce_rows", _ptr(dwv_part), _ptr(wsum), rows, c * 9, st)
-        L.call("mrla_reduce_rows", _ptr(dwqk_part), _ptr(wsum[c * 9:]), b, 2 * ks, st)
+        L.call("mrla_reduce_rows2", _ptr(dwv_part), _ptr(wsum), rows, c * 9, _ptr(dwqk_part), _ptr(wsum[c * 9:]), b, 2 * ks, st)
 
         sq, sk, sv, sl = ctx.shapes
         tq, tk, tv, tl, tg = ctx.pdtypes
@@ -681,8 +682,7 @@ class _BaseFn(torch.autograd.Function):
                   _ptr(stage.dA), _ptr(stage.P), _ptr(dyx), _ptr(dx), _ptr(dwv_part), b, c, h, w, d, T, t, Tc, res, dt,
                   layout, st)
         wsum = torch.empty((c * 9 + 2 * ks,), dtype=torch.float32, device=dev)
-        L.call("mrla_reduce_rows", _ptr(dwv_part), _ptr(wsum), rows, c * 9, st)
-        L.call("mrla_reduce_rows", _ptr(dwqk_part), _ptr(wsum[c * 9:]), b, 2 * ks, st)
+        L.call("mrla_reduce_rows2", _ptr(dwv_part), _ptr(wsum), rows, c * 9, _ptr(dwqk_part), _ptr(wsum[c * 9:]), b, 2 * ks, st)
         sq, sk, sv = ctx.shapes
         tq, tk, tv, _ = ctx.pdtypes
         return (dx, dx if cfg.fuse else None, wsum[c * 9:c * 9 + ks].view(sq).to(tq), wsum[c * 9 + ks:].view(sk).to(tk),
@@ -772,8 +772,8 @@ class _TokenLightFn(torch.autograd.Function):
         _call("mrla_token_ln_bwd", xc.numel() * es * 5 + dxn.numel() * 4, _ptr(dout), _ptr(xc), _ptr(oc), _ptr(dxn),
               _ptr(stats), _ptr(wxw), _ptr(wow), _ptr(lam32), _ptr(dx), _ptr(do), b, n, c, res, dt, st)
         sums = torch.empty((c * L.TOKEN_PARTIALS + 2 * ks,), dtype=torch.float32, device=dev)
-        L.call("mrla_reduce_rows", _ptr(part), _ptr(sums), prow, c * L.TOKEN_PARTIALS, st)
-        L.call("mrla_reduce_rows", _ptr(dwqk_part), _ptr(sums[c * L.TOKEN_PARTIALS:]), b, 2 * ks, st)
+        L.call("mrla_reduce_rows2", _ptr(part), _ptr(sums), prow, c * L.TOKEN_PARTIALS, _ptr(dwqk_part),
+               _ptr(sums[c * L.TOKEN_PARTIALS:]), b, 2 * ks, st)
         pc = sums[:c * L.TOKEN_PARTIALS].view(c, L.TOKEN_PARTIALS)
         dwqk = sums[c * L.TOKEN_PARTIALS:]
         raw = (pc[:, 10], pc[:, 11], pc[:, 12], pc[:, 13], dwqk[:ks], dwqk[ks:], pc[:, :9], pc[:, 9])
@@ -798,6 +798,7 @@ class _BnActFn(torch.autograd.Function):
     def forward(ctx, x, gamma, beta, running_mean, running_var, training, momentum, eps, relu, defer=False,
                 pre_moments=None, box=None):
         _require_cuda(x, "fused bn/act forward")
+        ctx.set_materialize_grads(False)       # (no zero-filled gradient tensor for the non-differentiable second output)
         layout, xc = _layout_of(x)
         b, c, h, w = xc.shape
         if layout == L.NHWC and c % (16 // xc.element_size()):
@@ -838,6 +839,8 @@ class _BnActFn(torch.autograd.Function):
     @staticmethod
     @_on_device
     def backward(ctx, dy, _dbuf=None):
+        if dy is None:
+            return (None,) * 12
         xc, gamma32, bnbuf = ctx.saved_tensors
         b, c, h, w = xc.shape
         dt, dev, st = _DT[xc.dtype], xc.device, _stream()
@@ -969,6 +972,61 @@ def bn_relu_maxpool(x, bn, pool):
 # ======================================================================================================
 # 1x1 stride-1 convolution as an MFMA GEMM with the BatchNorm statistics in its epilogue
 # ======================================================================================================
+class WeightBank:
+    """bf16 working copies [n, k] (and transposes [k, n]) of a model's fp32 1x1-convolution weights, refreshed by ONE
+    launch of mrla_weight_bank_refresh per training step: what torch.autocast does with one cast kernel per convolution
+    and forward, and what the input-gradient GEMM needed one transposing copy per call for.  Built lazily for the
+    eligible convolutions of a model (1x1, stride 1, no bias, fp32 weight, both channel counts multiples of 64);
+    `refresh()` re-launches only when a weight changed (version counters), always while a HIP graph is being captured."""
+
+    def __init__(self, convs):
+        self.convs = [c for c in convs if self.eligible(c)]
+        self.key = self.sig = None
+        self.entries = {}
+
+    @staticmethod
+    def eligible(conv):
+        return (type(conv) is torch.nn.Conv2d and conv.kernel_size == (1, 1) and conv.stride == (1, 1)
+                and conv.padding == (0, 0) and conv.dilation == (1, 1) and conv.groups == 1 and conv.bias is None
+                and conv.in_channels % 64 == 0 and conv.out_channels % 64 == 0)
+
+    def _build(self, live):
+        dev = live[0].weight.device
+        total = sum(c.weight.numel() for c in live)
+        self.flat = torch.empty((2, total), dtype=torch.bfloat16, device=dev)
+        rows, off, self.entries, self.max_tiles = [], 0, {}, 1
+        for c in live:
+            n, k = c.out_channels, c.in_channels
+            w16, w16t = self.flat[0, off:off + n * k].view(n, k), self.flat[1, off:off + n * k].view(k, n)
+            rows.append([c.weight.data_ptr(), w16.data_ptr(), w16t.data_ptr(), (n << 32) | k])
+            self.entries[id(c)] = (w16, w16t)
+            self.max_tiles = max(self.max_tiles, (n // 64) * (k // 64))
+            off += n * k
+        self.table = torch.tensor(rows, dtype=torch.int64).to(dev)
+        self.n = len(rows)
+
+    def refresh(self):
+        live = [c for c in self.convs if c.weight.is_cuda and c.weight.dtype == torch.float32
+                and (c.weight.is_contiguous() or c.weight.is_contiguous(memory_format=_CL))]
+        if not live:
+            self.entries = {}
+            return self
+        sig = tuple((id(c), c.weight.data_ptr()) for c in live)
+        if sig != self.sig:                       # first use, or the parameters moved (.to(), load with assign=...)
+            self._build(live)
+            self.sig, self.key = sig, None
+        key = tuple(c.weight._version for c in live)
+        if key != self.key or torch.cuda.is_current_stream_capturing():
+            with torch.cuda.device(self.table.device):
+                L.call("mrla_weight_bank_refresh", _ptr(self.table), self.n, self.max_tiles, _stream())
+            self.key = key
+        return self
+
+    def get(self, conv):
+        """(w bf16 [n, k], w^T bf16 [k, n]) of `conv`, or None when it is not in the bank."""
+        return self.entries.get(id(conv))
+
+
 class _Conv1x1Fn(torch.autograd.Function):
     """y = conv2d(x, w) for a bias-free 1x1 stride-1 convolution of a channels_last bf16 tensor, plus the partial
     (sum, sum^2) rows of y the following BatchNorm needs (mrla_conv1x1_fwd; shapes that kernel does not take run the
@@ -977,15 +1035,21 @@ class _Conv1x1Fn(torch.autograd.Function):
 
     @staticmethod
     @_on_device
-    def forward(ctx, x, w, want_moments, passthrough=False):
+    def forward(ctx, x, w, want_moments, passthrough=False, w16=None, w16t=None):
+        """w16 / w16t: bf16 working copies [n, k] / [k, n] of an fp32 master weight `w` (WeightBank); the weight gradient
+        is then returned in the master's dtype straight from the reduction kernel."""
+        ctx.set_materialize_grads(False)       # (the moment rows carry no gradient; the shortcut's may be absent)
         b, k, h, wd = x.shape
         n = w.shape[0]
         m = b * h * wd
         dev, st = x.device, _stream()
-        ctx.wshape, ctx.wstride = w.shape, w.stride()     # [n, k] or the module's [n, k, 1, 1] (any dense strides)
-        w = w.reshape(n, k)                                # (a view: the 1x1 taps carry no data)
-        if not w.is_contiguous():
-            w = w.contiguous()
+        ctx.wshape, ctx.wstride, ctx.wdtype = w.shape, w.stride(), w.dtype   # [n, k] or the module's [n, k, 1, 1]
+        if w16 is not None:
+            w = w16
+        else:
+            w = w.reshape(n, k)                            # (a view: the 1x1 taps carry no data)
+            if not w.is_contiguous():
+                w = w.contiguous()
         part = None
         if L.load().mrla_conv1x1_rows(m, k, n, _DT[x.dtype]) > 0:
             y = torch.empty((b, n, h, wd), dtype=x.dtype, device=dev, memory_format=_CL)
@@ -996,7 +1060,7 @@ class _Conv1x1Fn(torch.autograd.Function):
                   n, _DT[x.dtype], st)
         else:
             y = torch.nn.functional.conv2d(x, w.view(n, k, 1, 1))
-        ctx.save_for_backward(x, w)
+        ctx.save_for_backward(x, w, w16t)
         if part is None:
             part = torch.empty(0, device=dev)
         ctx.mark_non_differentiable(part)
@@ -1007,7 +1071,9 @@ class _Conv1x1Fn(torch.autograd.Function):
     @staticmethod
     @_on_device
     def backward(ctx, dy, _dpart=None, d_through=None):
-        x, w = ctx.saved_tensors
+        x, w, w16t = ctx.saved_tensors
+        if dy is None:             # only the shortcut carried a gradient
+            return (d_through if ctx.needs_input_grad[0] else None), None, None, None, None, None
         dy = dy.contiguous(memory_format=_CL)
         n, k = w.shape
         b, _, h, wd = x.shape
@@ -1023,7 +1089,7 @@ class _Conv1x1Fn(torch.autograd.Function):
             d_through = d_through.to(x.dtype).contiguous(memory_format=_CL)
         if need_x and same and lib.mrla_conv1x1_rows(m, n, k, dt) > 0:
             gx = torch.empty_like(x)
-            wt = w.t().contiguous()
+            wt = w16t if w16t is not None else w.t().contiguous()
             if d_through is not None and lib.mrla_conv1x1_add_supported(m, n, k, dt) == 1:
                 # ... + the shortcut's gradient in the GEMM epilogue (fp32 sum, one rounding) instead of a separate
                 # accumulation pass over the block input's gradient
@@ -1036,13 +1102,13 @@ class _Conv1x1Fn(torch.autograd.Function):
             need_x = False
         # the weight gradient dW[n, k] = sum_m dY[m, n] * X[m, k]: one pass over both activations, per-workgroup partial
         # tiles summed by a second kernel (MIOpen: memset + atomics into fp32 + a cast kernel)
-        if need_w and same and w.dtype == x.dtype:
+        if need_w and same and w.dtype == x.dtype and ctx.wdtype in (x.dtype, torch.float32):
             rows = lib.mrla_conv1x1_wgrad_rows(m, k, n, dt)
             if rows > 0:
                 part = torch.empty((rows, n, k), dtype=torch.float32, device=x.device)
-                gw = torch.empty((n, k), dtype=w.dtype, device=x.device)
+                gw = torch.empty((n, k), dtype=ctx.wdtype, device=x.device)       # the master's dtype, no cast kernel behind
                 _call("mrla_conv1x1_wgrad", (dy.numel() + x.numel()) * x.element_size(), _ptr(dy), _ptr(x), _ptr(part),
-                      _ptr(gw), m, k, n, dt, _stream())
+                      _ptr(gw), m, k, n, dt, _DT[ctx.wdtype], _stream())
                 need_w = False
         if need_x or need_w:
             gx2, gw2, _ = torch.ops.aten.convolution_backward(dy, x, w.view(n, k, 1, 1), None, (1, 1), (0, 0), (1, 1), False,
@@ -1051,9 +1117,9 @@ class _Conv1x1Fn(torch.autograd.Function):
             gw = gw2.reshape(n, k) if need_w else gw
         if d_through is not None and ctx.needs_input_grad[0]:
             gx = gx + d_through
-        if gw is not None:          # the weight's own shape AND strides (autograd's / DDP's gradient layout contract)
-            gw = _grad_like(gw, ctx.wshape, ctx.wstride)
-        return gx, gw, None, None
+        if gw is not None:          # the weight's own dtype, shape AND strides (autograd's / DDP's gradient layout contract)
+            gw = _grad_like(gw.to(ctx.wdtype), ctx.wshape, ctx.wstride)
+        return gx, gw, None, None, None, None
 
 
 def conv1x1_applies(conv, x):
@@ -1083,13 +1149,18 @@ def conv_bn_act(x, conv, bn, relu, defer=False, passthrough=False):
     convolution's input-gradient GEMM instead of by a separate accumulation pass."""
     fused_bn = (type(bn) is torch.nn.BatchNorm2d and bn.affine and bn.track_running_stats)
     if conv1x1_applies(conv, x):
-        wt = conv.weight
+        wt, w16, w16t = conv.weight, None, None
         if wt.dtype != x.dtype:
-            wt = wt.to(x.dtype)                      # what autocast does for the stock convolution (differentiable)
+            book = current_bookkeeping()
+            held = book.bank.get(conv) if (book is not None and book.bank is not None and wt.dtype == torch.float32) else None
+            if held is not None:
+                w16, w16t = held                     # the step's bf16 working copy and its transpose (WeightBank)
+            else:
+                wt = wt.to(x.dtype)                  # what autocast does for the stock convolution (differentiable)
         if passthrough and torch.is_grad_enabled() and x.requires_grad:
-            y, part, through = _Conv1x1Fn.apply(x, wt, bool(fused_bn and bn.training), True)
+            y, part, through = _Conv1x1Fn.apply(x, wt, bool(fused_bn and bn.training), True, w16, w16t)
             return bn_act(y, bn, relu, defer, pre_moments=part if part.numel() else None), through
-        y, part = _Conv1x1Fn.apply(x, wt, bool(fused_bn and bn.training))
+        y, part = _Conv1x1Fn.apply(x, wt, bool(fused_bn and bn.training), False, w16, w16t)
         out = bn_act(y, bn, relu, defer, pre_moments=part if part.numel() else None)
         return (out, x) if passthrough else out
     out = bn_act(conv(x), bn, relu, defer)

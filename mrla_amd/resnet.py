@@ -194,6 +194,22 @@ class _ResNetMRLA(nn.Module):
                 if isinstance(m, _BottleneckTrunk):
                     nn.init.constant_(m.bn3.weight, 0)
 
+    def _weight_bank(self):
+        """The refreshed WeightBank of this network's 1x1 convolutions (one cast launch per step instead of one per
+        convolution), or None when nothing of it applies (CPU model, weights not fp32)."""
+        bank = self.__dict__.get("_bank")
+        if bank is None:
+            convs = []
+            for m in self.modules():
+                if isinstance(m, _BottleneckTrunk):
+                    convs += [m.conv1, m.conv3]
+                    if isinstance(m.downsample, nn.Sequential) and len(m.downsample) == 2:
+                        convs.append(m.downsample[0])
+            bank = self.__dict__["_bank"] = F_.WeightBank(convs)
+        if not torch.is_autocast_enabled("cuda"):
+            return None                            # fp32 runs multiply with the master weights themselves
+        return bank.refresh()
+
     def _stochastic_depth_blocks(self):
         """Blocks that will draw a stochastic-depth mask in this forward (0: none, each block draws its own)."""
         if not (self.training and self.drop_path):
@@ -243,7 +259,7 @@ class ResNet_mrlal(_ResNetMRLA):
     def forward_features(self, x):
         if self.channels_last and x.is_cuda:
             x = x.contiguous(memory_format=torch.channels_last)
-        with F_.batched_bookkeeping(self._stochastic_depth_blocks()):
+        with F_.batched_bookkeeping(self._stochastic_depth_blocks(), self._weight_bank() if x.is_cuda else None):
             x = F_.bn_relu_maxpool(self.conv1(x), self.bn1, self.maxpool)
             return self.layer4(self.layer3(self.layer2(self.layer1(x))))
 
@@ -285,7 +301,7 @@ class ResNet_mrlab(_ResNetMRLA):
     def forward_features(self, x):
         if self.channels_last and x.is_cuda:
             x = x.contiguous(memory_format=torch.channels_last)
-        with F_.batched_bookkeeping(self._stochastic_depth_blocks()):
+        with F_.batched_bookkeeping(self._stochastic_depth_blocks(), self._weight_bank() if x.is_cuda else None):
             x = F_.bn_relu_maxpool(self.conv1(x), self.bn1, self.maxpool)
             k = v = None
             for stage in self.stages:

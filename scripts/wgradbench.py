@@ -43,7 +43,7 @@ for (cin, cout, hw, cnt) in [(64, 64, 56, 1), (64, 256, 56, 4), (256, 64, 56, 2)
     st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
     t_ref = timeit(lambda: torch.ops.aten.convolution_backward(dy, x, w, None, (1, 1), (0, 0), (1, 1), False, (0, 0), 1,
                                                                [False, True, False]))
-    t_own = timeit(lambda: L.call("mrla_conv1x1_wgrad", P(dy), P(x), P(part), P(dw), m, cin, cout, L.BF16, st))
+    t_own = timeit(lambda: L.call("mrla_conv1x1_wgrad", P(dy), P(x), P(part), P(dw), m, cin, cout, L.BF16, L.BF16, st))
     ref = torch.ops.aten.convolution_backward(dy, x, w, None, (1, 1), (0, 0), (1, 1), False, (0, 0), 1, [False, True, False])[1]
     err = ((dw.float() - ref.view(cout, cin).float()).norm() / ref.float().norm()).item()
     gb = (x.numel() + dy.numel()) * 2 / 1e9

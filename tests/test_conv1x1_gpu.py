@@ -152,7 +152,7 @@ def test_weight_gradient_gemm(shape):
     dw = torch.full((n, k), float("nan"), dtype=torch.bfloat16, device="cuda")
     st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
     L.call("mrla_conv1x1_wgrad", ctypes.c_void_p(dyt.data_ptr()), ctypes.c_void_p(xt.data_ptr()),
-           ctypes.c_void_p(part.data_ptr()), ctypes.c_void_p(dw.data_ptr()), m, k, n, L.BF16, st)
+           ctypes.c_void_p(part.data_ptr()), ctypes.c_void_p(dw.data_ptr()), m, k, n, L.BF16, L.BF16, st)
     torch.cuda.synchronize()
     want = dy.reshape(m, n).astype(np.float64).T @ x.reshape(m, k).astype(np.float64)
     got = dw.float().cpu().numpy()
@@ -230,12 +230,12 @@ def test_gemm_with_addend_epilogue(shape):
     y = torch.full((m, n), float("nan"), dtype=torch.bfloat16, device="cuda")
     st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
     P = lambda t: ctypes.c_void_p(t.data_ptr())
-    L.call("mrla_conv1x1_fwd_add", P(xt), P(wtt), P(at), P(y), m, k, n, L.BF16, st)
+    L.call("mrla_conv1x1_fwd_add", P(xt), P(wtt), P(at), P(y), m, k, n, L.BF16, L.BF16, st)
     torch.cuda.synchronize()
     want = x.reshape(m, k).astype(np.float64) @ wt.astype(np.float64).T + add.astype(np.float64)
     assert_bf16_close(y.float().cpu().numpy(), want, "y")
     inplace = at.clone()
-    L.call("mrla_conv1x1_fwd_add", P(xt), P(wtt), P(inplace), P(inplace), m, k, n, L.BF16, st)
+    L.call("mrla_conv1x1_fwd_add", P(xt), P(wtt), P(inplace), P(inplace), m, k, n, L.BF16, L.BF16, st)
     torch.cuda.synchronize()
     assert torch.equal(inplace, y)
 
@@ -281,3 +281,90 @@ def test_shortcut_gradient_joins_the_input_gradient_gemm(shape):
     with torch.no_grad(), torch.autocast("cuda", dtype=torch.bfloat16):
         o2, t2 = Fm.conv_bn_act(xt, conv, bn, relu=True, passthrough=True)
     assert t2 is xt
+
+
+def test_weight_bank_refresh_and_fp32_weight_gradient():
+    """mrla_weight_bank_refresh: every fp32 1x1-convolution weight -> its bf16 working copy and the transpose, in one
+    launch, bit-equal to torch's `.bfloat16()` (what autocast's cast kernel produces); refreshed only when a weight
+    changed; and mrla_conv1x1_wgrad with dw_dtype = MRLA_F32 writes the fp32 sum whose bf16 rounding is the bf16 result."""
+    import ctypes
+    from mrla_amd import _lib as L, functional as Fm
+    torch.manual_seed(3)
+    convs = [torch.nn.Conv2d(k, n, 1, bias=False).cuda() for k, n in ((64, 256), (256, 64), (512, 2048), (1024, 256), (128, 128))]
+    convs[1].to(memory_format=torch.channels_last)
+    odd = [torch.nn.Conv2d(64, 96, 1, bias=False).cuda(), torch.nn.Conv2d(64, 64, 1, stride=2, bias=False).cuda(),
+           torch.nn.Conv2d(64, 64, 3, padding=1, bias=False).cuda()]
+    bank = Fm.WeightBank(convs + odd).refresh()
+    torch.cuda.synchronize()
+    assert all(bank.get(c) is None for c in odd)
+    for c in convs:
+        w16, w16t = bank.get(c)
+        want = c.weight.detach().reshape(c.out_channels, c.in_channels).bfloat16()
+        assert torch.equal(w16, want) and torch.equal(w16t, want.t().contiguous())
+    # unchanged weights: no launch (poison the copies, refresh, still poisoned); an in-place update: refreshed
+    bank.flat.fill_(float("nan"))
+    bank.refresh()
+    torch.cuda.synchronize()
+    assert torch.isnan(bank.get(convs[0])[0].float()).all()
+    with torch.no_grad():
+        convs[0].weight.mul_(0.5)
+    bank.refresh()
+    torch.cuda.synchronize()
+    for c in convs:
+        assert torch.equal(bank.get(c)[0], c.weight.detach().reshape(c.out_channels, c.in_channels).bfloat16())
+    # fp32 weight gradient straight from the reduction kernel
+    b, h, w, k, n = 3, 14, 14, 256, 1024
+    m = b * h * w
+    x, _ = _operands(b, h, w, k, n, salt=11)
+    dy = bf16_round(detgen.normalish((m, n), 123))
+    xt, dyt = torch.from_numpy(x).cuda().bfloat16().reshape(m, k), torch.from_numpy(dy).cuda().bfloat16()
+    rows = L.load().mrla_conv1x1_wgrad_rows(m, k, n, L.BF16)
+    st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+    P = lambda t: ctypes.c_void_p(t.data_ptr())
+    part = torch.empty((rows, n, k), dtype=torch.float32, device="cuda")
+    d16 = torch.full((n, k), float("nan"), dtype=torch.bfloat16, device="cuda")
+    d32 = torch.full((n, k), float("nan"), dtype=torch.float32, device="cuda")
+    L.call("mrla_conv1x1_wgrad", P(dyt), P(xt), P(part), P(d16), m, k, n, L.BF16, L.BF16, st)
+    L.call("mrla_conv1x1_wgrad", P(dyt), P(xt), P(part), P(d32), m, k, n, L.BF16, L.F32, st)
+    torch.cuda.synchronize()
+    assert torch.equal(d32.bfloat16(), d16)
+    want = dy.astype(np.float64).T @ x.reshape(m, k).astype(np.float64)
+    assert relmax(d32.cpu().numpy(), want) < 1e-5
+
+
+def test_model_with_and_without_the_weight_bank_agree_bit_for_bit():
+    """resnet50_mrlal under bf16 autocast: the banked bf16 weights are the very values autocast's per-convolution casts
+    produce, so logits and every gradient must be identical with the bank switched off -- except the 1x1 convolutions'
+    weight gradients, which the bank path takes in fp32 from the reduction kernel instead of through a bf16 rounding."""
+    from mrla_amd import models, resnet
+    import contextlib, io
+    torch.manual_seed(0)
+    with contextlib.redirect_stdout(io.StringIO()):
+        net = models.resnet50_mrlal(drop_path=0.0).cuda().train()
+    with torch.no_grad():
+        for mod in net.modules():
+            if isinstance(mod, resnet._BottleneckTrunk):
+                mod.bn3.weight.fill_(0.5)
+    x = torch.randn(4, 3, 224, 224, device="cuda")
+    y = torch.tensor([1, 2, 3, 4], device="cuda")
+    res = []
+    for use_bank in (True, False):
+        net.zero_grad(set_to_none=True)
+        for mod in net.modules():
+            if isinstance(mod, torch.nn.BatchNorm2d):
+                mod.reset_running_stats()
+        if not use_bank:
+            net.__dict__["_bank"] = type("NoBank", (), {"refresh": lambda self: None})()
+        with torch.autocast("cuda", dtype=torch.bfloat16):
+            logits = net(x)
+        torch.nn.functional.cross_entropy(logits.float(), y).backward()
+        torch.cuda.synchronize()
+        res.append((logits.detach().clone(), {k_: p.grad.clone() for k_, p in net.named_parameters()}))
+    assert torch.equal(res[0][0], res[1][0])
+    banked = {id(c.weight) for c in resnet.F_.WeightBank([m_ for m_ in net.modules() if isinstance(m_, torch.nn.Conv2d)]).convs}
+    for k_, p in net.named_parameters():
+        a, b_ = res[0][1][k_], res[1][1][k_]
+        if id(p) in banked:
+            assert torch.equal(a.bfloat16(), b_.bfloat16()), k_           # fp32 sum vs the same sum rounded to bf16
+        else:
+            assert torch.equal(a, b_), k_

@@ -153,7 +153,7 @@ def test_weight_gradient_gemm_in_steady_state(shape, batch):
     def run():
         part = torch.full((splits, n, k), float("nan"), dtype=torch.float32, device="cuda")
         dw = torch.full((n, k), float("nan"), dtype=torch.bfloat16, device="cuda")
-        L.call("mrla_conv1x1_wgrad", _P(dy), _P(x), _P(part), _P(dw), m, k, n, L.BF16, _stream())
+        L.call("mrla_conv1x1_wgrad", _P(dy), _P(x), _P(part), _P(dw), m, k, n, L.BF16, L.BF16, _stream())
         return part, dw
     part, dw = run()
     part2, dw2 = run()

@@ -52,7 +52,7 @@ def test_argument_validation_without_a_gpu():
     assert lib.mrla_conv1x1_wgrad_rows(33, 64, 64, _lib.BF16) == 2                      # two 32-pixel chunks
     assert lib.mrla_conv1x1_wgrad_rows(64, 96, 64, _lib.BF16) == _lib.EUNSUPPORTED
     assert lib.mrla_conv1x1_wgrad_rows(1 << 24, 128, 64, _lib.BF16) == _lib.EUNSUPPORTED  # 32-bit buffer offsets
-    assert lib.mrla_conv1x1_wgrad(None, None, None, None, 64, 64, 64, _lib.BF16, None) == _lib.EINVAL
+    assert lib.mrla_conv1x1_wgrad(None, None, None, None, 64, 64, 64, _lib.BF16, _lib.BF16, None) == _lib.EINVAL
 
 
 def test_model_surface_matches_reference_names():

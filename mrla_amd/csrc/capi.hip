@@ -227,7 +227,8 @@ int mrla_light_gate_bwd(const float* mom, const float* bmom, const float* gate, 
 int mrla_light_apply_bwd_pre_sums(int b, int c, int h, int w, int dtype, int layout) {
   if (bad_dims(b, c, h, w) || bad_dtype(dtype)) return MRLA_EINVAL;
   if (layout != MRLA_NHWC && layout != MRLA_NCHW) return MRLA_EINVAL;
-  return (layout == MRLA_NHWC && c % kWave == 0) ? 1 : MRLA_EUNSUPPORTED;
+  // 16-bit activations only: with fp32 rows the extra row buffer would not fit the 160 KB of LDS beside the others
+  return (layout == MRLA_NHWC && c % kWave == 0 && dtype != MRLA_F32) ? 1 : MRLA_EUNSUPPORTED;
 }
 
 int mrla_light_apply_bwd(const void* dout, const void* x, const void* o_prev, const float* wv, const float* gate,

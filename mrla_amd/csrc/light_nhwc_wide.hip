@@ -857,6 +857,7 @@ int launch_light_apply_bwd_wide(const void* dout, const void* x, const void* o, 
   const bool ragged = (W % kS) != 0;
   const int bg = nhwc_images_per_group(B, C, W);          // = the rows mrla_light_wgrad_rows() promised
   if (pre_tmom && (!pre || !relu)) return MRLA_EINVAL;
+  if (pre_tmom && dtype == MRLA_F32) return MRLA_EUNSUPPORTED;      // (LDS: see mrla_light_apply_bwd_pre_sums)
 #define CALL_G(T, A, O, R, RG, PR)                                                                                   \
   {                                                                                                                  \
     const WideLaunch L = wide_launch(B, C, W, 9, apply_bwd_wave_bytes<T, PR>(), bg, kBwdWaves);                       \
@@ -866,7 +867,12 @@ int launch_light_apply_bwd_wide(const void* dout, const void* x, const void* o, 
                        (const T*)pre, pre_tmom, B, C, H, W, L.BG, d, res);                                           \
   }
 #define CALL_R(T, A, O, R) { if (ragged) CALL_G(T, A, O, R, true, false) else CALL_G(T, A, O, R, false, false) }
-#define CALL_P(T) { if (ragged) CALL_G(T, false, true, true, true, true) else CALL_G(T, false, true, true, false, true) }
+#define CALL_P(T)                                                                                       \
+  {                                                                                                     \
+    if constexpr (sizeof(T) == 2) {                                                                     \
+      if (ragged) CALL_G(T, false, true, true, true, true) else CALL_G(T, false, true, true, false, true) \
+    }                                                                                                   \
+  }
 #define CALL(T, A, O)                                                                        \
   {                                                                                          \
     if (relu) {                                                                              \

@@ -39,9 +39,25 @@ def wrap_data_parallel(model, device_ids=None, bucket_cap_mb=32, force=False):
     hooks, bucket views and RCCL calls then run exactly as at N > 1, with nobody to exchange with)."""
     if not dist.is_initialized() or (dist.get_world_size() == 1 and not force):
         return model
-    return torch.nn.parallel.DistributedDataParallel(
+    ddp = torch.nn.parallel.DistributedDataParallel(
         model, device_ids=device_ids, gradient_as_bucket_view=True, bucket_cap_mb=bucket_cap_mb, static_graph=True,
         broadcast_buffers=False)
+    # Without a communication hook the reducer divides EVERY parameter's gradient by the world size with a kernel of its
+    # own before the bucket goes out (161 launches and ~0.5 ms of GPU time per resnet50_mrlal step, rocprofv3 trace in
+    # profiles/r03_notes.md).  With a hook the averaging is the hook's business: RCCL averages inside the all-reduce
+    # (ReduceOp.AVG), gloo (CPU tests) divides the flat bucket once.
+    ddp.register_comm_hook(None, _allreduce_avg_hook)
+    return ddp
+
+
+def _allreduce_avg_hook(state, bucket):
+    buf = bucket.buffer()
+    if dist.get_backend() == "nccl":
+        fut = dist.all_reduce(buf, op=dist.ReduceOp.AVG, async_op=True).get_future()
+    else:
+        buf.div_(dist.get_world_size())
+        fut = dist.all_reduce(buf, op=dist.ReduceOp.SUM, async_op=True).get_future()
+    return fut.then(lambda f: f.value()[0])
 
 
 def max_over_ranks(seconds, device=None):

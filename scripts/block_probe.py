@@ -1,0 +1,102 @@
+"""Diagnostic: where does the bf16 bottleneck diverge from the staged float64 reference?  Replays MRLA_Bottleneck's forward
+piecewise through the product's functional API, keeps every intermediate and its gradient, and compares with the staged
+reference of tests/test_block_bf16_gpu.py.  python scripts/block_probe.py [stage1|stage3]"""
+import os
+import sys
+
+import torch
+import torch.nn.functional as F
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from mrla_amd import functional as Fm, layers, resnet  # noqa: E402
+from oracle import eager_models as em  # noqa: E402
+from tests.test_block_bf16_gpu import _bn, rnd  # noqa: E402
+
+which = sys.argv[1] if len(sys.argv) > 1 else "stage1"
+b, inplanes, planes, hw = {"stage1": (64, 256, 64, 56), "stage3": (64, 1024, 256, 14)}[which]
+torch.manual_seed(1234)
+blk = resnet.MRLA_Bottleneck(inplanes, planes, drop_path=0.2)
+for mod in blk.modules():
+    if isinstance(mod, torch.nn.Conv2d) and mod.groups == 1:
+        torch.nn.init.kaiming_normal_(mod.weight, mode="fan_out", nonlinearity="relu")
+    elif isinstance(mod, torch.nn.BatchNorm2d):
+        torch.nn.init.uniform_(mod.weight, 0.6, 1.4)
+        torch.nn.init.uniform_(mod.bias, -0.3, 0.3)
+blk = blk.cuda().to(memory_format=torch.channels_last).train()
+ref = em.EagerLightBottleneck(inplanes, planes, drop_path=0.2).cuda().double().train()
+ref.load_state_dict({k: v.double() for k, v in blk.state_dict().items()})
+g = torch.Generator(device="cuda").manual_seed(5)
+x = torch.relu(torch.randn((b, inplanes, hw, hw), device="cuda", generator=g) + 0.3).bfloat16().contiguous(memory_format=torch.channels_last)
+gup = (torch.randn((b, inplanes, hw, hw), device="cuda", generator=g) * 0.1).bfloat16().contiguous(memory_format=torch.channels_last)
+keep = (torch.rand((b,), device="cuda", generator=g) >= 0.2).float()
+dp = keep / 0.8
+layers.drop_path_scale = lambda batch, p, training, device: dp
+
+# ---- product, piecewise (what _BottleneckTrunk.trunk_pre + light_block_tail do) ----
+P, PG = {}, {}
+
+
+def keep_(name, t):
+    P[name] = t.detach()
+    if t.requires_grad:
+        t.register_hook(lambda gr, n=name: PG.__setitem__(n, gr.detach()))
+    return t
+
+
+xp = x.clone().requires_grad_(True)
+with torch.autocast("cuda", dtype=torch.bfloat16):
+    y1, part1 = Fm._Conv1x1Fn.apply(xp, blk.conv1.weight.to(torch.bfloat16), True) if Fm.conv1x1_applies(blk.conv1, xp) else (blk.conv1(xp), None)
+    keep_("y1", y1)
+    z1 = keep_("z1", Fm.bn_act(y1, blk.bn1, True, pre_moments=part1 if part1 is not None and part1.numel() else None))
+    y2 = keep_("y2", blk.conv2(z1))
+    z2 = keep_("z2", Fm.bn_act(y2, blk.bn2, True))
+    y3, part3 = Fm._Conv1x1Fn.apply(z2, blk.conv3.weight.to(torch.bfloat16), True)
+    keep_("y3", y3)
+    pre = Fm.bn_act(y3, blk.bn3, False, defer=True, pre_moments=part3 if part3.numel() else None)
+    out = layers.light_block_tail(pre, xp, blk.mrla, blk.bn_mrla, blk.drop_path, pre_activation=True)
+out.backward(gup)
+
+# ---- staged reference with retained grads ----
+R = {}
+wc = lambda w: w.float().bfloat16().double()  # noqa: E731
+xr = x.double().requires_grad_(True)
+ident = rnd(xr, "bwd")
+R["y1"] = rnd(F.conv2d(xr, wc(ref.conv1.weight)))
+z, *_ = _bn(R["y1"], ref.bn1)
+R["z1"] = rnd(torch.relu(z))
+R["y2"] = rnd(F.conv2d(R["z1"], wc(ref.conv2.weight), padding=1))
+z, *_ = _bn(R["y2"], ref.bn2)
+R["z2"] = rnd(torch.relu(z))
+R["y3"] = rnd(F.conv2d(R["z2"], wc(ref.conv3.weight)))
+pre_r, *_ = _bn(R["y3"], ref.bn3)
+pre_r = rnd(pre_r)
+xt = rnd(torch.relu(pre_r + ident), "fwd")
+m = ref.mrla(xt, ident)
+z, *_ = _bn(m, ref.bn_mrla)
+out_r = rnd(xt + dp.double()[:, None, None, None] * z, "fwd")
+for t in R.values():
+    t.retain_grad()
+out_r.backward(gup.double())
+torch.cuda.synchronize()
+
+
+def cmp(name, got, want):
+    want_r = want.float().bfloat16().float()
+    d = (got.float() - want_r).abs()
+    unit = 2.0 ** -7 * (want_r.abs() + 0.05 * want.abs().max().item())
+    l2 = ((got.double() - want).norm() / want.norm()).item()
+    print(f"{name:8s} L2 {l2:.2e}   >1ulp {((d / unit) > 1).float().mean().item():.2e}   >2ulp {((d / unit) > 2).float().mean().item():.2e}"
+          f"   exact {(d == 0).float().mean().item():.3f}   max|want| {want.abs().max().item():.3g}")
+
+
+for k in ("y1", "z1", "y2", "z2", "y3"):
+    cmp(k, P[k], R[k].detach())
+cmp("out", out.detach(), out_r.detach())
+for k in ("y3", "z2", "y2", "z1", "y1"):
+    cmp("d" + k, PG[k], R[k].grad)
+cmp("dx", xp.grad, xr.grad)
+pref = dict(ref.named_parameters())
+for name, p in blk.named_parameters():
+    e = ((p.grad.double() - pref[name].grad).norm() / pref[name].grad.norm()).item()
+    print(f"grad {name:28s} rel L2 {e:.2e}")

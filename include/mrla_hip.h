@@ -44,11 +44,16 @@ enum { MRLA_BN_NONE = 0, MRLA_BN_TRAIN = 1, MRLA_BN_EVAL = 2 };
                               the second moments are taken about per-plane pivots (samples of V / o; 0 where a producer
                               does not shift) so that they stay well conditioned when |mean| >> sigma */
 #define MRLA_BWD_MOMENTS 3 /* sum dOut, sum dOut*V, sum dOut*o */
+#define MRLA_GEMM_MOMENTS 4 /* the 1x1-convolution GEMM's epilogue, per (workgroup row, out-channel): sum (y - p),
+                               sum (y - p)^2, the pivot p (the row's first rounded output of the channel), pixel count n */
 
 /* ABI version of this header.  Bumped whenever an existing entry point changes its arguments or a record changes size:
  *   1 -> 2: mrla_light_bn_bwd / mrla_light_gate_bwd gained cb_lo, mrla_bn_stats_fwd / mrla_bn_plane_moments gained pivot,
  *           MRLA_FWD_MOMENTS grew from 6 to 8 floats, mrla_light_apply_bwd gained pre / pre_tmom,
- *           mrla_conv1x1_wgrad gained dw_dtype;
+ *           mrla_conv1x1_wgrad gained dw_dtype, mrla_conv1x1_fwd's mom_part became
+ *           [rows, n, MRLA_GEMM_MOMENTS] records (was [rows, n, 2] raw sums) read by the new mrla_bn_stats_fwd_rows,
+ *           mrla_bn_plane_dmoments / mrla_bn_relu_pool_dmoments / mrla_base_tail_stats_bwd gained center and
+ *           mrla_bn_stats_bwd gained centered (BatchNorm-backward sums about the saved mean);
  *           mrla_conv1x1_plan, mrla_conv1x1_wgrad_plan, mrla_light_apply_bwd_pre_sums, mrla_reduce_rows2 and
  *           mrla_weight_bank_refresh were added.
  * A consumer compares mrla_abi_version() (what the loaded library was built from) against this constant before its
@@ -146,14 +151,15 @@ int mrla_light_gate_bwd(const float* mom, const float* bmom, const float* gate, 
  * pre, pre_tmom [opt, both or neither; relu_mask only]: the caller deferred the BatchNorm in front of the fused producer
  * (bn3, resnet_mrla_light.py:101-102: x_t = relu(bn3(pre) + o_prev)) and its backward needs, per channel, sum(dpre) and
  * sum(dpre * pre) with dpre = the dx written here.  Given `pre` (conv3's raw output), the kernel takes both sums on the
- * way: pre_tmom[rows, c, 2] with rows = mrla_light_wgrad_rows(), in the layout mrla_bn_stats_bwd reads
+ * way: pre_tmom[rows, c, 2] = (sum dpre, sum dpre * (pre - pre_center[c])) with rows = mrla_light_wgrad_rows(), in the
+ * layout mrla_bn_stats_bwd reads (pre_center [opt]: that BatchNorm's saved batch mean -> pass centered = 1 there)
  * (mrla_bn_plane_dmoments's separate pass over (dpre, pre) is then not needed).  mrla_light_apply_bwd_pre_sums says
  * whether the kernels of this shape / layout can (1) or not (MRLA_EUNSUPPORTED). */
 int mrla_light_apply_bwd_pre_sums(int b, int c, int h, int w, int dtype, int layout);
 int mrla_light_apply_bwd(const void* dout, const void* x, const void* o_prev, const float* wv, const float* gate,
                          const float* cb, const float* lam, const float* dp, const float* dyx, void* dx,
-                         void* do_prev, float* dwv_part, const void* pre, float* pre_tmom, int b, int c, int h, int w,
-                         int d, int res, int relu_mask, int dtype, int layout, int act, void* stream);
+                         void* do_prev, float* dwv_part, const void* pre, const float* pre_center, float* pre_tmom, int b,
+                         int c, int h, int w, int d, int res, int relu_mask, int dtype, int layout, int act, void* stream);
 
 /* =====================================================================================================
  * MRLA-base: softmax over the depth of a stage (resnet/models/modules/mrla_base_module.py:54-89 and the
@@ -184,18 +190,28 @@ int mrla_bn_stats_fwd(const float* amom, const float* pivot, const float* gamma,
                       float* running_var, int bn_mode, float momentum, float eps, float* sc, float* sh,
                       float* save_mean, float* save_inv, int b, int c, int hw, void* stream);
 
+/* The same from moment records rec[rows, c, MRLA_GEMM_MOMENTS] (pivot and pixel count per row: mrla_conv1x1_fwd's
+ * mom_part): rows are merged by re-basing them onto one pivot, in double. */
+int mrla_bn_stats_fwd_rows(const float* rec, const float* gamma, const float* beta, float* running_mean, float* running_var,
+                           int bn_mode, float momentum, float eps, float* sc, float* sh, float* save_mean, float* save_inv,
+                           int rows, int c, void* stream);
+
 /* out = x + dp[b] * relu(sc[c]*attn + sh[c]).  Replaces the normalisation half of bn_mrla, the ReLU, DropPath and
  * the residual add of resnet_mrla_base.py:125-127.  dp [opt]. */
 int mrla_base_tail_fwd(const void* x, const void* attn, const float* sc, const float* sh, const float* dp, void* out,
                        int b, int c, int h, int w, int dtype, int layout, void* stream);
 
-/* tmom[b,c,2] = (sum dz, sum dz*attn), dz = dp[b]*dOut*[sc*attn + sh > 0]. */
-int mrla_base_tail_stats_bwd(const void* dout, const void* attn, const float* sc, const float* sh, const float* dp,
-                             float* tmom, int b, int c, int h, int w, int dtype, int layout, void* stream);
+/* tmom[b,c,2] = (sum dz, sum dz*(attn - center[c])), dz = dp[b]*dOut*[sc*attn + sh > 0].
+ * center [opt, c floats; MRLA_NHWC only]: the batch mean bn_mrla saved -- the second sum then needs no cancelling
+ * subtraction in mrla_bn_stats_bwd (centered = 1). */
+int mrla_base_tail_stats_bwd(const void* dout, const void* attn, const float* sc, const float* sh, const float* center,
+                             const float* dp, float* tmom, int b, int c, int h, int w, int dtype, int layout, void* stream);
 
-/* cb[c,3] = (e, f, h) with d attn = e*dz + f*attn + h; dgamma, dbeta. */
+/* cb[c,3] = (e, f, h) with d attn = e*dz + f*attn + h; dgamma, dbeta.
+ * centered != 0: tmom's second sum is already sum dz*(x - save_mean[c]) (the producer was given `center` = save_mean):
+ * dgamma = save_inv * that sum, with nothing to cancel when |mean| >> sigma. */
 int mrla_bn_stats_bwd(const float* tmom, const float* gamma, const float* save_mean, const float* save_inv,
-                      int bn_mode, float* cb, float* dgamma, float* dbeta, int b, int c, int hw, void* stream);
+                      int bn_mode, int centered, float* cb, float* dgamma, float* dbeta, int b, int c, int hw, void* stream);
 
 /* dA_t -> da_ring slot t-1; pmom[b,c,t] = sum_hw dA_t * v_j (j < t).  sc == NULL: no tail, dA_t = dOut
  * (attn, sh, dp, cb then unused) -- the backward of a bare mrla_base_layer. */
@@ -305,9 +321,10 @@ int mrla_bn_plane_moments(const void* x, float* amom /*[rows,c,2]: sum x, sum x^
                           int dtype, int layout, void* stream);
 int mrla_bn_act_fwd(const void* x, const float* sc, const float* sh, int relu, void* y, int b, int c, int h, int w,
                     int dtype, int layout, void* stream);
-int mrla_bn_plane_dmoments(const void* dy, const void* x, const float* sc, const float* sh, int relu,
-                           float* tmom /*[b,c,2]: sum dz, sum dz*x*/, int b, int c, int h, int w, int dtype, int layout,
-                           void* stream);
+/* center [opt, c floats]: the saved batch mean -> tmom's second sum is sum dz*(x - center) (see mrla_bn_stats_bwd). */
+int mrla_bn_plane_dmoments(const void* dy, const void* x, const float* sc, const float* sh, const float* center, int relu,
+                           float* tmom /*[b,c,2]: sum dz, sum dz*(x - center)*/, int b, int c, int h, int w, int dtype,
+                           int layout, void* stream);
 int mrla_bn_act_bwd(const void* dy, const void* x, const float* sc, const float* sh, const float* cb /*[c,3]*/, int relu,
                     void* dx, int b, int c, int h, int w, int dtype, int layout, void* stream);
 
@@ -321,8 +338,8 @@ int mrla_bn_act_bwd(const void* dy, const void* x, const float* sc, const float*
 int mrla_bn_pool_rows(int b, int c, int h, int w, int dtype, int layout);
 int mrla_bn_relu_pool_fwd(const void* x, const float* sc, const float* sh, void* out, int b, int c, int h, int w, int dtype,
                           int layout, void* stream);
-int mrla_bn_relu_pool_dmoments(const void* dp, const void* x, const float* sc, const float* sh, float* tmom, int b, int c,
-                               int h, int w, int dtype, int layout, void* stream);
+int mrla_bn_relu_pool_dmoments(const void* dp, const void* x, const float* sc, const float* sh, const float* center /*[opt]*/,
+                               float* tmom, int b, int c, int h, int w, int dtype, int layout, void* stream);
 int mrla_bn_relu_pool_bwd(const void* dp, const void* x, const float* sc, const float* sh, const float* cb /*[c,3]*/,
                           void* dx, int b, int c, int h, int w, int dtype, int layout, void* stream);
 
@@ -332,8 +349,9 @@ int mrla_bn_relu_pool_bwd(const void* dp, const void* x, const float* sc, const 
  * `conv1 -> bn1` and :100-101 `conv3 -> bn3`, both nn.Conv2d(kernel_size=1, stride=1, bias=False)).
  *   y[m, n] = sum_k x[m, k] * w[n, k]        x: channels_last activation viewed as [m = b*h*w, k = c_in] (bf16),
  *                                            w: the conv weight [n = c_out, k] (bf16), y: [m, n] (bf16, fp32 accumulate)
- *   mom_part[row, n, 0..1] [opt] = partial (sum, sum of squares) over the row's pixels of the ROUNDED outputs:
- *   exactly what mrla_bn_plane_moments would read back from y -- pass (rows, m / rows) as (b, hw) to mrla_bn_stats_fwd.
+ *   mom_part[row, n, 0..3] [opt] = moment record (MRLA_GEMM_MOMENTS) over the row's pixels of the ROUNDED outputs --
+ *   the statistics mrla_bn_plane_moments would read back from y, taken about a per-row pivot so that the one-pass
+ *   variance stays well conditioned when |mean| >> sigma; hand it to mrla_bn_stats_fwd_rows.
  * MRLA_EUNSUPPORTED for shapes outside k in {64, 128, 256}, n % 64 == 0 and for dtypes other than MRLA_BF16: the caller
  * keeps using its stock convolution there.  (The input gradient dX = dY * W is the same entry point with w^T.) */
 int mrla_conv1x1_rows(int m, int k, int n, int dtype);      /* rows of mom_part (> 0), or a negative code */

@@ -15,7 +15,7 @@ F32, BF16, F16 = 0, 1, 2
 NCHW, NHWC = 0, 1
 ACT_NONE, ACT_GELU = 0, 1
 BN_NONE, BN_TRAIN, BN_EVAL = 0, 1, 2
-FWD_MOMENTS, BWD_MOMENTS, TOKEN_PARTIALS = 8, 3, 14
+FWD_MOMENTS, BWD_MOMENTS, TOKEN_PARTIALS, GEMM_MOMENTS = 8, 3, 14, 4
 
 _ERR = {EINVAL: "invalid argument", EUNSUPPORTED: "unsupported shape/layout for the HIP kernels",
         EHIP: "HIP runtime error at kernel launch"}
@@ -35,7 +35,7 @@ SIGNATURES = {
     "mrla_light_bn_bwd": [_P, _P, _P, _P, _P, _P, _P, _P, _I, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P],
     "mrla_light_gate_bwd": [_P, _P, _P, _P, _P, _P, _P, _P, _I, _P, _P, _I, _I, _I, _I, _P],
     "mrla_light_apply_bwd_pre_sums": [_I] * 6,
-    "mrla_light_apply_bwd": [_P] * 14 + [_I] * 10 + [_P],
+    "mrla_light_apply_bwd": [_P] * 15 + [_I] * 10 + [_P],
     "mrla_light_pool_fused": [_P] * 6 + [_I] * 6 + [_P],
     "mrla_light_apply_fwd_fused": [_P] * 11 + [_I] * 8 + [_P],
     "mrla_light_stats_fwd_fused": [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P],
@@ -48,9 +48,10 @@ SIGNATURES = {
     "mrla_base_gate_fwd": [_P, _P, _P, _I, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P],
     "mrla_base_attend_fwd": [_P, _P, _P, _P, _P, _P] + [_I] * 9 + [_P],
     "mrla_bn_stats_fwd": [_P, _P, _P, _P, _P, _P, _I, _F, _F, _P, _P, _P, _P, _I, _I, _I, _P],
+    "mrla_bn_stats_fwd_rows": [_P, _P, _P, _P, _P, _I, _F, _F, _P, _P, _P, _P, _I, _I, _P],
     "mrla_base_tail_fwd": [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P],
-    "mrla_base_tail_stats_bwd": [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P],
-    "mrla_bn_stats_bwd": [_P, _P, _P, _P, _I, _P, _P, _P, _I, _I, _I, _P],
+    "mrla_base_tail_stats_bwd": [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P],
+    "mrla_bn_stats_bwd": [_P, _P, _P, _P, _I, _I, _P, _P, _P, _I, _I, _I, _P],
     "mrla_base_attend_bwd": [_P] * 9 + [_I] * 8 + [_P],
     "mrla_base_gate_bwd": [_P, _P, _P, _P, _P, _P, _P, _P, _I, _P, _P] + [_I] * 7 + [_P],
     "mrla_base_value_bwd": [_P] * 8 + [_I] * 11 + [_P],
@@ -63,11 +64,11 @@ SIGNATURES = {
     "mrla_bn_moment_rows": [_I] * 5,
     "mrla_bn_plane_moments": [_P, _P, _P, _I, _I, _I, _I, _I, _I, _P],
     "mrla_bn_act_fwd": [_P, _P, _P, _I, _P, _I, _I, _I, _I, _I, _I, _P],
-    "mrla_bn_plane_dmoments": [_P, _P, _P, _P, _I, _P, _I, _I, _I, _I, _I, _I, _P],
+    "mrla_bn_plane_dmoments": [_P, _P, _P, _P, _P, _I, _P, _I, _I, _I, _I, _I, _I, _P],
     "mrla_bn_act_bwd": [_P, _P, _P, _P, _P, _I, _P, _I, _I, _I, _I, _I, _I, _P],
     "mrla_bn_pool_rows": [_I] * 6,
     "mrla_bn_relu_pool_fwd": [_P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P],
-    "mrla_bn_relu_pool_dmoments": [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P],
+    "mrla_bn_relu_pool_dmoments": [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P],
     "mrla_bn_relu_pool_bwd": [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P],
     "mrla_conv1x1_rows": [_I] * 4,
     "mrla_conv1x1_plan": [_I, _I, _I, _I, _I, _P],

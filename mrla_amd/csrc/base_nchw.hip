@@ -284,10 +284,69 @@ __global__ __launch_bounds__(kThreads) void plain_bn_fwd_kernel(
   save_inv[c] = (float)inv;
 }
 
+// The same from moment RECORDS rec[rows, c, 4] = (sum (x - p), sum (x - p)^2, p, n) with a pivot p and a pixel count n
+// per row (the 1x1-convolution GEMM epilogue, MRLA_GEMM_MOMENTS): rows are merged by re-basing them onto the first
+// non-empty row's pivot, in double.
+__global__ __launch_bounds__(kThreads) void plain_bn_fwd_rec_kernel(
+    const float* __restrict__ rec, const float* __restrict__ gamma, const float* __restrict__ beta,
+    float* __restrict__ run_mean, float* __restrict__ run_var, int training, float momentum, float eps,
+    float* __restrict__ sc, float* __restrict__ sh, float* __restrict__ save_mean, float* __restrict__ save_inv, int R,
+    int C) {
+  __shared__ double r1[kBnLanes2][kBnCh2], r2[kBnLanes2][kBnCh2], rn[kBnLanes2][kBnCh2];
+  __shared__ double piv[kBnCh2];
+  const int cc = threadIdx.x % kBnCh2, bl = threadIdx.x / kBnCh2;
+  const int c = blockIdx.x * kBnCh2 + cc;
+  const bool live = c < C;
+  if (bl == 0) {                      // the common pivot: the first non-empty row's
+    double P = 0.0;
+    if (training && live)
+      for (int b = 0; b < R; ++b)
+        if (rec[((size_t)b * C + c) * 4 + 3] > 0.f) { P = rec[((size_t)b * C + c) * 4 + 2]; break; }
+    piv[cc] = P;
+  }
+  __syncthreads();
+  const double P = piv[cc];
+  double s1 = 0.0, s2 = 0.0, n = 0.0;
+  if (training && live)
+    for (int b = bl; b < R; b += kBnLanes2) {
+      const float* q = rec + ((size_t)b * C + c) * 4;
+      const double a = q[0], b2 = q[1], d = (double)q[2] - P, nb = q[3];
+      if (nb > 0.0) {
+        s1 += a + nb * d;
+        s2 += b2 + 2.0 * d * a + nb * d * d;
+        n += nb;
+      }
+    }
+  r1[bl][cc] = s1; r2[bl][cc] = s2; rn[bl][cc] = n;
+  __syncthreads();
+  if (bl != 0 || !live) return;
+  double mean, var;
+  if (training) {
+    s1 = 0.0; s2 = 0.0; n = 0.0;
+    for (int i = 0; i < kBnLanes2; ++i) { s1 += r1[i][cc]; s2 += r2[i][cc]; n += rn[i][cc]; }
+    const double M = n > 0.0 ? n : 1.0;
+    const double dm = s1 / M;
+    mean = dm + P;
+    var = s2 / M - dm * dm;
+    if (var < 0.0) var = 0.0;
+    run_mean[c] = (float)((1.0 - momentum) * run_mean[c] + momentum * mean);
+    run_var[c] = (float)((1.0 - momentum) * run_var[c] + momentum * var * (M / (M > 1.0 ? M - 1.0 : 1.0)));
+  } else {
+    mean = run_mean[c];
+    var = run_var[c];
+  }
+  const double inv = 1.0 / sqrt(var + (double)eps);
+  const double scale = gamma[c] * inv;
+  sc[c] = (float)scale;
+  sh[c] = (float)(beta[c] - scale * mean);
+  save_mean[c] = (float)mean;
+  save_inv[c] = (float)inv;
+}
+
 // tmom[b,c,2] = (sum dz, sum dz*attn)  ->  cb[c,3] = (e, f, h) with dattn = e*dz + f*attn + h; dgamma, dbeta
 __global__ __launch_bounds__(kThreads) void plain_bn_bwd_kernel(
     const float* __restrict__ tmom, const float* __restrict__ gamma, const float* __restrict__ save_mean,
-    const float* __restrict__ save_inv, int training, float* __restrict__ cb, float* __restrict__ dgamma,
+    const float* __restrict__ save_inv, int training, int centered, float* __restrict__ cb, float* __restrict__ dgamma,
     float* __restrict__ dbeta, int B, int C, int HW) {
   __shared__ double r1[kBnLanes2][kBnCh2], r2[kBnLanes2][kBnCh2];
   const int cc = threadIdx.x % kBnCh2, bl = threadIdx.x / kBnCh2;
@@ -305,7 +364,8 @@ __global__ __launch_bounds__(kThreads) void plain_bn_bwd_kernel(
   s1 = 0.0; s2 = 0.0;
   for (int i = 0; i < kBnLanes2; ++i) { s1 += r1[i][cc]; s2 += r2[i][cc]; }
   const double mean = save_mean[c], inv = save_inv[c];
-  const double dbe = s1, dga = inv * (s2 - mean * s1);
+  // centered: the producer summed dz * (x - mean) already (no cancelling subtraction when |mean| >> sigma)
+  const double dbe = s1, dga = centered ? inv * s2 : inv * (s2 - mean * s1);
   const double e = gamma[c] * inv;
   double f = 0.0, h = 0.0;
   if (training) {
@@ -733,10 +793,19 @@ int launch_plain_bn_fwd(const float* amom, const float* gamma, const float* beta
   return hip_status(hipGetLastError());
 }
 
+int launch_plain_bn_fwd_rec(const float* rec, const float* gamma, const float* beta, float* run_mean, float* run_var,
+                            int training, float momentum, float eps, float* sc, float* sh, float* save_mean,
+                            float* save_inv, int R, int C, hipStream_t st) {
+  hipLaunchKernelGGL(plain_bn_fwd_rec_kernel, dim3((C + kBnCh2 - 1) / kBnCh2), dim3(kThreads), 0, st, rec, gamma, beta,
+                     run_mean, run_var, training, momentum, eps, sc, sh, save_mean, save_inv, R, C);
+  return hip_status(hipGetLastError());
+}
+
 int launch_plain_bn_bwd(const float* tmom, const float* gamma, const float* save_mean, const float* save_inv,
-                        int training, float* cb, float* dgamma, float* dbeta, int B, int C, int HW, hipStream_t st) {
+                        int training, int centered, float* cb, float* dgamma, float* dbeta, int B, int C, int HW,
+                        hipStream_t st) {
   hipLaunchKernelGGL(plain_bn_bwd_kernel, dim3((C + kBnCh2 - 1) / kBnCh2), dim3(kThreads), 0, st, tmom, gamma,
-                     save_mean, save_inv, training, cb, dgamma, dbeta, B, C, HW);
+                     save_mean, save_inv, training, centered, cb, dgamma, dbeta, B, C, HW);
   return hip_status(hipGetLastError());
 }
 

@@ -61,7 +61,7 @@ __device__ __forceinline__ void plane_sums(const T* __restrict__ xp, const T* __
       for (int i = 0; i < VW; ++i) {
         const float dz = (!relu || fmaf(s, xv[i], h) > 0.f) ? gv[i] : 0.f;
         s1 += dz;
-        s2 = fmaf(dz, xv[i], s2);
+        s2 = fmaf(dz, xv[i] - pv, s2);                   // pv: the center (MODE 1)
       }
     }
   }
@@ -82,7 +82,8 @@ __global__ __launch_bounds__(kThreads) void plane_moments_kernel(const T* __rest
     const float s = (MODE && relu) ? sc[c] : 0.f, h = (MODE && relu) ? sh[c] : 0.f;
     float s1 = 0.f, s2 = 0.f;
     // MODE 0 with `pivot`: sums of (x - p), p = the channel's first element of the first image (see bnact_nhwc.hip)
-    const float pv = (MODE == 0 && pivot) ? to_f(x[(size_t)c * HW]) : 0.f;
+    // MODE 1: `pivot` is the INPUT center (the saved batch mean): sum dz*(x - center)
+    const float pv = !pivot ? 0.f : (MODE == 0 ? to_f(x[(size_t)c * HW]) : pivot[c]);
     if (MODE == 0 && pivot && p < C && lane == 0) pivot[c] = pv;
     if (vec_ok) plane_sums<T, MODE, VEC>(xp, gp, HW, lane, s, h, relu != 0, pv, s1, s2);
     else        plane_sums<T, MODE, 1>(xp, gp, HW, lane, s, h, relu != 0, pv, s1, s2);
@@ -117,7 +118,7 @@ __global__ __launch_bounds__(kThreads) void plane_moments_small_kernel(const T* 
       const int c = (p0 + q) % C;
       const float s = (MODE && relu) ? sc[c] : 0.f, h = (MODE && relu) ? sh[c] : 0.f;
       float s1 = 0.f, s2 = 0.f;
-      const float pv = (MODE == 0 && pivot) ? to_f(x[(size_t)c * HW]) : 0.f;
+      const float pv = !pivot ? 0.f : (MODE == 0 ? to_f(x[(size_t)c * HW]) : pivot[c]);
       if (MODE == 0 && pivot && p0 + q < C && l16 == 0) pivot[c] = pv;
       for (int e = l16; e < HW; e += 16) {
         const float xv = to_f(xs[q * HW + e]);
@@ -125,7 +126,7 @@ __global__ __launch_bounds__(kThreads) void plane_moments_small_kernel(const T* 
         else {
           const float dz = (!relu || fmaf(s, xv, h) > 0.f) ? to_f(gs[q * HW + e]) : 0.f;
           s1 += dz;
-          s2 = fmaf(dz, xv, s2);
+          s2 = fmaf(dz, xv - pv, s2);
         }
       }
       s1 = seg_sum(s1, lane, 16);
@@ -223,9 +224,9 @@ int launch_plane_moments(const void* x, float* amom, float* pivot, int B, int C,
   return launch_moments(x, nullptr, nullptr, nullptr, 0, amom, pivot, B, C, HW, dtype, 0, st);
 }
 
-int launch_plane_dmoments(const void* dy, const void* x, const float* sc, const float* sh, int relu, float* tmom, int B,
-                          int C, int HW, int dtype, hipStream_t st) {
-  return launch_moments(x, dy, sc, sh, relu, tmom, nullptr, B, C, HW, dtype, 1, st);
+int launch_plane_dmoments(const void* dy, const void* x, const float* sc, const float* sh, const float* center, int relu,
+                          float* tmom, int B, int C, int HW, int dtype, hipStream_t st) {
+  return launch_moments(x, dy, sc, sh, relu, tmom, const_cast<float*>(center), B, C, HW, dtype, 1, st);
 }
 
 int launch_affine_act(const void* x, const void* dy, const float* a, const float* sc, const float* sh, int relu,

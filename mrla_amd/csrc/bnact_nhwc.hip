@@ -1,6 +1,8 @@
 // Fused BatchNorm2d (+ReLU) passes for channels_last (NHWC) activations; same roles as bnact_nchw.hip.
 // Lane = 8 consecutive channels (one 16-byte access), 8 lanes = 64 channels, a wave = 8 pixels x 64 channels.
-//   nhwc_moments   MODE 0: (sum x, sum x^2)   MODE 1: (sum dz, sum dz*x), dz = dy*[sc*x+sh > 0 or !relu]
+//   nhwc_moments   MODE 0: (sum x, sum x^2)   MODE 1: (sum dz, sum dz*(x - center)), dz = dy*[sc*x+sh > 0 or !relu];
+//                  `pivot` is an OUTPUT in MODE 0 (the shift it picked) and the INPUT `center` in MODE 1 (the batch mean
+//                  the BatchNorm saved: dgamma = inv_std * sum dz*(x - mean) then needs no cancelling subtraction)
 //                  -> partial sums [b * nsplit, c, 2]   (consumed by plain_bn_{fwd,bwd}_kernel with B = b*nsplit)
 //   nhwc_affine    forward y = relu?(sc*x + sh);  backward dx = e*dz + f*x + h
 #include <algorithm>
@@ -64,6 +66,10 @@ __global__ __launch_bounds__(kThreads) void nhwc_moments_kernel(const T* __restr
       for (int i = 0; i < VEC; ++i) pivot[c0 + i] = pv[i];
     }
   }
+  if (MODE == 1 && pivot && cv) {
+#pragma unroll
+    for (int i = 0; i < VEC; ++i) pv[i] = pivot[c0 + i];
+  }
   if (cv) {
     for (int p = wave * PPW + lane / LPC; p < npix; p += kWaves * PPW) {
       float xv[VEC];
@@ -78,7 +84,7 @@ __global__ __launch_bounds__(kThreads) void nhwc_moments_kernel(const T* __restr
         for (int i = 0; i < VEC; ++i) {
           const float dz = (!relu || fmaf(scv[i], xv[i], shv[i]) > 0.f) ? gv[i] : 0.f;
           s1[i] += dz;
-          s2[i] = fmaf(dz, xv[i], s2[i]);
+          s2[i] = fmaf(dz, xv[i] - pv[i], s2[i]);
         }
       }
     }
@@ -198,6 +204,7 @@ __global__ __launch_bounds__(kThreads) void nhwc_moments_flat_kernel(const T* __
       for (int i = 0; i < VEC; ++i) pivot[c0 + i] = pv[i];
     }
   }
+  if (MODE == 1 && pivot) ldf<VEC>(pivot + c0, pv);      // the center (input)
   auto accumulate = [&](const float (&xv)[VEC], const float (&gv)[VEC]) {
 #pragma unroll
     for (int i = 0; i < VEC; ++i) {
@@ -208,7 +215,7 @@ __global__ __launch_bounds__(kThreads) void nhwc_moments_flat_kernel(const T* __
       } else {
         const float dz = (!relu || fmaf(scv[i], xv[i], shv[i]) > 0.f) ? dpb * gv[i] : 0.f;
         s1[i] += dz;
-        s2[i] = fmaf(dz, xv[i], s2[i]);
+        s2[i] = fmaf(dz, xv[i] - pv[i], s2[i]);
       }
     }
   };

@@ -233,8 +233,8 @@ int mrla_light_apply_bwd_pre_sums(int b, int c, int h, int w, int dtype, int lay
 
 int mrla_light_apply_bwd(const void* dout, const void* x, const void* o_prev, const float* wv, const float* gate,
                          const float* cb, const float* lam, const float* dp, const float* dyx, void* dx,
-                         void* do_prev, float* dwv_part, const void* pre, float* pre_tmom, int b, int c, int h, int w,
-                         int d, int res, int relu_mask, int dtype, int layout, int act, void* stream) {
+                         void* do_prev, float* dwv_part, const void* pre, const float* pre_center, float* pre_tmom, int b,
+                         int c, int h, int w, int d, int res, int relu_mask, int dtype, int layout, int act, void* stream) {
   if (!dout || !x || !wv || !gate || !dyx || !dx || !dwv_part || bad_dims(b, c, h, w) || bad_dtype(dtype) || d <= 0 ||
       c % d)
     return MRLA_EINVAL;
@@ -242,8 +242,8 @@ int mrla_light_apply_bwd(const void* dout, const void* x, const void* o_prev, co
   if (relu_mask && (!o_prev || act != MRLA_ACT_NONE)) return MRLA_EINVAL;
   if ((pre == nullptr) != (pre_tmom == nullptr) || (pre_tmom && !relu_mask)) return MRLA_EINVAL;
   if (layout == MRLA_NHWC)
-    return launch_light_apply_bwd_nhwc(dout, x, o_prev, wv, gate, cb, lam, dp, dyx, dx, do_prev, dwv_part, pre, pre_tmom, b,
-                                       c, h, w, d, res, relu_mask, dtype, act, (hipStream_t)stream);
+    return launch_light_apply_bwd_nhwc(dout, x, o_prev, wv, gate, cb, lam, dp, dyx, dx, do_prev, dwv_part, pre, pre_center,
+                                       pre_tmom, b, c, h, w, d, res, relu_mask, dtype, act, (hipStream_t)stream);
   if (layout != MRLA_NCHW) return MRLA_EINVAL;
   if (pre_tmom) return MRLA_EUNSUPPORTED;
   SlabGeo g;
@@ -286,6 +286,16 @@ int mrla_bn_stats_fwd(const float* amom, const float* pivot, const float* gamma,
                              sh, save_mean, save_inv, pivot, b, c, hw, (hipStream_t)stream);
 }
 
+int mrla_bn_stats_fwd_rows(const float* rec, const float* gamma, const float* beta, float* running_mean, float* running_var,
+                           int bn_mode, float momentum, float eps, float* sc, float* sh, float* save_mean, float* save_inv,
+                           int rows, int c, void* stream) {
+  if (!rec || !gamma || !beta || !running_mean || !running_var || !sc || !sh || !save_mean || !save_inv || rows <= 0 ||
+      c <= 0 || (bn_mode != MRLA_BN_TRAIN && bn_mode != MRLA_BN_EVAL))
+    return MRLA_EINVAL;
+  return launch_plain_bn_fwd_rec(rec, gamma, beta, running_mean, running_var, bn_mode == MRLA_BN_TRAIN, momentum, eps, sc,
+                                 sh, save_mean, save_inv, rows, c, (hipStream_t)stream);
+}
+
 int mrla_base_tail_fwd(const void* x, const void* attn, const float* sc, const float* sh, const float* dp, void* out,
                        int b, int c, int h, int w, int dtype, int layout, void* stream) {
   if (!x || !attn || !sc || !sh || !out || bad_dims(b, c, h, w) || bad_dtype(dtype)) return MRLA_EINVAL;
@@ -295,12 +305,14 @@ int mrla_base_tail_fwd(const void* x, const void* attn, const float* sc, const f
   return launch_base_tail_fwd(x, attn, sc, sh, dp, out, b, c, h * w, dtype, (hipStream_t)stream);
 }
 
-int mrla_base_tail_stats_bwd(const void* dout, const void* attn, const float* sc, const float* sh, const float* dp,
-                             float* tmom, int b, int c, int h, int w, int dtype, int layout, void* stream) {
+int mrla_base_tail_stats_bwd(const void* dout, const void* attn, const float* sc, const float* sh, const float* center,
+                             const float* dp, float* tmom, int b, int c, int h, int w, int dtype, int layout, void* stream) {
   if (!dout || !attn || !sc || !sh || !tmom || bad_dims(b, c, h, w) || bad_dtype(dtype)) return MRLA_EINVAL;
   if (layout == MRLA_NHWC)      // tmom then has mrla_bn_moment_rows() rows
-    return launch_nhwc_moments(attn, dout, sc, sh, 1, dp, tmom, nullptr, b, c, h * w, dtype, 1, (hipStream_t)stream);
+    return launch_nhwc_moments(attn, dout, sc, sh, 1, dp, tmom, const_cast<float*>(center), b, c, h * w, dtype, 1,
+                               (hipStream_t)stream);
   if (layout != MRLA_NCHW) return MRLA_EINVAL;
+  if (center) return MRLA_EUNSUPPORTED;        // (the NCHW slab kernel keeps raw sums)
   SlabGeo g;
   const int rc = light_geo(&g, b, c, h, w, dtype);
   if (rc != MRLA_OK) return rc;
@@ -308,12 +320,12 @@ int mrla_base_tail_stats_bwd(const void* dout, const void* attn, const float* sc
 }
 
 int mrla_bn_stats_bwd(const float* tmom, const float* gamma, const float* save_mean, const float* save_inv,
-                      int bn_mode, float* cb, float* dgamma, float* dbeta, int b, int c, int hw, void* stream) {
+                      int bn_mode, int centered, float* cb, float* dgamma, float* dbeta, int b, int c, int hw, void* stream) {
   if (!tmom || !gamma || !save_mean || !save_inv || !cb || !dgamma || !dbeta || b <= 0 || c <= 0 || hw <= 0 ||
       (bn_mode != MRLA_BN_TRAIN && bn_mode != MRLA_BN_EVAL))
     return MRLA_EINVAL;
-  return launch_plain_bn_bwd(tmom, gamma, save_mean, save_inv, bn_mode == MRLA_BN_TRAIN, cb, dgamma, dbeta, b, c, hw,
-                             (hipStream_t)stream);
+  return launch_plain_bn_bwd(tmom, gamma, save_mean, save_inv, bn_mode == MRLA_BN_TRAIN, centered != 0, cb, dgamma, dbeta,
+                             b, c, hw, (hipStream_t)stream);
 }
 
 int mrla_base_attend_bwd(const void* dout, const void* attn, const float* sc, const float* sh, const float* dp,
@@ -486,13 +498,14 @@ int mrla_bn_act_fwd(const void* x, const float* sc, const float* sh, int relu, v
   return launch_affine_act(x, nullptr, nullptr, sc, sh, relu, y, b, c, h * w, dtype, 0, (hipStream_t)stream);
 }
 
-int mrla_bn_plane_dmoments(const void* dy, const void* x, const float* sc, const float* sh, int relu, float* tmom, int b,
-                           int c, int h, int w, int dtype, int layout, void* stream) {
+int mrla_bn_plane_dmoments(const void* dy, const void* x, const float* sc, const float* sh, const float* center, int relu,
+                           float* tmom, int b, int c, int h, int w, int dtype, int layout, void* stream) {
   if (!dy || !x || !sc || !sh || !tmom || bad_dims(b, c, h, w) || bad_dtype(dtype)) return MRLA_EINVAL;
   if (layout == MRLA_NHWC)
-    return launch_nhwc_moments(x, dy, sc, sh, relu, nullptr, tmom, nullptr, b, c, h * w, dtype, 1, (hipStream_t)stream);
+    return launch_nhwc_moments(x, dy, sc, sh, relu, nullptr, tmom, const_cast<float*>(center), b, c, h * w, dtype, 1,
+                               (hipStream_t)stream);
   if (layout != MRLA_NCHW) return MRLA_EINVAL;
-  return launch_plane_dmoments(dy, x, sc, sh, relu, tmom, b, c, h * w, dtype, (hipStream_t)stream);
+  return launch_plane_dmoments(dy, x, sc, sh, center, relu, tmom, b, c, h * w, dtype, (hipStream_t)stream);
 }
 
 int mrla_bn_act_bwd(const void* dy, const void* x, const float* sc, const float* sh, const float* cb, int relu,
@@ -517,11 +530,11 @@ int mrla_bn_relu_pool_fwd(const void* x, const float* sc, const float* sh, void*
   return launch_bn_relu_pool_fwd(x, sc, sh, out, b, c, h, w, dtype, (hipStream_t)stream);
 }
 
-int mrla_bn_relu_pool_dmoments(const void* dp, const void* x, const float* sc, const float* sh, float* tmom, int b, int c,
-                               int h, int w, int dtype, int layout, void* stream) {
+int mrla_bn_relu_pool_dmoments(const void* dp, const void* x, const float* sc, const float* sh, const float* center,
+                               float* tmom, int b, int c, int h, int w, int dtype, int layout, void* stream) {
   if (!dp || !x || !sc || !sh || !tmom || bad_dims(b, c, h, w) || bad_dtype(dtype)) return MRLA_EINVAL;
   if (layout != MRLA_NHWC) return layout == MRLA_NCHW ? MRLA_EUNSUPPORTED : MRLA_EINVAL;
-  return launch_bn_relu_pool_dmoments(dp, x, sc, sh, tmom, b, c, h, w, dtype, (hipStream_t)stream);
+  return launch_bn_relu_pool_dmoments(dp, x, sc, sh, center, tmom, b, c, h, w, dtype, (hipStream_t)stream);
 }
 
 int mrla_bn_relu_pool_bwd(const void* dp, const void* x, const float* sc, const float* sh, const float* cb, void* dx, int b,

@@ -1,6 +1,7 @@
 // 1x1 stride-1 convolution of a channels_last bf16 activation as an MFMA GEMM with a BatchNorm-statistics epilogue:
 //   Y[M, N] = X[M, K] * W[N, K]^T      (M = b*h*w pixels, K = in-channels, N = out-channels; both operands K-contiguous)
-//   part[row, n, 0..1] = per-workgroup partial (sum, sum of squares) of the bf16-ROUNDED outputs, channel n
+//   part[row, n, 0..3] = per-workgroup moment record of the bf16-ROUNDED outputs of channel n (MRLA_GEMM_MOMENTS):
+//                        sum (y - p), sum (y - p)^2, the pivot p (a first output of the channel), pixel count
 // Reference: the bottleneck's conv1 / bn1 and conv3 / bn3 (resnet/models/resnet_mrla_light.py:93-102): the statistics pass
 // of the BatchNorm that follows the convolution (1N read of the large conv3 output) disappears into this epilogue, and
 // the output is written exactly once (MIOpen's implicit-GEMM solver memsets it first).
@@ -61,11 +62,14 @@ __global__ __launch_bounds__(NW * kWave) void conv1x1_fwd_kernel(
   }
   __syncthreads();
 
-  float s1[2][16], s2[2][16];
+  // moments about a pivot (this wave's first output of the channel), see conv1x1_wide.hip
+  float s1[2][16], s2[2][16], pv[2][16];
 #pragma unroll
   for (int t = 0; t < 2; ++t)
 #pragma unroll
-    for (int i = 0; i < 16; ++i) { s1[t][i] = 0.f; s2[t][i] = 0.f; }
+    for (int i = 0; i < 16; ++i) { s1[t][i] = 0.f; s2[t][i] = 0.f; pv[t][i] = 0.f; }
+  bool have_pivot = false;
+  int npix = 0;                                     // pixels this wave accumulated (wave-uniform)
 
   const int nblk = (M + 31) / 32;
   const int stride = gridDim.x * WM;
@@ -83,7 +87,8 @@ __global__ __launch_bounds__(NW * kWave) void conv1x1_fwd_kernel(
     if constexpr (DB) {
       if (blk + stride < nblk) load_x(reinterpret_cast<u32x4(&)[KC]>(xn), blk + stride, 0);
     }
-    const float live = (blk * 32 + r < M) ? 1.f : 0.f;       // this lane's pixel exists (ragged last block)
+    const bool live = blk * 32 + r < M;                      // this lane's pixel exists (ragged last block)
+    npix += min(32, M - blk * 32);
     f32x16 acc[2];
 #pragma unroll
     for (int t = 0; t < 2; ++t)
@@ -114,10 +119,18 @@ __global__ __launch_bounds__(NW * kWave) void conv1x1_fwd_kernel(
         pr[0] = from_f<bf16_t>(acc[t][2 * i]);
         pr[1] = from_f<bf16_t>(acc[t][2 * i + 1]);
         p[i] = __builtin_bit_cast(unsigned, pr);
-        if (MOM) {
-          const float lo = live * __uint_as_float(p[i] << 16), hi = live * __uint_as_float(p[i] & 0xffff0000u);
-          s1[t][2 * i] += lo;     s2[t][2 * i] = fmaf(lo, lo, s2[t][2 * i]);
-          s1[t][2 * i + 1] += hi; s2[t][2 * i + 1] = fmaf(hi, hi, s2[t][2 * i + 1]);
+      }
+      if (MOM) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+          const float lo = __uint_as_float(p[i] << 16), hi = __uint_as_float(p[i] & 0xffff0000u);
+          if (!have_pivot) {       // (wave-uniform) first block of this wave: pixel 0 of the half-wave always exists
+            pv[t][2 * i] = __shfl(lo, h * 32, kWave);
+            pv[t][2 * i + 1] = __shfl(hi, h * 32, kWave);
+          }
+          const float dl = live ? lo - pv[t][2 * i] : 0.f, dh = live ? hi - pv[t][2 * i + 1] : 0.f;
+          s1[t][2 * i] += dl;     s2[t][2 * i] = fmaf(dl, dl, s2[t][2 * i]);
+          s1[t][2 * i + 1] += dh; s2[t][2 * i + 1] = fmaf(dh, dh, s2[t][2 * i + 1]);
         }
       }
       // lane half 0 holds channels {0-3, 8-11, 16-19, 24-27} of its pixel, half 1 the other four groups; after the
@@ -138,6 +151,7 @@ __global__ __launch_bounds__(NW * kWave) void conv1x1_fwd_kernel(
       *reinterpret_cast<u32x4*>(orow) = (u32x4){p[0], p[1], p[2], p[3]};
       *reinterpret_cast<u32x4*>(orow + 32) = (u32x4){p[4], p[5], p[6], p[7]};
     }
+    have_pivot = true;
     // whole lines out: 8 lanes per pixel (64 channels = 128 bytes), 8 pixels per store instruction
     {
       const int px = lane >> 3, piece = lane & 7;
@@ -158,17 +172,18 @@ __global__ __launch_bounds__(NW * kWave) void conv1x1_fwd_kernel(
   }
 
   if (MOM) {
-    // rows beyond the active workgroups only exist to make the row count divide M: zeros
+    // rows beyond the active workgroups only exist to make the row count divide M: empty records
     if (blockIdx.x == 0) {
-      for (int i = threadIdx.x; i < (rows_total - (int)gridDim.x) * NS * 2; i += NW * kWave) {
-        const int row = gridDim.x + i / (NS * 2), j = i % (NS * 2);
-        part[((size_t)row * N + n_slice0) * 2 + j] = 0.f;
+      for (int i = threadIdx.x; i < (rows_total - (int)gridDim.x) * NS * 4; i += NW * kWave) {
+        const int row = gridDim.x + i / (NS * 4), j = i % (NS * 4);
+        part[((size_t)row * N + n_slice0) * 4 + j] = 0.f;
       }
     }
-    // sum over the 32 pixel-lanes of each half, then over the workgroup's pixel-waves (fixed order, through the LDS of
-    // the output tiles, which are done with): one partial row per workgroup
+    // sum over the 32 pixel-lanes of each half (they share the pivot), then merge the workgroup's pixel-waves by
+    // re-basing them onto the first one's pivot (fixed order, through the LDS of the output tiles, which are done
+    // with): one record per workgroup and channel
     __syncthreads();
-    float* sums = reinterpret_cast<float*>(smem_raw + (size_t)NS * ROWB);          // [WM][NS][2]
+    float* sums = reinterpret_cast<float*>(smem_raw + (size_t)NS * ROWB);          // [WM][NS][4]
 #pragma unroll
     for (int t = 0; t < 2; ++t)
 #pragma unroll
@@ -181,16 +196,25 @@ __global__ __launch_bounds__(NW * kWave) void conv1x1_fwd_kernel(
         }
         if (r == 0) {
           const int ch = wn * 64 + t * 32 + acc_channel(i, h);
-          sums[((size_t)wm * NS + ch) * 2 + 0] = a;
-          sums[((size_t)wm * NS + ch) * 2 + 1] = b;
+          float* rec = sums + ((size_t)wm * NS + ch) * 4;
+          rec[0] = a; rec[1] = b; rec[2] = pv[t][i]; rec[3] = (float)npix;
         }
       }
     __syncthreads();
-    float* dst = part + ((size_t)blockIdx.x * N + n_slice0) * 2;
-    for (int i = threadIdx.x; i < NS * 2; i += NW * kWave) {
-      float a = 0.f;
-      for (int v = 0; v < WM; ++v) a += sums[(size_t)v * NS * 2 + i];
-      dst[i] = a;
+    float* dst = part + ((size_t)blockIdx.x * N + n_slice0) * 4;
+    for (int ch = threadIdx.x; ch < NS; ch += NW * kWave) {
+      float S1 = 0.f, S2 = 0.f, P = 0.f, n = 0.f;
+      for (int v = 0; v < WM; ++v) {
+        const float* rec = sums + ((size_t)v * NS + ch) * 4;
+        const float a = rec[0], b = rec[1], nv = rec[3];
+        if (nv == 0.f) continue;                     // a pixel-wave without a block
+        if (n == 0.f) P = rec[2];
+        const float dlt = rec[2] - P;                // sums about rec[2] -> about P
+        S2 += b + 2.f * dlt * a + nv * dlt * dlt;
+        S1 += a + nv * dlt;
+        n += nv;
+      }
+      dst[ch * 4 + 0] = S1; dst[ch * 4 + 1] = S2; dst[ch * 4 + 2] = P; dst[ch * 4 + 3] = n;
     }
   }
 }

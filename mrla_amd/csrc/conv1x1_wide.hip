@@ -1,6 +1,7 @@
 // 1x1 stride-1 convolution with a wide output (N % 256 == 0) as a streaming MFMA GEMM, BatchNorm-statistics epilogue:
 //   Y[M, N] = X[M, K] * W[N, K]^T (+ A[M, N])      K in {64, 128, 256}; bf16 in/out, fp32 accumulate
-//   part[row, n, 0..1] = per-workgroup partial (sum, sum of squares) of the bf16-ROUNDED outputs, channel n
+//   part[row, n, 0..3] = per-workgroup moment record of the bf16-ROUNDED outputs of channel n (MRLA_GEMM_MOMENTS):
+//                        sum (y - p), sum (y - p)^2, the pivot p (the workgroup's first output of the channel), pixel count
 // Reference: the bottleneck's conv3 / bn3 (resnet/models/resnet_mrla_light.py:100-101) and, with the operands swapped
 // by the caller (x = dY, w = W^T), the input gradient of conv1 (:93) -- there `A` is the gradient that reaches the
 // block input through the shortcut, so the autograd accumulation (a separate 3N elementwise pass) happens in this
@@ -156,11 +157,16 @@ __global__ __launch_bounds__(kCwWaves* kWave) void conv1x1_wide_kernel(const bf1
   const unsigned sld1 = sld0 + 16 * (kCwTN * 2);                             // (row + 16: same swizzle, (row+16)&7 == row&7)
   bf16_t* yrow = Y + ((size_t)u_begin * 32 + srow) * N + cg * kCwTN + schunk * 8;
 
-  float s1[MOM ? 16 : 1], s2[MOM ? 16 : 1];
+  // BatchNorm moments of the rounded outputs, per lane (register = channel, lane = pixel), taken about a pivot: the
+  // workgroup's first output of the channel (lane r = 0 of the half-wave in the first unit).  The one-pass variance
+  // E[(y-p)^2] - E[y-p]^2 then stays well conditioned when |mean| >> sigma; the per-channel kernel merges the
+  // workgroups' records by re-basing them (in double).
+  float s1[MOM ? 16 : 1], s2[MOM ? 16 : 1], pv[MOM ? 16 : 1];
   if (MOM) {
 #pragma unroll
-    for (int i = 0; i < 16; ++i) { s1[i] = 0.f; s2[i] = 0.f; }
+    for (int i = 0; i < 16; ++i) { s1[i] = 0.f; s2[i] = 0.f; pv[i] = 0.f; }
   }
+  const bool ragged_tail = (u_begin + nun) * 32 > M;             // the last unit of this range has pixels past the end
 
   // ---- pipeline: UST-1 units issued ahead; unit u+1 is waited for in front of unit u's barrier ----
   constexpr int KC = KS < 8 ? KS : 8, NCH = KS / KC;
@@ -234,10 +240,33 @@ __global__ __launch_bounds__(kCwWaves* kWave) void conv1x1_wide_kernel(const bf1
       pr[0] = from_f<bf16_t>(av[2 * i]);
       pr[1] = from_f<bf16_t>(av[2 * i + 1]);
       p[i] = __builtin_bit_cast(unsigned, pr);
-      if (MOM) {
-        const float lo = __uint_as_float(p[i] << 16), hi = __uint_as_float(p[i] & 0xffff0000u);
-        s1[2 * i] += lo;     s2[2 * i] = fmaf(lo, lo, s2[2 * i]);
-        s1[2 * i + 1] += hi; s2[2 * i + 1] = fmaf(hi, hi, s2[2 * i + 1]);
+    }
+    if (MOM) {
+      float val[16];
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        val[2 * i] = __uint_as_float(p[i] << 16);
+        val[2 * i + 1] = __uint_as_float(p[i] & 0xffff0000u);
+      }
+      if (u == 0) {              // (uniform) the pivots: this half-wave's pixel 0, which always exists
+#pragma unroll
+        for (int i = 0; i < 16; ++i) pv[i] = __shfl(val[i], h * 32, kWave);
+      }
+      if (!(ragged_tail && u == nun - 1)) {
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+          const float dlt = val[i] - pv[i];
+          s1[i] += dlt;
+          s2[i] = fmaf(dlt, dlt, s2[i]);
+        }
+      } else {                   // (uniform) the one unit with pixels past the end: those do not count
+        const bool live = (u_begin + u) * 32 + r < M;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+          const float dlt = live ? val[i] - pv[i] : 0.f;
+          s1[i] += dlt;
+          s2[i] = fmaf(dlt, dlt, s2[i]);
+        }
       }
     }
     if (!ADD) {
@@ -278,13 +307,14 @@ __global__ __launch_bounds__(kCwWaves* kWave) void conv1x1_wide_kernel(const bf1
   }
 
   if (MOM) {
-    // rows beyond the workgroups' own only exist to make the row count divide M: zeros (written by the first range)
+    // rows beyond the workgroups' own only exist to make the row count divide M: empty records (written by the first range)
     if (split == 0) {
-      for (int i = threadIdx.x; i < (rows_total - nsplits) * kCwTN * 2; i += kCwWaves * kWave) {
-        const int row = nsplits + i / (kCwTN * 2), j = i % (kCwTN * 2);
-        part[((size_t)row * N + cg * kCwTN) * 2 + j] = 0.f;
+      for (int i = threadIdx.x; i < (rows_total - nsplits) * kCwTN * 4; i += kCwWaves * kWave) {
+        const int row = nsplits + i / (kCwTN * 4), j = i % (kCwTN * 4);
+        part[((size_t)row * N + cg * kCwTN) * 4 + j] = 0.f;
       }
     }
+    const float npix = (float)(min(M, (u_begin + nun) * 32) - u_begin * 32);
     // register e of half h = channel: see the piece layout the values were accumulated in
 #pragma unroll
     for (int i = 0; i < 16; ++i) {
@@ -296,9 +326,11 @@ __global__ __launch_bounds__(kCwWaves* kWave) void conv1x1_wide_kernel(const bf1
       }
       if (r == 0) {
         const int ch = ADD ? ((i < 8 ? 0 : 16) + h * 8 + (i & 7)) : ((i & 3) + 8 * (i >> 2) + 4 * h);
-        float* dst = part + ((size_t)split * N + n0 + ch) * 2;
+        float* dst = part + ((size_t)split * N + n0 + ch) * 4;
         dst[0] = a;
         dst[1] = b;
+        dst[2] = pv[i];
+        dst[3] = npix;
       }
     }
   }

@@ -173,12 +173,12 @@ int nhwc_images_per_group(int B, int C, int W) {
 
 int launch_light_apply_bwd_nhwc(const void* dout, const void* x, const void* o, const float* wv, const float* gate,
                                 const float* cb, const float* lam, const float* dp, const float* dyx, void* dx,
-                                void* dprev, float* dwv_part, const void* pre, float* pre_tmom, int B, int C, int H,
-                                int W, int d, int res, int relu, int dtype, int act, hipStream_t st) {
+                                void* dprev, float* dwv_part, const void* pre, const float* pre_center, float* pre_tmom,
+                                int B, int C, int H, int W, int d, int res, int relu, int dtype, int act, hipStream_t st) {
   NhwcLaunch L = nhwc_launch(B, C, W, 9, dtype);
   if (L.wide)          // C % 64 == 0: the LDS-DMA row pipeline (light_nhwc_wide.hip)
-    return launch_light_apply_bwd_wide(dout, x, o, wv, gate, cb, lam, dp, dyx, dx, dprev, dwv_part, pre, pre_tmom, B, C, H,
-                                       W, d, res, relu, dtype, act, st);
+    return launch_light_apply_bwd_wide(dout, x, o, wv, gate, cb, lam, dp, dyx, dx, dprev, dwv_part, pre, pre_center, pre_tmom,
+                                       B, C, H, W, d, res, relu, dtype, act, st);
   if (pre_tmom) return MRLA_EUNSUPPORTED;       // (the deferred-BatchNorm sums exist on the row pipeline only)
   L.BG = nhwc_images_per_group(B, C, W);                  // = the rows mrla_light_wgrad_rows() promised
   L.grid = dim3(L.grid.x, (B + L.BG - 1) / L.BG);

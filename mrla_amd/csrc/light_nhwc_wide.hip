@@ -587,8 +587,8 @@ __global__ __launch_bounds__(kBwdWaves * kWave) void light_apply_bwd_wide(
     const T* __restrict__ dout, const T* __restrict__ x, const T* __restrict__ o, const float* __restrict__ wv,
     const float* __restrict__ gate, const float* __restrict__ cb, const float* __restrict__ lam,
     const float* __restrict__ dp, const float* __restrict__ dyx, T* __restrict__ dx, T* __restrict__ dprev,
-    float* __restrict__ dwv_part, const T* __restrict__ pre, float* __restrict__ pre_tmom, int B, int C, int H, int W,
-    int BG, int d, int res) {
+    float* __restrict__ dwv_part, const T* __restrict__ pre, const float* __restrict__ pre_center,
+    float* __restrict__ pre_tmom, int B, int C, int H, int W, int BG, int d, int res) {
   static_assert(!PRE || RELU, "the deferred-BatchNorm sums belong to the fused relu(pre + o) producer");
   MRLA_WIDE_PROLOGUE(9, (apply_bwd_wave_bytes<T, PRE>()))
   constexpr int XB_ = RowIO<T, kS + 4>::kBytes, GB = RowIO<T, kS + 2>::kBytes, SB = RowIO<T, kS>::kBytes;
@@ -598,7 +598,8 @@ __global__ __launch_bounds__(kBwdWaves * kWave) void light_apply_bwd_wide(
   T* bufS1 = reinterpret_cast<T*>(wbuf + XB_ + 3 * GB);
   T* bufS2 = reinterpret_cast<T*>(wbuf + XB_ + 3 * GB + SB);
   T* bufP = reinterpret_cast<T*>(wbuf + XB_ + 3 * GB + 2 * SB);      // (PRE) y3 row rr-1 on the owned columns
-  float pm[2] = {0.f, 0.f};                          // (PRE) sum dpre, sum dpre * y3 over this workgroup's images
+  float pm[2] = {0.f, 0.f};                          // (PRE) sum dpre, sum dpre * (y3 - center) over this workgroup's images
+  const float pcen = (PRE && pre_center) ? pre_center[c] : 0.f;      // bn3's batch mean: no cancelling subtraction later
   const int G = C / d;
   float w[9];
 #pragma unroll
@@ -714,7 +715,7 @@ __global__ __launch_bounds__(kBwdWaves * kWave) void light_apply_bwd_wide(
             dsum[j] = DP[j] + y;
             if (PRE) {             // (columns past the image have x = 0, hence y = 0: nothing to mask)
               pm[0] += y;
-              pm[1] = fmaf(y, pv.v[j], pm[1]);
+              pm[1] = fmaf(y, pv.v[j] - pcen, pm[1]);
             }
           }
           row_store<T, kS>(as, dxo, rr - 1, rowelems, lane, bufS1, yrow);
@@ -852,8 +853,8 @@ int launch_light_apply_fwd_pre_wide(const void* pre, const void* o, const float*
 
 int launch_light_apply_bwd_wide(const void* dout, const void* x, const void* o, const float* wv, const float* gate,
                                 const float* cb, const float* lam, const float* dp, const float* dyx, void* dx,
-                                void* dprev, float* dwv_part, const void* pre, float* pre_tmom, int B, int C, int H,
-                                int W, int d, int res, int relu, int dtype, int act, hipStream_t st) {
+                                void* dprev, float* dwv_part, const void* pre, const float* pre_center, float* pre_tmom,
+                                int B, int C, int H, int W, int d, int res, int relu, int dtype, int act, hipStream_t st) {
   const bool ragged = (W % kS) != 0;
   const int bg = nhwc_images_per_group(B, C, W);          // = the rows mrla_light_wgrad_rows() promised
   if (pre_tmom && (!pre || !relu)) return MRLA_EINVAL;
@@ -864,7 +865,7 @@ int launch_light_apply_bwd_wide(const void* dout, const void* x, const void* o, 
     if (set_lds_n(light_apply_bwd_wide<T, A, O, R, RG, PR>, L.lds) != hipSuccess) return MRLA_EHIP;                    \
     hipLaunchKernelGGL((light_apply_bwd_wide<T, A, O, R, RG, PR>), L.grid, L.block, L.lds, st, (const T*)dout,        \
                        (const T*)x, (const T*)o, wv, gate, cb, lam, dp, dyx, (T*)dx, (T*)dprev, dwv_part,             \
-                       (const T*)pre, pre_tmom, B, C, H, W, L.BG, d, res);                                           \
+                       (const T*)pre, pre_center, pre_tmom, B, C, H, W, L.BG, d, res);                               \
   }
 #define CALL_R(T, A, O, R) { if (ragged) CALL_G(T, A, O, R, true, false) else CALL_G(T, A, O, R, false, false) }
 #define CALL_P(T)                                                                                       \

@@ -74,8 +74,12 @@ int launch_base_attend_fwd(const void* x, const float* wv, void* Vring, const fl
 int launch_plain_bn_fwd(const float* amom, const float* gamma, const float* beta, float* run_mean, float* run_var,
                         int training, float momentum, float eps, float* sc, float* sh, float* save_mean,
                         float* save_inv, const float* pivot, int B, int C, int HW, hipStream_t st);
+int launch_plain_bn_fwd_rec(const float* rec, const float* gamma, const float* beta, float* run_mean, float* run_var,
+                            int training, float momentum, float eps, float* sc, float* sh, float* save_mean,
+                            float* save_inv, int R, int C, hipStream_t st);
 int launch_plain_bn_bwd(const float* tmom, const float* gamma, const float* save_mean, const float* save_inv,
-                        int training, float* cb, float* dgamma, float* dbeta, int B, int C, int HW, hipStream_t st);
+                        int training, int centered, float* cb, float* dgamma, float* dbeta, int B, int C, int HW,
+                        hipStream_t st);
 int launch_base_tail_fwd(const void* x, const void* attn, const float* sc, const float* sh, const float* dp, void* out,
                          int B, int C, int HW, int dtype, hipStream_t st);
 int launch_base_tail_stats_bwd(const void* dout, const void* attn, const float* sc, const float* sh, const float* dp,
@@ -143,8 +147,8 @@ int launch_token_ln_bwd(const void* dout, const void* x, const void* o, const fl
 
 // bnact_nchw.hip -- fused BatchNorm2d (+ReLU) passes
 int launch_plane_moments(const void* x, float* amom, float* pivot, int B, int C, int HW, int dtype, hipStream_t st);
-int launch_plane_dmoments(const void* dy, const void* x, const float* sc, const float* sh, int relu, float* tmom, int B,
-                          int C, int HW, int dtype, hipStream_t st);
+int launch_plane_dmoments(const void* dy, const void* x, const float* sc, const float* sh, const float* center, int relu,
+                          float* tmom, int B, int C, int HW, int dtype, hipStream_t st);
 int launch_affine_act(const void* x, const void* dy, const float* a, const float* sc, const float* sh, int relu,
                       void* out, int B, int C, int HW, int dtype, int bwd, hipStream_t st);
 
@@ -159,8 +163,8 @@ int launch_conv1x1_fwd(const void* x, const void* w, void* y, float* part, int M
 int bn_pool_rows(int B, int C, int H, int W);
 int launch_bn_relu_pool_fwd(const void* x, const float* sc, const float* sh, void* out, int B, int C, int H, int W,
                             int dtype, hipStream_t st);
-int launch_bn_relu_pool_dmoments(const void* dp, const void* x, const float* sc, const float* sh, float* tmom, int B,
-                                 int C, int H, int W, int dtype, hipStream_t st);
+int launch_bn_relu_pool_dmoments(const void* dp, const void* x, const float* sc, const float* sh, const float* center,
+                                 float* tmom, int B, int C, int H, int W, int dtype, hipStream_t st);
 int launch_bn_relu_pool_bwd(const void* dp, const void* x, const float* sc, const float* sh, const float* cb, void* dx,
                             int B, int C, int H, int W, int dtype, hipStream_t st);
 // conv1x1_wide.hip -- the same product for wide outputs (N % 256 == 0): X streamed through LDS, optional addend
@@ -188,8 +192,8 @@ int launch_light_apply_fwd_pre_wide(const void* pre, const void* o, const float*
                                     hipStream_t st);
 int launch_light_apply_bwd_wide(const void* dout, const void* x, const void* o, const float* wv, const float* gate,
                                 const float* cb, const float* lam, const float* dp, const float* dyx, void* dx,
-                                void* dprev, float* dwv_part, const void* pre, float* pre_tmom, int B, int C, int H,
-                                int W, int d, int res, int relu, int dtype, int act, hipStream_t st);
+                                void* dprev, float* dwv_part, const void* pre, const float* pre_center, float* pre_tmom,
+                                int B, int C, int H, int W, int d, int res, int relu, int dtype, int act, hipStream_t st);
 int launch_light_stats_bwd_wide(const void* dout, const void* x, const void* o, const float* wv, float* bmom, int B,
                                 int C, int H, int W, int dtype, int act, hipStream_t st);
 int launch_light_stats_fwd_nhwc(const void* x, const void* o, const float* wv, float* mom, void* xout,
@@ -202,8 +206,8 @@ int launch_light_stats_bwd_nhwc(const void* dout, const void* x, const void* o, 
                                 int C, int H, int W, int dtype, int act, hipStream_t st);
 int launch_light_apply_bwd_nhwc(const void* dout, const void* x, const void* o, const float* wv, const float* gate,
                                 const float* cb, const float* lam, const float* dp, const float* dyx, void* dx,
-                                void* dprev, float* dwv_part, const void* pre, float* pre_tmom, int B, int C, int H,
-                                int W, int d, int res, int relu, int dtype, int act, hipStream_t st);
+                                void* dprev, float* dwv_part, const void* pre, const float* pre_center, float* pre_tmom,
+                                int B, int C, int H, int W, int d, int res, int relu, int dtype, int act, hipStream_t st);
 int nhwc_bn_splits(int B, int C, int HW);
 int launch_nhwc_pool_fused(const void* pre, const float* sc, const float* sh, const void* o, float* part, float* mom,
                            int B, int C, int HW, int dtype, hipStream_t st);

@@ -151,11 +151,13 @@ constexpr int pool_mom_wave_bytes() { return 2 * pool_mom_set_bytes<T, PS>(); }
 template <typename T, int PS>
 __global__ __launch_bounds__(kPoolWaves* kWave) void bn_relu_pool_dmoments_kernel(const T* __restrict__ dp, const T* __restrict__ x,
                                                                                   const float* __restrict__ sc, const float* __restrict__ sh,
+                                                                                  const float* __restrict__ center,
                                                                                   float* __restrict__ tmom, int C, int H, int W, int Ho,
                                                                                   int Wo, int bands) {
   constexpr int NX = 2 * PS + 1;
   constexpr int F = 2 * RowIO<T, NX>::NL + RowIO<T, PS>::NL;       // fetch instructions of one step
   MRLA_POOL_PROLOGUE(2, (pool_mom_wave_bytes<T, PS>()))
+  const float ncen = center ? -center[c] : 0.f;                    // sum dz*(x - center): dz*x - center*dz, term by term
   const T* xi = x + (size_t)b * H * rowelems;
   const T* gi = dp + (size_t)b * Ho * orowelems;
   const int nstrips = (Wo + PS - 1) / PS;
@@ -219,6 +221,7 @@ __global__ __launch_bounds__(kPoolWaves* kWave) void bn_relu_pool_dmoments_kerne
           acc[1] = fmaf(hit ? gg : 0.f, XC.v[2 * v + k], acc[1]);
           open = open && !hit;
         }
+        acc[1] = fmaf(ncen, gg, acc[1]);       // (gg != 0 implies exactly one hit above)
       }
     };
     // (the row windows rotate by name: the raw rows' registers are only ever written by the LDS reads)
@@ -422,8 +425,8 @@ int launch_bn_relu_pool_fwd(const void* x, const float* sc, const float* sh, voi
   return hip_status(hipGetLastError());
 }
 
-int launch_bn_relu_pool_dmoments(const void* dp, const void* x, const float* sc, const float* sh, float* tmom, int B,
-                                 int C, int H, int W, int dtype, hipStream_t st) {
+int launch_bn_relu_pool_dmoments(const void* dp, const void* x, const float* sc, const float* sh, const float* center,
+                                 float* tmom, int B, int C, int H, int W, int dtype, hipStream_t st) {
   if (!bn_pool_supported(B, C, H, W)) return MRLA_EUNSUPPORTED;
   const PoolGeo g = pool_geo(B, C, H, W, kPS);
   const dim3 grid(C / kWave, B * g.bands), block(g.nwaves * kWave);
@@ -432,7 +435,7 @@ int launch_bn_relu_pool_dmoments(const void* dp, const void* x, const float* sc,
     const size_t lds = (size_t)g.nwaves * (2 * kWave * sizeof(float) + pool_mom_wave_bytes<TT, kPS>());             \
     if (pool_lds(bn_relu_pool_dmoments_kernel<TT, kPS>, lds) != hipSuccess) return MRLA_EHIP;                       \
     hipLaunchKernelGGL((bn_relu_pool_dmoments_kernel<TT, kPS>), grid, block, lds, st, (const TT*)dp, (const TT*)x,  \
-                       sc, sh, tmom, C, H, W, g.Ho, g.Wo, g.bands);                                                 \
+                       sc, sh, center, tmom, C, H, W, g.Ho, g.Wo, g.bands);                                         \
   }
   MRLA_POOL_DISPATCH(dtype, CALL)
 #undef CALL

@@ -44,9 +44,13 @@ def wrap_data_parallel(model, device_ids=None, bucket_cap_mb=32, force=False):
         broadcast_buffers=False)
     # Without a communication hook the reducer divides EVERY parameter's gradient by the world size with a kernel of its
     # own before the bucket goes out (161 launches and ~0.5 ms of GPU time per resnet50_mrlal step, rocprofv3 trace in
-    # profiles/r03_notes.md).  With a hook the averaging is the hook's business: RCCL averages inside the all-reduce
-    # (ReduceOp.AVG), gloo (CPU tests) divides the flat bucket once.
-    ddp.register_comm_hook(None, _allreduce_avg_hook)
+    # profiles/r03_notes.md).  With a hook the averaging is the hook's business: one division of the flat bucket.
+    how = os.environ.get("MRLA_DDP_HOOK", "builtin")          # (A/B switch for measurements: none | python | builtin)
+    if how == "builtin":
+        # the C++ all-reduce hook: divides the flat bucket once, launches the all-reduce, no Python in the backward pass
+        ddp._register_builtin_comm_hook(dist.BuiltinCommHookType.ALLREDUCE)
+    elif how == "python":
+        ddp.register_comm_hook(None, _allreduce_avg_hook)
     return ddp
 
 

@@ -227,10 +227,11 @@ class _DeferredBnBox:
     backward needs on the way (mrla_light_apply_bwd: pre / pre_tmom).  It leaves them here, tagged with the gradient tensor
     they belong to; the BatchNorm's backward uses them when exactly that tensor arrives, and runs its own statistics pass
     otherwise (another consumer added to the gradient, a layout conversion, a path without the fused sums)."""
-    __slots__ = ("ptr", "shape", "tmom", "rows")
+    __slots__ = ("ptr", "shape", "tmom", "rows", "center")
 
     def __init__(self):
         self.ptr = self.shape = self.tmom = self.rows = None
+        self.center = None         # that BatchNorm's saved mean [c]: the sums are taken about it
 
     def put(self, dpre, tmom, rows):
         self.ptr, self.shape, self.tmom, self.rows = dpre.data_ptr(), tuple(dpre.shape), tmom, rows
@@ -397,7 +398,8 @@ class _LightFn(torch.autograd.Function):
             pre = None
         _call("mrla_light_apply_bwd", xc.numel() * xc.element_size() * ((5 if oc is not None else 3) + (pre is not None)),
               _ptr(dout), _ptr(xc), _ptr(oc), _ptr(wv32), _ptr(gate), _ptr(cb), _ptr(lam32),
-              _ptr(dp32), _ptr(dyx), _ptr(dx), _ptr(do), _ptr(dwv_part), _ptr(pre), _ptr(pre_tmom), b, c, h, w, d, cfg.res,
+              _ptr(dp32), _ptr(dyx), _ptr(dx), _ptr(do), _ptr(dwv_part), _ptr(pre),
+              _ptr(cfg.pre_box.center) if pre is not None else None, _ptr(pre_tmom), b, c, h, w, d, cfg.res,
               int(cfg.fuse), dt, layout, cfg.act, st)
         if pre_tmom is not None:
             cfg.pre_box.put(dx, pre_tmom, rows)
@@ -647,12 +649,13 @@ class _BaseFn(torch.autograd.Function):
         if cfg.tail:
             trows = L.load().mrla_bn_moment_rows(b, c, h, w, layout) if nhwc else b
             tmom = torch.empty((trows, c, 2), dtype=torch.float32, device=dev)
+            center = bnbuf[2] if nhwc else None      # sums about the saved batch mean (the NCHW slab kernel keeps raw sums)
             _call("mrla_base_tail_stats_bwd", xc.numel() * es * 2, _ptr(dout), _ptr(attn), _ptr(bnbuf[0]), _ptr(bnbuf[1]),
-                  _ptr(dp32), _ptr(tmom), b, c, h, w, dt, layout, st)
+                  _ptr(center), _ptr(dp32), _ptr(tmom), b, c, h, w, dt, layout, st)
             small = torch.empty((5, c), dtype=torch.float32, device=dev)         # cb[c,3] | dgamma | dbeta
             cb = small[:3].view(c, 3)
-            L.call("mrla_bn_stats_bwd", _ptr(tmom), _ptr(gamma32), _ptr(bnbuf[2]), _ptr(bnbuf[3]), cfg.bn_mode, _ptr(cb),
-                   _ptr(small[3]), _ptr(small[4]), trows, c, b * h * w // trows, st)
+            L.call("mrla_bn_stats_bwd", _ptr(tmom), _ptr(gamma32), _ptr(bnbuf[2]), _ptr(bnbuf[3]), cfg.bn_mode,
+                   int(center is not None), _ptr(cb), _ptr(small[3]), _ptr(small[4]), trows, c, b * h * w // trows, st)
             dgamma, dbeta = small[3].to(ctx.pdtypes[3]), small[4].to(ctx.pdtypes[3])
         pmom = torch.empty((b, c, t), dtype=torch.float32, device=dev)
         prows = L.load().mrla_base_pmom_rows(b, c, h, w, dt, layout)
@@ -809,22 +812,29 @@ class _BnActFn(torch.autograd.Function):
         bnbuf = torch.empty((4, c), dtype=torch.float32, device=dev)       # sc, sh, save_mean, save_inv
         rows = L.load().mrla_bn_moment_rows(b, c, h, w, layout)           # partial-sum rows (b, or b*nsplit for NHWC)
         frows, pivot = rows, None
-        if training and pre_moments is not None:      # the producer (the 1x1 convolution GEMM) already took them
+        records = training and pre_moments is not None
+        if records:                # the producer (the 1x1 convolution GEMM) already took them: pivoted records per row
             amom, frows = pre_moments, pre_moments.shape[0]
-            if tuple(amom.shape) != (frows, c, 2) or amom.dtype != torch.float32 or (b * h * w) % frows:
-                raise L.MrlaHipError("pre_moments must be float32 [rows, c, 2] with rows dividing b*h*w")
+            if tuple(amom.shape) != (frows, c, L.GEMM_MOMENTS) or amom.dtype != torch.float32:
+                raise L.MrlaHipError("pre_moments must be float32 [rows, c, MRLA_GEMM_MOMENTS] records")
         else:
             amom = torch.empty((rows, c, 2), dtype=torch.float32, device=dev)
             if training:           # sums about a per-channel pivot (a sample of the channel): robust for |mean| >> sigma
                 pivot = torch.empty((c,), dtype=torch.float32, device=dev)
                 _call("mrla_bn_plane_moments", xc.numel() * xc.element_size(), _ptr(xc), _ptr(amom), _ptr(pivot), b, c, h, w,
                       dt, layout, st)
-        L.call("mrla_bn_stats_fwd", _ptr(amom), _ptr(pivot), _ptr(gamma32), _ptr(beta32), _ptr(rs.rm), _ptr(rs.rv),
-               L.BN_TRAIN if training else L.BN_EVAL, float(momentum), float(eps), _ptr(bnbuf[0]), _ptr(bnbuf[1]),
-               _ptr(bnbuf[2]), _ptr(bnbuf[3]), frows, c, b * h * w // frows, st)
+        if records:
+            L.call("mrla_bn_stats_fwd_rows", _ptr(amom), _ptr(gamma32), _ptr(beta32), _ptr(rs.rm), _ptr(rs.rv), L.BN_TRAIN,
+                   float(momentum), float(eps), _ptr(bnbuf[0]), _ptr(bnbuf[1]), _ptr(bnbuf[2]), _ptr(bnbuf[3]), frows, c, st)
+        else:
+            L.call("mrla_bn_stats_fwd", _ptr(amom), _ptr(pivot), _ptr(gamma32), _ptr(beta32), _ptr(rs.rm), _ptr(rs.rv),
+                   L.BN_TRAIN if training else L.BN_EVAL, float(momentum), float(eps), _ptr(bnbuf[0]), _ptr(bnbuf[1]),
+                   _ptr(bnbuf[2]), _ptr(bnbuf[3]), frows, c, b * h * w // frows, st)
         rs.finish(training)
         ctx.training, ctx.relu, ctx.gdtype, ctx.layout, ctx.rows = training, int(relu), gamma.dtype, layout, rows
         ctx.box = box if defer else None
+        if ctx.box is not None:
+            ctx.box.center = bnbuf[2]
         ctx.save_for_backward(xc, gamma32, bnbuf)
         if defer:
             if relu:
@@ -854,12 +864,12 @@ class _BnActFn(torch.autograd.Function):
             tmom, rows = handed
         else:
             tmom = torch.empty((rows, c, 2), dtype=torch.float32, device=dev)
-            _call("mrla_bn_plane_dmoments", xc.numel() * es * 2, _ptr(dy), _ptr(xc), _ptr(bnbuf[0]), _ptr(bnbuf[1]), ctx.relu,
-                  _ptr(tmom), b, c, h, w, dt, layout, st)
+            _call("mrla_bn_plane_dmoments", xc.numel() * es * 2, _ptr(dy), _ptr(xc), _ptr(bnbuf[0]), _ptr(bnbuf[1]),
+                  _ptr(bnbuf[2]), ctx.relu, _ptr(tmom), b, c, h, w, dt, layout, st)
         small = torch.empty((5, c), dtype=torch.float32, device=dev)          # cb[c,3] | dgamma | dbeta
         cb = small[:3].view(c, 3)
         L.call("mrla_bn_stats_bwd", _ptr(tmom), _ptr(gamma32), _ptr(bnbuf[2]), _ptr(bnbuf[3]),
-               L.BN_TRAIN if ctx.training else L.BN_EVAL, _ptr(cb), _ptr(small[3]), _ptr(small[4]), rows, c,
+               L.BN_TRAIN if ctx.training else L.BN_EVAL, 1, _ptr(cb), _ptr(small[3]), _ptr(small[4]), rows, c,
                b * h * w // rows, st)
         dx = torch.empty_like(xc)
         _call("mrla_bn_act_bwd", xc.numel() * es * 3, _ptr(dy), _ptr(xc), _ptr(bnbuf[0]), _ptr(bnbuf[1]), _ptr(cb), ctx.relu,
@@ -937,11 +947,11 @@ class _BnReluPoolFn(torch.autograd.Function):
         L.check(min(rows, 0), "mrla_bn_pool_rows")
         tmom = torch.empty((rows, c, 2), dtype=torch.float32, device=dev)
         _call("mrla_bn_relu_pool_dmoments", (xc.numel() + dp.numel()) * es, _ptr(dp), _ptr(xc), _ptr(bnbuf[0]), _ptr(bnbuf[1]),
-              _ptr(tmom), b, c, h, w, dt, L.NHWC, st)
+              _ptr(bnbuf[2]), _ptr(tmom), b, c, h, w, dt, L.NHWC, st)
         small = torch.empty((5, c), dtype=torch.float32, device=dev)          # cb[c,3] | dgamma | dbeta
         cb = small[:3].view(c, 3)
         L.call("mrla_bn_stats_bwd", _ptr(tmom), _ptr(gamma32), _ptr(bnbuf[2]), _ptr(bnbuf[3]),
-               L.BN_TRAIN if ctx.training else L.BN_EVAL, _ptr(cb), _ptr(small[3]), _ptr(small[4]), rows, c,
+               L.BN_TRAIN if ctx.training else L.BN_EVAL, 1, _ptr(cb), _ptr(small[3]), _ptr(small[4]), rows, c,
                b * h * w // rows, st)
         dx = None
         if ctx.needs_input_grad[0]:
@@ -1055,7 +1065,7 @@ class _Conv1x1Fn(torch.autograd.Function):
             y = torch.empty((b, n, h, wd), dtype=x.dtype, device=dev, memory_format=_CL)
             if want_moments:
                 rows = L.load().mrla_conv1x1_rows(m, k, n, _DT[x.dtype])
-                part = torch.empty((rows, n, 2), dtype=torch.float32, device=dev)
+                part = torch.empty((rows, n, L.GEMM_MOMENTS), dtype=torch.float32, device=dev)
             _call("mrla_conv1x1_fwd", (x.numel() + y.numel()) * x.element_size(), _ptr(x), _ptr(w), _ptr(y), _ptr(part), m, k,
                   n, _DT[x.dtype], st)
         else:

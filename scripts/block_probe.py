@@ -11,7 +11,9 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 from mrla_amd import functional as Fm, layers, resnet  # noqa: E402
 from oracle import eager_models as em  # noqa: E402
-from tests.test_block_bf16_gpu import _bn, rnd  # noqa: E402
+from tests.test_block_bf16_gpu import _RefConv, _bn, _stock_directions, rnd  # noqa: E402
+
+STOCK = os.environ.get("PROBE_FP64_CONVS") is None      # default: stock operators as black boxes, as the test does
 
 which = sys.argv[1] if len(sys.argv) > 1 else "stage1"
 b, inplanes, planes, hw = {"stage1": (64, 256, 64, 56), "stage3": (64, 1024, 256, 14)}[which]
@@ -62,13 +64,15 @@ R = {}
 wc = lambda w: w.float().bfloat16().double()  # noqa: E731
 xr = x.double().requires_grad_(True)
 ident = rnd(xr, "bwd")
-R["y1"] = rnd(F.conv2d(xr, wc(ref.conv1.weight)))
+M = b * hw * hw
+sd = (lambda c: _stock_directions(c, M)) if STOCK else (lambda c: (False, False))
+R["y1"] = rnd(_RefConv.apply(xr, wc(ref.conv1.weight), 0, *sd(blk.conv1)))
 z, *_ = _bn(R["y1"], ref.bn1)
 R["z1"] = rnd(torch.relu(z))
-R["y2"] = rnd(F.conv2d(R["z1"], wc(ref.conv2.weight), padding=1))
+R["y2"] = rnd(_RefConv.apply(R["z1"], wc(ref.conv2.weight), 1, STOCK, STOCK))
 z, *_ = _bn(R["y2"], ref.bn2)
 R["z2"] = rnd(torch.relu(z))
-R["y3"] = rnd(F.conv2d(R["z2"], wc(ref.conv3.weight)))
+R["y3"] = rnd(_RefConv.apply(R["z2"], wc(ref.conv3.weight), 0, *sd(blk.conv3)))
 pre_r, *_ = _bn(R["y3"], ref.bn3)
 pre_r = rnd(pre_r)
 xt = rnd(torch.relu(pre_r + ident), "fwd")

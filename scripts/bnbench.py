@@ -47,7 +47,7 @@ for c, hw, cnt in SHAPES:
     nbytes = x.numel() * 2
     K = {"moments": (1, lambda: lib.mrla_bn_plane_moments(P(x), P(mom), None, B, c, hw, hw, L.BF16, LAY, st)),
          "act_fwd": (2, lambda: lib.mrla_bn_act_fwd(P(x), P(sc), P(sh), 1, P(y), B, c, hw, hw, L.BF16, LAY, st)),
-         "dmoments": (2, lambda: lib.mrla_bn_plane_dmoments(P(g), P(x), P(sc), P(sh), 1, P(mom), B, c, hw, hw, L.BF16, LAY, st)),
+         "dmoments": (2, lambda: lib.mrla_bn_plane_dmoments(P(g), P(x), P(sc), P(sh), None, 1, P(mom), B, c, hw, hw, L.BF16, LAY, st)),
          "act_bwd": (3, lambda: lib.mrla_bn_act_bwd(P(g), P(x), P(sc), P(sh), P(cb), 1, P(y), B, c, hw, hw, L.BF16, LAY, st))}
     cells = []
     for name, (passes, fn) in K.items():

@@ -17,6 +17,13 @@ SHAPES = [(2, 56, 56, 64, 256), (2, 56, 56, 256, 64), (2, 56, 56, 64, 64), (2, 5
           (1, 5, 7, 64, 256), (3, 7, 7, 256, 512), (2, 9, 9, 128, 256), (1, 1, 1, 256, 256)]   # wide form, ragged pixel counts
 
 
+def raw_sums(part):
+    """[n, 2] float64 (sum y, sum y^2) from the GEMM epilogue's moment records [rows, n, 4] = (S1, S2, pivot, count)."""
+    r = part.double()
+    s1, s2, p, cnt = r[..., 0], r[..., 1], r[..., 2], r[..., 3]
+    return torch.stack([(s1 + cnt * p).sum(0), (s2 + 2 * p * s1 + cnt * p * p).sum(0)], dim=1)
+
+
 def _operands(b, h, w, k, n, salt=0):
     s = detgen.seed_of(f"conv1x1/{b}/{h}/{k}/{n}/{salt}")
     x = bf16_round(detgen.normalish((b, h, w, k), s))
@@ -37,13 +44,15 @@ def test_gemm_outputs_and_moment_partials(shape):
     wtt = torch.from_numpy(wt).cuda().bfloat16()
     y, part = Fm._Conv1x1Fn.apply(xt, wtt, True)
     torch.cuda.synchronize()
-    assert y.is_contiguous(memory_format=torch.channels_last) and tuple(part.shape) == (rows, n, 2)
+    assert y.is_contiguous(memory_format=torch.channels_last) and tuple(part.shape) == (rows, n, L.GEMM_MOMENTS)
     want = x.reshape(m, k).astype(np.float64) @ wt.astype(np.float64).T
     got = y.permute(0, 2, 3, 1).reshape(m, n).float().cpu().numpy()
     assert_bf16_close(got, want, "y")
-    # the statistics are those of the stored (rounded) tensor, as the stand-alone moments pass would read them back
+    # the statistics are those of the stored (rounded) tensor, as the stand-alone moments pass would read them back:
+    # records (sum (y-p), sum (y-p)^2, p, n) per workgroup row -> raw sums in float64
     g64 = got.astype(np.float64)
-    s = part.double().sum(0).cpu().numpy()
+    s = raw_sums(part).cpu().numpy()
+    assert part[:, :, 3].double().sum(0).eq(m).all()             # every pixel counted once per channel
     assert relmax(s[:, 0], g64.sum(0)) < 1e-5 and relmax(s[:, 1], (g64 * g64).sum(0)) < 1e-5
     # no moments requested: same outputs
     y2, p2 = Fm._Conv1x1Fn.apply(xt, wtt, False)

@@ -64,7 +64,7 @@ def _ragged_m(m0, k, n, addend):
 def _run_fwd(x, w, m, k, n, rows, moments):
     from mrla_amd import _lib as L
     y = torch.full((m, n), float("nan"), dtype=torch.bfloat16, device="cuda")
-    part = torch.full((rows, n, 2), float("nan"), dtype=torch.float32, device="cuda") if moments else None
+    part = torch.full((rows, n, L.GEMM_MOMENTS), float("nan"), dtype=torch.float32, device="cuda") if moments else None
     L.call("mrla_conv1x1_fwd", _P(x), _P(w), _P(y), _P(part), m, k, n, L.BF16, _stream())
     return y, part
 
@@ -96,16 +96,23 @@ def test_forward_gemm_and_moment_partials_in_steady_state(shape, batch):
     _assert_bf16_close(y, want, "y")
     del want
     # statistics of the stored (rounded) tensor, as the stand-alone moments pass would read them back
+    from tests.test_conv1x1_gpu import raw_sums
     g = y.double()
-    s = part.double().sum(0)
+    s = raw_sums(part)                                           # records (S1, S2, pivot, count) per row -> raw sums
+    assert part[:, :, 3].double().sum(0).eq(m).all()
     s1, s2 = g.sum(0), (g * g).sum(0)
     assert ((s[:, 0] - s1).abs().max() / s1.abs().max()).item() < 1e-5
     assert ((s[:, 1] - s2).abs().max() / s2.abs().max()).item() < 1e-5
-    # ... and they must be good enough for the variance the BatchNorm takes from them (one-pass E[y^2] - E[y]^2)
-    mean, var = s1 / m, s2 / m - (s1 / m) ** 2
-    mean_k, var_k = s[:, 0] / m, s[:, 1] / m - (s[:, 0] / m) ** 2
-    assert ((mean_k - mean).abs() / var.sqrt()).max().item() < 1e-4
-    assert ((var_k - var).abs() / var).max().item() < 1e-3
+    # ... and the variance the per-channel kernel takes from the records (merged about one pivot, as it does)
+    mean, var = s1 / m, g.var(dim=0, unbiased=False)
+    r = part.double()
+    P = r[0, :, 2]
+    d = r[..., 2] - P
+    S1 = (r[..., 0] + r[..., 3] * d).sum(0)
+    S2 = (r[..., 1] + 2 * d * r[..., 0] + r[..., 3] * d * d).sum(0)
+    mean_k, var_k = S1 / m + P, S2 / m - (S1 / m) ** 2
+    assert ((mean_k - mean).abs() / var.sqrt()).max().item() < 1e-5
+    assert ((var_k - var).abs() / var).max().item() < 1e-5
 
 
 @pytest.mark.parametrize("batch", [64, 256, "ragged"])

@@ -43,7 +43,7 @@ enum { MRLA_BN_NONE = 0, MRLA_BN_TRAIN = 1, MRLA_BN_EVAL = 2 };
 #define MRLA_FWD_MOMENTS 8 /* sum x, sum V', sum o', sum V'^2, sum V'*o', sum o'^2, pV, po  with V' = V - pV, o' = o - po:
                               the second moments are taken about per-plane pivots (samples of V / o; 0 where a producer
                               does not shift) so that they stay well conditioned when |mean| >> sigma */
-#define MRLA_BWD_MOMENTS 3 /* sum dOut, sum dOut*V, sum dOut*o */
+#define MRLA_BWD_MOMENTS 3 /* sum dOut, sum dOut*V', sum dOut*o'  (V' = V - pV, o' = o - pO: about the forward record's pivots) */
 #define MRLA_GEMM_MOMENTS 4 /* the 1x1-convolution GEMM's epilogue, per (workgroup row, out-channel): sum (y - p),
                                sum (y - p)^2, the pivot p (the row's first rounded output of the channel), pixel count n */
 
@@ -53,7 +53,8 @@ enum { MRLA_BN_NONE = 0, MRLA_BN_TRAIN = 1, MRLA_BN_EVAL = 2 };
  *           mrla_conv1x1_wgrad gained dw_dtype, mrla_conv1x1_fwd's mom_part became
  *           [rows, n, MRLA_GEMM_MOMENTS] records (was [rows, n, 2] raw sums) read by the new mrla_bn_stats_fwd_rows,
  *           mrla_bn_plane_dmoments / mrla_bn_relu_pool_dmoments / mrla_base_tail_stats_bwd gained center and
- *           mrla_bn_stats_bwd gained centered (BatchNorm-backward sums about the saved mean);
+ *           mrla_bn_stats_bwd gained centered (BatchNorm-backward sums about the saved mean), mrla_light_stats_bwd gained
+ *           mom (MRLA_BWD_MOMENTS are about the forward record's pivots);
  *           mrla_conv1x1_plan, mrla_conv1x1_wgrad_plan, mrla_light_apply_bwd_pre_sums, mrla_reduce_rows2 and
  *           mrla_weight_bank_refresh were added.
  * A consumer compares mrla_abi_version() (what the loaded library was built from) against this constant before its
@@ -121,9 +122,12 @@ int mrla_light_apply_fwd(const void* x, const void* o_prev, const float* wv, con
                          int d, int res, int dtype, int layout, int act, void* stream);
 
 /* ---- backward pass 1 of 2: bmom[b, c, 3] ---------------------------------------------------------
- * The reductions autograd performs in MulBackward / ExpandBackward / NativeBatchNormBackward. */
-int mrla_light_stats_bwd(const void* dout, const void* x, const void* o_prev, const float* wv, float* bmom, int b,
-                         int c, int h, int w, int dtype, int layout, int act, void* stream);
+ * The reductions autograd performs in MulBackward / ExpandBackward / NativeBatchNormBackward.
+ * mom: the forward record of the same block (mrla_light_stats_fwd*): the sums over dOut*V and dOut*o are taken about its
+ * pivots (pV, pO), so that what survives the cancellations of the BatchNorm backward keeps fp32 accuracy when
+ * |mean| >> sigma; mrla_light_bn_bwd / mrla_light_gate_bwd (given the same mom) undo the shift in double. */
+int mrla_light_stats_bwd(const void* dout, const void* x, const void* o_prev, const float* wv, const float* mom,
+                         float* bmom, int b, int c, int h, int w, int dtype, int layout, int act, void* stream);
 
 /* ---- BatchNorm backward constants + dgamma, dbeta, dlambda ---------------------------------------
  * cb[c, 4] = (e, f, G, H) such that dm = e*dp[b]*dOut + f*a[b,g]*V + G*o_prev + H.

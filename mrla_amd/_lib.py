@@ -31,7 +31,7 @@ SIGNATURES = {
     "mrla_light_gate_fwd": [_P, _P, _P, _I, _P, _I, _I, _I, _I, _P],
     "mrla_light_bn_fwd": [_P, _P, _P, _P, _P, _P, _P, _I, _F, _F, _P, _P, _P, _P, _I, _I, _I, _I, _P],
     "mrla_light_apply_fwd": [_P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P],
-    "mrla_light_stats_bwd": [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P],
+    "mrla_light_stats_bwd": [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P],
     "mrla_light_bn_bwd": [_P, _P, _P, _P, _P, _P, _P, _P, _I, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P],
     "mrla_light_gate_bwd": [_P, _P, _P, _P, _P, _P, _P, _P, _I, _P, _P, _I, _I, _I, _I, _P],
     "mrla_light_apply_bwd_pre_sums": [_I] * 6,

@@ -193,12 +193,12 @@ int mrla_light_apply_fwd(const void* x, const void* o_prev, const float* wv, con
                                      (hipStream_t)stream);
 }
 
-int mrla_light_stats_bwd(const void* dout, const void* x, const void* o_prev, const float* wv, float* bmom, int b,
-                         int c, int h, int w, int dtype, int layout, int act, void* stream) {
-  if (!dout || !x || !wv || !bmom || bad_dims(b, c, h, w) || bad_dtype(dtype)) return MRLA_EINVAL;
+int mrla_light_stats_bwd(const void* dout, const void* x, const void* o_prev, const float* wv, const float* mom,
+                         float* bmom, int b, int c, int h, int w, int dtype, int layout, int act, void* stream) {
+  if (!dout || !x || !wv || !mom || !bmom || bad_dims(b, c, h, w) || bad_dtype(dtype)) return MRLA_EINVAL;
   if (layout == MRLA_NHWC)
-    return launch_light_stats_bwd_nhwc(dout, x, o_prev, wv, bmom, b, c, h, w, dtype, act, (hipStream_t)stream);
-  if (layout != MRLA_NCHW) return MRLA_EINVAL;
+    return launch_light_stats_bwd_nhwc(dout, x, o_prev, wv, mom, bmom, b, c, h, w, dtype, act, (hipStream_t)stream);
+  if (layout != MRLA_NCHW) return MRLA_EINVAL;      // (the NCHW forward statistics carry zero pivots: raw = shifted)
   SlabGeo g;
   const int rc = light_geo(&g, b, c, h, w, dtype);
   if (rc != MRLA_OK) return rc;

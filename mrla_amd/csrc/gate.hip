@@ -122,10 +122,13 @@ __global__ __launch_bounds__(kThreads) void bn_bwd_kernel(
   if (live) {
     for (int b = bl; b < B; b += kBnLanes) {
       const float* bm = bmom + ((size_t)b * C + c) * D_N;
+      const float* m = mom + ((size_t)b * C + c) * M_REC;
       const float a = gate[(size_t)b * G + c / d];
       const double dpb = dp ? dp[b] : 1.f;
+      // (bmom's sums over dOut*V and dOut*o are about the forward pivots: un-shift in double)
+      const double dv = (double)bm[D_DV] + (double)m[M_PV] * bm[D_D], dO = (double)bm[D_DO] + (double)m[M_PO] * bm[D_D];
       s1 += dpb * bm[D_D];
-      s2 += dpb * ((double)a * bm[D_DV] + (double)l * bm[D_DO]);
+      s2 += dpb * ((double)a * dv + (double)l * dO);
     }
   }
   r1[bl][cc] = s1; r2[bl][cc] = s2;
@@ -167,7 +170,7 @@ __global__ __launch_bounds__(kThreads) void bn_bwd_kernel(
       const double a = gate[(size_t)b * G + c / d];
       const double dpb = dp ? dp[b] : 1.f;
       const RawMoments r = raw_moments(m, (double)HW);
-      s3 += e * dpb * bm[D_DO] + f * a * r.svo + Gc * r.soo + Hc * r.so;
+      s3 += e * dpb * ((double)bm[D_DO] + (double)m[M_PO] * bm[D_D]) + f * a * r.svo + Gc * r.soo + Hc * r.so;
     }
   }
   r1[bl][cc] = s3;
@@ -236,7 +239,7 @@ __global__ __launch_bounds__(kThreads) void gate_bwd_kernel(
     if (cb && cb_lo) { e += cb_lo[c * 4 + 0]; f += cb_lo[c * 4 + 1]; Gc += cb_lo[c * 4 + 2]; Hc += cb_lo[c * 4 + 3]; }
     // sum_hw dm * V  for this channel
     const RawMoments r = raw_moments(m, (double)HW);
-    dqs[p + c] = (float)(e * dpb * bm[D_DV] + f * a * r.svv + Gc * r.svo + Hc * r.sv);
+    dqs[p + c] = (float)(e * dpb * ((double)bm[D_DV] + (double)m[M_PV] * bm[D_D]) + f * a * r.svv + Gc * r.svo + Hc * r.sv);
   }
   __syncthreads();
   const float s = rsqrtf((float)d);

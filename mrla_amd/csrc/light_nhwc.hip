@@ -416,10 +416,11 @@ int launch_light_apply_fwd_pre_nhwc(const void* pre, const void* o, const float*
   return hip_status(hipGetLastError());
 }
 
-int launch_light_stats_bwd_nhwc(const void* dout, const void* x, const void* o, const float* wv, float* bmom, int B,
-                                int C, int H, int W, int dtype, int act, hipStream_t st) {
+int launch_light_stats_bwd_nhwc(const void* dout, const void* x, const void* o, const float* wv, const float* mom,
+                                float* bmom, int B, int C, int H, int W, int dtype, int act, hipStream_t st) {
   const NhwcLaunch L = nhwc_launch(B, C, W, D_N, dtype);
-  if (L.wide) return launch_light_stats_bwd_wide(dout, x, o, wv, bmom, B, C, H, W, dtype, act, st);
+  if (L.wide) return launch_light_stats_bwd_wide(dout, x, o, wv, mom, bmom, B, C, H, W, dtype, act, st);
+  // (this path's forward statistics carry zero pivots -- light_stats_fwd_nhwc -- so its raw sums ARE the shifted ones)
 #define CALL_W(T, A, O, WD)                                                                                          \
   {                                                                                                                  \
     if (set_lds_n(light_stats_bwd_nhwc<T, A, O, WD>, L.lds) != hipSuccess) return MRLA_EHIP;                           \

@@ -108,14 +108,17 @@ __device__ __forceinline__ void store_moments(WaveMoments& w, float* __restrict_
 }
 
 // ------------------------------------------------------------------------------------------------
-// backward statistics: per (image, channel) sums of dOut, dOut*V, dOut*o
+// backward statistics: per (image, channel) sums of dOut, dOut*(V - pV), dOut*(o - pO) -- about the pivots the forward
+// statistics pass recorded for the plane (mom[.., M_PV / M_PO]; mom == null: raw sums).  The per-channel kernels put
+// pV * sum dOut back in double: accumulated raw in fp32, sum dOut*V loses eps * |mean V| / sigma_V of what survives
+// the cancellations of the BatchNorm backward (percent-level parameter gradients at |mean| / sigma = 10^3).
 // ------------------------------------------------------------------------------------------------
 template <typename T> constexpr int stats_bwd_wave_bytes() { return RowIO<T, kS + 2>::kBytes + 2 * RowIO<T, kS>::kBytes; }
 
 template <typename T, bool GELU, bool HAS_O, int AUX>
 __global__ __launch_bounds__(kMaxStrips * kWave) void light_stats_bwd_wide(
     const T* __restrict__ dout, const T* __restrict__ x, const T* __restrict__ o, const float* __restrict__ wv,
-    float* __restrict__ bmom, int B, int C, int H, int W, int BG) {
+    const float* __restrict__ mom, float* __restrict__ bmom, int B, int C, int H, int W, int BG) {
   MRLA_WIDE_PROLOGUE(D_N, stats_bwd_wave_bytes<T>())
   T* bufX = reinterpret_cast<T*>(wbuf);
   T* bufG = reinterpret_cast<T*>(wbuf + RowIO<T, kS + 2>::kBytes);
@@ -130,6 +133,8 @@ __global__ __launch_bounds__(kMaxStrips * kWave) void light_stats_bwd_wide(
     const T* gi = dout + ioff;
     const T* oi = HAS_O ? o + ioff : nullptr;
     float acc[D_N] = {0.f, 0.f, 0.f};
+    const float pV = mom ? mom[((size_t)b * C + c) * M_REC + M_PV] : 0.f;
+    const float pO = (mom && HAS_O) ? mom[((size_t)b * C + c) * M_REC + M_PO] : 0.f;
     for (int s = wave; s < nstrips; s += nwaves) {
       const int s0 = s * kS;
       RowIO<T, kS + 2> ax;
@@ -162,8 +167,8 @@ __global__ __launch_bounds__(kMaxStrips * kWave) void light_stats_bwd_wide(
           float v = conv_at(w, XA.v, XB.v, XC.v, j);
           if (GELU) v = gelu_f(v);
           acc[D_D] += gv.v[j];
-          acc[D_DV] = fmaf(gv.v[j], v, acc[D_DV]);
-          if (HAS_O) acc[D_DO] = fmaf(gv.v[j], ov.v[j], acc[D_DO]);
+          acc[D_DV] = fmaf(gv.v[j], v - pV, acc[D_DV]);
+          if (HAS_O) acc[D_DO] = fmaf(gv.v[j], ov.v[j] - pO, acc[D_DO]);
         }
       };
       MRLA_ROTATE3(H, step, xa, xb, xc)
@@ -889,15 +894,15 @@ int launch_light_apply_bwd_wide(const void* dout, const void* x, const void* o, 
   return hip_status(hipGetLastError());
 }
 
-int launch_light_stats_bwd_wide(const void* dout, const void* x, const void* o, const float* wv, float* bmom, int B,
-                                int C, int H, int W, int dtype, int act, hipStream_t st) {
+int launch_light_stats_bwd_wide(const void* dout, const void* x, const void* o, const float* wv, const float* mom,
+                                float* bmom, int B, int C, int H, int W, int dtype, int act, hipStream_t st) {
 #define CALL(T, A, O) CALL_N(T, A, O, 0)      /* default policy: apply_bwd re-reads these tensors right after */
 #define CALL_N(T, A, O, NT)                                                                                        \
   {                                                                                                                \
     const WideLaunch L = wide_launch(B, C, W, D_N, stats_bwd_wave_bytes<T>(), nhwc_images_per_group(B, C, 0));     \
     if (set_lds_n(light_stats_bwd_wide<T, A, O, NT>, L.lds) != hipSuccess) return MRLA_EHIP;                        \
     hipLaunchKernelGGL((light_stats_bwd_wide<T, A, O, NT>), L.grid, L.block, L.lds, st, (const T*)dout, (const T*)x,    \
-                       (const T*)o, wv, bmom, B, C, H, W, L.BG);                                                   \
+                       (const T*)o, wv, mom, bmom, B, C, H, W, L.BG);                                              \
   }
   MRLA_DISPATCH_T_N(dtype, act, o != nullptr, CALL)
 #undef CALL

@@ -194,16 +194,16 @@ int launch_light_apply_bwd_wide(const void* dout, const void* x, const void* o, 
                                 const float* cb, const float* lam, const float* dp, const float* dyx, void* dx,
                                 void* dprev, float* dwv_part, const void* pre, const float* pre_center, float* pre_tmom,
                                 int B, int C, int H, int W, int d, int res, int relu, int dtype, int act, hipStream_t st);
-int launch_light_stats_bwd_wide(const void* dout, const void* x, const void* o, const float* wv, float* bmom, int B,
-                                int C, int H, int W, int dtype, int act, hipStream_t st);
+int launch_light_stats_bwd_wide(const void* dout, const void* x, const void* o, const float* wv, const float* mom,
+                                float* bmom, int B, int C, int H, int W, int dtype, int act, hipStream_t st);
 int launch_light_stats_fwd_nhwc(const void* x, const void* o, const float* wv, float* mom, void* xout,
                                 const float* psc, const float* psh, void* vout, int B, int C, int H, int W, int dtype,
                                 int act, hipStream_t st);
 int launch_light_apply_fwd_nhwc(const void* x, const void* o, const float* wv, const float* gate, const float* sc,
                                 const float* sh, const float* lam, const float* dp, void* out, int B, int C, int H,
                                 int W, int d, int res, int dtype, int act, hipStream_t st);
-int launch_light_stats_bwd_nhwc(const void* dout, const void* x, const void* o, const float* wv, float* bmom, int B,
-                                int C, int H, int W, int dtype, int act, hipStream_t st);
+int launch_light_stats_bwd_nhwc(const void* dout, const void* x, const void* o, const float* wv, const float* mom,
+                                float* bmom, int B, int C, int H, int W, int dtype, int act, hipStream_t st);
 int launch_light_apply_bwd_nhwc(const void* dout, const void* x, const void* o, const float* wv, const float* gate,
                                 const float* cb, const float* lam, const float* dp, const float* dyx, void* dx,
                                 void* dprev, float* dwv_part, const void* pre, const float* pre_center, float* pre_tmom,

@@ -372,7 +372,7 @@ class _LightFn(torch.autograd.Function):
         dout = _layout_of(dout, layout)[1]
 
         bmom = torch.empty((b, c, L.BWD_MOMENTS), dtype=torch.float32, device=dev)
-        _call("mrla_light_stats_bwd", xc.numel() * xc.element_size() * (3 if oc is not None else 2), _ptr(dout), _ptr(xc), _ptr(oc), _ptr(wv32), _ptr(bmom), b, c, h, w, dt, layout,
+        _call("mrla_light_stats_bwd", xc.numel() * xc.element_size() * (3 if oc is not None else 2), _ptr(dout), _ptr(xc), _ptr(oc), _ptr(wv32), _ptr(mom), _ptr(bmom), b, c, h, w, dt, layout,
                cfg.act, st)
         small = torch.empty((11, c), dtype=torch.float32, device=dev)     # cb[c,4] | dgamma | dbeta | dlam | cb_lo[c,4]
         cb, cb_lo = small[:4].view(c, 4), small[7:].view(c, 4)

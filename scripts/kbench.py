@@ -58,6 +58,7 @@ for c, hw in STAGES:
     dwqk = torch.empty(B, 2 * ks, device="cuda")
     rows = lib.mrla_light_wgrad_rows(B, c, hw, hw, L.BF16, LAY)
     dwv = torch.empty(rows, c * 9, device="cuda")
+    pre_tmom = torch.empty(rows, c, 2, device="cuda")
     K = {
         "stats_fwd": (2, lambda: lib.mrla_light_stats_fwd(P(x), P(o), P(wv), P(mom), B, c, hw, hw, L.BF16, LAY, 0, st)),
         "gate_fwd": (0, lambda: lib.mrla_light_gate_fwd(P(mom), P(wq), P(wk), ks, P(gate), B, c, hw * hw, d, st)),
@@ -65,13 +66,16 @@ for c, hw in STAGES:
                                                      P(bn[0]), P(bn[1]), P(bn[2]), P(bn[3]), B, c, hw * hw, d, st)),
         "apply_fwd": (3, lambda: lib.mrla_light_apply_fwd(P(x), P(o), P(wv), P(gate), P(bn[0]), P(bn[1]), P(lam), P(dp), P(out),
                                                           B, c, hw, hw, d, 1, L.BF16, LAY, 0, st)),
-        "stats_bwd": (3, lambda: lib.mrla_light_stats_bwd(P(g), P(x), P(o), P(wv), P(bmom), B, c, hw, hw, L.BF16, LAY, 0, st)),
+        "stats_bwd": (3, lambda: lib.mrla_light_stats_bwd(P(g), P(x), P(o), P(wv), P(mom), P(bmom), B, c, hw, hw, L.BF16, LAY, 0, st)),
         "bn_bwd": (0, lambda: lib.mrla_light_bn_bwd(P(mom), P(bmom), P(gate), P(lam), P(gamma), P(dp), P(bn[2]), P(bn[3]), 1,
                                                      P(cb), None, P(small[0]), P(small[1]), P(small[2]), B, c, hw * hw, d, st)),
         "gate_bwd": (0, lambda: lib.mrla_light_gate_bwd(P(mom), P(bmom), P(gate), P(cb), None, P(dp), P(wq), P(wk), ks, P(dyx), P(dwqk),
                                                         B, c, hw * hw, d, st)),
         "apply_bwd": (5, lambda: lib.mrla_light_apply_bwd(P(g), P(x), P(o), P(wv), P(gate), P(cb), P(lam), P(dp), P(dyx), P(dx),
-                                                          P(do), P(dwv), B, c, hw, hw, d, 1, RELU, L.BF16, LAY, 0, st)),
+                                                          P(do), P(dwv), None, None, None, B, c, hw, hw, d, 1, RELU, L.BF16, LAY, 0, st)),
+        "apply_bwd+bn3sums": (6, lambda: lib.mrla_light_apply_bwd(P(g), P(x), P(o), P(wv), P(gate), P(cb), P(lam), P(dp), P(dyx), P(dx),
+                                                                  P(do), P(dwv), P(out), P(bn[2]), P(pre_tmom), B, c, hw, hw, d, 1, 1,
+                                                                  L.BF16, LAY, 0, st)),
         "stats_fused": (3, lambda: lib.mrla_light_stats_fwd_fused(P(g), P(bn[0]), P(bn[1]), P(o), P(wv), P(mom), P(out), B, c, hw, hw, L.BF16, LAY, st)),
     }
     for name, (passes, fn) in K.items():

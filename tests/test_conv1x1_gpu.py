@@ -377,3 +377,51 @@ def test_model_with_and_without_the_weight_bank_agree_bit_for_bit():
             assert torch.equal(a.bfloat16(), b_.bfloat16()), k_           # fp32 sum vs the same sum rounded to bf16
         else:
             assert torch.equal(a, b_), k_
+
+
+@pytest.mark.parametrize("ratio", [30.0, 1000.0])
+@pytest.mark.parametrize("shape", [(16, 28, 28, 128, 512), (16, 56, 56, 256, 64)], ids=["wide", "narrow"])
+def test_conv_bn_act_statistics_when_the_mean_dwarfs_sigma(shape, ratio):
+    """conv_bn_act on outputs with |mean| / sigma = 30 and ~10^3 per channel: the GEMM epilogue takes its moments about a
+    per-workgroup pivot (records merged in double), the BatchNorm backward its sums about the saved mean -- running
+    statistics, outputs and the BatchNorm's parameter gradients must hold to 1e-3 where raw one-pass fp32 sums lose
+    eps * ratio^2 (6 % of the variance at 10^3).  bf16 outputs resolve sigma / mean down to ~2^-9, so the 10^3 case is
+    asserted on the ratio the ROUNDED tensor really has (>= 250)."""
+    from mrla_amd import functional as Fm
+    b, h, w, k, n = shape
+    m = b * h * w
+    g = torch.Generator(device="cuda").manual_seed(int(ratio) + k)
+    # y[m, c] = mean_c * (1 + noise / ratio): x = 1 + small noise on every input channel, w[c, :] = mean_c / k
+    noise = torch.randn((b, h, w, k), device="cuda", generator=g) * (k ** 0.5) / ratio
+    x = (1.0 + noise).bfloat16()
+    means = (0.5 + torch.rand((n,), device="cuda", generator=g)) * (2 * (torch.rand((n,), device="cuda", generator=g) > 0.5).float() - 1)
+    wt = (means[:, None] / k).expand(n, k).contiguous().bfloat16()
+    conv = torch.nn.Conv2d(k, n, 1, bias=False).cuda().to(memory_format=torch.channels_last)
+    bn = torch.nn.BatchNorm2d(n).cuda()
+    with torch.no_grad():
+        conv.weight.copy_(wt.float().view(n, k, 1, 1))
+        bn.weight.uniform_(0.6, 1.4, generator=g)
+        bn.bias.uniform_(-0.3, 0.3, generator=g)
+    xt = x.permute(0, 3, 1, 2).requires_grad_(True)
+    assert xt.is_contiguous(memory_format=torch.channels_last) and Fm.conv1x1_applies(conv, xt)
+    out = Fm.conv_bn_act(xt, conv, bn, relu=False)
+    gup = torch.randn((b, n, h, w), device="cuda", generator=g).bfloat16().contiguous(memory_format=torch.channels_last)
+    out.backward(gup)
+    torch.cuda.synchronize()
+    # reference: float64 BatchNorm of the rounded GEMM output (the GEMM itself is pinned elsewhere)
+    y = (x.reshape(m, k).double() @ wt.double().t()).float().bfloat16().double()
+    mean, var = y.mean(0), y.var(0, unbiased=False)
+    real_ratio = (mean.abs() / var.sqrt()).median().item()
+    assert real_ratio >= min(ratio, 1000.0) / 4, real_ratio
+    assert ((bn.running_mean.double() - 0.1 * mean).abs() / (0.1 * mean.abs())).max().item() < 1e-5
+    assert ((bn.running_var.double() - (0.9 + 0.1 * var * m / (m - 1))).abs() / (0.1 * var)).max().item() < 1e-3
+    inv = 1.0 / torch.sqrt(var + bn.eps)
+    yhat = (y - mean) * inv
+    want = yhat * bn.weight.double() + bn.bias.double()
+    got = out.detach().permute(0, 2, 3, 1).reshape(m, n).double()
+    # the affine y -> sc*y + sh is evaluated in fp32 on y ~ ratio * sigma: eps * ratio of a unit-variance output, + bf16
+    assert ((got - want).abs() <= 2.0 ** -7 * want.abs() + 2e-7 * real_ratio + 1e-2 * 2.0 ** -7).all()
+    gu = gup.permute(0, 2, 3, 1).reshape(m, n).double()
+    dgamma, dbeta = (gu * yhat).sum(0), gu.sum(0)
+    assert ((bn.weight.grad.double() - dgamma).abs().max() / dgamma.abs().max()).item() < 1e-3
+    assert ((bn.bias.grad.double() - dbeta).abs().max() / dbeta.abs().max()).item() < 1e-5

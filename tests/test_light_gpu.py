@@ -300,9 +300,10 @@ def test_closed_form_bn_mrla_statistics_with_offset_inputs(cl, ratio):
     assert relmax(got["out"] - x, out - x) < tol          # the normalised branch (x itself is ~ratio)
     assert relmax(got["dx"], g["dx"]) < 3 * tol
     assert relmax(got["do"], g["do_prev"]) < 3 * tol
-    # parameter gradients: the backward statistics pass still takes sum dOut*V and sum dOut*o as raw fp32 sums
-    # (error ~ eps * ratio * sqrt(pixels) of a plane): tight at ratio 30, percent level at 1e3
-    ptol = 10 * tol if ratio <= 30 else 0.1
+    # parameter gradients: on the NHWC path the backward statistics pass takes sum dOut*V and sum dOut*o about the forward
+    # pivots (mrla_light_stats_bwd's `mom`), so they hold to 1e-3 at ratio 1e3 as well (raw fp32 sums: 10 % there);
+    # the NCHW kernels keep raw sums (error ~ eps * ratio * sqrt(pixels) of a plane, checked at ratio 30)
+    ptol = 1e-3 if cl else 10 * tol
     for ours, theirs in (("mrla.mrla.Wv.weight", "dwv"), ("mrla.lambda_t", "dlam"), ("bn_mrla.weight", "dgamma"),
                          ("bn_mrla.bias", "dbeta")):
         assert relmax(got["grad/" + ours].ravel(), np.asarray(g[theirs]).ravel()) < ptol, ours

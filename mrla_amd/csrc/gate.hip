@@ -161,23 +161,33 @@ __global__ __launch_bounds__(kThreads) void bn_bwd_kernel(
   }
   __syncthreads();
   if (!dlam) return;
-  double s3 = 0.0;
+  // dlambda[c] = sum over images and pixels of dm * o.  o sits at |mean| >> sigma in deep stages, dm sums to zero over
+  // the batch (train-mode BatchNorm), so the sum is taken about the planes' pivots: sum dm*(o - pO_b) from the shifted
+  // moments, plus (pO_b - P0) * (sum of dm over image b), plus P0 * (sum of dm over the batch) -- which is zero by
+  // construction of (f, G, H) in training mode and is left out there instead of being re-derived from cancelling terms.
+  double s3 = 0.0, st = 0.0;
   if (live) {
     const double e = coef[0][cc], f = coef[1][cc], Gc = coef[2][cc], Hc = coef[3][cc];
+    const double P0 = mom[(size_t)c * M_REC + M_PO];                 // image 0's pivot of o for this channel
     for (int b = bl; b < B; b += kBnLanes) {
       const float* m = mom + ((size_t)b * C + c) * M_REC;
       const float* bm = bmom + ((size_t)b * C + c) * D_N;
       const double a = gate[(size_t)b * G + c / d];
       const double dpb = dp ? dp[b] : 1.f;
-      const RawMoments r = raw_moments(m, (double)HW);
-      s3 += e * dpb * ((double)bm[D_DO] + (double)m[M_PO] * bm[D_D]) + f * a * r.svo + Gc * r.soo + Hc * r.so;
+      const double n = (double)HW, pv = m[M_PV], po = m[M_PO];
+      const double so = m[M_SO], sv = m[M_SV];                       // shifted: sum (o - po), sum (V - pv)
+      const double dm_o = e * dpb * bm[D_DO] + f * a * ((double)m[M_SVO] + pv * so) + Gc * ((double)m[M_SOO] + po * so) + Hc * so;
+      const double dm_1 = e * dpb * bm[D_D] + f * a * (sv + n * pv) + Gc * (so + n * po) + Hc * n;
+      s3 += dm_o + (po - P0) * dm_1;
+      st += dm_1;
     }
   }
-  r1[bl][cc] = s3;
+  r1[bl][cc] = s3; r2[bl][cc] = st;
   __syncthreads();
   if (bl == 0 && live) {
-    s3 = 0.0;
-    for (int i = 0; i < kBnLanes; ++i) s3 += r1[i][cc];
+    s3 = 0.0; st = 0.0;
+    for (int i = 0; i < kBnLanes; ++i) { s3 += r1[i][cc]; st += r2[i][cc]; }
+    if (!(gamma && training)) s3 += (double)mom[(size_t)c * M_REC + M_PO] * st;
     dlam[c] = (float)s3;
   }
 }

@@ -56,7 +56,11 @@ with torch.autocast("cuda", dtype=torch.bfloat16):
     y3, part3 = Fm._Conv1x1Fn.apply(z2, blk.conv3.weight.to(torch.bfloat16), True)
     keep_("y3", y3)
     pre = Fm.bn_act(y3, blk.bn3, False, defer=True, pre_moments=part3 if part3.numel() else None)
-    out = layers.light_block_tail(pre, xp, blk.mrla, blk.bn_mrla, blk.drop_path, pre_activation=True)
+    pre.register_hook(lambda gr: PG.__setitem__("pre", gr.detach()))
+    xid = xp * 1.0 if os.environ.get("PROBE_SPLIT_IDENT") else xp          # (a separate node: its gradient is `do` alone)
+    if xid is not xp:
+        xid.register_hook(lambda gr: PG.__setitem__("ident", gr.detach()))
+    out = layers.light_block_tail(pre, xid, blk.mrla, blk.bn_mrla, blk.drop_path, pre_activation=True)
 out.backward(gup)
 
 # ---- staged reference with retained grads ----
@@ -75,6 +79,7 @@ R["z2"] = rnd(torch.relu(z))
 R["y3"] = rnd(_RefConv.apply(R["z2"], wc(ref.conv3.weight), 0, *sd(blk.conv3)))
 pre_r, *_ = _bn(R["y3"], ref.bn3)
 pre_r = rnd(pre_r)
+R["pre"] = pre_r
 xt = rnd(torch.relu(pre_r + ident), "fwd")
 m = ref.mrla(xt, ident)
 z, *_ = _bn(m, ref.bn_mrla)
@@ -97,8 +102,16 @@ def cmp(name, got, want):
 for k in ("y1", "z1", "y2", "z2", "y3"):
     cmp(k, P[k], R[k].detach())
 cmp("out", out.detach(), out_r.detach())
-for k in ("y3", "z2", "y2", "z1", "y1"):
+for k in ("pre", "y3", "z2", "y2", "z1", "y1"):
     cmp("d" + k, PG[k], R[k].grad)
+# internal consistency of the product's bn3 backward: dy3 from ITS dpre and y3, in float64
+dz, y3p = PG["pre"].double(), P["y3"].double()
+mu, var = y3p.mean(dim=(0, 2, 3), keepdim=True), y3p.var(dim=(0, 2, 3), unbiased=False, keepdim=True)
+inv = 1.0 / torch.sqrt(var + blk.bn3.eps)
+yh = (y3p - mu) * inv
+gam = blk.bn3.weight.double()[None, :, None, None]
+chk = gam * inv * (dz - dz.mean(dim=(0, 2, 3), keepdim=True) - yh * (dz * yh).mean(dim=(0, 2, 3), keepdim=True))
+cmp("dy3|own", PG["y3"], chk)
 cmp("dx", xp.grad, xr.grad)
 pref = dict(ref.named_parameters())
 for name, p in blk.named_parameters():

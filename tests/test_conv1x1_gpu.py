@@ -341,87 +341,87 @@ def test_weight_bank_refresh_and_fp32_weight_gradient():
     assert relmax(d32.cpu().numpy(), want) < 1e-5
 
 
-def test_model_with_and_without_the_weight_bank_agree_bit_for_bit():
-    """resnet50_mrlal under bf16 autocast: the banked bf16 weights are the very values autocast's per-convolution casts
-    produce, so logits and every gradient must be identical with the bank switched off -- except the 1x1 convolutions'
-    weight gradients, which the bank path takes in fp32 from the reduction kernel instead of through a bf16 rounding."""
-    from mrla_amd import models, resnet
-    import contextlib, io
-    torch.manual_seed(0)
-    with contextlib.redirect_stdout(io.StringIO()):
-        net = models.resnet50_mrlal(drop_path=0.0).cuda().train()
-    with torch.no_grad():
-        for mod in net.modules():
-            if isinstance(mod, resnet._BottleneckTrunk):
-                mod.bn3.weight.fill_(0.5)
-    x = torch.randn(4, 3, 224, 224, device="cuda")
-    y = torch.tensor([1, 2, 3, 4], device="cuda")
+@pytest.mark.parametrize("shape", [(8, 56, 56, 256, 64), (8, 28, 28, 128, 512), (8, 14, 14, 1024, 256)],
+                         ids=lambda s: "x".join(map(str, s)))
+def test_conv_bn_act_with_and_without_the_weight_bank(shape):
+    """conv_bn_act under bf16 autocast with the banked working copies vs the per-call cast (what autocast does): the
+    banked bf16 weights are the very values the cast produces, so outputs, input gradients and BatchNorm gradients are
+    bit-identical; the weight gradient comes in fp32 from the reduction kernel and equals the bf16 path's after one
+    rounding.  (Whole models cannot be compared bit for bit: MIOpen's strided convolutions are not run-to-run
+    deterministic at small batches -- scripts/determinism_probe.py.)"""
+    from mrla_amd import functional as Fm
+    b, h, w, k, n = shape
+    torch.manual_seed(k + n)
+    conv = torch.nn.Conv2d(k, n, 1, bias=False).cuda().to(memory_format=torch.channels_last)
+    bn = torch.nn.BatchNorm2d(n).cuda()
+    x = torch.randn(b, k, h, w, device="cuda").bfloat16().contiguous(memory_format=torch.channels_last)
+    gup = torch.randn(b, n, h, w, device="cuda").bfloat16().contiguous(memory_format=torch.channels_last)
+    gsc = torch.randn(b, k, h, w, device="cuda").bfloat16().contiguous(memory_format=torch.channels_last)
     res = []
-    for use_bank in (True, False):
-        net.zero_grad(set_to_none=True)
-        for mod in net.modules():
-            if isinstance(mod, torch.nn.BatchNorm2d):
-                mod.reset_running_stats()
-        if not use_bank:
-            net.__dict__["_bank"] = type("NoBank", (), {"refresh": lambda self: None})()
-        with torch.autocast("cuda", dtype=torch.bfloat16):
-            logits = net(x)
-        torch.nn.functional.cross_entropy(logits.float(), y).backward()
+    for bank in (Fm.WeightBank([conv]), None):
+        conv.zero_grad(); bn.zero_grad(); bn.reset_running_stats()
+        xt = x.clone().requires_grad_(True)
+        with torch.autocast("cuda", dtype=torch.bfloat16), Fm.batched_bookkeeping(0, bank.refresh() if bank else None):
+            out, through = Fm.conv_bn_act(xt, conv, bn, relu=True, passthrough=True)
+        torch.autograd.backward([out, through], [gup, gsc])
         torch.cuda.synchronize()
-        res.append((logits.detach().clone(), {k_: p.grad.clone() for k_, p in net.named_parameters()}))
-    assert torch.equal(res[0][0], res[1][0])
-    banked = {id(c.weight) for c in resnet.F_.WeightBank([m_ for m_ in net.modules() if isinstance(m_, torch.nn.Conv2d)]).convs}
-    for k_, p in net.named_parameters():
-        a, b_ = res[0][1][k_], res[1][1][k_]
-        if id(p) in banked:
-            assert torch.equal(a.bfloat16(), b_.bfloat16()), k_           # fp32 sum vs the same sum rounded to bf16
-        else:
-            assert torch.equal(a, b_), k_
+        res.append((out.detach(), xt.grad, bn.weight.grad.clone(), bn.bias.grad.clone(), bn.running_var.clone(),
+                    conv.weight.grad.clone()))
+    assert res[0][5].dtype == torch.float32
+    for i in range(5):
+        assert torch.equal(res[0][i], res[1][i]), i
+    assert torch.equal(res[0][5].bfloat16(), res[1][5].bfloat16())
 
 
 @pytest.mark.parametrize("ratio", [30.0, 1000.0])
 @pytest.mark.parametrize("shape", [(16, 28, 28, 128, 512), (16, 56, 56, 256, 64)], ids=["wide", "narrow"])
-def test_conv_bn_act_statistics_when_the_mean_dwarfs_sigma(shape, ratio):
-    """conv_bn_act on outputs with |mean| / sigma = 30 and ~10^3 per channel: the GEMM epilogue takes its moments about a
-    per-workgroup pivot (records merged in double), the BatchNorm backward its sums about the saved mean -- running
-    statistics, outputs and the BatchNorm's parameter gradients must hold to 1e-3 where raw one-pass fp32 sums lose
-    eps * ratio^2 (6 % of the variance at 10^3).  bf16 outputs resolve sigma / mean down to ~2^-9, so the 10^3 case is
-    asserted on the ratio the ROUNDED tensor really has (>= 250)."""
+def test_conv_bn_statistics_when_the_mean_dwarfs_sigma(shape, ratio):
+    """The GEMM epilogue's BatchNorm moments and the BatchNorm backward on conv outputs with |mean| / sigma = 30 and
+    "10^3" per channel -- as far as bf16 resolves it: a bf16 tensor whose values spread over two or three neighbouring
+    grid points has |mean| / sigma of a few hundred at most (asserted >= 200 on the rounded tensor).  The epilogue takes its moments
+    about a per-workgroup pivot (records merged in double), the backward its sums about the saved mean: batch statistics to
+    1e-5 / 1e-4, outputs to the fp32 evaluation of the affine, parameter gradients to 1e-3 -- where raw one-pass fp32
+    sums lose eps * ratio^2 of the variance (6 % at 10^3)."""
     from mrla_amd import functional as Fm
     b, h, w, k, n = shape
     m = b * h * w
     g = torch.Generator(device="cuda").manual_seed(int(ratio) + k)
-    # y[m, c] = mean_c * (1 + noise / ratio): x = 1 + small noise on every input channel, w[c, :] = mean_c / k
-    noise = torch.randn((b, h, w, k), device="cuda", generator=g) * (k ** 0.5) / ratio
+    # y[m, c] = mean_c * (1 + noise / ratio) with |mean_c| ~ 64 .. 120: x = 1 + small noise, w[c, :] = mean_c / k
+    noise = torch.randn((b, h, w, k), device="cuda", generator=g) * (k ** 0.5) / min(ratio, 400.0)
     x = (1.0 + noise).bfloat16()
-    means = (0.5 + torch.rand((n,), device="cuda", generator=g)) * (2 * (torch.rand((n,), device="cuda", generator=g) > 0.5).float() - 1)
+    sign = 2 * (torch.rand((n,), device="cuda", generator=g) > 0.5).float() - 1
+    means = (64 + 56 * torch.rand((n,), device="cuda", generator=g)) * sign
     wt = (means[:, None] / k).expand(n, k).contiguous().bfloat16()
-    conv = torch.nn.Conv2d(k, n, 1, bias=False).cuda().to(memory_format=torch.channels_last)
     bn = torch.nn.BatchNorm2d(n).cuda()
     with torch.no_grad():
-        conv.weight.copy_(wt.float().view(n, k, 1, 1))
         bn.weight.uniform_(0.6, 1.4, generator=g)
         bn.bias.uniform_(-0.3, 0.3, generator=g)
-    xt = x.permute(0, 3, 1, 2).requires_grad_(True)
-    assert xt.is_contiguous(memory_format=torch.channels_last) and Fm.conv1x1_applies(conv, xt)
-    out = Fm.conv_bn_act(xt, conv, bn, relu=False)
+    xt = x.permute(0, 3, 1, 2)
+    assert xt.is_contiguous(memory_format=torch.channels_last)
+    yt, part = Fm._Conv1x1Fn.apply(xt, wt, True)                    # the GEMM itself is pinned elsewhere: take ITS output
+    yt = yt.detach().requires_grad_(True)
+    out = Fm.bn_act(yt, bn, relu=False, pre_moments=part)
     gup = torch.randn((b, n, h, w), device="cuda", generator=g).bfloat16().contiguous(memory_format=torch.channels_last)
     out.backward(gup)
     torch.cuda.synchronize()
-    # reference: float64 BatchNorm of the rounded GEMM output (the GEMM itself is pinned elsewhere)
-    y = (x.reshape(m, k).double() @ wt.double().t()).float().bfloat16().double()
+    y = yt.detach().permute(0, 2, 3, 1).reshape(m, n).double()
     mean, var = y.mean(0), y.var(0, unbiased=False)
     real_ratio = (mean.abs() / var.sqrt()).median().item()
-    assert real_ratio >= min(ratio, 1000.0) / 4, real_ratio
+    assert real_ratio >= min(ratio, 200.0) * 0.9, real_ratio
+    assert (var > 1e3 * bn.eps).all()                              # the variance matters next to eps
     assert ((bn.running_mean.double() - 0.1 * mean).abs() / (0.1 * mean.abs())).max().item() < 1e-5
-    assert ((bn.running_var.double() - (0.9 + 0.1 * var * m / (m - 1))).abs() / (0.1 * var)).max().item() < 1e-3
+    assert ((bn.running_var.double() - (0.9 + 0.1 * var * m / (m - 1))).abs() / (0.1 * var)).max().item() < 1e-4
     inv = 1.0 / torch.sqrt(var + bn.eps)
     yhat = (y - mean) * inv
     want = yhat * bn.weight.double() + bn.bias.double()
     got = out.detach().permute(0, 2, 3, 1).reshape(m, n).double()
     # the affine y -> sc*y + sh is evaluated in fp32 on y ~ ratio * sigma: eps * ratio of a unit-variance output, + bf16
-    assert ((got - want).abs() <= 2.0 ** -7 * want.abs() + 2e-7 * real_ratio + 1e-2 * 2.0 ** -7).all()
+    assert ((got - want).abs() <= 2.0 ** -7 * want.abs() + 4e-7 * real_ratio + 1e-2 * 2.0 ** -7).all()
     gu = gup.permute(0, 2, 3, 1).reshape(m, n).double()
     dgamma, dbeta = (gu * yhat).sum(0), gu.sum(0)
     assert ((bn.weight.grad.double() - dgamma).abs().max() / dgamma.abs().max()).item() < 1e-3
     assert ((bn.bias.grad.double() - dbeta).abs().max() / dbeta.abs().max()).item() < 1e-5
+    # the gradient wrt the conv output: gamma/sigma * (g - mean(g) - yhat * mean(g * yhat)), stored in bf16
+    dy = (bn.weight.double() * inv) * (gu - dbeta / m - yhat * dgamma / m)
+    dgot = yt.grad.permute(0, 2, 3, 1).reshape(m, n).double()
+    assert ((dgot - dy).abs() <= 2.0 ** -7 * dy.abs() + 1e-3 * dy.abs().max()).all()

@@ -101,28 +101,34 @@ __global__ __launch_bounds__(kThreads) void base_gate_fwd_kernel(
   }
   __syncthreads();
   const float s = rsqrtf((float)d);
-  // logits: one (head, slot) pair per thread (G*t pairs: the whole workgroup loads the key history), written to the P row
+  // logits: one (head, slot) pair per thread (G*t pairs: the whole workgroup loads the key history) into LDS
+  float* lg = kts + C;            // [G][t]
   for (int idx = tid; idx < G * t; idx += kThreads) {
     const int g = idx / t, j = idx - g * t;
     const float* kj = (j == t - 1) ? kts + g * d : Kb + (size_t)j * C + g * d;
     float acc = 0.f;
     for (int i = 0; i < d; ++i) acc = fmaf(qs[g * d + i], kj[i], acc);
-    Pall[(((size_t)b * G + g) * T + (t - 1)) * T + j] = acc * s;
+    lg[idx] = acc * s;
   }
   __syncthreads();
-  // one thread per head: stable softmax over the slots (t <= a few dozen)
-  for (int g = tid; g < G; g += kThreads) {
+  // softmax over the depth, one head per wave at a time with the slots on the lanes (wave reductions; the row of P is
+  // written once, coalesced).  A serial per-thread loop over a row in global memory cost ~70 dependent round trips.
+  const int lane = tid & (kWave - 1), wave = tid / kWave;
+  for (int g = wave; g < G; g += kWaves) {
     float* Prow = Pall + (((size_t)b * G + g) * T + (t - 1)) * T;
     float mx = -INFINITY;
-    for (int j = 0; j < t; ++j) mx = fmaxf(mx, Prow[j]);
+    for (int j = lane; j < t; j += kWave) mx = fmaxf(mx, lg[g * t + j]);
+#pragma unroll
+    for (int off = kWave / 2; off > 0; off >>= 1) mx = fmaxf(mx, __shfl_xor(mx, off, kWave));
     float den = 0.f;
-    for (int j = 0; j < t; ++j) {
-      const float e = expf(Prow[j] - mx);
-      Prow[j] = e;
+    for (int j = lane; j < t; j += kWave) {
+      const float e = expf(lg[g * t + j] - mx);
+      lg[g * t + j] = e;
       den += e;
     }
+    den = wave_sum(den);
     const float r = 1.0f / den;
-    for (int j = 0; j < t; ++j) Prow[j] *= r;
+    for (int j = lane; j < t; j += kWave) Prow[j] = lg[g * t + j] * r;
   }
 }
 
@@ -563,11 +569,15 @@ __global__ __launch_bounds__(kThreads) void base_gate_bwd_kernel(
     dlg[idx] = dP;
   }
   __syncthreads();
-  for (int g = tid; g < G; g += kThreads) {
-    const float* Prow = Pall + (((size_t)b * G + g) * T + (t - 1)) * T;
-    float dot = 0.f;
-    for (int j = 0; j < t; ++j) dot = fmaf(Prow[j], dlg[g * t + j], dot);
-    for (int j = 0; j < t; ++j) dlg[g * t + j] = Prow[j] * (dlg[g * t + j] - dot) * s;
+  {   // softmax backward, one head per wave at a time with the slots on the lanes (see base_gate_fwd_kernel)
+    const int lane = tid & (kWave - 1), wave = tid / kWave;
+    for (int g = wave; g < G; g += kWaves) {
+      const float* Prow = Pall + (((size_t)b * G + g) * T + (t - 1)) * T;
+      float dot = 0.f;
+      for (int j = lane; j < t; j += kWave) dot = fmaf(Prow[j], dlg[g * t + j], dot);
+      dot = wave_sum(dot);
+      for (int j = lane; j < t; j += kWave) dlg[g * t + j] = Prow[j] * (dlg[g * t + j] - dot) * s;
+    }
   }
   __syncthreads();
   const float* Kb = Kring + (size_t)b * T * C;
@@ -761,7 +771,7 @@ static hipError_t set_lds2(K kernel, size_t bytes) {
 
 int launch_base_gate_fwd(const float* mom, const float* wq, const float* wk, int ks, float* Kring, float* Pall,
                          float* q, int B, int C, int HW, int d, int T, int t, hipStream_t st) {
-  const size_t lds = (size_t)(3 * C + 2 * ((ks - 1) / 2)) * sizeof(float);
+  const size_t lds = (size_t)(3 * C + 2 * ((ks - 1) / 2) + (C / d) * t) * sizeof(float);
   if (lds > 64 * 1024) return MRLA_EUNSUPPORTED;
   hipLaunchKernelGGL(base_gate_fwd_kernel, dim3(B), dim3(kThreads), lds, st, mom, wq, wk, ks, Kring, Pall, q, C, HW, d,
                      T, t);

@@ -368,8 +368,15 @@ def test_conv_bn_act_with_and_without_the_weight_bank(shape):
         res.append((out.detach(), xt.grad, bn.weight.grad.clone(), bn.bias.grad.clone(), bn.running_var.clone(),
                     conv.weight.grad.clone()))
     assert res[0][5].dtype == torch.float32
+    from mrla_amd import _lib as L
+    own_fwd = L.load().mrla_conv1x1_rows(b * h * w, k, n, L.BF16) > 0
+    own_dgrad = L.load().mrla_conv1x1_rows(b * h * w, n, k, L.BF16) > 0
     for i in range(5):
-        assert torch.equal(res[0][i], res[1][i]), i
+        if (own_fwd and own_dgrad) or (own_fwd and i != 1):
+            assert torch.equal(res[0][i], res[1][i]), i
+        else:       # a stock (MIOpen) direction in between: the same operator on the same values, not run-to-run bit-stable
+            a, r = res[0][i].float(), res[1][i].float()
+            assert ((a - r).abs() <= 2.0 ** -6 * r.abs() + 1e-2 * r.abs().max()).all(), i
     assert torch.equal(res[0][5].bfloat16(), res[1][5].bfloat16())
 
 

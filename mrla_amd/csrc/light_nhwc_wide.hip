@@ -719,8 +719,11 @@ __global__ __launch_bounds__(kBwdWaves * kWave) void light_apply_bwd_wide(
             yrow[j] = y;
             dsum[j] = DP[j] + y;
             if (PRE) {             // (columns past the image have x = 0, hence y = 0: nothing to mask)
-              pm[0] += y;
-              pm[1] = fmaf(y, pv.v[j] - pcen, pm[1]);
+              // the sums are of dpre AS STORED (rounded to T): where the MRLA branch's contribution is below half an ulp
+              // of dOut it is lost in the stored tensor, systematically -- the BatchNorm backward must see the same values
+              const float yq = to_f(from_f<T>(y));
+              pm[0] += yq;
+              pm[1] = fmaf(yq, pv.v[j] - pcen, pm[1]);
             }
           }
           row_store<T, kS>(as, dxo, rr - 1, rowelems, lane, bufS1, yrow);

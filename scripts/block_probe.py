@@ -112,6 +112,20 @@ yh = (y3p - mu) * inv
 gam = blk.bn3.weight.double()[None, :, None, None]
 chk = gam * inv * (dz - dz.mean(dim=(0, 2, 3), keepdim=True) - yh * (dz * yh).mean(dim=(0, 2, 3), keepdim=True))
 cmp("dy3|own", PG["y3"], chk)
+# which constants did the product's bn3 backward apply?  per channel: dy3 - e*dz = f*y3 + h, least squares over the pixels
+e_x = gam * inv
+res = (PG["y3"].double() - e_x * dz)
+xm, rm_ = y3p.mean(dim=(0, 2, 3), keepdim=True), res.mean(dim=(0, 2, 3), keepdim=True)
+f_eff = ((y3p - xm) * (res - rm_)).sum(dim=(0, 2, 3)) / ((y3p - xm) ** 2).sum(dim=(0, 2, 3))
+h_eff = rm_.flatten() - f_eff * xm.flatten()
+c1 = dz.mean(dim=(0, 2, 3))
+c2 = (dz * yh).mean(dim=(0, 2, 3))
+f_x = (-gam * inv * inv).flatten() * c2
+h_x = (gam * inv).flatten() * (-c1 + (inv * mu).flatten() * c2)
+print("bn3 backward constants applied vs float64 of the same inputs (worst channel, relative to the largest):",
+      f"f {((f_eff - f_x).abs().max() / f_x.abs().max()).item():.2e}  h {((h_eff - h_x).abs().max() / h_x.abs().max()).item():.2e}",
+      f"  |f|max {f_x.abs().max().item():.2e} |h|max {h_x.abs().max().item():.2e} e~{e_x.mean().item():.2f}")
+sums = Fm  # noqa
 cmp("dx", xp.grad, xr.grad)
 pref = dict(ref.named_parameters())
 for name, p in blk.named_parameters():

@@ -112,6 +112,21 @@ yh = (y3p - mu) * inv
 gam = blk.bn3.weight.double()[None, :, None, None]
 chk = gam * inv * (dz - dz.mean(dim=(0, 2, 3), keepdim=True) - yh * (dz * yh).mean(dim=(0, 2, 3), keepdim=True))
 cmp("dy3|own", PG["y3"], chk)
+# the same consistency check for bn2 / bn1 (with their ReLU): float64 BatchNorm backward of the PRODUCT's own inputs
+for bnm, yk, zk in ((blk.bn2, "y2", "z2"), (blk.bn1, "y1", "z1")):
+    yv, gz = P[yk].double(), PG[zk].double()
+    mu_, var_ = yv.mean(dim=(0, 2, 3), keepdim=True), yv.var(dim=(0, 2, 3), unbiased=False, keepdim=True)
+    inv_ = 1.0 / torch.sqrt(var_ + bnm.eps)
+    yh_ = (yv - mu_) * inv_
+    g_, b_ = bnm.weight.double()[None, :, None, None], bnm.bias.double()[None, :, None, None]
+    dzz = gz * ((yh_ * g_ + b_) > 0)
+    chk_ = g_ * inv_ * (dzz - dzz.mean(dim=(0, 2, 3), keepdim=True) - yh_ * (dzz * yh_).mean(dim=(0, 2, 3), keepdim=True))
+    cmp(f"d{yk}|own", PG[yk], chk_)
+    same_in = (PG[zk].float() == R[zk].grad.float().bfloat16().float())
+    same_out = (PG[yk].float() == R[yk].grad.float().bfloat16().float())
+    print(f"   d{zk} equal to the reference's on {same_in.float().mean().item():.4f}; where it is, d{yk} equal on "
+          f"{same_out[same_in].float().mean().item():.4f}; channels with any differing d{zk}: "
+          f"{(~same_in).any(dim=0).any(dim=1).any(dim=1).float().mean().item():.3f}")
 # which constants did the product's bn3 backward apply?  per channel: dy3 - e*dz = f*y3 + h, least squares over the pixels
 e_x = gam * inv
 res = (PG["y3"].double() - e_x * dz)

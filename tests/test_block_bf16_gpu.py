@@ -173,19 +173,28 @@ def test_bf16_bottleneck_against_the_staged_float64_reference(shape, monkeypatch
     assert out.dtype == torch.bfloat16
     out.backward(gup)
     torch.cuda.synchronize()
-    running = {k: v.clone() for k, v in blk.state_dict().items() if "running" in k}
-    pgrads = {k: p.grad.clone() for k, p in blk.named_parameters()}
+    out_mod, dx_mod = out.detach().clone(), xp.grad.clone()
 
-    # the same two statements spelled out (bit-identical forward), for the ReLU decisions of the product's forward
+    # the same two statements spelled out, for the ReLU decisions of the product's forward: THIS run is the one compared
+    # with the reference below (the module call above pins the wiring: bit-identical where every direction runs on our
+    # kernels; with a stock 1x1 convolution in the chain -- stage 3: MIOpen, not run-to-run bit-stable -- to rounding)
     for mod in blk.modules():
         if isinstance(mod, torch.nn.BatchNorm2d):
             mod.reset_running_stats()
-    xq = x.clone().requires_grad_(True)
+    blk.zero_grad()
+    xp = x.clone().requires_grad_(True)
     with torch.autocast("cuda", dtype=torch.bfloat16):
-        out_q, seen = product_piecewise(blk, xq)
-    out_q.backward(gup)
+        out, seen = product_piecewise(blk, xp)
+    out.backward(gup)
     torch.cuda.synchronize()
-    assert torch.equal(out_q, out)
+    running = {k: v.clone() for k, v in blk.state_dict().items() if "running" in k}
+    pgrads = {k: p.grad.clone() for k, p in blk.named_parameters()}
+    m_ = b * hw * hw
+    if not any(_stock_directions(cv, m_)[0] for cv in (blk.conv1, blk.conv3)):
+        assert torch.equal(out_mod, out)
+    else:
+        assert (_ulps(out_mod, out.double()) > 2.0).float().mean().item() < 1e-3
+    assert (_ulps(dx_mod, xp.grad.double()) > 2.0).float().mean().item() < (1e-4 if planes == 64 else 5e-2)
     masks = dict(z1=(seen["z1"] > 0).double(), z2=(seen["z2"] > 0).double(), xt=(seen["dpre"] != 0).double())
 
     wc = lambda w: w.float().bfloat16().double()  # noqa: E731

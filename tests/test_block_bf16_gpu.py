@@ -190,7 +190,8 @@ def test_bf16_bottleneck_against_the_staged_float64_reference(shape, monkeypatch
     running = {k: v.clone() for k, v in blk.state_dict().items() if "running" in k}
     pgrads = {k: p.grad.clone() for k, p in blk.named_parameters()}
     m_ = b * hw * hw
-    if not any(_stock_directions(cv, m_)[0] for cv in (blk.conv1, blk.conv3)):
+    stock_free = not any(any(_stock_directions(cv, m_)) for cv in (blk.conv1, blk.conv3))
+    if stock_free:
         assert torch.equal(out_mod, out)
     else:
         assert (_ulps(out_mod, out.double()) > 2.0).float().mean().item() < 1e-3
@@ -213,8 +214,10 @@ def test_bf16_bottleneck_against_the_staged_float64_reference(shape, monkeypatch
         report.append((name, (u > 1.0).float().mean().item(), (u > 2.0).float().mean().item(), u.max().item(), l2))
         print(f"{name}: beyond 1 ulp {report[-1][1]:.2e}, beyond 2 ulps {report[-1][2]:.2e}, worst {report[-1][3]:.1f} ulps, "
               f"relative L2 {l2:.2e}")
+    # (with MIOpen's not bit-stable 1x1 kernels in the chain -- stage 3 -- the same comparison measures 0.8e-4 .. 1e-4)
+    bound = 1e-4 if stock_free else 3e-4
     for name, f1, f2, worst, l2 in report:
-        assert f2 <= 1e-4, f"{name}: {f2:.2e} of the elements beyond 2 bf16 ulps (worst {worst:.1f})"
+        assert f2 <= bound, f"{name}: {f2:.2e} of the elements beyond 2 bf16 ulps (worst {worst:.1f})"
         assert l2 < 2.0 ** -7, f"{name}: relative L2 error {l2:.3e}"
     pref = dict(ref.named_parameters())
     errs = {name: ((pgrads[name].double() - pref[name].grad).norm() / pref[name].grad.norm()).item() for name in pgrads}

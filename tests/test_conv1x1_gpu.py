@@ -377,7 +377,11 @@ def test_conv_bn_act_with_and_without_the_weight_bank(shape):
         else:       # a stock (MIOpen) direction in between: the same operator on the same values, not run-to-run bit-stable
             a, r = res[0][i].float(), res[1][i].float()
             assert ((a - r).abs() <= 2.0 ** -6 * r.abs() + 1e-2 * r.abs().max()).all(), i
-    assert torch.equal(res[0][5].bfloat16(), res[1][5].bfloat16())
+    if own_fwd:
+        assert torch.equal(res[0][5].bfloat16(), res[1][5].bfloat16())
+    else:           # (the stock forward's output, hence the BatchNorm backward feeding dY, is not bit-stable between the runs)
+        a, r = res[0][5].float(), res[1][5].float()
+        assert ((a - r).norm() / r.norm()).item() < 2.0 ** -7
 
 
 @pytest.mark.parametrize("ratio", [30.0, 1000.0])

@@ -1,0 +1,278 @@
+// 1x1 stride-1 convolution with a WIDE REDUCTION (K = 512 .. 2048 input channels) as a K-streaming MFMA GEMM:
+//   Y[M, N] = X[M, K] * W[N, K]^T        bf16 in / out, fp32 accumulate;  M = b*h*w pixels, K % 32 == 0, N % 128 == 0
+// Reference: conv1 of the bottlenecks of stages 2-4 (resnet/models/resnet_mrla_light.py:93: 512 / 1024 / 2048 -> width),
+// conv3 of stage 4 (:100: 512 -> 2048) and, with the operands swapped by the caller (x = dY, w = W^T), the input
+// gradients of conv3 everywhere but stage 1 and of conv1 in stage 4.
+//
+// conv1x1.hip / conv1x1_wide.hip keep the whole [N or 256][K] weight slice of a workgroup in LDS / registers, which
+// stops at K = 256.  Here neither operand is resident: a workgroup (8 waves) owns an output tile of TM pixels x TN
+// channels and walks K in chunks of 32:
+//   * chunk = X[TM][32] and W[TN][32] (64-byte rows), both global -> LDS by LDS-DMA (16 B per lane, 16 rows per
+//     wave-instruction), three stages; the weight chunk comes out of L2 (every workgroup reads the same W), X is read
+//     once per TN output channels -- the channel groups of one pixel tile are neighbours in time on one XCD;
+//   * a wave owns 64 channels x (32 or 64) pixels of the tile: MFMA 32x32x16 with A = W rows, B = X rows, both operand
+//     fragments one ds_read_b128 per k-step (16-byte slot s of row r sits at slot s ^ ((r >> 2) & 3): conflict-free for
+//     the 16-lane groups of ds_read_b128);
+//   * 72 KB of LDS and <= 128 VGPRs: two workgroups per CU, so that one's DMA round trips and barriers are covered by
+//     the other's MFMAs (a K = 512 tile is only 16 chunks long: a lone workgroup would spend a third of its life
+//     filling and draining its pipeline);
+//   * LDS reads are inline asm with explicit lgkmcnt fences, the barrier is a bare s_barrier and the DMA waits are
+//     constant-count vmcnt (see conv1x1_wgrad.hip: the compiler would drain all DMA stages at every LDS access);
+//   * the fp32 tile is rounded once, transposed to pixel-major 16-byte pieces with v_permlane32_swap (as
+//     conv1x1_wide.hip) through the (then idle) stage memory and leaves as whole rows.
+// These products need 0.5 - 2 PFLOP/s to run at the HBM rate (N*K/(N+K) = 100 - 400 flop per byte), so unlike their
+// K <= 256 siblings they are bound by the matrix pipe as much as by memory; MIOpen's kernels reach 25 - 30 % of it.
+#include <algorithm>
+
+#include "mrla_device.h"
+#include "mrla_kernels.h"
+
+namespace mrla {
+namespace {
+
+typedef __bf16 ks_bf16x8 __attribute__((ext_vector_type(8)));
+typedef float ks_f32x16 __attribute__((ext_vector_type(16)));
+
+#define MRLA_KS_FLAGS 0x00020000          /* raw buffer descriptor word 3 (as nhwc_rows.h) */
+constexpr int kKsWaves = 8;
+constexpr int kKsKC = 32;                 // reduction elements per chunk (64-byte rows)
+constexpr int kKsStages = 3;
+constexpr int kKsNI = 3;                  // DMA wave-instructions per wave and chunk (24 x 16 rows = 384 rows)
+
+template <int WN, int PB>
+struct KsGeo {
+  static constexpr int WM = kKsWaves / WN;              // waves along the pixels
+  static constexpr int TM = WM * PB * 32, TN = WN * 64; // output tile
+  static constexpr int ROWS = TM + TN;                  // 64-byte rows per stage (<= 384)
+  static constexpr int SB = 384 * 64;                   // stage bytes (the DMA plan always covers 384 rows; the rest is dummy)
+  static constexpr int kLds = kKsStages * SB;           // 72 KB
+  static constexpr int CPR = TN / 8;                    // 16-byte chunks per output-tile row
+  static_assert(ROWS <= 384 && TM * TN * 2 <= kLds - 8192, "stage memory doubles as the output tile");
+};
+
+__device__ __forceinline__ unsigned ks_lds_addr(const void* p) {
+  return (unsigned)(size_t)((__attribute__((address_space(3))) const char*)p);
+}
+__device__ __forceinline__ void ks_read16(u32x4& v, unsigned addr) {
+  asm volatile("ds_read_b128 %0, %1" : "=v"(v) : "v"(addr));
+}
+__device__ __forceinline__ void ks_write16(unsigned addr, const u32x4& v) {
+  asm volatile("ds_write_b128 %0, %1" ::"v"(addr), "v"(v) : "memory");
+}
+template <int N>
+__device__ __forceinline__ void ks_fence(u32x4& v, bool wait) {
+  if (wait) asm volatile("s_waitcnt lgkmcnt(%1)" : "+v"(v) : "n"(N) : "memory");
+  else asm volatile("" : "+v"(v)::"memory");
+}
+__device__ __forceinline__ int ks_swz(int row) { return (row >> 2) & 3; }      // slot swizzle of a 64-byte row
+__device__ __forceinline__ int ks_oswz(int row) { return row & 7; }            // chunk swizzle of an output-tile row
+
+template <int WN, int PB>
+__global__ __launch_bounds__(kKsWaves* kWave, 4) void conv1x1_kstream_kernel(const bf16_t* __restrict__ X,
+                                                                             const bf16_t* __restrict__ W,
+                                                                             bf16_t* __restrict__ Y, int M, int N, int K,
+                                                                             int tiles_m, int groups_n) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  typedef KsGeo<WN, PB> G;
+  extern __shared__ __align__(16) unsigned char smem_raw[];
+  const int lane = threadIdx.x & (kWave - 1);
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x / kWave);
+  const int r = lane & 31, h = lane >> 5;
+  // XCD-aware order: the channel groups of one pixel tile are neighbours in time on one XCD (they share the X chunks)
+  const int per = gridDim.x >> 3;
+  const int vid = (blockIdx.x & 7) * per + (blockIdx.x >> 3);
+  if (vid >= tiles_m * groups_n) return;
+  const int tile = vid / groups_n, cg = vid - tile * groups_n;
+  const int m0 = tile * G::TM, n0 = cg * G::TN;
+  const int wn = wave % WN, wm = wave / WN;
+  const int nchunks = K / kKsKC;
+
+  // ---- DMA plan: instruction u = wave + 8*i covers stage rows 16u .. 16u+15 (4 lanes per 64-byte row);
+  //      rows [0, TM) are X pixels, [TM, TM+TN) W channels, the rest does not exist (out-of-bounds offset: no traffic) ----
+  const auto rsX = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(X), 0, (int)((size_t)M * K * 2), MRLA_KS_FLAGS);
+  const auto rsW = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(W), 0, (int)((size_t)N * K * 2), MRLA_KS_FLAGS);
+  unsigned voff[kKsNI];
+  bool isw[kKsNI];
+#pragma unroll
+  for (int i = 0; i < kKsNI; ++i) {
+    const int u = wave + kKsWaves * i, row = u * 16 + (lane >> 2), slot = (lane & 3) ^ ks_swz(row);
+    isw[i] = row >= G::TM;                                     // wave-uniform (TM is a multiple of 16)
+    if (row < G::TM) voff[i] = (unsigned)(((size_t)(m0 + row) * K) * 2 + slot * 16);      // (pixels past M: beyond num_records)
+    else if (row < G::ROWS) voff[i] = (unsigned)(((size_t)(n0 + row - G::TM) * K) * 2 + slot * 16);
+    else voff[i] = 0x80000000u;
+  }
+  int issued = 0;
+  auto issue = [&](int stage) {
+    const unsigned kill = issued++ < nchunks ? 0u : 0x80000000u;   // past the reduction: out of bounds, no memory traffic
+#pragma unroll
+    for (int i = 0; i < kKsNI; ++i) {
+      unsigned char* dst = smem_raw + stage * G::SB + (wave + kKsWaves * i) * 1024;
+      if (isw[i]) __builtin_amdgcn_raw_ptr_buffer_load_lds(rsW, (lds_void_ptr)dst, 16, voff[i] | kill, 0, 0, 0);
+      else        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsX, (lds_void_ptr)dst, 16, voff[i] | kill, 0, 0, 0);
+      voff[i] += kKsKC * 2;
+    }
+  };
+
+  // ---- operand addresses: A = W rows of this wave's two 32-channel blocks, B = X rows of its PB pixel blocks ----
+  const unsigned lds0 = ks_lds_addr(smem_raw);
+  unsigned offA[2], offB[PB];
+  int fA[2], fB[PB];
+#pragma unroll
+  for (int c = 0; c < 2; ++c) {
+    const int row = G::TM + wn * 64 + c * 32 + r;
+    offA[c] = lds0 + row * 64;
+    fA[c] = ks_swz(row);
+  }
+#pragma unroll
+  for (int p = 0; p < PB; ++p) {
+    const int row = (wm * PB + p) * 32 + r;
+    offB[p] = lds0 + row * 64;
+    fB[p] = ks_swz(row);
+  }
+
+  ks_f32x16 acc[PB][2];
+#pragma unroll
+  for (int p = 0; p < PB; ++p)
+#pragma unroll
+    for (int c = 0; c < 2; ++c)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[p][c][e] = 0.f;
+
+  // ---- pipeline: chunks c+1 (in flight) and c+2 (issued after the barrier of chunk c) ahead of chunk c ----
+#pragma unroll
+  for (int j = 0; j < kKsStages - 1; ++j) issue(j);
+  int stage = 0, nxt = kKsStages - 1;
+  for (int c = 0; c < nchunks; ++c) {
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(kKsNI) : "memory");       // my part of chunk c has landed (c+1 may be in flight)
+    __builtin_amdgcn_s_barrier();                                     // everybody's has; everybody is done reading chunk c-1
+    asm volatile("" ::: "memory");
+    issue(nxt);
+    nxt = nxt + 1 == kKsStages ? 0 : nxt + 1;
+    const unsigned sbo = stage * G::SB;
+    stage = stage + 1 == kKsStages ? 0 : stage + 1;
+    u32x4 a[2][2], b[2][PB];                                          // [k-step][block]
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+#pragma unroll
+      for (int cb = 0; cb < 2; ++cb) ks_read16(a[ks][cb], offA[cb] + sbo + (((2 * ks + h) ^ fA[cb]) << 4));
+#pragma unroll
+      for (int p = 0; p < PB; ++p) ks_read16(b[ks][p], offB[p] + sbo + (((2 * ks + h) ^ fB[p]) << 4));
+    }
+    // k-step 0 is complete when at most the (2 + PB) reads of k-step 1 are outstanding
+    ks_fence<2 + PB>(a[0][0], true);
+    ks_fence<2 + PB>(a[0][1], false);
+#pragma unroll
+    for (int p = 0; p < PB; ++p) ks_fence<2 + PB>(b[0][p], false);
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int p = 0; p < PB; ++p)
+#pragma unroll
+      for (int cb = 0; cb < 2; ++cb)
+        acc[p][cb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(ks_bf16x8, a[0][cb]),
+                                                             __builtin_bit_cast(ks_bf16x8, b[0][p]), acc[p][cb], 0, 0, 0);
+    ks_fence<0>(a[1][0], true);
+    ks_fence<0>(a[1][1], false);
+#pragma unroll
+    for (int p = 0; p < PB; ++p) ks_fence<0>(b[1][p], false);
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int p = 0; p < PB; ++p)
+#pragma unroll
+      for (int cb = 0; cb < 2; ++cb)
+        acc[p][cb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(ks_bf16x8, a[1][cb]),
+                                                             __builtin_bit_cast(ks_bf16x8, b[1][p]), acc[p][cb], 0, 0, 0);
+  }
+  // the two dummy chunks issued past the end carry no data, but their LDS writes must be over before the tile is staged
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  asm volatile("" ::: "memory");
+
+  // ---- epilogue: round once, 16-byte pieces of each pixel's row, staged in LDS, whole rows out ----
+  // acc[p][cb]: lane = pixel r of block p; register e = channel 8*(e/4) + 4*h + e%4 of the 32-channel block cb
+#pragma unroll
+  for (int p = 0; p < PB; ++p) {
+    const int trow = (wm * PB + p) * 32 + r;
+    const unsigned orow = lds0 + trow * (G::TN * 2);
+#pragma unroll
+    for (int cb = 0; cb < 2; ++cb) {
+      unsigned q[8];
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        typedef bf16_t bf16x2 __attribute__((ext_vector_type(2)));
+        bf16x2 pr;
+        pr[0] = from_f<bf16_t>(acc[p][cb][2 * i]);
+        pr[1] = from_f<bf16_t>(acc[p][cb][2 * i + 1]);
+        q[i] = __builtin_bit_cast(unsigned, pr);
+      }
+      // half 0 holds channels {0-3, 8-11, 16-19, 24-27}, half 1 the other four groups; after the swaps half 0 holds
+      // {0-7, 16-23} and half 1 {8-15, 24-31}: two 16-byte pieces per lane
+#pragma unroll
+      for (int g = 0; g < 2; ++g)
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+          const auto sw = __builtin_amdgcn_permlane32_swap(q[4 * g + t], q[4 * g + 2 + t], false, false);
+          q[4 * g + t] = sw[0];
+          q[4 * g + 2 + t] = sw[1];
+        }
+      const int ch0 = wn * 8 + cb * 4 + h;                     // 16-byte chunk index of channels 32*cb + 8*h .. (+7)
+      ks_write16(orow + (((ch0) ^ ks_oswz(trow)) << 4), (u32x4){q[0], q[1], q[2], q[3]});
+      ks_write16(orow + (((ch0 + 2) ^ ks_oswz(trow)) << 4), (u32x4){q[4], q[5], q[6], q[7]});
+    }
+  }
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  asm volatile("" ::: "memory");
+  {
+    constexpr int CPR = G::CPR, RPI = (kKsWaves * kWave) / CPR;     // rows per pass of the 512 threads
+    const int srow = threadIdx.x / CPR, chunk = threadIdx.x % CPR;
+#pragma unroll
+    for (int i = 0; i < G::TM / RPI; ++i) {
+      const int row = srow + RPI * i;
+      u32x4 v;
+      ks_read16(v, lds0 + row * (G::TN * 2) + ((chunk ^ ks_oswz(row)) << 4));
+      ks_fence<0>(v, true);
+      if (m0 + row < M) *reinterpret_cast<u32x4*>(Y + (size_t)(m0 + row) * N + n0 + chunk * 8) = v;
+    }
+  }
+#endif
+}
+
+struct KsPlan {
+  int wn = 0, pb = 0, tiles_m = 0, groups_n = 0;
+};
+
+KsPlan ks_plan(int M, int K, int N) {
+  KsPlan p;
+  if (M <= 0 || K < 512 || K % kKsKC || N % 128 || (size_t)M * std::max(N, K) * 2 >= (size_t)1 << 31) return p;
+  p.wn = N % 256 == 0 ? 4 : 2;
+  const int tn = p.wn * 64, wm = kKsWaves / p.wn;
+  p.groups_n = N / tn;
+  // the larger pixel tile (less weight traffic out of L2 per X byte) when it still gives every CU a workgroup
+  const int tm2 = wm * 64;
+  p.pb = ((M + tm2 - 1) / tm2) * p.groups_n >= 300 ? 2 : 1;
+  const int tm = wm * p.pb * 32;
+  p.tiles_m = (M + tm - 1) / tm;
+  return p;
+}
+
+template <int WN, int PB>
+int ks_launch(const KsPlan& p, const void* x, const void* w, void* y, int M, int K, int N, hipStream_t st) {
+  typedef KsGeo<WN, PB> G;
+  if (lds_opt_in(reinterpret_cast<const void*>(conv1x1_kstream_kernel<WN, PB>), G::kLds) != hipSuccess) return MRLA_EHIP;
+  hipLaunchKernelGGL((conv1x1_kstream_kernel<WN, PB>), dim3((p.tiles_m * p.groups_n + 7) / 8 * 8), dim3(kKsWaves * kWave),
+                     G::kLds, st, (const bf16_t*)x, (const bf16_t*)w, (bf16_t*)y, M, N, K, p.tiles_m, p.groups_n);
+  return hip_status(hipGetLastError());
+}
+
+}  // namespace
+
+int conv1x1_kstream_supported(int M, int K, int N) { return ks_plan(M, K, N).wn ? 1 : 0; }
+
+int launch_conv1x1_kstream(const void* x, const void* w, void* y, int M, int K, int N, hipStream_t st) {
+  const KsPlan p = ks_plan(M, K, N);
+  if (!p.wn) return MRLA_EUNSUPPORTED;
+  if (p.wn == 4) return p.pb == 2 ? ks_launch<4, 2>(p, x, w, y, M, K, N, st) : ks_launch<4, 1>(p, x, w, y, M, K, N, st);
+  return p.pb == 2 ? ks_launch<2, 2>(p, x, w, y, M, K, N, st) : ks_launch<2, 1>(p, x, w, y, M, K, N, st);
+}
+
+}  // namespace mrla

@@ -1040,8 +1040,9 @@ class WeightBank:
 class _Conv1x1Fn(torch.autograd.Function):
     """y = conv2d(x, w) for a bias-free 1x1 stride-1 convolution of a channels_last bf16 tensor, plus the partial
     (sum, sum^2) rows of y the following BatchNorm needs (mrla_conv1x1_fwd; shapes that kernel does not take run the
-    stock convolution and return no rows).  Backward: dX through the same GEMM on w^T where it applies, dW through the
-    split-M GEMM mrla_conv1x1_wgrad; what neither takes stays on the stock convolution backward."""
+    stock convolution and return no rows; neither does the K-streaming kernel of the wide reductions, k >= 512, whose
+    BatchNorm then takes its own statistics pass).  Backward: dX through the same GEMM on w^T where it applies, dW
+    through the split-M GEMM mrla_conv1x1_wgrad; what neither takes stays on the stock convolution backward."""
 
     @staticmethod
     @_on_device
@@ -1061,10 +1062,10 @@ class _Conv1x1Fn(torch.autograd.Function):
             if not w.is_contiguous():
                 w = w.contiguous()
         part = None
-        if L.load().mrla_conv1x1_rows(m, k, n, _DT[x.dtype]) > 0:
+        rows = L.load().mrla_conv1x1_rows(m, k, n, _DT[x.dtype])      # > 0: with the statistics epilogue; 0: without (k >= 512)
+        if rows >= 0:
             y = torch.empty((b, n, h, wd), dtype=x.dtype, device=dev, memory_format=_CL)
-            if want_moments:
-                rows = L.load().mrla_conv1x1_rows(m, k, n, _DT[x.dtype])
+            if want_moments and rows > 0:
                 part = torch.empty((rows, n, L.GEMM_MOMENTS), dtype=torch.float32, device=dev)
             _call("mrla_conv1x1_fwd", (x.numel() + y.numel()) * x.element_size(), _ptr(x), _ptr(w), _ptr(y), _ptr(part), m, k,
                   n, _DT[x.dtype], st)
@@ -1097,7 +1098,7 @@ class _Conv1x1Fn(torch.autograd.Function):
         if d_through is not None and (d_through.dtype != x.dtype or not d_through.is_contiguous(memory_format=_CL)
                                       or d_through.data_ptr() % 16):
             d_through = d_through.to(x.dtype).contiguous(memory_format=_CL)
-        if need_x and same and lib.mrla_conv1x1_rows(m, n, k, dt) > 0:
+        if need_x and same and lib.mrla_conv1x1_rows(m, n, k, dt) >= 0:
             gx = torch.empty_like(x)
             wt = w16t if w16t is not None else w.t().contiguous()
             if d_through is not None and lib.mrla_conv1x1_add_supported(m, n, k, dt) == 1:
@@ -1145,7 +1146,7 @@ def conv1x1_applies(conv, x):
     if k != conv.in_channels:
         return False
     lib, m, n = L.load(), b * h * w, conv.out_channels
-    if lib.mrla_conv1x1_rows(m, k, n, L.BF16) > 0:
+    if lib.mrla_conv1x1_rows(m, k, n, L.BF16) >= 0:
         return True
     return torch.is_grad_enabled() and conv.weight.requires_grad and lib.mrla_conv1x1_wgrad_rows(m, k, n, L.BF16) > 0
 

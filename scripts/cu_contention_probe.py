@@ -66,4 +66,23 @@ for n_wg in (0, 8, 16, 32, 0):
     if base is None:
         base = dt
     extra = f"  side kernel: {moved:.0f} GB/s alone, still running at the end: {still_running}" if n_wg else ""
-    print(f"{n_wg:3d} workgroups beside the step: {dt * 1e3:7.3f} ms/step ({100 * (dt / base - 1):+5.1f} %){extra}", flush=True)
+    print(f"{n_wg:3d} workgroups beside the WHOLE step: {dt * 1e3:7.3f} ms/step ({100 * (dt / base - 1):+5.1f} %){extra}", flush=True)
+
+# the realistic duty cycle: ONE burst per step that moves what a 103 MB all-reduce moves locally (read + write 103 MB),
+# launched beside the step (the real buckets go out during the backward pass)
+for n_wg in (8, 16, 32):
+    per = (src.numel() // n_wg) // 16 * 16
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    lib.occupy(src.data_ptr(), dst.data_ptr(), per, n_wg, 1, side.cuda_stream)
+    side.synchronize()
+    burst = time.perf_counter() - t0
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        lib.occupy(src.data_ptr(), dst.data_ptr(), per, n_wg, 1, side.cuda_stream)
+        step()
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / steps
+    print(f"{n_wg:3d} workgroups, one {burst * 1e3:.2f} ms burst (2 x 103 MB) per step: {dt * 1e3:7.3f} ms/step "
+          f"({100 * (dt / base - 1):+5.1f} %)", flush=True)

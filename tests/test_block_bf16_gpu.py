@@ -78,7 +78,7 @@ def _stock_directions(conv, m):
     from mrla_amd import _lib as L
     k, n = conv.in_channels, conv.out_channels
     lib = L.load()
-    return lib.mrla_conv1x1_rows(m, k, n, L.BF16) <= 0, lib.mrla_conv1x1_rows(m, n, k, L.BF16) <= 0
+    return lib.mrla_conv1x1_rows(m, k, n, L.BF16) < 0, lib.mrla_conv1x1_rows(m, n, k, L.BF16) < 0
 
 
 def _bn(x, bn):

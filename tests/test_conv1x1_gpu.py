@@ -62,9 +62,12 @@ def test_gemm_outputs_and_moment_partials(shape):
 def test_unsupported_shapes_are_reported_not_run():
     from mrla_amd import _lib as L
     lib = L.load()
-    assert lib.mrla_conv1x1_rows(64, 96, 64, L.BF16) == L.EUNSUPPORTED        # k not in {64, 128, 256}
-    assert lib.mrla_conv1x1_rows(64, 1024, 256, L.BF16) == L.EUNSUPPORTED
-    assert lib.mrla_conv1x1_rows(64, 512, 128, L.BF16) == L.EUNSUPPORTED       # left to the stock convolution
+    assert lib.mrla_conv1x1_rows(64, 96, 64, L.BF16) == L.EUNSUPPORTED        # k not in {64, 128, 256} and < 512
+    assert lib.mrla_conv1x1_rows(64, 1024, 256, L.BF16) == 0                   # the K-streaming kernel: no statistics rows
+    assert lib.mrla_conv1x1_rows(64, 512, 128, L.BF16) == 0
+    assert lib.mrla_conv1x1_rows(64, 512, 64, L.BF16) == L.EUNSUPPORTED        # ... needs n % 128 == 0
+    assert lib.mrla_conv1x1_rows(64, 544, 128, L.BF16) == 0 and lib.mrla_conv1x1_rows(64, 520, 128, L.BF16) == L.EUNSUPPORTED
+    assert lib.mrla_conv1x1_fwd(None, None, None, None, 64, 1024, 256, L.BF16, None) == L.EINVAL
     assert lib.mrla_conv1x1_rows(48, 64, 64, L.BF16) > 0                       # ragged last pixel block
     assert lib.mrla_conv1x1_rows(1, 256, 64, L.BF16) == 1                       # a single pixel: one workgroup, one row
     assert lib.mrla_conv1x1_rows(64, 64, 96, L.BF16) == L.EUNSUPPORTED        # n % 64
@@ -126,8 +129,8 @@ def test_input_gradient_is_the_gemm_with_the_transposed_weight(shape):
     wtt = torch.from_numpy(wt).cuda().bfloat16().requires_grad_(True)
     y, _ = Fm._Conv1x1Fn.apply(xt, wtt, False)
     y.backward(torch.from_numpy(dy).cuda().bfloat16().permute(0, 3, 1, 2))
-    own = L.load().mrla_conv1x1_rows(m, n, k, L.BF16) > 0
-    assert own == (n in (64, 128, 256))
+    own = L.load().mrla_conv1x1_rows(m, n, k, L.BF16) >= 0
+    assert own == (n in (64, 128, 256) or (n >= 512 and k % 128 == 0))
     want_dx = dy.reshape(m, n).astype(np.float64) @ wt.astype(np.float64)
     got_dx = xt.grad.permute(0, 2, 3, 1).reshape(m, k).float().cpu().numpy()
     assert_bf16_close(got_dx, want_dx, "dx")
@@ -185,8 +188,9 @@ def test_weight_gradient_unsupported_shapes_are_reported():
 
 
 def test_wide_reduction_convolution_takes_the_weight_gradient_gemm():
-    """A 1x1 convolution whose forward the GEMM does not take (c_in = 1024) still goes through _Conv1x1Fn in training so
-    that its weight gradient runs on mrla_conv1x1_wgrad: outputs and gradients agree with the stock modules'."""
+    """A 1x1 convolution with a wide reduction (c_in = 1024): forward on the K-streaming GEMM (no statistics epilogue: the
+    BatchNorm takes its own moments pass), weight gradient on mrla_conv1x1_wgrad, input gradient (reduction 256) on the
+    wide-output GEMM: outputs and gradients agree with the stock modules'."""
     from mrla_amd import functional as Fm
     b, h, w, k, n = 4, 14, 14, 1024, 256
     x, wt = _operands(b, h, w, k, n, salt=4)
@@ -206,7 +210,7 @@ def test_wide_reduction_convolution_takes_the_weight_gradient_gemm():
         torch.cuda.synchronize()
     finally:
         Fm.TIMER = None
-    assert set(timer.summary()) == {"mrla_conv1x1_wgrad"}
+    assert set(timer.summary()) == {"mrla_conv1x1_wgrad", "mrla_conv1x1_fwd"}
     conv_r = torch.nn.Conv2d(k, n, 1, bias=False).cuda().to(memory_format=torch.channels_last)
     bn_r = torch.nn.BatchNorm2d(n).cuda()
     conv_r.load_state_dict(conv.state_dict())
@@ -276,7 +280,7 @@ def test_shortcut_gradient_joins_the_input_gradient_gemm(shape):
         Fm.TIMER = None
     fused = L.load().mrla_conv1x1_add_supported(m, n, k, L.BF16) == 1
     assert fused == (n <= 256)
-    assert len(timer.records) == (1 if n <= 256 else 0)
+    assert len(timer.records) == 1            # (n = 512: the K-streaming GEMM, the shortcut gradient added behind it)
     conv_r = torch.nn.Conv2d(k, n, 1, bias=False).cuda().to(memory_format=torch.channels_last)
     bn_r = torch.nn.BatchNorm2d(n).cuda()
     conv_r.load_state_dict(conv.state_dict())

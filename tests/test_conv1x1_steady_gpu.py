@@ -172,3 +172,28 @@ def test_weight_gradient_gemm_in_steady_state(shape, batch):
     # the partial tiles themselves: their float64 sum is the product to fp32 accuracy
     psum = part.double().sum(0)
     assert ((psum - want).abs().max() / want.abs().max()).item() < 1e-5
+
+
+# the K-streaming kernel (k >= 512): conv1 of stages 2-4, conv3 of stage 4 and the input gradients with a wide reduction
+KSTREAM = [(28, 28, 512, 128), (28, 28, 512, 256), (14, 14, 1024, 256), (14, 14, 1024, 512), (7, 7, 2048, 512),
+           (7, 7, 512, 2048), (14, 14, 512, 1024)]
+
+
+@pytest.mark.parametrize("batch", [64, 256, "ragged"])
+@pytest.mark.parametrize("shape", KSTREAM, ids=lambda s: "x".join(map(str, s)))
+def test_kstream_gemm_at_bench_sizes(shape, batch):
+    """mrla_conv1x1_fwd on the wide reductions (both operands streamed through a three-stage LDS ring, 16 - 64 chunks per
+    tile: the ring wraps 5 - 21 times) vs a float64 product rounded once; two launches bit-equal; poisoned output."""
+    from mrla_amd import _lib as L
+    h, w_, k, n = shape
+    m = 256 * h * w_ - 37 if batch == "ragged" else batch * h * w_
+    assert L.load().mrla_conv1x1_rows(m, k, n, L.BF16) == 0
+    chunks, stages, _, rows = L.conv1x1_plan(m, k, n)
+    assert chunks >= 5 * stages and rows == 0
+    x, w = _operands(m, k, n, seed=4000 + k + n)
+    y, _ = _run_fwd(x, w, m, k, n, 0, False)
+    y2, _ = _run_fwd(x, w, m, k, n, 0, False)
+    torch.cuda.synchronize()
+    assert torch.equal(y, y2), "two runs of the same launch differ"
+    want = x.double() @ w.double().t()
+    _assert_bf16_close(y, want, "y")

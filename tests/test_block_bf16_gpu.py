@@ -176,8 +176,8 @@ def test_bf16_bottleneck_against_the_staged_float64_reference(shape, monkeypatch
     out_mod, dx_mod = out.detach().clone(), xp.grad.clone()
 
     # the same two statements spelled out, for the ReLU decisions of the product's forward: THIS run is the one compared
-    # with the reference below (the module call above pins the wiring: bit-identical where every direction runs on our
-    # kernels; with a stock 1x1 convolution in the chain -- stage 3: MIOpen, not run-to-run bit-stable -- to rounding)
+    # with the reference below (the module call above pins the wiring: bit-identical where every kernel of the forward
+    # is run-to-run bit-stable, to rounding otherwise)
     for mod in blk.modules():
         if isinstance(mod, torch.nn.BatchNorm2d):
             mod.reset_running_stats()
@@ -191,9 +191,9 @@ def test_bf16_bottleneck_against_the_staged_float64_reference(shape, monkeypatch
     pgrads = {k: p.grad.clone() for k, p in blk.named_parameters()}
     m_ = b * hw * hw
     stock_free = not any(any(_stock_directions(cv, m_)) for cv in (blk.conv1, blk.conv3))
-    if stock_free:
+    if planes == 64:             # every kernel on the forward path bit-stable (MIOpen's 3x3 at 56x56x64 included)
         assert torch.equal(out_mod, out)
-    else:
+    else:                        # (its 3x3 at 14x14x256 is not: two calls of the same module differ in a few last bits)
         assert (_ulps(out_mod, out.double()) > 2.0).float().mean().item() < 1e-3
     assert (_ulps(dx_mod, xp.grad.double()) > 2.0).float().mean().item() < (1e-4 if planes == 64 else 5e-2)
     masks = dict(z1=(seen["z1"] > 0).double(), z2=(seen["z2"] > 0).double(), xt=(seen["dpre"] != 0).double())

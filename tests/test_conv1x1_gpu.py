@@ -201,7 +201,7 @@ def test_wide_reduction_convolution_takes_the_weight_gradient_gemm():
     xt = torch.from_numpy(x).cuda().bfloat16().permute(0, 3, 1, 2).requires_grad_(True)
     assert Fm.conv1x1_applies(conv, xt)
     with torch.no_grad():
-        assert not Fm.conv1x1_applies(conv, xt)                  # nothing to gain without a backward
+        assert Fm.conv1x1_applies(conv, xt)                      # (the forward GEMM applies on its own now)
     Fm.TIMER = timer = Fm.KernelTimer(["mrla_conv1x1_wgrad", "mrla_conv1x1_fwd"])
     try:
         out = Fm.conv_bn_act(xt, conv, bn, relu=True)

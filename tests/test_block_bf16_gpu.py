@@ -189,8 +189,6 @@ def test_bf16_bottleneck_against_the_staged_float64_reference(shape, monkeypatch
     torch.cuda.synchronize()
     running = {k: v.clone() for k, v in blk.state_dict().items() if "running" in k}
     pgrads = {k: p.grad.clone() for k, p in blk.named_parameters()}
-    m_ = b * hw * hw
-    stock_free = not any(any(_stock_directions(cv, m_)) for cv in (blk.conv1, blk.conv3))
     if planes == 64:             # every kernel on the forward path bit-stable (MIOpen's 3x3 at 56x56x64 included)
         assert torch.equal(out_mod, out)
     else:                        # (its 3x3 at 14x14x256 is not: two calls of the same module differ in a few last bits)
@@ -214,8 +212,9 @@ def test_bf16_bottleneck_against_the_staged_float64_reference(shape, monkeypatch
         report.append((name, (u > 1.0).float().mean().item(), (u > 2.0).float().mean().item(), u.max().item(), l2))
         print(f"{name}: beyond 1 ulp {report[-1][1]:.2e}, beyond 2 ulps {report[-1][2]:.2e}, worst {report[-1][3]:.1f} ulps, "
               f"relative L2 {l2:.2e}")
-    # (with MIOpen's not bit-stable 1x1 kernels in the chain -- stage 3 -- the same comparison measures 0.8e-4 .. 1e-4)
-    bound = 1e-4 if stock_free else 3e-4
+    # (stage 3: MIOpen's 3x3 kernels at 14x14x256 are not run-to-run bit-stable, and the reference calls them on its own:
+    # the same comparison measures 0.8e-4 .. 1.1e-4 there)
+    bound = 1e-4 if planes == 64 else 3e-4
     for name, f1, f2, worst, l2 in report:
         assert f2 <= bound, f"{name}: {f2:.2e} of the elements beyond 2 bf16 ulps (worst {worst:.1f})"
         assert l2 < 2.0 ** -7, f"{name}: relative L2 error {l2:.3e}"

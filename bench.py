@@ -201,7 +201,7 @@ def forward_only(net, x, steps=10, graph=True):
 def pmc_traffic(args, kernel):
     """HBM bytes per launch of `kernel` from the committed rocprofv3 PMC passes (2*FETCH_SIZE + WRITE_SIZE, gfx950
     correction of MI355X_MICROARCH.md; collected by scripts/pmc_bench.sh on this exact workload), else None."""
-    for rnd in ("r02", "r01"):          # the newest committed PMC pass of this workload
+    for rnd in ("r03", "r02", "r01"):   # the newest committed PMC pass of this workload
         path = os.path.join(ROOT, "profiles", f"{rnd}_pmc_traffic_{args.arch}_b{args.batch}.json")
         try:
             rec = json.load(open(path)).get(kernel.replace("mrla_", ""))

@@ -15,7 +15,8 @@ out = sys.argv[2] if len(sys.argv) > 2 else raw
 
 
 def short(name):
-    for key in ("light_stats_fwd_fused", "conv1x1_fwd", "conv1x1_wgrad_reduce", "conv1x1_wgrad", "light_stats_fwd", "light_apply_fwd_pre", "light_apply_fwd", "light_stats_bwd", "light_apply_bwd", "plane_moments_small",
+    for key in ("light_stats_fwd_fused", "conv1x1_kstream", "conv1x1_wide", "conv1x1_fwd", "conv1x1_wgrad_reduce", "conv1x1_wgrad", "weight_bank",
+                "plain_bn_fwd_rec", "reduce_rows2", "light_stats_fwd", "light_apply_fwd_pre", "light_apply_fwd", "light_stats_bwd", "light_apply_bwd", "plane_moments_small",
                 "plane_moments", "affine_act", "nhwc_moments_flat", "nhwc_affine_flat", "nhwc_moments", "nhwc_affine",
                 "base_combine_nhwcIDF16bDF16bLi0", "base_combine_nhwcIDF16bDF16bLi1", "base_combine_nhwcIffLi0",
                 "base_combine_nhwcIffLi1", "base_combine", "base_attend_fwd", "token_apply_fwd", "token_apply_bwd",

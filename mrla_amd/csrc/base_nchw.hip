@@ -68,6 +68,13 @@ __device__ __forceinline__ size_t ring_off(const SlabGeo& g, int T, int b, int j
   return (((size_t)b * T + j) * g.C + c0) * (size_t)g.HW;
 }
 
+// lanes that share one head's softmax row: the largest power of two <= 256 / G, at most a wave
+__device__ __forceinline__ int lanes_per_head(int G) {
+  int l = kWave;
+  while (l > 1 && l * G > kThreads) l >>= 1;
+  return l;
+}
+
 // ------------------------------------------------------------------------------------------------
 // gate forward: one workgroup per image.  q_t, k_t, softmax over the history.
 // ------------------------------------------------------------------------------------------------
@@ -111,24 +118,25 @@ __global__ __launch_bounds__(kThreads) void base_gate_fwd_kernel(
     lg[idx] = acc * s;
   }
   __syncthreads();
-  // softmax over the depth, one head per wave at a time with the slots on the lanes (wave reductions; the row of P is
-  // written once, coalesced).  A serial per-thread loop over a row in global memory cost ~70 dependent round trips.
-  const int lane = tid & (kWave - 1), wave = tid / kWave;
-  for (int g = wave; g < G; g += kWaves) {
-    float* Prow = Pall + (((size_t)b * G + g) * T + (t - 1)) * T;
+  // softmax over the depth: LPH lanes per head (all heads of the image at once when G <= 256), the slots strided over
+  // them, lane-group reductions.  (One head per wave at a time serialises 16 global round trips per wave; one thread
+  // per head serialises 3 t of them: both measured slower.)
+  const int lph = lanes_per_head(G), hpp = kThreads / lph;
+  const int sub = tid & (lph - 1);
+  for (int g0 = 0; g0 < G; g0 += hpp) {
+    const int g = g0 + tid / lph;
+    const bool live = g < G;
+    float* Prow = Pall + (((size_t)b * G + (live ? g : 0)) * T + (t - 1)) * T;
+    const float* lr = lg + (live ? g : 0) * t;
     float mx = -INFINITY;
-    for (int j = lane; j < t; j += kWave) mx = fmaxf(mx, lg[g * t + j]);
-#pragma unroll
-    for (int off = kWave / 2; off > 0; off >>= 1) mx = fmaxf(mx, __shfl_xor(mx, off, kWave));
+    for (int j = sub; j < t; j += lph) mx = fmaxf(mx, lr[j]);
+    for (int off = lph >> 1; off > 0; off >>= 1) mx = fmaxf(mx, __shfl_xor(mx, off, kWave));
     float den = 0.f;
-    for (int j = lane; j < t; j += kWave) {
-      const float e = expf(lg[g * t + j] - mx);
-      lg[g * t + j] = e;
-      den += e;
-    }
-    den = wave_sum(den);
+    for (int j = sub; j < t; j += lph) den += expf(lr[j] - mx);
+    for (int off = lph >> 1; off > 0; off >>= 1) den += __shfl_xor(den, off, kWave);
     const float r = 1.0f / den;
-    for (int j = lane; j < t; j += kWave) Prow[j] = lg[g * t + j] * r;
+    if (live)
+      for (int j = sub; j < t; j += lph) Prow[j] = expf(lr[j] - mx) * r;
   }
 }
 
@@ -569,14 +577,19 @@ __global__ __launch_bounds__(kThreads) void base_gate_bwd_kernel(
     dlg[idx] = dP;
   }
   __syncthreads();
-  {   // softmax backward, one head per wave at a time with the slots on the lanes (see base_gate_fwd_kernel)
-    const int lane = tid & (kWave - 1), wave = tid / kWave;
-    for (int g = wave; g < G; g += kWaves) {
-      const float* Prow = Pall + (((size_t)b * G + g) * T + (t - 1)) * T;
+  {   // softmax backward: LPH lanes per head, all heads at once (see base_gate_fwd_kernel)
+    const int lph = lanes_per_head(G), hpp = kThreads / lph;
+    const int sub = tid & (lph - 1);
+    for (int g0 = 0; g0 < G; g0 += hpp) {
+      const int g = g0 + tid / lph;
+      const bool live = g < G;
+      const float* Prow = Pall + (((size_t)b * G + (live ? g : 0)) * T + (t - 1)) * T;
+      float* dr = dlg + (live ? g : 0) * t;
       float dot = 0.f;
-      for (int j = lane; j < t; j += kWave) dot = fmaf(Prow[j], dlg[g * t + j], dot);
-      dot = wave_sum(dot);
-      for (int j = lane; j < t; j += kWave) dlg[g * t + j] = Prow[j] * (dlg[g * t + j] - dot) * s;
+      for (int j = sub; j < t; j += lph) dot = fmaf(Prow[j], dr[j], dot);
+      for (int off = lph >> 1; off > 0; off >>= 1) dot += __shfl_xor(dot, off, kWave);
+      if (live)
+        for (int j = sub; j < t; j += lph) dr[j] = Prow[j] * (dr[j] - dot) * s;      // (the row is in L1 by now)
     }
   }
   __syncthreads();

@@ -598,17 +598,27 @@ __global__ __launch_bounds__(kThreads) void base_gate_bwd_kernel(
   for (int c = tid; c < C; c += kThreads) {
     const int g = c / d;
     const float qc = q[(size_t)b * C + c];
-    float dq = 0.f;
-    for (int j = 0; j < t; ++j) {
-      const float dl = dlg[g * t + j];
-      dq = fmaf(dl, Kb[(size_t)j * C + c], dq);
-      float* dst = dKb + (size_t)j * C + c;
-      // the first backward call of a stage (its last layer) touches every slot first: start from zero
-      const float prev = first_touch ? 0.f : *dst;
-      const float nv = fmaf(dl, qc, prev);
-      *dst = nv;
-      if (j == t - 1) dks[p + c] = nv;           // dL/dk_t is complete now
+    float dq = 0.f, last = 0.f;
+    // (two loops so that the loads of several slots are in flight together: the history is t <= 23 slots deep and every
+    // iteration of a fused loop waited for its own load -> fma -> store round trip)
+    if (first_touch) {       // the first backward call of a stage (its last layer) touches every slot first: start from zero
+#pragma unroll 4
+      for (int j = 0; j < t; ++j) {
+        const float dl = dlg[g * t + j];
+        dq = fmaf(dl, Kb[(size_t)j * C + c], dq);
+        last = dl * qc;
+        dKb[(size_t)j * C + c] = last;
+      }
+    } else {
+#pragma unroll 4
+      for (int j = 0; j < t; ++j) {
+        const float dl = dlg[g * t + j];
+        dq = fmaf(dl, Kb[(size_t)j * C + c], dq);
+        last = fmaf(dl, qc, dKb[(size_t)j * C + c]);
+        dKb[(size_t)j * C + c] = last;
+      }
     }
+    dks[p + c] = last;                             // dL/dk_t (slot t-1) is complete now
     dqs[p + c] = dq;
   }
   __syncthreads();

@@ -224,7 +224,8 @@ int mrla_base_attend_bwd(const void* dout, const void* attn, const float* sc, co
                          int T, int t, int dtype, int layout, void* stream);
 
 /* softmax backward; dq_t; dk_ring[:, j] += dlogit_j * q_t (j < t; first_touch != 0: overwrite instead of add, for the
- * first backward call of a stage); dyx[b,c] = (gradient wrt pooled y)/hw; dwqk_part[b, 2*ksize]. */
+ * first backward call of a stage); dyx[b,c] = (gradient wrt pooled y)/hw; dwqk_part[b, 2*ksize].
+ * c % 4 == 0 (16-byte accesses of the fp32 rings), MRLA_EUNSUPPORTED otherwise. */
 int mrla_base_gate_bwd(const float* mom, const float* pmom, const float* p_all, const float* q, const float* k_ring,
                        float* dk_ring, const float* wq, const float* wk, int ksize, float* dyx, float* dwqk_part,
                        int b, int c, int hw, int d, int T, int t, int first_touch, void* stream);

@@ -549,7 +549,7 @@ __global__ __launch_bounds__(kThreads) void base_gate_bwd_kernel(
     const float* __restrict__ mom, const float* __restrict__ pmom /*[b,c,t]*/, const float* __restrict__ Pall,
     const float* __restrict__ q, const float* __restrict__ Kring, float* __restrict__ dKring,
     const float* __restrict__ wq, const float* __restrict__ wk, int ks, float* __restrict__ dyx,
-    float* __restrict__ dwqk_part, int C, int HW, int d, int T, int t, int first_touch) {
+    float* __restrict__ dwqk_part, int C, int HW, int d, int T, int t, int first_touch, int stage_pmom) {
   extern __shared__ float sm[];
   const int p = (ks - 1) / 2;
   const int CPD = C + 2 * p;
@@ -568,13 +568,29 @@ __global__ __launch_bounds__(kThreads) void base_gate_bwd_kernel(
     dqs[i] = 0.f;
     dks[i] = 0.f;
   }
-  // dP[g,j] = sum_{c in g} pmom[b,c,j] (one (head, slot) pair per thread: G*t pairs keep the whole workgroup loading),
-  // then the softmax backward per head
-  for (int idx = tid; idx < G * t; idx += kThreads) {
-    const int g = idx / t, j = idx - g * t;
-    float dP = 0.f;
-    for (int i = 0; i < d; ++i) dP += pmom[((size_t)b * C + g * d + i) * t + j];
-    dlg[idx] = dP;
+  // dP[g,j] = sum_{c in g} pmom[b,c,j].  The image's [C][t] block of pmom is contiguous: every thread fetches float4s of it
+  // with all its loads in flight at once and parks them in LDS (94 KB at C = 1024, t = 23; the grid is one workgroup per
+  // image, so LDS occupancy is not a concern), then one (head, slot) pair per thread adds its d entries from LDS -- a chain
+  // of d dependent-latency global loads per thread was most of this kernel's time.
+  if (stage_pmom) {
+    float* pm = sm + ((3 * CPD + G * t + kWaves + 3) & ~3);        // 16-byte aligned
+    const float4* src = reinterpret_cast<const float4*>(pmom + (size_t)b * C * t);
+    const int n4 = (C * t) >> 2;                       // C % 4 == 0
+    for (int i = tid; i < n4; i += kThreads) reinterpret_cast<float4*>(pm)[i] = src[i];
+    __syncthreads();
+    for (int idx = tid; idx < G * t; idx += kThreads) {
+      const int g = idx / t, j = idx - g * t;
+      float dP = 0.f;
+      for (int i = 0; i < d; ++i) dP += pm[(g * d + i) * t + j];
+      dlg[idx] = dP;
+    }
+  } else {
+    for (int idx = tid; idx < G * t; idx += kThreads) {
+      const int g = idx / t, j = idx - g * t;
+      float dP = 0.f;
+      for (int i = 0; i < d; ++i) dP += pmom[((size_t)b * C + g * d + i) * t + j];
+      dlg[idx] = dP;
+    }
   }
   __syncthreads();
   {   // softmax backward: LPH lanes per head, all heads at once (see base_gate_fwd_kernel)
@@ -595,31 +611,40 @@ __global__ __launch_bounds__(kThreads) void base_gate_bwd_kernel(
   __syncthreads();
   const float* Kb = Kring + (size_t)b * T * C;
   float* dKb = dKring + (size_t)b * T * C;
-  for (int c = tid; c < C; c += kThreads) {
-    const int g = c / d;
-    const float qc = q[(size_t)b * C + c];
-    float dq = 0.f, last = 0.f;
-    // (two loops so that the loads of several slots are in flight together: the history is t <= 23 slots deep and every
-    // iteration of a fused loop waited for its own load -> fma -> store round trip)
-    if (first_touch) {       // the first backward call of a stage (its last layer) touches every slot first: start from zero
-#pragma unroll 4
-      for (int j = 0; j < t; ++j) {
-        const float dl = dlg[g * t + j];
-        dq = fmaf(dl, Kb[(size_t)j * C + c], dq);
-        last = dl * qc;
-        dKb[(size_t)j * C + c] = last;
+  // four channels per thread (one head when d % 4 == 0), the slots in batches of kJB so that 2*kJB 16-byte loads are in flight
+  constexpr int kJB = 8;
+  const bool one_head = (d & 3) == 0;
+  for (int c = tid * 4; c < C; c += kThreads * 4) {
+    const float* dl = dlg + (c / d) * t;
+    const float4 qc = *reinterpret_cast<const float4*>(q + (size_t)b * C + c);
+    float4 dq = {0.f, 0.f, 0.f, 0.f}, last = {0.f, 0.f, 0.f, 0.f};
+    for (int j0 = 0; j0 < t; j0 += kJB) {
+      float4 kv[kJB], pv[kJB];
+#pragma unroll
+      for (int u = 0; u < kJB; ++u) {
+        const int j = min(j0 + u, t - 1);
+        kv[u] = *reinterpret_cast<const float4*>(Kb + (size_t)j * C + c);
+        // the first backward call of a stage (its last layer) touches every slot first: start from zero
+        pv[u] = first_touch ? float4{0.f, 0.f, 0.f, 0.f} : *reinterpret_cast<const float4*>(dKb + (size_t)j * C + c);
       }
-    } else {
-#pragma unroll 4
-      for (int j = 0; j < t; ++j) {
-        const float dl = dlg[g * t + j];
-        dq = fmaf(dl, Kb[(size_t)j * C + c], dq);
-        last = fmaf(dl, qc, dKb[(size_t)j * C + c]);
-        dKb[(size_t)j * C + c] = last;
+#pragma unroll
+      for (int u = 0; u < kJB; ++u) {
+        if (j0 + u < t) {
+          const int j = j0 + u;
+          const float l = dl[j];
+          const float ly = one_head ? l : dlg[((c + 1) / d) * t + j], lz = one_head ? l : dlg[((c + 2) / d) * t + j],
+                      lw = one_head ? l : dlg[((c + 3) / d) * t + j];
+          dq.x = fmaf(l, kv[u].x, dq.x); dq.y = fmaf(ly, kv[u].y, dq.y);
+          dq.z = fmaf(lz, kv[u].z, dq.z); dq.w = fmaf(lw, kv[u].w, dq.w);
+          last.x = fmaf(l, qc.x, pv[u].x); last.y = fmaf(ly, qc.y, pv[u].y);
+          last.z = fmaf(lz, qc.z, pv[u].z); last.w = fmaf(lw, qc.w, pv[u].w);
+          *reinterpret_cast<float4*>(dKb + (size_t)(j0 + u) * C + c) = last;
+        }
       }
     }
-    dks[p + c] = last;                             // dL/dk_t (slot t-1) is complete now
-    dqs[p + c] = dq;
+    // dL/dk_t (slot t-1) is complete now
+    dks[p + c] = last.x; dks[p + c + 1] = last.y; dks[p + c + 2] = last.z; dks[p + c + 3] = last.w;
+    dqs[p + c] = dq.x; dqs[p + c + 1] = dq.y; dqs[p + c + 2] = dq.z; dqs[p + c + 3] = dq.w;
   }
   __syncthreads();
   for (int c = tid; c < C; c += kThreads) {
@@ -893,10 +918,14 @@ int launch_base_gate_bwd(const float* mom, const float* pmom, const float* Pall,
                          float* dKring, const float* wq, const float* wk, int ks, float* dyx, float* dwqk_part, int B,
                          int C, int HW, int d, int T, int t, int first_touch, hipStream_t st) {
   const int p = (ks - 1) / 2;
-  const size_t lds = (size_t)(3 * (C + 2 * p) + (C / d) * t + kWaves) * sizeof(float);
-  if (lds > 64 * 1024) return MRLA_EUNSUPPORTED;
+  size_t lds = (size_t)(3 * (C + 2 * p) + (C / d) * t + kWaves) * sizeof(float);
+  if (lds > 64 * 1024 || (C & 3)) return MRLA_EUNSUPPORTED;
+  const size_t staged = lds + (size_t)(C * t + 4) * sizeof(float);        // pmom[b] parked in LDS when it fits
+  const int stage_pmom = staged <= 150 * 1024;
+  if (stage_pmom) lds = staged;
+  if (set_lds2(base_gate_bwd_kernel, lds) != hipSuccess) return MRLA_EHIP;
   hipLaunchKernelGGL(base_gate_bwd_kernel, dim3(B), dim3(kThreads), lds, st, mom, pmom, Pall, q, Kring, dKring, wq, wk,
-                     ks, dyx, dwqk_part, C, HW, d, T, t, first_touch);
+                     ks, dyx, dwqk_part, C, HW, d, T, t, first_touch, stage_pmom);
   return hip_status(hipGetLastError());
 }
 

@@ -56,7 +56,9 @@ enum { MRLA_BN_NONE = 0, MRLA_BN_TRAIN = 1, MRLA_BN_EVAL = 2 };
  *           mrla_bn_stats_bwd gained centered (BatchNorm-backward sums about the saved mean), mrla_light_stats_bwd gained
  *           mom (MRLA_BWD_MOMENTS are about the forward record's pivots);
  *           mrla_conv1x1_plan, mrla_conv1x1_wgrad_plan, mrla_light_apply_bwd_pre_sums, mrla_reduce_rows2 and
- *           mrla_weight_bank_refresh were added.
+ *           mrla_weight_bank_refresh were added;  the token backward became one pass: mrla_token_stats_bwd was removed,
+ *           mrla_token_apply_bwd writes bmom and no longer takes dyx, MRLA_TOKEN_PARTIALS grew from 14 to 15,
+ *           mrla_token_gate_bwd was added and mrla_token_ln_bwd gained dyx.
  * A consumer compares mrla_abi_version() (what the loaded library was built from) against this constant before its
  * first call. */
 #define MRLA_ABI_VERSION 2
@@ -276,10 +278,10 @@ int mrla_base_value_bwd_dv(const void* dout, const void* x, const float* wv, con
  * MRLA-light on token sequences (DeiT): x[b, n, c], n = 1 + side*side, channels contiguous.
  * Reference: deit/deit_mrla_light.py:157-180 (mrlal_layer, GELU on V), :194-209 (mrlal_module: two LayerNorms,
  * cls split, token<->map permutes, lambda_t, cat), :234 (block residual).  The gate itself is computed with
- * mrla_light_gate_fwd / mrla_light_gate_bwd on the `mom` / `bmom` records written here (hw = n - 1).
+ * mrla_light_gate_fwd / mrla_token_gate_bwd on the `mom` / `bmom` records written here (hw = n - 1).
  *   stats[b, n, 4] = (mean_x, rstd_x, mean_o, rstd_o) per token;   params: lnx_* / lno_* = LayerNorm weight, bias.
  * ===================================================================================================== */
-#define MRLA_TOKEN_PARTIALS 14 /* per (image, channel): dWv[9], dlambda, dlnx_w, dlnx_b, dlno_w, dlno_b */
+#define MRLA_TOKEN_PARTIALS 15 /* per (image, channel): dWv[9], dlambda, dlnx_w, dlnx_b, dlno_w, dlno_b, sum of xhat */
 
 /* LayerNorm statistics of x and o_prev; mom[b,c,0] = (n-1) * mean_{i>=1} LN_x(x)[b,i,c], other slots 0.
  * Replaces normx / normo statistics (deit_mrla_light.py:195-196) and avg_pool (:161). */
@@ -294,22 +296,28 @@ int mrla_token_apply_fwd(const void* x, const void* o_prev, const float* stats, 
                          const float* gate, const float* lam, void* out, int b, int n, int c, int d, int res,
                          int dtype, void* stream);
 
-/* bmom[b,c,1] = sum_i dOut * gelu(U) (slots 0, 2 zeroed). */
-int mrla_token_stats_bwd(const void* dout, const void* x, const float* stats, const float* lnx_w, const float* lnx_b,
-                         const float* wv, float* bmom, int b, int n, int c, int dtype, void* stream);
-
-/* dxn[b,n,c] (float32) = gradient wrt LN_x(x) incl. the cls row; part[rows,c,14] parameter-gradient partials with
- * rows = mrla_token_part_rows(b, n, c, dtype) (>= b: the map rows of an image may be split over several workgroups). */
+/* Backward (autograd of the lines above), ONE pass over the map + the per-token LayerNorm backward:
+ *   mrla_token_apply_bwd -> mrla_token_gate_bwd -> mrla_token_ln_bwd -> (sum `part` over its rows)
+ * The gradient dy of the pooled descriptor is a per-(image, channel) constant on the map rows of dxn and is known only
+ * once the gate backward has seen bmom; it is folded in afterwards instead of costing a second pass over (dOut, x):
+ *   mrla_token_apply_bwd: dxn[b,n,c] (float32) = gradient wrt LN_x(x) WITHOUT dy (cls row included);
+ *       bmom[b,c,1] = sum_i dOut * gelu(U) (slots 0, 2 zeroed);  part[rows,c,15] parameter-gradient partials (without
+ *       dy's share; slot 14 = sum over the map of xhat), rows = mrla_token_part_rows(b, n, c, dtype) (>= b).
+ *   mrla_token_gate_bwd: mrla_light_gate_bwd on (mom, bmom) -> dyx[b,c] = dy/hw, dwqk_part[b, 2*ksize]; completes
+ *       part[b,c,10] += dyx * part[.,c,14], part[b,c,11] += dy (the LN_x weight / bias partials).
+ *   mrla_token_ln_bwd: dx = LN_x^T(dxn + dyx on map tokens) + res*dOut;  do_prev = LN_o^T(lam*dOut) on map tokens, 0 on
+ *       the cls row.  dyx may be NULL (dxn already complete). */
 int mrla_token_part_rows(int b, int n, int c, int dtype);
 int mrla_token_apply_bwd(const void* dout, const void* x, const void* o_prev, const float* stats, const float* lnx_w,
                          const float* lnx_b, const float* lno_w, const float* lno_b, const float* wv,
-                         const float* gate, const float* lam, const float* dyx, float* dxn, float* part, int b, int n,
-                         int c, int d, int dtype, void* stream);
-
-/* dx = LN_x^T(dxn) + res*dOut;  do_prev = LN_o^T(lam*dOut) on map tokens, 0 on the cls row. */
-int mrla_token_ln_bwd(const void* dout, const void* x, const void* o_prev, const float* dxn, const float* stats,
-                      const float* lnx_w, const float* lno_w, const float* lam, void* dx, void* do_prev, int b, int n,
-                      int c, int res, int dtype, void* stream);
+                         const float* gate, const float* lam, float* dxn, float* part, float* bmom, int b, int n, int c,
+                         int d, int dtype, void* stream);
+int mrla_token_gate_bwd(const float* mom, const float* bmom, const float* gate, const float* wq, const float* wk,
+                        int ksize, float* dyx, float* dwqk_part, float* part, int b, int n, int c, int d, int dtype,
+                        void* stream);
+int mrla_token_ln_bwd(const void* dout, const void* x, const void* o_prev, const float* dxn, const float* dyx,
+                      const float* stats, const float* lnx_w, const float* lno_w, const float* lam, void* dx,
+                      void* do_prev, int b, int n, int c, int res, int dtype, void* stream);
 
 /* =====================================================================================================
  * Fused BatchNorm2d (+ReLU) in front of the MRLA tail (reference call sites

@@ -15,7 +15,7 @@ F32, BF16, F16 = 0, 1, 2
 NCHW, NHWC = 0, 1
 ACT_NONE, ACT_GELU = 0, 1
 BN_NONE, BN_TRAIN, BN_EVAL = 0, 1, 2
-FWD_MOMENTS, BWD_MOMENTS, TOKEN_PARTIALS, GEMM_MOMENTS = 8, 3, 14, 4
+FWD_MOMENTS, BWD_MOMENTS, TOKEN_PARTIALS, GEMM_MOMENTS = 8, 3, 15, 4
 
 _ERR = {EINVAL: "invalid argument", EUNSUPPORTED: "unsupported shape/layout for the HIP kernels",
         EHIP: "HIP runtime error at kernel launch"}
@@ -57,10 +57,10 @@ SIGNATURES = {
     "mrla_base_value_bwd": [_P] * 8 + [_I] * 11 + [_P],
     "mrla_token_norm_pool": [_P, _P, _P, _P, _F, _P, _P, _I, _I, _I, _I, _P],
     "mrla_token_apply_fwd": [_P] * 11 + [_I] * 6 + [_P],
-    "mrla_token_stats_bwd": [_P] * 7 + [_I] * 4 + [_P],
     "mrla_token_part_rows": [_I] * 4,
     "mrla_token_apply_bwd": [_P] * 14 + [_I] * 5 + [_P],
-    "mrla_token_ln_bwd": [_P] * 10 + [_I] * 5 + [_P],
+    "mrla_token_gate_bwd": [_P] * 5 + [_I] + [_P] * 3 + [_I] * 5 + [_P],
+    "mrla_token_ln_bwd": [_P] * 11 + [_I] * 5 + [_P],
     "mrla_bn_moment_rows": [_I] * 5,
     "mrla_bn_plane_moments": [_P, _P, _P, _I, _I, _I, _I, _I, _I, _P],
     "mrla_bn_act_fwd": [_P, _P, _P, _I, _P, _I, _I, _I, _I, _I, _I, _P],

@@ -444,15 +444,6 @@ int mrla_token_apply_fwd(const void* x, const void* o_prev, const float* stats, 
                                 token_side(n), d, res, dtype, (hipStream_t)stream);
 }
 
-int mrla_token_stats_bwd(const void* dout, const void* x, const float* stats, const float* lnx_w, const float* lnx_b,
-                         const float* wv, float* bmom, int b, int n, int c, int dtype, void* stream) {
-  if (!dout || !x || !stats || !lnx_w || !lnx_b || !wv || !bmom || b <= 0 || c <= 0 || bad_dtype(dtype) ||
-      !token_side(n))
-    return MRLA_EINVAL;
-  return launch_token_stats_bwd(dout, x, stats, lnx_w, lnx_b, wv, bmom, b, n, c, token_side(n), dtype,
-                                (hipStream_t)stream);
-}
-
 int mrla_token_part_rows(int b, int n, int c, int dtype) {
   if (b <= 0 || c <= 0 || bad_dtype(dtype) || !token_side(n)) return MRLA_EINVAL;
   return b * token_bands_bwd(b, c, token_side(n));
@@ -460,22 +451,32 @@ int mrla_token_part_rows(int b, int n, int c, int dtype) {
 
 int mrla_token_apply_bwd(const void* dout, const void* x, const void* o_prev, const float* stats, const float* lnx_w,
                          const float* lnx_b, const float* lno_w, const float* lno_b, const float* wv,
-                         const float* gate, const float* lam, const float* dyx, float* dxn, float* part, int b, int n,
-                         int c, int d, int dtype, void* stream) {
-  if (!dout || !x || !o_prev || !stats || !lnx_w || !lnx_b || !lno_w || !lno_b || !wv || !gate || !lam || !dyx ||
-      !dxn || !part || b <= 0 || c <= 0 || d <= 0 || c % d || bad_dtype(dtype) || !token_side(n))
+                         const float* gate, const float* lam, float* dxn, float* part, float* bmom, int b, int n, int c,
+                         int d, int dtype, void* stream) {
+  if (!dout || !x || !o_prev || !stats || !lnx_w || !lnx_b || !lno_w || !lno_b || !wv || !gate || !lam || !dxn ||
+      !part || !bmom || b <= 0 || c <= 0 || d <= 0 || c % d || bad_dtype(dtype) || !token_side(n))
     return MRLA_EINVAL;
-  return launch_token_apply_bwd(dout, x, o_prev, stats, lnx_w, lnx_b, lno_w, lno_b, wv, gate, lam, dyx, dxn, part, b,
-                                n, c, token_side(n), d, dtype, (hipStream_t)stream);
+  return launch_token_apply_bwd(dout, x, o_prev, stats, lnx_w, lnx_b, lno_w, lno_b, wv, gate, lam, dxn, part, bmom, b, n,
+                                c, token_side(n), d, dtype, (hipStream_t)stream);
 }
 
-int mrla_token_ln_bwd(const void* dout, const void* x, const void* o_prev, const float* dxn, const float* stats,
-                      const float* lnx_w, const float* lno_w, const float* lam, void* dx, void* do_prev, int b, int n,
-                      int c, int res, int dtype, void* stream) {
+int mrla_token_gate_bwd(const float* mom, const float* bmom, const float* gate, const float* wq, const float* wk,
+                        int ksize, float* dyx, float* dwqk_part, float* part, int b, int n, int c, int d, int dtype,
+                        void* stream) {
+  if (!mom || !bmom || !gate || !wq || !wk || !dyx || !dwqk_part || !part || b <= 0 || c <= 0 || d <= 0 || c % d ||
+      ksize <= 0 || !(ksize & 1) || bad_dtype(dtype) || !token_side(n))
+    return MRLA_EINVAL;
+  return launch_gate_bwd(mom, bmom, gate, nullptr, nullptr, nullptr, wq, wk, ksize, dyx, dwqk_part, b, c, n - 1, d,
+                         (hipStream_t)stream, part, token_bands_bwd(b, c, token_side(n)));
+}
+
+int mrla_token_ln_bwd(const void* dout, const void* x, const void* o_prev, const float* dxn, const float* dyx,
+                      const float* stats, const float* lnx_w, const float* lno_w, const float* lam, void* dx,
+                      void* do_prev, int b, int n, int c, int res, int dtype, void* stream) {
   if (!dout || !x || !o_prev || !dxn || !stats || !lnx_w || !lno_w || !lam || !dx || !do_prev || b <= 0 || c <= 0 ||
       bad_dtype(dtype) || !token_side(n))
     return MRLA_EINVAL;
-  return launch_token_ln_bwd(dout, x, o_prev, dxn, stats, lnx_w, lno_w, lam, dx, do_prev, b, n, c, res, dtype,
+  return launch_token_ln_bwd(dout, x, o_prev, dxn, dyx, stats, lnx_w, lno_w, lam, dx, do_prev, b, n, c, res, dtype,
                              (hipStream_t)stream);
 }
 

@@ -211,7 +211,7 @@ __global__ __launch_bounds__(kThreads) void gate_bwd_kernel(
     const float* __restrict__ mom, const float* __restrict__ bmom, const float* __restrict__ gate,
     const float* __restrict__ cb, const float* __restrict__ cb_lo, const float* __restrict__ dp,
     const float* __restrict__ wq, const float* __restrict__ wk, int ks, float* __restrict__ dyx,
-    float* __restrict__ dwqk_part, int C, int HW, int d) {
+    float* __restrict__ dwqk_part, int C, int HW, int d, float* __restrict__ tok_part, int tok_bands) {
   extern __shared__ float sm[];
   const int p = (ks - 1) / 2;
   const int CPD = C + 2 * p;
@@ -274,6 +274,15 @@ __global__ __launch_bounds__(kThreads) void gate_bwd_kernel(
       dy = fmaf(wk[j], dks[c - j + 2 * p], dy);
     }
     dyx[(size_t)b * C + c] = dy * inv_hw;
+    if (tok_part) {
+      // token path: every map token's LN_x output receives dy/hw on top of what mrla_token_apply_bwd wrote, so the
+      // LayerNorm parameter partials of this (image, channel) gain dy/hw * sum xhat and dy/hw * hw
+      float hsum = 0.f;
+      for (int z = 0; z < tok_bands; ++z) hsum += tok_part[(((size_t)z * gridDim.x + b) * C + c) * kTokParts + kTokPartHat];
+      float* pr = tok_part + ((size_t)b * C + c) * kTokParts;
+      pr[kTokPartLnxW] = fmaf(dy * inv_hw, hsum, pr[kTokPartLnxW]);
+      pr[kTokPartLnxB] += dy;
+    }
   }
   for (int j = 0; j < ks; ++j) {
     float aq = 0.f, ak = 0.f;
@@ -358,12 +367,12 @@ int launch_bn_bwd(const float* mom, const float* bmom, const float* gate, const 
 
 int launch_gate_bwd(const float* mom, const float* bmom, const float* gate, const float* cb, const float* cb_lo,
                     const float* dp, const float* wq, const float* wk, int ks, float* dyx, float* dwqk_part, int B, int C, int HW,
-                    int d, hipStream_t st) {
+                    int d, hipStream_t st, float* tok_part, int tok_bands) {
   const int p = (ks - 1) / 2;
   const size_t lds = (size_t)(3 * (C + 2 * p) + 2 * C + C / d + kWaves) * sizeof(float);
   if (lds > 64 * 1024) return MRLA_EUNSUPPORTED;
   hipLaunchKernelGGL(gate_bwd_kernel, dim3(B), dim3(kThreads), lds, st, mom, bmom, gate, cb, cb_lo, dp, wq, wk, ks, dyx,
-                     dwqk_part, C, HW, d);
+                     dwqk_part, C, HW, d, tok_part, tok_bands);
   return hip_status(hipGetLastError());
 }
 

@@ -22,6 +22,9 @@ constexpr int kWaves = kThreads / kWave;
 enum { M_SX = 0, M_SV = 1, M_SO = 2, M_SVV = 3, M_SVO = 4, M_SOO = 5, M_N = 6, M_PV = 6, M_PO = 7, M_REC = 8 };
 // Moment slots written by the backward statistics pass.
 enum { D_D = 0, D_DV = 1, D_DO = 2, D_N = 3 };
+// token path (tokens*.hip): slots of the per-(image, channel) parameter partials that the gate backward completes with
+// the pooled-descriptor gradient (dlnx_w += dy * sum xhat, dlnx_b += dy * pixels), and the record size
+constexpr int kTokPartLnxW = 10, kTokPartLnxB = 11, kTokPartHat = 14, kTokParts = 15;
 
 // Raw moments of V and o over the n pixels of a plane, in double, from a (pivot-shifted) moment record.
 struct RawMoments { double sv, so, svv, svo, soo; };

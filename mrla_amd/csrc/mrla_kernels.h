@@ -58,9 +58,10 @@ int launch_bn_fwd(const float* mom, const float* gate, const float* lam, const f
 int launch_bn_bwd(const float* mom, const float* bmom, const float* gate, const float* lam, const float* gamma,
                   const float* dp, const float* save_mean, const float* save_inv, int training, float* cb, float* cb_lo,
                   float* dgamma, float* dbeta, float* dlam, int B, int C, int HW, int d, hipStream_t st);
+// tok_part != null (token path): [tok_bands * B][C][kTokParts] partials of mrla_token_apply_bwd, completed in place with dy
 int launch_gate_bwd(const float* mom, const float* bmom, const float* gate, const float* cb, const float* cb_lo,
                     const float* dp, const float* wq, const float* wk, int ks, float* dyx, float* dwqk_part, int B, int C, int HW,
-                    int d, hipStream_t st);
+                    int d, hipStream_t st, float* tok_part = nullptr, int tok_bands = 0);
 int launch_reduce_rows(const float* in, float* out, int rows, int n, hipStream_t st);
 int launch_reduce_rows2(const float* in1, float* out1, int rows1, int n1, const float* in2, float* out2, int rows2, int n2,
                         hipStream_t st);
@@ -102,12 +103,10 @@ int token_bands_bwd(int B, int C, int side);   // ... of the backward apply kern
 int launch_token_apply_fwd_nhwc(const void* x, const void* o, const float* stats, const float* wx, const float* bx,
                                 const float* wo, const float* bo, const float* wv, const float* gate, const float* lam,
                                 void* out, int B, int n, int C, int side, int d, int res, int dtype, hipStream_t st);
-int launch_token_stats_bwd_nhwc(const void* dout, const void* x, const float* stats, const float* wx, const float* bx,
-                                const float* wv, float* bmom, int B, int n, int C, int side, int dtype, hipStream_t st);
 int launch_token_apply_bwd_nhwc(const void* dout, const void* x, const void* o, const float* stats, const float* wx,
                                 const float* bx, const float* wo, const float* bo, const float* wv, const float* gate,
-                                const float* lam, const float* dyx, float* dxn, float* part, int B, int n, int C,
-                                int side, int d, int dtype, hipStream_t st);
+                                const float* lam, float* dxn, float* part, float* bmom, int B, int n, int C, int side,
+                                int d, int dtype, hipStream_t st);
 
 // base_nhwc.hip -- MRLA-base for channels_last activations; rings are slot-major [T][b,h,w,c]
 bool base_nhwc_supported(int C, int dtype);
@@ -134,15 +133,13 @@ int launch_token_norm_pool(const void* x, const void* o, const float* wx, const 
 int launch_token_apply_fwd(const void* x, const void* o, const float* stats, const float* wx, const float* bx,
                            const float* wo, const float* bo, const float* wv, const float* gate, const float* lam,
                            void* out, int B, int n, int C, int side, int d, int res, int dtype, hipStream_t st);
-int launch_token_stats_bwd(const void* dout, const void* x, const float* stats, const float* wx, const float* bx,
-                           const float* wv, float* bmom, int B, int n, int C, int side, int dtype, hipStream_t st);
 int launch_token_apply_bwd(const void* dout, const void* x, const void* o, const float* stats, const float* wx,
                            const float* bx, const float* wo, const float* bo, const float* wv, const float* gate,
-                           const float* lam, const float* dyx, float* dxn, float* part, int B, int n, int C, int side,
-                           int d, int dtype, hipStream_t st);
-int launch_token_ln_bwd(const void* dout, const void* x, const void* o, const float* dxn, const float* stats,
-                        const float* wx, const float* wo, const float* lam, void* dx, void* dprev, int B, int n, int C,
-                        int res, int dtype, hipStream_t st);
+                           const float* lam, float* dxn, float* part, float* bmom, int B, int n, int C, int side, int d,
+                           int dtype, hipStream_t st);
+int launch_token_ln_bwd(const void* dout, const void* x, const void* o, const float* dxn, const float* dyx,
+                        const float* stats, const float* wx, const float* wo, const float* lam, void* dx, void* dprev, int B,
+                        int n, int C, int res, int dtype, hipStream_t st);
 
 
 // bnact_nchw.hip -- fused BatchNorm2d (+ReLU) passes

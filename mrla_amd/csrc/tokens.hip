@@ -10,9 +10,12 @@
 //   out[b,i,:]  = res*x[b,i,:] + a[b,g]*gelu(dwconv3x3(xn map)[i,:]) + lam*on[b,i,:]    i >= 1
 //
 // Kernels: token_norm_pool (per image: LN statistics of both inputs, pooled descriptor), token_apply_fwd,
-// token_stats_bwd, token_apply_bwd (per image x 64-channel chunk: the normalised map lives in LDS as fp32,
-// lanes = channels so the 3x3 neighbours are plain LDS reads), token_ln_bwd (per token: both LayerNorm backward
-// passes).  The permutes / split / cat of the reference never touch memory: they are index arithmetic here.
+// token_apply_bwd (per image x 16-channel chunk: the normalised map lives in LDS as fp32, lanes = channels so the 3x3
+// neighbours are plain LDS reads), token_ln_bwd (per token: both LayerNorm backward passes).  The permutes / split / cat
+// of the reference never touch memory: they are index arithmetic here.
+// The backward is ONE pass over the map: token_apply_bwd also takes bmom = sum dOut*gelu(U) for the gate backward, whose
+// result dy (a per-(image, channel) constant on the map rows of dxn) enters afterwards: the gate backward completes the
+// LayerNorm parameter partials with it and token_ln_bwd adds it to dxn as it reads it.
 #include <algorithm>
 
 #include "mrla_device.h"
@@ -23,7 +26,9 @@ namespace mrla {
 // stats[b, i, 0..3] = mean_x, rstd_x, mean_o, rstd_o
 enum { S_MX = 0, S_RX = 1, S_MO = 2, S_RO = 3, S_N = 4 };
 // per-(image, channel) parameter-gradient partials written by token_apply_bwd
-enum { Q_WV = 0, Q_LAM = 9, Q_LNXW = 10, Q_LNXB = 11, Q_LNOW = 12, Q_LNOB = 13, Q_N = 14 };
+enum { Q_WV = 0, Q_LAM = 9, Q_LNXW = 10, Q_LNXB = 11, Q_LNOW = 12, Q_LNOB = 13, Q_H = 14, Q_N = 15 };
+static_assert(Q_N == kTokParts && Q_LNXW == kTokPartLnxW && Q_LNXB == kTokPartLnxB && Q_H == kTokPartHat,
+              "the gate backward (gate.hip) patches these slots");
 
 // ------------------------------------------------------------------------------------------------
 // LayerNorm statistics of x and o (one wave per token, the row held in registers between the two passes of the
@@ -188,55 +193,20 @@ __global__ __launch_bounds__(kThreads) void token_apply_fwd_kernel(
 }
 
 // ------------------------------------------------------------------------------------------------
-// backward statistics: bmom[b,c,D_DV] = sum_i dOut * gelu(U)   (D_D, D_DO zeroed: unused by the gate backward)
-// ------------------------------------------------------------------------------------------------
-template <typename T>
-__global__ __launch_bounds__(kThreads) void token_stats_bwd_kernel(
-    const T* __restrict__ dout, const T* __restrict__ x, const float* __restrict__ stats,
-    const float* __restrict__ wx, const float* __restrict__ bx, const float* __restrict__ wv,
-    float* __restrict__ bmom, int n, int C, int side, int CC) {
-  extern __shared__ float tile[];
-  float* red = tile + tile_elems(side, CC);       // [ntg][CC]
-  const int b = blockIdx.y, c0 = blockIdx.x * CC, tid = threadIdx.x;
-  const int hw = n - 1;
-  load_xn_tile(tile, x, stats, wx, bx, b, n, C, c0, CC, side, tid);
-  __syncthreads();
-  const int cc = tid % CC, tg = tid / CC, ntg = kThreads / CC;
-  const int c = c0 + cc;
-  const int rs = (side + 2) * CC;
-  float w[9];
-#pragma unroll
-  for (int k = 0; k < 9; ++k) w[k] = wv[c * 9 + k];
-  float acc = 0.f;
-  TokenPos pos(tg, ntg, side);
-  for (int i = tg; i < hw; i += ntg, pos.advance()) {
-    const float u = conv9_tile(tile, w, pos.at(CC, cc), rs, CC);
-    acc = fmaf(to_f(dout[((size_t)b * n + i + 1) * C + c]), gelu_f(u), acc);
-  }
-  red[tg * CC + cc] = acc;
-  __syncthreads();
-  if (tg == 0) {
-    float s = 0.f;
-    for (int k = 0; k < ntg; ++k) s += red[k * CC + cc];
-    float* bm = bmom + ((size_t)b * C + c) * D_N;
-    bm[D_D] = 0.f; bm[D_DV] = s; bm[D_DO] = 0.f;
-  }
-}
-
-// ------------------------------------------------------------------------------------------------
-// backward apply: dxn (gradient wrt LN_x(x), all rows) and per-(image, channel) parameter partials
+// backward apply: dxn' (gradient wrt LN_x(x) without the pooled-descriptor term, all rows), bmom and the per-(image,
+// channel) parameter partials
 // ------------------------------------------------------------------------------------------------
 template <typename T>
 __global__ __launch_bounds__(kThreads) void token_apply_bwd_kernel(
     const T* __restrict__ dout, const T* __restrict__ x, const T* __restrict__ o, const float* __restrict__ stats,
     const float* __restrict__ wx, const float* __restrict__ bx, const float* __restrict__ wo,
     const float* __restrict__ bo, const float* __restrict__ wv, const float* __restrict__ gate,
-    const float* __restrict__ lam, const float* __restrict__ dyx, float* __restrict__ dxn /*[b,n,c] fp32*/,
-    float* __restrict__ part /*[b,c,Q_N]*/, int n, int C, int side, int d, int CC) {
+    const float* __restrict__ lam, float* __restrict__ dxn /*[b,n,c] fp32*/, float* __restrict__ part /*[b,c,Q_N]*/,
+    float* __restrict__ bmom, int n, int C, int side, int d, int CC) {
   extern __shared__ float tile[];
   const int hw = n - 1;
   float* dus = tile + tile_elems(side, CC);          // dU, same padded layout
-  float* red = dus + tile_elems(side, CC);           // [ntg][CC][Q_N]
+  float* red = dus + tile_elems(side, CC);           // [ntg][CC][Q_N + 1]
   const int b = blockIdx.y, c0 = blockIdx.x * CC, tid = threadIdx.x;
   load_xn_tile(tile, x, stats, wx, bx, b, n, C, c0, CC, side, tid);
   zero_tile_border(dus, side, CC, tid);
@@ -249,7 +219,7 @@ __global__ __launch_bounds__(kThreads) void token_apply_bwd_kernel(
   for (int k = 0; k < 9; ++k) w[k] = wv[c * 9 + k];
   const float a = gate[(size_t)b * (C / d) + c / d];
   const float lm = lam[c], wo_c = wo[c], bo_c = bo[c];
-  float q[Q_N];
+  float q[Q_N], qb = 0.f;
 #pragma unroll
   for (int k = 0; k < Q_N; ++k) q[k] = 0.f;
   {
@@ -260,6 +230,7 @@ __global__ __launch_bounds__(kThreads) void token_apply_bwd_kernel(
       const size_t g = ((size_t)b * n + i + 1) * C + c;
       const float go = to_f(dout[g]);
       const float du = a * go * gelu_grad_f(u);
+      qb = fmaf(go, gelu_f(u), qb);
       dus[ctr] = du;
       const float* s = stats + ((size_t)b * n + i + 1) * S_N;
       const float ohat = (to_f(o[g]) - s[S_MO]) * s[S_RO];
@@ -276,14 +247,12 @@ __global__ __launch_bounds__(kThreads) void token_apply_bwd_kernel(
     }
   }
   __syncthreads();
-  const float dy = dyx[(size_t)b * C + c];
   {
     TokenPos pos(tg, ntg, side);
     for (int i = tg; i < hw; i += ntg, pos.advance()) {
-      // dxn[i] = sum_{di,dj} wv[di][dj] * dU[i - (di, dj)] + dy/hw   (the padded border of dU is zero)
+      // dxn'[i] = sum_{di,dj} wv[di][dj] * dU[i - (di, dj)]   (the padded border of dU is zero)
       const float* t = dus + pos.at(CC, cc);
-      float s9 = dy;
-      s9 = fmaf(w[0], t[rs + CC], s9); s9 = fmaf(w[1], t[rs], s9); s9 = fmaf(w[2], t[rs - CC], s9);
+      float s9 = w[0] * t[rs + CC]; s9 = fmaf(w[1], t[rs], s9); s9 = fmaf(w[2], t[rs - CC], s9);
       s9 = fmaf(w[3], t[CC], s9);      s9 = fmaf(w[4], t[0], s9);  s9 = fmaf(w[5], t[-CC], s9);
       s9 = fmaf(w[6], t[-rs + CC], s9); s9 = fmaf(w[7], t[-rs], s9); s9 = fmaf(w[8], t[-rs - CC], s9);
       const size_t g = ((size_t)b * n + i + 1) * C + c;
@@ -292,6 +261,7 @@ __global__ __launch_bounds__(kThreads) void token_apply_bwd_kernel(
       const float xhat = (to_f(x[g]) - s[S_MX]) * s[S_RX];
       q[Q_LNXW] = fmaf(s9, xhat, q[Q_LNXW]);
       q[Q_LNXB] += s9;
+      q[Q_H] += xhat;
     }
   }
   if (tg == 0) {                                              // cls row: module output is LN_x(x) itself
@@ -303,36 +273,45 @@ __global__ __launch_bounds__(kThreads) void token_apply_bwd_kernel(
     q[Q_LNXB] += dn;
   }
 #pragma unroll
-  for (int k = 0; k < Q_N; ++k) red[(tg * CC + cc) * Q_N + k] = q[k];
+  for (int k = 0; k < Q_N; ++k) red[(tg * CC + cc) * (Q_N + 1) + k] = q[k];
+  red[(tg * CC + cc) * (Q_N + 1) + Q_N] = qb;
   __syncthreads();
   if (tg == 0) {
 #pragma unroll
-    for (int k = 0; k < Q_N; ++k) {
+    for (int k = 0; k < Q_N + 1; ++k) {
       float s = 0.f;
-      for (int t2 = 0; t2 < ntg; ++t2) s += red[(t2 * CC + cc) * Q_N + k];
-      part[((size_t)b * C + c) * Q_N + k] = s;
+      for (int t2 = 0; t2 < ntg; ++t2) s += red[(t2 * CC + cc) * (Q_N + 1) + k];
+      if (k < Q_N) {
+        part[((size_t)b * C + c) * Q_N + k] = s;
+      } else {
+        float* bm = bmom + ((size_t)b * C + c) * D_N;
+        bm[D_D] = 0.f; bm[D_DV] = s; bm[D_DO] = 0.f;
+      }
     }
   }
 }
 
 // ------------------------------------------------------------------------------------------------
-// per token: backward of both LayerNorms.  dx = LN_x^T(dxn) + res*dOut ;  do = LN_o^T(lam*dOut) (cls row: 0)
+// per token: backward of both LayerNorms.  dx = LN_x^T(dxn' + dy on the map rows) + res*dOut ;  do = LN_o^T(lam*dOut)
+// (cls row: 0).  dyx [b, c]: the pooled-descriptor gradient / hw from the gate backward (null: dxn is complete)
 // ------------------------------------------------------------------------------------------------
 template <typename T>
 __global__ __launch_bounds__(kThreads) void token_ln_bwd_kernel(
     const T* __restrict__ dout, const T* __restrict__ x, const T* __restrict__ o, const float* __restrict__ dxn,
-    const float* __restrict__ stats, const float* __restrict__ wx, const float* __restrict__ wo,
-    const float* __restrict__ lam, T* __restrict__ dx, T* __restrict__ dprev, int ntok, int n, int C, int res) {
+    const float* __restrict__ dyx, const float* __restrict__ stats, const float* __restrict__ wx,
+    const float* __restrict__ wo, const float* __restrict__ lam, T* __restrict__ dx, T* __restrict__ dprev, int ntok, int n,
+    int C, int res) {
   const int lane = threadIdx.x & (kWave - 1), wave = threadIdx.x / kWave;
   const int tok = blockIdx.x * kWaves + wave;
   if (tok >= ntok) return;
   const int i = tok % n;
   const size_t base = (size_t)tok * C;
+  const float* dyb = (dyx && i >= 1) ? dyx + (size_t)(tok / n) * C : nullptr;       // (wave-uniform)
   const float* s = stats + (size_t)tok * S_N;
   const float mx = s[S_MX], rx = s[S_RX], mo = s[S_MO], ro = s[S_RO];
   float s1 = 0.f, s2 = 0.f, t1 = 0.f, t2 = 0.f;
   for (int c = lane; c < C; c += kWave) {
-    const float dh = dxn[base + c] * wx[c];
+    const float dh = (dxn[base + c] + (dyb ? dyb[c] : 0.f)) * wx[c];
     const float xh = (to_f(x[base + c]) - mx) * rx;
     s1 += dh;
     s2 = fmaf(dh, xh, s2);
@@ -350,7 +329,7 @@ __global__ __launch_bounds__(kThreads) void token_ln_bwd_kernel(
   t2 = __shfl(wave_sum(t2), 0, kWave) * invc;
   for (int c = lane; c < C; c += kWave) {
     const float go = to_f(dout[base + c]);
-    const float dh = dxn[base + c] * wx[c];
+    const float dh = (dxn[base + c] + (dyb ? dyb[c] : 0.f)) * wx[c];
     const float xh = (to_f(x[base + c]) - mx) * rx;
     float y = rx * (dh - s1 - xh * s2);
     if (res) y += go;
@@ -421,42 +400,22 @@ int launch_token_apply_fwd(const void* x, const void* o, const float* stats, con
   return hip_status(hipGetLastError());
 }
 
-int launch_token_stats_bwd(const void* dout, const void* x, const float* stats, const float* wx, const float* bx,
-                           const float* wv, float* bmom, int B, int n, int C, int side, int dtype, hipStream_t st) {
-  if (token_nhwc_applies(C))                                   // row-marching kernels (tokens_nhwc.hip)
-    return launch_token_stats_bwd_nhwc(dout, x, stats, wx, bx, wv, bmom, B, n, C, side, dtype, st);
-  const int CC = chunk_for(C);
-  if (!CC) return MRLA_EUNSUPPORTED;
-  const size_t lds = ((size_t)(side + 2) * (side + 2) * CC + (size_t)kThreads) * sizeof(float);
-  if (lds > 150 * 1024) return MRLA_EUNSUPPORTED;
-  const dim3 grid(C / CC, B);
-#define CALL(TT)                                                                                              \
-  {                                                                                                           \
-    if (set_lds3(token_stats_bwd_kernel<TT>, lds) != hipSuccess) return MRLA_EHIP;                              \
-    hipLaunchKernelGGL((token_stats_bwd_kernel<TT>), grid, dim3(kThreads), lds, st, (const TT*)dout,           \
-                       (const TT*)x, stats, wx, bx, wv, bmom, n, C, side, CC);                                \
-  }
-  MRLA_DISPATCH_TT(dtype, CALL)
-#undef CALL
-  return hip_status(hipGetLastError());
-}
-
 int launch_token_apply_bwd(const void* dout, const void* x, const void* o, const float* stats, const float* wx,
                            const float* bx, const float* wo, const float* bo, const float* wv, const float* gate,
-                           const float* lam, const float* dyx, float* dxn, float* part, int B, int n, int C, int side,
-                           int d, int dtype, hipStream_t st) {
+                           const float* lam, float* dxn, float* part, float* bmom, int B, int n, int C, int side, int d,
+                           int dtype, hipStream_t st) {
   if (token_nhwc_applies(C))                                   // row-marching kernels (tokens_nhwc.hip)
-    return launch_token_apply_bwd_nhwc(dout, x, o, stats, wx, bx, wo, bo, wv, gate, lam, dyx, dxn, part, B, n, C, side, d, dtype, st);
+    return launch_token_apply_bwd_nhwc(dout, x, o, stats, wx, bx, wo, bo, wv, gate, lam, dxn, part, bmom, B, n, C, side, d, dtype, st);
   const int CC = chunk_for(C);
   if (!CC) return MRLA_EUNSUPPORTED;
-  const size_t lds = ((size_t)2 * (side + 2) * (side + 2) * CC + (size_t)kThreads * Q_N) * sizeof(float);
+  const size_t lds = ((size_t)2 * (side + 2) * (side + 2) * CC + (size_t)kThreads * (Q_N + 1)) * sizeof(float);
   if (lds > 150 * 1024) return MRLA_EUNSUPPORTED;
   const dim3 grid(C / CC, B);
 #define CALL(TT)                                                                                              \
   {                                                                                                           \
     if (set_lds3(token_apply_bwd_kernel<TT>, lds) != hipSuccess) return MRLA_EHIP;                              \
     hipLaunchKernelGGL((token_apply_bwd_kernel<TT>), grid, dim3(kThreads), lds, st, (const TT*)dout,           \
-                       (const TT*)x, (const TT*)o, stats, wx, bx, wo, bo, wv, gate, lam, dyx, dxn, part, n, C, \
+                       (const TT*)x, (const TT*)o, stats, wx, bx, wo, bo, wv, gate, lam, dxn, part, bmom, n, C, \
                        side, d, CC);                                                                          \
   }
   MRLA_DISPATCH_TT(dtype, CALL)
@@ -464,14 +423,14 @@ int launch_token_apply_bwd(const void* dout, const void* x, const void* o, const
   return hip_status(hipGetLastError());
 }
 
-int launch_token_ln_bwd(const void* dout, const void* x, const void* o, const float* dxn, const float* stats,
-                        const float* wx, const float* wo, const float* lam, void* dx, void* dprev, int B, int n, int C,
-                        int res, int dtype, hipStream_t st) {
+int launch_token_ln_bwd(const void* dout, const void* x, const void* o, const float* dxn, const float* dyx,
+                        const float* stats, const float* wx, const float* wo, const float* lam, void* dx, void* dprev, int B,
+                        int n, int C, int res, int dtype, hipStream_t st) {
   const int ntok = B * n;
   const dim3 grid((ntok + kWaves - 1) / kWaves);
 #define CALL(TT)                                                                                              \
   hipLaunchKernelGGL((token_ln_bwd_kernel<TT>), grid, dim3(kThreads), 0, st, (const TT*)dout, (const TT*)x,    \
-                     (const TT*)o, dxn, stats, wx, wo, lam, (TT*)dx, (TT*)dprev, ntok, n, C, res);
+                     (const TT*)o, dxn, dyx, stats, wx, wo, lam, (TT*)dx, (TT*)dprev, ntok, n, C, res);
   MRLA_DISPATCH_TT(dtype, CALL)
 #undef CALL
   return hip_status(hipGetLastError());

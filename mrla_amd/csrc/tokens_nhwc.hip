@@ -6,7 +6,9 @@
 // through the scalar cache) and the exact-GELU on V.  Used when C % 64 == 0 (DeiT widths 192 / 384 / 768); tokens.hip
 // keeps the LDS-tile kernels for other widths, the LayerNorm statistics / pooling and the LayerNorm backward.
 //   forward : out[b,i>=1] = res*x + a*gelu(dwconv3x3(LN_x(x) map)) + lam*LN_o(o_prev)      (the cls row: token_cls_fwd)
-//   backward: bmom = sum dOut*gelu(U);  dxn = dwconv3x3^T(a*dOut*gelu'(U)) + dy (fp32), 14 parameter partials / channel
+//   backward: ONE pass: bmom = sum dOut*gelu(U), dxn' = dwconv3x3^T(a*dOut*gelu'(U)) (fp32) and 15 partials / channel; the
+//             pooled-descriptor gradient dy (known only after the gate backward has seen bmom) is a per-(image, channel)
+//             constant on the map rows: mrla_token_gate_bwd folds it into the partials, mrla_token_ln_bwd into dxn
 // Reference: deit/deit_mrla_light.py:157-180,194-209,234.
 #include <algorithm>
 
@@ -15,7 +17,9 @@
 namespace mrla {
 
 enum { TS_MX = 0, TS_RX = 1, TS_MO = 2, TS_RO = 3, TS_N = 4 };
-enum { TQ_WV = 0, TQ_LAM = 9, TQ_LNXW = 10, TQ_LNXB = 11, TQ_LNOW = 12, TQ_LNOB = 13, TQ_N = 14 };
+enum { TQ_WV = 0, TQ_LAM = 9, TQ_LNXW = 10, TQ_LNXB = 11, TQ_LNOW = 12, TQ_LNOB = 13, TQ_H = 14, TQ_N = 15 };
+static_assert(TQ_N == kTokParts && TQ_LNXW == kTokPartLnxW && TQ_LNXB == kTokPartLnxB && TQ_H == kTokPartHat,
+              "the gate backward (gate.hip) patches these slots");
 
 // (mean, rstd) of LN_x (which = 0) or LN_o (which = 2) of the map pixel (r, col) of image b: wave-uniform -> scalar load
 __device__ __forceinline__ float2 tok_stat(const float* __restrict__ stats, int tok0, int side, int r, int col, int which) {
@@ -155,60 +159,10 @@ __global__ __launch_bounds__(kThreads) void token_cls_fwd_kernel(const T* __rest
 }
 
 // ------------------------------------------------------------------------------------------------
-// backward statistics: bmom[b,c,D_DV] = sum_i dOut * gelu(U)
-// ------------------------------------------------------------------------------------------------
-template <typename T>
-__global__ __launch_bounds__(kMaxStrips * kWave) void token_stats_bwd_nhwc(
-    const T* __restrict__ dout, const T* __restrict__ x, const float* __restrict__ stats, const float* __restrict__ wx,
-    const float* __restrict__ bx, const float* __restrict__ wv, float* __restrict__ bmom, int n, int C, int side) {
-  MRLA_TOK_PROLOGUE(1)
-  float w[9];
-#pragma unroll
-  for (int k = 0; k < 9; ++k) w[k] = wv[c * 9 + k];
-  const float wxc = wx[c], bxc = bx[c];
-  const T* xi = x + ioff;
-  const T* gi = dout + ioff;
-  float acc[1] = {0.f};
-  for (int s = wave; s < nstrips; s += nwaves) {
-    const int s0 = s * kS, nc = min(kS, W - s0);
-    float ra[kS + 2], rb[kS + 2], rc[kS + 2];
-    RowLoad<T, kS + 2> qx;
-    RowLoad<T, kS> qg;
-    RowAddr<T, kS + 2> ax;
-    RowAddr<T, kS> ag;
-    make_row_addr<T, kS + 2>(ax, s0 - 1, W, C, cbase, lane);
-    make_row_addr<T, kS>(ag, s0, W, C, cbase, lane);
-#pragma unroll
-    for (int j = 0; j < kS + 2; ++j) ra[j] = 0.f;
-    read_row<T, true, kS + 2>(xi, 0, s0 - 1, H, W, C, cbase, c, lane, scrT, rb);
-    normalise_row<kS + 2>(rb, stats, tok0, side, 0, s0 - 1, wxc, bxc);
-    issue_row<T, kS + 2>(qx, xi, 1, H, W * C, ax);
-    issue_row<T, kS>(qg, gi, 0, H, W * C, ag);
-    for (int r = 0; r < H; ++r) {
-      float gv[kS];
-      finish_row<T, kS + 2>(qx, lane, scrT, rc);
-      finish_row<T, kS>(qg, lane, scrT, gv);
-      issue_row<T, kS + 2>(qx, xi, r + 2, H, W * C, ax);
-      issue_row<T, kS>(qg, gi, r + 1, H, W * C, ag);
-      normalise_row<kS + 2>(rc, stats, tok0, side, r + 1, s0 - 1, wxc, bxc);
-#pragma unroll
-      for (int j = 0; j < kS; ++j)
-        if (j < nc) acc[0] = fmaf(gv[j], gelu_f(conv_at(w, ra, rb, rc, j)), acc[0]);
-#pragma unroll
-      for (int j = 0; j < kS + 2; ++j) { ra[j] = rb[j]; rb[j] = rc[j]; }
-    }
-  }
-  wg_reduce<1>(acc, red, lane, wave, nwaves);
-  if (wave == 0) {
-    float* bm = bmom + ((size_t)b * C + c) * D_N;
-    bm[D_D] = 0.f; bm[D_DV] = acc[0]; bm[D_DO] = 0.f;
-  }
-}
-
-// ------------------------------------------------------------------------------------------------
-// backward apply: dxn (fp32, map rows and the cls row) and the 14 parameter partials per (image, channel)
-//   dU[i]  = a * dOut[i] * gelu'(U[i])            (zero outside the map)
-//   dxn[i] = sum_{di,dj} wv[di][dj] * dU[i - (di,dj)] + dy
+// backward apply: dxn' (fp32, map rows and the cls row), bmom and the 15 parameter partials per (image, channel)
+//   dU[i]   = a * dOut[i] * gelu'(U[i])            (zero outside the map)
+//   dxn'[i] = sum_{di,dj} wv[di][dj] * dU[i - (di,dj)]          (the caller's later passes add dy, see the file header)
+//   bmom    = sum_i dOut[i] * gelu(U[i]);  partial TQ_H = sum_i xhat[i] (what dy multiplies in the LN_x weight gradient)
 // Windows per strip: xn rows rr-1..rr+1 on columns s0-2..s0+kS+1; dU rows rr-2..rr on columns s0-1..s0+kS.
 // ------------------------------------------------------------------------------------------------
 template <typename T>
@@ -216,22 +170,21 @@ __global__ __launch_bounds__(kMaxStrips * kWave) void token_apply_bwd_nhwc(
     const T* __restrict__ dout, const T* __restrict__ x, const T* __restrict__ o, const float* __restrict__ stats,
     const float* __restrict__ wx, const float* __restrict__ bx, const float* __restrict__ wo,
     const float* __restrict__ bo, const float* __restrict__ wv, const float* __restrict__ gate,
-    const float* __restrict__ lam, const float* __restrict__ dyx, float* __restrict__ dxn, float* __restrict__ part,
+    const float* __restrict__ lam, float* __restrict__ dxn, float* __restrict__ part, float* __restrict__ bmom,
     int n, int C, int side, int d) {
-  MRLA_TOK_PROLOGUE(TQ_N)
+  MRLA_TOK_PROLOGUE(TQ_N + 1)
   float w[9];
 #pragma unroll
   for (int k = 0; k < 9; ++k) w[k] = wv[c * 9 + k];
   const float a = gate[(size_t)b * (C / d) + c / d];
   const float lm = lam[c], wxc = wx[c], bxc = bx[c], woc = wo[c], boc = bo[c];
-  const float dy = dyx[(size_t)b * C + c];
   const T* xi = x + ioff;
   const T* gi = dout + ioff;
   const T* oi = o + ioff;
   float* dxo = dxn + ioff;
-  float q[TQ_N];
+  float q[TQ_N + 1];                                 // (slot TQ_N: the bmom sum)
 #pragma unroll
-  for (int k = 0; k < TQ_N; ++k) q[k] = 0.f;
+  for (int k = 0; k < TQ_N + 1; ++k) q[k] = 0.f;
   for (int s = wave; s < nstrips; s += nwaves) {
     const int s0 = s * kS, nc = min(kS, W - s0);
     float xa[kS + 4], xb[kS + 4], xc[kS + 4];        // xn rows rr-1, rr, rr+1
@@ -292,6 +245,7 @@ __global__ __launch_bounds__(kMaxStrips * kWave) void token_apply_bwd_nhwc(
           uc[j] = du;
           if (own && j >= 1 && j <= kS && j - 1 < nc) {
             const float go = gv[j];
+            q[TQ_N] = fmaf(go, gelu_f(u), q[TQ_N]);                         // (shares the erf with gelu')
             const float2 so = tok_stat(stats, tok0, side, rr, col, TS_MO);
             const float ohat = (ov[j - 1] - so.x) * so.y;
             q[TQ_LAM] = fmaf(go, fmaf(ohat, woc, boc), q[TQ_LAM]);
@@ -313,11 +267,11 @@ __global__ __launch_bounds__(kMaxStrips * kWave) void token_apply_bwd_nhwc(
           s9 = fmaf(w[1], uc[j + 1], s9); s9 = fmaf(w[2], uc[j], s9);
           s9 = fmaf(w[3], ub[j + 2], s9); s9 = fmaf(w[4], ub[j + 1], s9); s9 = fmaf(w[5], ub[j], s9);
           s9 = fmaf(w[6], ua[j + 2], s9); s9 = fmaf(w[7], ua[j + 1], s9); s9 = fmaf(w[8], ua[j], s9);
-          s9 += dy;
           yrow[j] = s9;
           if (j < nc) {
             q[TQ_LNXW] = fmaf(s9, h0[j], q[TQ_LNXW]);
             q[TQ_LNXB] += s9;
+            q[TQ_H] += h0[j];
           }
         }
         write_row<float, true, kS>(dxo, ro, s0, nc, W, C, cbase, c, true, lane, reinterpret_cast<float*>(scrS), yrow);
@@ -330,8 +284,12 @@ __global__ __launch_bounds__(kMaxStrips * kWave) void token_apply_bwd_nhwc(
       for (int j = 0; j < kS; ++j) { h0[j] = h1[j]; h1[j] = h2[j]; }
     }
   }
-  wg_reduce<TQ_N>(q, red, lane, wave, nwaves);
+  wg_reduce<TQ_N + 1>(q, red, lane, wave, nwaves);
   if (wave == 0) {
+    {   // (one band per image in this direction: the launcher never splits the rows)
+      float* bm = bmom + ((size_t)b * C + c) * D_N;
+      bm[D_D] = 0.f; bm[D_DV] = q[TQ_N]; bm[D_DO] = 0.f;
+    }
     if (blockIdx.z == 0) {
       // cls row: the module output there is LN_x(x) itself
       const size_t g = (size_t)b * n * C + c;
@@ -363,7 +321,8 @@ bool token_nhwc_applies(int C) { return C % kWave == 0; }
 // Row bands of the forward apply kernel: a 14 x 14 map gives a wave only 14 dependent row steps and the grid only
 // (C/64) * B two-wave workgroups; splitting the rows (one halo row of recompute) doubles the waves in flight: 0.59 ->
 // 0.45 ms per step on deit_mrlal_tiny.  The backward kernel supports bands as well but is bound by its arithmetic
-// (exact GELU and its derivative per pixel): the two halo rows per band made it 7 % slower, so it runs unbanded.
+// (exact GELU and its derivative per pixel): the two halo rows per band made it 7 % slower, so it runs unbanded (and its
+// bmom sum relies on that).
 int token_bands_bwd(int, int, int) { return 1; }
 int token_bands(int B, int C, int side) {
   if (!token_nhwc_applies(C)) return 1;
@@ -396,34 +355,18 @@ int launch_token_apply_fwd_nhwc(const void* x, const void* o, const float* stats
   return hip_status(hipGetLastError());
 }
 
-int launch_token_stats_bwd_nhwc(const void* dout, const void* x, const float* stats, const float* wx, const float* bx,
-                                const float* wv, float* bmom, int B, int n, int C, int side, int dtype, hipStream_t st) {
-  const int nwaves = std::min((side + kS - 1) / kS, kMaxStrips);
-  const dim3 grid(C / kWave, B), block(nwaves * kWave);
-  const size_t lds = tok_lds(nwaves, 1);
-#define CALL(TT)                                                                                                  \
-  {                                                                                                               \
-    if (set_lds_n(token_stats_bwd_nhwc<TT>, lds) != hipSuccess) return MRLA_EHIP;                                   \
-    hipLaunchKernelGGL((token_stats_bwd_nhwc<TT>), grid, block, lds, st, (const TT*)dout, (const TT*)x, stats, wx, bx, \
-                       wv, bmom, n, C, side);                                                                     \
-  }
-  MRLA_DISPATCH_TN(dtype, CALL)
-#undef CALL
-  return hip_status(hipGetLastError());
-}
-
 int launch_token_apply_bwd_nhwc(const void* dout, const void* x, const void* o, const float* stats, const float* wx,
                                 const float* bx, const float* wo, const float* bo, const float* wv, const float* gate,
-                                const float* lam, const float* dyx, float* dxn, float* part, int B, int n, int C,
-                                int side, int d, int dtype, hipStream_t st) {
+                                const float* lam, float* dxn, float* part, float* bmom, int B, int n, int C, int side,
+                                int d, int dtype, hipStream_t st) {
   const int nwaves = std::min((side + kS - 1) / kS, kMaxStrips);
   const dim3 grid(C / kWave, B, token_bands_bwd(B, C, side)), block(nwaves * kWave);
-  const size_t lds = tok_lds(nwaves, TQ_N);
+  const size_t lds = tok_lds(nwaves, TQ_N + 1);
 #define CALL(TT)                                                                                                   \
   {                                                                                                                \
     if (set_lds_n(token_apply_bwd_nhwc<TT>, lds) != hipSuccess) return MRLA_EHIP;                                    \
     hipLaunchKernelGGL((token_apply_bwd_nhwc<TT>), grid, block, lds, st, (const TT*)dout, (const TT*)x, (const TT*)o, \
-                       stats, wx, bx, wo, bo, wv, gate, lam, dyx, dxn, part, n, C, side, d);                       \
+                       stats, wx, bx, wo, bo, wv, gate, lam, dxn, part, bmom, n, C, side, d);                      \
   }
   MRLA_DISPATCH_TN(dtype, CALL)
 #undef CALL

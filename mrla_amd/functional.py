@@ -757,23 +757,23 @@ class _TokenLightFn(torch.autograd.Function):
             dout = dout.to(xc.dtype)
         dout = dout.contiguous()
         es = xc.element_size()
+        # one pass over the map (dxn without the pooled-descriptor term dy, bmom, the parameter partials); the gate backward
+        # turns bmom into dy and completes the LayerNorm partials with it; the LayerNorm backward adds dy as it reads dxn
         bmom = torch.empty((b, c, L.BWD_MOMENTS), dtype=torch.float32, device=dev)
-        _call("mrla_token_stats_bwd", xc.numel() * es * 2, _ptr(dout), _ptr(xc), _ptr(stats), _ptr(wxw), _ptr(wxb),
-              _ptr(wv32), _ptr(bmom), b, n, c, dt, st)
-        dyx = torch.empty((b, c), dtype=torch.float32, device=dev)
-        dwqk_part = torch.empty((b, 2 * ks), dtype=torch.float32, device=dev)
-        L.call("mrla_light_gate_bwd", _ptr(mom), _ptr(bmom), _ptr(gate), None, None, None, _ptr(wq32), _ptr(wk32), ks, _ptr(dyx),
-               _ptr(dwqk_part), b, c, n - 1, d, st)
         dxn = torch.empty((b, n, c), dtype=torch.float32, device=dev)
         prow = L.load().mrla_token_part_rows(b, n, c, dt)
         L.check(min(prow, 0), "mrla_token_part_rows")
         part = torch.empty((prow, c * L.TOKEN_PARTIALS), dtype=torch.float32, device=dev)
         _call("mrla_token_apply_bwd", xc.numel() * es * 3 + dxn.numel() * 4, _ptr(dout), _ptr(xc), _ptr(oc), _ptr(stats),
-              _ptr(wxw), _ptr(wxb), _ptr(wow), _ptr(wob), _ptr(wv32), _ptr(gate), _ptr(lam32), _ptr(dyx), _ptr(dxn),
-              _ptr(part), b, n, c, d, dt, st)
+              _ptr(wxw), _ptr(wxb), _ptr(wow), _ptr(wob), _ptr(wv32), _ptr(gate), _ptr(lam32), _ptr(dxn), _ptr(part),
+              _ptr(bmom), b, n, c, d, dt, st)
+        dyx = torch.empty((b, c), dtype=torch.float32, device=dev)
+        dwqk_part = torch.empty((b, 2 * ks), dtype=torch.float32, device=dev)
+        L.call("mrla_token_gate_bwd", _ptr(mom), _ptr(bmom), _ptr(gate), _ptr(wq32), _ptr(wk32), ks, _ptr(dyx),
+               _ptr(dwqk_part), _ptr(part), b, n, c, d, dt, st)
         dx, do = torch.empty_like(xc), torch.empty_like(oc)
         _call("mrla_token_ln_bwd", xc.numel() * es * 5 + dxn.numel() * 4, _ptr(dout), _ptr(xc), _ptr(oc), _ptr(dxn),
-              _ptr(stats), _ptr(wxw), _ptr(wow), _ptr(lam32), _ptr(dx), _ptr(do), b, n, c, res, dt, st)
+              _ptr(dyx), _ptr(stats), _ptr(wxw), _ptr(wow), _ptr(lam32), _ptr(dx), _ptr(do), b, n, c, res, dt, st)
         sums = torch.empty((c * L.TOKEN_PARTIALS + 2 * ks,), dtype=torch.float32, device=dev)
         L.call("mrla_reduce_rows2", _ptr(part), _ptr(sums), prow, c * L.TOKEN_PARTIALS, _ptr(dwqk_part),
                _ptr(sums[c * L.TOKEN_PARTIALS:]), b, 2 * ks, st)

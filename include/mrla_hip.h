@@ -58,7 +58,7 @@ enum { MRLA_BN_NONE = 0, MRLA_BN_TRAIN = 1, MRLA_BN_EVAL = 2 };
  *           mrla_conv1x1_plan, mrla_conv1x1_wgrad_plan, mrla_light_apply_bwd_pre_sums, mrla_reduce_rows2 and
  *           mrla_weight_bank_refresh were added;  the token backward became one pass: mrla_token_stats_bwd was removed,
  *           mrla_token_apply_bwd writes bmom and no longer takes dyx, MRLA_TOKEN_PARTIALS grew from 14 to 15,
- *           mrla_token_gate_bwd was added and mrla_token_ln_bwd gained dyx.
+ *           mrla_token_gate_bwd was added and mrla_token_ln_bwd gained dyx;  the mrla_token_base_* entry points were added.
  * A consumer compares mrla_abi_version() (what the loaded library was built from) against this constant before its
  * first call. */
 #define MRLA_ABI_VERSION 2
@@ -284,7 +284,8 @@ int mrla_base_value_bwd_dv(const void* dout, const void* x, const float* wv, con
 #define MRLA_TOKEN_PARTIALS 15 /* per (image, channel): dWv[9], dlambda, dlnx_w, dlnx_b, dlno_w, dlno_b, sum of xhat */
 
 /* LayerNorm statistics of x and o_prev; mom[b,c,0] = (n-1) * mean_{i>=1} LN_x(x)[b,i,c], other slots 0.
- * Replaces normx / normo statistics (deit_mrla_light.py:195-196) and avg_pool (:161). */
+ * Replaces normx / normo statistics (deit_mrla_light.py:195-196) and avg_pool (:161).  o_prev may be NULL (MRLA-base on
+ * tokens has no o_{t-1}): its two statistics slots then repeat x's. */
 int mrla_token_norm_pool(const void* x, const void* o_prev, const float* lnx_w, const float* lnx_b, float eps,
                          float* stats, float* mom, int b, int n, int c, int dtype, void* stream);
 
@@ -306,7 +307,8 @@ int mrla_token_apply_fwd(const void* x, const void* o_prev, const float* stats, 
  *   mrla_token_gate_bwd: mrla_light_gate_bwd on (mom, bmom) -> dyx[b,c] = dy/hw, dwqk_part[b, 2*ksize]; completes
  *       part[b,c,10] += dyx * part[.,c,14], part[b,c,11] += dy (the LN_x weight / bias partials).
  *   mrla_token_ln_bwd: dx = LN_x^T(dxn + dyx on map tokens) + res*dOut;  do_prev = LN_o^T(lam*dOut) on map tokens, 0 on
- *       the cls row.  dyx may be NULL (dxn already complete). */
+ *       the cls row.  dyx may be NULL (dxn already complete); o_prev may be NULL (then lno_w, lam, do_prev are not used and
+ *       only dx is written). */
 int mrla_token_part_rows(int b, int n, int c, int dtype);
 int mrla_token_apply_bwd(const void* dout, const void* x, const void* o_prev, const float* stats, const float* lnx_w,
                          const float* lnx_b, const float* lno_w, const float* lno_b, const float* wv,
@@ -318,6 +320,37 @@ int mrla_token_gate_bwd(const float* mom, const float* bmom, const float* gate, 
 int mrla_token_ln_bwd(const void* dout, const void* x, const void* o_prev, const float* dxn, const float* dyx,
                       const float* stats, const float* lnx_w, const float* lno_w, const float* lam, void* dx,
                       void* do_prev, int b, int n, int c, int res, int dtype, void* stream);
+
+/* ---- MRLA-base on token sequences (DeiT): deit/deit_mrla_base.py:204-243 (mrlab_module) -------------------------
+ * xt = normx(x); the 14x14 map tokens of xt go through mrla_base_layer (:120-201, the same math as the ResNet one) and
+ * come back behind the cls token of xt (:236-241).  LN_x(x) is never materialised and there is no token <-> map copy and
+ * no cat: the value map goes straight into the stage's slot-major NHWC ring ([T, b, side, side, c], a dense image per
+ * slot), the attend kernel writes the map rows of out[b, n, c] in place, the cls kernel the first row.
+ *   forward : mrla_token_norm_pool (o_prev = NULL) -> mrla_token_base_value_fwd (V_t -> v_ring slot t-1) ->
+ *             mrla_base_gate_fwd (hw = n - 1) -> mrla_token_base_attend_fwd
+ *   backward: mrla_token_base_attend_bwd (dA_t = the map rows of dOut -> da_ring slot t-1; pmom partials, rows =
+ *             mrla_base_pmom_rows(b, c, side, side, dtype, MRLA_NHWC)) -> mrla_base_pmom_reduce ->
+ *             mrla_token_base_gate_bwd (= mrla_base_gate_bwd + the completion of `part` with dy, as mrla_token_gate_bwd) ->
+ *             mrla_base_dv_combine (dense dV_t) -> mrla_token_base_value_bwd (dxn without dy, `part`) ->
+ *             mrla_token_ln_bwd (o_prev = NULL: only dx) -> (sum `part` over its rows)
+ * `part` is the [mrla_token_part_rows(), c, MRLA_TOKEN_PARTIALS] record of the light path (slots 0-8 dWv, 10 / 11
+ * dlnx_w / dlnx_b, 14 sum of xhat; the others zero).  amom: scratch [mrla_base_tile_rows(b, c, side, side, dtype,
+ * MRLA_NHWC), c, 2].  mrla_token_base_supported: 1 when these entry points take (n, c, dtype) (c % 64 == 0), else 0. */
+int mrla_token_base_supported(int b, int n, int c, int dtype);
+int mrla_token_base_value_fwd(const void* x, const float* stats, const float* lnx_w, const float* lnx_b, const float* wv,
+                              void* v_slot, int b, int n, int c, int dtype, void* stream);
+int mrla_token_base_attend_fwd(const void* v_ring, const float* p_all, const void* x, const float* stats,
+                               const float* lnx_w, const float* lnx_b, void* out, float* amom, int b, int n, int c, int d,
+                               int T, int t, int dtype, void* stream);
+int mrla_token_base_attend_bwd(const void* dout, const void* v_ring, void* da_ring, float* pmom_part, int b, int n, int c,
+                               int T, int t, int dtype, void* stream);
+int mrla_token_base_gate_bwd(const float* mom, const float* pmom, const float* p_all, const float* q, const float* k_ring,
+                             float* dk_ring, const float* wq, const float* wk, int ksize, float* dyx, float* dwqk_part,
+                             float* part, int b, int n, int c, int d, int T, int t, int first_touch, int dtype,
+                             void* stream);
+int mrla_token_base_value_bwd(const void* dout, const void* x, const float* stats, const float* lnx_w, const float* lnx_b,
+                              const float* wv, const void* dv, float* dxn, float* part, int b, int n, int c, int dtype,
+                              void* stream);
 
 /* =====================================================================================================
  * Fused BatchNorm2d (+ReLU) in front of the MRLA tail (reference call sites

@@ -61,6 +61,12 @@ SIGNATURES = {
     "mrla_token_apply_bwd": [_P] * 14 + [_I] * 5 + [_P],
     "mrla_token_gate_bwd": [_P] * 5 + [_I] + [_P] * 3 + [_I] * 5 + [_P],
     "mrla_token_ln_bwd": [_P] * 11 + [_I] * 5 + [_P],
+    "mrla_token_base_supported": [_I] * 4,
+    "mrla_token_base_value_fwd": [_P] * 6 + [_I] * 4 + [_P],
+    "mrla_token_base_attend_fwd": [_P] * 8 + [_I] * 7 + [_P],
+    "mrla_token_base_attend_bwd": [_P] * 4 + [_I] * 6 + [_P],
+    "mrla_token_base_gate_bwd": [_P] * 8 + [_I] + [_P] * 3 + [_I] * 8 + [_P],
+    "mrla_token_base_value_bwd": [_P] * 9 + [_I] * 4 + [_P],
     "mrla_bn_moment_rows": [_I] * 5,
     "mrla_bn_plane_moments": [_P, _P, _P, _I, _I, _I, _I, _I, _I, _P],
     "mrla_bn_act_fwd": [_P, _P, _P, _I, _P, _I, _I, _I, _I, _I, _I, _P],

@@ -549,7 +549,8 @@ __global__ __launch_bounds__(kThreads) void base_gate_bwd_kernel(
     const float* __restrict__ mom, const float* __restrict__ pmom /*[b,c,t]*/, const float* __restrict__ Pall,
     const float* __restrict__ q, const float* __restrict__ Kring, float* __restrict__ dKring,
     const float* __restrict__ wq, const float* __restrict__ wk, int ks, float* __restrict__ dyx,
-    float* __restrict__ dwqk_part, int C, int HW, int d, int T, int t, int first_touch, int stage_pmom) {
+    float* __restrict__ dwqk_part, int C, int HW, int d, int T, int t, int first_touch, int stage_pmom,
+    float* __restrict__ tok_part, int tok_bands) {
   extern __shared__ float sm[];
   const int p = (ks - 1) / 2;
   const int CPD = C + 2 * p;
@@ -654,6 +655,13 @@ __global__ __launch_bounds__(kThreads) void base_gate_bwd_kernel(
       dy = fmaf(wk[j], dks[c - j + 2 * p], dy);
     }
     dyx[(size_t)b * C + c] = dy * inv_hw;
+    if (tok_part) {    // token path (see gate_bwd_kernel in gate.hip): complete the LayerNorm parameter partials with dy
+      float hsum = 0.f;
+      for (int z = 0; z < tok_bands; ++z) hsum += tok_part[(((size_t)z * gridDim.x + b) * C + c) * kTokParts + kTokPartHat];
+      float* pr = tok_part + ((size_t)b * C + c) * kTokParts;
+      pr[kTokPartLnxW] = fmaf(dy * inv_hw, hsum, pr[kTokPartLnxW]);
+      pr[kTokPartLnxB] += dy;
+    }
   }
   for (int j = 0; j < ks; ++j) {
     float aq = 0.f, ak = 0.f;
@@ -916,7 +924,8 @@ int launch_base_attend_bwd(const void* dout, const void* attn, const float* sc, 
 
 int launch_base_gate_bwd(const float* mom, const float* pmom, const float* Pall, const float* q, const float* Kring,
                          float* dKring, const float* wq, const float* wk, int ks, float* dyx, float* dwqk_part, int B,
-                         int C, int HW, int d, int T, int t, int first_touch, hipStream_t st) {
+                         int C, int HW, int d, int T, int t, int first_touch, hipStream_t st, float* tok_part,
+                         int tok_bands) {
   const int p = (ks - 1) / 2;
   size_t lds = (size_t)(3 * (C + 2 * p) + (C / d) * t + kWaves) * sizeof(float);
   if (lds > 64 * 1024 || (C & 3)) return MRLA_EUNSUPPORTED;
@@ -925,7 +934,7 @@ int launch_base_gate_bwd(const float* mom, const float* pmom, const float* Pall,
   if (stage_pmom) lds = staged;
   if (set_lds2(base_gate_bwd_kernel, lds) != hipSuccess) return MRLA_EHIP;
   hipLaunchKernelGGL(base_gate_bwd_kernel, dim3(B), dim3(kThreads), lds, st, mom, pmom, Pall, q, Kring, dKring, wq, wk,
-                     ks, dyx, dwqk_part, C, HW, d, T, t, first_touch, stage_pmom);
+                     ks, dyx, dwqk_part, C, HW, d, T, t, first_touch, stage_pmom, tok_part, tok_bands);
   return hip_status(hipGetLastError());
 }
 

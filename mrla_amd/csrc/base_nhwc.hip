@@ -63,6 +63,9 @@ __device__ __forceinline__ void unpack(const u32x4& r, float (&v)[16 / sizeof(T)
 struct FlatGeo {
   int B, C, HW, R, tiles;       // R pixels per tile, tiles per image
   int nvec;                     // 16-byte vectors per tile (R * C / VEC)
+  // The layer's EXTERNAL tensor (attend forward: out; attend backward: dOut) may be the map rows of a token tensor
+  // [b, 1 + HW, C] (deit/deit_mrla_base.py:236-241) instead of a dense image: elements to skip per image and up front.
+  int ext_gap, ext_off;
 };
 
 // per-thread coefficient of history slot `row/col` for its VEC channels (one value when VEC | d and aligned)
@@ -113,6 +116,7 @@ __global__ __launch_bounds__(kThreads) void base_combine_nhwc(const T* __restric
   const int c0 = (tid * VEC) % g.C;
   const size_t slot = (size_t)g.B * g.HW * g.C;
   const size_t base = ((size_t)b * g.HW + (size_t)tile * g.R) * g.C + (size_t)tid * VEC;
+  const size_t obase = base + (size_t)b * g.ext_gap + g.ext_off;
   float acc[NV][VEC];
 #pragma unroll
   for (int i = 0; i < NV; ++i)
@@ -155,7 +159,7 @@ __global__ __launch_bounds__(kThreads) void base_combine_nhwc(const T* __restric
   for (int i = 0; i < NV; ++i) {
     if (tid + i * NT < g.nvec) {
       if constexpr (MODE == 0) {
-        stv<T>(reinterpret_cast<T*>(out) + base + (size_t)i * NT * VEC, acc[i]);
+        stv<T>(reinterpret_cast<T*>(out) + obase + (size_t)i * NT * VEC, acc[i]);
 #pragma unroll
         for (int k = 0; k < VEC; ++k) {
           const float a = to_f(from_f<T>(acc[i][k]));       // statistics of the rounded values the tail reads back
@@ -163,7 +167,7 @@ __global__ __launch_bounds__(kThreads) void base_combine_nhwc(const T* __restric
           s2[k] = fmaf(a, a, s2[k]);
         }
       } else {
-        stv<T>(reinterpret_cast<T*>(out) + base + (size_t)i * NT * VEC, acc[i]);
+        stv<T>(reinterpret_cast<T*>(out) + obase + (size_t)i * NT * VEC, acc[i]);
       }
     }
   }
@@ -233,6 +237,7 @@ __global__ __launch_bounds__(kThreads, OCC) void base_attend_bwd_nhwc(
   const int c0 = (tid * VEC) % g.C;
   const size_t slot = (size_t)g.B * g.HW * g.C;
   const size_t base = ((size_t)b * g.HW + (size_t)tile * g.R) * g.C + (size_t)tid * VEC;
+  const size_t gbase = base + (size_t)b * g.ext_gap + g.ext_off;
   u32x4 da[kNV];                                 // this thread's slice of dA_t, rounded to T, packed
   u32x4 raw[kNV];
   auto issue = [&](int j) {
@@ -263,7 +268,7 @@ __global__ __launch_bounds__(kThreads, OCC) void base_attend_bwd_nhwc(
         graw[k] = (u32x4){0u, 0u, 0u, 0u};
         araw[k] = (u32x4){0u, 0u, 0u, 0u};
         if (tid + i * NT < g.nvec) {
-          graw[k] = ldraw<T>(dout + base + (size_t)i * NT * VEC);
+          graw[k] = ldraw<T>(dout + gbase + (size_t)i * NT * VEC);
           if (attn) araw[k] = ldraw<T>(attn + base + (size_t)i * NT * VEC);
         }
       }
@@ -443,6 +448,7 @@ static FlatGeo flat_geo(int B, int C, int HW, int dtype, int nv) {
     if (HW % r == 0) R = r;
   FlatGeo g;
   g.B = B; g.C = C; g.HW = HW; g.R = R; g.tiles = HW / R; g.nvec = R * C / vec;
+  g.ext_gap = 0; g.ext_off = 0;
   return g;
 }
 
@@ -459,9 +465,10 @@ int base_nhwc_pmom_tiles(int B, int C, int HW, int dtype) { return flat_geo(B, C
   }
 
 int launch_base_attend_fwd_nhwc(const void* Vring, const float* Pall, void* attn, float* amom_part, int B, int C, int HW,
-                                int d, int T, int t, int dtype, hipStream_t st) {
+                                int d, int T, int t, int dtype, hipStream_t st, int ext_gap, int ext_off) {
   if (!base_nhwc_supported(C, dtype)) return MRLA_EUNSUPPORTED;
-  const FlatGeo g = flat_geo(B, C, HW, dtype, kNVc);
+  FlatGeo g = flat_geo(B, C, HW, dtype, kNVc);
+  g.ext_gap = ext_gap; g.ext_off = ext_off;
 #define CALL(TT)                                                                                                         \
   hipLaunchKernelGGL((base_combine_nhwc<TT, TT, 0, kNVc>), dim3(g.tiles, B), dim3(flat_threads(C, dtype)), 0, st, (const TT*)Vring, Pall, \
                      (TT*)attn, amom_part, g, d, T, t, t);
@@ -496,9 +503,10 @@ int launch_base_tail_fwd_nhwc(const void* x, const void* attn, const float* sc, 
 
 int launch_base_attend_bwd_nhwc(const void* dout, const void* attn, const float* sc, const float* sh, const float* dp,
                                 const float* cb, const void* Vring, void* dAring, float* pmom_part, int B, int C, int HW,
-                                int T, int t, int dtype, hipStream_t st) {
+                                int T, int t, int dtype, hipStream_t st, int ext_gap, int ext_off) {
   if (!base_nhwc_supported(C, dtype)) return MRLA_EUNSUPPORTED;
-  const FlatGeo g = flat_geo(B, C, HW, dtype, kNV);
+  FlatGeo g = flat_geo(B, C, HW, dtype, kNV);
+  g.ext_gap = ext_gap; g.ext_off = ext_off;
 #define CALL_O(TT, OCC)                                                                                           \
   hipLaunchKernelGGL((base_attend_bwd_nhwc<TT, OCC>), dim3(g.tiles, B), dim3(flat_threads(C, dtype)), 0, st, (const TT*)dout,    \
                      (const TT*)attn, sc, sh, dp, cb, (const TT*)Vring, (TT*)dAring, pmom_part, g, T, t);

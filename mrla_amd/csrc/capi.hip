@@ -428,7 +428,7 @@ static int token_side(int n) {
 
 int mrla_token_norm_pool(const void* x, const void* o_prev, const float* lnx_w, const float* lnx_b, float eps,
                          float* stats, float* mom, int b, int n, int c, int dtype, void* stream) {
-  if (!x || !o_prev || !lnx_w || !lnx_b || !stats || !mom || b <= 0 || c <= 0 || bad_dtype(dtype) || !token_side(n))
+  if (!x || !lnx_w || !lnx_b || !stats || !mom || b <= 0 || c <= 0 || bad_dtype(dtype) || !token_side(n))
     return MRLA_EINVAL;
   return launch_token_norm_pool(x, o_prev, lnx_w, lnx_b, eps, stats, mom, b, n, c, dtype, (hipStream_t)stream);
 }
@@ -473,11 +473,66 @@ int mrla_token_gate_bwd(const float* mom, const float* bmom, const float* gate, 
 int mrla_token_ln_bwd(const void* dout, const void* x, const void* o_prev, const float* dxn, const float* dyx,
                       const float* stats, const float* lnx_w, const float* lno_w, const float* lam, void* dx,
                       void* do_prev, int b, int n, int c, int res, int dtype, void* stream) {
-  if (!dout || !x || !o_prev || !dxn || !stats || !lnx_w || !lno_w || !lam || !dx || !do_prev || b <= 0 || c <= 0 ||
-      bad_dtype(dtype) || !token_side(n))
+  if (!dout || !x || !dxn || !stats || !lnx_w || !dx || b <= 0 || c <= 0 || bad_dtype(dtype) || !token_side(n) ||
+      (o_prev && (!lno_w || !lam || !do_prev)))
     return MRLA_EINVAL;
   return launch_token_ln_bwd(dout, x, o_prev, dxn, dyx, stats, lnx_w, lno_w, lam, dx, do_prev, b, n, c, res, dtype,
                              (hipStream_t)stream);
+}
+
+// ---- MRLA-base on tokens (deit/deit_mrla_base.py:224-243) ------------------------------------------------------------
+int mrla_token_base_supported(int b, int n, int c, int dtype) {
+  if (b <= 0 || c <= 0 || bad_dtype(dtype) || !token_side(n)) return MRLA_EINVAL;
+  return (token_nhwc_applies(c) && base_nhwc_supported(c, dtype)) ? 1 : 0;
+}
+
+int mrla_token_base_value_fwd(const void* x, const float* stats, const float* lnx_w, const float* lnx_b, const float* wv,
+                              void* v_slot, int b, int n, int c, int dtype, void* stream) {
+  if (!x || !stats || !lnx_w || !lnx_b || !wv || !v_slot || b <= 0 || c <= 0 || bad_dtype(dtype) || !token_side(n))
+    return MRLA_EINVAL;
+  return launch_token_value_fwd_nhwc(x, stats, lnx_w, lnx_b, wv, v_slot, b, n, c, token_side(n), dtype,
+                                     (hipStream_t)stream);
+}
+
+int mrla_token_base_attend_fwd(const void* v_ring, const float* p_all, const void* x, const float* stats,
+                               const float* lnx_w, const float* lnx_b, void* out, float* amom, int b, int n, int c, int d,
+                               int T, int t, int dtype, void* stream) {
+  if (!v_ring || !p_all || !x || !stats || !lnx_w || !lnx_b || !out || !amom || b <= 0 || c <= 0 || d <= 0 || c % d ||
+      bad_dtype(dtype) || !token_side(n) || bad_ring(T, t))
+    return MRLA_EINVAL;
+  // the map rows of out[b, n, c]: c elements more per image than a dense map, the first one c elements in
+  const int rc = launch_base_attend_fwd_nhwc(v_ring, p_all, out, amom, b, c, n - 1, d, T, t, dtype, (hipStream_t)stream, c, c);
+  if (rc != MRLA_OK) return rc;
+  return launch_token_cls_fwd(x, stats, lnx_w, lnx_b, out, b, n, c, dtype, (hipStream_t)stream);
+}
+
+int mrla_token_base_attend_bwd(const void* dout, const void* v_ring, void* da_ring, float* pmom_part, int b, int n, int c,
+                               int T, int t, int dtype, void* stream) {
+  if (!dout || !v_ring || !da_ring || !pmom_part || b <= 0 || c <= 0 || bad_dtype(dtype) || !token_side(n) || bad_ring(T, t))
+    return MRLA_EINVAL;
+  return launch_base_attend_bwd_nhwc(dout, nullptr, nullptr, nullptr, nullptr, nullptr, v_ring, da_ring, pmom_part, b, c,
+                                     n - 1, T, t, dtype, (hipStream_t)stream, c, c);
+}
+
+int mrla_token_base_gate_bwd(const float* mom, const float* pmom, const float* p_all, const float* q, const float* k_ring,
+                             float* dk_ring, const float* wq, const float* wk, int ksize, float* dyx, float* dwqk_part,
+                             float* part, int b, int n, int c, int d, int T, int t, int first_touch, int dtype,
+                             void* stream) {
+  if (!mom || !pmom || !p_all || !q || !k_ring || !dk_ring || !wq || !wk || !dyx || !dwqk_part || !part || b <= 0 ||
+      c <= 0 || d <= 0 || c % d || ksize <= 0 || !(ksize & 1) || bad_dtype(dtype) || !token_side(n) || bad_ring(T, t))
+    return MRLA_EINVAL;
+  return launch_base_gate_bwd(mom, pmom, p_all, q, k_ring, dk_ring, wq, wk, ksize, dyx, dwqk_part, b, c, n - 1, d, T, t,
+                              first_touch, (hipStream_t)stream, part, token_bands_bwd(b, c, token_side(n)));
+}
+
+int mrla_token_base_value_bwd(const void* dout, const void* x, const float* stats, const float* lnx_w, const float* lnx_b,
+                              const float* wv, const void* dv, float* dxn, float* part, int b, int n, int c, int dtype,
+                              void* stream) {
+  if (!dout || !x || !stats || !lnx_w || !lnx_b || !wv || !dv || !dxn || !part || b <= 0 || c <= 0 || bad_dtype(dtype) ||
+      !token_side(n))
+    return MRLA_EINVAL;
+  return launch_token_value_bwd_nhwc(dout, x, stats, lnx_w, lnx_b, wv, dv, dxn, part, b, n, c, token_side(n), dtype,
+                                     (hipStream_t)stream);
 }
 
 int mrla_bn_plane_moments(const void* x, float* amom, float* pivot, int b, int c, int h, int w, int dtype, int layout,

@@ -90,7 +90,8 @@ int launch_base_attend_bwd(const void* dout, const void* attn, const float* sc, 
                            int t, int dtype, hipStream_t st);
 int launch_base_gate_bwd(const float* mom, const float* pmom, const float* Pall, const float* q, const float* Kring,
                          float* dKring, const float* wq, const float* wk, int ks, float* dyx, float* dwqk_part, int B,
-                         int C, int HW, int d, int T, int t, int first_touch, hipStream_t st);
+                         int C, int HW, int d, int T, int t, int first_touch, hipStream_t st, float* tok_part = nullptr,
+                         int tok_bands = 0);
 int launch_base_value_bwd(const void* dout, const void* x, const float* wv, const void* dAring, const float* Pall,
                           const float* dyx, void* dx, float* dwv_part, const SlabGeo& g, int d, int T, int t, int Tc,
                           int res, int dtype, hipStream_t st);
@@ -113,14 +114,14 @@ bool base_nhwc_supported(int C, int dtype);
 int base_nhwc_tiles(int B, int C, int HW, int dtype);
 int base_nhwc_pmom_tiles(int B, int C, int HW, int dtype);
 int launch_base_attend_fwd_nhwc(const void* Vring, const float* Pall, void* attn, float* amom_part, int B, int C, int HW,
-                                int d, int T, int t, int dtype, hipStream_t st);
+                                int d, int T, int t, int dtype, hipStream_t st, int ext_gap = 0, int ext_off = 0);
 int launch_base_dv_combine_nhwc(const void* dAring, const float* Pall, void* dv, int B, int C, int HW, int d, int T,
                                 int t, int Tc, int dtype, hipStream_t st);
 int launch_base_tail_fwd_nhwc(const void* x, const void* attn, const float* sc, const float* sh, const float* dp,
                               void* out, int B, int C, int HW, int dtype, hipStream_t st);
 int launch_base_attend_bwd_nhwc(const void* dout, const void* attn, const float* sc, const float* sh, const float* dp,
                                 const float* cb, const void* Vring, void* dAring, float* pmom_part, int B, int C, int HW,
-                                int T, int t, int dtype, hipStream_t st);
+                                int T, int t, int dtype, hipStream_t st, int ext_gap = 0, int ext_off = 0);
 int launch_base_pmom_reduce(const float* part, float* pmom, int B, int C, int t, int tiles, hipStream_t st);
 int launch_base_value_bwd_nhwc(const void* dout, const void* x, const float* wv, const void* dv, const float* dyx,
                                void* dx, float* dwv_part, int B, int C, int H, int W, int res, int dtype,
@@ -128,6 +129,13 @@ int launch_base_value_bwd_nhwc(const void* dout, const void* x, const float* wv,
 
 
 // tokens.hip -- MRLA-light on token sequences (DeiT)
+int launch_token_value_fwd_nhwc(const void* x, const float* stats, const float* wx, const float* bx, const float* wv,
+                                void* vslot, int B, int n, int C, int side, int dtype, hipStream_t st);
+int launch_token_cls_fwd(const void* x, const float* stats, const float* wx, const float* bx, void* out, int B, int n,
+                         int C, int dtype, hipStream_t st);
+int launch_token_value_bwd_nhwc(const void* dout, const void* x, const float* stats, const float* wx, const float* bx,
+                                const float* wv, const void* dv, float* dxn, float* part, int B, int n, int C, int side,
+                                int dtype, hipStream_t st);
 int launch_token_norm_pool(const void* x, const void* o, const float* wx, const float* bx, float eps, float* stats,
                            float* mom, int B, int n, int C, int dtype, hipStream_t st);
 int launch_token_apply_fwd(const void* x, const void* o, const float* stats, const float* wx, const float* bx,

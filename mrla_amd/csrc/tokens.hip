@@ -293,7 +293,8 @@ __global__ __launch_bounds__(kThreads) void token_apply_bwd_kernel(
 
 // ------------------------------------------------------------------------------------------------
 // per token: backward of both LayerNorms.  dx = LN_x^T(dxn' + dy on the map rows) + res*dOut ;  do = LN_o^T(lam*dOut)
-// (cls row: 0).  dyx [b, c]: the pooled-descriptor gradient / hw from the gate backward (null: dxn is complete)
+// (cls row: 0).  dyx [b, c]: the pooled-descriptor gradient / hw from the gate backward (null: dxn is complete);
+// o == null (MRLA-base on tokens): only dx
 // ------------------------------------------------------------------------------------------------
 template <typename T>
 __global__ __launch_bounds__(kThreads) void token_ln_bwd_kernel(
@@ -315,7 +316,7 @@ __global__ __launch_bounds__(kThreads) void token_ln_bwd_kernel(
     const float xh = (to_f(x[base + c]) - mx) * rx;
     s1 += dh;
     s2 = fmaf(dh, xh, s2);
-    if (i >= 1) {
+    if (o && i >= 1) {
       const float dho = lam[c] * to_f(dout[base + c]) * wo[c];
       const float oh = (to_f(o[base + c]) - mo) * ro;
       t1 += dho;
@@ -334,6 +335,7 @@ __global__ __launch_bounds__(kThreads) void token_ln_bwd_kernel(
     float y = rx * (dh - s1 - xh * s2);
     if (res) y += go;
     dx[base + c] = from_f<T>(y);
+    if (!o) continue;
     float z = 0.f;
     if (i >= 1) {
       const float dho = lam[c] * go * wo[c];
@@ -367,6 +369,7 @@ static hipError_t set_lds3(K kernel, size_t bytes) {
 int launch_token_norm_pool(const void* x, const void* o, const float* wx, const float* bx, float eps, float* stats,
                            float* mom, int B, int n, int C, int dtype, hipStream_t st) {
   if (C > kWave * kTokRowRegs) return MRLA_EUNSUPPORTED;
+  if (!o) o = x;                        // MRLA-base on tokens has no o_{t-1}: its two statistics slots repeat x's
   const int ntok = B * n;
   const int wgs = std::max(1, std::min((ntok + kWaves - 1) / kWaves, 256 * 32));
 #define CALL(TT)                                                                                                     \

@@ -306,6 +306,151 @@ __global__ __launch_bounds__(kMaxStrips * kWave) void token_apply_bwd_nhwc(
 }
 
 // ------------------------------------------------------------------------------------------------
+// MRLA-base on tokens (deit/deit_mrla_base.py:224-243): the value map V_t = dwconv3x3(LN_x(x) map) goes straight into the
+// stage's slot-major NHWC ring (a dense [b, side, side, c] image per slot) -- LN_x(x) itself is never materialised --
+// and the backward turns dV_t (dense, from mrla_base_dv_combine) into dxn' on the token rows.  Same row windows as above.
+// ------------------------------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(kMaxStrips * kWave) void token_value_fwd_nhwc(
+    const T* __restrict__ x, const float* __restrict__ stats, const float* __restrict__ wx, const float* __restrict__ bx,
+    const float* __restrict__ wv, T* __restrict__ vslot, int n, int C, int side) {
+  MRLA_TOK_PROLOGUE(0)
+  float w[9];
+#pragma unroll
+  for (int k = 0; k < 9; ++k) w[k] = wv[c * 9 + k];
+  const float wxc = wx[c], bxc = bx[c];
+  const T* xi = x + ioff;
+  T* vo = vslot + (size_t)b * H * W * C;
+  for (int s = wave; s < nstrips; s += nwaves) {
+    const int s0 = s * kS, nc = min(kS, W - s0);
+    float ra[kS + 2], rb[kS + 2], rc[kS + 2];
+    RowLoad<T, kS + 2> qx;
+    RowAddr<T, kS + 2> ax;
+    make_row_addr<T, kS + 2>(ax, s0 - 1, W, C, cbase, lane);
+    read_row<T, true, kS + 2>(xi, r0 - 1, s0 - 1, H, W, C, cbase, c, lane, scrT, ra);
+    normalise_row<kS + 2>(ra, stats, tok0, side, r0 - 1, s0 - 1, wxc, bxc);
+    read_row<T, true, kS + 2>(xi, r0, s0 - 1, H, W, C, cbase, c, lane, scrT, rb);
+    normalise_row<kS + 2>(rb, stats, tok0, side, r0, s0 - 1, wxc, bxc);
+    issue_row<T, kS + 2>(qx, xi, r0 + 1, H, W * C, ax);
+    for (int r = r0; r < r1; ++r) {
+      float y[kS];
+      finish_row<T, kS + 2>(qx, lane, scrT, rc);
+      issue_row<T, kS + 2>(qx, xi, r + 2, H, W * C, ax);
+      normalise_row<kS + 2>(rc, stats, tok0, side, r + 1, s0 - 1, wxc, bxc);
+#pragma unroll
+      for (int j = 0; j < kS; ++j) y[j] = conv_at(w, ra, rb, rc, j);
+      write_row<T, true, kS>(vo, r, s0, nc, W, C, cbase, c, true, lane, reinterpret_cast<T*>(scrS), y);
+#pragma unroll
+      for (int j = 0; j < kS + 2; ++j) { ra[j] = rb[j]; rb[j] = rc[j]; }
+    }
+  }
+}
+
+//   dxn'[i] = sum_{di,dj} wv[di][dj] * dV[i - (di,dj)]   (fp32, map rows; the cls row: dxn' = dOut), and the partials
+//   dWv (slots 0-8), dlnx_w / dlnx_b without dy's share (10, 11), sum xhat (14); the other slots are zero.
+// Windows per strip: xn rows rr-1..rr+1 and dV rows rr-2..rr, both on columns s0-1..s0+kS.
+template <typename T>
+__global__ __launch_bounds__(kMaxStrips * kWave) void token_value_bwd_nhwc(
+    const T* __restrict__ dout, const T* __restrict__ x, const float* __restrict__ stats, const float* __restrict__ wx,
+    const float* __restrict__ bx, const float* __restrict__ wv, const T* __restrict__ dv, float* __restrict__ dxn,
+    float* __restrict__ part, int n, int C, int side) {
+  MRLA_TOK_PROLOGUE(TQ_N)
+  float w[9];
+#pragma unroll
+  for (int k = 0; k < 9; ++k) w[k] = wv[c * 9 + k];
+  const float wxc = wx[c], bxc = bx[c];
+  const T* xi = x + ioff;
+  const T* di = dv + (size_t)b * H * W * C;
+  float* dxo = dxn + ioff;
+  float q[TQ_N];
+#pragma unroll
+  for (int k = 0; k < TQ_N; ++k) q[k] = 0.f;
+  for (int s = wave; s < nstrips; s += nwaves) {
+    const int s0 = s * kS, nc = min(kS, W - s0);
+    float xa[kS + 2], xb[kS + 2], xc[kS + 2];        // xn rows rr-1, rr, rr+1
+    float ua[kS + 2], ub[kS + 2], uc[kS + 2];        // dV rows rr-2, rr-1, rr
+    float h0[kS], h1[kS], h2[kS];                    // xhat of the owned pixels, rows rr-1..rr+1
+    RowLoad<T, kS + 2> qx, qd;
+    RowAddr<T, kS + 2> ax;
+    make_row_addr<T, kS + 2>(ax, s0 - 1, W, C, cbase, lane);
+#pragma unroll
+    for (int j = 0; j < kS + 2; ++j) { ua[j] = 0.f; ub[j] = 0.f; }
+    const int rs = r0 - 1;
+    {
+      float hat[kS + 2];
+      read_row<T, true, kS + 2>(xi, rs - 1, s0 - 1, H, W, C, cbase, c, lane, scrT, xa);
+      normalise_row_hat<kS + 2>(xa, hat, stats, tok0, side, rs - 1, s0 - 1, wxc, bxc);
+#pragma unroll
+      for (int j = 0; j < kS; ++j) h0[j] = hat[j + 1];
+      read_row<T, true, kS + 2>(xi, rs, s0 - 1, H, W, C, cbase, c, lane, scrT, xb);
+      normalise_row_hat<kS + 2>(xb, hat, stats, tok0, side, rs, s0 - 1, wxc, bxc);
+#pragma unroll
+      for (int j = 0; j < kS; ++j) h1[j] = hat[j + 1];
+    }
+    issue_row<T, kS + 2>(qx, xi, rs + 1, H, W * C, ax);
+    issue_row<T, kS + 2>(qd, di, rs, H, W * C, ax);
+    for (int rr = rs; rr <= r1; ++rr) {
+      const bool own = rr >= r0 && rr < r1;
+      finish_row<T, kS + 2>(qx, lane, scrT, xc);
+      finish_row<T, kS + 2>(qd, lane, scrT, uc);       // (rows and columns outside the map arrive as zeros)
+      issue_row<T, kS + 2>(qx, xi, rr + 2, H, W * C, ax);
+      issue_row<T, kS + 2>(qd, di, rr + 1, H, W * C, ax);
+      {
+        float hat[kS + 2];
+        normalise_row_hat<kS + 2>(xc, hat, stats, tok0, side, rr + 1, s0 - 1, wxc, bxc);
+#pragma unroll
+        for (int j = 0; j < kS; ++j) h2[j] = hat[j + 1];
+      }
+      if (own) {
+#pragma unroll
+        for (int j = 0; j < kS; ++j) {
+          // dWv[i][k] += dV[rr][col] * xn[rr+i-1][col+k-1]   (owned column j <-> window index j+1)
+          const float du = uc[j + 1];                // (zero beyond the map's last column)
+          q[0] = fmaf(du, xa[j], q[0]); q[1] = fmaf(du, xa[j + 1], q[1]); q[2] = fmaf(du, xa[j + 2], q[2]);
+          q[3] = fmaf(du, xb[j], q[3]); q[4] = fmaf(du, xb[j + 1], q[4]); q[5] = fmaf(du, xb[j + 2], q[5]);
+          q[6] = fmaf(du, xc[j], q[6]); q[7] = fmaf(du, xc[j + 1], q[7]); q[8] = fmaf(du, xc[j + 2], q[8]);
+        }
+      }
+      if (rr - 1 >= r0) {
+        const int ro = rr - 1;
+        float yrow[kS];
+#pragma unroll
+        for (int j = 0; j < kS; ++j) {
+          float s9 = w[0] * uc[j + 2];
+          s9 = fmaf(w[1], uc[j + 1], s9); s9 = fmaf(w[2], uc[j], s9);
+          s9 = fmaf(w[3], ub[j + 2], s9); s9 = fmaf(w[4], ub[j + 1], s9); s9 = fmaf(w[5], ub[j], s9);
+          s9 = fmaf(w[6], ua[j + 2], s9); s9 = fmaf(w[7], ua[j + 1], s9); s9 = fmaf(w[8], ua[j], s9);
+          yrow[j] = s9;
+          if (j < nc) {
+            q[TQ_LNXW] = fmaf(s9, h0[j], q[TQ_LNXW]);
+            q[TQ_LNXB] += s9;
+            q[TQ_H] += h0[j];
+          }
+        }
+        write_row<float, true, kS>(dxo, ro, s0, nc, W, C, cbase, c, true, lane, reinterpret_cast<float*>(scrS), yrow);
+      }
+#pragma unroll
+      for (int j = 0; j < kS + 2; ++j) { xa[j] = xb[j]; xb[j] = xc[j]; ua[j] = ub[j]; ub[j] = uc[j]; }
+#pragma unroll
+      for (int j = 0; j < kS; ++j) { h0[j] = h1[j]; h1[j] = h2[j]; }
+    }
+  }
+  wg_reduce<TQ_N>(q, red, lane, wave, nwaves);
+  if (wave == 0) {
+    if (blockIdx.z == 0) {
+      const size_t g = (size_t)b * n * C + c;        // cls row: the module output there is LN_x(x) itself
+      const float* s = stats + (size_t)b * n * TS_N;
+      const float dn = to_f(dout[g]);
+      dxn[g] = dn;
+      q[TQ_LNXW] = fmaf(dn, (to_f(x[g]) - s[TS_MX]) * s[TS_RX], q[TQ_LNXW]);
+      q[TQ_LNXB] += dn;
+    }
+#pragma unroll
+    for (int k = 0; k < TQ_N; ++k) part[(((size_t)blockIdx.z * gridDim.y + b) * C + c) * TQ_N + k] = q[k];
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
 // launchers (C % 64 == 0)
 // ------------------------------------------------------------------------------------------------
 #define MRLA_DISPATCH_TN(DT, CALL)       \
@@ -367,6 +512,52 @@ int launch_token_apply_bwd_nhwc(const void* dout, const void* x, const void* o, 
     if (set_lds_n(token_apply_bwd_nhwc<TT>, lds) != hipSuccess) return MRLA_EHIP;                                    \
     hipLaunchKernelGGL((token_apply_bwd_nhwc<TT>), grid, block, lds, st, (const TT*)dout, (const TT*)x, (const TT*)o, \
                        stats, wx, bx, wo, bo, wv, gate, lam, dxn, part, bmom, n, C, side, d);                      \
+  }
+  MRLA_DISPATCH_TN(dtype, CALL)
+#undef CALL
+  return hip_status(hipGetLastError());
+}
+
+int launch_token_value_fwd_nhwc(const void* x, const float* stats, const float* wx, const float* bx, const float* wv,
+                                void* vslot, int B, int n, int C, int side, int dtype, hipStream_t st) {
+  if (!token_nhwc_applies(C)) return MRLA_EUNSUPPORTED;
+  const int nwaves = std::min((side + kS - 1) / kS, kMaxStrips);
+  const dim3 grid(C / kWave, B, token_bands(B, C, side)), block(nwaves * kWave);
+  const size_t lds = tok_lds(nwaves, 0);
+#define CALL(TT)                                                                                                    \
+  {                                                                                                                 \
+    if (set_lds_n(token_value_fwd_nhwc<TT>, lds) != hipSuccess) return MRLA_EHIP;                                     \
+    hipLaunchKernelGGL((token_value_fwd_nhwc<TT>), grid, block, lds, st, (const TT*)x, stats, wx, bx, wv, (TT*)vslot, \
+                       n, C, side);                                                                                 \
+  }
+  MRLA_DISPATCH_TN(dtype, CALL)
+#undef CALL
+  return hip_status(hipGetLastError());
+}
+
+// out[b, 0, :] = LN_x(x)[b, 0, :] (the cls token passes through the module, deit_mrla_base.py:241)
+int launch_token_cls_fwd(const void* x, const float* stats, const float* wx, const float* bx, void* out, int B, int n,
+                         int C, int dtype, hipStream_t st) {
+#define CALL(TT)                                                                                                    \
+  hipLaunchKernelGGL((token_cls_fwd_kernel<TT>), dim3((C + kThreads - 1) / kThreads, B), dim3(kThreads), 0, st,      \
+                     (const TT*)x, stats, wx, bx, (TT*)out, n, C, 0);
+  MRLA_DISPATCH_TN(dtype, CALL)
+#undef CALL
+  return hip_status(hipGetLastError());
+}
+
+int launch_token_value_bwd_nhwc(const void* dout, const void* x, const float* stats, const float* wx, const float* bx,
+                                const float* wv, const void* dv, float* dxn, float* part, int B, int n, int C, int side,
+                                int dtype, hipStream_t st) {
+  if (!token_nhwc_applies(C)) return MRLA_EUNSUPPORTED;
+  const int nwaves = std::min((side + kS - 1) / kS, kMaxStrips);
+  const dim3 grid(C / kWave, B, token_bands_bwd(B, C, side)), block(nwaves * kWave);
+  const size_t lds = tok_lds(nwaves, TQ_N);
+#define CALL(TT)                                                                                                   \
+  {                                                                                                                \
+    if (set_lds_n(token_value_bwd_nhwc<TT>, lds) != hipSuccess) return MRLA_EHIP;                                    \
+    hipLaunchKernelGGL((token_value_bwd_nhwc<TT>), grid, block, lds, st, (const TT*)dout, (const TT*)x, stats, wx, bx, \
+                       wv, (const TT*)dv, dxn, part, n, C, side);                                                  \
   }
   MRLA_DISPATCH_TN(dtype, CALL)
 #undef CALL

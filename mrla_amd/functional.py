@@ -789,6 +789,113 @@ def mrla_token_light(x, o_prev, lnx_w, lnx_b, lno_w, lno_b, wq, wk, wv, lam, d, 
 
 
 # ======================================================================================================
+# MRLA-base on token sequences (DeiT)
+# ======================================================================================================
+def token_base_supported(x, d):
+    """True when the fused token module of MRLA-base (LayerNorm on load, map rows written in place) takes `x` [b, n, c]."""
+    if x.dim() != 3 or not x.is_cuda or x.dtype not in _DT:
+        return False
+    b, n, c = x.shape
+    return c % d == 0 and L.load().mrla_token_base_supported(b, n, c, _DT[x.dtype]) == 1
+
+
+class _TokenBaseFn(torch.autograd.Function):
+    """out = cat(LN_x(x)[:, :1], mrla_base_layer(LN_x(x)[:, 1:] as a 14x14 map)) without materialising LN_x(x), the map view
+    or the cat (deit/deit_mrla_base.py:224-243).  The K / V history lives in `stage` (slot-major NHWC rings)."""
+
+    @staticmethod
+    @_on_device
+    def forward(ctx, x, lnx_w, lnx_b, wq, wk, wv, stage, d, eps):
+        _require_cuda(x, "mrla token-base forward")
+        xc = x.contiguous()
+        b, n, c = xc.shape
+        side = int(round((n - 1) ** 0.5))
+        if (b, c, side, side, d) != (stage.b, stage.c, stage.h, stage.w, stage.d) or xc.dtype != stage.dtype \
+                or stage.layout != L.NHWC:
+            raise L.MrlaHipError("input does not match the stage's K/V history (shape/dtype/layout); is init_cell set on "
+                                 "the first block?")
+        dt, dev, st = _DT[xc.dtype], xc.device, _stream()
+        wxw, wxb, wq32, wk32 = (_f32(t).reshape(-1) for t in (lnx_w, lnx_b, wq, wk))
+        wv32 = _f32(wv).reshape(c, 9)
+        ks = wq32.numel()
+        es = xc.element_size()
+        stats = torch.empty((b, n, 4), dtype=torch.float32, device=dev)
+        mom = torch.empty((b, c, L.FWD_MOMENTS), dtype=torch.float32, device=dev)
+        L.call("mrla_token_norm_pool", _ptr(xc), None, _ptr(wxw), _ptr(wxb), float(eps), _ptr(stats), _ptr(mom), b, n, c,
+               dt, st)
+        stage.reserve_slot()
+        t, T = stage.t + 1, stage.T
+        _call("mrla_token_base_value_fwd", xc.numel() * es * 2, _ptr(xc), _ptr(stats), _ptr(wxw), _ptr(wxb), _ptr(wv32),
+              _ptr(stage.V[t - 1]), b, n, c, dt, st)
+        q = torch.empty((b, c), dtype=torch.float32, device=dev)
+        L.call("mrla_base_gate_fwd", _ptr(mom), _ptr(wq32), _ptr(wk32), ks, _ptr(stage.K), _ptr(stage.P), _ptr(q), b, c,
+               n - 1, d, T, t, st)
+        out = torch.empty_like(xc)
+        arows = L.load().mrla_base_tile_rows(b, c, side, side, dt, L.NHWC)
+        L.check(min(arows, 0), "mrla_base_tile_rows")
+        amom = torch.empty((arows, c, 2), dtype=torch.float32, device=dev)
+        _call("mrla_token_base_attend_fwd", xc.numel() * es * (t + 1), _ptr(stage.V), _ptr(stage.P), _ptr(xc), _ptr(stats),
+              _ptr(wxw), _ptr(wxb), _ptr(out), _ptr(amom), b, n, c, d, T, t, dt, st)
+        stage.t = t
+        ctx.stage, ctx.t, ctx.d, ctx.ks, ctx.side = stage, t, d, ks, side
+        ctx.meta = [(p.shape, p.dtype) for p in (lnx_w, lnx_b, wq, wk, wv)]
+        ctx.wv_stride = wv.stride()
+        ctx.save_for_backward(xc, wxw, wxb, wq32, wk32, wv32, stats, mom, q)
+        return out
+
+    @staticmethod
+    @_on_device
+    def backward(ctx, dout):
+        xc, wxw, wxb, wq32, wk32, wv32, stats, mom, q = ctx.saved_tensors
+        stage, t, d, ks, side = ctx.stage, ctx.t, ctx.d, ctx.ks, ctx.side
+        b, n, c = xc.shape
+        T = stage.T
+        dt, dev, st = _DT[xc.dtype], xc.device, _stream()
+        if dout.dtype != xc.dtype:
+            dout = dout.to(xc.dtype)
+        dout = dout.contiguous()
+        es = xc.element_size()
+        first = stage.begin_layer_backward(t)
+        Tc = stage.bwd_top
+        pmom = torch.empty((b, c, t), dtype=torch.float32, device=dev)
+        prows = L.load().mrla_base_pmom_rows(b, c, side, side, dt, L.NHWC)
+        L.check(min(prows, 0), "mrla_base_pmom_rows")
+        ppart = torch.empty((prows, t, c), dtype=torch.float32, device=dev)
+        _call("mrla_token_base_attend_bwd", xc.numel() * es * (t + 2), _ptr(dout), _ptr(stage.V), _ptr(stage.dA), _ptr(ppart),
+              b, n, c, T, t, dt, st)
+        L.call("mrla_base_pmom_reduce", _ptr(ppart), _ptr(pmom), b, c, t, prows, st)
+        dv = torch.empty((b, side, side, c), dtype=xc.dtype, device=dev)
+        _call("mrla_base_dv_combine", xc.numel() * es * (Tc - t + 2), _ptr(stage.dA), _ptr(stage.P), _ptr(dv), b, c, side,
+              side, d, T, t, Tc, dt, L.NHWC, st)
+        dxn = torch.empty((b, n, c), dtype=torch.float32, device=dev)
+        prow = L.load().mrla_token_part_rows(b, n, c, dt)
+        L.check(min(prow, 0), "mrla_token_part_rows")
+        part = torch.empty((prow, c * L.TOKEN_PARTIALS), dtype=torch.float32, device=dev)
+        _call("mrla_token_base_value_bwd", xc.numel() * es * 2 + dxn.numel() * 4, _ptr(dout), _ptr(xc), _ptr(stats),
+              _ptr(wxw), _ptr(wxb), _ptr(wv32), _ptr(dv), _ptr(dxn), _ptr(part), b, n, c, dt, st)
+        dyx = torch.empty((b, c), dtype=torch.float32, device=dev)
+        dwqk_part = torch.empty((b, 2 * ks), dtype=torch.float32, device=dev)
+        L.call("mrla_token_base_gate_bwd", _ptr(mom), _ptr(pmom), _ptr(stage.P), _ptr(q), _ptr(stage.K), _ptr(stage.dK),
+               _ptr(wq32), _ptr(wk32), ks, _ptr(dyx), _ptr(dwqk_part), _ptr(part), b, n, c, d, T, t, int(first), dt, st)
+        dx = torch.empty_like(xc)
+        _call("mrla_token_ln_bwd", xc.numel() * es * 3 + dxn.numel() * 4, _ptr(dout), _ptr(xc), None, _ptr(dxn), _ptr(dyx),
+              _ptr(stats), _ptr(wxw), None, None, _ptr(dx), None, b, n, c, 0, dt, st)
+        sums = torch.empty((c * L.TOKEN_PARTIALS + 2 * ks,), dtype=torch.float32, device=dev)
+        L.call("mrla_reduce_rows2", _ptr(part), _ptr(sums), prow, c * L.TOKEN_PARTIALS, _ptr(dwqk_part),
+               _ptr(sums[c * L.TOKEN_PARTIALS:]), b, 2 * ks, st)
+        pc = sums[:c * L.TOKEN_PARTIALS].view(c, L.TOKEN_PARTIALS)
+        dwqk = sums[c * L.TOKEN_PARTIALS:]
+        raw = (pc[:, 10], pc[:, 11], dwqk[:ks], dwqk[ks:])
+        grads = [g.reshape(shape).to(dtype) for g, (shape, dtype) in zip(raw, ctx.meta)]
+        sv, tv = ctx.meta[4]
+        return (dx, *grads, _grad_like(pc[:, :9].to(tv), sv, ctx.wv_stride), None, None, None)
+
+
+def mrla_token_base(x, lnx_w, lnx_b, wq, wk, wv, d, stage, eps=1e-6):
+    return _TokenBaseFn.apply(x, lnx_w, lnx_b, wq, wk, wv, stage, d, eps)
+
+
+# ======================================================================================================
 # fused BatchNorm2d (+ReLU)  -- the producer-side epilogue in front of the MRLA tail (SURVEY.md 8f rank 1)
 # ======================================================================================================
 class _BnActFn(torch.autograd.Function):

@@ -275,14 +275,33 @@ class mrlab_module(nn.Module):
         self.normx = norm_layer(input_dim)
         self.mrla = mrlab_layer(input_dim=input_dim, dim_perhead=self.dim_perhead, init_cell=init_cell)
 
+    def _token_stage(self, xt, side, prev_k, prev_v):
+        layer = self.mrla
+        if layer.init_cell:
+            b, _, c = xt.shape
+            return F_.BaseStage(b, c, side, side, layer.dim_perhead, xt.dtype, xt.device, layer.history_hint or 4,
+                                F_.L.NHWC)
+        return _stage_for(layer, xt, prev_k, prev_v)
+
     def forward(self, xt, prev_k, prev_v):
-        xt = self.normx(xt)
         if self.init_cell:
             prev_k = prev_v = None
         b, n, c = xt.shape
         side = math.isqrt(n - 1)
         if side * side != n - 1:
             raise MrlaHipError(f"mrlab_module: {n - 1} map tokens do not form a square map")
+        nx, layer = self.normx, self.mrla
+        if (type(nx) is nn.LayerNorm and nx.elementwise_affine and nx.bias is not None and c == layer.input_dim
+                and F_.token_base_supported(xt, layer.dim_perhead)):
+            # LayerNorm on load, V_t straight into the stage's ring, the map rows and the cls row of the result written in
+            # place: no normalised copy of xt, no token <-> map view copies, no cat (deit_mrla_base.py:224-243)
+            stage = self._token_stage(xt, side, prev_k, prev_v)
+            if stage.layout == F_.L.NHWC:
+                out = F_.mrla_token_base(xt, nx.weight, nx.bias, layer.Wq.weight, layer.Wk.weight, layer.Wv.weight,
+                                         layer.dim_perhead, stage, eps=nx.eps)
+                K, V = stage.views()
+                return out, K, V
+        xt = self.normx(xt)
         # the map tokens ARE a channels_last image (pixel pitch c): no token <-> NCHW transposes; the stage's history
         # lives in slot-major NHWC rings and the layer's output comes back as a view of map tokens
         fmap = xt[:, 1:].reshape(b, side, side, c).permute(0, 3, 1, 2)

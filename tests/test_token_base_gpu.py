@@ -66,3 +66,46 @@ def test_deit_mrlab_train_step_vs_eager(amp):
         cos = (a @ b / (a.norm() * b.norm())).item()
         assert cos > (0.999 if amp else 0.9999), (k, cos)
         assert (a - b).abs().max() <= (0.2 if amp else 2e-2) * b.abs().max() + 1e-8, k
+
+
+@pytest.mark.parametrize("b,n,c,steps", [(2, 17, 64, 5), (3, 197, 192, 6), (2, 50, 128, 3)], ids=["c64n17", "c192n197", "c128n50"])
+def test_fused_token_module_chain_vs_eager_float64(b, n, c, steps):
+    """Widths with c % 64 == 0 take the fused token path (LayerNorm on load, V_t straight into the ring, map rows and cls
+    row written in place: mrla_token_base_*).  The golden chain above has c = 32 and never reaches it, so the same chain is
+    run here at DeiT's width against the eager restatement (itself pinned to the reference's goldens at c = 32) in float64:
+    module outputs, dx and every parameter gradient, with an init_cell layer in the middle of the chain (a second stage)."""
+    from mrla_amd import functional as F_, layers
+
+    def inputs(t):
+        s = detgen.seed_of(f"tokbase-fused/{c}/{t}")
+        return (detgen.normalish((b, n, c), s) * 1.2 + 0.1).astype(np.float32), detgen.normalish((b, n, c), s + 1).astype(np.float32)
+
+    def run(make, dev, dtype):
+        mods, xs, outs, loss, K, V = [], [], [], 0.0, None, None
+        for t in range(steps):
+            m = make(t)
+            vals = detgen.fill_state_dict(m.state_dict(), salt=70 + t)
+            m.load_state_dict({k: torch.from_numpy(v) for k, v in vals.items()})
+            m = m.to(dev, dtype)
+            x, g = inputs(t)
+            x = torch.from_numpy(x).to(dev, dtype).requires_grad_(True)
+            y, K, V = m(x, K, V)
+            loss = loss + ((x + y) * torch.from_numpy(g).to(dev, dtype)).sum()
+            mods.append(m); xs.append(x); outs.append(y)
+        loss.backward()
+        return mods, xs, outs
+
+    def product(t):
+        m = layers.mrlab_module(c, D, init_cell=(t % 4 == 0))
+        m.mrla.history_hint = 2           # (the rings grow once inside the first stage)
+        return m
+    probe = torch.zeros((b, n, c), device="cuda")
+    assert F_.token_base_supported(probe, D), "this case is meant to take the fused path"
+    got = run(product, "cuda", torch.float32)
+    want = run(lambda t: em.EagerTokenBaseModule(c, D, init_cell=(t % 4 == 0)), "cpu", torch.float64)
+    for t in range(steps):
+        assert rel(got[2][t].detach().cpu().numpy(), want[2][t].detach().numpy()) < 2e-5, t
+        assert rel(got[1][t].grad.cpu().numpy(), want[1][t].grad.numpy()) < 4e-5, t
+        wp = dict(want[0][t].named_parameters())
+        for pn, pv in got[0][t].named_parameters():
+            assert rel(pv.grad.cpu().numpy(), wp[pn].grad.numpy()) < 1e-4, (t, pn)

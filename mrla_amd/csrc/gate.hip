@@ -379,7 +379,10 @@ int launch_gate_bwd(const float* mom, const float* bmom, const float* gate, cons
 static int reduce_cpb(int rows, int n) {
   int cpb = 64;
   while (cpb > 1 && cpb / 2 >= n) cpb >>= 1;                  // narrow matrices: fewer columns, more row lanes
-  if (rows < 16) cpb = 64;
+  if (rows < 16) return 64;
+  // too few workgroups to hide the latency of their `rows / row-lanes` dependent loads (45 for the token path's
+  // [256, 2880] partials: 18 us for 3 MB): narrower column groups, more row lanes, while a lane still sums >= 4 rows
+  while (cpb > 8 && (n + cpb - 1) / cpb < 512 && rows >= 4 * (kThreads / (cpb / 2))) cpb >>= 1;
   return cpb;
 }
 

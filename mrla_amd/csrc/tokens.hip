@@ -67,25 +67,35 @@ __global__ __launch_bounds__(kThreads) void token_stats_kernel(const T* __restri
   }
 }
 
-// mom[b,c,0] = wx[c] * sum_{i>=1} (x[b,i,c] - mean_i) * rstd_i + (n-1) * bx[c]   (other slots 0).  grid (C/64.., b)
+// mom[b,c,0] = wx[c] * sum_{i>=1} (x[b,i,c] - mean_i) * rstd_i + (n-1) * bx[c]   (other slots 0).  grid (C/64.., b);
+// the four waves of a workgroup take every fourth token each (a single wave per (image, 64 channels) walked 196 tokens
+// in 49 dependent steps: 20 us for a 39 MB read), partial sums combined in wave order.
 template <typename T>
-__global__ __launch_bounds__(kWave) void token_pool_kernel(const T* __restrict__ x, const float* __restrict__ stats,
-                                                           const float* __restrict__ wx, const float* __restrict__ bx,
-                                                           float* __restrict__ mom, int n, int C) {
-  const int b = blockIdx.y, c = blockIdx.x * kWave + threadIdx.x;
-  if (c >= C) return;
-  const T* xb = x + (size_t)b * n * C + c;
+__global__ __launch_bounds__(kThreads) void token_pool_kernel(const T* __restrict__ x, const float* __restrict__ stats,
+                                                              const float* __restrict__ wx, const float* __restrict__ bx,
+                                                              float* __restrict__ mom, int n, int C) {
+  __shared__ float part[kWaves][kWave];
+  const int lane = threadIdx.x & (kWave - 1), wave = threadIdx.x / kWave;
+  const int b = blockIdx.y, c = blockIdx.x * kWave + lane;
+  const bool live = c < C;
+  const T* xb = x + (size_t)b * n * C + (live ? c : 0);
   const float* sb = stats + (size_t)b * n * S_N;
-  float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;          // four independent chains, summed in a fixed order
-  int i = 1;
-  for (; i + 3 < n; i += 4) {
+  float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;          // four independent chains per wave, summed in a fixed order
+  int i = 1 + wave;
+  for (; i + 3 * kWaves < n; i += 4 * kWaves) {
+    const int i1 = i + kWaves, i2 = i + 2 * kWaves, i3 = i + 3 * kWaves;
     s0 = fmaf(to_f(xb[(size_t)i * C]) - sb[i * S_N + S_MX], sb[i * S_N + S_RX], s0);
-    s1 = fmaf(to_f(xb[(size_t)(i + 1) * C]) - sb[(i + 1) * S_N + S_MX], sb[(i + 1) * S_N + S_RX], s1);
-    s2 = fmaf(to_f(xb[(size_t)(i + 2) * C]) - sb[(i + 2) * S_N + S_MX], sb[(i + 2) * S_N + S_RX], s2);
-    s3 = fmaf(to_f(xb[(size_t)(i + 3) * C]) - sb[(i + 3) * S_N + S_MX], sb[(i + 3) * S_N + S_RX], s3);
+    s1 = fmaf(to_f(xb[(size_t)i1 * C]) - sb[i1 * S_N + S_MX], sb[i1 * S_N + S_RX], s1);
+    s2 = fmaf(to_f(xb[(size_t)i2 * C]) - sb[i2 * S_N + S_MX], sb[i2 * S_N + S_RX], s2);
+    s3 = fmaf(to_f(xb[(size_t)i3 * C]) - sb[i3 * S_N + S_MX], sb[i3 * S_N + S_RX], s3);
   }
-  for (; i < n; ++i) s0 = fmaf(to_f(xb[(size_t)i * C]) - sb[i * S_N + S_MX], sb[i * S_N + S_RX], s0);
-  const float s = (s0 + s1) + (s2 + s3);
+  for (; i < n; i += kWaves) s0 = fmaf(to_f(xb[(size_t)i * C]) - sb[i * S_N + S_MX], sb[i * S_N + S_RX], s0);
+  part[wave][lane] = (s0 + s1) + (s2 + s3);
+  __syncthreads();
+  if (wave != 0 || !live) return;
+  float s = part[0][lane];
+#pragma unroll
+  for (int k = 1; k < kWaves; ++k) s += part[k][lane];
   float* m = mom + ((size_t)b * C + c) * M_REC;
   m[M_PV] = 0.f; m[M_PO] = 0.f;
   // slot 0 holds hw * y so that the shared gate kernels' y = Sx / hw is the LN-affine pooled value
@@ -375,7 +385,7 @@ int launch_token_norm_pool(const void* x, const void* o, const float* wx, const 
 #define CALL(TT)                                                                                                     \
   hipLaunchKernelGGL((token_stats_kernel<TT>), dim3(wgs), dim3(kThreads), 0, st, (const TT*)x, (const TT*)o, eps, stats, \
                      ntok, C);                                                                                       \
-  hipLaunchKernelGGL((token_pool_kernel<TT>), dim3((C + kWave - 1) / kWave, B), dim3(kWave), 0, st, (const TT*)x, stats, \
+  hipLaunchKernelGGL((token_pool_kernel<TT>), dim3((C + kWave - 1) / kWave, B), dim3(kThreads), 0, st, (const TT*)x, stats, \
                      wx, bx, mom, n, C);
   MRLA_DISPATCH_TT(dtype, CALL)
 #undef CALL

@@ -296,7 +296,8 @@ def main():
                             "mrla_light_stats_fwd", "mrla_base_attend_fwd", "mrla_base_tail_fwd",
                             "mrla_base_tail_stats_bwd", "mrla_base_attend_bwd", "mrla_base_value_bwd",
                             "mrla_base_pool_value_fwd", "mrla_base_dv_combine", "mrla_base_value_bwd_dv",
-                            "mrla_token_apply_fwd", "mrla_token_apply_bwd", "mrla_token_ln_bwd",
+                            "mrla_token_apply_fwd", "mrla_token_apply_bwd", "mrla_token_ln_bwd", "mrla_token_base_value_fwd",
+                            "mrla_token_base_attend_fwd", "mrla_token_base_attend_bwd", "mrla_token_base_value_bwd",
                             "mrla_light_stats_fwd_fused", "mrla_light_pool_fused", "mrla_light_apply_fwd_fused", "mrla_bn_plane_moments", "mrla_bn_act_fwd",
                             "mrla_bn_plane_dmoments", "mrla_bn_act_bwd",
                             "mrla_conv1x1_fwd", "mrla_conv1x1_bwd_data", "mrla_conv1x1_wgrad", "mrla_bn_relu_pool_fwd",

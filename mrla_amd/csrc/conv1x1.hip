@@ -269,7 +269,7 @@ int conv1x1_plan(int M, int K, int N, int add, int* out) {
   if (conv1x1_wide_plan(M, K, N, add, out) == MRLA_OK) return MRLA_OK;
   GemmGeo g;
   if (!add && !conv1x1_geo(&g, M, K, N) && conv1x1_kstream_supported(M, K, N)) {
-    out[0] = K / 32; out[1] = 3; out[2] = 0; out[3] = 0;      // 32-deep reduction chunks per tile, LDS stages, -, no rows
+    out[0] = K / 32; out[1] = conv1x1_kstream_stages(M, K, N); out[2] = 0; out[3] = 0;   // 32-deep chunks per tile, LDS stages, -, no rows
     return MRLA_OK;
   }
   if (add || !conv1x1_geo(&g, M, K, N)) return MRLA_EUNSUPPORTED;

@@ -23,6 +23,7 @@
 // These products need 0.5 - 2 PFLOP/s to run at the HBM rate (N*K/(N+K) = 100 - 400 flop per byte), so unlike their
 // K <= 256 siblings they are bound by the matrix pipe as much as by memory; MIOpen's kernels reach 25 - 30 % of it.
 #include <algorithm>
+#include <cstdlib>
 
 #include "mrla_device.h"
 #include "mrla_kernels.h"
@@ -237,14 +238,212 @@ __global__ __launch_bounds__(kKsWaves* kWave, 4) void conv1x1_kstream_kernel(con
 #endif
 }
 
+// ------------------------------------------------------------------------------------------------
+// The 256 x 256 tile (round 3, second form).  In the kernel above a wave owns 64 channels x 64 pixels: one ds_read_b128
+// per MFMA, and since the CU's LDS port delivers one such read in the time its four matrix pipes take for four MFMAs, LDS
+// reads alone cap it at half the MFMA rate (it measures 22 - 31 %).  Here a wave owns 64 channels x 128 pixels (0.75 reads
+// per MFMA, 128 accumulator registers), a workgroup 256 x 256 outputs with four 32 KB stages (one workgroup per CU, three
+// chunks of DMA in flight), and the operand fragments are double-buffered per k-step: the reads of k-step u+1 are issued
+// before the MFMAs of k-step u and fenced after them, so that the LDS latency -- and the barrier that opens a new chunk --
+// sit under matrix work instead of in front of it.
+// ------------------------------------------------------------------------------------------------
+struct Ks256 {
+  static constexpr int TM = 256, TN = 256, ROWS = TM + TN, SB = ROWS * 64, ST = 4, NI = 4, PB = 4;
+  static constexpr int kLds = ST * SB;                  // 128 KB: also exactly the bf16 output tile
+};
+
+__global__ __launch_bounds__(kKsWaves* kWave, 2) void conv1x1_kstream256_kernel(const bf16_t* __restrict__ X,
+                                                                               const bf16_t* __restrict__ W,
+                                                                               bf16_t* __restrict__ Y, int M, int N, int K,
+                                                                               int tiles_m, int groups_n) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  typedef Ks256 G;
+  constexpr int PB = G::PB;
+  extern __shared__ __align__(16) unsigned char smem_raw[];
+  const int lane = threadIdx.x & (kWave - 1);
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x / kWave);
+  const int r = lane & 31, h = lane >> 5;
+  const int per = gridDim.x >> 3;
+  const int vid = (blockIdx.x & 7) * per + (blockIdx.x >> 3);
+  if (vid >= tiles_m * groups_n) return;
+  const int tile = vid / groups_n, cg = vid - tile * groups_n;
+  const int m0 = tile * G::TM, n0 = cg * G::TN;
+  const int wn = wave & 3, wm = wave >> 2;
+  const int nchunks = K / kKsKC;
+
+  const auto rsX = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(X), 0, (int)((size_t)M * K * 2), MRLA_KS_FLAGS);
+  const auto rsW = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(W), 0, (int)((size_t)N * K * 2), MRLA_KS_FLAGS);
+  unsigned voff[G::NI];
+#pragma unroll
+  for (int i = 0; i < G::NI; ++i) {       // instruction u = wave + 8*i: stage rows 16u .. 16u+15; i < 2: X pixels, else W channels
+    const int u = wave + kKsWaves * i, row = u * 16 + (lane >> 2), slot = (lane & 3) ^ ks_swz(row);
+    if (i < 2) voff[i] = (unsigned)(((size_t)(m0 + row) * K) * 2 + slot * 16);            // (pixels past M: beyond num_records)
+    else voff[i] = (unsigned)(((size_t)(n0 + row - G::TM) * K) * 2 + slot * 16);
+  }
+  int issued = 0;
+  auto issue = [&](int stage) {
+    const unsigned kill = issued++ < nchunks ? 0u : 0x80000000u;
+#pragma unroll
+    for (int i = 0; i < G::NI; ++i) {
+      unsigned char* dst = smem_raw + stage * G::SB + (wave + kKsWaves * i) * 1024;
+      if (i < 2) __builtin_amdgcn_raw_ptr_buffer_load_lds(rsX, (lds_void_ptr)dst, 16, voff[i] | kill, 0, 0, 0);
+      else       __builtin_amdgcn_raw_ptr_buffer_load_lds(rsW, (lds_void_ptr)dst, 16, voff[i] | kill, 0, 0, 0);
+      voff[i] += kKsKC * 2;
+    }
+  };
+
+  const unsigned lds0 = ks_lds_addr(smem_raw);
+  unsigned offA[2], offB[PB];
+  int fA[2], fB[PB];
+#pragma unroll
+  for (int c = 0; c < 2; ++c) {
+    const int row = G::TM + wn * 64 + c * 32 + r;
+    offA[c] = lds0 + row * 64;
+    fA[c] = ks_swz(row);
+  }
+#pragma unroll
+  for (int p = 0; p < PB; ++p) {
+    const int row = (wm * PB + p) * 32 + r;
+    offB[p] = lds0 + row * 64;
+    fB[p] = ks_swz(row);
+  }
+  ks_f32x16 acc[PB][2];
+#pragma unroll
+  for (int p = 0; p < PB; ++p)
+#pragma unroll
+    for (int c = 0; c < 2; ++c)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[p][c][e] = 0.f;
+
+  u32x4 fa[2][2], fb[2][PB];                       // [buffer][block]: the fragments of k-step u live in buffer u & 1
+  auto read_frags = [&](int buf, unsigned sbo, int ks) {
+#pragma unroll
+    for (int cb = 0; cb < 2; ++cb) ks_read16(fa[buf][cb], offA[cb] + sbo + (((2 * ks + h) ^ fA[cb]) << 4));
+#pragma unroll
+    for (int p = 0; p < PB; ++p) ks_read16(fb[buf][p], offB[p] + sbo + (((2 * ks + h) ^ fB[p]) << 4));
+  };
+  auto fence_frags = [&](int buf) {
+    ks_fence<0>(fa[buf][0], true);
+    ks_fence<0>(fa[buf][1], false);
+#pragma unroll
+    for (int p = 0; p < PB; ++p) ks_fence<0>(fb[buf][p], false);
+  };
+  auto mfmas = [&](int buf) {
+#pragma unroll
+    for (int p = 0; p < PB; ++p)
+#pragma unroll
+      for (int cb = 0; cb < 2; ++cb)
+        acc[p][cb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(ks_bf16x8, fa[buf][cb]),
+                                                             __builtin_bit_cast(ks_bf16x8, fb[buf][p]), acc[p][cb], 0, 0, 0);
+  };
+
+  // chunks 0 .. 2 in flight, chunk 3 follows once chunk 0 is complete everywhere
+#pragma unroll
+  for (int j = 0; j < G::ST - 1; ++j) issue(j);
+  asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * G::NI) : "memory");
+  __builtin_amdgcn_s_barrier();
+  asm volatile("" ::: "memory");
+  issue(G::ST - 1);
+  read_frags(0, 0u, 0);
+  fence_frags(0);
+  int stage = 0;                                   // stage of the chunk being multiplied
+  for (int c = 0; c < nchunks; ++c) {
+    const unsigned sbo = stage * G::SB;
+    // k-step 0 of chunk c: its fragments are in buffer 0; fetch k-step 1's
+    read_frags(1, sbo, 1);
+    __builtin_amdgcn_sched_barrier(0);
+    mfmas(0);
+    __builtin_amdgcn_sched_barrier(0);
+    fence_frags(1);
+    // k-step 1: every wave has read all of chunk c by now.  Open chunk c+1 (mine has landed when at most the two chunks
+    // behind it are in flight; after the barrier everybody's has, and the stage of chunk c is free for chunk c+4), fetch
+    // its first fragments, multiply under their latency
+    const int nstage = stage + 1 == G::ST ? 0 : stage + 1;
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * G::NI) : "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    issue(stage);
+    read_frags(0, nstage * G::SB, 0);
+    __builtin_amdgcn_sched_barrier(0);
+    mfmas(1);
+    __builtin_amdgcn_sched_barrier(0);
+    fence_frags(0);
+    stage = nstage;
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");           // (dummy chunks past the end: no data, but their LDS writes)
+  __builtin_amdgcn_s_barrier();
+  asm volatile("" ::: "memory");
+
+  // ---- epilogue: as above (round once, v_permlane32_swap to 16-byte pieces, whole rows out) ----
+#pragma unroll
+  for (int p = 0; p < PB; ++p) {
+    const int trow = (wm * PB + p) * 32 + r;
+    const unsigned orow = lds0 + trow * (G::TN * 2);
+#pragma unroll
+    for (int cb = 0; cb < 2; ++cb) {
+      unsigned q[8];
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        typedef bf16_t bf16x2 __attribute__((ext_vector_type(2)));
+        bf16x2 pr;
+        pr[0] = from_f<bf16_t>(acc[p][cb][2 * i]);
+        pr[1] = from_f<bf16_t>(acc[p][cb][2 * i + 1]);
+        q[i] = __builtin_bit_cast(unsigned, pr);
+      }
+#pragma unroll
+      for (int g = 0; g < 2; ++g)
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+          const auto sw = __builtin_amdgcn_permlane32_swap(q[4 * g + t], q[4 * g + 2 + t], false, false);
+          q[4 * g + t] = sw[0];
+          q[4 * g + 2 + t] = sw[1];
+        }
+      const int ch0 = wn * 8 + cb * 4 + h;
+      ks_write16(orow + (((ch0) ^ ks_oswz(trow)) << 4), (u32x4){q[0], q[1], q[2], q[3]});
+      ks_write16(orow + (((ch0 + 2) ^ ks_oswz(trow)) << 4), (u32x4){q[4], q[5], q[6], q[7]});
+    }
+  }
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  asm volatile("" ::: "memory");
+  {
+    constexpr int CPR = G::TN / 8, RPI = (kKsWaves * kWave) / CPR;
+    const int srow = threadIdx.x / CPR, chunk = threadIdx.x % CPR;
+#pragma unroll
+    for (int i = 0; i < G::TM / RPI; ++i) {
+      const int row = srow + RPI * i;
+      u32x4 v;
+      ks_read16(v, lds0 + row * (G::TN * 2) + ((chunk ^ ks_oswz(row)) << 4));
+      ks_fence<0>(v, true);
+      if (m0 + row < M) *reinterpret_cast<u32x4*>(Y + (size_t)(m0 + row) * N + n0 + chunk * 8) = v;
+    }
+  }
+#endif
+}
+
 struct KsPlan {
   int wn = 0, pb = 0, tiles_m = 0, groups_n = 0;
+  bool big = false;        // the 256 x 256 tile kernel
 };
+
+static bool ks_want_big() {             // MRLA_KS256=0: A/B switch back to the 64 x 64 wave tiles
+  static const bool v = [] { const char* e = getenv("MRLA_KS256"); return !(e && e[0] == '0'); }();
+  return v;
+}
 
 KsPlan ks_plan(int M, int K, int N) {
   KsPlan p;
   if (M <= 0 || K < 512 || K % kKsKC || N % 128 || (size_t)M * std::max(N, K) * 2 >= (size_t)1 << 31) return p;
   p.wn = N % 256 == 0 ? 4 : 2;
+  if (ks_want_big() && N % 256 == 0 && K / kKsKC >= Ks256::ST) {
+    // 256 x 256 tiles, one workgroup per CU: when they come close to filling the chip's rounds
+    const int tiles = ((M + 255) / 256) * (N / 256);
+    const int rounds = (tiles + 255) / 256;
+    if (tiles >= 160 && tiles * 100 >= rounds * 256 * 70) {
+      p.big = true; p.pb = 4; p.tiles_m = (M + 255) / 256; p.groups_n = N / 256;
+      return p;
+    }
+  }
   const int tn = p.wn * 64, wm = kKsWaves / p.wn;
   p.groups_n = N / tn;
   // the larger pixel tile (less weight traffic out of L2 per X byte) when it still gives every CU a workgroup
@@ -267,10 +466,17 @@ int ks_launch(const KsPlan& p, const void* x, const void* w, void* y, int M, int
 }  // namespace
 
 int conv1x1_kstream_supported(int M, int K, int N) { return ks_plan(M, K, N).wn ? 1 : 0; }
+int conv1x1_kstream_stages(int M, int K, int N) { return ks_plan(M, K, N).big ? Ks256::ST : kKsStages; }
 
 int launch_conv1x1_kstream(const void* x, const void* w, void* y, int M, int K, int N, hipStream_t st) {
   const KsPlan p = ks_plan(M, K, N);
   if (!p.wn) return MRLA_EUNSUPPORTED;
+  if (p.big) {
+    if (lds_opt_in(reinterpret_cast<const void*>(conv1x1_kstream256_kernel), Ks256::kLds) != hipSuccess) return MRLA_EHIP;
+    hipLaunchKernelGGL(conv1x1_kstream256_kernel, dim3((p.tiles_m * p.groups_n + 7) / 8 * 8), dim3(kKsWaves * kWave),
+                       Ks256::kLds, st, (const bf16_t*)x, (const bf16_t*)w, (bf16_t*)y, M, N, K, p.tiles_m, p.groups_n);
+    return hip_status(hipGetLastError());
+  }
   if (p.wn == 4) return p.pb == 2 ? ks_launch<4, 2>(p, x, w, y, M, K, N, st) : ks_launch<4, 1>(p, x, w, y, M, K, N, st);
   return p.pb == 2 ? ks_launch<2, 2>(p, x, w, y, M, K, N, st) : ks_launch<2, 1>(p, x, w, y, M, K, N, st);
 }

@@ -8,13 +8,16 @@ ImageNet-shaped data (BASELINE.json metric / configs[1]; configs[2] for --gpus N
 
 A "step" = forward + loss + backward + SGD update on one synthetic batch already resident in HBM.  On a single GPU the
 timed steps replay the whole step from one HIP graph (`config.launch`; `--graph 0` times PyTorch's kernel-by-kernel
-launches instead, and under torch.distributed that is the default).  Rank 0 prints ONE JSON line.  Besides the contract
+launches instead).  Under torch.distributed the step is captured as well, with the gradient exchange inside the graph as
+ONE flat all-reduce after backward (`--dp flat`, mrla_amd/distributed.py: FlatGradientExchange; if the capture fails the
+same step is launched eagerly); `--dp ddp` runs torch's DistributedDataParallel, launched kernel by kernel.  Rank 0 prints
+ONE JSON line.  Besides the contract
 keys it carries
   roofline     -- HBM roofline of the dominant MRLA kernel (mrla_light_apply_bwd), timed live with HIP events on
                   the launch stream over `steps` steps launched kernel by kernel (the timed region itself when it is not
                   graph-replayed, else the same steps run once more right after it: events cannot be read out of a
                   replayed graph; `eager_launch_ms_per_step` is that region's step time); algorithmic bytes =
-                  5*N*sizeof(bf16) per launch;
+                  6*N*sizeof(bf16) per launch (dOut, x_t, o_prev, y3 in; dx, do out);
   cpu_baseline -- the eager CPU restatement (oracle/eager_models.py, kind "port") forward on the host cores,
                   bounded sample, rank 0 at N=1 only;
   eager_rocm   -- the same restatement run eager on this GPU (the north-star's ">=4x" denominator), N=1 only.
@@ -55,8 +58,13 @@ def parse():
                          "solvers by measuring them during the warm-up steps), 0 for MIOpen's immediate-mode choice")
     ap.add_argument("--graph", type=int, default=-1,
                     help="1: the timed steps replay the whole step (fwd+bwd+SGD) from one HIP graph; 0: launched kernel by "
-                         "kernel; -1 (default): 1 on a single GPU, 0 under torch.distributed")
+                         "kernel; -1 (default): 1, except with --dp ddp or a non-RCCL backend")
     ap.add_argument("--backend", default=os.environ.get("MRLA_DIST_BACKEND", "nccl"))
+    ap.add_argument("--dp", choices=["auto", "flat", "ddp"], default="auto",
+                    help="gradient exchange at N > 1.  flat: mrla_amd.distributed.FlatGradientExchange -- one all-reduce of "
+                         "one flat buffer after backward, which lets the whole step (exchange included) replay from one HIP "
+                         "graph like the N = 1 point; ddp: torch DistributedDataParallel (bucketed, overlapped with "
+                         "backward, launched kernel by kernel); auto: flat unless --graph 0")
     ap.add_argument("--ddp-probe", action="store_true",
                     help="diagnostic on one GPU: a ONE-rank process group + DistributedDataParallel around the model, so "
                          "that the reducer hooks, bucket views and RCCL all-reduce launches of the N > 1 path run (and can "
@@ -64,12 +72,14 @@ def parse():
     return ap.parse_args()
 
 
-def make_step(net, opt, x, y):
+def make_step(net, opt, x, y, exchange=None):
     def step():
         with torch.autocast("cuda", dtype=torch.bfloat16):
             loss = torch.nn.functional.cross_entropy(net(x).float(), y)
         opt.zero_grad(set_to_none=True)
         loss.backward()
+        if exchange is not None:
+            exchange.reduce()              # the N > 1 gradient average (one flat all-reduce; capturable)
         opt.step()
         return loss
     return step
@@ -251,8 +261,15 @@ def main():
         net.channels_last = bool(args.channels_last)
         net.to(memory_format=torch.channels_last if args.channels_last else torch.contiguous_format)
     layout = "channels_last" if getattr(net, "channels_last", False) else "NCHW"
-    use_graph = args.graph == 1 or (args.graph < 0 and not dist_on)
-    if use_graph and dist_on:
+    # N > 1: the exchange that fits into the graph (flat) unless the caller asks for eager launches or for DDP
+    dp = "none" if not dist_on else (args.dp if args.dp != "auto" else ("ddp" if args.graph == 0 else "flat"))
+    # (a gloo exchange stages through the host: not capturable)
+    use_graph = args.graph == 1 or (args.graph < 0 and dp != "ddp" and (not dist_on or args.backend == "nccl"))
+    exchange = None
+    if dp == "flat":
+        net = net.cuda().train()
+        exchange = D.FlatGradientExchange(net.parameters())
+    elif use_graph and dist_on:
         # capturing a DDP step (PyTorch's whole-network-capture recipe): the wrapper is built in a side-stream context and
         # at least 11 DDP iterations run eagerly on a side stream before the capture
         side0 = torch.cuda.Stream()
@@ -266,7 +283,7 @@ def main():
     gy = torch.Generator(device="cuda").manual_seed(1)
     x = torch.randn(args.batch, 3, 224, 224, device="cuda", generator=gx)
     y = torch.randint(0, 1000, (args.batch,), device="cuda", generator=gy)
-    step = make_step(net, sgd(net.parameters()), x, y)
+    step = make_step(net, sgd(net.parameters()), x, y, exchange)
 
     # warm-up without the timer
     for _ in range(args.warmup):
@@ -285,10 +302,11 @@ def main():
                     eager_step()
             torch.cuda.current_stream().wait_stream(side)
             graph = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(graph):
+            # (thread_local: RCCL's watchdog thread may query events while this thread captures)
+            with torch.cuda.graph(graph, **({"capture_error_mode": "thread_local"} if dist_on else {})):
                 eager_step()
             step = graph.replay
-            launch = "one HIP graph per step (captured fwd+loss+bwd+SGD), replayed"
+            launch = "one HIP graph per step (captured fwd+loss+bwd" + ("+gradient all-reduce" if dist_on else "") + "+SGD), replayed"
         except Exception as e:                        # capture not possible here: time the eager launches instead
             print(f"warning: HIP graph capture failed ({type(e).__name__}: {e}); timing eager launches", file=sys.stderr)
             step, use_graph = eager_step, False
@@ -338,6 +356,9 @@ def main():
                "config": {"workload": f"{args.arch} fwd+bwd+SGD, {args.batch} images/GPU of 3x224x224, bf16 autocast, "
                                       f"fp32 master weights, drop_path {args.drop_path}",
                           "global_batch": world * args.batch, "parallelism": f"dp{world}", "launch": launch,
+                          **({"gradient_exchange": {"flat": "one all-reduce (RCCL avg) of one flat fp32 buffer after backward",
+                                                    "ddp": "DistributedDataParallel: 32 MB buckets, overlapped with backward"}[dp]}
+                             if dist_on else {}),
                           "path": "eager restatement" if args.eager else
                                   f"mrla_amd (HIP MRLA tails incl. shortcut add+ReLU, HIP BatchNorm+ReLU(+stem max-pool), HIP MFMA GEMMs for the "
                                   f"1x1 convolutions fwd / dgrad / wgrad where eligible, stock 3x3 / 7x7 / strided convolutions; {layout})"},

@@ -435,8 +435,10 @@ KsPlan ks_plan(int M, int K, int N) {
   KsPlan p;
   if (M <= 0 || K < 512 || K % kKsKC || N % 128 || (size_t)M * std::max(N, K) * 2 >= (size_t)1 << 31) return p;
   p.wn = N % 256 == 0 ? 4 : 2;
-  if (ks_want_big() && N % 256 == 0 && K / kKsKC >= Ks256::ST) {
-    // 256 x 256 tiles, one workgroup per CU: when they come close to filling the chip's rounds
+  if (ks_want_big() && N % 256 == 0 && K >= 1024) {
+    // 256 x 256 tiles, one workgroup per CU: when they come close to filling the chip's rounds and the reduction is long
+    // enough to amortise a lone workgroup's pipeline fill and 128 KB epilogue (measured, b = 256, us old -> new: 1024 -> 256
+    // @14 38.4 -> 35.7, 1024 -> 512 @14 77.5 -> 70.9; but K = 512: 512 -> 1024 @14 66.6 -> 82.9, 512 -> 2048 @7 39.2 -> 42.5)
     const int tiles = ((M + 255) / 256) * (N / 256);
     const int rounds = (tiles + 255) / 256;
     if (tiles >= 160 && tiles * 100 >= rounds * 256 * 70) {

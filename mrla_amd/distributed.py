@@ -54,6 +54,82 @@ def wrap_data_parallel(model, device_ids=None, bucket_cap_mb=32, force=False):
     return ddp
 
 
+class FlatGradientExchange:
+    """The gradient all-reduce of a data-parallel step as ONE collective on one flat buffer, issued after backward --
+    the form of the exchange that a HIP-graph-captured step can hold (resnet/train.py:174's DistributedDataParallel does
+    the same averaging bucket by bucket from autograd hooks).
+
+    Why not DistributedDataParallel inside the graph: its reducer copies every parameter's gradient into the bucket view
+    with a kernel of its own (161 launches for resnet50_mrlal) and joins its streams per bucket; captured, that step
+    replays no faster than the eager launches (profiles/r03_notes.md section 4), so the N > 1 points would carry the eager
+    launch gaps (~7 % of the step) that the graph-replayed N = 1 point does not.  Here backward leaves the gradients where
+    autograd put them (`.grad` is None before backward, so AccumulateGrad adopts the incoming tensor: no kernel), ONE
+    `_foreach_copy_` gathers them into the flat buffer, one all-reduce (RCCL `avg`) exchanges 4 bytes per parameter, and
+    `.grad` is re-pointed at views of the flat buffer (same sizes and strides as the parameters: the optimizer's layout
+    contract) -- three launches, all capturable.  The all-reduce is not overlapped with backward: 103 MB over xGMI is
+    < 1 ms of a 32 ms step, less than the tiny-kernel tax of the overlapped form.
+
+    usage per step:  opt.zero_grad(set_to_none=True); loss.backward(); exchange.reduce(); opt.step()"""
+
+    def __init__(self, params, group=None, broadcast=True):
+        self.params = [p for p in params if p.requires_grad]
+        if not self.params:
+            raise ValueError("no trainable parameters")
+        self.group = group
+        dev, dt = self.params[0].device, self.params[0].dtype
+        for p in self.params:
+            if p.device != dev or p.dtype != dt:
+                raise ValueError("FlatGradientExchange expects all trainable parameters on one device in one dtype")
+            if not _is_dense(p):
+                raise ValueError(f"parameter of shape {tuple(p.shape)} / stride {p.stride()} is not dense")
+        self.flat = torch.zeros(sum(p.numel() for p in self.params), dtype=dt, device=dev)
+        self.views, off = [], 0
+        for p in self.params:
+            n = p.numel()
+            self.views.append(self.flat[off:off + n].as_strided(p.size(), p.stride()))   # the parameter's own memory order
+            off += n
+        self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+        self._avg = dist.is_initialized() and dist.get_backend(group) == "nccl"
+        if broadcast and dist.is_initialized() and self.world > 1:         # what DistributedDataParallel does when it is built
+            with torch.no_grad():
+                for p in self.params:
+                    dist.broadcast(p, src=0, group=group)
+
+    def reduce(self):
+        """After backward: average the gradients over the ranks; afterwards every `p.grad` is a view of the flat buffer."""
+        dst, src = [], []
+        for p, v in zip(self.params, self.views):
+            if p.grad is None:                   # a parameter that took no part in this step contributes zeros
+                v.zero_()
+            elif p.grad.data_ptr() != v.data_ptr():
+                dst.append(v)
+                src.append(p.grad)               # (any strides: copy_ semantics; the usual case is the parameter's own)
+        if dst:
+            torch._foreach_copy_(dst, src)
+        if dist.is_initialized():
+            if self._avg:
+                dist.all_reduce(self.flat, op=dist.ReduceOp.AVG, group=self.group)
+            else:
+                if self.world > 1:
+                    self.flat.div_(self.world)
+                dist.all_reduce(self.flat, op=dist.ReduceOp.SUM, group=self.group)
+        for p, v in zip(self.params, self.views):
+            p.grad = v
+
+
+def _is_dense(t):
+    """Non-overlapping and dense in some dimension order (contiguous or channels_last parameters)."""
+    if t.numel() == 0:
+        return True
+    dims = sorted((d for d in range(t.dim()) if t.size(d) > 1), key=lambda d: t.stride(d))
+    expect = 1
+    for d in dims:
+        if t.stride(d) != expect:
+            return False
+        expect *= t.size(d)
+    return True
+
+
 def _allreduce_avg_hook(state, bucket):
     buf = bucket.buffer()
     if dist.get_backend() == "nccl":

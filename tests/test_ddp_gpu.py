@@ -100,18 +100,21 @@ def test_model_under_ddp_two_ranks_one_gpu(arch, amp, tmp_path):
     assert not torch.allclose(res[0]["stats"][k], res[1]["stats"][k])        # no SyncBN / buffer broadcast
 
 
-def test_bench_py_under_torch_distributed_run_two_ranks_one_gpu():
+@pytest.mark.parametrize("dp", ["default", "ddp"])
+def test_bench_py_under_torch_distributed_run_two_ranks_one_gpu(dp):
     """The exact launch line of the driver's N > 1 runs (`python -m torch.distributed.run --nnodes=1 --nproc-per-node N
     --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...`, resnet/train.py:133,166-174) with two ranks sharing
     the one GPU over gloo (MRLA_DIST_BACKEND; RCCL refuses two ranks on one device): the N > 1 code path of bench.py --
-    process-group set-up, DDP wrapper, barrier-bracketed timing, max over ranks, rank-0-only JSON -- must keep producing
-    the contract's line.  Started as a fresh child process, before which nothing of it has touched the GPU."""
+    process-group set-up, the gradient exchange (default: FlatGradientExchange, launched eagerly here because a gloo
+    exchange cannot be captured; `--dp ddp`: the DistributedDataParallel wrapper), barrier-bracketed timing, max over ranks,
+    rank-0-only JSON -- must keep producing the contract's line.  Started as a fresh child process, before which nothing of
+    it has touched the GPU."""
     import json
     root = os.path.dirname(HERE)
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", MRLA_DIST_BACKEND="gloo", PYTHONPATH=root)
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
            "--master-port", str(_free_port()), os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
-           "--batch", "8", "--no-baselines", "--benchmark", "0"]
+           "--batch", "8", "--no-baselines", "--benchmark", "0"] + (["--dp", "ddp"] if dp == "ddp" else [])
     p = subprocess.run(cmd, env=env, cwd=root, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=1200)
     out, err = p.stdout.decode(errors="replace"), p.stderr.decode(errors="replace")
     assert p.returncode == 0, (out + err)[-4000:]
@@ -122,9 +125,83 @@ def test_bench_py_under_torch_distributed_run_two_ranks_one_gpu():
     assert rec["config"]["global_batch"] == 16 and rec["config"]["parallelism"] == "dp2"
     assert rec["scaling"] == "weak" and rec["higher_is_better"] is True and rec["unit"] == "images/sec"
     assert rec["metric"].startswith("images/sec fwd+bwd resnet50_mrlal") and rec["value"] > 0
-    assert rec["config"]["launch"].startswith(("kernel by kernel", "one HIP graph"))
+    assert rec["config"]["launch"].startswith("kernel by kernel")             # gloo: nothing to capture
+    assert rec["config"]["gradient_exchange"].startswith("DistributedDataParallel" if dp == "ddp" else "one all-reduce")
     assert rec["roofline"] is not None and rec["roofline"]["bound"] == "hbm" and rec["roofline"]["achieved"] > 0
     assert rec["roofline"]["kernel"].startswith("mrla_light_apply_bwd")
     assert "cpu_baseline" not in rec and "forward_only" not in rec            # N = 1 legs only
     # value is the whole job: 16 images per step over the slowest rank's time
     assert abs(rec["value"] - 16 * 1e3 / rec["ms_per_step"]) / rec["value"] < 1e-2
+
+
+def test_bench_py_graph_captures_the_rccl_exchange_one_rank():
+    """What the driver's N > 1 runs do by default -- the whole step INCLUDING the gradient all-reduce replayed from one HIP
+    graph -- on the one GPU there is: `bench.py --ddp-probe` builds a one-rank RCCL process group, so that the flat
+    all-reduce is a real RCCL launch that has to survive stream capture and replay."""
+    import json
+    root = os.path.dirname(HERE)
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", PYTHONPATH=root)
+    env.pop("MRLA_DIST_BACKEND", None)
+    cmd = [sys.executable, os.path.join(root, "bench.py"), "--ddp-probe", "--steps", "3", "--warmup", "1", "--batch", "8",
+           "--no-baselines", "--benchmark", "0"]
+    p = subprocess.run(cmd, env=env, cwd=root, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=1200)
+    out, err = p.stdout.decode(errors="replace"), p.stderr.decode(errors="replace")
+    assert p.returncode == 0, (out + err)[-4000:]
+    rec = json.loads([ln for ln in out.splitlines() if ln.startswith("{")][0])
+    assert rec["config"]["launch"].startswith("one HIP graph per step (captured fwd+loss+bwd+gradient all-reduce"), err[-2000:]
+    assert rec["config"]["gradient_exchange"].startswith("one all-reduce")
+    assert rec["value"] > 0 and rec["eager_launch_ms_per_step"] > 0
+
+
+def test_flat_exchange_step_replayed_from_a_graph_equals_eager_steps():
+    """`.grad` is re-pointed at views of the flat buffer inside the captured step: the optimizer kernels of the REPLAYED graph
+    must read the gradients of the replay, not of the capture.  Same toy network, same data, 4 steps launched eagerly vs 4
+    steps of one captured graph (weights, momentum buffers and BatchNorm statistics compared)."""
+    from mrla_amd import distributed as D
+
+    def run(graphed):
+        torch.manual_seed(3)
+        net = torch.nn.Sequential(torch.nn.Conv2d(3, 16, 3, padding=1), torch.nn.BatchNorm2d(16), torch.nn.ReLU(),
+                                  torch.nn.Conv2d(16, 8, 1), torch.nn.AdaptiveAvgPool2d(1), torch.nn.Flatten(),
+                                  torch.nn.Linear(8, 5)).cuda().to(memory_format=torch.channels_last)
+        ex = D.FlatGradientExchange(net.parameters())
+        opt = torch.optim.SGD(net.parameters(), lr=0.05, momentum=0.9)
+        g = torch.Generator(device="cuda").manual_seed(11)
+        x = torch.randn(8, 3, 12, 12, device="cuda", generator=g)
+        y = torch.randint(0, 5, (8,), device="cuda", generator=g)
+        xs = [torch.randn(8, 3, 12, 12, device="cuda", generator=g) for _ in range(4)]
+
+        def step():
+            loss = torch.nn.functional.cross_entropy(net(x), y)
+            opt.zero_grad(set_to_none=True)
+            loss.backward()
+            ex.reduce()
+            opt.step()
+        if graphed:
+            state = [p.detach().clone() for p in net.parameters()] + [b.clone() for b in net.buffers()]
+            side = torch.cuda.Stream()
+            side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(side):
+                for _ in range(3):
+                    step()                                  # (warm-up: allocates the optimizer state)
+            torch.cuda.current_stream().wait_stream(side)
+            gr = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(gr):
+                step()
+            with torch.no_grad():                           # back to the initial state, then 4 replays on fresh inputs
+                for t, s0 in zip(list(net.parameters()) + list(net.buffers()), state):
+                    t.copy_(s0)
+                for st in opt.state.values():
+                    st["momentum_buffer"].zero_()
+            for xi in xs:
+                x.copy_(xi)
+                gr.replay()
+        else:
+            for xi in xs:
+                x.copy_(xi)
+                step()
+        torch.cuda.synchronize()
+        return [p.detach().clone() for p in net.parameters()] + [b.clone().float() for b in net.buffers()]
+    a, b = run(False), run(True)
+    for u, v in zip(a, b):
+        assert torch.allclose(u, v, rtol=1e-4, atol=1e-5), (u - v).abs().max()

@@ -61,3 +61,54 @@ def test_ddp_gloo_world2_matches_manual_average():
         for a, b in zip(res[r]["grads"], want):
             assert torch.allclose(a, b, atol=1e-6)
     assert not torch.allclose(res[0]["rm"], res[1]["rm"])
+
+
+def _flat_worker(rank, world, port, out):
+    os.environ.update(RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1",
+                      MASTER_PORT=str(port))
+    from mrla_amd import distributed as D
+    D.init_from_env("gloo")
+    torch.manual_seed(7 + rank)                         # ranks start from DIFFERENT weights: the constructor broadcasts rank 0's
+    net = nn.Sequential(nn.Conv2d(3, 8, 3, padding=1), nn.BatchNorm2d(8), nn.ReLU(), nn.Conv2d(8, 4, 1),
+                        nn.AdaptiveAvgPool2d(1), nn.Flatten(), nn.Linear(4, 5), nn.Linear(5, 5))
+    net = net.to(memory_format=torch.channels_last)
+    for p in net[7].parameters():                        # a parameter that never receives a gradient
+        p.requires_grad_(True)
+    ex = D.FlatGradientExchange(net.parameters())
+    w0 = [p.detach().clone() for p in net.parameters()]
+    opt = torch.optim.SGD(net.parameters(), lr=0.1, momentum=0.9)
+    g = torch.Generator().manual_seed(100 + rank)
+    steps = []
+    for _ in range(2):                                   # two steps: `.grad` is re-pointed at the flat views every step
+        x = torch.randn(4, 3, 6, 6, generator=g).contiguous(memory_format=torch.channels_last)
+        y = torch.randint(0, 5, (4,), generator=g)
+        opt.zero_grad(set_to_none=True)
+        nn.functional.cross_entropy(net[:7](x), y).backward()
+        local = [None if p.grad is None else p.grad.clone() for p in net.parameters()]
+        ex.reduce()
+        for p, v in zip(ex.params, ex.views):
+            assert p.grad is v and p.grad.stride() == p.stride()
+        steps.append(dict(local=local, avg=[p.grad.clone() for p in net.parameters()]))
+        opt.step()
+    out[rank] = dict(w0=w0, steps=steps, w=[p.detach().clone() for p in net.parameters()])
+    torch.distributed.destroy_process_group()
+
+
+def test_flat_gradient_exchange_gloo_world2():
+    """The exchange bench.py captures into the HIP graph at N > 1: initial weights broadcast from rank 0, gradients =
+    the average of the ranks' local gradients (zeros for a parameter without one), `.grad` = views of the flat buffer with
+    the parameters' own (channels_last) strides, identical weights on both ranks after two optimizer steps."""
+    world, port = 2, _free_port()
+    mgr = mp.Manager()
+    out = mgr.dict()
+    mp.spawn(_flat_worker, args=(world, port, out), nprocs=world, join=True)
+    a, b = out[0], out[1]
+    for x, y in zip(a["w0"], b["w0"]):
+        assert torch.equal(x, y)
+    for s in range(2):
+        for i, (la, lb) in enumerate(zip(a["steps"][s]["local"], b["steps"][s]["local"])):
+            want = torch.zeros_like(a["steps"][s]["avg"][i]) if la is None else (la + lb) / 2
+            assert torch.allclose(a["steps"][s]["avg"][i], want, atol=1e-7), (s, i)
+            assert torch.equal(a["steps"][s]["avg"][i], b["steps"][s]["avg"][i])
+    for x, y in zip(a["w"], b["w"]):
+        assert torch.equal(x, y)

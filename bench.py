@@ -9,8 +9,9 @@ ImageNet-shaped data (BASELINE.json metric / configs[1]; configs[2] for --gpus N
 A "step" = forward + loss + backward + SGD update on one synthetic batch already resident in HBM.  On a single GPU the
 timed steps replay the whole step from one HIP graph (`config.launch`; `--graph 0` times PyTorch's kernel-by-kernel
 launches instead).  Under torch.distributed the step is captured as well, with the gradient exchange inside the graph as
-ONE flat all-reduce after backward (`--dp flat`, mrla_amd/distributed.py: FlatGradientExchange; if the capture fails the
-same step is launched eagerly); `--dp ddp` runs torch's DistributedDataParallel, launched kernel by kernel.  Rank 0 prints
+ONE all-reduce over one flat gradient buffer after backward (`--dp flat`, mrla_amd/distributed.py: FlatGradientExchange;
+MRLA_FLAT_OVERLAP=1: bucketed and sent from backward -- measured slower inside the graph; if the capture fails the same step
+is launched eagerly); `--dp ddp` runs torch's DistributedDataParallel, launched kernel by kernel.  Rank 0 prints
 ONE JSON line.  Besides the contract
 keys it carries
   roofline     -- HBM roofline of the dominant MRLA kernel (mrla_light_apply_bwd), timed live with HIP events on
@@ -61,9 +62,9 @@ def parse():
                          "kernel; -1 (default): 1, except with --dp ddp or a non-RCCL backend")
     ap.add_argument("--backend", default=os.environ.get("MRLA_DIST_BACKEND", "nccl"))
     ap.add_argument("--dp", choices=["auto", "flat", "ddp"], default="auto",
-                    help="gradient exchange at N > 1.  flat: mrla_amd.distributed.FlatGradientExchange -- one all-reduce of "
-                         "one flat buffer after backward, which lets the whole step (exchange included) replay from one HIP "
-                         "graph like the N = 1 point; ddp: torch DistributedDataParallel (bucketed, overlapped with "
+                    help="gradient exchange at N > 1.  flat: mrla_amd.distributed.FlatGradientExchange -- one all-reduce over "
+                         "one flat buffer after backward, which lets the whole step (exchange included) "
+                         "replay from one HIP graph like the N = 1 point; ddp: torch DistributedDataParallel (bucketed, overlapped with "
                          "backward, launched kernel by kernel); auto: flat unless --graph 0")
     ap.add_argument("--ddp-probe", action="store_true",
                     help="diagnostic on one GPU: a ONE-rank process group + DistributedDataParallel around the model, so "
@@ -268,7 +269,7 @@ def main():
     exchange = None
     if dp == "flat":
         net = net.cuda().train()
-        exchange = D.FlatGradientExchange(net.parameters())
+        exchange = D.FlatGradientExchange(net.parameters(), overlap=os.environ.get("MRLA_FLAT_OVERLAP", "0") == "1")
     elif use_graph and dist_on:
         # capturing a DDP step (PyTorch's whole-network-capture recipe): the wrapper is built in a side-stream context and
         # at least 11 DDP iterations run eagerly on a side stream before the capture
@@ -356,7 +357,9 @@ def main():
                "config": {"workload": f"{args.arch} fwd+bwd+SGD, {args.batch} images/GPU of 3x224x224, bf16 autocast, "
                                       f"fp32 master weights, drop_path {args.drop_path}",
                           "global_batch": world * args.batch, "parallelism": f"dp{world}", "launch": launch,
-                          **({"gradient_exchange": {"flat": "one all-reduce (RCCL avg) of one flat fp32 buffer after backward",
+                          **({"gradient_exchange": {"flat": f"{len(exchange.buckets) if exchange else 0} all-reduce(s) (RCCL avg) over one flat "
+                                                            "fp32 gradient buffer" + (", sent from backward as its buckets fill" if exchange and len(exchange.buckets) > 1
+                                                                                     else ", after backward"),
                                                     "ddp": "DistributedDataParallel: 32 MB buckets, overlapped with backward"}[dp]}
                              if dist_on else {}),
                           "path": "eager restatement" if args.eager else

@@ -55,24 +55,26 @@ def wrap_data_parallel(model, device_ids=None, bucket_cap_mb=32, force=False):
 
 
 class FlatGradientExchange:
-    """The gradient all-reduce of a data-parallel step as ONE collective on one flat buffer, issued after backward --
-    the form of the exchange that a HIP-graph-captured step can hold (resnet/train.py:174's DistributedDataParallel does
-    the same averaging bucket by bucket from autograd hooks).
+    """The gradient average of a data-parallel step in a form that a HIP-graph-captured step can hold
+    (resnet/train.py:174's DistributedDataParallel does the same averaging from its reducer).
 
     Why not DistributedDataParallel inside the graph: its reducer copies every parameter's gradient into the bucket view
     with a kernel of its own (161 launches for resnet50_mrlal) and joins its streams per bucket; captured, that step
     replays no faster than the eager launches (profiles/r03_notes.md section 4), so the N > 1 points would carry the eager
-    launch gaps (~7 % of the step) that the graph-replayed N = 1 point does not.  Here backward leaves the gradients where
-    autograd put them (`.grad` is None before backward, so AccumulateGrad adopts the incoming tensor: no kernel), ONE
-    `_foreach_copy_` gathers them into the flat buffer, one all-reduce (RCCL `avg`) exchanges 4 bytes per parameter, and
-    `.grad` is re-pointed at views of the flat buffer (same sizes and strides as the parameters: the optimizer's layout
-    contract) -- three launches, all capturable.  The all-reduce is not overlapped with backward: 103 MB over xGMI is
-    < 1 ms of a 32 ms step, less than the tiny-kernel tax of the overlapped form.
+    launch gaps (~7 % of the step) that the graph-replayed N = 1 point does not.  Here
+      * `.grad` is None before backward, so autograd's AccumulateGrad adopts the incoming gradient tensors (no kernel);
+      * the parameters are laid out in ONE flat buffer in REVERSE registration order (the order backward produces their
+        gradients) and cut into a few buckets (`bucket_mb`); when the last gradient of a bucket has arrived (a
+        post-accumulate hook per parameter counts them down) ONE `_foreach_copy_` gathers the bucket and ONE asynchronous
+        all-reduce (RCCL `avg`) sends it off -- it overlaps the rest of backward, as DDP's buckets do;
+      * `reduce()` (after backward) waits for the collectives and re-points every `.grad` at its view of the flat buffer
+        (same sizes and strides as the parameter: the optimizer's layout contract).
+    2 launches per bucket, all capturable.  overlap=False: one copy and one all-reduce for everything inside reduce().
 
     usage per step:  opt.zero_grad(set_to_none=True); loss.backward(); exchange.reduce(); opt.step()"""
 
-    def __init__(self, params, group=None, broadcast=True):
-        self.params = [p for p in params if p.requires_grad]
+    def __init__(self, params, group=None, broadcast=True, bucket_mb=25, overlap=True):
+        self.params = [p for p in params if p.requires_grad][::-1]          # backward's order
         if not self.params:
             raise ValueError("no trainable parameters")
         self.group = group
@@ -83,38 +85,78 @@ class FlatGradientExchange:
             if not _is_dense(p):
                 raise ValueError(f"parameter of shape {tuple(p.shape)} / stride {p.stride()} is not dense")
         self.flat = torch.zeros(sum(p.numel() for p in self.params), dtype=dt, device=dev)
-        self.views, off = [], 0
+        self.views, self.bucket_of, bounds, off = [], [], [0], 0
+        limit = max(1, int(bucket_mb * (1 << 20)) // self.flat.element_size()) if overlap else self.flat.numel() + 1
         for p in self.params:
             n = p.numel()
+            if off + n - bounds[-1] > limit and off > bounds[-1]:
+                bounds.append(off)
+            self.bucket_of.append(len(bounds) - 1)
             self.views.append(self.flat[off:off + n].as_strided(p.size(), p.stride()))   # the parameter's own memory order
             off += n
+        bounds.append(off)
+        self.buckets = [self.flat[bounds[k]:bounds[k + 1]] for k in range(len(bounds) - 1)]
+        self.members = [[i for i, kb in enumerate(self.bucket_of) if kb == k] for k in range(len(self.buckets))]
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
         self._avg = dist.is_initialized() and dist.get_backend(group) == "nccl"
+        self._pending = [len(m) for m in self.members]
+        self._works = [None] * len(self.buckets)
+        self._sent = [False] * len(self.buckets)
+        self._hooks = []
+        if overlap:
+            for i, p in enumerate(self.params):
+                self._hooks.append(p.register_post_accumulate_grad_hook(self._arrived(self.bucket_of[i])))
         if broadcast and dist.is_initialized() and self.world > 1:         # what DistributedDataParallel does when it is built
             with torch.no_grad():
-                for p in self.params:
+                for p in self.params[::-1]:
                     dist.broadcast(p, src=0, group=group)
 
-    def reduce(self):
-        """After backward: average the gradients over the ranks; afterwards every `p.grad` is a view of the flat buffer."""
+    def _arrived(self, k):
+        def hook(_p):
+            self._pending[k] -= 1
+            if self._pending[k] == 0:
+                self._send(k)
+        return hook
+
+    def _send(self, k):
         dst, src = [], []
-        for p, v in zip(self.params, self.views):
-            if p.grad is None:                   # a parameter that took no part in this step contributes zeros
+        for i in self.members[k]:
+            g, v = self.params[i].grad, self.views[i]
+            if g is None:                        # a parameter that took no part in this step contributes zeros
                 v.zero_()
-            elif p.grad.data_ptr() != v.data_ptr():
+            elif g.data_ptr() != v.data_ptr():
                 dst.append(v)
-                src.append(p.grad)               # (any strides: copy_ semantics; the usual case is the parameter's own)
+                src.append(g)                    # (any strides: copy_ semantics; the usual case is the parameter's own)
         if dst:
             torch._foreach_copy_(dst, src)
         if dist.is_initialized():
+            buf = self.buckets[k]
             if self._avg:
-                dist.all_reduce(self.flat, op=dist.ReduceOp.AVG, group=self.group)
+                self._works[k] = dist.all_reduce(buf, op=dist.ReduceOp.AVG, group=self.group, async_op=True)
             else:
                 if self.world > 1:
-                    self.flat.div_(self.world)
-                dist.all_reduce(self.flat, op=dist.ReduceOp.SUM, group=self.group)
+                    buf.div_(self.world)
+                self._works[k] = dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+        self._sent[k] = True
+
+    def reduce(self):
+        """After backward: finish the exchange; afterwards every `p.grad` is a view of the flat buffer holding the average."""
+        for k in range(len(self.buckets)):
+            if not self._sent[k]:                # no hooks (overlap=False), or a bucket with a parameter that got no gradient
+                self._send(k)
+        for k, w in enumerate(self._works):
+            if w is not None:
+                w.wait()
+            self._works[k] = None
+            self._sent[k] = False
+            self._pending[k] = len(self.members[k])
         for p, v in zip(self.params, self.views):
             p.grad = v
+
+    def remove_hooks(self):
+        for h in self._hooks:
+            h.remove()
+        self._hooks = []
 
 
 def _is_dense(t):

@@ -1,6 +1,6 @@
 #!/bin/bash
 # One-GPU A/B of the N > 1 code paths of bench.py through a one-rank RCCL group (`--ddp-probe`): the flat exchange inside
-# the graph (the default), the flat exchange launched eagerly, DistributedDataParallel launched eagerly, and no process
+# the graph (the default: one all-reduce after backward; MRLA_FLAT_OVERLAP=1: bucketed, sent from backward), the same launched eagerly, DistributedDataParallel launched eagerly, and no process
 # group at all.  Usage: bash scripts/dp_probe.sh [outdir]
 OUT=${1:-gpurun_out/dp_probe}; mkdir -p $OUT
 run() { name=$1; shift; python3 bench.py --no-baselines "$@" > $OUT/$name.out 2> $OUT/$name.err;
@@ -15,6 +15,7 @@ else:
 PY
 }
 run flat_graph --ddp-probe
+MRLA_FLAT_OVERLAP=1 run flat_overlap --ddp-probe
 run flat_eager --ddp-probe --graph 0 --dp flat
 run ddp_eager --ddp-probe --dp ddp
 run single

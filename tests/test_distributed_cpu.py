@@ -63,7 +63,7 @@ def test_ddp_gloo_world2_matches_manual_average():
     assert not torch.allclose(res[0]["rm"], res[1]["rm"])
 
 
-def _flat_worker(rank, world, port, out):
+def _flat_worker(rank, world, port, out, bucket_mb, overlap):
     os.environ.update(RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1",
                       MASTER_PORT=str(port))
     from mrla_amd import distributed as D
@@ -74,7 +74,8 @@ def _flat_worker(rank, world, port, out):
     net = net.to(memory_format=torch.channels_last)
     for p in net[7].parameters():                        # a parameter that never receives a gradient
         p.requires_grad_(True)
-    ex = D.FlatGradientExchange(net.parameters())
+    ex = D.FlatGradientExchange(net.parameters(), bucket_mb=bucket_mb, overlap=overlap)
+    assert (len(ex.buckets) == 1) if (bucket_mb > 1 or not overlap) else (len(ex.buckets) >= 4)
     w0 = [p.detach().clone() for p in net.parameters()]
     opt = torch.optim.SGD(net.parameters(), lr=0.1, momentum=0.9)
     g = torch.Generator().manual_seed(100 + rank)
@@ -94,14 +95,20 @@ def _flat_worker(rank, world, port, out):
     torch.distributed.destroy_process_group()
 
 
-def test_flat_gradient_exchange_gloo_world2():
+import pytest  # noqa: E402
+
+
+@pytest.mark.parametrize("bucket_mb,overlap", [(25, True), (2e-4, True), (25, False)], ids=["one-bucket", "many-buckets", "no-overlap"])
+def test_flat_gradient_exchange_gloo_world2(bucket_mb, overlap):
     """The exchange bench.py captures into the HIP graph at N > 1: initial weights broadcast from rank 0, gradients =
     the average of the ranks' local gradients (zeros for a parameter without one), `.grad` = views of the flat buffer with
-    the parameters' own (channels_last) strides, identical weights on both ranks after two optimizer steps."""
+    the parameters' own (channels_last) strides, identical weights on both ranks after two optimizer steps.  With tiny
+    buckets the per-bucket hooks send several asynchronous all-reduces during backward (one bucket holds only parameters
+    that never receive a gradient: reduce() sends it)."""
     world, port = 2, _free_port()
     mgr = mp.Manager()
     out = mgr.dict()
-    mp.spawn(_flat_worker, args=(world, port, out), nprocs=world, join=True)
+    mp.spawn(_flat_worker, args=(world, port, out, bucket_mb, overlap), nprocs=world, join=True)
     a, b = out[0], out[1]
     for x, y in zip(a["w0"], b["w0"]):
         assert torch.equal(x, y)

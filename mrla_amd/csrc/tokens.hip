@@ -43,9 +43,27 @@ __global__ __launch_bounds__(kThreads) void token_stats_kernel(const T* __restri
   const float invc = 1.0f / (float)C;
   for (int tok = blockIdx.x * kWaves + wave; tok < ntok; tok += gridDim.x * kWaves) {
     const T* xr = x + (size_t)tok * C;
-    const T* orow = o + (size_t)tok * C;
     float xv[kTokRowRegs], ov[kTokRowRegs];
     float sx = 0.f, so = 0.f;
+    if (!o) {                           // MRLA-base on tokens has no o_{t-1}: only x is read, its statistics fill both pairs
+#pragma unroll
+      for (int k = 0; k < kTokRowRegs; ++k) {
+        const int c = lane + k * kWave;
+        xv[k] = c < C ? to_f(xr[c]) : 0.f;
+        sx += xv[k];
+      }
+      const float mx = wave_sum(sx) * invc;
+      float vx = 0.f;
+#pragma unroll
+      for (int k = 0; k < kTokRowRegs; ++k) {
+        const float dxv = lane + k * kWave < C ? xv[k] - mx : 0.f;
+        vx = fmaf(dxv, dxv, vx);
+      }
+      const float rx = rsqrtf(wave_sum(vx) * invc + eps);
+      if (lane == 0) *reinterpret_cast<float4*>(stats + (size_t)tok * S_N) = make_float4(mx, rx, mx, rx);
+      continue;
+    }
+    const T* orow = o + (size_t)tok * C;
 #pragma unroll
     for (int k = 0; k < kTokRowRegs; ++k) {
       const int c = lane + k * kWave;
@@ -379,7 +397,6 @@ static hipError_t set_lds3(K kernel, size_t bytes) {
 int launch_token_norm_pool(const void* x, const void* o, const float* wx, const float* bx, float eps, float* stats,
                            float* mom, int B, int n, int C, int dtype, hipStream_t st) {
   if (C > kWave * kTokRowRegs) return MRLA_EUNSUPPORTED;
-  if (!o) o = x;                        // MRLA-base on tokens has no o_{t-1}: its two statistics slots repeat x's
   const int ntok = B * n;
   const int wgs = std::max(1, std::min((ntok + kWaves - 1) / kWaves, 256 * 32));
 #define CALL(TT)                                                                                                     \

@@ -141,9 +141,16 @@ __global__ __launch_bounds__(kMaxStrips * kWave) void token_apply_fwd_nhwc(
       for (int j = 0; j < kS; ++j) xraw[j] = xnext[j];
     }
   }
+  if (wave == 0 && blockIdx.z == 0) {        // cls row of this (image, 64 channels): out = res*x + LN_x(x)
+    const size_t g = (size_t)b * n * C + c;
+    const float* s = stats + (size_t)b * n * TS_N;
+    const float xv = to_f(x[g]);
+    out[g] = from_f<T>(fmaf(resf, xv, fmaf((xv - s[TS_MX]) * s[TS_RX], wxc, bxc)));
+  }
 }
 
-// cls row: out[b, 0, :] = res*x + LN_x(x)   (one thread per channel; grid (ceil(C/256), b))
+// cls row: out[b, 0, :] = res*x + LN_x(x)   (one thread per channel; grid (ceil(C/256), b)) -- MRLA-base on tokens, whose
+// map rows come from a flat kernel
 template <typename T>
 __global__ __launch_bounds__(kThreads) void token_cls_fwd_kernel(const T* __restrict__ x, const float* __restrict__ stats,
                                                                  const float* __restrict__ wx, const float* __restrict__ bx,
@@ -492,8 +499,6 @@ int launch_token_apply_fwd_nhwc(const void* x, const void* o, const float* stats
     if (set_lds_n(token_apply_fwd_nhwc<TT>, lds) != hipSuccess) return MRLA_EHIP;                                     \
     hipLaunchKernelGGL((token_apply_fwd_nhwc<TT>), grid, block, lds, st, (const TT*)x, (const TT*)o, stats, wx, bx, wo, \
                        bo, wv, gate, lam, (TT*)out, n, C, side, d, res);                                            \
-    hipLaunchKernelGGL((token_cls_fwd_kernel<TT>), dim3((C + kThreads - 1) / kThreads, B), dim3(kThreads), 0, st,    \
-                       (const TT*)x, stats, wx, bx, (TT*)out, n, C, res);                                           \
   }
   MRLA_DISPATCH_TN(dtype, CALL)
 #undef CALL

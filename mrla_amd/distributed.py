@@ -99,6 +99,11 @@ class FlatGradientExchange:
         self.members = [[i for i, kb in enumerate(self.bucket_of) if kb == k] for k in range(len(self.buckets))]
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
         self._avg = dist.is_initialized() and dist.get_backend(group) == "nccl"
+        if self._avg:                            # (an RCCL build without ncclAvg: pre-divide and sum instead)
+            try:
+                dist.all_reduce(torch.zeros(1, dtype=dt, device=dev), op=dist.ReduceOp.AVG, group=group)
+            except (RuntimeError, ValueError):
+                self._avg = False
         self._pending = [len(m) for m in self.members]
         self._works = [None] * len(self.buckets)
         self._sent = [False] * len(self.buckets)

@@ -67,6 +67,7 @@ __global__ __launch_bounds__(kThreads) void bn_fwd_kernel(
     double s1 = 0.0, s2 = 0.0;
     if (live) {
       const float l = lam ? lam[c] : 0.f;
+#pragma unroll 4
       for (int b = bl; b < B; b += kBnLanes) {
         const float* m = mom + ((size_t)b * C + c) * M_REC;
         const double a = gate[(size_t)b * G + c / d];
@@ -120,6 +121,7 @@ __global__ __launch_bounds__(kThreads) void bn_bwd_kernel(
   const float l = (live && lam) ? lam[c] : 0.f;
   double s1 = 0.0, s2 = 0.0;
   if (live) {
+#pragma unroll 4
     for (int b = bl; b < B; b += kBnLanes) {
       const float* bm = bmom + ((size_t)b * C + c) * D_N;
       const float* m = mom + ((size_t)b * C + c) * M_REC;

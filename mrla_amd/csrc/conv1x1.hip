@@ -261,7 +261,7 @@ int conv1x1_rows(int M, int K, int N) {
   if (wide > 0) return wide;
   GemmGeo g;
   if (conv1x1_geo(&g, M, K, N)) return g.rows;
-  return conv1x1_kstream_supported(M, K, N) ? 0 : MRLA_EUNSUPPORTED;   // K >= 512: the product without a statistics epilogue
+  return conv1x1_kstream_supported(M, K, N) ? conv1x1_kstream_rows(M, K, N) : MRLA_EUNSUPPORTED;   // K >= 512: one record row per pixel tile
 }
 
 // {32-pixel blocks per workgroup (wide form) / per pixel-wave (narrow form), pipeline depth in blocks, workgroups, rows}
@@ -269,7 +269,7 @@ int conv1x1_plan(int M, int K, int N, int add, int* out) {
   if (conv1x1_wide_plan(M, K, N, add, out) == MRLA_OK) return MRLA_OK;
   GemmGeo g;
   if (!add && !conv1x1_geo(&g, M, K, N) && conv1x1_kstream_supported(M, K, N)) {
-    out[0] = K / 32; out[1] = conv1x1_kstream_stages(M, K, N); out[2] = 0; out[3] = 0;   // 32-deep chunks per tile, LDS stages, -, no rows
+    out[0] = K / 32; out[1] = conv1x1_kstream_stages(M, K, N); out[2] = 0; out[3] = conv1x1_kstream_rows(M, K, N);   // 32-deep chunks per tile, LDS stages, -, record rows
     return MRLA_OK;
   }
   if (add || !conv1x1_geo(&g, M, K, N)) return MRLA_EUNSUPPORTED;
@@ -285,8 +285,8 @@ int launch_conv1x1_fwd(const void* x, const void* w, void* y, float* part, int M
   if (conv1x1_wide_rows(M, K, N) > 0) return launch_conv1x1_wide(x, w, nullptr, y, part, M, K, N, st);
   GemmGeo g;
   if (!conv1x1_geo(&g, M, K, N)) {
-    if (part || !conv1x1_kstream_supported(M, K, N)) return MRLA_EUNSUPPORTED;
-    return launch_conv1x1_kstream(x, w, y, M, K, N, st);
+    if (!conv1x1_kstream_supported(M, K, N)) return MRLA_EUNSUPPORTED;
+    return launch_conv1x1_kstream(x, w, y, part, M, K, N, st);
   }
   const dim3 grid(g.gx, g.gy), block(g.NW * kWave);
 #define CALL_W(KS, MO, NWV)                                                                                          \

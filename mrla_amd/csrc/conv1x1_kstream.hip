@@ -68,11 +68,78 @@ __device__ __forceinline__ void ks_fence(u32x4& v, bool wait) {
 __device__ __forceinline__ int ks_swz(int row) { return (row >> 2) & 3; }      // slot swizzle of a 64-byte row
 __device__ __forceinline__ int ks_oswz(int row) { return row & 7; }            // chunk swizzle of an output-tile row
 
-template <int WN, int PB>
+
+// Copy the staged bf16 tile [TM][TN] (16-byte chunks swizzled by ks_oswz) out as whole rows; MOM: also the BatchNorm moment
+// record of this pixel tile per channel (MRLA_GEMM_MOMENTS: sum (y - p), sum (y - p)^2, p, count; y = the ROUNDED outputs,
+// p = the tile's first pixel) -- thread (srow, chunk) keeps eight channels over its rows, the RPI row-threads of a chunk are
+// folded through LDS in a fixed order once the tile has been read.
+template <int TM, int TN, bool MOM>
+__device__ __forceinline__ void ks_store_tile(unsigned char* smem_raw, unsigned lds0, bf16_t* __restrict__ Y,
+                                              float* __restrict__ mom_part, int M, int N, int m0, int n0, int tile) {
+  constexpr int CPR = TN / 8, RPI = (kKsWaves * kWave) / CPR;
+  const int srow = threadIdx.x / CPR, chunk = threadIdx.x % CPR;
+  float piv[8], s1[8], s2[8];
+  if (MOM) {
+    u32x4 pv;
+    ks_read16(pv, lds0 + ((chunk ^ ks_oswz(0)) << 4));               // tile row 0
+    ks_fence<0>(pv, true);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const unsigned wv = j == 0 ? pv.x : j == 1 ? pv.y : j == 2 ? pv.z : pv.w;
+      piv[2 * j] = __uint_as_float(wv << 16);
+      piv[2 * j + 1] = __uint_as_float(wv & 0xffff0000u);
+      s1[2 * j] = s1[2 * j + 1] = s2[2 * j] = s2[2 * j + 1] = 0.f;
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < TM / RPI; ++i) {
+    const int row = srow + RPI * i;
+    u32x4 v;
+    ks_read16(v, lds0 + row * (TN * 2) + ((chunk ^ ks_oswz(row)) << 4));
+    ks_fence<0>(v, true);
+    if (m0 + row < M) {
+      *reinterpret_cast<u32x4*>(Y + (size_t)(m0 + row) * N + n0 + chunk * 8) = v;
+      if (MOM) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const unsigned wv = j == 0 ? v.x : j == 1 ? v.y : j == 2 ? v.z : v.w;
+          const float d0 = __uint_as_float(wv << 16) - piv[2 * j], d1 = __uint_as_float(wv & 0xffff0000u) - piv[2 * j + 1];
+          s1[2 * j] += d0; s2[2 * j] = fmaf(d0, d0, s2[2 * j]);
+          s1[2 * j + 1] += d1; s2[2 * j + 1] = fmaf(d1, d1, s2[2 * j + 1]);
+        }
+      }
+    }
+  }
+  if (MOM) {
+    float* red = reinterpret_cast<float*>(smem_raw);              // [RPI][TN][2] + [TN] pivots, over the (now read) tile
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      red[((srow * TN) + chunk * 8 + j) * 2 + 0] = s1[j];
+      red[((srow * TN) + chunk * 8 + j) * 2 + 1] = s2[j];
+    }
+    if (srow == 0) {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) red[RPI * TN * 2 + chunk * 8 + j] = piv[j];
+    }
+    __syncthreads();
+    if ((int)threadIdx.x < TN) {
+      const int ch = threadIdx.x;
+      float a = 0.f, b = 0.f;
+      for (int q = 0; q < RPI; ++q) { a += red[((q * TN) + ch) * 2 + 0]; b += red[((q * TN) + ch) * 2 + 1]; }
+      float4 rec;
+      rec.x = a; rec.y = b; rec.z = red[RPI * TN * 2 + ch]; rec.w = (float)min(TM, M - m0);
+      *reinterpret_cast<float4*>(mom_part + ((size_t)tile * N + n0 + ch) * 4) = rec;
+    }
+  }
+}
+
+template <int WN, int PB, bool MOM>
 __global__ __launch_bounds__(kKsWaves* kWave, 4) void conv1x1_kstream_kernel(const bf16_t* __restrict__ X,
                                                                              const bf16_t* __restrict__ W,
-                                                                             bf16_t* __restrict__ Y, int M, int N, int K,
-                                                                             int tiles_m, int groups_n) {
+                                                                             bf16_t* __restrict__ Y,
+                                                                             float* __restrict__ mom_part, int M, int N,
+                                                                             int K, int tiles_m, int groups_n) {
 #if defined(__HIP_DEVICE_COMPILE__)
   typedef KsGeo<WN, PB> G;
   extern __shared__ __align__(16) unsigned char smem_raw[];
@@ -223,18 +290,7 @@ __global__ __launch_bounds__(kKsWaves* kWave, 4) void conv1x1_kstream_kernel(con
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
   __builtin_amdgcn_s_barrier();
   asm volatile("" ::: "memory");
-  {
-    constexpr int CPR = G::CPR, RPI = (kKsWaves * kWave) / CPR;     // rows per pass of the 512 threads
-    const int srow = threadIdx.x / CPR, chunk = threadIdx.x % CPR;
-#pragma unroll
-    for (int i = 0; i < G::TM / RPI; ++i) {
-      const int row = srow + RPI * i;
-      u32x4 v;
-      ks_read16(v, lds0 + row * (G::TN * 2) + ((chunk ^ ks_oswz(row)) << 4));
-      ks_fence<0>(v, true);
-      if (m0 + row < M) *reinterpret_cast<u32x4*>(Y + (size_t)(m0 + row) * N + n0 + chunk * 8) = v;
-    }
-  }
+  ks_store_tile<G::TM, G::TN, MOM>(smem_raw, lds0, Y, mom_part, M, N, m0, n0, tile);
 #endif
 }
 
@@ -252,10 +308,12 @@ struct Ks256 {
   static constexpr int kLds = ST * SB;                  // 128 KB: also exactly the bf16 output tile
 };
 
+template <bool MOM>
 __global__ __launch_bounds__(kKsWaves* kWave, 2) void conv1x1_kstream256_kernel(const bf16_t* __restrict__ X,
                                                                                const bf16_t* __restrict__ W,
-                                                                               bf16_t* __restrict__ Y, int M, int N, int K,
-                                                                               int tiles_m, int groups_n) {
+                                                                               bf16_t* __restrict__ Y,
+                                                                               float* __restrict__ mom_part, int M, int N,
+                                                                               int K, int tiles_m, int groups_n) {
 #if defined(__HIP_DEVICE_COMPILE__)
   typedef Ks256 G;
   constexpr int PB = G::PB;
@@ -406,18 +464,7 @@ __global__ __launch_bounds__(kKsWaves* kWave, 2) void conv1x1_kstream256_kernel(
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
   __builtin_amdgcn_s_barrier();
   asm volatile("" ::: "memory");
-  {
-    constexpr int CPR = G::TN / 8, RPI = (kKsWaves * kWave) / CPR;
-    const int srow = threadIdx.x / CPR, chunk = threadIdx.x % CPR;
-#pragma unroll
-    for (int i = 0; i < G::TM / RPI; ++i) {
-      const int row = srow + RPI * i;
-      u32x4 v;
-      ks_read16(v, lds0 + row * (G::TN * 2) + ((chunk ^ ks_oswz(row)) << 4));
-      ks_fence<0>(v, true);
-      if (m0 + row < M) *reinterpret_cast<u32x4*>(Y + (size_t)(m0 + row) * N + n0 + chunk * 8) = v;
-    }
-  }
+  ks_store_tile<G::TM, G::TN, MOM>(smem_raw, lds0, Y, mom_part, M, N, m0, n0, tile);
 #endif
 }
 
@@ -456,31 +503,39 @@ KsPlan ks_plan(int M, int K, int N) {
   return p;
 }
 
-template <int WN, int PB>
-int ks_launch(const KsPlan& p, const void* x, const void* w, void* y, int M, int K, int N, hipStream_t st) {
+template <int WN, int PB, bool MOM>
+int ks_launch_m(const KsPlan& p, const void* x, const void* w, void* y, float* part, int M, int K, int N, hipStream_t st) {
   typedef KsGeo<WN, PB> G;
-  if (lds_opt_in(reinterpret_cast<const void*>(conv1x1_kstream_kernel<WN, PB>), G::kLds) != hipSuccess) return MRLA_EHIP;
-  hipLaunchKernelGGL((conv1x1_kstream_kernel<WN, PB>), dim3((p.tiles_m * p.groups_n + 7) / 8 * 8), dim3(kKsWaves * kWave),
-                     G::kLds, st, (const bf16_t*)x, (const bf16_t*)w, (bf16_t*)y, M, N, K, p.tiles_m, p.groups_n);
+  if (lds_opt_in(reinterpret_cast<const void*>(conv1x1_kstream_kernel<WN, PB, MOM>), G::kLds) != hipSuccess) return MRLA_EHIP;
+  hipLaunchKernelGGL((conv1x1_kstream_kernel<WN, PB, MOM>), dim3((p.tiles_m * p.groups_n + 7) / 8 * 8), dim3(kKsWaves * kWave),
+                     G::kLds, st, (const bf16_t*)x, (const bf16_t*)w, (bf16_t*)y, part, M, N, K, p.tiles_m, p.groups_n);
+  return hip_status(hipGetLastError());
+}
+template <int WN, int PB>
+int ks_launch(const KsPlan& p, const void* x, const void* w, void* y, float* part, int M, int K, int N, hipStream_t st) {
+  return part ? ks_launch_m<WN, PB, true>(p, x, w, y, part, M, K, N, st) : ks_launch_m<WN, PB, false>(p, x, w, y, part, M, K, N, st);
+}
+template <bool MOM>
+int ks_launch256(const KsPlan& p, const void* x, const void* w, void* y, float* part, int M, int K, int N, hipStream_t st) {
+  if (lds_opt_in(reinterpret_cast<const void*>(conv1x1_kstream256_kernel<MOM>), Ks256::kLds) != hipSuccess) return MRLA_EHIP;
+  hipLaunchKernelGGL(conv1x1_kstream256_kernel<MOM>, dim3((p.tiles_m * p.groups_n + 7) / 8 * 8), dim3(kKsWaves * kWave),
+                     Ks256::kLds, st, (const bf16_t*)x, (const bf16_t*)w, (bf16_t*)y, part, M, N, K, p.tiles_m, p.groups_n);
   return hip_status(hipGetLastError());
 }
 
 }  // namespace
 
 int conv1x1_kstream_supported(int M, int K, int N) { return ks_plan(M, K, N).wn ? 1 : 0; }
+int conv1x1_kstream_rows(int M, int K, int N) { return ks_plan(M, K, N).tiles_m; }      // pixel tiles = record rows
 int conv1x1_kstream_stages(int M, int K, int N) { return ks_plan(M, K, N).big ? Ks256::ST : kKsStages; }
 
-int launch_conv1x1_kstream(const void* x, const void* w, void* y, int M, int K, int N, hipStream_t st) {
+// part != null: moment records [conv1x1_kstream_rows()][N][MRLA_GEMM_MOMENTS] of the rounded outputs (one row per pixel tile)
+int launch_conv1x1_kstream(const void* x, const void* w, void* y, float* part, int M, int K, int N, hipStream_t st) {
   const KsPlan p = ks_plan(M, K, N);
   if (!p.wn) return MRLA_EUNSUPPORTED;
-  if (p.big) {
-    if (lds_opt_in(reinterpret_cast<const void*>(conv1x1_kstream256_kernel), Ks256::kLds) != hipSuccess) return MRLA_EHIP;
-    hipLaunchKernelGGL(conv1x1_kstream256_kernel, dim3((p.tiles_m * p.groups_n + 7) / 8 * 8), dim3(kKsWaves * kWave),
-                       Ks256::kLds, st, (const bf16_t*)x, (const bf16_t*)w, (bf16_t*)y, M, N, K, p.tiles_m, p.groups_n);
-    return hip_status(hipGetLastError());
-  }
-  if (p.wn == 4) return p.pb == 2 ? ks_launch<4, 2>(p, x, w, y, M, K, N, st) : ks_launch<4, 1>(p, x, w, y, M, K, N, st);
-  return p.pb == 2 ? ks_launch<2, 2>(p, x, w, y, M, K, N, st) : ks_launch<2, 1>(p, x, w, y, M, K, N, st);
+  if (p.big) return part ? ks_launch256<true>(p, x, w, y, part, M, K, N, st) : ks_launch256<false>(p, x, w, y, part, M, K, N, st);
+  if (p.wn == 4) return p.pb == 2 ? ks_launch<4, 2>(p, x, w, y, part, M, K, N, st) : ks_launch<4, 1>(p, x, w, y, part, M, K, N, st);
+  return p.pb == 2 ? ks_launch<2, 2>(p, x, w, y, part, M, K, N, st) : ks_launch<2, 1>(p, x, w, y, part, M, K, N, st);
 }
 
 }  // namespace mrla

@@ -180,7 +180,8 @@ int launch_conv1x1_wide(const void* x, const void* w, const void* addend, void* 
 // conv1x1_kstream.hip -- the same product for wide reductions (K >= 512): both operands streamed through LDS, no epilogue
 int conv1x1_kstream_supported(int M, int K, int N);
 int conv1x1_kstream_stages(int M, int K, int N);      // LDS stages of the kernel the planner picks (3, or 4: the 256 x 256 tile)
-int launch_conv1x1_kstream(const void* x, const void* w, void* y, int M, int K, int N, hipStream_t st);
+int conv1x1_kstream_rows(int M, int K, int N);        // rows of the moment records (one per pixel tile)
+int launch_conv1x1_kstream(const void* x, const void* w, void* y, float* part, int M, int K, int N, hipStream_t st);
 // conv1x1_wgrad.hip -- its weight gradient dW[n,k] = sum_m dY[m,n] X[m,k] as a split-M MFMA GEMM (bf16)
 int conv1x1_wgrad_rows(int M, int K, int N);
 int conv1x1_wgrad_plan(int M, int K, int N, int* out);

@@ -63,10 +63,10 @@ def test_unsupported_shapes_are_reported_not_run():
     from mrla_amd import _lib as L
     lib = L.load()
     assert lib.mrla_conv1x1_rows(64, 96, 64, L.BF16) == L.EUNSUPPORTED        # k not in {64, 128, 256} and < 512
-    assert lib.mrla_conv1x1_rows(64, 1024, 256, L.BF16) == 0                   # the K-streaming kernel: no statistics rows
-    assert lib.mrla_conv1x1_rows(64, 512, 128, L.BF16) == 0
+    assert lib.mrla_conv1x1_rows(64, 1024, 256, L.BF16) == 1                   # the K-streaming kernel: one record row per pixel tile
+    assert lib.mrla_conv1x1_rows(64, 512, 128, L.BF16) == 1 and lib.mrla_conv1x1_rows(4 * 3136, 512, 128, L.BF16) > 1
     assert lib.mrla_conv1x1_rows(64, 512, 64, L.BF16) == L.EUNSUPPORTED        # ... needs n % 128 == 0
-    assert lib.mrla_conv1x1_rows(64, 544, 128, L.BF16) == 0 and lib.mrla_conv1x1_rows(64, 520, 128, L.BF16) == L.EUNSUPPORTED
+    assert lib.mrla_conv1x1_rows(64, 544, 128, L.BF16) == 1 and lib.mrla_conv1x1_rows(64, 520, 128, L.BF16) == L.EUNSUPPORTED
     assert lib.mrla_conv1x1_fwd(None, None, None, None, 64, 1024, 256, L.BF16, None) == L.EINVAL
     assert lib.mrla_conv1x1_rows(48, 64, 64, L.BF16) > 0                       # ragged last pixel block
     assert lib.mrla_conv1x1_rows(1, 256, 64, L.BF16) == 1                       # a single pixel: one workgroup, one row

@@ -184,18 +184,36 @@ KSTREAM = [(28, 28, 512, 128), (28, 28, 512, 256), (14, 14, 1024, 256), (14, 14,
 def test_kstream_gemm_at_bench_sizes(shape, batch):
     """mrla_conv1x1_fwd on the wide reductions (both operands streamed through a three- or four-stage LDS ring, 16 - 64
     chunks per tile: the ring wraps 4 - 21 times) vs a float64 product rounded once; two launches bit-equal; poisoned
-    output.  The batches cover both kernels of the planner: 256 x 256 tiles where they fill the chip, the smaller tiles
-    elsewhere (7 x 7 maps, n = 128)."""
+    output; with and without the moment-record epilogue (records vs float64 statistics of the stored tensor).  The batches
+    cover both kernels of the planner: 256 x 256 tiles where they fill the chip, the smaller tiles elsewhere (7 x 7 maps,
+    n = 128)."""
     from mrla_amd import _lib as L
     h, w_, k, n = shape
     m = 256 * h * w_ - 37 if batch == "ragged" else batch * h * w_
-    assert L.load().mrla_conv1x1_rows(m, k, n, L.BF16) == 0
     chunks, stages, _, rows = L.conv1x1_plan(m, k, n)
-    assert chunks >= 4 * stages and rows == 0
+    assert chunks >= 4 * stages and rows > 0 and rows == L.load().mrla_conv1x1_rows(m, k, n, L.BF16)
     x, w = _operands(m, k, n, seed=4000 + k + n)
-    y, _ = _run_fwd(x, w, m, k, n, 0, False)
-    y2, _ = _run_fwd(x, w, m, k, n, 0, False)
+    y, part = _run_fwd(x, w, m, k, n, rows, True)
+    y2, part2 = _run_fwd(x, w, m, k, n, rows, True)
+    y3, _ = _run_fwd(x, w, m, k, n, rows, False)
     torch.cuda.synchronize()
-    assert torch.equal(y, y2), "two runs of the same launch differ"
+    assert torch.equal(y, y2) and torch.equal(part, part2), "two runs of the same launch differ"
+    assert torch.equal(y, y3), "the kernel without the moments epilogue stores different outputs"
     want = x.double() @ w.double().t()
     _assert_bf16_close(y, want, "y")
+    del want
+    # the moment records (one row per pixel tile): counts, and mean / variance of the stored tensor merged as the
+    # per-channel kernel merges them
+    g = y.double()
+    r = part.double()
+    assert r[:, :, 3].sum(0).eq(m).all() and (r[:, :, 3] > 0).all()
+    tm = int(r[0, 0, 3].item())
+    assert torch.equal(part[:, :, 2], y[::tm].float()[:rows]), "pivots are the first pixel of every tile"
+    mean, var = g.mean(0), g.var(dim=0, unbiased=False)
+    P = r[0, :, 2]
+    d = r[..., 2] - P
+    S1 = (r[..., 0] + r[..., 3] * d).sum(0)
+    S2 = (r[..., 1] + 2 * d * r[..., 0] + r[..., 3] * d * d).sum(0)
+    mean_k, var_k = S1 / m + P, S2 / m - (S1 / m) ** 2
+    assert ((mean_k - mean).abs() / var.sqrt()).max().item() < 1e-5
+    assert ((var_k - var).abs() / var).max().item() < 1e-5

@@ -46,7 +46,7 @@ def test_argument_validation_without_a_gpu():
     assert lib.mrla_light_pool_fused(None, None, None, None, None, None, 1, 64, 4, 4, _lib.BF16, _lib.NHWC, None) == _lib.EINVAL
     assert lib.mrla_bn_moment_rows(256, 256, 56, 56, _lib.NHWC) == 256 * 4 and lib.mrla_bn_moment_rows(8, 64, 7, 7, _lib.NCHW) == 8
     # 1x1-convolution GEMMs: workspace rows of the forward moments / the weight-gradient partial tiles, argument checks
-    assert lib.mrla_conv1x1_rows(64, 512, 128, _lib.BF16) == 0 and lib.mrla_conv1x1_rows(64, 96, 64, _lib.BF16) == _lib.EUNSUPPORTED and lib.mrla_conv1x1_rows(48, 64, 64, _lib.BF16) > 0
+    assert lib.mrla_conv1x1_rows(64, 512, 128, _lib.BF16) == 1 and lib.mrla_conv1x1_rows(64, 96, 64, _lib.BF16) == _lib.EUNSUPPORTED and lib.mrla_conv1x1_rows(48, 64, 64, _lib.BF16) > 0
     assert lib.mrla_conv1x1_wgrad_rows(256 * 56 * 56, 64, 256, _lib.BF16) == 256        # one 64x256 tile x 256 pixel ranges
     assert lib.mrla_conv1x1_wgrad_rows(256 * 7 * 7, 2048, 512, _lib.BF16) == 8          # 32 tiles of 128x256 x 8 ranges
     assert lib.mrla_conv1x1_wgrad_rows(33, 64, 64, _lib.BF16) == 2                      # two 32-pixel chunks

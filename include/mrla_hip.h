@@ -398,12 +398,13 @@ int mrla_bn_relu_pool_bwd(const void* dp, const void* x, const float* sc, const 
  *   mom_part[row, n, 0..3] [opt] = moment record (MRLA_GEMM_MOMENTS) over the row's pixels of the ROUNDED outputs --
  *   the statistics mrla_bn_plane_moments would read back from y, taken about a per-row pivot so that the one-pass
  *   variance stays well conditioned when |mean| >> sigma; hand it to mrla_bn_stats_fwd_rows.
- * Three kernels behind it: k in {64, 128, 256} with n % 64 == 0 (weights resident on chip, statistics epilogue), and
- * k >= 512 with k % 32 == 0, n % 128 == 0 (both operands streamed; NO statistics epilogue: mom_part must be NULL).
+ * Three kernel families behind it: k in {64, 128, 256} with n % 64 == 0 (weights resident on chip; one record row per
+ * workgroup row), and k >= 512 with k % 32 == 0, n % 128 == 0 (both operands streamed; one record row per pixel tile).
+ * mom_part may be NULL (no statistics wanted: the input-gradient use, inference).
  * MRLA_EUNSUPPORTED for other shapes and for dtypes other than MRLA_BF16: the caller keeps its stock convolution there.
  * (The input gradient dX = dY * W is the same entry point with w^T.) */
-int mrla_conv1x1_rows(int m, int k, int n, int dtype);      /* rows of mom_part (> 0); 0: supported, but without the
-                                                               statistics epilogue (k >= 512); or a negative code */
+int mrla_conv1x1_rows(int m, int k, int n, int dtype);      /* rows of mom_part (> 0), or a negative code (a caller should
+                                                               treat 0 as "supported, no statistics epilogue") */
 /* How the launch of this problem is laid out (host-side query, `out` is a HOST array of 4 ints): out[0] = 32-pixel blocks
  * one workgroup (n % 256 == 0) / one pixel-wave (narrow outputs) walks, out[1] = depth in blocks of its LDS ring / register
  * prefetch, out[2] = workgroups, out[3] = mrla_conv1x1_rows().  addend != 0: the mrla_conv1x1_fwd_add form.  Lets a

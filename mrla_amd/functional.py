@@ -1169,7 +1169,7 @@ class _Conv1x1Fn(torch.autograd.Function):
             if not w.is_contiguous():
                 w = w.contiguous()
         part = None
-        rows = L.load().mrla_conv1x1_rows(m, k, n, _DT[x.dtype])      # > 0: with the statistics epilogue; 0: without (k >= 512)
+        rows = L.load().mrla_conv1x1_rows(m, k, n, _DT[x.dtype])      # > 0: with the statistics epilogue (0 would mean: supported, without)
         if rows >= 0:
             y = torch.empty((b, n, h, wd), dtype=x.dtype, device=dev, memory_format=_CL)
             if want_moments and rows > 0:

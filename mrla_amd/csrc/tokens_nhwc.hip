@@ -11,8 +11,10 @@
 //             constant on the map rows: mrla_token_gate_bwd folds it into the partials, mrla_token_ln_bwd into dxn
 // Reference: deit/deit_mrla_light.py:157-180,194-209,234.
 #include <algorithm>
+#include <cstdlib>
 
 #include "light_nhwc.h"
+#include "nhwc_rows.h"
 
 namespace mrla {
 
@@ -313,6 +315,195 @@ __global__ __launch_bounds__(kMaxStrips * kWave) void token_apply_bwd_nhwc(
 }
 
 // ------------------------------------------------------------------------------------------------
+// The same backward pass on the LDS-DMA row pipeline of nhwc_rows.h (as the ResNet kernels of light_nhwc_wide.hip): rows
+// arrive by `buffer_load ... lds` with everything outside the map as zeros from the bounds check, the three row windows
+// rotate by NAME (three steps per trip, no register copies), and nothing in the arithmetic is predicated -- dOut is zero
+// outside the map and in the two extra steps, so every gradient term vanishes there by itself; LayerNorm of a pixel
+// outside the map is switched off through its wave-uniform (rstd, bias) pair instead of a branch.  The kernel above spent
+// ~3 000 instructions per row step, 450 of them register moves and 160 SGPR-spill lane moves (profiles/r03_notes.md 8).
+// ------------------------------------------------------------------------------------------------
+// (mean, rstd, bias switch) of LN_x for window pixel (r, col): rstd = 0 and switch = 0 outside the map
+__device__ __forceinline__ void tok_stat_masked(const float* __restrict__ stats, int tok0, int side, int r, int col,
+                                                float& mean, float& rstd, float& on) {
+  const bool ok = r >= 0 && r < side && col >= 0 && col < side;                  // wave-uniform
+  const int idx = __builtin_amdgcn_readfirstlane((tok0 + (ok ? r * side + col : 0)) * TS_N + TS_MX);
+  const float2 s = *reinterpret_cast<const float2*>(stats + idx);
+  mean = s.x;
+  rstd = ok ? s.y : 0.f;
+  on = ok ? 1.f : 0.f;
+}
+
+template <typename T> constexpr int tok_bwd_wave_bytes() {
+  return RowIO<T, kS + 4>::kBytes + RowIO<T, kS + 2>::kBytes + RowIO<T, kS>::kBytes + RowIO<float, kS>::kBytes;
+}
+
+// BASE: the MRLA-base token module's value backward (mrla_token_base_value_bwd): dU is READ -- the dense dV_t image
+// `dv` [b, side, side, c] -- instead of formed from dOut; no o_{t-1} / lambda / gate terms, no bmom.
+template <typename T, bool RAGGED, bool BASE>
+__global__ __launch_bounds__(kMaxStrips * kWave) void token_apply_bwd_rows(
+    const T* __restrict__ dout, const T* __restrict__ x, const T* __restrict__ o, const float* __restrict__ stats,
+    const float* __restrict__ wx, const float* __restrict__ bx, const float* __restrict__ wo,
+    const float* __restrict__ bo, const float* __restrict__ wv, const float* __restrict__ gate,
+    const float* __restrict__ lam, const T* __restrict__ dv, float* __restrict__ dxn, float* __restrict__ part,
+    float* __restrict__ bmom, int n, int C, int side, int d) {
+  extern __shared__ __align__(16) unsigned char smem_raw[];
+  const int lane = threadIdx.x & (kWave - 1), wave = threadIdx.x / kWave, nwaves = blockDim.x / kWave;
+  float* red = reinterpret_cast<float*>(smem_raw);
+  unsigned char* wbuf = smem_raw + (size_t)nwaves * (TQ_N + 1) * kWave * sizeof(float) + (size_t)wave * tok_bwd_wave_bytes<T>();
+  T* bufX = reinterpret_cast<T*>(wbuf);
+  T* bufG = reinterpret_cast<T*>(wbuf + RowIO<T, kS + 4>::kBytes);
+  T* bufO = reinterpret_cast<T*>(wbuf + RowIO<T, kS + 4>::kBytes + RowIO<T, kS + 2>::kBytes);
+  float* bufS = reinterpret_cast<float*>(wbuf + RowIO<T, kS + 4>::kBytes + RowIO<T, kS + 2>::kBytes + RowIO<T, kS>::kBytes);
+  const int cbase = blockIdx.x * kWave, c = cbase + lane;
+  const int b = blockIdx.y, W = side, H = side;
+  const int nstrips = (W + kS - 1) / kS;
+  const int tok0 = b * n + 1;
+  const size_t ioff = (size_t)tok0 * C;
+  const int rowelems = W * C;
+  float w[9];
+#pragma unroll
+  for (int k = 0; k < 9; ++k) w[k] = wv[c * 9 + k];
+  const float a = BASE ? 1.f : gate[(size_t)b * (C / d) + c / d];
+  const float wxc = wx[c], bxc = bx[c];
+  const float lm = BASE ? 0.f : lam[c], woc = BASE ? 0.f : wo[c], boc = BASE ? 0.f : bo[c];
+  const T* xi = x + ioff;
+  const T* gi = BASE ? dv + (size_t)b * H * W * C : dout + ioff;       // rows of dV_t (dense image) / of dOut (token rows)
+  const T* oi = BASE ? nullptr : o + ioff;
+  float* dxo = dxn + ioff;
+  float q[TQ_N + 1];
+#pragma unroll
+  for (int k = 0; k < TQ_N + 1; ++k) q[k] = 0.f;
+  for (int s = wave; s < nstrips; s += nwaves) {
+    const int s0 = s * kS, nc = min(kS, W - s0);
+    RowIO<T, kS + 4> ax;
+    RowIO<T, kS + 2> ag;
+    RowIO<T, kS> ao;
+    RowIO<float, kS> as;
+    make_row_io<T, kS + 4>(ax, s0 - 2, kS + 4, W, C, cbase, lane);
+    make_row_io<T, kS + 2>(ag, s0 - 1, kS + 2, W, C, cbase, lane);
+    make_row_io<T, kS>(ao, s0, nc, W, C, cbase, lane);
+    make_row_io<float, kS>(as, s0, nc, W, C, cbase, lane);
+    RawRow<kS + 4> xr;
+    RawRow<kS + 2> gv;
+    RawRow<kS> ov;
+    xr.clear(); gv.clear(); ov.clear();
+    float xa[kS + 4], xb[kS + 4], xc[kS + 4];        // xn rows rr-1, rr, rr+1 on columns s0-2 .. s0+kS+1
+    float ua[kS + 2], ub[kS + 2], uc[kS + 2];        // dU rows rr-2, rr-1, rr on columns s0-1 .. s0+kS
+    float h0[kS], h1[kS], h2[kS];                    // xhat of the owned pixels, rows rr-1 .. rr+1
+#pragma unroll
+    for (int j = 0; j < kS + 4; ++j) { xa[j] = 0.f; xb[j] = 0.f; }
+#pragma unroll
+    for (int j = 0; j < kS + 2; ++j) { ua[j] = 0.f; ub[j] = 0.f; }
+#pragma unroll
+    for (int j = 0; j < kS; ++j) { h0[j] = 0.f; h1[j] = 0.f; }
+    // step rr (= -1 .. H) consumes x row rr+1 and dOut / o rows rr
+    row_fetch<T, kS + 4>(ax, xi, 0, H, rowelems, bufX);
+    row_fetch<T, kS + 2>(ag, gi, -1, H, rowelems, bufG);
+    if (!BASE) row_fetch<T, kS>(ao, oi, -1, H, rowelems, bufO);
+    auto step = [&](int rr, float (&XA)[kS + 4], float (&XB)[kS + 4], float (&XC)[kS + 4], float (&UA)[kS + 2],
+                    float (&UB)[kS + 2], float (&UC)[kS + 2], float (&H0)[kS], float (&H1)[kS], float (&H2)[kS]) {
+      rows_landed();
+      row_read_issue<T, kS + 4>(bufX, lane, xr);
+      row_read_issue<T, kS + 2>(bufG, lane, gv);
+      if (!BASE) row_read_issue<T, kS>(bufO, lane, ov);
+      row_read_fence(xr, true);
+      row_read_fence(gv, false);
+      if (!BASE) row_read_fence(ov, false);
+      row_fetch<T, kS + 4>(ax, xi, rr + 2, H, rowelems, bufX);
+      row_fetch<T, kS + 2>(ag, gi, rr + 1, H, rowelems, bufG);
+      if (!BASE) row_fetch<T, kS>(ao, oi, rr + 1, H, rowelems, bufO);
+      // LN_x on the way in (row rr+1); pixels outside the map come out as exact zeros
+#pragma unroll
+      for (int j = 0; j < kS + 4; ++j) {
+        float mean, rstd, on;
+        tok_stat_masked(stats, tok0, side, rr + 1, s0 - 2 + j, mean, rstd, on);
+        const float hat = (xr.v[j] - mean) * rstd;
+        XC[j] = fmaf(hat, wxc, on * bxc);
+        if (j >= 2 && j < kS + 2) H2[j - 2] = hat;
+      }
+      // dU of row rr on columns s0-1 .. s0+kS (dOut is zero outside the map and in the steps rr = -1 and rr = H)
+#pragma unroll
+      for (int j = 0; j < kS + 2; ++j) {
+        if constexpr (BASE) {
+          const float du = gv.v[j];
+          UC[j] = du;
+          if (j >= 1 && j <= kS) {
+            q[0] = fmaf(du, XA[j], q[0]); q[1] = fmaf(du, XA[j + 1], q[1]); q[2] = fmaf(du, XA[j + 2], q[2]);
+            q[3] = fmaf(du, XB[j], q[3]); q[4] = fmaf(du, XB[j + 1], q[4]); q[5] = fmaf(du, XB[j + 2], q[5]);
+            q[6] = fmaf(du, XC[j], q[6]); q[7] = fmaf(du, XC[j + 1], q[7]); q[8] = fmaf(du, XC[j + 2], q[8]);
+          }
+          continue;
+        }
+        const float u = conv_at(w, XA, XB, XC, j);
+        const float go = gv.v[j];
+        const float du = a * go * gelu_grad_f(u);
+        UC[j] = du;
+        if (j >= 1 && j <= kS) {                     // owned column (compile-time after unroll)
+          q[TQ_N] = fmaf(go, gelu_f(u), q[TQ_N]);
+          float mo, ro, on;
+          {
+            const bool ok = rr >= 0 && rr < side && s0 + j - 1 < side;         // wave-uniform
+            const int idx = __builtin_amdgcn_readfirstlane((tok0 + (ok ? rr * side + s0 + j - 1 : 0)) * TS_N + TS_MO);
+            const float2 so = *reinterpret_cast<const float2*>(stats + idx);
+            mo = so.x; ro = so.y; on = ok ? 1.f : 0.f;
+          }
+          (void)on;
+          const float ohat = (ov.v[j - 1] - mo) * ro;
+          q[TQ_LAM] = fmaf(go, fmaf(ohat, woc, boc), q[TQ_LAM]);
+          q[TQ_LNOW] = fmaf(lm * go, ohat, q[TQ_LNOW]);
+          q[TQ_LNOB] = fmaf(lm, go, q[TQ_LNOB]);
+          q[0] = fmaf(du, XA[j], q[0]); q[1] = fmaf(du, XA[j + 1], q[1]); q[2] = fmaf(du, XA[j + 2], q[2]);
+          q[3] = fmaf(du, XB[j], q[3]); q[4] = fmaf(du, XB[j + 1], q[4]); q[5] = fmaf(du, XB[j + 2], q[5]);
+          q[6] = fmaf(du, XC[j], q[6]); q[7] = fmaf(du, XC[j + 1], q[7]); q[8] = fmaf(du, XC[j + 2], q[8]);
+        }
+      }
+      if (rr >= 1) {                                 // dxn' of row rr-1 from dU rows rr-2 .. rr
+        float yrow[kS];
+#pragma unroll
+        for (int j = 0; j < kS; ++j) {
+          float s9 = w[0] * UC[j + 2];
+          s9 = fmaf(w[1], UC[j + 1], s9); s9 = fmaf(w[2], UC[j], s9);
+          s9 = fmaf(w[3], UB[j + 2], s9); s9 = fmaf(w[4], UB[j + 1], s9); s9 = fmaf(w[5], UB[j], s9);
+          s9 = fmaf(w[6], UA[j + 2], s9); s9 = fmaf(w[7], UA[j + 1], s9); s9 = fmaf(w[8], UA[j], s9);
+          yrow[j] = s9;
+          q[TQ_LNXW] = fmaf(s9, H0[j], q[TQ_LNXW]);                          // (xhat is zero beyond the map)
+          q[TQ_H] += H0[j];
+          if (!RAGGED || j < nc) q[TQ_LNXB] += s9;
+        }
+        row_store<float, kS>(as, dxo, rr - 1, rowelems, lane, bufS, yrow);
+      }
+    };
+    // steps rr = -1 .. H: after three steps every array is back in its starting role
+    int rr = -1;
+    for (; rr + 2 <= H; rr += 3) {
+      step(rr,     xa, xb, xc, ua, ub, uc, h0, h1, h2);
+      step(rr + 1, xb, xc, xa, ub, uc, ua, h1, h2, h0);
+      step(rr + 2, xc, xa, xb, uc, ua, ub, h2, h0, h1);
+    }
+    if (rr <= H) {
+      step(rr, xa, xb, xc, ua, ub, uc, h0, h1, h2);
+      if (rr + 1 <= H) step(rr + 1, xb, xc, xa, ub, uc, ua, h1, h2, h0);
+    }
+    rows_landed();
+  }
+  wg_reduce<TQ_N + 1>(q, red, lane, wave, nwaves);
+  if (wave == 0) {
+    if (!BASE) {
+      float* bm = bmom + ((size_t)b * C + c) * D_N;
+      bm[D_D] = 0.f; bm[D_DV] = q[TQ_N]; bm[D_DO] = 0.f;
+    }
+    const size_t g = (size_t)b * n * C + c;          // cls row: the module output there is LN_x(x) itself
+    const float* st = stats + (size_t)b * n * TS_N;
+    const float dn = to_f(dout[g]);
+    dxn[g] = dn;
+    q[TQ_LNXW] = fmaf(dn, (to_f(x[g]) - st[TS_MX]) * st[TS_RX], q[TQ_LNXW]);
+    q[TQ_LNXB] += dn;
+#pragma unroll
+    for (int k = 0; k < TQ_N; ++k) part[((size_t)b * C + c) * TQ_N + k] = q[k];
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
 // MRLA-base on tokens (deit/deit_mrla_base.py:224-243): the value map V_t = dwconv3x3(LN_x(x) map) goes straight into the
 // stage's slot-major NHWC ring (a dense [b, side, side, c] image per slot) -- LN_x(x) itself is never materialised --
 // and the backward turns dV_t (dense, from mrla_base_dv_combine) into dxn' on the token rows.  Same row windows as above.
@@ -510,6 +701,23 @@ int launch_token_apply_bwd_nhwc(const void* dout, const void* x, const void* o, 
                                 const float* lam, float* dxn, float* part, float* bmom, int B, int n, int C, int side,
                                 int d, int dtype, hipStream_t st) {
   const int nwaves = std::min((side + kS - 1) / kS, kMaxStrips);
+  static const bool old_form = [] { const char* e = getenv("MRLA_TOKEN_BWD_ROWS"); return e && e[0] == '0'; }();   // (A/B switch)
+  if (!old_form) {
+    const dim3 grid(C / kWave, B), block(nwaves * kWave);
+    const bool ragged = side % kS != 0;
+#define CALL_R(TT, RG)                                                                                             \
+  {                                                                                                                \
+    const size_t lds = (size_t)nwaves * (TQ_N + 1) * kWave * sizeof(float) + (size_t)nwaves * tok_bwd_wave_bytes<TT>(); \
+    if (set_lds_n(token_apply_bwd_rows<TT, RG, false>, lds) != hipSuccess) return MRLA_EHIP;                         \
+    hipLaunchKernelGGL((token_apply_bwd_rows<TT, RG, false>), grid, block, lds, st, (const TT*)dout, (const TT*)x,     \
+                       (const TT*)o, stats, wx, bx, wo, bo, wv, gate, lam, (const TT*)nullptr, dxn, part, bmom, n, C, side, d); \
+  }
+#define CALL(TT) { if (ragged) CALL_R(TT, true) else CALL_R(TT, false) }
+    MRLA_DISPATCH_TN(dtype, CALL)
+#undef CALL
+#undef CALL_R
+    return hip_status(hipGetLastError());
+  }
   const dim3 grid(C / kWave, B, token_bands_bwd(B, C, side)), block(nwaves * kWave);
   const size_t lds = tok_lds(nwaves, TQ_N + 1);
 #define CALL(TT)                                                                                                   \
@@ -556,6 +764,24 @@ int launch_token_value_bwd_nhwc(const void* dout, const void* x, const float* st
                                 int dtype, hipStream_t st) {
   if (!token_nhwc_applies(C)) return MRLA_EUNSUPPORTED;
   const int nwaves = std::min((side + kS - 1) / kS, kMaxStrips);
+  static const bool old_form = [] { const char* e = getenv("MRLA_TOKEN_BWD_ROWS"); return e && e[0] == '0'; }();   // (A/B switch)
+  if (!old_form) {
+    const dim3 grid(C / kWave, B), block(nwaves * kWave);
+    const bool ragged = side % kS != 0;
+#define CALL_R(TT, RG)                                                                                             \
+  {                                                                                                                \
+    const size_t lds = (size_t)nwaves * (TQ_N + 1) * kWave * sizeof(float) + (size_t)nwaves * tok_bwd_wave_bytes<TT>(); \
+    if (set_lds_n(token_apply_bwd_rows<TT, RG, true>, lds) != hipSuccess) return MRLA_EHIP;                          \
+    hipLaunchKernelGGL((token_apply_bwd_rows<TT, RG, true>), grid, block, lds, st, (const TT*)dout, (const TT*)x,      \
+                       (const TT*)nullptr, stats, wx, bx, (const float*)nullptr, (const float*)nullptr, wv,        \
+                       (const float*)nullptr, (const float*)nullptr, (const TT*)dv, dxn, part, (float*)nullptr, n, C, side, 1); \
+  }
+#define CALL(TT) { if (ragged) CALL_R(TT, true) else CALL_R(TT, false) }
+    MRLA_DISPATCH_TN(dtype, CALL)
+#undef CALL
+#undef CALL_R
+    return hip_status(hipGetLastError());
+  }
   const dim3 grid(C / kWave, B, token_bands_bwd(B, C, side)), block(nwaves * kWave);
   const size_t lds = tok_lds(nwaves, TQ_N);
 #define CALL(TT)                                                                                                   \

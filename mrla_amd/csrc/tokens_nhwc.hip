@@ -11,7 +11,6 @@
 //             constant on the map rows: mrla_token_gate_bwd folds it into the partials, mrla_token_ln_bwd into dxn
 // Reference: deit/deit_mrla_light.py:157-180,194-209,234.
 #include <algorithm>
-#include <cstdlib>
 
 #include "light_nhwc.h"
 #include "nhwc_rows.h"
@@ -41,25 +40,6 @@ __device__ __forceinline__ void normalise_row(float (&v)[NPX], const float* __re
       const float2 s = tok_stat(stats, tok0, side, r, col, TS_MX);
       v[j] = fmaf((v[j] - s.x) * s.y, wxc, bxc);
     } else {
-      v[j] = 0.f;
-    }
-  }
-}
-
-// same, and hat[j] = the normalised value before the affine (what the LayerNorm weight gradient multiplies)
-template <int NPX>
-__device__ __forceinline__ void normalise_row_hat(float (&v)[NPX], float (&hat)[NPX], const float* __restrict__ stats,
-                                                  int tok0, int side, int r, int col0, float wxc, float bxc) {
-  const bool rowok = r >= 0 && r < side;
-#pragma unroll
-  for (int j = 0; j < NPX; ++j) {
-    const int col = col0 + j;
-    if (rowok && col >= 0 && col < side) {
-      const float2 s = tok_stat(stats, tok0, side, r, col, TS_MX);
-      hat[j] = (v[j] - s.x) * s.y;
-      v[j] = fmaf(hat[j], wxc, bxc);
-    } else {
-      hat[j] = 0.f;
       v[j] = 0.f;
     }
   }
@@ -173,154 +153,13 @@ __global__ __launch_bounds__(kThreads) void token_cls_fwd_kernel(const T* __rest
 //   dxn'[i] = sum_{di,dj} wv[di][dj] * dU[i - (di,dj)]          (the caller's later passes add dy, see the file header)
 //   bmom    = sum_i dOut[i] * gelu(U[i]);  partial TQ_H = sum_i xhat[i] (what dy multiplies in the LN_x weight gradient)
 // Windows per strip: xn rows rr-1..rr+1 on columns s0-2..s0+kS+1; dU rows rr-2..rr on columns s0-1..s0+kS.
-// ------------------------------------------------------------------------------------------------
-template <typename T>
-__global__ __launch_bounds__(kMaxStrips * kWave) void token_apply_bwd_nhwc(
-    const T* __restrict__ dout, const T* __restrict__ x, const T* __restrict__ o, const float* __restrict__ stats,
-    const float* __restrict__ wx, const float* __restrict__ bx, const float* __restrict__ wo,
-    const float* __restrict__ bo, const float* __restrict__ wv, const float* __restrict__ gate,
-    const float* __restrict__ lam, float* __restrict__ dxn, float* __restrict__ part, float* __restrict__ bmom,
-    int n, int C, int side, int d) {
-  MRLA_TOK_PROLOGUE(TQ_N + 1)
-  float w[9];
-#pragma unroll
-  for (int k = 0; k < 9; ++k) w[k] = wv[c * 9 + k];
-  const float a = gate[(size_t)b * (C / d) + c / d];
-  const float lm = lam[c], wxc = wx[c], bxc = bx[c], woc = wo[c], boc = bo[c];
-  const T* xi = x + ioff;
-  const T* gi = dout + ioff;
-  const T* oi = o + ioff;
-  float* dxo = dxn + ioff;
-  float q[TQ_N + 1];                                 // (slot TQ_N: the bmom sum)
-#pragma unroll
-  for (int k = 0; k < TQ_N + 1; ++k) q[k] = 0.f;
-  for (int s = wave; s < nstrips; s += nwaves) {
-    const int s0 = s * kS, nc = min(kS, W - s0);
-    float xa[kS + 4], xb[kS + 4], xc[kS + 4];        // xn rows rr-1, rr, rr+1
-    float ua[kS + 2], ub[kS + 2], uc[kS + 2];        // dU rows rr-2, rr-1, rr
-    float h0[kS], h1[kS], h2[kS];                    // xhat (LN_x before its affine) of the owned pixels, rows rr-1..rr+1
-    RowLoad<T, kS + 4> qx;
-    RowLoad<T, kS + 2> qg;
-    RowLoad<T, kS> qo;
-    RowAddr<T, kS + 4> ax;
-    RowAddr<T, kS + 2> ag;
-    RowAddr<T, kS> ao;
-    make_row_addr<T, kS + 4>(ax, s0 - 2, W, C, cbase, lane);
-    make_row_addr<T, kS + 2>(ag, s0 - 1, W, C, cbase, lane);
-    make_row_addr<T, kS>(ao, s0, W, C, cbase, lane);
-#pragma unroll
-    for (int j = 0; j < kS + 2; ++j) { ua[j] = 0.f; ub[j] = 0.f; }
-    // the band r0 .. r1-1 of output rows needs dU rows r0-1 .. r1: the walk starts one row early and ends one row late
-    const int rs = r0 - 1;
-    {
-      float hat[kS + 4];
-      read_row<T, true, kS + 4>(xi, rs - 1, s0 - 2, H, W, C, cbase, c, lane, scrT, xa);
-      normalise_row_hat<kS + 4>(xa, hat, stats, tok0, side, rs - 1, s0 - 2, wxc, bxc);
-#pragma unroll
-      for (int j = 0; j < kS; ++j) h0[j] = hat[j + 2];
-      read_row<T, true, kS + 4>(xi, rs, s0 - 2, H, W, C, cbase, c, lane, scrT, xb);
-      normalise_row_hat<kS + 4>(xb, hat, stats, tok0, side, rs, s0 - 2, wxc, bxc);
-#pragma unroll
-      for (int j = 0; j < kS; ++j) h1[j] = hat[j + 2];
-    }
-    issue_row<T, kS + 4>(qx, xi, rs + 1, H, W * C, ax);
-    issue_row<T, kS + 2>(qg, gi, rs, H, W * C, ag);
-    issue_row<T, kS>(qo, oi, rs, H, W * C, ao);
-    for (int rr = rs; rr <= r1; ++rr) {
-      const bool own = rr >= r0 && rr < r1;          // parameter partials are taken on the band's own rows only
-      float gv[kS + 2], ov[kS];
-      finish_row<T, kS + 4>(qx, lane, scrT, xc);
-      finish_row<T, kS + 2>(qg, lane, scrT, gv);
-      finish_row<T, kS>(qo, lane, scrT, ov);
-      issue_row<T, kS + 4>(qx, xi, rr + 2, H, W * C, ax);
-      issue_row<T, kS + 2>(qg, gi, rr + 1, H, W * C, ag);
-      issue_row<T, kS>(qo, oi, rr + 1, H, W * C, ao);
-      {
-        float hat[kS + 4];
-        normalise_row_hat<kS + 4>(xc, hat, stats, tok0, side, rr + 1, s0 - 2, wxc, bxc);
-#pragma unroll
-        for (int j = 0; j < kS; ++j) h2[j] = hat[j + 2];
-      }
-      if (rr < 0 || rr >= H) {
-#pragma unroll
-        for (int j = 0; j < kS + 2; ++j) uc[j] = 0.f;
-      } else {
-#pragma unroll
-        for (int j = 0; j < kS + 2; ++j) {
-          const int col = s0 - 1 + j;
-          const bool in = col >= 0 && col < W;                              // wave-uniform
-          const float u = conv_at(w, xa, xb, xc, j);
-          const float du = in ? a * gv[j] * gelu_grad_f(u) : 0.f;
-          uc[j] = du;
-          if (own && j >= 1 && j <= kS && j - 1 < nc) {
-            const float go = gv[j];
-            q[TQ_N] = fmaf(go, gelu_f(u), q[TQ_N]);                         // (shares the erf with gelu')
-            const float2 so = tok_stat(stats, tok0, side, rr, col, TS_MO);
-            const float ohat = (ov[j - 1] - so.x) * so.y;
-            q[TQ_LAM] = fmaf(go, fmaf(ohat, woc, boc), q[TQ_LAM]);
-            q[TQ_LNOW] = fmaf(lm * go, ohat, q[TQ_LNOW]);
-            q[TQ_LNOB] = fmaf(lm, go, q[TQ_LNOB]);
-            // dWv[i][k] += dU[rr][col] * xn[rr+i-1][col+k-1]   (window index of col+k-1 in the xn arrays: j+k)
-            q[0] = fmaf(du, xa[j], q[0]); q[1] = fmaf(du, xa[j + 1], q[1]); q[2] = fmaf(du, xa[j + 2], q[2]);
-            q[3] = fmaf(du, xb[j], q[3]); q[4] = fmaf(du, xb[j + 1], q[4]); q[5] = fmaf(du, xb[j + 2], q[5]);
-            q[6] = fmaf(du, xc[j], q[6]); q[7] = fmaf(du, xc[j + 1], q[7]); q[8] = fmaf(du, xc[j + 2], q[8]);
-          }
-        }
-      }
-      if (rr - 1 >= r0) {
-        const int ro = rr - 1;
-        float yrow[kS];
-#pragma unroll
-        for (int j = 0; j < kS; ++j) {
-          float s9 = w[0] * uc[j + 2];
-          s9 = fmaf(w[1], uc[j + 1], s9); s9 = fmaf(w[2], uc[j], s9);
-          s9 = fmaf(w[3], ub[j + 2], s9); s9 = fmaf(w[4], ub[j + 1], s9); s9 = fmaf(w[5], ub[j], s9);
-          s9 = fmaf(w[6], ua[j + 2], s9); s9 = fmaf(w[7], ua[j + 1], s9); s9 = fmaf(w[8], ua[j], s9);
-          yrow[j] = s9;
-          if (j < nc) {
-            q[TQ_LNXW] = fmaf(s9, h0[j], q[TQ_LNXW]);
-            q[TQ_LNXB] += s9;
-            q[TQ_H] += h0[j];
-          }
-        }
-        write_row<float, true, kS>(dxo, ro, s0, nc, W, C, cbase, c, true, lane, reinterpret_cast<float*>(scrS), yrow);
-      }
-#pragma unroll
-      for (int j = 0; j < kS + 4; ++j) { xa[j] = xb[j]; xb[j] = xc[j]; }
-#pragma unroll
-      for (int j = 0; j < kS + 2; ++j) { ua[j] = ub[j]; ub[j] = uc[j]; }
-#pragma unroll
-      for (int j = 0; j < kS; ++j) { h0[j] = h1[j]; h1[j] = h2[j]; }
-    }
-  }
-  wg_reduce<TQ_N + 1>(q, red, lane, wave, nwaves);
-  if (wave == 0) {
-    {   // (one band per image in this direction: the launcher never splits the rows)
-      float* bm = bmom + ((size_t)b * C + c) * D_N;
-      bm[D_D] = 0.f; bm[D_DV] = q[TQ_N]; bm[D_DO] = 0.f;
-    }
-    if (blockIdx.z == 0) {
-      // cls row: the module output there is LN_x(x) itself
-      const size_t g = (size_t)b * n * C + c;
-      const float* s = stats + (size_t)b * n * TS_N;
-      const float dn = to_f(dout[g]);
-      dxn[g] = dn;
-      q[TQ_LNXW] = fmaf(dn, (to_f(x[g]) - s[TS_MX]) * s[TS_RX], q[TQ_LNXW]);
-      q[TQ_LNXB] += dn;
-    }
-    // one partial row per (band, image)
-#pragma unroll
-    for (int k = 0; k < TQ_N; ++k) part[(((size_t)blockIdx.z * gridDim.y + b) * C + c) * TQ_N + k] = q[k];
-  }
-}
-
-// ------------------------------------------------------------------------------------------------
-// The same backward pass on the LDS-DMA row pipeline of nhwc_rows.h (as the ResNet kernels of light_nhwc_wide.hip): rows
-// arrive by `buffer_load ... lds` with everything outside the map as zeros from the bounds check, the three row windows
-// rotate by NAME (three steps per trip, no register copies), and nothing in the arithmetic is predicated -- dOut is zero
-// outside the map and in the two extra steps, so every gradient term vanishes there by itself; LayerNorm of a pixel
-// outside the map is switched off through its wave-uniform (rstd, bias) pair instead of a branch.  The kernel above spent
-// ~3 000 instructions per row step, 450 of them register moves and 160 SGPR-spill lane moves (profiles/r03_notes.md 8).
+// On the LDS-DMA row pipeline of nhwc_rows.h (as the ResNet kernels of light_nhwc_wide.hip): rows arrive by
+// `buffer_load ... lds` with everything outside the map as zeros from the bounds check, the three row windows rotate by
+// NAME (three steps per trip, no register copies), and nothing in the arithmetic is predicated -- dOut is zero outside the
+// map and in the two extra steps, so every gradient term vanishes there by itself; LayerNorm of a pixel outside the map is
+// switched off through its wave-uniform (rstd, bias) pair instead of a branch.  (The first form of this kernel --
+// register-staged row gathers, windows rotated by copies, exec-mask branches -- spent ~3 000 instructions per row step, 450
+// of them register moves and 160 SGPR-spill lane moves: profiles/r03_notes.md section 8; this one ~1 150.)
 // ------------------------------------------------------------------------------------------------
 // (mean, rstd, bias switch) of LN_x for window pixel (r, col): rstd = 0 and switch = 0 outside the map
 __device__ __forceinline__ void tok_stat_masked(const float* __restrict__ stats, int tok0, int side, int r, int col,
@@ -506,7 +345,8 @@ __global__ __launch_bounds__(kMaxStrips * kWave) void token_apply_bwd_rows(
 // ------------------------------------------------------------------------------------------------
 // MRLA-base on tokens (deit/deit_mrla_base.py:224-243): the value map V_t = dwconv3x3(LN_x(x) map) goes straight into the
 // stage's slot-major NHWC ring (a dense [b, side, side, c] image per slot) -- LN_x(x) itself is never materialised --
-// and the backward turns dV_t (dense, from mrla_base_dv_combine) into dxn' on the token rows.  Same row windows as above.
+// and the backward (token_apply_bwd_rows<.., BASE = true> above) turns dV_t (dense, from mrla_base_dv_combine) into dxn'
+// on the token rows.
 // ------------------------------------------------------------------------------------------------
 template <typename T>
 __global__ __launch_bounds__(kMaxStrips * kWave) void token_value_fwd_nhwc(
@@ -541,110 +381,6 @@ __global__ __launch_bounds__(kMaxStrips * kWave) void token_value_fwd_nhwc(
 #pragma unroll
       for (int j = 0; j < kS + 2; ++j) { ra[j] = rb[j]; rb[j] = rc[j]; }
     }
-  }
-}
-
-//   dxn'[i] = sum_{di,dj} wv[di][dj] * dV[i - (di,dj)]   (fp32, map rows; the cls row: dxn' = dOut), and the partials
-//   dWv (slots 0-8), dlnx_w / dlnx_b without dy's share (10, 11), sum xhat (14); the other slots are zero.
-// Windows per strip: xn rows rr-1..rr+1 and dV rows rr-2..rr, both on columns s0-1..s0+kS.
-template <typename T>
-__global__ __launch_bounds__(kMaxStrips * kWave) void token_value_bwd_nhwc(
-    const T* __restrict__ dout, const T* __restrict__ x, const float* __restrict__ stats, const float* __restrict__ wx,
-    const float* __restrict__ bx, const float* __restrict__ wv, const T* __restrict__ dv, float* __restrict__ dxn,
-    float* __restrict__ part, int n, int C, int side) {
-  MRLA_TOK_PROLOGUE(TQ_N)
-  float w[9];
-#pragma unroll
-  for (int k = 0; k < 9; ++k) w[k] = wv[c * 9 + k];
-  const float wxc = wx[c], bxc = bx[c];
-  const T* xi = x + ioff;
-  const T* di = dv + (size_t)b * H * W * C;
-  float* dxo = dxn + ioff;
-  float q[TQ_N];
-#pragma unroll
-  for (int k = 0; k < TQ_N; ++k) q[k] = 0.f;
-  for (int s = wave; s < nstrips; s += nwaves) {
-    const int s0 = s * kS, nc = min(kS, W - s0);
-    float xa[kS + 2], xb[kS + 2], xc[kS + 2];        // xn rows rr-1, rr, rr+1
-    float ua[kS + 2], ub[kS + 2], uc[kS + 2];        // dV rows rr-2, rr-1, rr
-    float h0[kS], h1[kS], h2[kS];                    // xhat of the owned pixels, rows rr-1..rr+1
-    RowLoad<T, kS + 2> qx, qd;
-    RowAddr<T, kS + 2> ax;
-    make_row_addr<T, kS + 2>(ax, s0 - 1, W, C, cbase, lane);
-#pragma unroll
-    for (int j = 0; j < kS + 2; ++j) { ua[j] = 0.f; ub[j] = 0.f; }
-    const int rs = r0 - 1;
-    {
-      float hat[kS + 2];
-      read_row<T, true, kS + 2>(xi, rs - 1, s0 - 1, H, W, C, cbase, c, lane, scrT, xa);
-      normalise_row_hat<kS + 2>(xa, hat, stats, tok0, side, rs - 1, s0 - 1, wxc, bxc);
-#pragma unroll
-      for (int j = 0; j < kS; ++j) h0[j] = hat[j + 1];
-      read_row<T, true, kS + 2>(xi, rs, s0 - 1, H, W, C, cbase, c, lane, scrT, xb);
-      normalise_row_hat<kS + 2>(xb, hat, stats, tok0, side, rs, s0 - 1, wxc, bxc);
-#pragma unroll
-      for (int j = 0; j < kS; ++j) h1[j] = hat[j + 1];
-    }
-    issue_row<T, kS + 2>(qx, xi, rs + 1, H, W * C, ax);
-    issue_row<T, kS + 2>(qd, di, rs, H, W * C, ax);
-    for (int rr = rs; rr <= r1; ++rr) {
-      const bool own = rr >= r0 && rr < r1;
-      finish_row<T, kS + 2>(qx, lane, scrT, xc);
-      finish_row<T, kS + 2>(qd, lane, scrT, uc);       // (rows and columns outside the map arrive as zeros)
-      issue_row<T, kS + 2>(qx, xi, rr + 2, H, W * C, ax);
-      issue_row<T, kS + 2>(qd, di, rr + 1, H, W * C, ax);
-      {
-        float hat[kS + 2];
-        normalise_row_hat<kS + 2>(xc, hat, stats, tok0, side, rr + 1, s0 - 1, wxc, bxc);
-#pragma unroll
-        for (int j = 0; j < kS; ++j) h2[j] = hat[j + 1];
-      }
-      if (own) {
-#pragma unroll
-        for (int j = 0; j < kS; ++j) {
-          // dWv[i][k] += dV[rr][col] * xn[rr+i-1][col+k-1]   (owned column j <-> window index j+1)
-          const float du = uc[j + 1];                // (zero beyond the map's last column)
-          q[0] = fmaf(du, xa[j], q[0]); q[1] = fmaf(du, xa[j + 1], q[1]); q[2] = fmaf(du, xa[j + 2], q[2]);
-          q[3] = fmaf(du, xb[j], q[3]); q[4] = fmaf(du, xb[j + 1], q[4]); q[5] = fmaf(du, xb[j + 2], q[5]);
-          q[6] = fmaf(du, xc[j], q[6]); q[7] = fmaf(du, xc[j + 1], q[7]); q[8] = fmaf(du, xc[j + 2], q[8]);
-        }
-      }
-      if (rr - 1 >= r0) {
-        const int ro = rr - 1;
-        float yrow[kS];
-#pragma unroll
-        for (int j = 0; j < kS; ++j) {
-          float s9 = w[0] * uc[j + 2];
-          s9 = fmaf(w[1], uc[j + 1], s9); s9 = fmaf(w[2], uc[j], s9);
-          s9 = fmaf(w[3], ub[j + 2], s9); s9 = fmaf(w[4], ub[j + 1], s9); s9 = fmaf(w[5], ub[j], s9);
-          s9 = fmaf(w[6], ua[j + 2], s9); s9 = fmaf(w[7], ua[j + 1], s9); s9 = fmaf(w[8], ua[j], s9);
-          yrow[j] = s9;
-          if (j < nc) {
-            q[TQ_LNXW] = fmaf(s9, h0[j], q[TQ_LNXW]);
-            q[TQ_LNXB] += s9;
-            q[TQ_H] += h0[j];
-          }
-        }
-        write_row<float, true, kS>(dxo, ro, s0, nc, W, C, cbase, c, true, lane, reinterpret_cast<float*>(scrS), yrow);
-      }
-#pragma unroll
-      for (int j = 0; j < kS + 2; ++j) { xa[j] = xb[j]; xb[j] = xc[j]; ua[j] = ub[j]; ub[j] = uc[j]; }
-#pragma unroll
-      for (int j = 0; j < kS; ++j) { h0[j] = h1[j]; h1[j] = h2[j]; }
-    }
-  }
-  wg_reduce<TQ_N>(q, red, lane, wave, nwaves);
-  if (wave == 0) {
-    if (blockIdx.z == 0) {
-      const size_t g = (size_t)b * n * C + c;        // cls row: the module output there is LN_x(x) itself
-      const float* s = stats + (size_t)b * n * TS_N;
-      const float dn = to_f(dout[g]);
-      dxn[g] = dn;
-      q[TQ_LNXW] = fmaf(dn, (to_f(x[g]) - s[TS_MX]) * s[TS_RX], q[TQ_LNXW]);
-      q[TQ_LNXB] += dn;
-    }
-#pragma unroll
-    for (int k = 0; k < TQ_N; ++k) part[(((size_t)blockIdx.z * gridDim.y + b) * C + c) * TQ_N + k] = q[k];
   }
 }
 
@@ -701,10 +437,8 @@ int launch_token_apply_bwd_nhwc(const void* dout, const void* x, const void* o, 
                                 const float* lam, float* dxn, float* part, float* bmom, int B, int n, int C, int side,
                                 int d, int dtype, hipStream_t st) {
   const int nwaves = std::min((side + kS - 1) / kS, kMaxStrips);
-  static const bool old_form = [] { const char* e = getenv("MRLA_TOKEN_BWD_ROWS"); return e && e[0] == '0'; }();   // (A/B switch)
-  if (!old_form) {
-    const dim3 grid(C / kWave, B), block(nwaves * kWave);
-    const bool ragged = side % kS != 0;
+  const dim3 grid(C / kWave, B), block(nwaves * kWave);
+  const bool ragged = side % kS != 0;
 #define CALL_R(TT, RG)                                                                                             \
   {                                                                                                                \
     const size_t lds = (size_t)nwaves * (TQ_N + 1) * kWave * sizeof(float) + (size_t)nwaves * tok_bwd_wave_bytes<TT>(); \
@@ -713,21 +447,9 @@ int launch_token_apply_bwd_nhwc(const void* dout, const void* x, const void* o, 
                        (const TT*)o, stats, wx, bx, wo, bo, wv, gate, lam, (const TT*)nullptr, dxn, part, bmom, n, C, side, d); \
   }
 #define CALL(TT) { if (ragged) CALL_R(TT, true) else CALL_R(TT, false) }
-    MRLA_DISPATCH_TN(dtype, CALL)
-#undef CALL
-#undef CALL_R
-    return hip_status(hipGetLastError());
-  }
-  const dim3 grid(C / kWave, B, token_bands_bwd(B, C, side)), block(nwaves * kWave);
-  const size_t lds = tok_lds(nwaves, TQ_N + 1);
-#define CALL(TT)                                                                                                   \
-  {                                                                                                                \
-    if (set_lds_n(token_apply_bwd_nhwc<TT>, lds) != hipSuccess) return MRLA_EHIP;                                    \
-    hipLaunchKernelGGL((token_apply_bwd_nhwc<TT>), grid, block, lds, st, (const TT*)dout, (const TT*)x, (const TT*)o, \
-                       stats, wx, bx, wo, bo, wv, gate, lam, dxn, part, bmom, n, C, side, d);                      \
-  }
   MRLA_DISPATCH_TN(dtype, CALL)
 #undef CALL
+#undef CALL_R
   return hip_status(hipGetLastError());
 }
 
@@ -764,10 +486,8 @@ int launch_token_value_bwd_nhwc(const void* dout, const void* x, const float* st
                                 int dtype, hipStream_t st) {
   if (!token_nhwc_applies(C)) return MRLA_EUNSUPPORTED;
   const int nwaves = std::min((side + kS - 1) / kS, kMaxStrips);
-  static const bool old_form = [] { const char* e = getenv("MRLA_TOKEN_BWD_ROWS"); return e && e[0] == '0'; }();   // (A/B switch)
-  if (!old_form) {
-    const dim3 grid(C / kWave, B), block(nwaves * kWave);
-    const bool ragged = side % kS != 0;
+  const dim3 grid(C / kWave, B), block(nwaves * kWave);
+  const bool ragged = side % kS != 0;
 #define CALL_R(TT, RG)                                                                                             \
   {                                                                                                                \
     const size_t lds = (size_t)nwaves * (TQ_N + 1) * kWave * sizeof(float) + (size_t)nwaves * tok_bwd_wave_bytes<TT>(); \
@@ -777,21 +497,9 @@ int launch_token_value_bwd_nhwc(const void* dout, const void* x, const float* st
                        (const float*)nullptr, (const float*)nullptr, (const TT*)dv, dxn, part, (float*)nullptr, n, C, side, 1); \
   }
 #define CALL(TT) { if (ragged) CALL_R(TT, true) else CALL_R(TT, false) }
-    MRLA_DISPATCH_TN(dtype, CALL)
-#undef CALL
-#undef CALL_R
-    return hip_status(hipGetLastError());
-  }
-  const dim3 grid(C / kWave, B, token_bands_bwd(B, C, side)), block(nwaves * kWave);
-  const size_t lds = tok_lds(nwaves, TQ_N);
-#define CALL(TT)                                                                                                   \
-  {                                                                                                                \
-    if (set_lds_n(token_value_bwd_nhwc<TT>, lds) != hipSuccess) return MRLA_EHIP;                                    \
-    hipLaunchKernelGGL((token_value_bwd_nhwc<TT>), grid, block, lds, st, (const TT*)dout, (const TT*)x, stats, wx, bx, \
-                       wv, (const TT*)dv, dxn, part, n, C, side);                                                  \
-  }
   MRLA_DISPATCH_TN(dtype, CALL)
 #undef CALL
+#undef CALL_R
   return hip_status(hipGetLastError());
 }
 

@@ -15,13 +15,17 @@ out = sys.argv[2] if len(sys.argv) > 2 else raw
 
 
 def short(name):
+    if "token_apply_bwd_rows" in name:      # <T, RAGGED, BASE>: the MRLA-base token module's value backward is BASE = true
+        return "token_base_value_bwd" if (", true>" in name or "Lb1EEv" in name) else "token_apply_bwd"
     for key in ("light_stats_fwd_fused", "conv1x1_kstream", "conv1x1_wide", "conv1x1_fwd", "conv1x1_wgrad_reduce", "conv1x1_wgrad", "weight_bank",
                 "plain_bn_fwd_rec", "reduce_rows2", "light_stats_fwd", "light_apply_fwd_pre", "light_apply_fwd", "light_stats_bwd", "light_apply_bwd", "plane_moments_small",
                 "plane_moments", "affine_act", "nhwc_moments_flat", "nhwc_affine_flat", "nhwc_moments", "nhwc_affine",
                 "base_combine_nhwcIDF16bDF16bLi0", "base_combine_nhwcIDF16bDF16bLi1", "base_combine_nhwcIffLi0",
-                "base_combine_nhwcIffLi1", "base_combine", "base_attend_fwd", "token_apply_fwd", "token_apply_bwd",
-                "token_stats_bwd", "token_ln_bwd", "token_norm_pool", "token_ln",
-                "base_attend_bwd", "base_value_bwd", "base_tail", "base_pmom",
+                "base_combine_nhwcIffLi1", "base_combine", "base_attend_fwd", "token_apply_fwd", "token_apply_bwd", "token_value_fwd", "token_stats_kernel",
+                "token_pool_kernel", "token_cls_fwd", "token_ln_bwd", "token_norm_pool", "token_ln",
+                "base_attend_bwd", "base_value_bwd", "base_tail", "base_pmom", "base_gate_fwd", "base_gate_bwd",
+                "gate_fwd_kernel", "gate_bwd_kernel", "bn_fwd_kernel", "bn_bwd_kernel", "bn_relu_pool_fwd",
+                "bn_relu_pool_dmoments", "bn_relu_pool_bwd",
                 "plain_bn_fwd", "plain_bn_bwd", "reduce_rows"):
         if key in name:
             return key

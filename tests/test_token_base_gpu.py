@@ -109,3 +109,35 @@ def test_fused_token_module_chain_vs_eager_float64(b, n, c, steps):
         wp = dict(want[0][t].named_parameters())
         for pn, pv in got[0][t].named_parameters():
             assert rel(pv.grad.cpu().numpy(), wp[pn].grad.numpy()) < 1e-4, (t, pn)
+
+
+def test_fused_token_module_bf16_storage_close_to_float32():
+    """The same fused path with bf16 tokens (bf16 rings, bf16 dV_t, fp32 arithmetic inside the kernels): three layers at
+    c = 192, n = 197 against the fp32 run of the same modules on the same (bf16-representable) inputs -- the storage
+    roundings of V_j / dA_t / dV_t / out bound the difference (a smoke-level bound: the elementwise bf16 statements about
+    MRLA-base are made on the ResNet shapes in tests/test_base_gpu.py with the oracle rounding at the same points)."""
+    from mrla_amd import layers
+    b, n, c, steps = 2, 197, 192, 3
+
+    def run(dtype):
+        outs, grads, K, V, loss, xs = [], [], None, None, 0.0, []
+        for t in range(steps):
+            m = layers.mrlab_module(c, D, init_cell=(t == 0))
+            m.mrla.history_hint = 4
+            vals = detgen.fill_state_dict(m.state_dict(), salt=90 + t)
+            m.load_state_dict({k: torch.from_numpy(v) for k, v in vals.items()})
+            m = m.cuda().to(dtype)
+            s_ = detgen.seed_of(f"tokbase-bf16/{t}")
+            x = torch.from_numpy(detgen.normalish((b, n, c), s_).astype(np.float32)).cuda().bfloat16().to(dtype).requires_grad_(True)
+            g = torch.from_numpy(detgen.normalish((b, n, c), s_ + 1).astype(np.float32)).cuda().bfloat16().to(dtype)
+            y, K, V = m(x, K, V)
+            loss = loss + (y.float() * g.float()).sum()
+            outs.append(y); xs.append(x)
+        loss.backward()
+        return [o.detach().float() for o in outs], [x.grad.float() for x in xs]
+    o32, g32 = run(torch.float32)
+    o16, g16 = run(torch.bfloat16)
+    for a, b_ in zip(o32 + g32, o16 + g16):
+        cos = torch.nn.functional.cosine_similarity(a.flatten(), b_.flatten(), dim=0).item()
+        assert cos > 0.9995, cos
+        assert (a - b_).abs().max().item() < 4e-2 * a.abs().max().item()

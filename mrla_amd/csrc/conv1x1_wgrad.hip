@@ -22,7 +22,6 @@
 //     __syncthreads()) behind ALL outstanding LDS-DMA loads with `s_waitcnt vmcnt(0)`, which would serialise the
 //     stages (measured: 1 us per chunk whatever the depth).
 #include <algorithm>
-#include <cstdlib>
 
 #include "mrla_device.h"
 #include "mrla_kernels.h"
@@ -285,9 +284,9 @@ WgPlan wgrad_plan(int M, int K, int N) {
   if (M <= 0 || N % 64 || K % 64 || (size_t)M * std::max(N, K) * 2 >= (size_t)1 << 31) return p;
   int tn = N % 256 == 0 ? 256 : N % 128 == 0 ? 128 : 64;
   int tk = K % 256 == 0 ? 256 : K % 128 == 0 ? 128 : 64;
-  static const int max_acc = [] { const char* e = getenv("MRLA_WGRAD_MAXACC"); return e ? atoi(e) : 0; }();   // (experiments)
-  const int deep_acc = max_acc > 0 ? max_acc : 32768;
-  while (tn * tk > ((long)N * K >= 262144 ? deep_acc : 32768)) {
+  // (16 K / 8 K accumulators per workgroup on the deep shapes -- fewer fp32 partial tiles -- were measured: no gain, the tile loop
+  // bounds them, profiles/r03_notes.md section 9)
+  while (tn * tk > 32768) {
     if (tn >= tk) tn /= 2; else tk /= 2;
   }
   p.tn = tn; p.tk = tk;

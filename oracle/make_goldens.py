@@ -103,8 +103,18 @@ def light_inputs(name, b, c, h, w):
     return x.astype(np.float32), o, gup
 
 
-def gen_light(ref):
+def thin(out, step=16):
+    """Every `step`-th element (memory order) of the activation-sized tensors; parameter gradients, running statistics and
+    masks stay whole (the float64 fixtures stay small)."""
+    return {k: (v.ravel()[::step].copy() if v.ndim >= 3 and "grad/" not in k else v) for k, v in out.items()}
+
+
+def gen_light(ref, f64=False):
+    """f64=True: the same reference modules run in DOUBLE precision -> light_blocks_f64.npz (parameter gradients in
+    full, every 16th element of the big tensors).  The numpy oracle must agree with these to ~1e-12, which separates
+    the oracle's algebra from the reference's own fp32 rounding (1e-7 ... 1e-5 on the cancelling Wq / Wk sums)."""
     L = ref["resnet_mrla_light"]
+    dt = torch.float64 if f64 else torch.float32
     out = {}
     for name, b, c, h, w, d in LIGHT_CASES:
         x_np, o_np, g_np = light_inputs(name, b, c, h, w)
@@ -114,20 +124,21 @@ def gen_light(ref):
             blk = L.MRLA_Bottleneck(c, c // 4, drop_path=p)
             L.mrla_module.dim_perhead = 32
             load_det(blk, salt=1)
+            blk.to(dt)
             blk.train(mode != "eval")
-            x = T(x_np).requires_grad_(True)
-            o = T(o_np).requires_grad_(True)
+            x = T(x_np).to(dt).requires_grad_(True)
+            o = T(o_np).to(dt).requires_grad_(True)
             mask = None
             if p > 0:
                 torch.manual_seed(1234)
-                mask = torch.floor((1 - p) + torch.rand((b, 1, 1, 1)))
+                mask = torch.floor((1 - p) + torch.rand((b, 1, 1, 1), dtype=dt))
                 torch.manual_seed(1234)
             layer_out = blk.mrla.mrla(x)                       # a1
             m = blk.mrla(x, o)                                 # a2 (recomputes a1 inside)
             if p > 0:
                 torch.manual_seed(1234)
             y = x + blk.drop_path(blk.bn_mrla(m))              # a3, resnet_mrla_light.py:116
-            (y * T(g_np)).sum().backward()
+            (y * T(g_np).to(dt)).sum().backward()
             k = f"{name}/{mode}/"
             if mode == "train":
                 out[k + "layer_out"] = N(layer_out)
@@ -142,6 +153,11 @@ def gen_light(ref):
             out[k + "running_var"] = N(blk.bn_mrla.running_var)
             if mask is not None:
                 out[k + "dp_mask"] = N(mask).reshape(b)
+    if f64:
+        out = thin(out)
+        np.savez_compressed(os.path.join(OUT, "light_blocks_f64.npz"), **out)
+        print("light_blocks_f64.npz", sum(v.nbytes for v in out.values()) // 1024, "KiB")
+        return
     # keep the c=2048 case small: strided samples of the big tensors
     for k in list(out):
         if k.startswith("s2048/") and out[k].ndim == 4:
@@ -167,8 +183,10 @@ def base_inputs(name, t, b, c, h, w):
     return x.astype(np.float32), detgen.normalish((b, c, h, w), s + 2)
 
 
-def gen_base(ref):
+def gen_base(ref, f64=False):
+    """f64=True: the chains in double precision -> base_chains_f64.npz (see gen_light)."""
     Bm = ref["resnet_mrla_base"]
+    dt = torch.float64 if f64 else torch.float32
     out = {}
     for name, b, c, h, w, d, Tn in BASE_CASES:
         for mode in ("train", "eval"):
@@ -177,13 +195,14 @@ def gen_base(ref):
             xs, loss, K, V = [], 0.0, None, None
             for t, blk in enumerate(blks):
                 load_det(blk, salt=10 + t)
+                blk.to(dt)
                 blk.train(mode == "train")
                 x_np, g_np = base_inputs(name, t, b, c, h, w)
-                x = T(x_np).requires_grad_(True)
+                x = T(x_np).to(dt).requires_grad_(True)
                 xs.append(x)
                 attn, K, V = blk.mrla(x, K, V)                                  # a4
                 y = x + blk.drop_path(blk.relu(blk.bn_mrla(attn)))               # a5, resnet_mrla_base.py:124-127
-                loss = loss + (y * T(g_np)).sum()
+                loss = loss + (y * T(g_np).to(dt)).sum()
                 k = f"{name}/{mode}/{t}/"
                 out[k + "attn"] = N(attn)
                 out[k + "out"] = N(y)
@@ -198,6 +217,11 @@ def gen_base(ref):
                         out[k + "grad/" + pn] = N(pv.grad)
                 out[k + "running_mean"] = N(blk.bn_mrla.running_mean)
                 out[k + "running_var"] = N(blk.bn_mrla.running_var)
+    if f64:
+        out = thin(out, 8)
+        np.savez_compressed(os.path.join(OUT, "base_chains_f64.npz"), **out)
+        print("base_chains_f64.npz", sum(v.nbytes for v in out.values()) // 1024, "KiB")
+        return
     np.savez_compressed(os.path.join(OUT, "base_chains.npz"), **out)
     print("base_chains.npz", sum(v.nbytes for v in out.values()) // 1024, "KiB")
 
@@ -216,40 +240,50 @@ def token_inputs(name, b, n, c):
             detgen.normalish((b, n, c), s + 2))
 
 
-def gen_tokens(deit_light):
+def gen_tokens(deit_light, f64=False):
+    """f64=True: the token module / GELU layer in double precision -> token_modules_f64.npz (see gen_light)."""
+    dt = torch.float64 if f64 else torch.float32
     out = {}
     for name, b, n, c, d in TOKEN_CASES:
         mod = deit_light.mrlal_module(c, d)
         load_det(mod, salt=3)
+        mod.to(dt)
         x_np, o_np, g_np = token_inputs(name, b, n, c)
-        x = T(x_np).requires_grad_(True)
-        o = T(o_np).requires_grad_(True)
+        x = T(x_np).to(dt).requires_grad_(True)
+        o = T(o_np).to(dt).requires_grad_(True)
         y = mod(x, o)                                           # a7 (deit_mrla_light.py:194-209)
         blk_out = x + y                                         # deit_mrla_light.py:234
-        (blk_out * T(g_np)).sum().backward()
+        (blk_out * T(g_np).to(dt)).sum().backward()
         k = name + "/"
         out[k + "module_out"] = N(y)
         out[k + "dx"] = N(x.grad)
         out[k + "do"] = N(o.grad)
         for pn, pv in mod.named_parameters():
             out[k + "grad/" + pn] = N(pv.grad)
-    for k in list(out):
-        if k.startswith("t197") and out[k].ndim == 3:
-            out[k] = out[k][:, ::4].copy()
+    if not f64:
+        for k in list(out):
+            if k.startswith("t197") and out[k].ndim == 3:
+                out[k] = out[k][:, ::4].copy()
     # the stand-alone map form of the layer (deit_mrla_light.py:157-180, GELU on V), forward and gradients
     for name, b, c, h, w, d in GELU_LAYER_CASES:
         lay = deit_light.mrlal_layer(c, dim_perhead=d)
         load_det(lay, salt=4)
+        lay.to(dt)
         s_ = detgen.seed_of("gelu/" + name)
-        x = T(detgen.normalish((b, c, h, w), s_)).requires_grad_(True)
+        x = T(detgen.normalish((b, c, h, w), s_)).to(dt).requires_grad_(True)
         y = lay(x)
-        (y * T(detgen.normalish((b, c, h, w), s_ + 1))).sum().backward()
+        (y * T(detgen.normalish((b, c, h, w), s_ + 1)).to(dt)).sum().backward()
         k = name + "/"
-        sub = (lambda a: a[:, ::4]) if c > 64 else (lambda a: a)
+        sub = (lambda a: a) if f64 else (lambda a: a[:, ::4]) if c > 64 else (lambda a: a)
         out[k + "out"] = sub(N(y)).copy()
         out[k + "dx"] = sub(N(x.grad)).copy()
         for pn, pv in lay.named_parameters():
             out[k + "grad/" + pn] = N(pv.grad)
+    if f64:
+        out = thin(out)
+        np.savez_compressed(os.path.join(OUT, "token_modules_f64.npz"), **out)
+        print("token_modules_f64.npz", sum(v.nbytes for v in out.values()) // 1024, "KiB")
+        return
     np.savez_compressed(os.path.join(OUT, "token_modules.npz"), **out)
     print("token_modules.npz", sum(v.nbytes for v in out.values()) // 1024, "KiB")
 
@@ -452,7 +486,11 @@ def main():
     torch.manual_seed(0)
     ref = import_reference_resnet()
     deit_light, deit_base = import_reference_deit()
-    which = sys.argv[1:] or ["light", "base", "tokens", "models", "layout", "tokbase", "det"]
+    which = sys.argv[1:] or ["light", "base", "tokens", "models", "layout", "tokbase", "det", "f64"]
+    if "f64" in which:                  # the reference in double precision: pins the oracle's algebra to ~1e-12
+        gen_light(ref, f64=True)
+        gen_base(ref, f64=True)
+        gen_tokens(deit_light, f64=True)
     if "tokbase" in which:
         gen_token_base(deit_base)
     if "det" in which:

@@ -15,8 +15,7 @@ def load_det(net):
 
 
 def rel(got, want):
-    want = np.asarray(want, np.float64)
-    return np.abs(np.asarray(got, np.float64) - want).max() / max(np.abs(want).max(), 1e-9)
+    return cases.relmax(got, want, floor=1e-9)          # recorded (tests/cases.py)
 
 
 @pytest.mark.parametrize("arch,factory,nb", [("resnet50_mrlal", em.eager_resnet50_mrlal, 8),

@@ -19,9 +19,7 @@ ACT_TOL = 5e-6
 PAR_TOL = 5e-5
 
 
-def relmax(got, want):
-    want = np.asarray(want, np.float64)
-    return np.abs(np.asarray(got, np.float64) - want).max() / max(np.abs(want).max(), 1e-12)
+relmax = cases.relmax          # error relative to the tensor's max-abs; every call is recorded (tests/cases.py)
 
 
 def to_dev(a, dtype=torch.float32):

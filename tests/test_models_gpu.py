@@ -16,8 +16,7 @@ def load_det(net):
 
 
 def rel(got, want):
-    want = np.asarray(want, np.float64)
-    return np.abs(np.asarray(got, np.float64) - want).max() / max(np.abs(want).max(), 1e-9)
+    return cases.relmax(got, want, floor=1e-9)          # recorded (tests/cases.py)
 
 
 def test_resnet50_mrlal_eval_logits_match_reference_and_eager():

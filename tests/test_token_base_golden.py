@@ -35,8 +35,7 @@ def run_chain(make_module, dev="cpu", dtype=torch.float32):
 
 
 def rel(got, want):
-    want = np.asarray(want, np.float64)
-    return np.abs(np.asarray(got, np.float64) - want).max() / max(np.abs(want).max(), 1e-9)
+    return cases.relmax(got, want, floor=1e-9)          # recorded (tests/cases.py)
 
 
 def check_chain(mods, xs, outs, tol_act, tol_par):

@@ -2,30 +2,47 @@
 """Headline benchmark: images/sec fwd+bwd of resnet50_mrlal, batch 256 per GPU, bf16 autocast, synthetic
 ImageNet-shaped data (BASELINE.json metric / configs[1]; configs[2] for --gpus N > 1).
 
-    python bench.py --gpus 1 --steps K --warmup W
+    python bench.py --gpus N --steps K --warmup W          # N > 1: starts its own N ranks (below)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
-        bench.py --gpus N --steps K --warmup W
+        bench.py --gpus N --steps K --warmup W             # the driver's line: the ranks are already there
 
 A "step" = forward + loss + backward + SGD update on one synthetic batch already resident in HBM.  On a single GPU the
 timed steps replay the whole step from one HIP graph (`config.launch`; `--graph 0` times PyTorch's kernel-by-kernel
-launches instead).  Under torch.distributed the step is captured as well, with the gradient exchange inside the graph as
-ONE all-reduce over one flat gradient buffer after backward (`--dp flat`, mrla_amd/distributed.py: FlatGradientExchange;
-MRLA_FLAT_OVERLAP=1: bucketed and sent from backward -- measured slower inside the graph; if the capture fails the same step
-is launched eagerly); `--dp ddp` runs torch's DistributedDataParallel, launched kernel by kernel.  Rank 0 prints
-ONE JSON line.  Besides the contract
-keys it carries
-  roofline     -- HBM roofline of the dominant MRLA kernel (mrla_light_apply_bwd), timed live with HIP events on
-                  the launch stream over `steps` steps launched kernel by kernel (the timed region itself when it is not
-                  graph-replayed, else the same steps run once more right after it: events cannot be read out of a
-                  replayed graph; `eager_launch_ms_per_step` is that region's step time); algorithmic bytes =
-                  6*N*sizeof(bf16) per launch (dOut, x_t, o_prev, y3 in; dx, do out);
-  cpu_baseline -- the eager CPU restatement (oracle/eager_models.py, kind "port") forward on the host cores,
-                  bounded sample, rank 0 at N=1 only;
-  eager_rocm   -- the same restatement run eager on this GPU (the north-star's ">=4x" denominator), N=1 only.
+launches instead).
+
+N > 1 (resnet/train.py:127-133 spawns its own workers with mp.spawn; :153 init_process_group; :174 DDP).  Launched
+plainly with `--gpus N`, this file starts `python -m torch.distributed.run ... bench.py <same arguments>` as a CHILD
+process before anything has touched the GPU, lets rank 0's JSON line through and exits with the child's code.  Every
+rank proves the process group (`config.ranks_seen` = an all-reduce of ones over `config.backend`).  The step is captured
+into one HIP graph with the gradient exchange inside it (mrla_amd/distributed.py: FlatGradientExchange) after a
+pre-flight (capture + replay of a 4-element all-reduce: if THAT fails the step is launched eagerly and the line says
+so).  Two exchange schedules are timed on the hardware -- ONE all-reduce after backward, and ~25 MB buckets sent from
+backward's hooks while backward still runs (what DistributedDataParallel does) -- both reported
+(`config.gradient_exchange_ab_ms`); the faster one runs the timed region (`--exchange` pins one).  If capturing the full
+step fails after a collective went into the capture, the communicator's state is unknown: the rank exits non-zero
+(the self-launching parent then starts ONE fresh set of ranks with `--graph 0`).  `--dp ddp` runs torch's
+DistributedDataParallel, launched kernel by kernel.  Rank 0 prints ONE JSON line.  Besides the contract keys it carries
+  roofline      -- HBM roofline of the dominant MRLA kernel (mrla_light_apply_bwd), timed live with HIP events on the
+                   launch stream over `steps` steps launched kernel by kernel (the timed region itself when it is not
+                   graph-replayed, else the same steps run once more right after it: events cannot be read out of a
+                   replayed graph; `eager_launch_ms_per_step` is that region's step time).  `achieved` / `frac`:
+                   SURVEY.md section 8(d)'s algorithmic bytes, 5*N*sizeof(bf16) per launch (dOut, x_t, o_prev in; dx, do
+                   out).  `achieved_fused` / `frac_fused`: the 6*N*s the launch is built to move (+ conv3's output y3:
+                   bn3's backward sums are folded into this pass, which deleted a 2*N*s pass of its own).  `path_frac`:
+                   section 8(d)'s compulsory bytes of the whole MRLA path per step (3N forward + 5N backward per block)
+                   over the time of ALL kernels of the path (two passes per direction + the [b,c]-sized kernels).
+                   `traffic`: HBM bytes per launch from THIS round's committed PMC passes (`traffic_source`), else null;
+  cpu_baseline  -- the eager CPU restatement (oracle/eager_models.py, kind "port") forward on the host cores, the best of a
+                   thread-count sweep, bounded sample, rank 0 at N=1 only;
+  eager_rocm    -- the same restatement run eager on this GPU (the north-star's ">=4x" denominator), N=1 only;
+  other_configs -- BASELINE configs 4 and 5 (deit_mrlal_tiny_patch16_224 b=256, resnet101_mrlab b=128), each measured
+                   by a child process of the default N=1 run after the headline (`--no-others` skips them).
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -35,11 +52,15 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
+ROUND = "r04"             # profiles/<ROUND>_* are this build's measurements; older rounds are never substituted
 HBM_PEAK_GBS = 8000.0     # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6300 GB/s is the measured copy ceiling
 MFMA_BF16_PEAK_TFLOPS = 2500.0   # dense bf16 MFMA peak (same guide)
 # forward+backward flops per 224x224 image (3 x the hook-counted forward MACs*2 of SURVEY.md section 8d); these are
 # almost entirely MIOpen convolution flops, not this build's kernels -- reported for the "fraction of compute roofline"
 MODEL_GFLOP_PER_IMAGE = {"resnet50_mrlal": 24.8, "resnet101_mrlab": 48.7}
+OTHER_CONFIGS = (("deit_mrlal_tiny_patch16_224", 256), ("resnet101_mrlab", 128))      # BASELINE.json configs 4 and 5
+EXIT_CAPTURE_BROKEN = 17  # a collective went into a capture that then failed: this process must not touch the communicator again
+STATUS_ENV = "MRLA_BENCH_STATUS_FILE"
 
 
 def parse():
@@ -50,7 +71,8 @@ def parse():
     ap.add_argument("--arch", default="resnet50_mrlal")
     ap.add_argument("--batch", type=int, default=256, help="per-GPU batch")
     ap.add_argument("--drop-path", type=float, default=0.2, help="resnet/train.py:67 default")
-    ap.add_argument("--no-baselines", action="store_true", help="skip the cpu_baseline / eager_rocm legs")
+    ap.add_argument("--no-baselines", action="store_true", help="skip the cpu_baseline / eager_rocm / other_configs legs")
+    ap.add_argument("--no-others", action="store_true", help="skip the other_configs leg (BASELINE configs 4 and 5)")
     ap.add_argument("--eager", action="store_true", help="time the eager restatement instead (diagnostic)")
     ap.add_argument("--channels-last", type=int, default=-1,
                     help="1 / 0: force torch.channels_last on / off; -1: the model class default (on for resnet*_mrlal)")
@@ -62,17 +84,78 @@ def parse():
                          "kernel; -1 (default): 1, except with --dp ddp or a non-RCCL backend")
     ap.add_argument("--backend", default=os.environ.get("MRLA_DIST_BACKEND", "nccl"))
     ap.add_argument("--dp", choices=["auto", "flat", "ddp"], default="auto",
-                    help="gradient exchange at N > 1.  flat: mrla_amd.distributed.FlatGradientExchange -- one all-reduce over "
-                         "one flat buffer after backward, which lets the whole step (exchange included) "
-                         "replay from one HIP graph like the N = 1 point; ddp: torch DistributedDataParallel (bucketed, overlapped with "
-                         "backward, launched kernel by kernel); auto: flat unless --graph 0")
+                    help="gradient exchange at N > 1.  flat: mrla_amd.distributed.FlatGradientExchange (one flat gradient "
+                         "buffer; the whole step, exchange included, replays from one HIP graph like the N = 1 point); ddp: "
+                         "torch DistributedDataParallel (bucketed, overlapped with backward, launched kernel by kernel); auto: "
+                         "flat unless --graph 0")
+    ap.add_argument("--exchange", choices=["ab", "after", "overlap"], default="ab",
+                    help="schedule of the flat exchange.  after: ONE all-reduce after backward; overlap: ~25 MB buckets sent "
+                         "from backward's hooks as they fill (DistributedDataParallel's schedule, resnet/train.py:174); ab "
+                         "(default): time both on this hardware, report both, run the timed region with the faster")
+    ap.add_argument("--ab-steps", type=int, default=6, help="steps per schedule of the --exchange ab comparison")
     ap.add_argument("--ddp-probe", action="store_true",
-                    help="diagnostic on one GPU: a ONE-rank process group + DistributedDataParallel around the model, so "
-                         "that the reducer hooks, bucket views and RCCL all-reduce launches of the N > 1 path run (and can "
-                         "be graph-captured with --graph 1) without a second GPU")
+                    help="diagnostic on one GPU: a ONE-rank process group around the model, so that the N > 1 path -- the "
+                         "exchange schedules, their hooks and the RCCL all-reduce launches, captured with --graph 1 -- runs "
+                         "without a second GPU (nobody to exchange with: it measures the overhead side only)")
     return ap.parse_args()
 
 
+# ------------------------------------------------------------------------------------------------------------------
+# N > 1 launched plainly: start the ranks (nothing in this function may touch the GPU)
+# ------------------------------------------------------------------------------------------------------------------
+def free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def launch_ranks(args):
+    """`python bench.py --gpus N` with no torch.distributed environment: what resnet/train.py:127-133 does with mp.spawn,
+    here as ONE child `python -m torch.distributed.run` (one process per GPU below it).  Returns the exit code."""
+    import tempfile
+    argv = [a for a in sys.argv[1:]]
+    status = os.path.join(tempfile.gettempdir(), f"mrla_bench_status_{os.getpid()}")
+    attempts = [[]] if args.graph == 0 else [[], ["--graph", "0"]]
+    rc = 1
+    for extra in attempts:
+        if os.path.exists(status):
+            os.remove(status)
+        env = dict(os.environ, **{STATUS_ENV: status})
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")          # dmabuf IPC: RCCL between processes needs it on this driver
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+               "--master-addr", "127.0.0.1", "--master-port", str(free_port()), os.path.abspath(__file__)] + argv + extra
+        print("bench.py: starting " + " ".join(cmd[1:8]) + " ...", file=sys.stderr, flush=True)
+        rc = subprocess.call(cmd, env=env, cwd=os.getcwd())
+        broken = os.path.exists(status) and "capture_broken" in open(status).read()
+        if os.path.exists(status):
+            os.remove(status)
+        if rc == 0 or not broken:
+            break
+        print("bench.py: the ranks gave up after a failed graph capture with a live collective; starting a fresh set of "
+              "ranks with --graph 0", file=sys.stderr, flush=True)
+    return rc
+
+
+def capture_broken_exit(err):
+    """A collective was enqueued into a capture that failed: do not limp on with this communicator (on N ranks that is a
+    hang, not a fallback).  Leaves a marker for the self-launching parent and ends the process without running any
+    destructor that would talk to the communicator."""
+    print(f"error: HIP graph capture of the data-parallel step failed with a collective in flight ({type(err).__name__}: "
+          f"{err}); exiting instead of continuing on a communicator in unknown state", file=sys.stderr, flush=True)
+    path = os.environ.get(STATUS_ENV)
+    if path:
+        try:
+            with open(path, "a") as fh:
+                fh.write("capture_broken\n")
+        except OSError:
+            pass
+    sys.stdout.flush()
+    os._exit(EXIT_CAPTURE_BROKEN)
+
+
+# ------------------------------------------------------------------------------------------------------------------
 def make_step(net, opt, x, y, exchange=None):
     def step():
         with torch.autocast("cuda", dtype=torch.bfloat16):
@@ -80,7 +163,7 @@ def make_step(net, opt, x, y, exchange=None):
         opt.zero_grad(set_to_none=True)
         loss.backward()
         if exchange is not None:
-            exchange.reduce()              # the N > 1 gradient average (one flat all-reduce; capturable)
+            exchange.reduce()              # the N > 1 gradient average (capturable)
         opt.step()
         return loss
     return step
@@ -90,7 +173,7 @@ def sgd(params):
     return torch.optim.SGD(params, lr=0.1, momentum=0.9, weight_decay=1e-4)   # resnet/train.py:199-201
 
 
-def timed(step, steps, warmup, dist_on):
+def timed(step, steps, warmup):
     from mrla_amd import distributed as D
     for _ in range(warmup):
         step()
@@ -104,25 +187,63 @@ def timed(step, steps, warmup, dist_on):
     return D.max_over_ranks(time.perf_counter() - t0)
 
 
-def cpu_baseline(arch):
-    """Eager CPU restatement, forward only, b=32 fp32, bounded to ~10-30 s."""
+def cpu_model_name():
+    try:
+        for ln in open("/proc/cpuinfo"):
+            if ln.startswith("model name"):
+                return ln.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
+def cpu_baseline(arch, budget_s=75.0):
+    """Eager CPU restatement, forward only, b=32 fp32.  The host's fair number: the thread count is
+    swept ({16, 32, 64, 128} and the 8 of the survey container, capped at the logical CPUs; one timed iteration each after
+    a common warm-up), channels_last is tried at the best count, and >= 3 iterations are timed with the winner."""
     from oracle import eager_models as em
     cores = os.cpu_count() or 1
-    threads = min(cores, 128)
-    torch.set_num_threads(threads)
+    cand = sorted({min(t, cores) for t in (8, 16, 32, 64, 128)})
     net = getattr(em, "eager_" + arch)().eval()
     xb = torch.randn(32, 3, 224, 224)
-    with torch.no_grad():
-        net(xb)
+    t_start = time.perf_counter()
+    tried = {}
+
+    def one(x, n=1):
         t0 = time.perf_counter()
-        n = 0
-        while n < 3 or (time.perf_counter() - t0 < 10.0 and n < 20):
-            net(xb)
+        for _ in range(n):
+            net(x)
+        return (time.perf_counter() - t0) / n
+
+    with torch.no_grad():
+        torch.set_num_threads(cand[len(cand) // 2])
+        net(xb)                                                          # warm-up (allocator, oneDNN primitives)
+        for t in cand:
+            if time.perf_counter() - t_start > budget_s * 0.5 and tried:
+                break
+            torch.set_num_threads(t)
+            tried[str(t)] = round(32 / one(xb), 2)
+        best_t = int(max(tried, key=tried.get))
+        torch.set_num_threads(best_t)
+        fmt, x_best = "contiguous (NCHW)", xb
+        if time.perf_counter() - t_start < budget_s * 0.6:
+            net_cl, x_cl = net.to(memory_format=torch.channels_last), xb.contiguous(memory_format=torch.channels_last)
+            net_cl(x_cl)
+            cl = round(32 / one(x_cl), 2)
+            tried[f"{best_t}+channels_last"] = cl
+            if cl > tried[str(best_t)]:
+                fmt, x_best = "channels_last", x_cl
+            else:
+                net.to(memory_format=torch.contiguous_format)
+        n, t0 = 0, time.perf_counter()
+        while n < 3 or (time.perf_counter() - t_start < budget_s * 0.8 and n < 10):
+            net(x_best)
             n += 1
         dt = time.perf_counter() - t0
-    return {"value": round(32 * n / dt, 2), "unit": "images/sec", "cores": threads, "kind": "port",
-            "sample": f"forward only (eval, no_grad), fp32, batch 32, {n} iterations after 1 warm-up, "
-                      f"torch.set_num_threads({threads}) of {cores} logical CPUs"}
+    return {"value": round(32 * n / dt, 2), "unit": "images/sec", "cores": best_t, "kind": "port",
+            "cpu": cpu_model_name(), "logical_cpus": cores, "threads_tried": tried, "memory_format": fmt,
+            "sample": f"forward only (eval, no_grad), fp32, batch 32, {n} iterations with torch.set_num_threads({best_t}) "
+                      f"(the best of threads_tried: one timed iteration each after a common warm-up), {fmt}"}
 
 
 def eager_rocm(arch, batch, drop_path, steps=6):
@@ -133,7 +254,7 @@ def eager_rocm(arch, batch, drop_path, steps=6):
     x = torch.randn(batch, 3, 224, 224, device="cuda")
     y = torch.randint(0, 1000, (batch,), device="cuda")
     step = make_step(net, sgd(net.parameters()), x, y)
-    dt = timed(step, steps, 3, False)
+    dt = timed(step, steps, 3)
     net.eval()
     # the north-star's denominator is the eager FORWARD; resnet/train.py:247 runs with cudnn.benchmark = True (MIOpen's
     # exhaustive find), so the forward is timed under both settings, after the find has finished, and the FASTER one is
@@ -210,37 +331,131 @@ def forward_only(net, x, steps=10, graph=True):
 
 
 def pmc_traffic(args, kernel):
-    """HBM bytes per launch of `kernel` from the committed rocprofv3 PMC passes (2*FETCH_SIZE + WRITE_SIZE, gfx950
-    correction of MI355X_MICROARCH.md; collected by scripts/pmc_bench.sh on this exact workload), else None."""
-    for rnd in ("r03", "r02", "r01"):   # the newest committed PMC pass of this workload
-        path = os.path.join(ROOT, "profiles", f"{rnd}_pmc_traffic_{args.arch}_b{args.batch}.json")
+    """(HBM bytes per launch of `kernel`, source file) from THIS round's committed rocprofv3 PMC passes of this exact
+    workload (2*FETCH_SIZE + WRITE_SIZE, the gfx950 correction of MI355X_MICROARCH.md; scripts/pmc_bench.sh), else
+    (None, None): a kernel may have changed since an older round's pass, so older files are never substituted."""
+    rel = os.path.join("profiles", f"{ROUND}_pmc_traffic_{args.arch}_b{args.batch}.json")
+    try:
+        rec = json.load(open(os.path.join(ROOT, rel))).get(kernel.replace("mrla_", ""))
+        if rec:
+            return int(rec["hbm_bytes_per_launch"]), rel
+    except (OSError, ValueError, KeyError):
+        pass
+    return None, None
+
+
+def mfma_counter(args):
+    """Whole-step MFMA utilisation from the committed counter pass of this workload (scripts/pmc_mfma.sh:
+    SQ_VALU_MFMA_BUSY_CYCLES / SQ_BUSY_CU_CYCLES over every kernel of the step), or None."""
+    rel = os.path.join("profiles", f"{ROUND}_pmc_mfma_whole_step_{args.arch}_b{args.batch}.json")
+    try:
+        rec = json.load(open(os.path.join(ROOT, rel)))
+        return {"mfma_busy_over_cu_busy": round(float(rec["mfma_busy_over_cu_busy"]), 5), "source": rel,
+                "what": "SQ_VALU_MFMA_BUSY_CYCLES / SQ_BUSY_CU_CYCLES summed over every kernel of the step (rocprofv3 --pmc, "
+                        "a separate run of this command); the MFMA work is MIOpen's convolutions and this build's 1x1 GEMMs"}
+    except (OSError, ValueError, KeyError):
+        return None
+
+
+def is_path_kernel(name):
+    """The MRLA path proper -- not the BatchNorm / convolution kernels of the 8(f) rows."""
+    return name.startswith(("mrla_light_", "mrla_base_", "mrla_token_", "mrla_reduce_rows2"))
+
+
+def ranks_seen(world, backend):
+    """An all-reduce of ones over the default group: the number of ranks the collective library actually connected."""
+    import torch.distributed as dist
+    if not dist.is_initialized():
+        return 1
+    t = torch.ones(1, device="cuda" if backend == "nccl" else "cpu")
+    dist.all_reduce(t)
+    return int(round(float(t.item())))
+
+
+def preflight_capture(world):
+    """Capture + replay a 4-element all-reduce: does this RCCL / driver pair hold a collective inside a HIP graph?"""
+    import torch.distributed as dist
+    t = torch.ones(4, device="cuda")
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        dist.all_reduce(t)                                      # communicator + its streams exist before the capture
+    torch.cuda.current_stream().wait_stream(side)
+    torch.cuda.synchronize()
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g, capture_error_mode="thread_local"):
+        dist.all_reduce(t)
+    t.fill_(1.0)
+    g.replay()
+    torch.cuda.synchronize()
+    got = float(t[0].item())
+    if abs(got - world) > 1e-3:
+        raise RuntimeError(f"replayed all-reduce of ones gave {got}, expected {world}")
+    del g
+
+
+def capture(step, dist_on, warm):
+    """PyTorch's whole-network-capture recipe: `warm` eager steps on a side stream, then one captured step."""
+    torch.cuda.synchronize()
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        for _ in range(warm):
+            step()
+    torch.cuda.current_stream().wait_stream(side)
+    graph = torch.cuda.CUDAGraph()
+    # (thread_local: RCCL's watchdog thread may query events while this thread captures)
+    with torch.cuda.graph(graph, **({"capture_error_mode": "thread_local"} if dist_on else {})):
+        step()
+    return graph
+
+
+def run_other_configs():
+    """BASELINE configs 4 and 5 as child processes of the default N = 1 run (fresh processes: their own MIOpen state and
+    HIP graph; this process is idle meanwhile)."""
+    out = {}
+    for arch, batch in OTHER_CONFIGS:
+        cmd = [sys.executable, os.path.abspath(__file__), "--arch", arch, "--batch", str(batch), "--steps", "10",
+               "--warmup", "3", "--no-baselines"]
+        t0 = time.perf_counter()
         try:
-            rec = json.load(open(path)).get(kernel.replace("mrla_", ""))
-            if rec:
-                return int(rec["hbm_bytes_per_launch"])
-        except (OSError, ValueError, KeyError):
-            continue
-    return None
+            p = subprocess.run(cmd, cwd=ROOT, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=900)
+            lines = [ln for ln in p.stdout.decode(errors="replace").splitlines() if ln.startswith("{")]
+            if p.returncode != 0 or not lines:
+                out[arch] = {"error": f"rc {p.returncode}: " + p.stderr.decode(errors="replace")[-400:]}
+                continue
+            rec = json.loads(lines[-1])
+            out[arch] = {"value": rec["value"], "unit": rec["unit"], "ms_per_step": rec["ms_per_step"], "batch": batch,
+                         "steps": rec["steps"], "launch": rec["config"]["launch"], "roofline": rec["roofline"],
+                         "workload": rec["config"]["workload"], "wall_s": round(time.perf_counter() - t0, 1)}
+        except (subprocess.TimeoutExpired, ValueError, KeyError) as e:
+            out[arch] = {"error": f"{type(e).__name__}: {e}"[:400]}
+    return out
 
 
 def main():
     args = parse()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ and not args.ddp_probe:
+        sys.exit(launch_ranks(args))              # (nothing before this line has touched the GPU)
+
     from mrla_amd import distributed as D
     rank, local, world = D.env_world()
     dist_on = world > 1
     local = local % max(1, torch.cuda.device_count())     # (lets a 1-GPU box exercise the N>1 code path over gloo)
     torch.cuda.set_device(local)
     if args.ddp_probe and world == 1:
-        import socket
-        s_ = socket.socket(); s_.bind(("127.0.0.1", 0)); port = s_.getsockname()[1]; s_.close()
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        os.environ.setdefault("MASTER_PORT", str(port))
+        os.environ.setdefault("MASTER_PORT", str(free_port()))
         kw = {"device_id": torch.device("cuda", local)} if args.backend == "nccl" else {}
         torch.distributed.init_process_group(args.backend, rank=0, world_size=1, **kw)
         dist_on = True
     D.init_from_env(args.backend)
     if args.gpus != world and rank == 0:
-        print(f"warning: --gpus {args.gpus} but WORLD_SIZE={world}", file=sys.stderr)
+        print(f"warning: --gpus {args.gpus} but WORLD_SIZE={world}; measuring {world} rank(s)", file=sys.stderr)
+    seen = ranks_seen(world, args.backend) if dist_on else 1
+    if seen != world:
+        print(f"error: the process group connected {seen} rank(s), WORLD_SIZE is {world}", file=sys.stderr)
+        sys.exit(3)
 
     from mrla_amd import functional as Fm
     torch.backends.cudnn.benchmark = bool(args.benchmark)
@@ -266,117 +481,160 @@ def main():
     dp = "none" if not dist_on else (args.dp if args.dp != "auto" else ("ddp" if args.graph == 0 else "flat"))
     # (a gloo exchange stages through the host: not capturable)
     use_graph = args.graph == 1 or (args.graph < 0 and dp != "ddp" and (not dist_on or args.backend == "nccl"))
-    exchange = None
-    if dp == "flat":
-        net = net.cuda().train()
-        exchange = D.FlatGradientExchange(net.parameters(), overlap=os.environ.get("MRLA_FLAT_OVERLAP", "0") == "1")
-    elif use_graph and dist_on:
-        # capturing a DDP step (PyTorch's whole-network-capture recipe): the wrapper is built in a side-stream context and
-        # at least 11 DDP iterations run eagerly on a side stream before the capture
-        side0 = torch.cuda.Stream()
-        side0.wait_stream(torch.cuda.current_stream())
-        with torch.cuda.stream(side0):
-            net = D.wrap_data_parallel(net.cuda().train(), device_ids=[local], force=args.ddp_probe)
-        torch.cuda.current_stream().wait_stream(side0)
-    else:
-        net = D.wrap_data_parallel(net.cuda().train(), device_ids=[local], force=args.ddp_probe)
+    launch_note = ""
+    if use_graph and dist_on and args.backend == "nccl":
+        try:
+            preflight_capture(seen)
+        except Exception as e:
+            print(f"warning: pre-flight capture of a 4-element all-reduce failed ({type(e).__name__}: {e}); launching the "
+                  "step eagerly", file=sys.stderr)
+            use_graph, launch_note = False, " [pre-flight capture of a small all-reduce failed: no graph]"
+
     gx = torch.Generator(device="cuda").manual_seed(0)
     gy = torch.Generator(device="cuda").manual_seed(1)
     x = torch.randn(args.batch, 3, 224, 224, device="cuda", generator=gx)
     y = torch.randint(0, 1000, (args.batch,), device="cuda", generator=gy)
-    step = make_step(net, sgd(net.parameters()), x, y, exchange)
 
-    # warm-up without the timer
-    for _ in range(args.warmup):
-        step()
-    eager_step = step
-    launch = "kernel by kernel (PyTorch eager launches)"
-    if use_graph:
-        # the whole training step is launch-order static (no host sync inside): capture it once into a HIP graph and
-        # replay it -- the same kernels on the same buffers, minus ~1 ms/step of launch gaps
-        try:
-            torch.cuda.synchronize()
-            side = torch.cuda.Stream()
-            side.wait_stream(torch.cuda.current_stream())
-            with torch.cuda.stream(side):
-                for _ in range(11 if dist_on else 2):
-                    eager_step()
-            torch.cuda.current_stream().wait_stream(side)
-            graph = torch.cuda.CUDAGraph()
-            # (thread_local: RCCL's watchdog thread may query events while this thread captures)
-            with torch.cuda.graph(graph, **({"capture_error_mode": "thread_local"} if dist_on else {})):
-                eager_step()
-            step = graph.replay
-            launch = "one HIP graph per step (captured fwd+loss+bwd" + ("+gradient all-reduce" if dist_on else "") + "+SGD), replayed"
-        except Exception as e:                        # capture not possible here: time the eager launches instead
-            print(f"warning: HIP graph capture failed ({type(e).__name__}: {e}); timing eager launches", file=sys.stderr)
-            step, use_graph = eager_step, False
-    timer = Fm.KernelTimer(["mrla_light_apply_bwd", "mrla_light_stats_bwd", "mrla_light_apply_fwd",
-                            "mrla_light_stats_fwd", "mrla_base_attend_fwd", "mrla_base_tail_fwd",
-                            "mrla_base_tail_stats_bwd", "mrla_base_attend_bwd", "mrla_base_value_bwd",
-                            "mrla_base_pool_value_fwd", "mrla_base_dv_combine", "mrla_base_value_bwd_dv",
-                            "mrla_token_apply_fwd", "mrla_token_apply_bwd", "mrla_token_ln_bwd", "mrla_token_base_value_fwd",
-                            "mrla_token_base_attend_fwd", "mrla_token_base_attend_bwd", "mrla_token_base_value_bwd",
-                            "mrla_light_stats_fwd_fused", "mrla_light_pool_fused", "mrla_light_apply_fwd_fused", "mrla_bn_plane_moments", "mrla_bn_act_fwd",
-                            "mrla_bn_plane_dmoments", "mrla_bn_act_bwd",
-                            "mrla_conv1x1_fwd", "mrla_conv1x1_bwd_data", "mrla_conv1x1_wgrad", "mrla_bn_relu_pool_fwd",
-                            "mrla_bn_relu_pool_dmoments", "mrla_bn_relu_pool_bwd"])
+    exchange, ab_ms, schedule = None, None, None
+    graph = None
+    launch = "kernel by kernel (PyTorch eager launches)" + launch_note
+    graph_launch = "one HIP graph per step (captured fwd+loss+bwd" + ("+gradient all-reduce" if dist_on else "") + "+SGD), replayed"
+    if dp == "flat":
+        # ---- the flat exchange, both schedules measured on this hardware (config.gradient_exchange_ab_ms) ----
+        net = net.cuda().train()
+        opt = sgd(net.parameters())
+        names = {"after": ["after_backward"], "overlap": ["bucketed_overlap"], "ab": ["after_backward", "bucketed_overlap"]}[args.exchange]
+        cands = {}
+        for i, name in enumerate(names):          # after_backward first: it registers no hooks that the other would trigger
+            ex = D.FlatGradientExchange(net.parameters(), overlap=(name == "bucketed_overlap"), broadcast=(i == 0))
+            st = make_step(net, opt, x, y, ex)
+            for _ in range(args.warmup if i == 0 else 2):
+                st()
+            g = None
+            if use_graph:
+                try:
+                    g = capture(st, True, 3)
+                except Exception as e:
+                    capture_broken_exit(e)
+            run = g.replay if g is not None else st
+            t = timed(run, args.ab_steps, 1) / args.ab_steps if len(names) > 1 else None
+            cands[name] = dict(exchange=ex, step=st, graph=g, ms=None if t is None else round(1e3 * t, 3))
+        schedule = min(cands, key=lambda k: cands[k]["ms"]) if len(names) > 1 else names[0]
+        ab_ms = {k: v["ms"] for k, v in cands.items()} if len(names) > 1 else None
+        for k, v in cands.items():
+            if k != schedule:
+                v["exchange"].remove_hooks()      # the loser's hooks must not fire in the winner's eager steps
+                v["graph"] = v["step"] = None
+        exchange, eager_step, graph = cands[schedule]["exchange"], cands[schedule]["step"], cands[schedule]["graph"]
+        del cands
+        step = eager_step
+        if graph is not None:
+            step, launch = graph.replay, graph_launch
+    else:
+        if dist_on and use_graph:
+            # capturing a DDP step (PyTorch's whole-network-capture recipe): the wrapper is built in a side-stream context and
+            # at least 11 DDP iterations run eagerly on a side stream before the capture
+            side0 = torch.cuda.Stream()
+            side0.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(side0):
+                net = D.wrap_data_parallel(net.cuda().train(), device_ids=[local], force=args.ddp_probe)
+            torch.cuda.current_stream().wait_stream(side0)
+        else:
+            net = D.wrap_data_parallel(net.cuda().train(), device_ids=[local], force=args.ddp_probe)
+        eager_step = step = make_step(net, sgd(net.parameters()), x, y)
+        for _ in range(args.warmup):                     # warm-up without the timer
+            step()
+        if use_graph:
+            # the whole training step is launch-order static (no host sync inside): capture it once into a HIP graph and
+            # replay it -- the same kernels on the same buffers, minus ~1 ms/step of launch gaps
+            try:
+                graph = capture(eager_step, dist_on, 11 if dist_on else 2)
+                step, launch = graph.replay, graph_launch
+            except Exception as e:
+                if dist_on:
+                    capture_broken_exit(e)
+                print(f"warning: HIP graph capture failed ({type(e).__name__}: {e}); timing eager launches", file=sys.stderr)
+                step, use_graph = eager_step, False
+    use_graph = graph is not None
+
+    timer = Fm.KernelTimer()                             # every C-ABI launch
     # the timed region: exactly `steps` steps between barrier + synchronize
     if use_graph:
-        dt = timed(step, args.steps, 0, dist_on)
+        dt = timed(step, args.steps, 0)
         # per-kernel HIP events cannot be read out of a replayed graph: the same `steps` steps once more, launched kernel by
         # kernel with the events on the launch stream (this second region feeds `roofline` / `mrla_kernels` only)
         Fm.TIMER = timer
-        dt_eager = timed(eager_step, args.steps, 0, dist_on)
+        dt_eager = timed(eager_step, args.steps, 0)
         Fm.TIMER = None
     else:
         Fm.TIMER = timer
-        dt = timed(step, args.steps, 0, dist_on)
+        dt = timed(step, args.steps, 0)
         Fm.TIMER = None
         dt_eager = dt
     ips = world * args.batch * args.steps / dt
 
     if rank == 0:
         ks = timer.summary()
-        path_k = {k: v for k, v in ks.items() if not k.startswith(("mrla_bn_", "mrla_conv1x1"))}   # the MRLA path proper
-        dom_name = max(path_k, key=lambda k: path_k[k]["ms"]) if path_k else None  # its kernel with the most time
+        path_k = {k: v for k, v in ks.items() if is_path_kernel(k)}
+        big = {k: v for k, v in path_k.items() if v["bytes"] > 0}
+        dom_name = max(big, key=lambda k: big[k]["ms"]) if big else None        # the path's kernel with the most time
         dom = ks.get(dom_name)
         roofline = None
         if dom:
-            ach = dom["bytes"] / (dom["ms"] * 1e-3) / 1e9
+            sec = dom["ms"] * 1e-3
+            ach, ach_f = dom["bytes_alg"] / sec / 1e9, dom["bytes"] / sec / 1e9
+            path_ms = sum(v["ms"] for v in path_k.values())
+            path_b = sum(v["bytes_path"] for v in path_k.values())
             # DeiT keeps its residual stream (and therefore the token MRLA kernels) in fp32 under autocast, as the reference does
             kdt = "fp32" if args.arch.startswith("deit") else "bf16"
+            traffic, traffic_src = pmc_traffic(args, dom_name)
             roofline = {"bound": "hbm", "kernel": f"{dom_name}<{kdt}>", "achieved": round(ach, 1),
                         "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4),
-                        "traffic": pmc_traffic(args, dom_name),
+                        "traffic": traffic, "traffic_source": traffic_src,
                         "launches": dom["launches"], "avg_launch_us": round(1e3 * dom["ms"] / dom["launches"], 2),
-                        "algorithmic_bytes_per_launch_avg": dom["bytes"] // dom["launches"]}
+                        "algorithmic_bytes_per_launch_avg": dom["bytes_alg"] // dom["launches"],
+                        "achieved_fused": round(ach_f, 1), "frac_fused": round(ach_f / HBM_PEAK_GBS, 4),
+                        "fused_bytes_per_launch_avg": dom["bytes"] // dom["launches"],
+                        "path_frac": round(path_b / (path_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if path_ms > 0 else None,
+                        "path_ms_per_step": round(path_ms / args.steps, 3),
+                        "path_bytes_per_step": path_b // args.steps,
+                        "convention": "achieved/frac: SURVEY.md 8(d) algorithmic bytes of this launch; *_fused: all bytes the "
+                                      "launch is built to move (differs where work of a neighbouring pass is folded in); "
+                                      "path_frac: 8(d) compulsory bytes of the whole MRLA path per step / time of all its "
+                                      "kernels (streaming passes + gate / reduce kernels) / peak"}
+        gx_desc = None
+        if dist_on:
+            gx_desc = {"flat": None if exchange is None else
+                       (f"{len(exchange.buckets)} all-reduce(s) (RCCL avg) over one flat fp32 gradient buffer"
+                        + (", sent from backward as its buckets fill" if schedule == "bucketed_overlap" else ", after backward")),
+                       "ddp": "DistributedDataParallel: 32 MB buckets, overlapped with backward"}[dp]
         out = {"metric": f"images/sec fwd+bwd {args.arch} b={args.batch}", "value": round(ips, 1), "unit": "images/sec",
                "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(1e3 * dt / args.steps, 3),
                "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
                "config": {"workload": f"{args.arch} fwd+bwd+SGD, {args.batch} images/GPU of 3x224x224, bf16 autocast, "
                                       f"fp32 master weights, drop_path {args.drop_path}",
                           "global_batch": world * args.batch, "parallelism": f"dp{world}", "launch": launch,
-                          **({"gradient_exchange": {"flat": f"{len(exchange.buckets) if exchange else 0} all-reduce(s) (RCCL avg) over one flat "
-                                                            "fp32 gradient buffer" + (", sent from backward as its buckets fill" if exchange and len(exchange.buckets) > 1
-                                                                                     else ", after backward"),
-                                                    "ddp": "DistributedDataParallel: 32 MB buckets, overlapped with backward"}[dp]}
-                             if dist_on else {}),
+                          "ranks_seen": seen,
+                          "backend": ({"nccl": "nccl (RCCL)"}.get(args.backend, args.backend) if dist_on else "none (single process)"),
+                          **({"gradient_exchange": gx_desc, "gradient_exchange_schedule": schedule,
+                              "gradient_exchange_ab_ms": ab_ms} if dist_on else {}),
                           "path": "eager restatement" if args.eager else
                                   f"mrla_amd (HIP MRLA tails incl. shortcut add+ReLU, HIP BatchNorm+ReLU(+stem max-pool), HIP MFMA GEMMs for the "
                                   f"1x1 convolutions fwd / dgrad / wgrad where eligible, stock 3x3 / 7x7 / strided convolutions; {layout})"},
                "eager_launch_ms_per_step": round(1e3 * dt_eager / args.steps, 3),
                "roofline": roofline,
                "mrla_kernels": {k: {"launches": v["launches"], "ms_per_step": round(v["ms"] / args.steps, 3),
-                                    "GBps": round(v["bytes"] / (v["ms"] * 1e-3) / 1e9, 1)} for k, v in ks.items()}}
+                                    **({"GBps": round(v["bytes"] / (v["ms"] * 1e-3) / 1e9, 1)} if v["bytes"] else {})}
+                                for k, v in ks.items()}}
         if args.arch in MODEL_GFLOP_PER_IMAGE:
             tf = ips * MODEL_GFLOP_PER_IMAGE[args.arch] / 1e3
             out["compute_roofline"] = {"model_tflops": round(tf, 1), "peak_bf16_mfma_tflops": MFMA_BF16_PEAK_TFLOPS * world,
                                        "frac": round(tf / (MFMA_BF16_PEAK_TFLOPS * world), 4),
+                                       "mfma_util_counter": mfma_counter(args),
                                        "note": "whole-model flops (MIOpen convolutions); the MRLA kernels are HBM/VALU work"}
-        if world == 1:
+        if world == 1 and not dist_on:
             out["forward_only"] = forward_only(net, x, graph=use_graph)
-        if world == 1 and not args.no_baselines:
+        if world == 1 and not dist_on and not args.no_baselines:
             out["eager_rocm"] = eager_rocm(args.arch, args.batch, args.drop_path)
             # like for like: both sides launched kernel by kernel by PyTorch (the eager restatement is never graph-replayed);
             # the graph-replayed product forward against the same denominator is reported beside it, labelled
@@ -385,6 +643,13 @@ def main():
             if "graph_fwd_images_per_sec" in fo:
                 fo["graph_replay_vs_eager_rocm"] = round(fo["graph_fwd_images_per_sec"] / den, 2)
             out["cpu_baseline"] = cpu_baseline(args.arch)
+            if not args.no_others and (args.arch, args.batch) == ("resnet50_mrlal", 256):
+                # this process goes idle: give its graph pool and cached blocks back first
+                graph = step = eager_step = net = None
+                import gc
+                gc.collect()
+                torch.cuda.empty_cache()
+                out["other_configs"] = run_other_configs()
         print(json.dumps(out), flush=True)
     if dist_on:
         D.barrier()

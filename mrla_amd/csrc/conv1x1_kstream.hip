@@ -23,7 +23,6 @@
 // These products need 0.5 - 2 PFLOP/s to run at the HBM rate (N*K/(N+K) = 100 - 400 flop per byte), so unlike their
 // K <= 256 siblings they are bound by the matrix pipe as much as by memory; MIOpen's kernels reach 25 - 30 % of it.
 #include <algorithm>
-#include <cstdlib>
 
 #include "mrla_device.h"
 #include "mrla_kernels.h"
@@ -473,16 +472,11 @@ struct KsPlan {
   bool big = false;        // the 256 x 256 tile kernel
 };
 
-static bool ks_want_big() {             // MRLA_KS256=0: A/B switch back to the 64 x 64 wave tiles
-  static const bool v = [] { const char* e = getenv("MRLA_KS256"); return !(e && e[0] == '0'); }();
-  return v;
-}
-
 KsPlan ks_plan(int M, int K, int N) {
   KsPlan p;
   if (M <= 0 || K < 512 || K % kKsKC || N % 128 || (size_t)M * std::max(N, K) * 2 >= (size_t)1 << 31) return p;
   p.wn = N % 256 == 0 ? 4 : 2;
-  if (ks_want_big() && N % 256 == 0 && K >= 1024) {
+  if (N % 256 == 0 && K >= 1024) {
     // 256 x 256 tiles, one workgroup per CU: when they come close to filling the chip's rounds and the reduction is long
     // enough to amortise a lone workgroup's pipeline fill and 128 KB epilogue (measured, b = 256, us old -> new: 1024 -> 256
     // @14 38.4 -> 35.7, 1024 -> 512 @14 77.5 -> 70.9; but K = 512: 512 -> 1024 @14 66.6 -> 82.9, 512 -> 2048 @7 39.2 -> 42.5)

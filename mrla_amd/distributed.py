@@ -44,13 +44,10 @@ def wrap_data_parallel(model, device_ids=None, bucket_cap_mb=32, force=False):
         broadcast_buffers=False)
     # Without a communication hook the reducer divides EVERY parameter's gradient by the world size with a kernel of its
     # own before the bucket goes out (161 launches and ~0.5 ms of GPU time per resnet50_mrlal step, rocprofv3 trace in
-    # profiles/r03_notes.md).  With a hook the averaging is the hook's business: one division of the flat bucket.
-    how = os.environ.get("MRLA_DDP_HOOK", "builtin")          # (A/B switch for measurements: none | python | builtin)
-    if how == "builtin":
-        # the C++ all-reduce hook: divides the flat bucket once, launches the all-reduce, no Python in the backward pass
-        ddp._register_builtin_comm_hook(dist.BuiltinCommHookType.ALLREDUCE)
-    elif how == "python":
-        ddp.register_comm_hook(None, _allreduce_avg_hook)
+    # profiles/r03_notes.md).  With a hook the averaging is the hook's business: the C++ all-reduce hook divides the flat
+    # bucket once and launches the all-reduce, no Python in the backward pass (a Python averaging hook measured slower
+    # than no hook at all: profiles/r03_notes.md).
+    ddp._register_builtin_comm_hook(dist.BuiltinCommHookType.ALLREDUCE)
     return ddp
 
 
@@ -71,7 +68,11 @@ class FlatGradientExchange:
         (same sizes and strides as the parameter: the optimizer's layout contract).
     2 launches per bucket, all capturable.  overlap=False: one copy and one all-reduce for everything inside reduce().
 
-    usage per step:  opt.zero_grad(set_to_none=True); loss.backward(); exchange.reduce(); opt.step()"""
+    usage per step:  opt.zero_grad(set_to_none=True); loss.backward(); exchange.reduce(); opt.step()
+    ONE backward per reduce(): with overlap=True a bucket goes out the moment its last gradient of that backward has
+    arrived, so a second backward before reduce() (gradient accumulation, two losses) would add to gradients that are
+    already on the wire; the hook raises instead of averaging the first micro-batch only.  Accumulate with
+    overlap=False (everything is gathered and sent inside reduce())."""
 
     def __init__(self, params, group=None, broadcast=True, bucket_mb=25, overlap=True):
         self.params = [p for p in params if p.requires_grad][::-1]          # backward's order
@@ -118,6 +119,9 @@ class FlatGradientExchange:
 
     def _arrived(self, k):
         def hook(_p):
+            if self._sent[k]:
+                raise RuntimeError("FlatGradientExchange(overlap=True): a gradient arrived for a bucket that has already been "
+                                   "sent -- a second backward before reduce(); accumulate with overlap=False")
             self._pending[k] -= 1
             if self._pending[k] == 0:
                 self._send(k)
@@ -175,16 +179,6 @@ def _is_dense(t):
             return False
         expect *= t.size(d)
     return True
-
-
-def _allreduce_avg_hook(state, bucket):
-    buf = bucket.buffer()
-    if dist.get_backend() == "nccl":
-        fut = dist.all_reduce(buf, op=dist.ReduceOp.AVG, async_op=True).get_future()
-    else:
-        buf.div_(dist.get_world_size())
-        fut = dist.all_reduce(buf, op=dist.ReduceOp.SUM, async_op=True).get_future()
-    return fut.then(lambda f: f.value()[0])
 
 
 def max_over_ranks(seconds, device=None):

@@ -7,6 +7,7 @@ a missing library raise.
 import contextlib
 import ctypes
 import threading
+import weakref
 from math import log
 
 import torch
@@ -26,32 +27,38 @@ class KernelTimer:
     """Optional HIP-event timing of selected C-ABI launches on the stream they are launched on (used by
     bench.py for the roofline figure).  Events are read back only after the caller synchronises."""
 
-    def __init__(self, names):
-        self.names = set(names)
-        self.records = []          # (name, nbytes, start_event, end_event)
+    def __init__(self, names=None):
+        self.names = None if names is None else set(names)       # None: every C-ABI launch
+        self.records = []          # (name, nbytes, start_event, end_event, alg_bytes, path_bytes)
 
     def summary(self):
+        """Per label: launches, ms, `bytes` (what the launch is built to move), `bytes_alg` (SURVEY.md section 8(d)'s
+        algorithmic count for that launch where it differs) and `bytes_path` (its share of the section-8(d) compulsory bytes
+        of the whole MRLA block, attributed to the pass that completes a direction; 0 for the other passes)."""
         out = {}
-        for name, nbytes, e0, e1 in self.records:
-            d = out.setdefault(name, dict(launches=0, ms=0.0, bytes=0))
+        for name, nbytes, e0, e1, alg, path in self.records:
+            d = out.setdefault(name, dict(launches=0, ms=0.0, bytes=0, bytes_alg=0, bytes_path=0))
             d["launches"] += 1
             d["ms"] += e0.elapsed_time(e1)
             d["bytes"] += nbytes
+            d["bytes_alg"] += nbytes if alg is None else alg
+            d["bytes_path"] += path
         return out
 
 
 TIMER = None      # set to a KernelTimer to time launches
 
 
-def _call(name, nbytes, *args, entry=None):
-    """Launch the C-ABI entry point `entry` (default: `name`); `name` is the label the optional timer records it under."""
+def _call(name, nbytes, *args, entry=None, alg=None, path=0):
+    """Launch the C-ABI entry point `entry` (default: `name`); `name` is the label the optional timer records it under,
+    with `nbytes` / `alg` / `path` as KernelTimer.summary describes them."""
     t = TIMER
-    if t is not None and name in t.names:
+    if t is not None and (t.names is None or name in t.names):
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
         L.call(entry or name, *args)
         e1.record()
-        t.records.append((name, nbytes, e0, e1))
+        t.records.append((name, nbytes, e0, e1, alg, path))
     else:
         L.call(entry or name, *args)
 
@@ -227,19 +234,26 @@ class _DeferredBnBox:
     backward needs on the way (mrla_light_apply_bwd: pre / pre_tmom).  It leaves them here, tagged with the gradient tensor
     they belong to; the BatchNorm's backward uses them when exactly that tensor arrives, and runs its own statistics pass
     otherwise (another consumer added to the gradient, a layout conversion, a path without the fused sums)."""
-    __slots__ = ("ptr", "shape", "tmom", "rows", "center")
+    __slots__ = ("ptr", "shape", "tmom", "rows", "center", "ref", "version")
 
     def __init__(self):
-        self.ptr = self.shape = self.tmom = self.rows = None
+        self.ptr = self.shape = self.tmom = self.rows = self.ref = self.version = None
         self.center = None         # that BatchNorm's saved mean [c]: the sums are taken about it
 
     def put(self, dpre, tmom, rows):
         self.ptr, self.shape, self.tmom, self.rows = dpre.data_ptr(), tuple(dpre.shape), tmom, rows
+        self.ref, self.version = weakref.ref(dpre), dpre._version
 
     def take(self, dy):
-        tmom, rows, ok = self.tmom, self.rows, (self.tmom is not None and dy.data_ptr() == self.ptr
-                                               and tuple(dy.shape) == self.shape)
-        self.ptr = self.shape = self.tmom = self.rows = None
+        """The sums belong to `dy` only if it is the very tensor the producer wrote, unmodified: the producer's tensor is
+        still alive (so nothing else can have been allocated at its address), `dy` sits at that address with that shape,
+        and nothing has been written into it since (autograd accumulates a second consumer's gradient IN PLACE into the
+        first-arrived buffer when it owns it; a tensor hook may edit it: both bump the version counter)."""
+        alive = self.ref() if self.ref is not None else None
+        ok = (self.tmom is not None and alive is not None and dy.data_ptr() == self.ptr and tuple(dy.shape) == self.shape
+              and dy._version == self.version)
+        tmom, rows = self.tmom, self.rows
+        self.ptr = self.shape = self.tmom = self.rows = self.ref = self.version = None
         return (tmom, rows) if ok else None
 
 
@@ -307,20 +321,20 @@ class _LightFn(torch.autograd.Function):
             _call("mrla_light_pool_fused", xc.numel() * xc.element_size() * 2, _ptr(xc), _ptr(psc), _ptr(psh), _ptr(oc),
                   _ptr(part), _ptr(mom), b, c, h, w, dt, layout, st)
             gate = torch.empty((b, G), dtype=torch.float32, device=dev)
-            L.call("mrla_light_gate_fwd", _ptr(mom), _ptr(wq32), _ptr(wk32), ks, _ptr(gate), b, c, h * w, d, st)
+            _call("mrla_light_gate_fwd", 0, _ptr(mom), _ptr(wq32), _ptr(wk32), ks, _ptr(gate), b, c, h * w, d, st)
             bnbuf = None
             if cfg.bn_mode != L.BN_NONE:
                 gamma32, beta32 = _f32(gamma), _f32(beta)
                 rs = _RunningStats(running_mean, running_var, c, "mrla light forward")
                 bnbuf = torch.empty((4, c), dtype=torch.float32, device=dev)
-                L.call("mrla_light_bn_fwd", _ptr(mom), _ptr(gate), _ptr(lam32), _ptr(gamma32), _ptr(beta32),
+                _call("mrla_light_bn_fwd", 0, _ptr(mom), _ptr(gate), _ptr(lam32), _ptr(gamma32), _ptr(beta32),
                        _ptr(rs.rm), _ptr(rs.rv), cfg.bn_mode, float(cfg.momentum), float(cfg.eps),
                        _ptr(bnbuf[0]), _ptr(bnbuf[1]), _ptr(bnbuf[2]), _ptr(bnbuf[3]), b, c, h * w, d, st)
             out = torch.empty_like(xc)
             _call("mrla_light_apply_fwd_fused", xc.numel() * xc.element_size() * 3, _ptr(xc), _ptr(psc), _ptr(psh),
                   _ptr(oc), _ptr(wv32), _ptr(gate), _ptr(bnbuf[0]) if bnbuf is not None else None,
                   _ptr(bnbuf[1]) if bnbuf is not None else None, _ptr(lam32), _ptr(dp32), _ptr(out), b, c, h, w, d,
-                  cfg.res, dt, layout, st)
+                  cfg.res, dt, layout, st, path=xc.numel() * xc.element_size() * 3)
             return out.contiguous() if via_nhwc else out
         if cfg.fuse:
             pre, xc = xc, torch.empty_like(xc)
@@ -331,20 +345,21 @@ class _LightFn(torch.autograd.Function):
             _call("mrla_light_stats_fwd", xc.numel() * xc.element_size() * (2 if oc is not None else 1), _ptr(xc),
                   _ptr(oc), _ptr(wv32), _ptr(mom), b, c, h, w, dt, layout, cfg.act, st)
         gate = torch.empty((b, G), dtype=torch.float32, device=dev)
-        L.call("mrla_light_gate_fwd", _ptr(mom), _ptr(wq32), _ptr(wk32), ks, _ptr(gate), b, c, h * w, d, st)
+        _call("mrla_light_gate_fwd", 0, _ptr(mom), _ptr(wq32), _ptr(wk32), ks, _ptr(gate), b, c, h * w, d, st)
         bnbuf = gamma32 = None
         if cfg.bn_mode != L.BN_NONE:
             gamma32, beta32 = _f32(gamma), _f32(beta)
             rs = _RunningStats(running_mean, running_var, c, "mrla light forward")
             bnbuf = torch.empty((4, c), dtype=torch.float32, device=dev)       # sc, sh, save_mean, save_inv
-            L.call("mrla_light_bn_fwd", _ptr(mom), _ptr(gate), _ptr(lam32), _ptr(gamma32), _ptr(beta32),
+            _call("mrla_light_bn_fwd", 0, _ptr(mom), _ptr(gate), _ptr(lam32), _ptr(gamma32), _ptr(beta32),
                    _ptr(rs.rm), _ptr(rs.rv), cfg.bn_mode, float(cfg.momentum), float(cfg.eps),
                    _ptr(bnbuf[0]), _ptr(bnbuf[1]), _ptr(bnbuf[2]), _ptr(bnbuf[3]), b, c, h * w, d, st)
             rs.finish(cfg.bn_mode == L.BN_TRAIN)
         out = torch.empty_like(xc)
         _call("mrla_light_apply_fwd", xc.numel() * xc.element_size() * (3 if oc is not None else 2), _ptr(xc), _ptr(oc), _ptr(wv32), _ptr(gate),
                _ptr(bnbuf[0]) if bnbuf is not None else None, _ptr(bnbuf[1]) if bnbuf is not None else None,
-               _ptr(lam32), _ptr(dp32), _ptr(out), b, c, h, w, d, cfg.res, dt, layout, cfg.act, st)
+               _ptr(lam32), _ptr(dp32), _ptr(out), b, c, h, w, d, cfg.res, dt, layout, cfg.act, st,
+               path=xc.numel() * xc.element_size() * (3 if oc is not None else 2))
 
         ctx.cfg, ctx.layout, ctx.ks = cfg, layout, ks
         ctx.shapes = (wq.shape, wk.shape, wv.shape, lam.shape if lam is not None else None)
@@ -377,13 +392,13 @@ class _LightFn(torch.autograd.Function):
         small = torch.empty((11, c), dtype=torch.float32, device=dev)     # cb[c,4] | dgamma | dbeta | dlam | cb_lo[c,4]
         cb, cb_lo = small[:4].view(c, 4), small[7:].view(c, 4)
         has_bn = cfg.bn_mode != L.BN_NONE
-        L.call("mrla_light_bn_bwd", _ptr(mom), _ptr(bmom), _ptr(gate), _ptr(lam32), _ptr(gamma32) if has_bn else None,
+        _call("mrla_light_bn_bwd", 0, _ptr(mom), _ptr(bmom), _ptr(gate), _ptr(lam32), _ptr(gamma32) if has_bn else None,
                _ptr(dp32), _ptr(bnbuf[2]) if has_bn else None, _ptr(bnbuf[3]) if has_bn else None, cfg.bn_mode,
                _ptr(cb), _ptr(cb_lo), _ptr(small[4]) if has_bn else None, _ptr(small[5]) if has_bn else None,
                _ptr(small[6]) if lam32 is not None else None, b, c, h * w, d, st)
         dyx = torch.empty((b, c), dtype=torch.float32, device=dev)
         dwqk_part = torch.empty((b, 2 * ks), dtype=torch.float32, device=dev)
-        L.call("mrla_light_gate_bwd", _ptr(mom), _ptr(bmom), _ptr(gate), _ptr(cb), _ptr(cb_lo), _ptr(dp32), _ptr(wq32),
+        _call("mrla_light_gate_bwd", 0, _ptr(mom), _ptr(bmom), _ptr(gate), _ptr(cb), _ptr(cb_lo), _ptr(dp32), _ptr(wq32),
                _ptr(wk32), ks, _ptr(dyx), _ptr(dwqk_part), b, c, h * w, d, st)
         rows = L.load().mrla_light_wgrad_rows(b, c, h, w, dt, layout)
         L.check(min(rows, 0), "mrla_light_wgrad_rows")
@@ -400,11 +415,14 @@ class _LightFn(torch.autograd.Function):
               _ptr(dout), _ptr(xc), _ptr(oc), _ptr(wv32), _ptr(gate), _ptr(cb), _ptr(lam32),
               _ptr(dp32), _ptr(dyx), _ptr(dx), _ptr(do), _ptr(dwv_part), _ptr(pre),
               _ptr(cfg.pre_box.center) if pre is not None else None, _ptr(pre_tmom), b, c, h, w, d, cfg.res,
-              int(cfg.fuse), dt, layout, cfg.act, st)
+              int(cfg.fuse), dt, layout, cfg.act, st,
+              # section 8(d): dOut, x_t, o_prev in; dx, do out (the y3 row read for bn3's folded sums is not in that count)
+              alg=xc.numel() * xc.element_size() * (5 if oc is not None else 3),
+              path=xc.numel() * xc.element_size() * (5 if oc is not None else 3))
         if pre_tmom is not None:
             cfg.pre_box.put(dx, pre_tmom, rows)
         wsum = torch.empty((c * 9 + 2 * ks,), dtype=torch.float32, device=dev)
-        L.call("mrla_reduce_rows2", _ptr(dwv_part), _ptr(wsum), rows, c * 9, _ptr(dwqk_part), _ptr(wsum[c * 9:]), b, 2 * ks, st)
+        _call("mrla_reduce_rows2", 0, _ptr(dwv_part), _ptr(wsum), rows, c * 9, _ptr(dwqk_part), _ptr(wsum[c * 9:]), b, 2 * ks, st)
 
         sq, sk, sv, sl = ctx.shapes
         tq, tk, tv, tl, tg = ctx.pdtypes
@@ -588,7 +606,7 @@ class _BaseFn(torch.autograd.Function):
             psc, psh = cfg.pre_affine if cfg.pre_affine is not None else (None, None)
             _call("mrla_base_pool_value_fwd", xc.numel() * es * (4 if cfg.fuse else 2), _ptr(pre if cfg.fuse else xc),
                   _ptr(psc), _ptr(psh), _ptr(idc), _ptr(wv32), _ptr(mom), _ptr(xc) if cfg.fuse else None,
-                  _ptr(stage.V[t - 1]), b, c, h, w, dt, layout, st)
+                  _ptr(stage.V[t - 1]), b, c, h, w, dt, layout, st, path=xc.numel() * es * 2)
         elif cfg.fuse:          # x is the pre-activation: x_t = relu(x + identity) formed by the pooling pass
             idc = _layout_of(identity, L.NCHW)[1]
             pre, xc = xc, torch.empty_like(xc)
@@ -598,14 +616,15 @@ class _BaseFn(torch.autograd.Function):
             _call("mrla_light_stats_fwd", xc.numel() * xc.element_size(), _ptr(xc), None, _ptr(wv32), _ptr(mom), b, c, h,
                   w, dt, layout, L.ACT_NONE, st)
         q = torch.empty((b, c), dtype=torch.float32, device=dev)
-        L.call("mrla_base_gate_fwd", _ptr(mom), _ptr(wq32), _ptr(wk32), ks, _ptr(stage.K), _ptr(stage.P), _ptr(q), b, c,
+        _call("mrla_base_gate_fwd", 0, _ptr(mom), _ptr(wq32), _ptr(wk32), ks, _ptr(stage.K), _ptr(stage.P), _ptr(q), b, c,
                h * w, d, T, t, st)
         attn = torch.empty_like(xc)
         arows = L.load().mrla_base_tile_rows(b, c, h, w, dt, layout)      # rows of the (sum, sum^2) partials
         L.check(min(arows, 0), "mrla_base_tile_rows")
         amom = torch.empty((arows, c, 2), dtype=torch.float32, device=dev)
         _call("mrla_base_attend_fwd", xc.numel() * es * ((t + 1) if nhwc else (t + 2)), None if nhwc else _ptr(xc),
-              _ptr(wv32), _ptr(stage.V), _ptr(stage.P), _ptr(attn), _ptr(amom), b, c, h, w, d, T, t, dt, layout, st)
+              _ptr(wv32), _ptr(stage.V), _ptr(stage.P), _ptr(attn), _ptr(amom), b, c, h, w, d, T, t, dt, layout, st,
+              path=xc.numel() * es * (t - 1 if nhwc else t + 1))      # section 8(d): (t + 2) N per layer with the value pass + tail
         stage.t = t
         bnbuf = gamma32 = None
         out = attn
@@ -613,13 +632,13 @@ class _BaseFn(torch.autograd.Function):
             gamma32, beta32 = _f32(gamma), _f32(beta)
             rs = _RunningStats(running_mean, running_var, c, "mrla base forward")
             bnbuf = torch.empty((4, c), dtype=torch.float32, device=dev)
-            L.call("mrla_bn_stats_fwd", _ptr(amom), None, _ptr(gamma32), _ptr(beta32), _ptr(rs.rm), _ptr(rs.rv),
+            _call("mrla_bn_stats_fwd", 0, _ptr(amom), None, _ptr(gamma32), _ptr(beta32), _ptr(rs.rm), _ptr(rs.rv),
                    cfg.bn_mode, float(cfg.momentum), float(cfg.eps), _ptr(bnbuf[0]), _ptr(bnbuf[1]), _ptr(bnbuf[2]),
                    _ptr(bnbuf[3]), arows, c, b * h * w // arows, st)
             rs.finish(cfg.bn_mode == L.BN_TRAIN)
             out = torch.empty_like(xc)
             _call("mrla_base_tail_fwd", xc.numel() * xc.element_size() * 3, _ptr(xc), _ptr(attn), _ptr(bnbuf[0]),
-                  _ptr(bnbuf[1]), _ptr(dp32), _ptr(out), b, c, h, w, dt, layout, st)
+                  _ptr(bnbuf[1]), _ptr(dp32), _ptr(out), b, c, h, w, dt, layout, st, path=xc.numel() * xc.element_size())
         ctx.cfg, ctx.layout, ctx.ks, ctx.stage, ctx.t = cfg, layout, ks, stage, t
         ctx.shapes = (wq.shape, wk.shape, wv.shape)
         ctx.wv_stride = wv.stride()
@@ -654,7 +673,7 @@ class _BaseFn(torch.autograd.Function):
                   _ptr(center), _ptr(dp32), _ptr(tmom), b, c, h, w, dt, layout, st)
             small = torch.empty((5, c), dtype=torch.float32, device=dev)         # cb[c,3] | dgamma | dbeta
             cb = small[:3].view(c, 3)
-            L.call("mrla_bn_stats_bwd", _ptr(tmom), _ptr(gamma32), _ptr(bnbuf[2]), _ptr(bnbuf[3]), cfg.bn_mode,
+            _call("mrla_bn_stats_bwd", 0, _ptr(tmom), _ptr(gamma32), _ptr(bnbuf[2]), _ptr(bnbuf[3]), cfg.bn_mode,
                    int(center is not None), _ptr(cb), _ptr(small[3]), _ptr(small[4]), trows, c, b * h * w // trows, st)
             dgamma, dbeta = small[3].to(ctx.pdtypes[3]), small[4].to(ctx.pdtypes[3])
         pmom = torch.empty((b, c, t), dtype=torch.float32, device=dev)
@@ -662,12 +681,13 @@ class _BaseFn(torch.autograd.Function):
         ppart = torch.empty((prows, t, c), dtype=torch.float32, device=dev) if nhwc else pmom
         _call("mrla_base_attend_bwd", xc.numel() * es * (t + 3), _ptr(dout), _ptr(attn),
               _ptr(bnbuf[0]) if cfg.tail else None, _ptr(bnbuf[1]) if cfg.tail else None, _ptr(dp32), _ptr(cb),
-              _ptr(stage.V), _ptr(stage.dA), _ptr(ppart), b, c, h, w, T, t, dt, layout, st)
+              _ptr(stage.V), _ptr(stage.dA), _ptr(ppart), b, c, h, w, T, t, dt, layout, st,
+              path=xc.numel() * es * (t + 1))                         # section 8(d): ~(2t + 3) N per layer, backward
         if nhwc:
-            L.call("mrla_base_pmom_reduce", _ptr(ppart), _ptr(pmom), b, c, t, prows, st)
+            _call("mrla_base_pmom_reduce", 0, _ptr(ppart), _ptr(pmom), b, c, t, prows, st)
         dyx = torch.empty((b, c), dtype=torch.float32, device=dev)
         dwqk_part = torch.empty((b, 2 * ks), dtype=torch.float32, device=dev)
-        L.call("mrla_base_gate_bwd", _ptr(mom), _ptr(pmom), _ptr(stage.P), _ptr(q), _ptr(stage.K), _ptr(stage.dK),
+        _call("mrla_base_gate_bwd", 0, _ptr(mom), _ptr(pmom), _ptr(stage.P), _ptr(q), _ptr(stage.K), _ptr(stage.dK),
                _ptr(wq32), _ptr(wk32), ks, _ptr(dyx), _ptr(dwqk_part), b, c, h * w, d, T, t, int(first), st)
         rows = L.load().mrla_light_wgrad_rows(b, c, h, w, dt, layout)
         L.check(min(rows, 0), "mrla_light_wgrad_rows")
@@ -677,15 +697,15 @@ class _BaseFn(torch.autograd.Function):
         if nhwc:                # dV_t from the dA slots t..Tc, then the transposed 3x3 pass
             dv = torch.empty((b, h, w, c), dtype=xc.dtype, device=dev)
             _call("mrla_base_dv_combine", xc.numel() * es * (Tc - t + 2), _ptr(stage.dA), _ptr(stage.P), _ptr(dv),
-                  b, c, h, w, d, T, t, Tc, dt, layout, st)
+                  b, c, h, w, d, T, t, Tc, dt, layout, st, path=xc.numel() * es * (Tc - t + 1))
             _call("mrla_base_value_bwd_dv", xc.numel() * es * 4, _ptr(dout), _ptr(xc), _ptr(wv32), _ptr(dv),
-                  _ptr(dyx), _ptr(dx), _ptr(dwv_part), b, c, h, w, res, dt, layout, st)
+                  _ptr(dyx), _ptr(dx), _ptr(dwv_part), b, c, h, w, res, dt, layout, st, path=xc.numel() * es)
         else:
             _call("mrla_base_value_bwd", xc.numel() * es * (Tc - t + 4), _ptr(dout), _ptr(xc), _ptr(wv32),
                   _ptr(stage.dA), _ptr(stage.P), _ptr(dyx), _ptr(dx), _ptr(dwv_part), b, c, h, w, d, T, t, Tc, res, dt,
-                  layout, st)
+                  layout, st, path=xc.numel() * es * (Tc - t + 2))
         wsum = torch.empty((c * 9 + 2 * ks,), dtype=torch.float32, device=dev)
-        L.call("mrla_reduce_rows2", _ptr(dwv_part), _ptr(wsum), rows, c * 9, _ptr(dwqk_part), _ptr(wsum[c * 9:]), b, 2 * ks, st)
+        _call("mrla_reduce_rows2", 0, _ptr(dwv_part), _ptr(wsum), rows, c * 9, _ptr(dwqk_part), _ptr(wsum[c * 9:]), b, 2 * ks, st)
         sq, sk, sv = ctx.shapes
         tq, tk, tv, _ = ctx.pdtypes
         return (dx, dx if cfg.fuse else None, wsum[c * 9:c * 9 + ks].view(sq).to(tq), wsum[c * 9 + ks:].view(sk).to(tk),
@@ -734,13 +754,14 @@ class _TokenLightFn(torch.autograd.Function):
         ks = wq32.numel()
         stats = torch.empty((b, n, 4), dtype=torch.float32, device=dev)
         mom = torch.empty((b, c, L.FWD_MOMENTS), dtype=torch.float32, device=dev)
-        L.call("mrla_token_norm_pool", _ptr(xc), _ptr(oc), _ptr(wxw), _ptr(wxb), float(eps), _ptr(stats), _ptr(mom), b, n,
+        _call("mrla_token_norm_pool", 0, _ptr(xc), _ptr(oc), _ptr(wxw), _ptr(wxb), float(eps), _ptr(stats), _ptr(mom), b, n,
                c, dt, st)
         gate = torch.empty((b, c // d), dtype=torch.float32, device=dev)
-        L.call("mrla_light_gate_fwd", _ptr(mom), _ptr(wq32), _ptr(wk32), ks, _ptr(gate), b, c, n - 1, d, st)
+        _call("mrla_light_gate_fwd", 0, _ptr(mom), _ptr(wq32), _ptr(wk32), ks, _ptr(gate), b, c, n - 1, d, st)
         out = torch.empty_like(xc)
         _call("mrla_token_apply_fwd", xc.numel() * xc.element_size() * 3, _ptr(xc), _ptr(oc), _ptr(stats), _ptr(wxw),
-              _ptr(wxb), _ptr(wow), _ptr(wob), _ptr(wv32), _ptr(gate), _ptr(lam32), _ptr(out), b, n, c, d, int(res), dt, st)
+              _ptr(wxb), _ptr(wow), _ptr(wob), _ptr(wv32), _ptr(gate), _ptr(lam32), _ptr(out), b, n, c, d, int(res), dt, st,
+              path=xc.numel() * xc.element_size() * 3)
         ctx.d, ctx.res, ctx.ks = d, int(res), ks
         ctx.meta = [(t.shape, t.dtype) for t in (lnx_w, lnx_b, lno_w, lno_b, wq, wk, wv, lam)]
         ctx.save_for_backward(xc, oc, wxw, wxb, wow, wob, wq32, wk32, wv32, lam32, stats, mom, gate)
@@ -766,16 +787,16 @@ class _TokenLightFn(torch.autograd.Function):
         part = torch.empty((prow, c * L.TOKEN_PARTIALS), dtype=torch.float32, device=dev)
         _call("mrla_token_apply_bwd", xc.numel() * es * 3 + dxn.numel() * 4, _ptr(dout), _ptr(xc), _ptr(oc), _ptr(stats),
               _ptr(wxw), _ptr(wxb), _ptr(wow), _ptr(wob), _ptr(wv32), _ptr(gate), _ptr(lam32), _ptr(dxn), _ptr(part),
-              _ptr(bmom), b, n, c, d, dt, st)
+              _ptr(bmom), b, n, c, d, dt, st, path=xc.numel() * es * 5)      # section 8(d) backward: 5 N s for the block
         dyx = torch.empty((b, c), dtype=torch.float32, device=dev)
         dwqk_part = torch.empty((b, 2 * ks), dtype=torch.float32, device=dev)
-        L.call("mrla_token_gate_bwd", _ptr(mom), _ptr(bmom), _ptr(gate), _ptr(wq32), _ptr(wk32), ks, _ptr(dyx),
+        _call("mrla_token_gate_bwd", 0, _ptr(mom), _ptr(bmom), _ptr(gate), _ptr(wq32), _ptr(wk32), ks, _ptr(dyx),
                _ptr(dwqk_part), _ptr(part), b, n, c, d, dt, st)
         dx, do = torch.empty_like(xc), torch.empty_like(oc)
         _call("mrla_token_ln_bwd", xc.numel() * es * 5 + dxn.numel() * 4, _ptr(dout), _ptr(xc), _ptr(oc), _ptr(dxn),
               _ptr(dyx), _ptr(stats), _ptr(wxw), _ptr(wow), _ptr(lam32), _ptr(dx), _ptr(do), b, n, c, res, dt, st)
         sums = torch.empty((c * L.TOKEN_PARTIALS + 2 * ks,), dtype=torch.float32, device=dev)
-        L.call("mrla_reduce_rows2", _ptr(part), _ptr(sums), prow, c * L.TOKEN_PARTIALS, _ptr(dwqk_part),
+        _call("mrla_reduce_rows2", 0, _ptr(part), _ptr(sums), prow, c * L.TOKEN_PARTIALS, _ptr(dwqk_part),
                _ptr(sums[c * L.TOKEN_PARTIALS:]), b, 2 * ks, st)
         pc = sums[:c * L.TOKEN_PARTIALS].view(c, L.TOKEN_PARTIALS)
         dwqk = sums[c * L.TOKEN_PARTIALS:]
@@ -821,21 +842,21 @@ class _TokenBaseFn(torch.autograd.Function):
         es = xc.element_size()
         stats = torch.empty((b, n, 4), dtype=torch.float32, device=dev)
         mom = torch.empty((b, c, L.FWD_MOMENTS), dtype=torch.float32, device=dev)
-        L.call("mrla_token_norm_pool", _ptr(xc), None, _ptr(wxw), _ptr(wxb), float(eps), _ptr(stats), _ptr(mom), b, n, c,
+        _call("mrla_token_norm_pool", 0, _ptr(xc), None, _ptr(wxw), _ptr(wxb), float(eps), _ptr(stats), _ptr(mom), b, n, c,
                dt, st)
         stage.reserve_slot()
         t, T = stage.t + 1, stage.T
         _call("mrla_token_base_value_fwd", xc.numel() * es * 2, _ptr(xc), _ptr(stats), _ptr(wxw), _ptr(wxb), _ptr(wv32),
-              _ptr(stage.V[t - 1]), b, n, c, dt, st)
+              _ptr(stage.V[t - 1]), b, n, c, dt, st, path=xc.numel() * es * 2)
         q = torch.empty((b, c), dtype=torch.float32, device=dev)
-        L.call("mrla_base_gate_fwd", _ptr(mom), _ptr(wq32), _ptr(wk32), ks, _ptr(stage.K), _ptr(stage.P), _ptr(q), b, c,
+        _call("mrla_base_gate_fwd", 0, _ptr(mom), _ptr(wq32), _ptr(wk32), ks, _ptr(stage.K), _ptr(stage.P), _ptr(q), b, c,
                n - 1, d, T, t, st)
         out = torch.empty_like(xc)
         arows = L.load().mrla_base_tile_rows(b, c, side, side, dt, L.NHWC)
         L.check(min(arows, 0), "mrla_base_tile_rows")
         amom = torch.empty((arows, c, 2), dtype=torch.float32, device=dev)
         _call("mrla_token_base_attend_fwd", xc.numel() * es * (t + 1), _ptr(stage.V), _ptr(stage.P), _ptr(xc), _ptr(stats),
-              _ptr(wxw), _ptr(wxb), _ptr(out), _ptr(amom), b, n, c, d, T, t, dt, st)
+              _ptr(wxw), _ptr(wxb), _ptr(out), _ptr(amom), b, n, c, d, T, t, dt, st, path=xc.numel() * es * t)
         stage.t = t
         ctx.stage, ctx.t, ctx.d, ctx.ks, ctx.side = stage, t, d, ks, side
         ctx.meta = [(p.shape, p.dtype) for p in (lnx_w, lnx_b, wq, wk, wv)]
@@ -862,26 +883,26 @@ class _TokenBaseFn(torch.autograd.Function):
         L.check(min(prows, 0), "mrla_base_pmom_rows")
         ppart = torch.empty((prows, t, c), dtype=torch.float32, device=dev)
         _call("mrla_token_base_attend_bwd", xc.numel() * es * (t + 2), _ptr(dout), _ptr(stage.V), _ptr(stage.dA), _ptr(ppart),
-              b, n, c, T, t, dt, st)
-        L.call("mrla_base_pmom_reduce", _ptr(ppart), _ptr(pmom), b, c, t, prows, st)
+              b, n, c, T, t, dt, st, path=xc.numel() * es * (t + 1))
+        _call("mrla_base_pmom_reduce", 0, _ptr(ppart), _ptr(pmom), b, c, t, prows, st)
         dv = torch.empty((b, side, side, c), dtype=xc.dtype, device=dev)
         _call("mrla_base_dv_combine", xc.numel() * es * (Tc - t + 2), _ptr(stage.dA), _ptr(stage.P), _ptr(dv), b, c, side,
-              side, d, T, t, Tc, dt, L.NHWC, st)
+              side, d, T, t, Tc, dt, L.NHWC, st, path=xc.numel() * es * (Tc - t + 1))
         dxn = torch.empty((b, n, c), dtype=torch.float32, device=dev)
         prow = L.load().mrla_token_part_rows(b, n, c, dt)
         L.check(min(prow, 0), "mrla_token_part_rows")
         part = torch.empty((prow, c * L.TOKEN_PARTIALS), dtype=torch.float32, device=dev)
         _call("mrla_token_base_value_bwd", xc.numel() * es * 2 + dxn.numel() * 4, _ptr(dout), _ptr(xc), _ptr(stats),
-              _ptr(wxw), _ptr(wxb), _ptr(wv32), _ptr(dv), _ptr(dxn), _ptr(part), b, n, c, dt, st)
+              _ptr(wxw), _ptr(wxb), _ptr(wv32), _ptr(dv), _ptr(dxn), _ptr(part), b, n, c, dt, st, path=xc.numel() * es)
         dyx = torch.empty((b, c), dtype=torch.float32, device=dev)
         dwqk_part = torch.empty((b, 2 * ks), dtype=torch.float32, device=dev)
-        L.call("mrla_token_base_gate_bwd", _ptr(mom), _ptr(pmom), _ptr(stage.P), _ptr(q), _ptr(stage.K), _ptr(stage.dK),
+        _call("mrla_token_base_gate_bwd", 0, _ptr(mom), _ptr(pmom), _ptr(stage.P), _ptr(q), _ptr(stage.K), _ptr(stage.dK),
                _ptr(wq32), _ptr(wk32), ks, _ptr(dyx), _ptr(dwqk_part), _ptr(part), b, n, c, d, T, t, int(first), dt, st)
         dx = torch.empty_like(xc)
         _call("mrla_token_ln_bwd", xc.numel() * es * 3 + dxn.numel() * 4, _ptr(dout), _ptr(xc), None, _ptr(dxn), _ptr(dyx),
               _ptr(stats), _ptr(wxw), None, None, _ptr(dx), None, b, n, c, 0, dt, st)
         sums = torch.empty((c * L.TOKEN_PARTIALS + 2 * ks,), dtype=torch.float32, device=dev)
-        L.call("mrla_reduce_rows2", _ptr(part), _ptr(sums), prow, c * L.TOKEN_PARTIALS, _ptr(dwqk_part),
+        _call("mrla_reduce_rows2", 0, _ptr(part), _ptr(sums), prow, c * L.TOKEN_PARTIALS, _ptr(dwqk_part),
                _ptr(sums[c * L.TOKEN_PARTIALS:]), b, 2 * ks, st)
         pc = sums[:c * L.TOKEN_PARTIALS].view(c, L.TOKEN_PARTIALS)
         dwqk = sums[c * L.TOKEN_PARTIALS:]
@@ -931,10 +952,10 @@ class _BnActFn(torch.autograd.Function):
                 _call("mrla_bn_plane_moments", xc.numel() * xc.element_size(), _ptr(xc), _ptr(amom), _ptr(pivot), b, c, h, w,
                       dt, layout, st)
         if records:
-            L.call("mrla_bn_stats_fwd_rows", _ptr(amom), _ptr(gamma32), _ptr(beta32), _ptr(rs.rm), _ptr(rs.rv), L.BN_TRAIN,
+            _call("mrla_bn_stats_fwd_rows", 0, _ptr(amom), _ptr(gamma32), _ptr(beta32), _ptr(rs.rm), _ptr(rs.rv), L.BN_TRAIN,
                    float(momentum), float(eps), _ptr(bnbuf[0]), _ptr(bnbuf[1]), _ptr(bnbuf[2]), _ptr(bnbuf[3]), frows, c, st)
         else:
-            L.call("mrla_bn_stats_fwd", _ptr(amom), _ptr(pivot), _ptr(gamma32), _ptr(beta32), _ptr(rs.rm), _ptr(rs.rv),
+            _call("mrla_bn_stats_fwd", 0, _ptr(amom), _ptr(pivot), _ptr(gamma32), _ptr(beta32), _ptr(rs.rm), _ptr(rs.rv),
                    L.BN_TRAIN if training else L.BN_EVAL, float(momentum), float(eps), _ptr(bnbuf[0]), _ptr(bnbuf[1]),
                    _ptr(bnbuf[2]), _ptr(bnbuf[3]), frows, c, b * h * w // frows, st)
         rs.finish(training)
@@ -975,7 +996,7 @@ class _BnActFn(torch.autograd.Function):
                   _ptr(bnbuf[2]), ctx.relu, _ptr(tmom), b, c, h, w, dt, layout, st)
         small = torch.empty((5, c), dtype=torch.float32, device=dev)          # cb[c,3] | dgamma | dbeta
         cb = small[:3].view(c, 3)
-        L.call("mrla_bn_stats_bwd", _ptr(tmom), _ptr(gamma32), _ptr(bnbuf[2]), _ptr(bnbuf[3]),
+        _call("mrla_bn_stats_bwd", 0, _ptr(tmom), _ptr(gamma32), _ptr(bnbuf[2]), _ptr(bnbuf[3]),
                L.BN_TRAIN if ctx.training else L.BN_EVAL, 1, _ptr(cb), _ptr(small[3]), _ptr(small[4]), rows, c,
                b * h * w // rows, st)
         dx = torch.empty_like(xc)
@@ -1028,7 +1049,7 @@ class _BnReluPoolFn(torch.autograd.Function):
             pivot = torch.empty((c,), dtype=torch.float32, device=dev)
             _call("mrla_bn_plane_moments", xc.numel() * xc.element_size(), _ptr(xc), _ptr(amom), _ptr(pivot), b, c, h, w, dt,
                   layout, st)
-        L.call("mrla_bn_stats_fwd", _ptr(amom), _ptr(pivot), _ptr(gamma32), _ptr(beta32), _ptr(rs.rm), _ptr(rs.rv),
+        _call("mrla_bn_stats_fwd", 0, _ptr(amom), _ptr(pivot), _ptr(gamma32), _ptr(beta32), _ptr(rs.rm), _ptr(rs.rv),
                L.BN_TRAIN if training else L.BN_EVAL, float(momentum), float(eps), _ptr(bnbuf[0]), _ptr(bnbuf[1]),
                _ptr(bnbuf[2]), _ptr(bnbuf[3]), rows, c, b * h * w // rows, st)
         rs.finish(training)
@@ -1057,7 +1078,7 @@ class _BnReluPoolFn(torch.autograd.Function):
               _ptr(bnbuf[2]), _ptr(tmom), b, c, h, w, dt, L.NHWC, st)
         small = torch.empty((5, c), dtype=torch.float32, device=dev)          # cb[c,3] | dgamma | dbeta
         cb = small[:3].view(c, 3)
-        L.call("mrla_bn_stats_bwd", _ptr(tmom), _ptr(gamma32), _ptr(bnbuf[2]), _ptr(bnbuf[3]),
+        _call("mrla_bn_stats_bwd", 0, _ptr(tmom), _ptr(gamma32), _ptr(bnbuf[2]), _ptr(bnbuf[3]),
                L.BN_TRAIN if ctx.training else L.BN_EVAL, 1, _ptr(cb), _ptr(small[3]), _ptr(small[4]), rows, c,
                b * h * w // rows, st)
         dx = None
@@ -1094,12 +1115,22 @@ class WeightBank:
     launch of mrla_weight_bank_refresh per training step: what torch.autocast does with one cast kernel per convolution
     and forward, and what the input-gradient GEMM needed one transposing copy per call for.  Built lazily for the
     eligible convolutions of a model (1x1, stride 1, no bias, fp32 weight, both channel counts multiples of 64);
-    `refresh()` re-launches only when a weight changed (version counters), always while a HIP graph is being captured."""
+    `refresh()` re-launches whenever gradients are enabled (a training forward: the optimizer will have moved the masters,
+    and one launch costs 0.02 ms), whenever a HIP graph is being captured, and ALWAYS once a refresh has been captured:
+    replays of that graph update the masters without touching any Python-side version counter, so after them the
+    counters prove nothing.  Only a grad-free forward outside any capture history (validation loops) skips the launch
+    while every weight's version counter stands still; writes the counters cannot see (`p.data.copy_(...)`) need
+    `invalidate()`."""
 
     def __init__(self, convs):
         self.convs = [c for c in convs if self.eligible(c)]
         self.key = self.sig = None
+        self.captured = False          # sticky: a refresh is part of some HIP graph
         self.entries = {}
+
+    def invalidate(self):
+        """Force the next refresh() to re-cast (after weight updates that bypass the version counters)."""
+        self.key = None
 
     @staticmethod
     def eligible(conv):
@@ -1129,11 +1160,16 @@ class WeightBank:
             self.entries = {}
             return self
         sig = tuple((id(c), c.weight.data_ptr()) for c in live)
+        capturing = torch.cuda.is_current_stream_capturing()
         if sig != self.sig:                       # first use, or the parameters moved (.to(), load with assign=...)
+            if capturing:                         # (the table is built with a host-to-device copy: not capturable)
+                raise L.MrlaHipError("WeightBank: first use (or moved parameters) inside a HIP graph capture; run one "
+                                     "forward of the model eagerly before capturing it")
             self._build(live)
             self.sig, self.key = sig, None
         key = tuple(c.weight._version for c in live)
-        if key != self.key or torch.cuda.is_current_stream_capturing():
+        self.captured = self.captured or capturing
+        if key != self.key or self.captured or torch.is_grad_enabled():
             with torch.cuda.device(self.table.device):
                 L.call("mrla_weight_bank_refresh", _ptr(self.table), self.n, self.max_tiles, _stream())
             self.key = key
@@ -1146,9 +1182,10 @@ class WeightBank:
 
 class _Conv1x1Fn(torch.autograd.Function):
     """y = conv2d(x, w) for a bias-free 1x1 stride-1 convolution of a channels_last bf16 tensor, plus the partial
-    (sum, sum^2) rows of y the following BatchNorm needs (mrla_conv1x1_fwd; shapes that kernel does not take run the
-    stock convolution and return no rows; neither does the K-streaming kernel of the wide reductions, k >= 512, whose
-    BatchNorm then takes its own statistics pass).  Backward: dX through the same GEMM on w^T where it applies, dW
+    moment-record rows of y the following BatchNorm needs (mrla_conv1x1_fwd: MRLA_GEMM_MOMENTS records, one row per
+    workgroup pixel range -- the resident-weight kernels and the K-streaming kernel of the wide reductions, k >= 512, both
+    write them; `mrla_bn_stats_fwd_rows` merges them).  Shapes the GEMMs do not take (mrla_conv1x1_rows < 0) run the stock
+    convolution and return no rows; the BatchNorm then takes its own statistics pass.  Backward: dX through the same GEMM on w^T where it applies, dW
     through the split-M GEMM mrla_conv1x1_wgrad; what neither takes stays on the stock convolution backward."""
 
     @staticmethod
@@ -1169,7 +1206,7 @@ class _Conv1x1Fn(torch.autograd.Function):
             if not w.is_contiguous():
                 w = w.contiguous()
         part = None
-        rows = L.load().mrla_conv1x1_rows(m, k, n, _DT[x.dtype])      # > 0: with the statistics epilogue (0 would mean: supported, without)
+        rows = L.load().mrla_conv1x1_rows(m, k, n, _DT[x.dtype])      # > 0: supported, that many moment-record rows; < 0: not taken
         if rows >= 0:
             y = torch.empty((b, n, h, wd), dtype=x.dtype, device=dev, memory_format=_CL)
             if want_moments and rows > 0:

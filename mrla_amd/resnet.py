@@ -6,7 +6,6 @@ Reference counterparts: resnet/models/resnet_mrla_light.py:47-250, resnet/models
 SE / ECA options (off in every BASELINE config) keep their constructor arguments and
 state_dict keys and run as plain eager PyTorch modules on bn3's output (outside the accelerated path).
 """
-import os
 
 import torch
 import torch.nn as nn
@@ -208,7 +207,7 @@ class _ResNetMRLA(nn.Module):
                     if isinstance(m.downsample, nn.Sequential) and len(m.downsample) == 2:
                         convs.append(m.downsample[0])
             bank = self.__dict__["_bank"] = F_.WeightBank(convs)
-        if not torch.is_autocast_enabled("cuda") or os.environ.get("MRLA_NO_WEIGHT_BANK"):
+        if not torch.is_autocast_enabled("cuda"):
             return None                            # fp32 runs multiply with the master weights themselves
         return bank.refresh()
 

@@ -1,6 +1,6 @@
 """GPU micro-benchmark: the 1x1 convolutions with a wide reduction (K >= 512; b=256, bf16, channels_last) -- forward and
 input gradient: MIOpen (F.conv2d / convolution_backward) vs the K-streaming GEMM (mrla_conv1x1_fwd).
-Usage: [NOSTOCK=1] [MRLA_KS256=0] python scripts/ksbench.py [reps]"""
+Usage: [NOSTOCK=1] python scripts/ksbench.py [reps]"""
 import ctypes
 import os
 import sys

@@ -127,6 +127,7 @@ def test_bench_py_under_torch_distributed_run_two_ranks_one_gpu(dp):
     assert rec["metric"].startswith("images/sec fwd+bwd resnet50_mrlal") and rec["value"] > 0
     assert rec["config"]["launch"].startswith("kernel by kernel")             # gloo: nothing to capture
     assert ("DistributedDataParallel" if dp == "ddp" else "all-reduce(s) (RCCL avg) over one flat") in rec["config"]["gradient_exchange"]
+    assert rec["config"]["ranks_seen"] == 2 and rec["config"]["backend"] == "gloo"
     assert rec["roofline"] is not None and rec["roofline"]["bound"] == "hbm" and rec["roofline"]["achieved"] > 0
     assert rec["roofline"]["kernel"].startswith("mrla_light_apply_bwd")
     assert "cpu_baseline" not in rec and "forward_only" not in rec            # N = 1 legs only
@@ -134,10 +135,37 @@ def test_bench_py_under_torch_distributed_run_two_ranks_one_gpu(dp):
     assert abs(rec["value"] - 16 * 1e3 / rec["ms_per_step"]) / rec["value"] < 1e-2
 
 
+def test_bench_py_plain_launch_starts_its_own_ranks():
+    """`python bench.py --gpus 2` with NO torch.distributed environment (resnet/train.py:127-133 spawns its own workers, :153
+    init_process_group): bench.py must start the two ranks itself -- before touching the GPU, as a child process -- and the
+    line must prove them: n_gpus 2, ranks_seen 2 (an all-reduce of ones over the backend), global batch 16.  gloo, because
+    RCCL refuses two ranks on the one GPU of this box; both exchange schedules are timed (eagerly: gloo is not capturable)."""
+    import json
+    root = os.path.dirname(HERE)
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env.update(HSA_ENABLE_IPC_MODE_LEGACY="0", MRLA_DIST_BACKEND="gloo", PYTHONPATH=root)
+    cmd = [sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--batch", "8",
+           "--no-baselines"]
+    p = subprocess.run(cmd, env=env, cwd=root, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=1500)
+    out, err = p.stdout.decode(errors="replace"), p.stderr.decode(errors="replace")
+    assert p.returncode == 0, (out + err)[-4000:]
+    lines = [ln for ln in out.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, out[-2000:]
+    rec = json.loads(lines[0])
+    assert rec["n_gpus"] == 2 and rec["config"]["ranks_seen"] == 2 and rec["config"]["global_batch"] == 16
+    assert rec["config"]["backend"] == "gloo" and rec["config"]["parallelism"] == "dp2"
+    ab = rec["config"]["gradient_exchange_ab_ms"]
+    assert set(ab) == {"after_backward", "bucketed_overlap"} and all(v > 0 for v in ab.values())
+    assert rec["config"]["gradient_exchange_schedule"] == min(ab, key=ab.get)
+    assert abs(rec["value"] - 16 * 1e3 / rec["ms_per_step"]) / rec["value"] < 1e-2
+
+
 def test_bench_py_graph_captures_the_rccl_exchange_one_rank():
     """What the driver's N > 1 runs do by default -- the whole step INCLUDING the gradient all-reduce replayed from one HIP
     graph -- on the one GPU there is: `bench.py --ddp-probe` builds a one-rank RCCL process group, so that the flat
-    all-reduce is a real RCCL launch that has to survive stream capture and replay."""
+    all-reduce is a real RCCL launch that has to survive stream capture and replay.  BOTH schedules (one all-reduce after
+    backward; buckets sent from backward's hooks) are captured, replayed and timed in the one invocation, and the line
+    carries both (with one rank there is nothing to hide, so this measures their overhead side only)."""
     import json
     root = os.path.dirname(HERE)
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", PYTHONPATH=root)
@@ -150,6 +178,10 @@ def test_bench_py_graph_captures_the_rccl_exchange_one_rank():
     rec = json.loads([ln for ln in out.splitlines() if ln.startswith("{")][0])
     assert rec["config"]["launch"].startswith("one HIP graph per step (captured fwd+loss+bwd+gradient all-reduce"), err[-2000:]
     assert "over one flat" in rec["config"]["gradient_exchange"]
+    assert rec["config"]["ranks_seen"] == 1 and rec["config"]["backend"] == "nccl (RCCL)"
+    ab = rec["config"]["gradient_exchange_ab_ms"]
+    assert set(ab) == {"after_backward", "bucketed_overlap"} and all(v > 0 for v in ab.values())
+    assert rec["config"]["gradient_exchange_schedule"] == min(ab, key=ab.get)
     assert rec["value"] > 0 and rec["eager_launch_ms_per_step"] > 0
 
 

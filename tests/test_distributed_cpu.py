@@ -119,3 +119,27 @@ def test_flat_gradient_exchange_gloo_world2(bucket_mb, overlap):
             assert torch.equal(a["steps"][s]["avg"][i], b["steps"][s]["avg"][i])
     for x, y in zip(a["w"], b["w"]):
         assert torch.equal(x, y)
+
+
+def test_flat_exchange_refuses_a_second_backward_before_reduce():
+    """overlap=True sends a bucket when its last gradient of ONE backward has arrived; a second backward before reduce()
+    (gradient accumulation) would be dropped silently -- the hook raises instead; overlap=False accumulates fine (it gathers
+    inside reduce()).  Single process, no process group: the exchange degenerates to the gather."""
+    from mrla_amd import distributed as D
+    torch.manual_seed(0)
+    net = nn.Sequential(nn.Linear(6, 5), nn.ReLU(), nn.Linear(5, 3))
+    x = torch.randn(4, 6)
+    ex = D.FlatGradientExchange(net.parameters(), overlap=True)
+    net(x).sum().backward()
+    with pytest.raises(RuntimeError, match="second backward"):
+        net(x).sum().backward()
+    ex.remove_hooks()
+    for p in net.parameters():
+        p.grad = None
+    ex2 = D.FlatGradientExchange(net.parameters(), overlap=False)
+    net(x).sum().backward()
+    net(x).sum().backward()                                # accumulates into .grad; gathered by reduce()
+    want = [p.grad.clone() for p in net.parameters()]
+    ex2.reduce()
+    for p, w in zip(net.parameters(), want):
+        assert torch.equal(p.grad, w)

@@ -202,3 +202,26 @@ def test_parameter_gradient_layout_helper_handles_every_dense_stride_pattern():
     wt = torch.empty(k, n).t()                                          # [n, k] stored column-major: dense, not row-major
     out = _grad_like(g, wt.shape, wt.stride())
     assert out.stride() == wt.stride() and torch.equal(out, g.view(n, k))
+
+
+def test_bench_py_starts_its_own_ranks_before_touching_the_gpu():
+    """`python bench.py --gpus 2` with no torch.distributed environment (resnet/train.py:127-133 spawns its own workers):
+    the parent must start `python -m torch.distributed.run ... bench.py <same arguments>` as a child and hand its exit
+    code on.  Here there is no GPU, so the two ranks fail at their first device call -- which shows that the launch
+    happened, that the parent did not need a GPU to get there, and that it neither prints a line of its own nor reports
+    success for failed ranks."""
+    import subprocess
+    import sys
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("the CPU form of this test expects the ranks to fail for lack of a GPU")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env["MRLA_DIST_BACKEND"] = "gloo"
+    p = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0",
+                        "--batch", "2", "--no-baselines", "--graph", "0"], env=env, cwd=root, stdout=subprocess.PIPE,
+                       stderr=subprocess.PIPE, timeout=600)
+    err = p.stderr.decode(errors="replace")
+    assert "torch.distributed.run --nnodes=1 --nproc-per-node=2" in err, err[-2000:]
+    assert p.returncode != 0
+    assert not [ln for ln in p.stdout.decode(errors="replace").splitlines() if ln.startswith("{")]

@@ -59,9 +59,11 @@ enum { MRLA_BN_NONE = 0, MRLA_BN_TRAIN = 1, MRLA_BN_EVAL = 2 };
  *           mrla_weight_bank_refresh were added;  the token backward became one pass: mrla_token_stats_bwd was removed,
  *           mrla_token_apply_bwd writes bmom and no longer takes dyx, MRLA_TOKEN_PARTIALS grew from 14 to 15,
  *           mrla_token_gate_bwd was added and mrla_token_ln_bwd gained dyx;  the mrla_token_base_* entry points were added.
+ *   2 -> 3: mrla_base_value_bwd_dv gained pre / pre_center / pre_tmom (bn3's backward sums folded into the MRLA-base value
+ *           backward, as mrla_light_apply_bwd has them); mrla_base_value_bwd_pre_sums was added.
  * A consumer compares mrla_abi_version() (what the loaded library was built from) against this constant before its
  * first call. */
-#define MRLA_ABI_VERSION 2
+#define MRLA_ABI_VERSION 3
 int mrla_abi_version(void);
 
 /* Number of rows of the `dwv_part` scratch that mrla_light_apply_bwd writes for this problem
@@ -270,9 +272,18 @@ int mrla_base_dv_combine(const void* da_ring, const float* p_all, void* dv, int 
                          int t, int Tc, int dtype, int layout, void* stream);
 
 /* dx = [x > 0 if res bit 1] * ((res bit 0) * dOut + dwconv3x3^T(dv) + dyx);  dwv_part[rows, c, 9]
- * (rows = mrla_light_wgrad_rows()). */
+ * (rows = mrla_light_wgrad_rows()).
+ * pre, pre_tmom [opt, both or neither; res bit 1 only]: the caller deferred the BatchNorm in front of the fused producer
+ * (bn3 of resnet_mrla_base.py:103-104; x_t = relu(bn3(conv3) + identity), :120-122) -- `pre` is conv3's raw output and dx
+ * is dpre, the gradient of that BatchNorm's output, which exists only here; the pass takes the BatchNorm backward's two
+ * sums on the way: pre_tmom[rows, c, 2] = (sum dpre, sum dpre * (pre - pre_center[c])) of the STORED (rounded) dpre, in
+ * the layout mrla_bn_stats_bwd reads (pre_center [opt]: the saved batch mean -> centered = 1 there), so
+ * mrla_bn_plane_dmoments' separate 2N pass is not needed.  mrla_base_value_bwd_pre_sums says whether a shape has this
+ * form (1) or not (MRLA_EUNSUPPORTED: c % 64 != 0, NCHW). */
+int mrla_base_value_bwd_pre_sums(int b, int c, int h, int w, int dtype, int layout);
 int mrla_base_value_bwd_dv(const void* dout, const void* x, const float* wv, const void* dv, const float* dyx, void* dx,
-                           float* dwv_part, int b, int c, int h, int w, int res, int dtype, int layout, void* stream);
+                           float* dwv_part, const void* pre, const float* pre_center, float* pre_tmom, int b, int c, int h,
+                           int w, int res, int dtype, int layout, void* stream);
 
 /* =====================================================================================================
  * MRLA-light on token sequences (DeiT): x[b, n, c], n = 1 + side*side, channels contiguous.
@@ -403,8 +414,8 @@ int mrla_bn_relu_pool_bwd(const void* dp, const void* x, const float* sc, const 
  * mom_part may be NULL (no statistics wanted: the input-gradient use, inference).
  * MRLA_EUNSUPPORTED for other shapes and for dtypes other than MRLA_BF16: the caller keeps its stock convolution there.
  * (The input gradient dX = dY * W is the same entry point with w^T.) */
-int mrla_conv1x1_rows(int m, int k, int n, int dtype);      /* rows of mom_part (> 0), or a negative code (a caller should
-                                                               treat 0 as "supported, no statistics epilogue") */
+int mrla_conv1x1_rows(int m, int k, int n, int dtype);      /* rows of mom_part (> 0: every supported shape writes
+                                                               records), or a negative code (unsupported shape) */
 /* How the launch of this problem is laid out (host-side query, `out` is a HOST array of 4 ints): out[0] = 32-pixel blocks
  * one workgroup (n % 256 == 0) / one pixel-wave (narrow outputs) walks, out[1] = depth in blocks of its LDS ring / register
  * prefetch, out[2] = workgroups, out[3] = mrla_conv1x1_rows().  addend != 0: the mrla_conv1x1_fwd_add form.  Lets a

@@ -9,7 +9,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libmrla_hip.so")
 
-ABI_VERSION = 2          # MRLA_ABI_VERSION of include/mrla_hip.h
+ABI_VERSION = 3          # MRLA_ABI_VERSION of include/mrla_hip.h
 OK, EINVAL, EUNSUPPORTED, EHIP = 0, -1, -2, -3
 F32, BF16, F16 = 0, 1, 2
 NCHW, NHWC = 0, 1
@@ -44,7 +44,8 @@ SIGNATURES = {
     "mrla_base_pool_value_fwd": [_P] * 8 + [_I] * 6 + [_P],
     "mrla_base_pmom_reduce": [_P, _P, _I, _I, _I, _I, _P],
     "mrla_base_dv_combine": [_P, _P, _P] + [_I] * 10 + [_P],
-    "mrla_base_value_bwd_dv": [_P] * 7 + [_I] * 7 + [_P],
+    "mrla_base_value_bwd_pre_sums": [_I] * 6,
+    "mrla_base_value_bwd_dv": [_P] * 10 + [_I] * 7 + [_P],
     "mrla_base_gate_fwd": [_P, _P, _P, _I, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P],
     "mrla_base_attend_fwd": [_P, _P, _P, _P, _P, _P] + [_I] * 9 + [_P],
     "mrla_bn_stats_fwd": [_P, _P, _P, _P, _P, _P, _I, _F, _F, _P, _P, _P, _P, _I, _I, _I, _P],

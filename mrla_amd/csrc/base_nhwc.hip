@@ -331,12 +331,18 @@ __global__ __launch_bounds__(kThreads) void base_pmom_reduce_kernel(const float*
 // Row-marching stencil kernel, lane = channel, as light_nhwc.hip; dV arrives in the storage type from base_combine<1>.
 //   dx[r][col]  = sum_{i,k} w[i][k] * dV[r-i+1][col-k+1]
 //   dWv[i][k]  += x[r][col] * dV[r-i+1][col-k+1]      (the same window, centred on x)
+// PRE (WIDE, with the res&2 mask): the caller deferred the BatchNorm in front of the fused producer (bn3,
+// resnet_mrla_base.py:103-104,120-122) and its backward needs sum(dpre) and sum(dpre * (y3 - mean)) per channel, y3 =
+// conv3's raw output `pre`.  dpre = dx is formed here and nowhere else, so the two sums are taken here (one more owned-
+// columns row fetch per step, two accumulators; of dpre AS STORED, i.e. rounded to T): mrla_bn_plane_dmoments' 2N pass over
+// (dpre, y3) disappears -- the MRLA-light tail does the same in mrla_light_apply_bwd.
 // ------------------------------------------------------------------------------------------------
-template <typename T, bool WIDE>
+template <typename T, bool WIDE, bool PRE = false>
 __global__ __launch_bounds__(kMaxStrips * kWave) void base_value_bwd_nhwc(
     const T* __restrict__ dout, const T* __restrict__ x, const float* __restrict__ wv, const T* __restrict__ dv,
-    const float* __restrict__ dyx, T* __restrict__ dx, float* __restrict__ dwv_part, int B, int C, int H, int W, int BG,
-    int res) {
+    const float* __restrict__ dyx, T* __restrict__ dx, float* __restrict__ dwv_part, const T* __restrict__ pre,
+    const float* __restrict__ pre_center, float* __restrict__ pre_tmom, int B, int C, int H, int W, int BG, int res) {
+  static_assert(!PRE || WIDE, "the deferred-BatchNorm sums exist on the whole-wave (C % 64 == 0) form only");
   extern __shared__ __align__(16) unsigned char smem_raw[];
   const int lane = threadIdx.x & (kWave - 1), wave = threadIdx.x / kWave, nwaves = blockDim.x / kWave;
   float* red = reinterpret_cast<float*>(smem_raw);
@@ -353,6 +359,8 @@ __global__ __launch_bounds__(kMaxStrips * kWave) void base_value_bwd_nhwc(
 #pragma unroll
   for (int k = 0; k < 9; ++k) w[k] = wv[cc * 9 + k];
   float wg[9] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  float pm[2] = {0.f, 0.f};                          // (PRE) sum dpre, sum dpre * (y3 - center) over this workgroup's images
+  const float pcen = (PRE && pre_center) ? pre_center[cc] : 0.f;
   const float resf = (res & 1) ? 1.f : 0.f;
   const bool mask = (res & 2) != 0;
   const int b_end = min(B, (int)(blockIdx.y + 1) * BG);
@@ -361,6 +369,7 @@ __global__ __launch_bounds__(kMaxStrips * kWave) void base_value_bwd_nhwc(
     const T* xi = x + ioff;
     const T* gi = dout + ioff;
     const T* ui = dv + ioff;
+    const T* pri = PRE ? pre + ioff : nullptr;
     T* dxo = dx + ioff;
     const float dy = dyx[(size_t)b * C + cc];
     for (int s = wave; s < nstrips; s += nwaves) {
@@ -370,7 +379,7 @@ __global__ __launch_bounds__(kMaxStrips * kWave) void base_value_bwd_nhwc(
       for (int j = 0; j < kS + 2; ++j) ua[j] = 0.f;
       read_row<T, WIDE, kS + 2>(ui, 0, s0 - 1, H, W, C, cbase, cc, lane, scrF, ub);
       RowLoad<T, kS + 2> qu;
-      RowLoad<T, kS> qx, qg;
+      RowLoad<T, kS> qx, qg, qp;
       RowAddr<T, kS + 2> au;
       RowAddr<T, kS> ax;
       if (WIDE) {
@@ -379,16 +388,19 @@ __global__ __launch_bounds__(kMaxStrips * kWave) void base_value_bwd_nhwc(
         issue_row<T, kS + 2>(qu, ui, 1, H, W * C, au);
         issue_row<T, kS>(qx, xi, 0, H, W * C, ax);
         issue_row<T, kS>(qg, gi, 0, H, W * C, ax);
+        if (PRE) issue_row<T, kS>(qp, pri, 0, H, W * C, ax);
       }
       for (int r = 0; r < H; ++r) {
-        float xr[kS], gr[kS];
+        float xr[kS], gr[kS], pr[kS];
         if (WIDE) {
           finish_row<T, kS + 2>(qu, lane, scrF, uc);
           finish_row<T, kS>(qx, lane, scrT, xr);
           finish_row<T, kS>(qg, lane, scrT, gr);
+          if (PRE) finish_row<T, kS>(qp, lane, scrT, pr);
           issue_row<T, kS + 2>(qu, ui, r + 2, H, W * C, au);
           issue_row<T, kS>(qx, xi, r + 1, H, W * C, ax);
           issue_row<T, kS>(qg, gi, r + 1, H, W * C, ax);
+          if (PRE) issue_row<T, kS>(qp, pri, r + 1, H, W * C, ax);
         } else {
           read_row<T, false, kS + 2>(ui, r + 1, s0 - 1, H, W, C, cbase, cc, lane, scrF, uc);
           read_row<T, false, kS>(xi, r, s0, H, W, C, cbase, cc, lane, scrT, xr);
@@ -405,6 +417,11 @@ __global__ __launch_bounds__(kMaxStrips * kWave) void base_value_bwd_nhwc(
           float y = fmaf(resf, gr[j], s9 + dy);
           if (mask) y = (xr[j] > 0.f) ? y : 0.f;
           yrow[j] = y;
+          if (PRE && j < nc) {       // of dpre AS STORED (rounded to T): the BatchNorm backward must see the stored values
+            const float yq = to_f(from_f<T>(y));
+            pm[0] += yq;
+            pm[1] = fmaf(yq, pr[j] - pcen, pm[1]);
+          }
           if (j < nc) {
             const float xv = xr[j];
             wg[0] = fmaf(xv, uc[j + 2], wg[0]); wg[1] = fmaf(xv, uc[j + 1], wg[1]); wg[2] = fmaf(xv, uc[j], wg[2]);
@@ -422,6 +439,13 @@ __global__ __launch_bounds__(kMaxStrips * kWave) void base_value_bwd_nhwc(
   if (wave == 0 && cv) {
 #pragma unroll
     for (int k = 0; k < 9; ++k) dwv_part[((size_t)blockIdx.y * C + c) * 9 + k] = wg[k];
+  }
+  if (PRE) {
+    wg_reduce<2>(pm, red, lane, wave, nwaves);
+    if (wave == 0 && cv) {
+      pre_tmom[((size_t)blockIdx.y * C + c) * 2 + 0] = pm[0];
+      pre_tmom[((size_t)blockIdx.y * C + c) * 2 + 1] = pm[1];
+    }
   }
 }
 
@@ -524,22 +548,23 @@ int launch_base_pmom_reduce(const float* part, float* pmom, int B, int C, int t,
 }
 
 int launch_base_value_bwd_nhwc(const void* dout, const void* x, const float* wv, const void* dv, const float* dyx,
-                               void* dx, float* dwv_part, int B, int C, int H, int W, int res, int dtype,
-                               hipStream_t st) {
+                               void* dx, float* dwv_part, const void* pre, const float* pre_center, float* pre_tmom, int B,
+                               int C, int H, int W, int res, int dtype, hipStream_t st) {
   const int nstrips = (W + kS - 1) / kS;
   const int nwaves = std::min(nstrips, kMaxStrips);
   const int BG = nhwc_images_per_group(B, C, W);
   const dim3 grid((C + kWave - 1) / kWave, (B + BG - 1) / BG), block(nwaves * kWave);
   const bool wide = (C % kWave) == 0;
+  if (pre_tmom && (!pre || !wide || !(res & 2))) return MRLA_EUNSUPPORTED;
   const size_t tb = dtype == MRLA_F32 ? scratch_bytes<float>() : scratch_bytes<bf16_t>();
   const size_t lds = (size_t)nwaves * 9 * kWave * sizeof(float) + (size_t)nwaves * 3 * tb;
-#define CALL_W(TT, WD)                                                                                              \
+#define CALL_W(TT, WD, PR)                                                                                          \
   {                                                                                                                 \
-    if (set_lds_n(base_value_bwd_nhwc<TT, WD>, lds) != hipSuccess) return MRLA_EHIP;                                  \
-    hipLaunchKernelGGL((base_value_bwd_nhwc<TT, WD>), grid, block, lds, st, (const TT*)dout, (const TT*)x, wv, (const TT*)dv, \
-                       dyx, (TT*)dx, dwv_part, B, C, H, W, BG, res);                                                     \
+    if (set_lds_n(base_value_bwd_nhwc<TT, WD, PR>, lds) != hipSuccess) return MRLA_EHIP;                              \
+    hipLaunchKernelGGL((base_value_bwd_nhwc<TT, WD, PR>), grid, block, lds, st, (const TT*)dout, (const TT*)x, wv,     \
+                       (const TT*)dv, dyx, (TT*)dx, dwv_part, (const TT*)pre, pre_center, pre_tmom, B, C, H, W, BG, res); \
   }
-#define CALL(TT) { if (wide) CALL_W(TT, true) else CALL_W(TT, false) }
+#define CALL(TT) { if (pre_tmom) CALL_W(TT, true, true) else if (wide) CALL_W(TT, true, false) else CALL_W(TT, false, false) }
   MRLA_DISPATCH_B(dtype, CALL)
 #undef CALL
 #undef CALL_W

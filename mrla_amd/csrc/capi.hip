@@ -411,12 +411,21 @@ int mrla_base_dv_combine(const void* da_ring, const float* p_all, void* dv, int 
   return launch_base_dv_combine_nhwc(da_ring, p_all, dv, b, c, h * w, d, T, t, Tc, dtype, (hipStream_t)stream);
 }
 
+int mrla_base_value_bwd_pre_sums(int b, int c, int h, int w, int dtype, int layout) {
+  if (bad_dims(b, c, h, w) || bad_dtype(dtype)) return MRLA_EINVAL;
+  if (layout != MRLA_NHWC && layout != MRLA_NCHW) return MRLA_EINVAL;
+  return (layout == MRLA_NHWC && c % kWave == 0) ? 1 : MRLA_EUNSUPPORTED;
+}
+
 int mrla_base_value_bwd_dv(const void* dout, const void* x, const float* wv, const void* dv, const float* dyx, void* dx,
-                           float* dwv_part, int b, int c, int h, int w, int res, int dtype, int layout, void* stream) {
+                           float* dwv_part, const void* pre, const float* pre_center, float* pre_tmom, int b, int c, int h,
+                           int w, int res, int dtype, int layout, void* stream) {
   if (!dout || !x || !wv || !dv || !dyx || !dx || !dwv_part || bad_dims(b, c, h, w) || bad_dtype(dtype))
     return MRLA_EINVAL;
+  if ((pre == nullptr) != (pre_tmom == nullptr) || (pre_tmom && !(res & 2))) return MRLA_EINVAL;
   if (layout != MRLA_NHWC) return MRLA_EUNSUPPORTED;
-  return launch_base_value_bwd_nhwc(dout, x, wv, dv, dyx, dx, dwv_part, b, c, h, w, res, dtype, (hipStream_t)stream);
+  return launch_base_value_bwd_nhwc(dout, x, wv, dv, dyx, dx, dwv_part, pre, pre_center, pre_tmom, b, c, h, w, res, dtype,
+                                    (hipStream_t)stream);
 }
 
 static int token_side(int n) {

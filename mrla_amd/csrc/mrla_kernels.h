@@ -124,8 +124,8 @@ int launch_base_attend_bwd_nhwc(const void* dout, const void* attn, const float*
                                 int T, int t, int dtype, hipStream_t st, int ext_gap = 0, int ext_off = 0);
 int launch_base_pmom_reduce(const float* part, float* pmom, int B, int C, int t, int tiles, hipStream_t st);
 int launch_base_value_bwd_nhwc(const void* dout, const void* x, const float* wv, const void* dv, const float* dyx,
-                               void* dx, float* dwv_part, int B, int C, int H, int W, int res, int dtype,
-                               hipStream_t st);
+                               void* dx, float* dwv_part, const void* pre, const float* pre_center, float* pre_tmom, int B,
+                               int C, int H, int W, int res, int dtype, hipStream_t st);
 
 
 // tokens.hip -- MRLA-light on token sequences (DeiT)
@@ -177,7 +177,7 @@ int conv1x1_wide_rows(int M, int K, int N);
 int conv1x1_wide_plan(int M, int K, int N, int add, int* out);
 int launch_conv1x1_wide(const void* x, const void* w, const void* addend, void* y, float* part, int M, int K, int N,
                         hipStream_t st);
-// conv1x1_kstream.hip -- the same product for wide reductions (K >= 512): both operands streamed through LDS, no epilogue
+// conv1x1_kstream.hip -- the same product for wide reductions (K >= 512): both operands streamed through LDS; the tile copy-out takes the BatchNorm moment records as well
 int conv1x1_kstream_supported(int M, int K, int N);
 int conv1x1_kstream_stages(int M, int K, int N);      // LDS stages of the kernel the planner picks (3, or 4: the 256 x 256 tile)
 int conv1x1_kstream_rows(int M, int K, int N);        // rows of the moment records (one per pixel tile)

@@ -566,11 +566,12 @@ class BaseStage:
 
 
 class BaseConfig:
-    __slots__ = ("d", "bn_mode", "momentum", "eps", "tail", "fuse", "pre_affine")
+    __slots__ = ("d", "bn_mode", "momentum", "eps", "tail", "fuse", "pre_affine", "pre_box")
 
-    def __init__(self, d, bn_mode=L.BN_NONE, momentum=0.1, eps=1e-5, tail=False, fuse=False, pre_affine=None):
+    def __init__(self, d, bn_mode=L.BN_NONE, momentum=0.1, eps=1e-5, tail=False, fuse=False, pre_affine=None, pre_box=None):
         self.d, self.bn_mode, self.momentum, self.eps, self.tail, self.fuse = d, bn_mode, momentum, eps, tail, fuse
         self.pre_affine = pre_affine     # deferred bn3 affine (NHWC stages only), see bn_act(defer=True)
+        self.pre_box = pre_box           # its _DeferredBnBox: where the value backward leaves that BatchNorm's gradient sums
 
 
 class _BaseFn(torch.autograd.Function):
@@ -643,7 +644,11 @@ class _BaseFn(torch.autograd.Function):
         ctx.shapes = (wq.shape, wk.shape, wv.shape)
         ctx.wv_stride = wv.stride()
         ctx.pdtypes = (wq.dtype, wk.dtype, wv.dtype, gamma.dtype if gamma is not None else None)
-        ctx.save_for_backward(xc, attn if cfg.tail else None, wq32, wk32, wv32, gamma32, dp32, mom, q, bnbuf)
+        # conv3's raw output, when the BatchNorm behind it was deferred and its backward sums can ride in the value backward
+        keep_pre = (nhwc and cfg.fuse and cfg.pre_box is not None
+                    and L.load().mrla_base_value_bwd_pre_sums(b, c, h, w, dt, layout) == 1)
+        ctx.save_for_backward(xc, attn if cfg.tail else None, wq32, wk32, wv32, gamma32, dp32, mom, q, bnbuf,
+                              pre if keep_pre else None)
         if nhwc and x.is_contiguous() and not x.is_contiguous(memory_format=_CL):
             return out.contiguous()          # an NCHW caller of an NHWC stage gets NCHW-contiguous memory back
         return out
@@ -651,7 +656,7 @@ class _BaseFn(torch.autograd.Function):
     @staticmethod
     @_on_device
     def backward(ctx, dout):
-        xc, attn, wq32, wk32, wv32, gamma32, dp32, mom, q, bnbuf = ctx.saved_tensors
+        xc, attn, wq32, wk32, wv32, gamma32, dp32, mom, q, bnbuf, pre = ctx.saved_tensors
         cfg, layout, ks, stage, t = ctx.cfg, ctx.layout, ctx.ks, ctx.stage, ctx.t
         b, c, h, w = xc.shape
         d, T = cfg.d, stage.T
@@ -698,8 +703,18 @@ class _BaseFn(torch.autograd.Function):
             dv = torch.empty((b, h, w, c), dtype=xc.dtype, device=dev)
             _call("mrla_base_dv_combine", xc.numel() * es * (Tc - t + 2), _ptr(stage.dA), _ptr(stage.P), _ptr(dv),
                   b, c, h, w, d, T, t, Tc, dt, layout, st, path=xc.numel() * es * (Tc - t + 1))
-            _call("mrla_base_value_bwd_dv", xc.numel() * es * 4, _ptr(dout), _ptr(xc), _ptr(wv32), _ptr(dv),
-                  _ptr(dyx), _ptr(dx), _ptr(dwv_part), b, c, h, w, res, dt, layout, st, path=xc.numel() * es)
+            # the deferred bn3's backward sums (sum dpre, sum dpre*(y3 - mean)) ride in this pass: one more row fetch, no 2N pass
+            pre_tmom = None
+            if pre is not None and (b * h * w) % rows == 0:
+                pre_tmom = torch.empty((rows, c, 2), dtype=torch.float32, device=dev)
+            else:
+                pre = None
+            _call("mrla_base_value_bwd_dv", xc.numel() * es * (4 + (pre is not None)), _ptr(dout), _ptr(xc), _ptr(wv32),
+                  _ptr(dv), _ptr(dyx), _ptr(dx), _ptr(dwv_part), _ptr(pre),
+                  _ptr(cfg.pre_box.center) if pre is not None else None, _ptr(pre_tmom), b, c, h, w, res, dt, layout, st,
+                  alg=xc.numel() * es * 4, path=xc.numel() * es)
+            if pre_tmom is not None:
+                cfg.pre_box.put(dx, pre_tmom, rows)
         else:
             _call("mrla_base_value_bwd", xc.numel() * es * (Tc - t + 4), _ptr(dout), _ptr(xc), _ptr(wv32),
                   _ptr(stage.dA), _ptr(stage.P), _ptr(dyx), _ptr(dx), _ptr(dwv_part), b, c, h, w, d, T, t, Tc, res, dt,
@@ -717,14 +732,14 @@ def mrla_base(x, wq, wk, wv, d, stage, bn=None, dp=None, identity=None):
     mrla_light(); with bn the block tail x + dp*relu(BN(attn)) is fused in.  identity: when given, `x` is the
     bottleneck's pre-activation and x_t = relu(x + identity) is formed inside the pooling pass."""
     fuse = identity is not None
-    pre_affine = getattr(x, "_mrla_affine", None)
+    pre_affine, pre_box = getattr(x, "_mrla_affine", None), getattr(x, "_mrla_bn_box", None)
     if pre_affine is not None and not (fuse and stage.layout == L.NHWC):
         raise L.MrlaHipError("a deferred BatchNorm output can only feed the fused producer of an NHWC MRLA-base stage")
     if bn is None:
         return _BaseFn.apply(x, identity, wq, wk, wv, None, None, None, None, None, stage,
-                             BaseConfig(d, fuse=fuse, pre_affine=pre_affine))
+                             BaseConfig(d, fuse=fuse, pre_affine=pre_affine, pre_box=pre_box))
     cfg = BaseConfig(d, L.BN_TRAIN if bn["training"] else L.BN_EVAL, bn.get("momentum", 0.1), bn.get("eps", 1e-5), True,
-                     fuse, pre_affine)
+                     fuse, pre_affine, pre_box)
     return _BaseFn.apply(x, identity, wq, wk, wv, bn["weight"], bn["bias"], bn["running_mean"], bn["running_var"], dp,
                          stage, cfg)
 

@@ -6,9 +6,13 @@ import torch
 
 from oracle import detgen, mrla_numpy as mn
 from tests import cases
-from tests.test_light_gpu import ACT_TOL, PAR_TOL, assert_bf16_close, bf16_round, relmax, to_dev
+from tests.test_light_gpu import ACT_TOL, GOLD_TOL, assert_bf16_close, bf16_round, par_tol, relmax, to_dev
 
 pytestmark = pytest.mark.gpu
+
+# whole models in fp32 (50+ layers: the per-op 1e-7 roundings add up).  vs the eager restatement on the same GPU (the very
+# same MIOpen convolutions on both sides) and vs the reference's CPU logits (other convolution arithmetic on their side)
+MODEL_TOL, MODEL_REF_TOL = 5e-6, 1e-5
 
 
 def run_chain(xs, gups, params, d, training, dtype=torch.float32, hint=None, dp=None, cl=False):
@@ -98,17 +102,17 @@ def test_base_chain_fp32_vs_oracle_and_reference(case, mode, cl):
     got, K, V = run_chain(xs, gups, params, d, mode == "train", hint=2 if name == "chain5" else None, cl=cl)   # chain5: ring growth
     outs, caches, grads, Ko, Vo = oracle_chain(xs, gups, params, d, mode == "train")
     assert relmax(K, Ko) < ACT_TOL and relmax(V, Vo) < ACT_TOL
-    assert relmax(K, G[f"{name}/{mode}/K"]) < 2e-5 and relmax(V, G[f"{name}/{mode}/V"]) < 2e-5
+    assert relmax(K, G[f"{name}/{mode}/K"]) < GOLD_TOL and relmax(V, G[f"{name}/{mode}/V"]) < GOLD_TOL
     for t in range(Tn):
         key = f"{name}/{mode}/{t}/"
         assert relmax(got[t]["out"], outs[t]) < ACT_TOL, t
-        assert relmax(got[t]["dx"], grads[t]["dx"]) < 2 * ACT_TOL, t
+        assert relmax(got[t]["dx"], grads[t]["dx"]) < ACT_TOL, t
         assert relmax(got[t]["rv"], caches[t]["bn"]["new_rv"]) < ACT_TOL, t
         for ours, theirs in PAIRS:
-            assert relmax(got[t]["grad/" + ours].ravel(), np.asarray(grads[t][theirs]).ravel()) < PAR_TOL, (t, ours)
-        assert relmax(got[t]["out"], G[key + "out"]) < 2e-5
-        assert relmax(got[t]["dx"], G[key + "dx"]) < 5e-5
-        assert relmax(got[t]["grad/mrla.mrla.Wv.weight"], G[key + "grad/mrla.mrla.Wv.weight"]) < 2e-4
+            assert relmax(got[t]["grad/" + ours].ravel(), np.asarray(grads[t][theirs]).ravel()) < par_tol(ours), (t, ours)
+        assert relmax(got[t]["out"], G[key + "out"]) < GOLD_TOL
+        assert relmax(got[t]["dx"], G[key + "dx"]) < GOLD_TOL
+        assert relmax(got[t]["grad/mrla.mrla.Wv.weight"], G[key + "grad/mrla.mrla.Wv.weight"]) < GOLD_TOL
 
 
 @pytest.mark.parametrize("shape", [(3, 256, 56, 56, 16, 3), (2, 1024, 14, 14, 16, 6), (2, 2048, 7, 7, 16, 3),
@@ -135,9 +139,9 @@ def test_base_chain_resnet_stage_shapes(shape, dtype, cl):
         outs, caches, grads, Ko, Vo = oracle_chain(xs, gups, params, d, True, dp=dps)
         for t in range(Tn):
             assert relmax(got[t]["out"], outs[t]) < ACT_TOL, t
-            assert relmax(got[t]["dx"], grads[t]["dx"]) < 2 * ACT_TOL, t
+            assert relmax(got[t]["dx"], grads[t]["dx"]) < ACT_TOL, t
             for ours, theirs in PAIRS:
-                assert relmax(got[t]["grad/" + ours].ravel(), np.asarray(grads[t][theirs]).ravel()) < PAR_TOL, (t, ours)
+                assert relmax(got[t]["grad/" + ours].ravel(), np.asarray(grads[t][theirs]).ravel()) < par_tol(ours), (t, ours)
     else:
         # the bf16 path stores v_j, attn and dA_t in bf16 between kernels (as eager bf16 does): the oracle rounds at
         # the same three points (`rnd`), everything else stays fp64, so the ReLU masks agree and elementwise bounds hold
@@ -171,7 +175,7 @@ def test_bare_base_layer_api_matches_reference_attn():
         x, _ = cases.base_inputs(name, t, b, c, h, w)
         attn, K, V = lay(to_dev(x), K, V)
         assert tuple(K.shape) == (b, t + 1, c) and tuple(V.shape) == (b, t + 1, c, h, w)
-        assert relmax(attn.detach().cpu().numpy(), G[f"{name}/eval/{t}/attn"]) < 2e-5
+        assert relmax(attn.detach().cpu().numpy(), G[f"{name}/eval/{t}/attn"]) < GOLD_TOL
 
 
 def test_resnet50_mrlab_logits_match_reference_and_eager():
@@ -187,13 +191,13 @@ def test_resnet50_mrlab_logits_match_reference_and_eager():
     x = torch.from_numpy(cases.image_batch(4)).cuda()
     with torch.no_grad():
         y, yr = net(x), ref(x)
-    assert relmax(y.cpu().numpy(), yr.cpu().numpy()) < 2e-5
-    assert relmax(y.cpu().numpy(), G["resnet50_mrlab/eval4/logits"]) < 2e-4
+    assert relmax(y.cpu().numpy(), yr.cpu().numpy()) < MODEL_TOL          # (measured 3.9e-7)
+    assert relmax(y.cpu().numpy(), G["resnet50_mrlab/eval4/logits"]) < MODEL_REF_TOL   # (measured 6.3e-7)
     net.train(); ref.train()
     xb = torch.from_numpy(cases.image_batch(4, "img-train")).cuda()
     tgt = (torch.arange(4) * 37 % 1000).cuda()
     y, yr = net(xb), ref(xb)
-    assert relmax(y.detach().cpu().numpy(), yr.detach().cpu().numpy()) < 1e-4
+    assert relmax(y.detach().cpu().numpy(), yr.detach().cpu().numpy()) < 4 * MODEL_TOL   # train mode, 53+16 BatchNorms at batch 4 (measured 1.6e-6)
     torch.nn.functional.cross_entropy(y, tgt).backward()
     torch.nn.functional.cross_entropy(yr, tgt).backward()
     gp, gr = dict(net.named_parameters()), dict(ref.named_parameters())
@@ -254,7 +258,7 @@ def test_repeated_backward_over_one_stage_restarts_the_gradient_rings(cl):
     params = [cases.block_params(c, 10 + t, light=False) for t in range(Tn - 1)]
     _, _, og, _, _ = oracle_chain(xs64, [g.cpu().numpy() for g in gups[:-1]], params, d, True)
     for t in range(Tn - 1):
-        assert relmax(g3[t].cpu().numpy(), og[t]["dx"]) < 2 * ACT_TOL, t
+        assert relmax(g3[t].cpu().numpy(), og[t]["dx"]) < ACT_TOL, t
     # a pass whose deepest layer is SHALLOWER than the previous pass's last layer (t decreases across the pass boundary:
     # the ordering heuristic alone would take it for a continuation): passes are told apart by the autograd graph-task id
     shallow = sum((o * g).sum() for o, g in zip(outs[:2], gups[:2]))
@@ -262,7 +266,7 @@ def test_repeated_backward_over_one_stage_restarts_the_gradient_rings(cl):
     g5 = grads_of(shallow, True)                           # ... and this one starts at layer 2 of 4
     _, _, og2, _, _ = oracle_chain(xs64[:2], [g.cpu().numpy() for g in gups[:2]], params[:2], d, True)
     for t in range(2):
-        assert relmax(g5[t].cpu().numpy(), og2[t]["dx"]) < 2 * ACT_TOL, t
+        assert relmax(g5[t].cpu().numpy(), og2[t]["dx"]) < ACT_TOL, t
     # and directly after a partial pass that stopped at layer 3 (torch.autograd.grad down to x_3 only)
     torch.autograd.grad(full, [xs[2]], retain_graph=True)
     g6 = grads_of(shallow, True)
@@ -294,4 +298,78 @@ def test_wide_nchw_base_stage_goes_through_nhwc_rings():
     want, _, grads, _, _ = oracle_chain(xs, gups, params, d, True)
     for t in range(Tn):
         assert relmax(outs[t].detach().cpu().numpy(), want[t]) < ACT_TOL, t
-        assert relmax(xts[t].grad.cpu().numpy(), grads[t]["dx"]) < 2 * ACT_TOL, t
+        assert relmax(xts[t].grad.cpu().numpy(), grads[t]["dx"]) < ACT_TOL, t
+
+
+@pytest.mark.parametrize("shape", [(3, 64, 6, 9), (4, 256, 14, 14), (2, 1024, 14, 14), (8, 128, 28, 28)],
+                         ids=lambda s: "x".join(map(str, s)))
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16], ids=["fp32", "bf16"])
+def test_deferred_bn3_backward_sums_ride_in_the_base_value_backward(shape, dtype):
+    """resnet_mrla_base.py:103-104,120-127 on an NHWC stage: with bn3's affine deferred into the MRLA-base pooling pass, its
+    BACKWARD statistics (sum dpre, sum dpre * (y3 - mean)) are taken inside mrla_base_value_bwd_dv -- the kernel that forms
+    dpre -- instead of by a 2N pass of mrla_bn_plane_dmoments (33 launches fewer per resnet101_mrlab step).  Two layers of a
+    stage, both with their own bn3; compared with the same chain where the hand-over is refused (the box emptied between
+    the kernels, so bn3's backward runs its own statistics pass): outputs and every other gradient bit-identical, bn3's
+    parameter gradients and the constants of its input gradient equal up to fp32 summation order."""
+    from mrla_amd import _lib as L, functional as Fm
+    b, c, h, w = shape
+    d = 16
+    torch.manual_seed(9)
+    mk = lambda *s: torch.randn(*s, device="cuda")                                             # noqa: E731
+    cl = lambda t: t.contiguous(memory_format=torch.channels_last)                              # noqa: E731
+    probe = cl(torch.empty((b, c, h, w), dtype=dtype, device="cuda"))
+    assert Fm.BaseStage.layout_for(probe, d) == L.NHWC
+    dt = L.BF16 if dtype == torch.bfloat16 else L.F32
+    assert L.load().mrla_base_value_bwd_pre_sums(b, c, h, w, dt, L.NHWC) == 1
+    k = 3 if c == 64 else 5
+    convs = [cl(mk(b, c, h, w).to(dtype)) for _ in range(2)]
+    idn, gs = cl(mk(b, c, h, w).to(dtype)), [cl(mk(b, c, h, w).to(dtype)) for _ in range(2)]
+    wts = [(mk(1, 1, k) * 0.5, mk(1, 1, k) * 0.5, mk(c, 1, 3, 3) * 0.3) for _ in range(2)]
+    results, launches = [], []
+    for handed in (False, True):
+        stage = Fm.BaseStage(b, c, h, w, d, dtype, torch.device("cuda"), 2, L.NHWC)
+        bn3s = [torch.nn.BatchNorm2d(c).cuda() for _ in range(2)]
+        bnms = [torch.nn.BatchNorm2d(c).cuda() for _ in range(2)]
+        with torch.no_grad():
+            for bn in bn3s + bnms:
+                bn.weight.copy_(torch.linspace(0.5, 1.5, c)); bn.bias.copy_(torch.linspace(-0.3, 0.3, c))
+        xins = [t.clone().requires_grad_(True) for t in convs]
+        oin = idn.clone().requires_grad_(True)
+        prms = [[p.clone().requires_grad_(True) for p in wt] for wt in wts]
+        loss, prev, outs = 0.0, oin, []
+        for t in range(2):
+            pre = Fm.bn_act(xins[t], bn3s[t], relu=False, defer=True)
+            assert getattr(pre, "_mrla_bn_box", None) is not None
+            if not handed:
+                pre._mrla_bn_box = None              # no box: the value backward takes no sums, bn3 runs its own pass
+            out = Fm.mrla_base(pre, prms[t][0], prms[t][1], prms[t][2], d, stage,
+                               bn=dict(weight=bnms[t].weight, bias=bnms[t].bias, running_mean=bnms[t].running_mean,
+                                       running_var=bnms[t].running_var, training=True, momentum=0.1, eps=1e-5),
+                               identity=prev)
+            outs.append(out)
+            loss = loss + (out.float() * gs[t].float()).sum()
+            prev = out
+        timer = Fm.KernelTimer(["mrla_bn_plane_dmoments", "mrla_base_value_bwd_dv"])
+        Fm.TIMER = timer
+        try:
+            loss.backward()
+        finally:
+            Fm.TIMER = None
+        torch.cuda.synchronize()
+        launches.append(timer.summary())
+        results.append([o.detach() for o in outs] + [x.grad for x in xins] + [oin.grad]
+                       + [g for bn in bn3s for g in (bn.weight.grad, bn.bias.grad)]
+                       + [bn.weight.grad for bn in bnms] + [p.grad for pr in prms for p in pr])
+    assert launches[0]["mrla_bn_plane_dmoments"]["launches"] == 2 and "mrla_bn_plane_dmoments" not in launches[1]
+    assert launches[1]["mrla_base_value_bwd_dv"]["launches"] == 2
+    for i, (a, bb) in enumerate(zip(*results)):
+        if i in (5, 6, 7, 8):                    # bn3.weight.grad / bn3.bias.grad of the two layers
+            assert ((a - bb).abs().max() / bb.abs().max()).item() < 1e-3, i          # VERDICT bound; measured ~1e-6
+            cases.record(((a - bb).abs().max() / bb.abs().max()).item(), depth=1)
+        elif i in (2, 3):                        # gradient wrt conv3's output: e*dpre + f*y3 + h with those constants
+            af, bf_ = a.float(), bb.float()
+            unit = (2.0 ** -7 if dtype == torch.bfloat16 else 1e-5) * (bf_.abs() + 0.05 * bf_.abs().max())
+            assert ((af - bf_).abs() <= unit).all(), i
+            assert (af != bf_).float().mean().item() < (1e-3 if dtype == torch.bfloat16 else 1.0), i
+        else:
+            assert torch.equal(a, bb), i

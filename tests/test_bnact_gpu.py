@@ -34,12 +34,13 @@ def test_bn_act_matches_torch(shape, relu, training, cl):
     yr = ref(xr)
     yr = torch.relu(yr) if relu else yr
     y.backward(g); yr.backward(g.double())
-    assert relmax(y.detach().cpu().numpy(), yr.detach().cpu().numpy()) < 5e-6
-    assert relmax(xa.grad.cpu().numpy(), xr.grad.cpu().numpy()) < 2e-5
-    assert relmax(bn.weight.grad.cpu().numpy(), ref.weight.grad.cpu().numpy()) < 5e-5
-    assert relmax(bn.bias.grad.cpu().numpy(), ref.bias.grad.cpu().numpy()) < 5e-5
-    assert relmax(bn.running_mean.cpu().numpy(), ref.running_mean.cpu().numpy()) < 5e-6
-    assert relmax(bn.running_var.cpu().numpy(), ref.running_var.cpu().numpy()) < 5e-6
+    # vs torch's own fp32 BatchNorm2d on the same GPU: both sides round in fp32 (measured <= 4.8e-7)
+    assert relmax(y.detach().cpu().numpy(), yr.detach().cpu().numpy()) < 2e-6
+    assert relmax(xa.grad.cpu().numpy(), xr.grad.cpu().numpy()) < 2e-6
+    assert relmax(bn.weight.grad.cpu().numpy(), ref.weight.grad.cpu().numpy()) < 2e-6
+    assert relmax(bn.bias.grad.cpu().numpy(), ref.bias.grad.cpu().numpy()) < 2e-6
+    assert relmax(bn.running_mean.cpu().numpy(), ref.running_mean.cpu().numpy()) < 2e-6
+    assert relmax(bn.running_var.cpu().numpy(), ref.running_var.cpu().numpy()) < 2e-6
     assert int(bn.num_batches_tracked) == int(ref.num_batches_tracked)
 
 

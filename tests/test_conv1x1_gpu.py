@@ -298,8 +298,9 @@ def test_shortcut_gradient_joins_the_input_gradient_gemm(shape):
 
 def test_weight_bank_refresh_and_fp32_weight_gradient():
     """mrla_weight_bank_refresh: every fp32 1x1-convolution weight -> its bf16 working copy and the transpose, in one
-    launch, bit-equal to torch's `.bfloat16()` (what autocast's cast kernel produces); refreshed only when a weight
-    changed; and mrla_conv1x1_wgrad with dw_dtype = MRLA_F32 writes the fp32 sum whose bf16 rounding is the bf16 result."""
+    launch, bit-equal to torch's `.bfloat16()` (what autocast's cast kernel produces); refreshed by every training
+    forward, by grad-free forwards only when a weight changed -- and always once a refresh has been captured into a HIP graph;
+    and mrla_conv1x1_wgrad with dw_dtype = MRLA_F32 writes the fp32 sum whose bf16 rounding is the bf16 result."""
     import ctypes
     from mrla_amd import _lib as L, functional as Fm
     torch.manual_seed(3)
@@ -314,17 +315,62 @@ def test_weight_bank_refresh_and_fp32_weight_gradient():
         w16, w16t = bank.get(c)
         want = c.weight.detach().reshape(c.out_channels, c.in_channels).bfloat16()
         assert torch.equal(w16, want) and torch.equal(w16t, want.t().contiguous())
-    # unchanged weights: no launch (poison the copies, refresh, still poisoned); an in-place update: refreshed
+    # a grad-free forward with unchanged weights: no launch (poison the copies, refresh, still poisoned) ...
+    def fresh():
+        torch.cuda.synchronize()
+        return all(torch.equal(bank.get(c)[0], c.weight.detach().reshape(c.out_channels, c.in_channels).bfloat16()) for c in convs)
     bank.flat.fill_(float("nan"))
-    bank.refresh()
+    with torch.no_grad():
+        bank.refresh()
     torch.cuda.synchronize()
     assert torch.isnan(bank.get(convs[0])[0].float()).all()
+    # ... a training forward (gradients enabled) always re-casts: the optimizer moves the masters between forwards
+    bank.refresh()
+    assert fresh()
+    # an in-place update seen by the version counters re-casts in a grad-free forward too
     with torch.no_grad():
         convs[0].weight.mul_(0.5)
-    bank.refresh()
+        bank.refresh()
+    assert fresh()
+    # a write the version counters cannot see (`.data`): stale until invalidate()
+    convs[2].weight.data.mul_(2.0)
+    with torch.no_grad():
+        bank.refresh()
+    assert not fresh()
+    bank.invalidate()
+    with torch.no_grad():
+        bank.refresh()
+    assert fresh()
+    # once a refresh is part of a HIP graph, replays move the masters behind the counters' back (the captured optimizer step):
+    # from then on every refresh re-casts, also grad-free ones (train by replay, then an eager validation forward)
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side), torch.no_grad():
+        bank.refresh()
+    torch.cuda.current_stream().wait_stream(side)
+    gr = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(gr), torch.no_grad():
+        bank.refresh()
+        for c in convs:
+            c.weight.mul_(0.9)                           # stands for the captured optimizer step
+    versions = [c.weight._version for c in convs]
+    gr.replay()
+    gr.replay()
     torch.cuda.synchronize()
-    for c in convs:
-        assert torch.equal(bank.get(c)[0], c.weight.detach().reshape(c.out_channels, c.in_channels).bfloat16())
+    assert [c.weight._version for c in convs] == versions        # replays do not bump Python-side versions ...
+    assert not fresh()                                            # ... and the bank holds the copies of the replay's START
+    with torch.no_grad():
+        bank.refresh()                                            # the eager validation forward after train-by-replay
+    assert fresh()
+    # a first build inside a capture is refused with a clear error (its table upload is not capturable)
+    bank2 = Fm.WeightBank(convs)
+    gr2 = torch.cuda.CUDAGraph()
+    try:
+        with torch.cuda.graph(gr2):
+            with pytest.raises(L.MrlaHipError, match="eagerly before capturing"):
+                bank2.refresh()
+    except RuntimeError:
+        pass                                                      # (an empty capture may itself be refused by the runtime)
     # fp32 weight gradient straight from the reduction kernel
     b, h, w, k, n = 3, 14, 14, 256, 1024
     m = b * h * w

@@ -62,7 +62,7 @@ def check_against_golden(net, dev, tol_map, tol_grad, amp=False):
 def test_eager_det_backbone_vs_reference():
     net = em.EagerDetBackbone(frozen_stages=1, norm_eval=True)
     load_det(net)
-    check_against_golden(net, "cpu", 2e-5, 2e-3)
+    check_against_golden(net, "cpu", 5e-6, 2e-3)          # maps measured 9.5e-7
 
 
 def test_product_det_backbone_surface():

@@ -13,7 +13,7 @@ def test_det_backbone_fp32_vs_reference_golden():
     from mrla_amd import mmdet_backbone as mb
     net = mb.ResNet_mrlal(frozen_stages=1, norm_eval=True)
     load_det(net)
-    check_against_golden(net.cuda(), "cuda", 1e-4, 5e-3)
+    check_against_golden(net.cuda(), "cuda", 5e-6, 5e-3)          # maps measured 8.3e-7
 
 
 def test_det_backbone_wide_image_fp32_and_bf16_autocast_vs_eager():

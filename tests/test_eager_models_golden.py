@@ -29,11 +29,11 @@ def test_full_model_logits_and_grads(arch, factory, nb):
     net.eval()
     with torch.no_grad():
         logits = net(torch.from_numpy(cases.image_batch(nb)))
-    assert rel(logits.numpy(), G[f"{arch}/eval{nb}/logits"]) < 1e-5
+    assert rel(logits.numpy(), G[f"{arch}/eval{nb}/logits"]) < 5e-6                   # (measured 5.4e-7)
     net.train()
     xb = torch.from_numpy(cases.image_batch(4, "img-train"))
     logits = net(xb)
-    assert rel(logits.detach().numpy(), G[f"{arch}/train4/logits"]) < 1e-4
+    assert rel(logits.detach().numpy(), G[f"{arch}/train4/logits"]) < 1e-5          # (measured 5.8e-7)
     loss = torch.nn.functional.cross_entropy(logits, torch.arange(4) * 37 % 1000)
     loss.backward()
     grads = dict(net.named_parameters())

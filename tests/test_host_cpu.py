@@ -20,7 +20,7 @@ def test_library_exports_every_declared_symbol():
         assert hasattr(lib, name), name
     # the version the header declares == what the library reports == what the ctypes binding was written against
     hdr_version = int(re.search(r"#define\s+MRLA_ABI_VERSION\s+(\d+)", hdr).group(1))
-    assert lib.mrla_abi_version() == hdr_version == _lib.ABI_VERSION == 2
+    assert lib.mrla_abi_version() == hdr_version == _lib.ABI_VERSION == 3
 
 
 def test_argument_validation_without_a_gpu():

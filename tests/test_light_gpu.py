@@ -1,8 +1,9 @@
 """GPU parity: HIP MRLA-light path (through the C ABI) vs the numpy oracle and the reference's goldens.
 
 Protocol (SURVEY.md section 7 "bf16 tolerance"):
-  fp32  : kernel vs fp64 oracle on the same fp32 inputs, error relative to the tensor's max-abs; bound 5e-6 for
-          activations (the reference's own fp32 result differs from the fp64 oracle by about as much).
+  fp32  : kernel vs fp64 oracle on the same fp32 inputs, error relative to the tensor's max-abs; bound 1e-6 for
+          activations / input gradients (north_star), 5e-6 for parameter gradients, 3e-5 for the cancelling dWq / dWk
+          sums (tests/cases.py: the bounds with their measured maxima and reasons).
   bf16  : inputs/weights pre-rounded to bf16; kernel output (bf16) vs the fp64 oracle rounded once to bf16 must
           agree within 1 bf16 ulp (2^-7 relative), plus an absolute floor for values near zero.
 """
@@ -15,8 +16,12 @@ from tests import cases
 
 pytestmark = pytest.mark.gpu
 
-ACT_TOL = 5e-6
-PAR_TOL = 5e-5
+ACT_TOL, PAR_TOL, QK_TOL, GOLD_TOL, TINY_BN_TOL = cases.ACT_TOL, cases.PAR_TOL, cases.QK_TOL, cases.GOLD_TOL, cases.TINY_BN_TOL
+
+
+def par_tol(name):
+    """Bound for a parameter gradient by (reference or oracle) name: the cancelling Wq / Wk sums get QK_TOL."""
+    return QK_TOL if ("Wq" in name or "Wk" in name or name in ("dwq", "dwk")) else PAR_TOL
 
 
 relmax = cases.relmax          # error relative to the tensor's max-abs; every call is recorded (tests/cases.py)
@@ -83,14 +88,19 @@ def test_light_tail_fp32_vs_oracle_and_reference(case, mode, cl):
     assert relmax(got["rv"], cache["bn"]["new_rv"]) < ACT_TOL
     for ours, theirs in (("mrla.mrla.Wq.weight", "dwq"), ("mrla.mrla.Wk.weight", "dwk"), ("mrla.mrla.Wv.weight", "dwv"),
                          ("mrla.lambda_t", "dlam"), ("bn_mrla.weight", "dgamma"), ("bn_mrla.bias", "dbeta")):
-        assert relmax(got["grad/" + ours].ravel(), np.asarray(g[theirs]).ravel()) < PAR_TOL, ours
+        assert relmax(got["grad/" + ours].ravel(), np.asarray(g[theirs]).ravel()) < par_tol(ours), ours
     # and directly against what the reference itself produced (fp32, so its own rounding is in the budget)
     sub = (lambda a: a[:, ::8]) if name == "s2048" else (lambda a: a)
-    assert relmax(sub(got["out"]), G[key + "out"]) < 2e-5
-    assert relmax(sub(got["dx"]), G[key + "dx"]) < 2e-5
-    assert relmax(sub(got["do"]), G[key + "do"]) < 2e-5
-    assert relmax(got["grad/mrla.mrla.Wv.weight"], G[key + "grad/mrla.mrla.Wv.weight"]) < 1e-4
-    assert relmax(got["grad/mrla.lambda_t"], G[key + "grad/mrla.lambda_t"]) < 1e-4
+    assert relmax(sub(got["out"]), G[key + "out"]) < GOLD_TOL
+    assert relmax(sub(got["dx"]), G[key + "dx"]) < GOLD_TOL
+    assert relmax(sub(got["do"]), G[key + "do"]) < GOLD_TOL
+    assert relmax(got["grad/mrla.mrla.Wv.weight"], G[key + "grad/mrla.mrla.Wv.weight"]) < GOLD_TOL
+    assert relmax(got["grad/mrla.lambda_t"], G[key + "grad/mrla.lambda_t"]) < GOLD_TOL
+    # ... and against the reference run in float64 (light_blocks_f64.npz): every parameter gradient, the Wq / Wk sums included
+    G64 = cases.golden("light_blocks_f64")
+    for ours in ("mrla.mrla.Wq.weight", "mrla.mrla.Wk.weight", "mrla.mrla.Wv.weight", "mrla.lambda_t", "bn_mrla.weight",
+                 "bn_mrla.bias"):
+        assert relmax(got["grad/" + ours].ravel(), G64[key + "grad/" + ours].ravel()) < par_tol(ours), ours
 
 
 def bf16_round(a):
@@ -137,7 +147,8 @@ def test_light_tail_resnet50_stage_shapes(shape, dtype, cl):
     got = run_light(x, o, P, d, "train", mask, 0.2, gup, dtype, cl=cl)
     out, cache, g = oracle_light(x, o, P, d, "train", mask, 0.2, gup)
     # BatchNorm over a handful of values (b*h*w <= 9) is ill-conditioned: 1/sigma amplifies the fp32 input rounding
-    tol, ptol = (ACT_TOL, PAR_TOL) if b * h * w > 9 else (20 * ACT_TOL, 20 * PAR_TOL)
+    tiny = b * h * w <= 9
+    tol = TINY_BN_TOL if tiny else ACT_TOL
     if dtype == torch.float32:
         assert relmax(got["out"], out) < tol
         assert relmax(got["dx"], g["dx"]) < tol
@@ -151,7 +162,10 @@ def test_light_tail_resnet50_stage_shapes(shape, dtype, cl):
         assert_bf16_close(got["do"], g["do_prev"], "do")
     for ours, theirs in (("mrla.mrla.Wq.weight", "dwq"), ("mrla.mrla.Wk.weight", "dwk"), ("mrla.mrla.Wv.weight", "dwv"),
                          ("mrla.lambda_t", "dlam"), ("bn_mrla.weight", "dgamma"), ("bn_mrla.bias", "dbeta")):
-        assert relmax(got["grad/" + ours].ravel(), np.asarray(g[theirs]).ravel()) < (2e-2 if (dtype != torch.float32 and b * h * w <= 9) else ptol), ours
+        # bf16 I/O too: the oracle sees the same bf16-rounded inputs and the parameter gradients are fp32 sums, so the
+        # kernel's fp32 accumulation is what is measured and the fp32 bounds hold (measured <= 3.5e-6; 8.2e-6 tiny-BN)
+        ptol = TINY_BN_TOL if tiny else par_tol(theirs)
+        assert relmax(got["grad/" + ours].ravel(), np.asarray(g[theirs]).ravel()) < ptol, ours
 
 
 def test_fused_relu_add_producer_fp32_and_bf16():
@@ -205,9 +219,9 @@ def test_layer_only_and_module_forms():
     wq, wk, wv, lam = (to_dev(P[k]).requires_grad_(True) for k in
                        ("mrla.mrla.Wq.weight", "mrla.mrla.Wk.weight", "mrla.mrla.Wv.weight", "mrla.lambda_t"))
     layer = mrla_light(xt, wq, wk, wv, d)
-    assert relmax(layer.detach().cpu().numpy(), G[f"{name}/train/layer_out"]) < 2e-5
+    assert relmax(layer.detach().cpu().numpy(), G[f"{name}/train/layer_out"]) < GOLD_TOL
     m = mrla_light(xt, wq, wk, wv, d, o_prev=ot, lam=lam)
-    assert relmax(m.detach().cpu().numpy(), G[f"{name}/train/m"]) < 2e-5
+    assert relmax(m.detach().cpu().numpy(), G[f"{name}/train/m"]) < GOLD_TOL
     lo, cache = mn.light_layer_fwd(x.astype(np.float64), P["mrla.mrla.Wq.weight"].ravel().astype(np.float64),
                                    P["mrla.mrla.Wk.weight"].ravel().astype(np.float64),
                                    P["mrla.mrla.Wv.weight"][:, 0].astype(np.float64), d)
@@ -215,7 +229,7 @@ def test_layer_only_and_module_forms():
     layer.backward(to_dev(gup))
     assert relmax(xt.grad.cpu().numpy(), gl["dx"]) < ACT_TOL
     assert relmax(wv.grad.cpu().numpy()[:, 0], gl["dwv"]) < PAR_TOL
-    assert relmax(wq.grad.cpu().numpy().ravel(), gl["dwq"]) < PAR_TOL
+    assert relmax(wq.grad.cpu().numpy().ravel(), gl["dwq"]) < QK_TOL
 
 
 def test_cpu_tensor_is_rejected_loudly():

@@ -32,8 +32,8 @@ def test_resnet50_mrlal_eval_logits_match_reference_and_eager():
     with torch.no_grad():
         y, yr = net(x), ref(x)
     # MIOpen fp32 convolutions differ from the CPU's by ~1e-5; the product and eager share them exactly
-    assert rel(y.cpu().numpy(), yr.cpu().numpy()) < 2e-5
-    assert rel(y.cpu().numpy(), G["resnet50_mrlal/eval8/logits"]) < 2e-4
+    assert rel(y.cpu().numpy(), yr.cpu().numpy()) < 5e-6                            # (measured 5.4e-7)
+    assert rel(y.cpu().numpy(), G["resnet50_mrlal/eval8/logits"]) < 1e-5           # (measured 7.0e-7)
 
 
 def test_resnet50_mrlal_train_step_matches_eager():
@@ -47,8 +47,9 @@ def test_resnet50_mrlal_train_step_matches_eager():
     x = torch.from_numpy(cases.image_batch(4, "img-train")).cuda()
     tgt = (torch.arange(4) * 37 % 1000).cuda()
     y, yr = net(x), ref(x)
-    assert rel(y.detach().cpu().numpy(), yr.detach().cpu().numpy()) < 1e-4
-    assert rel(y.detach().cpu().numpy(), G["resnet50_mrlal/train4/logits"]) < 1e-3
+    # train mode at batch 4: 69 BatchNorms over 4 x h x w samples each (measured 1.5e-6 / 1.1e-6)
+    assert rel(y.detach().cpu().numpy(), yr.detach().cpu().numpy()) < 2e-5
+    assert rel(y.detach().cpu().numpy(), G["resnet50_mrlal/train4/logits"]) < 2e-5
     torch.nn.functional.cross_entropy(y, tgt).backward()
     torch.nn.functional.cross_entropy(yr, tgt).backward()
     gp, gr = dict(net.named_parameters()), dict(ref.named_parameters())
@@ -74,7 +75,7 @@ def test_resnet50_mrlal_train_step_matches_eager():
     assert dots[0] / np.sqrt(dots[1] * dots[2]) > 0.9999
     sp, sr = net.state_dict(), ref.state_dict()
     for k in ("layer1.0.bn_mrla.running_mean", "layer4.2.bn_mrla.running_var", "layer2.1.bn_mrla.num_batches_tracked"):
-        assert rel(sp[k].float().cpu().numpy(), sr[k].float().cpu().numpy()) < 1e-4, k
+        assert rel(sp[k].float().cpu().numpy(), sr[k].float().cpu().numpy()) < 1e-5, k       # (measured 4.1e-7)
 
 
 @pytest.mark.parametrize("arch", ["resnet50_mrlal", "resnet50_mrlab"])
@@ -93,7 +94,7 @@ def test_nchw_and_channels_last_paths_agree(arch):
     a.train(); b.train()
     x = torch.from_numpy(cases.image_batch(4, "img-train")).cuda()
     ya, yb = a(x), b(x)
-    assert rel(ya.detach().cpu().numpy(), yb.detach().cpu().numpy()) < 2e-4
+    assert rel(ya.detach().cpu().numpy(), yb.detach().cpu().numpy()) < 2e-5               # (measured 1.7e-6)
     ya.square().mean().backward(); yb.square().mean().backward()
     dots = np.zeros(3)
     for (k, pa), (_, pb) in zip(a.named_parameters(), b.named_parameters()):

@@ -38,17 +38,20 @@ def rel(got, want):
     return cases.relmax(got, want, floor=1e-9)          # recorded (tests/cases.py)
 
 
-def check_chain(mods, xs, outs, tol_act, tol_par):
+def check_chain(mods, xs, outs, tol_act=cases.GOLD_TOL, tol_par=cases.GOLD_TOL, tol_qk=cases.QK_TOL):
+    """vs what the reference computed in fp32 (tests/cases.py: the bounds; the cancelling Wq / Wk sums by name)."""
     G = cases.golden("token_base")
     for t in range(STEPS):
         assert rel(outs[t].detach().float().cpu().numpy(), G[f"{t}/module_out"]) < tol_act, t
-        assert rel(xs[t].grad.float().cpu().numpy(), G[f"{t}/dx"]) < 2 * tol_act, t
+        assert rel(xs[t].grad.float().cpu().numpy(), G[f"{t}/dx"]) < tol_act, t
         for pn, pv in mods[t].named_parameters():
-            assert rel(pv.grad.float().cpu().numpy(), G[f"{t}/grad/{pn}"]) < tol_par, (t, pn)
+            tol = tol_qk if ("Wq" in pn or "Wk" in pn) else tol_par
+            assert rel(pv.grad.float().cpu().numpy(), G[f"{t}/grad/{pn}"]) < tol, (t, pn)
 
 
 def test_eager_token_base_chain_vs_reference():
-    check_chain(*run_chain(lambda t: em.EagerTokenBaseModule(C, D, init_cell=(t % 4 == 0))), 2e-5, 1e-4)
+    # the eager restatement issues the very ATen calls of the reference: measured 0.0 on this container
+    check_chain(*run_chain(lambda t: em.EagerTokenBaseModule(C, D, init_cell=(t % 4 == 0))), 1e-6, 1e-6, 1e-6)
 
 
 def test_eager_deit_mrlab_logits_vs_reference():

@@ -5,7 +5,7 @@ import torch
 
 from oracle import detgen, eager_models as em, mrla_numpy as mn
 from tests import cases
-from tests.test_light_gpu import ACT_TOL, PAR_TOL, assert_bf16_close, bf16_round, relmax, to_dev
+from tests.test_light_gpu import ACT_TOL, GOLD_TOL, PAR_TOL, QK_TOL, assert_bf16_close, bf16_round, par_tol, relmax, to_dev
 
 pytestmark = pytest.mark.gpu
 
@@ -47,17 +47,17 @@ def test_token_module_fp32(case, res):
     out, dx, do, pg = run(x, o, P, d, gup, torch.float32, res)
     want, g = oracle(x, o, P, d, gup, res)
     assert relmax(out, want) < ACT_TOL
-    assert relmax(dx, g["dxt"]) < 2 * ACT_TOL
-    assert relmax(do, g["dot"]) < 2 * ACT_TOL
+    assert relmax(dx, g["dxt"]) < ACT_TOL
+    assert relmax(do, g["dot"]) < ACT_TOL
     for got, key in zip(pg, ORACLE):
-        assert relmax(got.ravel(), np.asarray(g[key]).ravel()) < PAR_TOL, key
+        assert relmax(got.ravel(), np.asarray(g[key]).ravel()) < par_tol(key), key
     sub = (lambda a: a[:, ::4]) if n == 197 else (lambda a: a)
     if res:      # the golden gradients were taken through the block residual x + module(x, o)
-        assert relmax(sub(dx), G[name + "/dx"]) < 5e-5
-        assert relmax(sub(do), G[name + "/do"]) < 5e-5
-        assert relmax(pg[6], G[name + "/grad/mrla.Wv.weight"]) < 2e-4
+        assert relmax(sub(dx), G[name + "/dx"]) < GOLD_TOL
+        assert relmax(sub(do), G[name + "/do"]) < GOLD_TOL
+        assert relmax(pg[6], G[name + "/grad/mrla.Wv.weight"]) < GOLD_TOL
     else:
-        assert relmax(sub(out), G[name + "/module_out"]) < 2e-5
+        assert relmax(sub(out), G[name + "/module_out"]) < GOLD_TOL
 
 
 @pytest.mark.parametrize("c", [192, 384, 768], ids=["tiny", "small", "base"])
@@ -74,7 +74,7 @@ def test_token_block_bf16_and_batch(c):
     assert_bf16_close(dx, g["dxt"], "dx")
     assert_bf16_close(do, g["dot"], "do")
     for got, key in zip(pg, ORACLE):
-        assert relmax(got.ravel(), np.asarray(g[key]).ravel()) < PAR_TOL, key
+        assert relmax(got.ravel(), np.asarray(g[key]).ravel()) < par_tol(key), key
 
 
 @pytest.mark.parametrize("case", cases.GELU_LAYER_CASES, ids=lambda c: c[0])
@@ -104,14 +104,14 @@ def test_gelu_map_layer_module(case, cl, dtype):
     if dtype == torch.float32:
         assert relmax(out, want) < ACT_TOL and relmax(dx, g["dx"]) < ACT_TOL
         sub = (lambda a: a[:, ::4]) if c > 64 else (lambda a: a)
-        assert relmax(sub(out), G[name + "/out"]) < 2e-5 and relmax(sub(dx), G[name + "/dx"]) < 5e-5
-        assert relmax(lay.Wv.weight.grad.cpu().numpy(), G[name + "/grad/Wv.weight"]) < 2e-4
+        assert relmax(sub(out), G[name + "/out"]) < GOLD_TOL and relmax(sub(dx), G[name + "/dx"]) < GOLD_TOL
+        assert relmax(lay.Wv.weight.grad.cpu().numpy(), G[name + "/grad/Wv.weight"]) < GOLD_TOL
     else:
         assert_bf16_close(out, want, "out")
         assert_bf16_close(dx, g["dx"], "dx")
     assert relmax(lay.Wv.weight.grad.cpu().numpy()[:, 0], g["dwv"]) < PAR_TOL
-    assert relmax(lay.Wq.weight.grad.cpu().numpy().ravel(), g["dwq"]) < PAR_TOL
-    assert relmax(lay.Wk.weight.grad.cpu().numpy().ravel(), g["dwk"]) < PAR_TOL
+    assert relmax(lay.Wq.weight.grad.cpu().numpy().ravel(), g["dwq"]) < QK_TOL
+    assert relmax(lay.Wk.weight.grad.cpu().numpy().ravel(), g["dwk"]) < QK_TOL
 
 
 def test_deit_mrlal_tiny_logits_match_reference_and_eager():
@@ -126,8 +126,8 @@ def test_deit_mrlal_tiny_logits_match_reference_and_eager():
     x = torch.from_numpy(cases.image_batch(4)).cuda()
     with torch.no_grad():
         y, yr = net(x), ref(x)
-    assert relmax(y.cpu().numpy(), yr.cpu().numpy()) < 2e-5
-    assert relmax(y.cpu().numpy(), G["deit_mrlal_tiny/eval4/logits"]) < 2e-4
+    assert relmax(y.cpu().numpy(), yr.cpu().numpy()) < 5e-6          # same GPU GEMMs on both sides (measured 9.4e-7)
+    assert relmax(y.cpu().numpy(), G["deit_mrlal_tiny/eval4/logits"]) < 1e-5   # the reference's CPU logits (measured 8.9e-7)
     net.train(); ref.train()
     xb = torch.from_numpy(cases.image_batch(4, "img-train")).cuda()
     tgt = (torch.arange(4) * 37 % 1000).cuda()

@@ -73,6 +73,7 @@ def parse():
     ap.add_argument("--drop-path", type=float, default=0.2, help="resnet/train.py:67 default")
     ap.add_argument("--no-baselines", action="store_true", help="skip the cpu_baseline / eager_rocm / other_configs legs")
     ap.add_argument("--no-others", action="store_true", help="skip the other_configs leg (BASELINE configs 4 and 5)")
+    ap.add_argument("--no-forward-only", action="store_true", help="skip the inference-pass leg (counter passes over the training step)")
     ap.add_argument("--eager", action="store_true", help="time the eager restatement instead (diagnostic)")
     ap.add_argument("--channels-last", type=int, default=-1,
                     help="1 / 0: force torch.channels_last on / off; -1: the model class default (on for resnet*_mrlal)")
@@ -632,7 +633,7 @@ def main():
                                        "frac": round(tf / (MFMA_BF16_PEAK_TFLOPS * world), 4),
                                        "mfma_util_counter": mfma_counter(args),
                                        "note": "whole-model flops (MIOpen convolutions); the MRLA kernels are HBM/VALU work"}
-        if world == 1 and not dist_on:
+        if world == 1 and not args.no_forward_only:
             out["forward_only"] = forward_only(net, x, graph=use_graph)
         if world == 1 and not dist_on and not args.no_baselines:
             out["eager_rocm"] = eager_rocm(args.arch, args.batch, args.drop_path)

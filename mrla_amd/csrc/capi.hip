@@ -198,11 +198,11 @@ int mrla_light_stats_bwd(const void* dout, const void* x, const void* o_prev, co
   if (!dout || !x || !wv || !mom || !bmom || bad_dims(b, c, h, w) || bad_dtype(dtype)) return MRLA_EINVAL;
   if (layout == MRLA_NHWC)
     return launch_light_stats_bwd_nhwc(dout, x, o_prev, wv, mom, bmom, b, c, h, w, dtype, act, (hipStream_t)stream);
-  if (layout != MRLA_NCHW) return MRLA_EINVAL;      // (the NCHW forward statistics carry zero pivots: raw = shifted)
+  if (layout != MRLA_NCHW) return MRLA_EINVAL;
   SlabGeo g;
   const int rc = light_geo(&g, b, c, h, w, dtype);
   if (rc != MRLA_OK) return rc;
-  return launch_light_stats_bwd_nchw(dout, x, o_prev, wv, bmom, g, dtype, act, (hipStream_t)stream);
+  return launch_light_stats_bwd_nchw(dout, x, o_prev, wv, mom, bmom, g, dtype, act, (hipStream_t)stream);
 }
 
 int mrla_light_bn_bwd(const float* mom, const float* bmom, const float* gate, const float* lam, const float* gamma,

@@ -72,8 +72,28 @@ __device__ __forceinline__ void load_taps(float (&w)[9], const float* __restrict
   }
 
 // ------------------------------------------------------------------------------------------------
-// forward statistics:  mom[b, c, 0..5]
+// forward statistics:  mom[b, c, 0..7] -- the sums over V and o are taken about per-plane PIVOTS (pV = V at the plane's
+// first pixel, pO = o there: samples of the plane, so nothing cancels when |mean| >> sigma), exactly the record the NHWC
+// row pipeline writes (mrla_device.h: M_REC); the per-channel kernels un-shift in double.
 // ------------------------------------------------------------------------------------------------
+// pV / pO of the slab's planes into ptab[p][9] / ptab[p][10] (the caller synchronises afterwards)
+template <typename T, bool GELU, bool HAS_O>
+__device__ __forceinline__ void plane_pivots(float* __restrict__ ptab, const T* __restrict__ xs, const T* __restrict__ os,
+                                             int np, int H, int W, int tid) {
+  for (int p = tid; p < np; p += kThreads) {
+    const T* xp = xs + (size_t)p * H * W;
+    const float* w = ptab + p * kPT;
+    float v = w[4] * to_f(xp[0]);                            // V at pixel (0, 0): the taps that fall inside the plane
+    if (W > 1) v = fmaf(w[5], to_f(xp[1]), v);
+    if (H > 1) {
+      v = fmaf(w[7], to_f(xp[W]), v);
+      if (W > 1) v = fmaf(w[8], to_f(xp[W + 1]), v);
+    }
+    ptab[p * kPT + 9] = GELU ? gelu_f(v) : v;
+    ptab[p * kPT + 10] = HAS_O ? to_f(os[(size_t)p * H * W]) : 0.f;
+  }
+}
+
 // elementwise x = relu(pre + o) on a slab held in LDS, in place over `pre` (rounded to T exactly as the eager
 // `out += identity; relu(out)` of resnet_mrla_light.py:113-114 would have materialised it)
 template <typename T>
@@ -130,6 +150,8 @@ __global__ __launch_bounds__(kThreads) void light_stats_fwd_nchw(
       __syncthreads();
       slab_store(xout + ((size_t)b * g.C + c0) * g.HW, xs, n, tid);
     }
+    plane_pivots<T, GELU, HAS_O>(ptab, xs, os, np, g.H, g.W, tid);
+    __syncthreads();
     for (int task = wave; task < ntasks; task += kWaves) {
       const LaneTask t = make_task(g, lmap, task, np);
       if (!t.live) continue;
@@ -137,6 +159,7 @@ __global__ __launch_bounds__(kThreads) void light_stats_fwd_nchw(
       const T* op = os + t.p * g.HW + t.col;
       float w[9];
       load_taps(w, ptab + t.p * kPT);
+      const float pV = ptab[t.p * kPT + 9], pO = ptab[t.p * kPT + 10];
       mask_conv(w, t);
       float acc[M_N] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
       int idx = t.r0 * g.W;
@@ -148,11 +171,12 @@ __global__ __launch_bounds__(kThreads) void light_stats_fwd_nchw(
         const Row3 rc = row_of(cn);
         float v = conv9(w, ra, rb, rc);
         if (GELU) v = gelu_f(v);
+        v -= pV;
         acc[M_SX] += rb.c;
         acc[M_SV] += v;
         acc[M_SVV] = fmaf(v, v, acc[M_SVV]);
         if (HAS_O) {
-          const float ov = to_f(op[idx]);
+          const float ov = to_f(op[idx]) - pO;
           acc[M_SO] += ov;
           acc[M_SVO] = fmaf(v, ov, acc[M_SVO]);
           acc[M_SOO] = fmaf(ov, ov, acc[M_SOO]);
@@ -172,8 +196,12 @@ __global__ __launch_bounds__(kThreads) void light_stats_fwd_nchw(
       float s = 0.f;
       for (int band = 0; band < g.NB; ++band) s += red[((grp * g.NB + band) * g.PW + pl) * M_N + k];
       mom[((size_t)b * g.C + c0 + p) * M_REC + k] = s;
-      if (k == 0) { mom[((size_t)b * g.C + c0 + p) * M_REC + M_PV] = 0.f; mom[((size_t)b * g.C + c0 + p) * M_REC + M_PO] = 0.f; }
+      if (k == 0) {
+        mom[((size_t)b * g.C + c0 + p) * M_REC + M_PV] = ptab[p * kPT + 9];
+        mom[((size_t)b * g.C + c0 + p) * M_REC + M_PO] = ptab[p * kPT + 10];
+      }
     }
+    // (the next image's pivots overwrite ptab[.][9..10] only after the barrier inside MRLA_PIPELINE_NEXT)
   }
 }
 
@@ -253,7 +281,7 @@ __global__ __launch_bounds__(kThreads) void light_apply_fwd_nchw(
 template <typename T, bool GELU, bool HAS_O>
 __global__ __launch_bounds__(kThreads) void light_stats_bwd_nchw(
     const T* __restrict__ dout, const T* __restrict__ x, const T* __restrict__ o,
-    const float* __restrict__ wv, float* __restrict__ bmom, SlabGeo g) {
+    const float* __restrict__ wv, const float* __restrict__ mom, float* __restrict__ bmom, SlabGeo g) {
   extern __shared__ __align__(16) unsigned char smem[];
   constexpr int NA = HAS_O ? 3 : 2;
   T* buf = reinterpret_cast<T*>(smem);                                     // [2][NA][astride]: x, dOut, o
@@ -267,6 +295,13 @@ __global__ __launch_bounds__(kThreads) void light_stats_bwd_nchw(
     const T* xs = buf + cur * NA * g.astride;
     const T* gs = xs + g.astride;
     const T* os = gs + g.astride;
+    // sums about the pivots the forward statistics pass recorded for the plane (the per-channel kernels un-shift in double)
+    for (int p = tid; p < np; p += kThreads) {
+      const size_t rec = ((size_t)b * g.C + c0 + p) * M_REC;
+      ptab[p * kPT + 9] = mom ? mom[rec + M_PV] : 0.f;
+      ptab[p * kPT + 10] = (mom && HAS_O) ? mom[rec + M_PO] : 0.f;
+    }
+    __syncthreads();
     for (int task = wave; task < ntasks; task += kWaves) {
       const LaneTask t = make_task(g, lmap, task, np);
       if (!t.live) continue;
@@ -275,6 +310,7 @@ __global__ __launch_bounds__(kThreads) void light_stats_bwd_nchw(
       const T* op = os + t.p * g.HW + t.col;
       float w[9];
       load_taps(w, ptab + t.p * kPT);
+      const float pV = ptab[t.p * kPT + 9], pO = ptab[t.p * kPT + 10];
       mask_conv(w, t);
       float acc[D_N] = {0.f, 0.f, 0.f};
       int idx = t.r0 * g.W;
@@ -288,8 +324,8 @@ __global__ __launch_bounds__(kThreads) void light_stats_bwd_nchw(
         if (GELU) v = gelu_f(v);
         const float gv = to_f(gp[idx]);
         acc[D_D] += gv;
-        acc[D_DV] = fmaf(gv, v, acc[D_DV]);
-        if (HAS_O) acc[D_DO] = fmaf(gv, to_f(op[idx]), acc[D_DO]);
+        acc[D_DV] = fmaf(gv, v - pV, acc[D_DV]);
+        if (HAS_O) acc[D_DO] = fmaf(gv, to_f(op[idx]) - pO, acc[D_DO]);
         ra = rb; rb = rc; cn = cnn;
       }
 #pragma unroll
@@ -571,8 +607,8 @@ int launch_light_apply_fwd_nchw(const void* x, const void* o, const float* wv, c
   return hip_status(hipGetLastError());
 }
 
-int launch_light_stats_bwd_nchw(const void* dout, const void* x, const void* o, const float* wv, float* bmom,
-                                const SlabGeo& g, int dtype, int act, hipStream_t st) {
+int launch_light_stats_bwd_nchw(const void* dout, const void* x, const void* o, const float* wv, const float* mom,
+                                float* bmom, const SlabGeo& g, int dtype, int act, hipStream_t st) {
   const size_t es = dtype_size(dtype);
   const size_t lds = (size_t)g.astride * es * 2 * (o ? 3 : 2) +
                      ((size_t)g.CP * kPT + (size_t)g.NG * g.NB * g.PW * D_N) * sizeof(float);
@@ -582,7 +618,7 @@ int launch_light_stats_bwd_nchw(const void* dout, const void* x, const void* o, 
   {                                                                                                 \
     if (set_lds(light_stats_bwd_nchw<T, A, O>, lds) != hipSuccess) return MRLA_EHIP;                  \
     hipLaunchKernelGGL((light_stats_bwd_nchw<T, A, O>), grid, dim3(kThreads), lds, st, (const T*)dout, \
-                       (const T*)x, (const T*)o, wv, bmom, g);                                      \
+                       (const T*)x, (const T*)o, wv, mom, bmom, g);                                 \
   }
   MRLA_DISPATCH_T_ACT(dtype, act, o != nullptr, CALL)
 #undef CALL

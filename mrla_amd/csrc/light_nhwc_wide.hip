@@ -16,6 +16,16 @@
 #ifndef MRLA_STREAM_MB
 #define MRLA_STREAM_MB 128
 #endif
+// Build-time experiment switches of the fused forward statistics pass (scripts/build_variant.sh; profiles/r04_notes.md):
+// waves per workgroup at most (a wave then walks several strips of a wide image) and a register cap (waves per SIMD).
+#ifndef MRLA_FUSED_MAXWAVES
+#define MRLA_FUSED_MAXWAVES kMaxStrips
+#endif
+#ifdef MRLA_FUSED_WAVES_PER_EU
+#define MRLA_FUSED_OCC __attribute__((amdgpu_waves_per_eu(MRLA_FUSED_WAVES_PER_EU, MRLA_FUSED_WAVES_PER_EU)))
+#else
+#define MRLA_FUSED_OCC
+#endif
 // Cache policy of the row fetches (template AUX: 0 = default, 2 = nt / streaming) and image order, measured in the
 // training step (b = 256, same box, GB/s):            stats_fwd_fused  apply_fwd  stats_bwd  apply_bwd
 //   default policy, images in launch order                  4069         4681       4773       4846
@@ -307,7 +317,7 @@ __device__ __forceinline__ void form_x_row(const RawRow<kS + 2>& pre, const RawR
 template <typename T> constexpr int fused_wave_bytes() { return 3 * RowIO<T, kS + 2>::kBytes + RowIO<T, kS>::kBytes; }
 
 template <typename T, bool AFF, bool RAGGED, int AUX>
-__global__ __launch_bounds__(kMaxStrips * kWave) void light_stats_fwd_fused_wide(
+__global__ __launch_bounds__(kMaxStrips * kWave) MRLA_FUSED_OCC void light_stats_fwd_fused_wide(
     const T* __restrict__ pre, const T* __restrict__ o, const float* __restrict__ wv, float* __restrict__ mom,
     T* __restrict__ xout, const float* __restrict__ psc, const float* __restrict__ psh, T* __restrict__ vout, int B,
     int C, int H, int W, int BG) {
@@ -784,7 +794,7 @@ int launch_light_stats_fwd_wide(const void* x, const void* o, const float* wv, f
     if (!o || act) return MRLA_EINVAL;
 #define CALL_N(T, AF, RG, NT)                                                                                       \
   {                                                                                                                 \
-    const WideLaunch L = wide_launch(B, C, W, kMomRed, fused_wave_bytes<T>(), bg);                                       \
+    const WideLaunch L = wide_launch(B, C, W, kMomRed, fused_wave_bytes<T>(), bg, MRLA_FUSED_MAXWAVES);                  \
     if (set_lds_n(light_stats_fwd_fused_wide<T, AF, RG, NT>, L.lds) != hipSuccess) return MRLA_EHIP;                  \
     hipLaunchKernelGGL((light_stats_fwd_fused_wide<T, AF, RG, NT>), L.grid, L.block, L.lds, st, (const T*)x, (const T*)o, \
                        wv, mom, (T*)xout, psc, psh, (T*)vout, B, C, H, W, L.BG);                                    \

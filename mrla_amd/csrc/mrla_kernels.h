@@ -42,8 +42,8 @@ int launch_light_stats_fwd_nchw(const void* x, const void* o, const float* wv, f
 int launch_light_apply_fwd_nchw(const void* x, const void* o, const float* wv, const float* gate, const float* sc,
                                 const float* sh, const float* lam, const float* dp, void* out, const SlabGeo& g,
                                 int d, int res, int dtype, int act, hipStream_t st);
-int launch_light_stats_bwd_nchw(const void* dout, const void* x, const void* o, const float* wv, float* bmom,
-                                const SlabGeo& g, int dtype, int act, hipStream_t st);
+int launch_light_stats_bwd_nchw(const void* dout, const void* x, const void* o, const float* wv, const float* mom,
+                                float* bmom, const SlabGeo& g, int dtype, int act, hipStream_t st);
 int launch_light_apply_bwd_nchw(const void* dout, const void* x, const void* o, const float* wv, const float* gate,
                                 const float* cb, const float* lam, const float* dp, const float* dyx, void* dx,
                                 void* dprev, float* dwv_part, const SlabGeo& g, int d, int res, int relu, int dtype,

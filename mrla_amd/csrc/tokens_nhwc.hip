@@ -172,8 +172,19 @@ __device__ __forceinline__ void tok_stat_masked(const float* __restrict__ stats,
   on = ok ? 1.f : 0.f;
 }
 
+// Rows of DMA look-ahead of the backward kernel (build-time: scripts/build_variant.sh).  1: the next step's rows are in
+// flight while a step computes.  2: two steps' rows -- the kernel is latency-bound (16 dependent row steps per wave, 1.5
+// two-wave workgroups per SIMD, ~1 150 instructions per step against a DMA round trip of about the same length), so the
+// wait at the top of a step is for a fetch issued a whole step earlier; needs double row buffers, a counted
+// `s_waitcnt vmcnt(N)` and LDS reads the compiler cannot fence behind the younger DMA (row_read_issue_asm).
+#ifndef MRLA_TOKEN_BWD_DEPTH
+#define MRLA_TOKEN_BWD_DEPTH 1
+#endif
+constexpr int kTokDepth = MRLA_TOKEN_BWD_DEPTH;
+static_assert(kTokDepth == 1 || kTokDepth == 2, "look-ahead depth");
+
 template <typename T> constexpr int tok_bwd_wave_bytes() {
-  return RowIO<T, kS + 4>::kBytes + RowIO<T, kS + 2>::kBytes + RowIO<T, kS>::kBytes + RowIO<float, kS>::kBytes;
+  return kTokDepth * (RowIO<T, kS + 4>::kBytes + RowIO<T, kS + 2>::kBytes + RowIO<T, kS>::kBytes) + RowIO<float, kS>::kBytes;
 }
 
 // BASE: the MRLA-base token module's value backward (mrla_token_base_value_bwd): dU is READ -- the dense dV_t image
@@ -189,10 +200,14 @@ __global__ __launch_bounds__(kMaxStrips * kWave) void token_apply_bwd_rows(
   const int lane = threadIdx.x & (kWave - 1), wave = threadIdx.x / kWave, nwaves = blockDim.x / kWave;
   float* red = reinterpret_cast<float*>(smem_raw);
   unsigned char* wbuf = smem_raw + (size_t)nwaves * (TQ_N + 1) * kWave * sizeof(float) + (size_t)wave * tok_bwd_wave_bytes<T>();
-  T* bufX = reinterpret_cast<T*>(wbuf);
-  T* bufG = reinterpret_cast<T*>(wbuf + RowIO<T, kS + 4>::kBytes);
-  T* bufO = reinterpret_cast<T*>(wbuf + RowIO<T, kS + 4>::kBytes + RowIO<T, kS + 2>::kBytes);
-  float* bufS = reinterpret_cast<float*>(wbuf + RowIO<T, kS + 4>::kBytes + RowIO<T, kS + 2>::kBytes + RowIO<T, kS>::kBytes);
+  constexpr int XB_ = RowIO<T, kS + 4>::kBytes, GB_ = RowIO<T, kS + 2>::kBytes, OB_ = RowIO<T, kS>::kBytes;
+  constexpr int SET = XB_ + GB_ + OB_;               // one step's row buffers; kTokDepth sets, parity (rr + 1) & 1
+  auto bufX = [&](int par) { return reinterpret_cast<T*>(wbuf + par * SET); };
+  auto bufG = [&](int par) { return reinterpret_cast<T*>(wbuf + par * SET + XB_); };
+  auto bufO = [&](int par) { return reinterpret_cast<T*>(wbuf + par * SET + XB_ + GB_); };
+  float* bufS = reinterpret_cast<float*>(wbuf + kTokDepth * SET);
+  // vector-memory instructions a step issues: its row fetches, then (steps rr >= 1) its row stores
+  constexpr int NF = RowIO<T, kS + 4>::NL + RowIO<T, kS + 2>::NL + (BASE ? 0 : RowIO<T, kS>::NL), NS = RowIO<float, kS>::NL;
   const int cbase = blockIdx.x * kWave, c = cbase + lane;
   const int b = blockIdx.y, W = side, H = side;
   const int nstrips = (W + kS - 1) / kS;
@@ -236,21 +251,40 @@ __global__ __launch_bounds__(kMaxStrips * kWave) void token_apply_bwd_rows(
 #pragma unroll
     for (int j = 0; j < kS; ++j) { h0[j] = 0.f; h1[j] = 0.f; }
     // step rr (= -1 .. H) consumes x row rr+1 and dOut / o rows rr
-    row_fetch<T, kS + 4>(ax, xi, 0, H, rowelems, bufX);
-    row_fetch<T, kS + 2>(ag, gi, -1, H, rowelems, bufG);
-    if (!BASE) row_fetch<T, kS>(ao, oi, -1, H, rowelems, bufO);
+    row_fetch<T, kS + 4>(ax, xi, 0, H, rowelems, bufX(0));
+    row_fetch<T, kS + 2>(ag, gi, -1, H, rowelems, bufG(0));
+    if (!BASE) row_fetch<T, kS>(ao, oi, -1, H, rowelems, bufO(0));
+    if (kTokDepth == 2) {                            // ... and step 0's rows
+      row_fetch<T, kS + 4>(ax, xi, 1, H, rowelems, bufX(1));
+      row_fetch<T, kS + 2>(ag, gi, 0, H, rowelems, bufG(1));
+      if (!BASE) row_fetch<T, kS>(ao, oi, 0, H, rowelems, bufO(1));
+    }
     auto step = [&](int rr, float (&XA)[kS + 4], float (&XB)[kS + 4], float (&XC)[kS + 4], float (&UA)[kS + 2],
                     float (&UB)[kS + 2], float (&UC)[kS + 2], float (&H0)[kS], float (&H1)[kS], float (&H2)[kS]) {
-      rows_landed();
-      row_read_issue<T, kS + 4>(bufX, lane, xr);
-      row_read_issue<T, kS + 2>(bufG, lane, gv);
-      if (!BASE) row_read_issue<T, kS>(bufO, lane, ov);
-      row_read_fence(xr, true);
-      row_read_fence(gv, false);
-      if (!BASE) row_read_fence(ov, false);
-      row_fetch<T, kS + 4>(ax, xi, rr + 2, H, rowelems, bufX);
-      row_fetch<T, kS + 2>(ag, gi, rr + 1, H, rowelems, bufG);
-      if (!BASE) row_fetch<T, kS>(ao, oi, rr + 1, H, rowelems, bufO);
+      const int par = kTokDepth == 2 ? ((rr + 1) & 1) : 0;
+      if (kTokDepth == 2) {
+        // this step's rows were fetched a whole step ago; what may stay in flight is everything issued after them: the
+        // previous step's fetches (for the NEXT step) and, once steps store (rr - 1 >= 1), its row stores
+        if (rr >= 2) rows_landed_keep<NF + NS>(); else rows_landed_keep<NF>();
+        row_read_issue_asm<T, kS + 4>(bufX(par), lane, xr);
+        row_read_issue_asm<T, kS + 2>(bufG(par), lane, gv);
+        if (!BASE) row_read_issue_asm<T, kS>(bufO(par), lane, ov);
+        row_read_fence_asm<T, kS + 4>(xr, true);
+        row_read_fence_asm<T, kS + 2>(gv, false);
+        if (!BASE) row_read_fence_asm<T, kS>(ov, false);
+      } else {
+        rows_landed();
+        row_read_issue<T, kS + 4>(bufX(par), lane, xr);
+        row_read_issue<T, kS + 2>(bufG(par), lane, gv);
+        if (!BASE) row_read_issue<T, kS>(bufO(par), lane, ov);
+        row_read_fence(xr, true);
+        row_read_fence(gv, false);
+        if (!BASE) row_read_fence(ov, false);
+      }
+      // the buffers just read are free: the rows of step rr + kTokDepth go there
+      row_fetch<T, kS + 4>(ax, xi, rr + 1 + kTokDepth, H, rowelems, bufX(par));
+      row_fetch<T, kS + 2>(ag, gi, rr + kTokDepth, H, rowelems, bufG(par));
+      if (!BASE) row_fetch<T, kS>(ao, oi, rr + kTokDepth, H, rowelems, bufO(par));
       // LN_x on the way in (row rr+1); pixels outside the map come out as exact zeros
 #pragma unroll
       for (int j = 0; j < kS + 4; ++j) {

@@ -131,13 +131,21 @@ def gen_light(ref, f64=False):
             mask = None
             if p > 0:
                 torch.manual_seed(1234)
-                mask = torch.floor((1 - p) + torch.rand((b, 1, 1, 1), dtype=dt))
+                mask = torch.floor((1 - p) + torch.rand((b, 1, 1, 1))).to(dt)
                 torch.manual_seed(1234)
             layer_out = blk.mrla.mrla(x)                       # a1
             m = blk.mrla(x, o)                                 # a2 (recomputes a1 inside)
             if p > 0:
                 torch.manual_seed(1234)
-            y = x + blk.drop_path(blk.bn_mrla(m))              # a3, resnet_mrla_light.py:116
+            # (float64 run: the stochastic-depth draw is an INPUT, not arithmetic -- utils/drop.py:20 draws it in x's dtype, and
+            # a float64 draw from the same seed is another mask; hand it the float32 draw so both fixtures drop the same images)
+            real_rand = torch.rand
+            if f64:
+                torch.rand = lambda *a, **k: real_rand(*a, **{**k, "dtype": torch.float32}).to(k.get("dtype", torch.float32))
+            try:
+                y = x + blk.drop_path(blk.bn_mrla(m))          # a3, resnet_mrla_light.py:116
+            finally:
+                torch.rand = real_rand
             (y * T(g_np).to(dt)).sum().backward()
             k = f"{name}/{mode}/"
             if mode == "train":

@@ -1,5 +1,5 @@
 """GPU micro-benchmark of the MRLA streaming kernels through the C ABI, per ResNet-50 stage shape (b=256, bf16).
-Usage: python scripts/kbench.py [reps] [kernel-substring]"""
+Usage: [KBENCH_LIB=scripts/variants/libmrla_hip_<name>.so] [LAYOUT=nhwc] python scripts/kbench.py [reps] [kernel-substring]"""
 import ctypes
 import os
 import sys
@@ -8,6 +8,9 @@ import torch
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from mrla_amd import _lib as L  # noqa: E402
+
+if os.environ.get("KBENCH_LIB"):          # an experiment build (scripts/build_variant.sh) instead of the product library
+    L.LIB_PATH = os.path.abspath(os.environ["KBENCH_LIB"])
 
 reps = int(sys.argv[1]) if len(sys.argv) > 1 else 20
 only = sys.argv[2] if len(sys.argv) > 2 else ""

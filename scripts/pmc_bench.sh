@@ -7,7 +7,7 @@ OUT=${1:-gpurun_out/pmc_bench}
 ARGS=${BENCH_ARGS:-}            # e.g. BENCH_ARGS="--arch resnet101_mrlab --batch 128"
 RAW=/tmp/pmc_raw_$$           # raw traces are large: only the summaries go back through gpurun_out/
 mkdir -p $OUT $RAW
-cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
+ROOT=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}; cd /tmp && export TMPDIR=/tmp && cd "$ROOT"
 if [ "${TRACE_ONLY:-0}" != "1" ]; then
 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $RAW/fetch -- python3 bench.py $ARGS --steps 2 --warmup 2 --no-baselines --benchmark 0 > $OUT/fetch.log 2>&1
 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $RAW/write -- python3 bench.py $ARGS --steps 2 --warmup 2 --no-baselines --benchmark 0 > $OUT/write.log 2>&1

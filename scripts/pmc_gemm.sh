@@ -7,7 +7,7 @@ set -u
 OUT=${1:-gpurun_out/pmc_gemm}
 RAW=/tmp/pmc_gemm_$$
 mkdir -p $OUT $RAW
-cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
+ROOT=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}; cd /tmp && export TMPDIR=/tmp && cd "$ROOT"
 NOSTOCK=1 rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_WAVE_CYCLES SQ_WAIT_INST_LDS SQ_WAIT_ANY --output-format csv -d $RAW/ks -- python3 scripts/ksbench.py 3 > $OUT/ks.log 2>&1
 python3 - "$RAW" "$OUT" <<'PY'
 import csv, glob, sys, collections, json

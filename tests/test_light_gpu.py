@@ -97,7 +97,10 @@ def test_light_tail_fp32_vs_oracle_and_reference(case, mode, cl):
     assert relmax(got["grad/mrla.mrla.Wv.weight"], G[key + "grad/mrla.mrla.Wv.weight"]) < GOLD_TOL
     assert relmax(got["grad/mrla.lambda_t"], G[key + "grad/mrla.lambda_t"]) < GOLD_TOL
     # ... and against the reference run in float64 (light_blocks_f64.npz): every parameter gradient, the Wq / Wk sums included
+    # (torch.rand draws another stochastic-depth mask in float64: those cases are covered where the masks coincide)
     G64 = cases.golden("light_blocks_f64")
+    if mask is not None and not np.array_equal(G64[key + "dp_mask"], mask):
+        return
     for ours in ("mrla.mrla.Wq.weight", "mrla.mrla.Wk.weight", "mrla.mrla.Wv.weight", "mrla.lambda_t", "bn_mrla.weight",
                  "bn_mrla.bias"):
         assert relmax(got["grad/" + ours].ravel(), G64[key + "grad/" + ours].ravel()) < par_tol(ours), ours
@@ -292,11 +295,13 @@ def test_wide_nchw_maps_run_through_one_internal_channels_last_conversion(shape)
     assert y.is_contiguous() and y.view(b, c // d, d, h, w).shape[1] == c // d
 
 
-@pytest.mark.parametrize("cl,ratio", [(False, 30.0), (True, 30.0), (True, 1000.0)], ids=["nchw-30", "nhwc-30", "nhwc-1000"])
+@pytest.mark.parametrize("cl,ratio", [(False, 30.0), (False, 1000.0), (True, 30.0), (True, 1000.0)],
+                         ids=["nchw-30", "nchw-1000", "nhwc-30", "nhwc-1000"])
 def test_closed_form_bn_mrla_statistics_with_offset_inputs(cl, ratio):
-    """bn_mrla's batch statistics come in closed form from per-(image, channel) moments of V and o_{t-1}.  The NHWC kernels
-    (the production path) take those moments about per-plane pivots, so |mean| / sigma ~ 1e3 in o and, through the 3x3 taps,
-    in V costs nothing; the NCHW kernels accumulate raw fp32 sums (error ~ eps * ratio^2: checked at ratio 30).  The
+    """bn_mrla's batch statistics come in closed form from per-(image, channel) moments of V and o_{t-1}.  Both kernel
+    families -- the NHWC row pipeline and (since round 4) the NCHW slab kernels that serve the reference's own layout
+    contract (mrla_light_module.py:62-64) -- take those moments about per-plane pivots, so |mean| / sigma ~ 1e3 in o and,
+    through the 3x3 taps, in V costs nothing (raw fp32 sums: error ~ eps * ratio^2, 10 % parameter gradients at 1e3).  The
     elementwise passes evaluate affine forms of V and o in fp32, which bounds every output at ~ eps * ratio."""
     from oracle import detgen
     b, c, h, w, d = 4, 64, 14, 14, 32
@@ -307,15 +312,14 @@ def test_closed_form_bn_mrla_statistics_with_offset_inputs(cl, ratio):
     P = cases.block_params(c, 11)
     got = run_light(x, o, P, d, "train", None, 0.0, gup, cl=cl)
     out, cache, g = oracle_light(x, o, P, d, "train", None, 0.0, gup)
-    tol = 2e-3 if not cl else max(2e-4, 1.5e-6 * ratio)
+    tol = max(2e-4, 1.5e-6 * ratio)
     assert relmax(got["rv"], cache["bn"]["new_rv"]) < tol
     assert relmax(got["out"] - x, out - x) < tol          # the normalised branch (x itself is ~ratio)
     assert relmax(got["dx"], g["dx"]) < 3 * tol
     assert relmax(got["do"], g["do_prev"]) < 3 * tol
-    # parameter gradients: on the NHWC path the backward statistics pass takes sum dOut*V and sum dOut*o about the forward
-    # pivots (mrla_light_stats_bwd's `mom`), so they hold to 1e-3 at ratio 1e3 as well (raw fp32 sums: 10 % there);
-    # the NCHW kernels keep raw sums (error ~ eps * ratio * sqrt(pixels) of a plane, checked at ratio 30)
-    ptol = 1e-3 if cl else 10 * tol
+    # parameter gradients: the backward statistics pass takes sum dOut*V and sum dOut*o about the forward pivots
+    # (mrla_light_stats_bwd's `mom`), so they hold to 1e-3 at ratio 1e3 as well (raw fp32 sums: 10 % there)
+    ptol = 1e-3
     for ours, theirs in (("mrla.mrla.Wv.weight", "dwv"), ("mrla.lambda_t", "dlam"), ("bn_mrla.weight", "dgamma"),
                          ("bn_mrla.bias", "dbeta")):
         assert relmax(got["grad/" + ours].ravel(), np.asarray(g[theirs]).ravel()) < ptol, ours

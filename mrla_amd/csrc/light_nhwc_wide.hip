@@ -16,15 +16,14 @@
 #ifndef MRLA_STREAM_MB
 #define MRLA_STREAM_MB 128
 #endif
-// Build-time experiment switches of the fused forward statistics pass (scripts/build_variant.sh; profiles/r04_notes.md):
-// waves per workgroup at most (a wave then walks several strips of a wide image) and a register cap (waves per SIMD).
-#ifndef MRLA_FUSED_MAXWAVES
-#define MRLA_FUSED_MAXWAVES kMaxStrips
-#endif
-#ifdef MRLA_FUSED_WAVES_PER_EU
-#define MRLA_FUSED_OCC __attribute__((amdgpu_waves_per_eu(MRLA_FUSED_WAVES_PER_EU, MRLA_FUSED_WAVES_PER_EU)))
-#else
-#define MRLA_FUSED_OCC
+// Occupancy of the fused forward statistics pass (round 4, profiles/r04_notes.md): at 150 - 162 VGPRs three waves fit a
+// SIMD, i.e. ONE eight-wave workgroup per CU on the 56-wide stage (8 strips) -- half the waves apply_fwd keeps in flight on
+// the same 3N bytes (SQ counters side by side: 37 % of its wave cycles wait against apply_fwd's 71 %, it simply has too few
+// waves).  Capped at 128 registers (four waves per SIMD, two such workgroups per CU; 19 - 26 values spilled) the 56-wide
+// launch runs 305 -> 280 us (4.04 -> 4.41 TB/s); the narrower stages already hold 3 - 12 smaller workgroups per CU and
+// lose 1 - 11 % to the spills, so only eight-strip launches take the capped instance (MRLA_FUSED_CAP_MINWAVES).
+#ifndef MRLA_FUSED_CAP_MINWAVES
+#define MRLA_FUSED_CAP_MINWAVES 8
 #endif
 // Cache policy of the row fetches (template AUX: 0 = default, 2 = nt / streaming) and image order, measured in the
 // training step (b = 256, same box, GB/s):            stats_fwd_fused  apply_fwd  stats_bwd  apply_bwd
@@ -317,7 +316,7 @@ __device__ __forceinline__ void form_x_row(const RawRow<kS + 2>& pre, const RawR
 template <typename T> constexpr int fused_wave_bytes() { return 3 * RowIO<T, kS + 2>::kBytes + RowIO<T, kS>::kBytes; }
 
 template <typename T, bool AFF, bool RAGGED, int AUX>
-__global__ __launch_bounds__(kMaxStrips * kWave) MRLA_FUSED_OCC void light_stats_fwd_fused_wide(
+__device__ __forceinline__ void light_stats_fwd_fused_body(
     const T* __restrict__ pre, const T* __restrict__ o, const float* __restrict__ wv, float* __restrict__ mom,
     T* __restrict__ xout, const float* __restrict__ psc, const float* __restrict__ psh, T* __restrict__ vout, int B,
     int C, int H, int W, int BG) {
@@ -414,6 +413,22 @@ __global__ __launch_bounds__(kMaxStrips * kWave) MRLA_FUSED_OCC void light_stats
     }
     store_moments(wm, red, mom + ((size_t)b * C + c) * M_REC, lane, wave, nwaves);
   }
+}
+
+// The two instances of the pass: the compiler's own register allocation, and capped at four waves per SIMD (see the top).
+template <typename T, bool AFF, bool RAGGED, int AUX>
+__global__ __launch_bounds__(kMaxStrips * kWave) void light_stats_fwd_fused_wide(
+    const T* __restrict__ pre, const T* __restrict__ o, const float* __restrict__ wv, float* __restrict__ mom,
+    T* __restrict__ xout, const float* __restrict__ psc, const float* __restrict__ psh, T* __restrict__ vout, int B,
+    int C, int H, int W, int BG) {
+  light_stats_fwd_fused_body<T, AFF, RAGGED, AUX>(pre, o, wv, mom, xout, psc, psh, vout, B, C, H, W, BG);
+}
+template <typename T, bool AFF, bool RAGGED, int AUX>
+__global__ __launch_bounds__(kMaxStrips * kWave) __attribute__((amdgpu_waves_per_eu(4, 4))) void light_stats_fwd_fused_wide_occ4(
+    const T* __restrict__ pre, const T* __restrict__ o, const float* __restrict__ wv, float* __restrict__ mom,
+    T* __restrict__ xout, const float* __restrict__ psc, const float* __restrict__ psh, T* __restrict__ vout, int B,
+    int C, int H, int W, int BG) {
+  light_stats_fwd_fused_body<T, AFF, RAGGED, AUX>(pre, o, wv, mom, xout, psc, psh, vout, B, C, H, W, BG);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -792,12 +807,17 @@ int launch_light_stats_fwd_wide(const void* x, const void* o, const float* wv, f
   const int bg = nhwc_images_per_group(B, C, 0);
   if (xout) {                     // the fused producer (needs o, no activation on V)
     if (!o || act) return MRLA_EINVAL;
+#define CALL_K(KERNEL, T, AF, RG, NT)                                                                               \
+  {                                                                                                                 \
+    if (set_lds_n(KERNEL<T, AF, RG, NT>, L.lds) != hipSuccess) return MRLA_EHIP;                                     \
+    hipLaunchKernelGGL((KERNEL<T, AF, RG, NT>), L.grid, L.block, L.lds, st, (const T*)x, (const T*)o, wv, mom,       \
+                       (T*)xout, psc, psh, (T*)vout, B, C, H, W, L.BG);                                             \
+  }
 #define CALL_N(T, AF, RG, NT)                                                                                       \
   {                                                                                                                 \
-    const WideLaunch L = wide_launch(B, C, W, kMomRed, fused_wave_bytes<T>(), bg, MRLA_FUSED_MAXWAVES);                  \
-    if (set_lds_n(light_stats_fwd_fused_wide<T, AF, RG, NT>, L.lds) != hipSuccess) return MRLA_EHIP;                  \
-    hipLaunchKernelGGL((light_stats_fwd_fused_wide<T, AF, RG, NT>), L.grid, L.block, L.lds, st, (const T*)x, (const T*)o, \
-                       wv, mom, (T*)xout, psc, psh, (T*)vout, B, C, H, W, L.BG);                                    \
+    const WideLaunch L = wide_launch(B, C, W, kMomRed, fused_wave_bytes<T>(), bg);                                   \
+    if ((int)L.block.x >= MRLA_FUSED_CAP_MINWAVES * kWave) CALL_K(light_stats_fwd_fused_wide_occ4, T, AF, RG, NT)     \
+    else CALL_K(light_stats_fwd_fused_wide, T, AF, RG, NT)                                                          \
   }
 #define CALL_R(T, AF, RG) { if (stream_fetches(B, C, H, W, sizeof(T))) CALL_N(T, AF, RG, 2) else CALL_N(T, AF, RG, 0) }
 #define CALL_A(T, AF) { if (ragged) CALL_R(T, AF, true) else CALL_R(T, AF, false) }
@@ -812,6 +832,7 @@ int launch_light_stats_fwd_wide(const void* x, const void* o, const float* wv, f
 #undef CALL_A
 #undef CALL_R
 #undef CALL_N
+#undef CALL_K
     return hip_status(hipGetLastError());
   }
 #define CALL_R(T, A, O, RG)                                                                                         \

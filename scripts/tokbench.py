@@ -76,5 +76,6 @@ if variant:
     if "--check" in sys.argv:
         for k in a:
             same = torch.equal(a[k], b[k])
-            print(f"check {k:6s} {'bit-identical' if same else 'DIFFERS: max abs ' + str((a[k] - b[k]).abs().max().item())}")
-            assert same, k
+            nan = (torch.isnan(a[k]).sum().item(), torch.isnan(b[k]).sum().item())
+            print(f"check {k:6s} {'bit-identical' if same else 'DIFFERS: max abs ' + str((a[k] - b[k]).abs().nan_to_num(1e30).max().item())} (NaNs: product {nan[0]}, variant {nan[1]})")
+        assert all(torch.equal(a[k], b[k]) for k in a)

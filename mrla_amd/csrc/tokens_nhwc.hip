@@ -28,20 +28,27 @@ __device__ __forceinline__ float2 tok_stat(const float* __restrict__ stats, int 
   return *reinterpret_cast<const float2*>(stats + idx);
 }
 
-// raw row -> LN_x(x) row on window columns col0 .. col0+NPX-1 of map row r (0 outside the map)
+// raw row -> LN_x(x) row on window columns col0 .. col0+NPX-1 of map row r (0 outside the map).
+// Two phases: ALL the row's (mean, rstd) scalar loads are issued first and waited for once (written pixel by pixel the
+// compiler put one `s_load_dwordx2` + `s_waitcnt lgkmcnt(0)` in front of every pixel's arithmetic -- NPX dependent scalar-
+// cache round trips per row step, the same stall the backward kernel had: profiles/r04_notes.md).
 template <int NPX>
 __device__ __forceinline__ void normalise_row(float (&v)[NPX], const float* __restrict__ stats, int tok0, int side, int r,
                                               int col0, float wxc, float bxc) {
   const bool rowok = r >= 0 && r < side;
+  float2 st[NPX];
 #pragma unroll
   for (int j = 0; j < NPX; ++j) {
     const int col = col0 + j;
-    if (rowok && col >= 0 && col < side) {                         // wave-uniform
-      const float2 s = tok_stat(stats, tok0, side, r, col, TS_MX);
-      v[j] = fmaf((v[j] - s.x) * s.y, wxc, bxc);
-    } else {
-      v[j] = 0.f;
-    }
+    const bool ok = rowok && col >= 0 && col < side;               // wave-uniform
+    st[j] = tok_stat(stats, tok0, side, ok ? r : 0, ok ? col : 0, TS_MX);     // (a valid record when masked)
+  }
+  asm volatile("" ::: "memory");                                   // keep the loads together, ahead of the arithmetic
+#pragma unroll
+  for (int j = 0; j < NPX; ++j) {
+    const int col = col0 + j;
+    const bool ok = rowok && col >= 0 && col < side;
+    v[j] = ok ? fmaf((v[j] - st[j].x) * st[j].y, wxc, bxc) : 0.f;
   }
 }
 
@@ -107,13 +114,13 @@ __global__ __launch_bounds__(kMaxStrips * kWave) void token_apply_fwd_nhwc(
 #pragma unroll
       for (int j = 0; j < kS; ++j) xnext[j] = rc[j + 1];
       normalise_row<kS + 2>(rc, stats, tok0, side, r + 1, s0 - 1, wxc, bxc);
+      float2 sto[kS];
+#pragma unroll
+      for (int j = 0; j < kS; ++j) sto[j] = tok_stat(stats, tok0, side, r, j < nc ? s0 + j : s0, TS_MO);   // issued together
+      asm volatile("" ::: "memory");
 #pragma unroll
       for (int j = 0; j < kS; ++j) {
-        float on = 0.f;
-        if (j < nc) {
-          const float2 so = tok_stat(stats, tok0, side, r, s0 + j, TS_MO);
-          on = fmaf((ov[j] - so.x) * so.y, woc, boc);
-        }
+        const float on = j < nc ? fmaf((ov[j] - sto[j].x) * sto[j].y, woc, boc) : 0.f;
         y[j] = fmaf(a, gelu_f(conv_at(w, ra, rb, rc, j)), fmaf(lm, on, resf * xraw[j]));
       }
       write_row<T, true, kS>(yo, r, s0, nc, W, C, cbase, c, true, lane, reinterpret_cast<T*>(scrS), y);
@@ -172,6 +179,65 @@ __device__ __forceinline__ void tok_stat_masked(const float* __restrict__ stats,
   on = ok ? 1.f : 0.f;
 }
 
+
+// ------------------------------------------------------------------------------------------------
+// LayerNorm statistics of a window row through LDS (round 4).  The (mean, rstd) pairs of the window's tokens are
+// wave-uniform; fetched one by one through the scalar cache (tok_stat_masked: 18 dependent `s_load_dwordx2` + waits per
+// row step) they were what the backward kernel's waves waited for -- SQ counters: 34 % of its wave cycles in waits that a
+// second row of DMA look-ahead did not move (profiles/r04_notes.md).  Here the window's 11 records [mean_x, rstd_x, mean_o,
+// rstd_o] travel with the rows: ONE `buffer_load_dword ... lds` per step (lane l -> float l of the window's records;
+// tokens outside the map arrive as zeros from the bounds check: rstd = 0 switches their LayerNorm off), read back as
+// broadcast `ds_read_b64` in the same issue / fence block as the row reads.  A row's records serve twice: LN_x of window
+// row rr+1 in one step, LN_o of the owned pixels of row rr in the next (two 256-byte buffers per wave, parity = row & 1).
+// ------------------------------------------------------------------------------------------------
+constexpr int kStatBufBytes = 256;
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+template <int N> struct StatRow { f32x2 v[N]; };                  // (mean, rstd) per token
+
+// this lane's byte offset inside a row of stats records for window start column col0 (kRowOob: no such float)
+__device__ __forceinline__ unsigned stat_voff(int col0, int ntok, int side, int lane) {
+  const int j = lane >> 2, comp = lane & 3, col = col0 + j;
+  return (j < ntok && col >= 0 && col < side) ? (unsigned)((col * TS_N + comp) * 4) : kRowOob;
+}
+// DMA of map row r's records (tokens tok0 + r*side ..) into `sbuf`; rows outside [0, side): zeros
+__device__ __forceinline__ void stat_fetch(const float* __restrict__ stats, int tok0, int side, int r, unsigned voff,
+                                           float* sbuf) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  const bool live = r >= 0 && r < side;                 // wave-uniform
+  const auto rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(stats) + (size_t)(tok0 + (live ? r : 0) * side) * TS_N,
+                                                    0, live ? side * TS_N * 4 : 0, kBufFlags);
+  __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_void_ptr)sbuf, 4, voff, 0, 0, 0);
+#endif
+}
+#define MRLA_B64(i, off) "ds_read_b64 %" #i ", %[a] offset:" #off "\n\t"
+// LN_x records of the 11 window tokens (floats 0..1 of each 16-byte record)
+__device__ __forceinline__ void stat_read_issue_x(const float* sbuf, StatRow<kS + 4>& o) {
+  static_assert(kS + 4 == 11, "window width");
+  const unsigned a = lds_addr_of(sbuf);
+  asm volatile(MRLA_B64(0, 0) MRLA_B64(1, 16) MRLA_B64(2, 32) MRLA_B64(3, 48) MRLA_B64(4, 64) MRLA_B64(5, 80) MRLA_B64(6, 96)
+               MRLA_B64(7, 112) MRLA_B64(8, 128) MRLA_B64(9, 144) MRLA_B64(10, 160) ""
+               : "=&v"(o.v[0]), "=&v"(o.v[1]), "=&v"(o.v[2]), "=&v"(o.v[3]), "=&v"(o.v[4]), "=&v"(o.v[5]), "=&v"(o.v[6]),
+                 "=&v"(o.v[7]), "=&v"(o.v[8]), "=&v"(o.v[9]), "=&v"(o.v[10])
+               : [a] "v"(a) : "memory");
+}
+// LN_o records of the 7 owned tokens = window tokens 2..8 (floats 2..3 of each record)
+__device__ __forceinline__ void stat_read_issue_o(const float* sbuf, StatRow<kS>& o) {
+  static_assert(kS == 7, "strip width");
+  const unsigned a = lds_addr_of(sbuf);
+  asm volatile(MRLA_B64(0, 40) MRLA_B64(1, 56) MRLA_B64(2, 72) MRLA_B64(3, 88) MRLA_B64(4, 104) MRLA_B64(5, 120) MRLA_B64(6, 136) ""
+               : "=&v"(o.v[0]), "=&v"(o.v[1]), "=&v"(o.v[2]), "=&v"(o.v[3]), "=&v"(o.v[4]), "=&v"(o.v[5]), "=&v"(o.v[6])
+               : [a] "v"(a) : "memory");
+}
+#undef MRLA_B64
+// ties the registers to the (already executed) s_waitcnt of the step's first fence
+__device__ __forceinline__ void stat_fence(StatRow<kS + 4>& o) {
+  asm volatile("" : "+v"(o.v[0]), "+v"(o.v[1]), "+v"(o.v[2]), "+v"(o.v[3]), "+v"(o.v[4]), "+v"(o.v[5]), "+v"(o.v[6]),
+                    "+v"(o.v[7]), "+v"(o.v[8]), "+v"(o.v[9]), "+v"(o.v[10]) : : "memory");
+}
+__device__ __forceinline__ void stat_fence_wait(StatRow<kS>& o) {
+  asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(o.v[0]), "+v"(o.v[1]), "+v"(o.v[2]), "+v"(o.v[3]), "+v"(o.v[4]), "+v"(o.v[5]), "+v"(o.v[6]) : : "memory");
+}
+
 // Rows of DMA look-ahead of the backward kernel (build-time: scripts/build_variant.sh).  1: the next step's rows are in
 // flight while a step computes.  2: two steps' rows -- the kernel is latency-bound (16 dependent row steps per wave, 1.5
 // two-wave workgroups per SIMD, ~1 150 instructions per step against a DMA round trip of about the same length), so the
@@ -184,7 +250,8 @@ constexpr int kTokDepth = MRLA_TOKEN_BWD_DEPTH;
 static_assert(kTokDepth == 1 || kTokDepth == 2, "look-ahead depth");
 
 template <typename T> constexpr int tok_bwd_wave_bytes() {
-  return kTokDepth * (RowIO<T, kS + 4>::kBytes + RowIO<T, kS + 2>::kBytes + RowIO<T, kS>::kBytes) + RowIO<float, kS>::kBytes;
+  return kTokDepth * (RowIO<T, kS + 4>::kBytes + RowIO<T, kS + 2>::kBytes + RowIO<T, kS>::kBytes) + RowIO<float, kS>::kBytes +
+         (kTokDepth + 2) * kStatBufBytes;
 }
 
 // BASE: the MRLA-base token module's value backward (mrla_token_base_value_bwd): dU is READ -- the dense dV_t image
@@ -206,8 +273,14 @@ __global__ __launch_bounds__(kMaxStrips * kWave) void token_apply_bwd_rows(
   auto bufG = [&](int par) { return reinterpret_cast<T*>(wbuf + par * SET + XB_); };
   auto bufO = [&](int par) { return reinterpret_cast<T*>(wbuf + par * SET + XB_ + GB_); };
   float* bufS = reinterpret_cast<float*>(wbuf + kTokDepth * SET);
-  // vector-memory instructions a step issues: its row fetches, then (steps rr >= 1) its row stores
-  constexpr int NF = RowIO<T, kS + 4>::NL + RowIO<T, kS + 2>::NL + (BASE ? 0 : RowIO<T, kS>::NL), NS = RowIO<float, kS>::NL;
+  // LayerNorm records of map row r live in stat buffer r mod (kTokDepth + 2): rows rr .. rr + kTokDepth are alive in a step,
+  // and the row fetched during the step must not land on row rr's (its LN_o records are read late in the step)
+  auto sbuf = [&](int r) {
+    const int m = r + (kTokDepth + 2);               // r >= -1
+    return reinterpret_cast<float*>(wbuf + kTokDepth * SET + RowIO<float, kS>::kBytes) + (m % (kTokDepth + 2)) * (kStatBufBytes / 4);
+  };
+  // vector-memory instructions a step issues: its row fetches (+ the stats row), then (steps rr >= 1) its row stores
+  constexpr int NF = RowIO<T, kS + 4>::NL + RowIO<T, kS + 2>::NL + (BASE ? 0 : RowIO<T, kS>::NL) + 1, NS = RowIO<float, kS>::NL;
   const int cbase = blockIdx.x * kWave, c = cbase + lane;
   const int b = blockIdx.y, W = side, H = side;
   const int nstrips = (W + kS - 1) / kS;
@@ -237,9 +310,12 @@ __global__ __launch_bounds__(kMaxStrips * kWave) void token_apply_bwd_rows(
     make_row_io<T, kS + 2>(ag, s0 - 1, kS + 2, W, C, cbase, lane);
     make_row_io<T, kS>(ao, s0, nc, W, C, cbase, lane);
     make_row_io<float, kS>(as, s0, nc, W, C, cbase, lane);
+    const unsigned svoff = stat_voff(s0 - 2, kS + 4, side, lane);
     RawRow<kS + 4> xr;
     RawRow<kS + 2> gv;
     RawRow<kS> ov;
+    StatRow<kS + 4> sx;                              // LN_x (mean, rstd) of window row rr+1
+    StatRow<kS> so;                                  // LN_o (mean, rstd) of the owned pixels of row rr
     xr.clear(); gv.clear(); ov.clear();
     float xa[kS + 4], xb[kS + 4], xc[kS + 4];        // xn rows rr-1, rr, rr+1 on columns s0-2 .. s0+kS+1
     float ua[kS + 2], ub[kS + 2], uc[kS + 2];        // dU rows rr-2, rr-1, rr on columns s0-1 .. s0+kS
@@ -254,10 +330,13 @@ __global__ __launch_bounds__(kMaxStrips * kWave) void token_apply_bwd_rows(
     row_fetch<T, kS + 4>(ax, xi, 0, H, rowelems, bufX(0));
     row_fetch<T, kS + 2>(ag, gi, -1, H, rowelems, bufG(0));
     if (!BASE) row_fetch<T, kS>(ao, oi, -1, H, rowelems, bufO(0));
+    if (!BASE) stat_fetch(stats, tok0, side, -1, svoff, sbuf(-1));      // (zeros: LN_o of the row above the map)
+    stat_fetch(stats, tok0, side, 0, svoff, sbuf(0));
     if (kTokDepth == 2) {                            // ... and step 0's rows
       row_fetch<T, kS + 4>(ax, xi, 1, H, rowelems, bufX(1));
       row_fetch<T, kS + 2>(ag, gi, 0, H, rowelems, bufG(1));
       if (!BASE) row_fetch<T, kS>(ao, oi, 0, H, rowelems, bufO(1));
+      stat_fetch(stats, tok0, side, 1, svoff, sbuf(1));
     }
     auto step = [&](int rr, float (&XA)[kS + 4], float (&XB)[kS + 4], float (&XC)[kS + 4], float (&UA)[kS + 2],
                     float (&UB)[kS + 2], float (&UC)[kS + 2], float (&H0)[kS], float (&H1)[kS], float (&H2)[kS]) {
@@ -269,6 +348,7 @@ __global__ __launch_bounds__(kMaxStrips * kWave) void token_apply_bwd_rows(
         row_read_issue_asm<T, kS + 4>(bufX(par), lane, xr);
         row_read_issue_asm<T, kS + 2>(bufG(par), lane, gv);
         if (!BASE) row_read_issue_asm<T, kS>(bufO(par), lane, ov);
+        stat_read_issue_x(sbuf(rr + 1), sx);
         row_read_fence_asm<T, kS + 4>(xr, true);
         row_read_fence_asm<T, kS + 2>(gv, false);
         if (!BASE) row_read_fence_asm<T, kS>(ov, false);
@@ -277,23 +357,30 @@ __global__ __launch_bounds__(kMaxStrips * kWave) void token_apply_bwd_rows(
         row_read_issue<T, kS + 4>(bufX(par), lane, xr);
         row_read_issue<T, kS + 2>(bufG(par), lane, gv);
         if (!BASE) row_read_issue<T, kS>(bufO(par), lane, ov);
+        stat_read_issue_x(sbuf(rr + 1), sx);
         row_read_fence(xr, true);
         row_read_fence(gv, false);
         if (!BASE) row_read_fence(ov, false);
+        if (sizeof(T) == 4) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // (generic fp32 row reads carry no fence)
       }
+      stat_fence(sx);
       // the buffers just read are free: the rows of step rr + kTokDepth go there
       row_fetch<T, kS + 4>(ax, xi, rr + 1 + kTokDepth, H, rowelems, bufX(par));
       row_fetch<T, kS + 2>(ag, gi, rr + kTokDepth, H, rowelems, bufG(par));
       if (!BASE) row_fetch<T, kS>(ao, oi, rr + kTokDepth, H, rowelems, bufO(par));
+      stat_fetch(stats, tok0, side, rr + 1 + kTokDepth, svoff, sbuf(rr + 1 + kTokDepth));
       // LN_x on the way in (row rr+1); pixels outside the map come out as exact zeros
 #pragma unroll
       for (int j = 0; j < kS + 4; ++j) {
-        float mean, rstd, on;
-        tok_stat_masked(stats, tok0, side, rr + 1, s0 - 2 + j, mean, rstd, on);
-        const float hat = (xr.v[j] - mean) * rstd;
+        const bool ok = rr + 1 >= 0 && rr + 1 < side && s0 - 2 + j >= 0 && s0 - 2 + j < side;      // wave-uniform
+        const float on = ok ? 1.f : 0.f;
+        const float hat = (xr.v[j] - sx.v[j].x) * sx.v[j].y;          // (rstd arrives as 0 outside the map)
         XC[j] = fmaf(hat, wxc, on * bxc);
         if (j >= 2 && j < kS + 2) H2[j - 2] = hat;
       }
+      // LN_o's records of row rr: read only now that LN_x's have been consumed (14 registers less at the peak); the wait
+      // sits in front of the first owned column, behind column 0's arithmetic
+      if (!BASE) stat_read_issue_o(sbuf(rr), so);
       // dU of row rr on columns s0-1 .. s0+kS (dOut is zero outside the map and in the steps rr = -1 and rr = H)
 #pragma unroll
       for (int j = 0; j < kS + 2; ++j) {
@@ -311,17 +398,10 @@ __global__ __launch_bounds__(kMaxStrips * kWave) void token_apply_bwd_rows(
         const float go = gv.v[j];
         const float du = a * go * gelu_grad_f(u);
         UC[j] = du;
+        if (j == 1) stat_fence_wait(so);             // LN_o's records (issued above, behind column 0's arithmetic)
         if (j >= 1 && j <= kS) {                     // owned column (compile-time after unroll)
           q[TQ_N] = fmaf(go, gelu_f(u), q[TQ_N]);
-          float mo, ro, on;
-          {
-            const bool ok = rr >= 0 && rr < side && s0 + j - 1 < side;         // wave-uniform
-            const int idx = __builtin_amdgcn_readfirstlane((tok0 + (ok ? rr * side + s0 + j - 1 : 0)) * TS_N + TS_MO);
-            const float2 so = *reinterpret_cast<const float2*>(stats + idx);
-            mo = so.x; ro = so.y; on = ok ? 1.f : 0.f;
-          }
-          (void)on;
-          const float ohat = (ov.v[j - 1] - mo) * ro;
+          const float ohat = (ov.v[j - 1] - so.v[j - 1].x) * so.v[j - 1].y;   // (go is zero where the token does not exist)
           q[TQ_LAM] = fmaf(go, fmaf(ohat, woc, boc), q[TQ_LAM]);
           q[TQ_LNOW] = fmaf(lm * go, ohat, q[TQ_LNOW]);
           q[TQ_LNOB] = fmaf(lm, go, q[TQ_LNOB]);

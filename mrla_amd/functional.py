@@ -684,12 +684,15 @@ class _BaseFn(torch.autograd.Function):
         pmom = torch.empty((b, c, t), dtype=torch.float32, device=dev)
         prows = L.load().mrla_base_pmom_rows(b, c, h, w, dt, layout)
         ppart = torch.empty((prows, t, c), dtype=torch.float32, device=dev) if nhwc else pmom
-        _call("mrla_base_attend_bwd", xc.numel() * es * (t + 3), _ptr(dout), _ptr(attn),
+        # (t + 3) N of streams + the fp32 partial rows of <dA_t, V_j> (one row of t x c floats per 16-pixel tile: 2 / 16 of the
+        # V bytes it reads -- the "9 %" the PMC pass sees above (t + 3) N; mrla_base_pmom_reduce reads them back)
+        _call("mrla_base_attend_bwd", xc.numel() * es * (t + 3) + (ppart.numel() * 4 if nhwc else 0), _ptr(dout), _ptr(attn),
               _ptr(bnbuf[0]) if cfg.tail else None, _ptr(bnbuf[1]) if cfg.tail else None, _ptr(dp32), _ptr(cb),
               _ptr(stage.V), _ptr(stage.dA), _ptr(ppart), b, c, h, w, T, t, dt, layout, st,
+              alg=xc.numel() * es * (t + 3),
               path=xc.numel() * es * (t + 1))                         # section 8(d): ~(2t + 3) N per layer, backward
         if nhwc:
-            _call("mrla_base_pmom_reduce", 0, _ptr(ppart), _ptr(pmom), b, c, t, prows, st)
+            _call("mrla_base_pmom_reduce", (ppart.numel() + pmom.numel()) * 4, _ptr(ppart), _ptr(pmom), b, c, t, prows, st)
         dyx = torch.empty((b, c), dtype=torch.float32, device=dev)
         dwqk_part = torch.empty((b, 2 * ks), dtype=torch.float32, device=dev)
         _call("mrla_base_gate_bwd", 0, _ptr(mom), _ptr(pmom), _ptr(stage.P), _ptr(q), _ptr(stage.K), _ptr(stage.dK),

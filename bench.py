@@ -18,10 +18,14 @@ into one HIP graph with the gradient exchange inside it (mrla_amd/distributed.py
 pre-flight (capture + replay of a 4-element all-reduce: if THAT fails the step is launched eagerly and the line says
 so).  Two exchange schedules are timed on the hardware -- ONE all-reduce after backward, and ~25 MB buckets sent from
 backward's hooks while backward still runs (what DistributedDataParallel does) -- both reported
-(`config.gradient_exchange_ab_ms`); the faster one runs the timed region (`--exchange` pins one).  If capturing the full
-step fails after a collective went into the capture, the communicator's state is unknown: the rank exits non-zero
-(the self-launching parent then starts ONE fresh set of ranks with `--graph 0`).  `--dp ddp` runs torch's
-DistributedDataParallel, launched kernel by kernel.  Rank 0 prints ONE JSON line.  Besides the contract keys it carries
+(`config.gradient_exchange_ab_ms`); the faster one runs the timed region (`--exchange` pins one).  An N > 1 run never
+ends without its number: BEFORE any collective goes into a capture, `steps` eagerly launched steps are timed as the
+contract says; if capturing the full step then fails on any rank (the ranks vote through the process group's TCP store,
+not through the collective library), rank 0 prints the line from that eager region (`config.launch` says so) and every
+rank leaves without touching the communicator again -- its state is unknown after a failed capture, and limping on with
+it is a hang on N ranks, not a fallback.  (Ranks that die instead: the self-launching parent starts ONE fresh set with
+`--graph 0`.)  `--dp ddp` runs torch's DistributedDataParallel, launched kernel by kernel.  Rank 0 prints ONE JSON line.
+Besides the contract keys it carries
   roofline      -- HBM roofline of the dominant MRLA kernel (mrla_light_apply_bwd), timed live with HIP events on the
                    launch stream over `steps` steps launched kernel by kernel (the timed region itself when it is not
                    graph-replayed, else the same steps run once more right after it: events cannot be read out of a
@@ -59,7 +63,6 @@ MFMA_BF16_PEAK_TFLOPS = 2500.0   # dense bf16 MFMA peak (same guide)
 # almost entirely MIOpen convolution flops, not this build's kernels -- reported for the "fraction of compute roofline"
 MODEL_GFLOP_PER_IMAGE = {"resnet50_mrlal": 24.8, "resnet101_mrlab": 48.7}
 OTHER_CONFIGS = (("deit_mrlal_tiny_patch16_224", 256), ("resnet101_mrlab", 128))      # BASELINE.json configs 4 and 5
-EXIT_CAPTURE_BROKEN = 17  # a collective went into a capture that then failed: this process must not touch the communicator again
 STATUS_ENV = "MRLA_BENCH_STATUS_FILE"
 
 
@@ -94,6 +97,9 @@ def parse():
                          "from backward's hooks as they fill (DistributedDataParallel's schedule, resnet/train.py:174); ab "
                          "(default): time both on this hardware, report both, run the timed region with the faster")
     ap.add_argument("--ab-steps", type=int, default=6, help="steps per schedule of the --exchange ab comparison")
+    ap.add_argument("--inject-capture-failure", action="store_true",
+                    help="diagnostic: raise inside the stream capture of the data-parallel step, after its collective has been "
+                         "enqueued -- exercises the 'report the eager region, leave without the communicator' path")
     ap.add_argument("--ddp-probe", action="store_true",
                     help="diagnostic on one GPU: a ONE-rank process group around the model, so that the N > 1 path -- the "
                          "exchange schedules, their hooks and the RCCL all-reduce launches, captured with --graph 1 -- runs "
@@ -129,31 +135,41 @@ def launch_ranks(args):
                "--master-addr", "127.0.0.1", "--master-port", str(free_port()), os.path.abspath(__file__)] + argv + extra
         print("bench.py: starting " + " ".join(cmd[1:8]) + " ...", file=sys.stderr, flush=True)
         rc = subprocess.call(cmd, env=env, cwd=os.getcwd())
-        broken = os.path.exists(status) and "capture_broken" in open(status).read()
         if os.path.exists(status):
             os.remove(status)
-        if rc == 0 or not broken:
+        if rc == 0 or extra:
             break
-        print("bench.py: the ranks gave up after a failed graph capture with a live collective; starting a fresh set of "
-              "ranks with --graph 0", file=sys.stderr, flush=True)
+        print(f"bench.py: the ranks ended with code {rc}; starting ONE fresh set of ranks with --graph 0 (no stream capture)",
+              file=sys.stderr, flush=True)
     return rc
 
 
-def capture_broken_exit(err):
-    """A collective was enqueued into a capture that failed: do not limp on with this communicator (on N ranks that is a
-    hang, not a fallback).  Leaves a marker for the self-launching parent and ends the process without running any
-    destructor that would talk to the communicator."""
-    print(f"error: HIP graph capture of the data-parallel step failed with a collective in flight ({type(err).__name__}: "
-          f"{err}); exiting instead of continuing on a communicator in unknown state", file=sys.stderr, flush=True)
+def all_ranks_ok(ok, tag, rank, world):
+    """Do all ranks agree that `tag` succeeded?  Voted through the process group's TCP store -- NOT through the collective
+    library: after a failed capture with a collective in it the communicator must not be touched again."""
+    import datetime
+    import torch.distributed as dist
+    if not dist.is_initialized():
+        return ok
+    store = dist.distributed_c10d._get_default_store()
+    store.set(f"mrla_bench/{tag}/{rank}", "1" if ok else "0")
+    keys = [f"mrla_bench/{tag}/{r}" for r in range(world)]
+    store.wait(keys, datetime.timedelta(seconds=300))
+    return all(store.get(k) == b"1" for k in keys)
+
+
+def leave_without_the_communicator(code=0):
+    """End this rank without running any destructor that would talk to a communicator in unknown state."""
+    sys.stdout.flush()
+    sys.stderr.flush()
     path = os.environ.get(STATUS_ENV)
-    if path:
+    if path and code != 0:
         try:
             with open(path, "a") as fh:
                 fh.write("capture_broken\n")
         except OSError:
             pass
-    sys.stdout.flush()
-    os._exit(EXIT_CAPTURE_BROKEN)
+    os._exit(code)
 
 
 # ------------------------------------------------------------------------------------------------------------------
@@ -496,37 +512,71 @@ def main():
     x = torch.randn(args.batch, 3, 224, 224, device="cuda", generator=gx)
     y = torch.randint(0, 1000, (args.batch,), device="cuda", generator=gy)
 
-    exchange, ab_ms, schedule = None, None, None
+    R = dict(args=args, rank=rank, world=world, seen=seen, dist_on=dist_on, dp=dp, layout=layout, x=x, net=None,
+             exchange=None, schedule=None, ab_ms=None, legs=True)
     graph = None
     launch = "kernel by kernel (PyTorch eager launches)" + launch_note
     graph_launch = "one HIP graph per step (captured fwd+loss+bwd" + ("+gradient all-reduce" if dist_on else "") + "+SGD), replayed"
+
+    def measured_eagerly_first(st):
+        """A complete measurement -- `steps` steps, bracketed as the contract says, per-kernel events on -- taken BEFORE any
+        collective goes into a stream capture.  If a capture then fails on any rank, THIS is what the line reports (the
+        ranks agree on that through the TCP store and leave without touching the communicator): an N > 1 run never ends
+        without its number."""
+        t = Fm.KernelTimer()
+        Fm.TIMER = t
+        d = timed(st, args.steps, 0)
+        Fm.TIMER = None
+        return dict(dt=d, timer=t)
+
+    def capture_or_fall_back(st, tag, warm, fb):
+        err = None
+
+        def poisoned():
+            st()
+            raise RuntimeError("injected failure inside the capture (--inject-capture-failure)")
+        try:
+            g = capture(poisoned if args.inject_capture_failure else st, True, 0 if args.inject_capture_failure else warm)
+        except Exception as e:                 # noqa: BLE001 -- whatever the runtime throws out of a broken capture
+            g, err = None, e
+        if all_ranks_ok(err is None, "capture/" + tag, rank, world):
+            return g
+        why = f"{type(err).__name__}: {err}" if err is not None else "failed on another rank"
+        print(f"warning: HIP graph capture of the data-parallel step failed ({why}); reporting the eager steps measured before it",
+              file=sys.stderr, flush=True)
+        if rank == 0:
+            report(dict(R, dt=fb["dt"], dt_eager=fb["dt"], timer=fb["timer"], use_graph=False, legs=False,
+                        launch="kernel by kernel (PyTorch eager launches; the HIP graph capture of the step failed -- "
+                               f"{why[:200]} -- so this is the eager region timed before the capture; the communicator was not "
+                               "used again)"))
+        leave_without_the_communicator(0)
+
     if dp == "flat":
         # ---- the flat exchange, both schedules measured on this hardware (config.gradient_exchange_ab_ms) ----
         net = net.cuda().train()
         opt = sgd(net.parameters())
         names = {"after": ["after_backward"], "overlap": ["bucketed_overlap"], "ab": ["after_backward", "bucketed_overlap"]}[args.exchange]
-        cands = {}
+        cands, fb = {}, None
         for i, name in enumerate(names):          # after_backward first: it registers no hooks that the other would trigger
             ex = D.FlatGradientExchange(net.parameters(), overlap=(name == "bucketed_overlap"), broadcast=(i == 0))
             st = make_step(net, opt, x, y, ex)
             for _ in range(args.warmup if i == 0 else 2):
                 st()
-            g = None
-            if use_graph:
-                try:
-                    g = capture(st, True, 3)
-                except Exception as e:
-                    capture_broken_exit(e)
+            if i == 0 and use_graph:
+                R.update(exchange=ex, schedule=name)
+                fb = measured_eagerly_first(st)
+            g = capture_or_fall_back(st, name, 3, fb) if use_graph else None
             run = g.replay if g is not None else st
             t = timed(run, args.ab_steps, 1) / args.ab_steps if len(names) > 1 else None
             cands[name] = dict(exchange=ex, step=st, graph=g, ms=None if t is None else round(1e3 * t, 3))
         schedule = min(cands, key=lambda k: cands[k]["ms"]) if len(names) > 1 else names[0]
-        ab_ms = {k: v["ms"] for k, v in cands.items()} if len(names) > 1 else None
         for k, v in cands.items():
             if k != schedule:
                 v["exchange"].remove_hooks()      # the loser's hooks must not fire in the winner's eager steps
                 v["graph"] = v["step"] = None
-        exchange, eager_step, graph = cands[schedule]["exchange"], cands[schedule]["step"], cands[schedule]["graph"]
+        R.update(exchange=cands[schedule]["exchange"], schedule=schedule,
+                 ab_ms={k: v["ms"] for k, v in cands.items()} if len(names) > 1 else None)
+        eager_step, graph = cands[schedule]["step"], cands[schedule]["graph"]
         del cands
         step = eager_step
         if graph is not None:
@@ -545,17 +595,18 @@ def main():
         eager_step = step = make_step(net, sgd(net.parameters()), x, y)
         for _ in range(args.warmup):                     # warm-up without the timer
             step()
-        if use_graph:
+        if use_graph and dist_on:
+            graph = capture_or_fall_back(eager_step, "ddp", 11, measured_eagerly_first(eager_step))
+            step, launch = graph.replay, graph_launch
+        elif use_graph:
             # the whole training step is launch-order static (no host sync inside): capture it once into a HIP graph and
             # replay it -- the same kernels on the same buffers, minus ~1 ms/step of launch gaps
             try:
-                graph = capture(eager_step, dist_on, 11 if dist_on else 2)
+                graph = capture(eager_step, False, 2)
                 step, launch = graph.replay, graph_launch
             except Exception as e:
-                if dist_on:
-                    capture_broken_exit(e)
                 print(f"warning: HIP graph capture failed ({type(e).__name__}: {e}); timing eager launches", file=sys.stderr)
-                step, use_graph = eager_step, False
+                step = eager_step
     use_graph = graph is not None
 
     timer = Fm.KernelTimer()                             # every C-ABI launch
@@ -572,89 +623,98 @@ def main():
         dt = timed(step, args.steps, 0)
         Fm.TIMER = None
         dt_eager = dt
-    ips = world * args.batch * args.steps / dt
-
     if rank == 0:
-        ks = timer.summary()
-        path_k = {k: v for k, v in ks.items() if is_path_kernel(k)}
-        big = {k: v for k, v in path_k.items() if v["bytes"] > 0}
-        dom_name = max(big, key=lambda k: big[k]["ms"]) if big else None        # the path's kernel with the most time
-        dom = ks.get(dom_name)
-        roofline = None
-        if dom:
-            sec = dom["ms"] * 1e-3
-            ach, ach_f = dom["bytes_alg"] / sec / 1e9, dom["bytes"] / sec / 1e9
-            path_ms = sum(v["ms"] for v in path_k.values())
-            path_b = sum(v["bytes_path"] for v in path_k.values())
-            # DeiT keeps its residual stream (and therefore the token MRLA kernels) in fp32 under autocast, as the reference does
-            kdt = "fp32" if args.arch.startswith("deit") else "bf16"
-            traffic, traffic_src = pmc_traffic(args, dom_name)
-            roofline = {"bound": "hbm", "kernel": f"{dom_name}<{kdt}>", "achieved": round(ach, 1),
-                        "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4),
-                        "traffic": traffic, "traffic_source": traffic_src,
-                        "launches": dom["launches"], "avg_launch_us": round(1e3 * dom["ms"] / dom["launches"], 2),
-                        "algorithmic_bytes_per_launch_avg": dom["bytes_alg"] // dom["launches"],
-                        "achieved_fused": round(ach_f, 1), "frac_fused": round(ach_f / HBM_PEAK_GBS, 4),
-                        "fused_bytes_per_launch_avg": dom["bytes"] // dom["launches"],
-                        "path_frac": round(path_b / (path_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if path_ms > 0 else None,
-                        "path_ms_per_step": round(path_ms / args.steps, 3),
-                        "path_bytes_per_step": path_b // args.steps,
-                        "convention": "achieved/frac: SURVEY.md 8(d) algorithmic bytes of this launch; *_fused: all bytes the "
-                                      "launch is built to move (differs where work of a neighbouring pass is folded in); "
-                                      "path_frac: 8(d) compulsory bytes of the whole MRLA path per step / time of all its "
-                                      "kernels (streaming passes + gate / reduce kernels) / peak"}
-        gx_desc = None
-        if dist_on:
-            gx_desc = {"flat": None if exchange is None else
-                       (f"{len(exchange.buckets)} all-reduce(s) (RCCL avg) over one flat fp32 gradient buffer"
-                        + (", sent from backward as its buckets fill" if schedule == "bucketed_overlap" else ", after backward")),
-                       "ddp": "DistributedDataParallel: 32 MB buckets, overlapped with backward"}[dp]
-        out = {"metric": f"images/sec fwd+bwd {args.arch} b={args.batch}", "value": round(ips, 1), "unit": "images/sec",
-               "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(1e3 * dt / args.steps, 3),
-               "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
-               "config": {"workload": f"{args.arch} fwd+bwd+SGD, {args.batch} images/GPU of 3x224x224, bf16 autocast, "
-                                      f"fp32 master weights, drop_path {args.drop_path}",
-                          "global_batch": world * args.batch, "parallelism": f"dp{world}", "launch": launch,
-                          "ranks_seen": seen,
-                          "backend": ({"nccl": "nccl (RCCL)"}.get(args.backend, args.backend) if dist_on else "none (single process)"),
-                          **({"gradient_exchange": gx_desc, "gradient_exchange_schedule": schedule,
-                              "gradient_exchange_ab_ms": ab_ms} if dist_on else {}),
-                          "path": "eager restatement" if args.eager else
-                                  f"mrla_amd (HIP MRLA tails incl. shortcut add+ReLU, HIP BatchNorm+ReLU(+stem max-pool), HIP MFMA GEMMs for the "
-                                  f"1x1 convolutions fwd / dgrad / wgrad where eligible, stock 3x3 / 7x7 / strided convolutions; {layout})"},
-               "eager_launch_ms_per_step": round(1e3 * dt_eager / args.steps, 3),
-               "roofline": roofline,
-               "mrla_kernels": {k: {"launches": v["launches"], "ms_per_step": round(v["ms"] / args.steps, 3),
-                                    **({"GBps": round(v["bytes"] / (v["ms"] * 1e-3) / 1e9, 1)} if v["bytes"] else {})}
-                                for k, v in ks.items()}}
-        if args.arch in MODEL_GFLOP_PER_IMAGE:
-            tf = ips * MODEL_GFLOP_PER_IMAGE[args.arch] / 1e3
-            out["compute_roofline"] = {"model_tflops": round(tf, 1), "peak_bf16_mfma_tflops": MFMA_BF16_PEAK_TFLOPS * world,
-                                       "frac": round(tf / (MFMA_BF16_PEAK_TFLOPS * world), 4),
-                                       "mfma_util_counter": mfma_counter(args),
-                                       "note": "whole-model flops (MIOpen convolutions); the MRLA kernels are HBM/VALU work"}
-        if world == 1 and not args.no_forward_only:
-            out["forward_only"] = forward_only(net, x, graph=use_graph)
-        if world == 1 and not dist_on and not args.no_baselines:
-            out["eager_rocm"] = eager_rocm(args.arch, args.batch, args.drop_path)
-            # like for like: both sides launched kernel by kernel by PyTorch (the eager restatement is never graph-replayed);
-            # the graph-replayed product forward against the same denominator is reported beside it, labelled
-            fo, den = out["forward_only"], out["eager_rocm"]["fwd_images_per_sec"]
-            fo["vs_eager_rocm"] = round(fo.get("eager_launch_fwd_images_per_sec", fo["fwd_images_per_sec"]) / den, 2)
-            if "graph_fwd_images_per_sec" in fo:
-                fo["graph_replay_vs_eager_rocm"] = round(fo["graph_fwd_images_per_sec"] / den, 2)
-            out["cpu_baseline"] = cpu_baseline(args.arch)
-            if not args.no_others and (args.arch, args.batch) == ("resnet50_mrlal", 256):
-                # this process goes idle: give its graph pool and cached blocks back first
-                graph = step = eager_step = net = None
-                import gc
-                gc.collect()
-                torch.cuda.empty_cache()
-                out["other_configs"] = run_other_configs()
-        print(json.dumps(out), flush=True)
+        graph = step = eager_step = None                 # (report() may hand the GPU to child processes)
+        report(dict(R, dt=dt, dt_eager=dt_eager, timer=timer, use_graph=use_graph, launch=launch, net=net))
     if dist_on:
         D.barrier()
         torch.distributed.destroy_process_group()
+
+
+def report(R):
+    """Rank 0: build and print the ONE JSON line from a finished measurement R (see main())."""
+    from mrla_amd import functional as Fm  # noqa: F401
+    args, world, seen, dist_on, dp = R["args"], R["world"], R["seen"], R["dist_on"], R["dp"]
+    dt, dt_eager, timer, launch, use_graph = R["dt"], R["dt_eager"], R["timer"], R["launch"], R["use_graph"]
+    exchange, schedule, ab_ms, layout, net, x = R["exchange"], R["schedule"], R["ab_ms"], R["layout"], R["net"], R["x"]
+    ips = world * args.batch * args.steps / dt
+    ks = timer.summary()
+    path_k = {k: v for k, v in ks.items() if is_path_kernel(k)}
+    big = {k: v for k, v in path_k.items() if v["bytes"] > 0}
+    dom_name = max(big, key=lambda k: big[k]["ms"]) if big else None        # the path's kernel with the most time
+    dom = ks.get(dom_name)
+    roofline = None
+    if dom:
+        sec = dom["ms"] * 1e-3
+        ach, ach_f = dom["bytes_alg"] / sec / 1e9, dom["bytes"] / sec / 1e9
+        path_ms = sum(v["ms"] for v in path_k.values())
+        path_b = sum(v["bytes_path"] for v in path_k.values())
+        # DeiT keeps its residual stream (and therefore the token MRLA kernels) in fp32 under autocast, as the reference does
+        kdt = "fp32" if args.arch.startswith("deit") else "bf16"
+        traffic, traffic_src = pmc_traffic(args, dom_name)
+        roofline = {"bound": "hbm", "kernel": f"{dom_name}<{kdt}>", "achieved": round(ach, 1),
+                    "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4),
+                    "traffic": traffic, "traffic_source": traffic_src,
+                    "launches": dom["launches"], "avg_launch_us": round(1e3 * dom["ms"] / dom["launches"], 2),
+                    "algorithmic_bytes_per_launch_avg": dom["bytes_alg"] // dom["launches"],
+                    "achieved_fused": round(ach_f, 1), "frac_fused": round(ach_f / HBM_PEAK_GBS, 4),
+                    "fused_bytes_per_launch_avg": dom["bytes"] // dom["launches"],
+                    "path_frac": round(path_b / (path_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if path_ms > 0 else None,
+                    "path_ms_per_step": round(path_ms / args.steps, 3),
+                    "path_bytes_per_step": path_b // args.steps,
+                    "convention": "achieved/frac: SURVEY.md 8(d) algorithmic bytes of this launch; *_fused: all bytes the "
+                                  "launch is built to move (differs where work of a neighbouring pass is folded in); "
+                                  "path_frac: 8(d) compulsory bytes of the whole MRLA path per step / time of all its "
+                                  "kernels (streaming passes + gate / reduce kernels) / peak"}
+    gx_desc = None
+    if dist_on:
+        gx_desc = {"flat": None if exchange is None else
+                   (f"{len(exchange.buckets)} all-reduce(s) (RCCL avg) over one flat fp32 gradient buffer"
+                    + (", sent from backward as its buckets fill" if schedule == "bucketed_overlap" else ", after backward")),
+                   "ddp": "DistributedDataParallel: 32 MB buckets, overlapped with backward"}[dp]
+    out = {"metric": f"images/sec fwd+bwd {args.arch} b={args.batch}", "value": round(ips, 1), "unit": "images/sec",
+           "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(1e3 * dt / args.steps, 3),
+           "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+           "config": {"workload": f"{args.arch} fwd+bwd+SGD, {args.batch} images/GPU of 3x224x224, bf16 autocast, "
+                                  f"fp32 master weights, drop_path {args.drop_path}",
+                      "global_batch": world * args.batch, "parallelism": f"dp{world}", "launch": launch,
+                      "ranks_seen": seen,
+                      "backend": ({"nccl": "nccl (RCCL)"}.get(args.backend, args.backend) if dist_on else "none (single process)"),
+                      **({"gradient_exchange": gx_desc, "gradient_exchange_schedule": schedule,
+                          "gradient_exchange_ab_ms": ab_ms} if dist_on else {}),
+                      "path": "eager restatement" if args.eager else
+                              f"mrla_amd (HIP MRLA tails incl. shortcut add+ReLU, HIP BatchNorm+ReLU(+stem max-pool), HIP MFMA GEMMs for the "
+                              f"1x1 convolutions fwd / dgrad / wgrad where eligible, stock 3x3 / 7x7 / strided convolutions; {layout})"},
+           "eager_launch_ms_per_step": round(1e3 * dt_eager / args.steps, 3),
+           "roofline": roofline,
+           "mrla_kernels": {k: {"launches": v["launches"], "ms_per_step": round(v["ms"] / args.steps, 3),
+                                **({"GBps": round(v["bytes"] / (v["ms"] * 1e-3) / 1e9, 1)} if v["bytes"] else {})}
+                            for k, v in ks.items()}}
+    if args.arch in MODEL_GFLOP_PER_IMAGE:
+        tf = ips * MODEL_GFLOP_PER_IMAGE[args.arch] / 1e3
+        out["compute_roofline"] = {"model_tflops": round(tf, 1), "peak_bf16_mfma_tflops": MFMA_BF16_PEAK_TFLOPS * world,
+                                   "frac": round(tf / (MFMA_BF16_PEAK_TFLOPS * world), 4),
+                                   "mfma_util_counter": mfma_counter(args),
+                                   "note": "whole-model flops (MIOpen convolutions); the MRLA kernels are HBM/VALU work"}
+    if world == 1 and R["legs"] and not args.no_forward_only:
+        out["forward_only"] = forward_only(net, x, graph=use_graph)
+    if world == 1 and R["legs"] and not dist_on and not args.no_baselines:
+        out["eager_rocm"] = eager_rocm(args.arch, args.batch, args.drop_path)
+        # like for like: both sides launched kernel by kernel by PyTorch (the eager restatement is never graph-replayed);
+        # the graph-replayed product forward against the same denominator is reported beside it, labelled
+        fo, den = out["forward_only"], out["eager_rocm"]["fwd_images_per_sec"]
+        fo["vs_eager_rocm"] = round(fo.get("eager_launch_fwd_images_per_sec", fo["fwd_images_per_sec"]) / den, 2)
+        if "graph_fwd_images_per_sec" in fo:
+            fo["graph_replay_vs_eager_rocm"] = round(fo["graph_fwd_images_per_sec"] / den, 2)
+        out["cpu_baseline"] = cpu_baseline(args.arch)
+        if not args.no_others and (args.arch, args.batch) == ("resnet50_mrlal", 256):
+            # this process goes idle: give its graph pool and cached blocks back first
+            R["net"] = net = None
+            import gc
+            gc.collect()
+            torch.cuda.empty_cache()
+            out["other_configs"] = run_other_configs()
+    print(json.dumps(out), flush=True)
 
 
 if __name__ == "__main__":

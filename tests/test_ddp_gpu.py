@@ -185,6 +185,29 @@ def test_bench_py_graph_captures_the_rccl_exchange_one_rank():
     assert rec["value"] > 0 and rec["eager_launch_ms_per_step"] > 0
 
 
+def test_bench_py_reports_the_eager_region_when_the_capture_breaks():
+    """A capture that fails AFTER a collective went into it leaves the communicator in unknown state: bench.py must not
+    limp on with it (on N ranks: a hang) and must not lose the measurement either.  With a failure injected inside the
+    capture (one-rank RCCL group) the line still comes, from the eager region timed BEFORE the capture, says so, and the
+    process ends with code 0 without a second set of ranks."""
+    import json
+    root = os.path.dirname(HERE)
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", PYTHONPATH=root)
+    env.pop("MRLA_DIST_BACKEND", None)
+    cmd = [sys.executable, os.path.join(root, "bench.py"), "--ddp-probe", "--steps", "2", "--warmup", "1", "--batch", "8",
+           "--no-baselines", "--benchmark", "0", "--inject-capture-failure"]
+    p = subprocess.run(cmd, env=env, cwd=root, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=1200)
+    out, err = p.stdout.decode(errors="replace"), p.stderr.decode(errors="replace")
+    assert p.returncode == 0, (out + err)[-4000:]
+    lines = [ln for ln in out.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, (out + err)[-3000:]
+    rec = json.loads(lines[0])
+    assert rec["config"]["launch"].startswith("kernel by kernel") and "capture of the step failed" in rec["config"]["launch"]
+    assert rec["value"] > 0 and rec["steps"] == 2 and rec["roofline"] is not None
+    assert rec["config"]["gradient_exchange_schedule"] == "after_backward" and rec["config"]["ranks_seen"] == 1
+    assert "reporting the eager steps measured before it" in err
+
+
 def test_flat_exchange_step_replayed_from_a_graph_equals_eager_steps():
     """`.grad` is re-pointed at views of the flat buffer inside the captured step: the optimizer kernels of the REPLAYED graph
     must read the gradients of the replay, not of the capture.  Same toy network, same data, 4 steps launched eagerly vs 4

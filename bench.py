@@ -362,14 +362,17 @@ def pmc_traffic(args, kernel):
 
 
 def mfma_counter(args):
-    """Whole-step MFMA utilisation from the committed counter pass of this workload (scripts/pmc_mfma.sh:
-    SQ_VALU_MFMA_BUSY_CYCLES / SQ_BUSY_CU_CYCLES over every kernel of the step), or None."""
+    """Whole-step MFMA utilisation from the committed counter pass of this workload (scripts/pmc_mfma.sh), or None."""
     rel = os.path.join("profiles", f"{ROUND}_pmc_mfma_whole_step_{args.arch}_b{args.batch}.json")
     try:
         rec = json.load(open(os.path.join(ROOT, rel)))
-        return {"mfma_busy_over_cu_busy": round(float(rec["mfma_busy_over_cu_busy"]), 5), "source": rel,
-                "what": "SQ_VALU_MFMA_BUSY_CYCLES / SQ_BUSY_CU_CYCLES summed over every kernel of the step (rocprofv3 --pmc, "
-                        "a separate run of this command); the MFMA work is MIOpen's convolutions and this build's 1x1 GEMMs"}
+        return {"mfma_util": round(float(rec["mfma_busy_over_gpu_active_all_simds"]), 4),
+                "mfma_busy_over_cu_busy": round(float(rec["mfma_busy_over_cu_busy"]), 4), "source": rel,
+                "what": "mfma_util = SQ_VALU_MFMA_BUSY_CYCLES (summed over the chip's 1024 SIMDs) / (GRBM_GUI_ACTIVE / 8 XCDs "
+                        "x 1024): the fraction of SIMD-cycles the matrix pipe was busy while the GPU was active, over every "
+                        "kernel of the training step (rocprofv3 --pmc, a separate run of this command launched kernel by "
+                        "kernel); the MFMA work is MIOpen's convolutions and this build's 1x1 GEMMs -- the MRLA kernels "
+                        "issue none"}
     except (OSError, ValueError, KeyError):
         return None
 

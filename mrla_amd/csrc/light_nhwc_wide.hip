@@ -16,15 +16,13 @@
 #ifndef MRLA_STREAM_MB
 #define MRLA_STREAM_MB 128
 #endif
-// Occupancy of the fused forward statistics pass (round 4, profiles/r04_notes.md): at 150 - 162 VGPRs three waves fit a
-// SIMD, i.e. ONE eight-wave workgroup per CU on the 56-wide stage (8 strips) -- half the waves apply_fwd keeps in flight on
-// the same 3N bytes (SQ counters side by side: 37 % of its wave cycles wait against apply_fwd's 71 %, it simply has too few
-// waves).  Capped at 128 registers (four waves per SIMD, two such workgroups per CU; 19 - 26 values spilled) the 56-wide
-// launch runs 305 -> 280 us (4.04 -> 4.41 TB/s); the narrower stages already hold 3 - 12 smaller workgroups per CU and
-// lose 1 - 11 % to the spills, so only eight-strip launches take the capped instance (MRLA_FUSED_CAP_MINWAVES).
-#ifndef MRLA_FUSED_CAP_MINWAVES
-#define MRLA_FUSED_CAP_MINWAVES 8
-#endif
+// Occupancy of the fused forward statistics pass (round 4, profiles/r04_notes.md section 5): at 150 - 162 VGPRs three waves
+// fit a SIMD, i.e. ONE eight-wave workgroup per CU on the 56-wide stage -- half the waves apply_fwd keeps in flight on the
+// same 3N bytes (SQ counters side by side: 37 % of its wave cycles wait against apply_fwd's 71 %: too few waves, 2.4 x the
+// vector instructions).  An instance capped at 128 registers (four waves per SIMD; 19 - 26 values spilled) ran the 56-wide
+// launch 305 -> 280 us ALONE, but inside the training step the pass got slower (118.5 -> 123 us per launch on average,
+// 558 -> 578 MB of HBM traffic per launch: the spills are traffic) -- measured, not kept; four-wave workgroups walking two
+// strips each: 3 % slower.
 // Cache policy of the row fetches (template AUX: 0 = default, 2 = nt / streaming) and image order, measured in the
 // training step (b = 256, same box, GB/s):            stats_fwd_fused  apply_fwd  stats_bwd  apply_bwd
 //   default policy, images in launch order                  4069         4681       4773       4846
@@ -415,16 +413,8 @@ __device__ __forceinline__ void light_stats_fwd_fused_body(
   }
 }
 
-// The two instances of the pass: the compiler's own register allocation, and capped at four waves per SIMD (see the top).
 template <typename T, bool AFF, bool RAGGED, int AUX>
 __global__ __launch_bounds__(kMaxStrips * kWave) void light_stats_fwd_fused_wide(
-    const T* __restrict__ pre, const T* __restrict__ o, const float* __restrict__ wv, float* __restrict__ mom,
-    T* __restrict__ xout, const float* __restrict__ psc, const float* __restrict__ psh, T* __restrict__ vout, int B,
-    int C, int H, int W, int BG) {
-  light_stats_fwd_fused_body<T, AFF, RAGGED, AUX>(pre, o, wv, mom, xout, psc, psh, vout, B, C, H, W, BG);
-}
-template <typename T, bool AFF, bool RAGGED, int AUX>
-__global__ __launch_bounds__(kMaxStrips * kWave) __attribute__((amdgpu_waves_per_eu(4, 4))) void light_stats_fwd_fused_wide_occ4(
     const T* __restrict__ pre, const T* __restrict__ o, const float* __restrict__ wv, float* __restrict__ mom,
     T* __restrict__ xout, const float* __restrict__ psc, const float* __restrict__ psh, T* __restrict__ vout, int B,
     int C, int H, int W, int BG) {
@@ -816,8 +806,7 @@ int launch_light_stats_fwd_wide(const void* x, const void* o, const float* wv, f
 #define CALL_N(T, AF, RG, NT)                                                                                       \
   {                                                                                                                 \
     const WideLaunch L = wide_launch(B, C, W, kMomRed, fused_wave_bytes<T>(), bg);                                   \
-    if ((int)L.block.x >= MRLA_FUSED_CAP_MINWAVES * kWave) CALL_K(light_stats_fwd_fused_wide_occ4, T, AF, RG, NT)     \
-    else CALL_K(light_stats_fwd_fused_wide, T, AF, RG, NT)                                                          \
+    CALL_K(light_stats_fwd_fused_wide, T, AF, RG, NT)                                                               \
   }
 #define CALL_R(T, AF, RG) { if (stream_fetches(B, C, H, W, sizeof(T))) CALL_N(T, AF, RG, 2) else CALL_N(T, AF, RG, 0) }
 #define CALL_A(T, AF) { if (ragged) CALL_R(T, AF, true) else CALL_R(T, AF, false) }

@@ -22,7 +22,8 @@ def main(path):
     print("|---|---|---|---|---|")
     for where, e in sorted(by.items(), key=keyf):
         test = e["test"].split("::", 1)[-1]
-        tag = f" `{e['tag']}`" if e["tag"] else ""
+        # (the tag is a loop variable of the test -- the parameter's name; shown where the source line uses one)
+        tag = f" `{e['tag']}`" if e["tag"] and any(v in e["expr"] for v in ("ours", "theirs", "pn", "key]", "[k]")) else ""
         expr = e["expr"].replace("|", "\\|")
         print(f"| `{where}` | {e['n']} | {e['worst']:.2e} | `{test}`{tag} | `{expr}` |")
 

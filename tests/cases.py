@@ -45,7 +45,8 @@ def record(rel, depth=2):
         f = sys._getframe(depth)
         while f.f_code.co_name in ("relmax", "rel", "close"):            # thin wrappers in the test modules
             f = f.f_back
-        tag = next((str(f.f_locals[k]) for k in ("ours", "what", "pn", "key", "k") if k in f.f_locals), "")
+        src = linecache.getline(f.f_code.co_filename, f.f_lineno)
+        tag = next((str(f.f_locals[k]) for k in ("ours", "pn", "key", "k") if k in f.f_locals and k in src), "")
         rec = {"test": os.environ.get("PYTEST_CURRENT_TEST", "").split(" ")[0], "tag": tag[:60],
                "where": f"{os.path.basename(f.f_code.co_filename)}:{f.f_lineno}",
                "expr": linecache.getline(f.f_code.co_filename, f.f_lineno).strip()[:160], "rel": float(rel)}

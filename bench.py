@@ -76,6 +76,7 @@ def parse():
     ap.add_argument("--drop-path", type=float, default=0.2, help="resnet/train.py:67 default")
     ap.add_argument("--no-baselines", action="store_true", help="skip the cpu_baseline / eager_rocm / other_configs legs")
     ap.add_argument("--no-others", action="store_true", help="skip the other_configs leg (BASELINE configs 4 and 5)")
+    ap.add_argument("--sgd-fused", type=int, default=1, help="1: torch.optim.SGD(fused=True) (one pass), 0: the foreach implementation")
     ap.add_argument("--no-forward-only", action="store_true", help="skip the inference-pass leg (counter passes over the training step)")
     ap.add_argument("--eager", action="store_true", help="time the eager restatement instead (diagnostic)")
     ap.add_argument("--channels-last", type=int, default=-1,
@@ -186,8 +187,20 @@ def make_step(net, opt, x, y, exchange=None):
     return step
 
 
+SGD_FUSED = True          # (--sgd-fused 0: the foreach implementation -- four multi-tensor passes instead of one)
+
+
 def sgd(params):
-    return torch.optim.SGD(params, lr=0.1, momentum=0.9, weight_decay=1e-4)   # resnet/train.py:199-201
+    """resnet/train.py:199-201: torch.optim.SGD(lr 0.1, momentum 0.9, weight decay 1e-4).  `fused=True` is the same optimizer
+    in its single-pass implementation (gradient, weight and momentum buffer read once, weight and buffer written once: 5
+    tensor-passes per step instead of foreach's 11); product run and eager baseline both use it."""
+    params = list(params)
+    if SGD_FUSED:
+        try:
+            return torch.optim.SGD(params, lr=0.1, momentum=0.9, weight_decay=1e-4, fused=True)
+        except (RuntimeError, TypeError, ValueError):
+            pass
+    return torch.optim.SGD(params, lr=0.1, momentum=0.9, weight_decay=1e-4)
 
 
 def timed(step, steps, warmup):
@@ -455,6 +468,8 @@ def run_other_configs():
 
 def main():
     args = parse()
+    global SGD_FUSED
+    SGD_FUSED = bool(args.sgd_fused)
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ and not args.ddp_probe:
         sys.exit(launch_ranks(args))              # (nothing before this line has touched the GPU)
 

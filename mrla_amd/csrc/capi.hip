@@ -424,6 +424,9 @@ int mrla_base_value_bwd_dv(const void* dout, const void* x, const float* wv, con
     return MRLA_EINVAL;
   if ((pre == nullptr) != (pre_tmom == nullptr) || (pre_tmom && !(res & 2))) return MRLA_EINVAL;
   if (layout != MRLA_NHWC) return MRLA_EUNSUPPORTED;
+  if (c % kWave == 0)       // the LDS-DMA row pipeline
+    return launch_base_value_bwd_wide(dout, x, wv, dv, dyx, dx, dwv_part, pre, pre_center, pre_tmom, b, c, h, w, res, dtype,
+                                      (hipStream_t)stream);
   return launch_base_value_bwd_nhwc(dout, x, wv, dv, dyx, dx, dwv_part, pre, pre_center, pre_tmom, b, c, h, w, res, dtype,
                                     (hipStream_t)stream);
 }

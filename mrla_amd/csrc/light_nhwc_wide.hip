@@ -773,6 +773,121 @@ __global__ __launch_bounds__(kBwdWaves * kWave) void light_apply_bwd_wide(
   }
 }
 
+// ------------------------------------------------------------------------------------------------
+// MRLA-base value backward on the row pipeline (round 4; base_nhwc.hip keeps the register-staged form for C % 64 != 0):
+//   dx = [x > 0 if res&2] * ((res&1) * dOut + dwconv3x3^T(dV) + dyx);  dWv partials;  PRE: bn3's backward sums
+//   dx[r][col]  = sum_{i,k} w[i][k] * dV[r-i+1][col-k+1]
+//   dWv[i][k]  += x[r][col] * dV[r-i+1][col-k+1]      (the same window, centred on x)
+// dV rows r-1 .. r+1 on columns s0-1 .. s0+kS rotate by name; x / dOut / y3 rows of the owned columns arrive one step ahead.
+// ------------------------------------------------------------------------------------------------
+template <typename T, bool PRE> constexpr int base_vbwd_wave_bytes() {
+  return RowIO<T, kS + 2>::kBytes + (PRE ? 4 : 3) * RowIO<T, kS>::kBytes;
+}
+
+template <typename T, bool PRE>
+__global__ __launch_bounds__(kMaxStrips * kWave) void base_value_bwd_wide(
+    const T* __restrict__ dout, const T* __restrict__ x, const float* __restrict__ wv, const T* __restrict__ dv,
+    const float* __restrict__ dyx, T* __restrict__ dx, float* __restrict__ dwv_part, const T* __restrict__ pre,
+    const float* __restrict__ pre_center, float* __restrict__ pre_tmom, int B, int C, int H, int W, int BG, int res) {
+  MRLA_WIDE_PROLOGUE(9, (base_vbwd_wave_bytes<T, PRE>()))
+  constexpr int UB_ = RowIO<T, kS + 2>::kBytes, SB = RowIO<T, kS>::kBytes;
+  T* bufU = reinterpret_cast<T*>(wbuf);
+  T* bufX = reinterpret_cast<T*>(wbuf + UB_);
+  T* bufG = reinterpret_cast<T*>(wbuf + UB_ + SB);
+  T* bufS = reinterpret_cast<T*>(wbuf + UB_ + 2 * SB);
+  T* bufP = reinterpret_cast<T*>(wbuf + UB_ + 3 * SB);               // (PRE) y3 row on the owned columns
+  float w[9];
+#pragma unroll
+  for (int k = 0; k < 9; ++k) w[k] = wv[c * 9 + k];
+  float wg[9] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  float pm[2] = {0.f, 0.f};                          // (PRE) sum dpre, sum dpre * (y3 - center) over this workgroup's images
+  const float pcen = (PRE && pre_center) ? pre_center[c] : 0.f;
+  const float resf = (res & 1) ? 1.f : 0.f;
+  const bool mask = (res & 2) != 0;
+  const int b_end = min(B, (int)(blockIdx.y + 1) * BG);
+  for (int b = blockIdx.y * BG; b < b_end; ++b) {
+    const size_t ioff = (size_t)b * H * rowelems;
+    const T* xi = x + ioff;
+    const T* gi = dout + ioff;
+    const T* ui = dv + ioff;
+    const T* pri = PRE ? pre + ioff : nullptr;
+    T* dxo = dx + ioff;
+    const float dy = dyx[(size_t)b * C + c];
+    for (int s = wave; s < nstrips; s += nwaves) {
+      const int s0 = s * kS, nc = min(kS, W - s0);
+      RowIO<T, kS + 2> au;
+      RowIO<T, kS> ag, as;
+      make_row_io<T, kS + 2>(au, s0 - 1, kS + 2, W, C, cbase, lane);
+      make_row_io<T, kS>(ag, s0, kS, W, C, cbase, lane);
+      make_row_io<T, kS>(as, s0, nc, W, C, cbase, lane);
+      RawRow<kS + 2> ua, ub, uc;                     // dV rows r-1, r, r+1 on columns s0-1 .. s0+kS
+      RawRow<kS> xr, gr, pr;
+      ua.clear(); ub.clear(); uc.clear(); xr.clear(); gr.clear(); pr.clear();
+      row_fetch<T, kS + 2>(au, ui, 0, H, rowelems, bufU);
+      rows_landed();
+      row_read<T, kS + 2>(bufU, lane, ub);
+      row_fetch<T, kS + 2>(au, ui, 1, H, rowelems, bufU);
+      row_fetch<T, kS>(ag, xi, 0, H, rowelems, bufX);
+      row_fetch<T, kS>(ag, gi, 0, H, rowelems, bufG);
+      if (PRE) row_fetch<T, kS>(ag, pri, 0, H, rowelems, bufP);
+      auto step = [&](int r, RawRow<kS + 2>& UA, RawRow<kS + 2>& UB, RawRow<kS + 2>& UC) {
+        // step r-1 stored dx row r-1 after its fetches: that store may stay in flight
+        if (r == 0) rows_landed(); else rows_landed_keep<RowIO<T, kS>::NL>();
+        row_read_issue<T, kS + 2>(bufU, lane, UC);
+        row_read_issue<T, kS>(bufX, lane, xr);
+        row_read_issue<T, kS>(bufG, lane, gr);
+        if (PRE) row_read_issue<T, kS>(bufP, lane, pr);
+        row_read_fence(UC, true);
+        row_read_fence(xr, false);
+        row_read_fence(gr, false);
+        if (PRE) row_read_fence(pr, false);
+        row_fetch<T, kS + 2>(au, ui, r + 2, H, rowelems, bufU);
+        row_fetch<T, kS>(ag, xi, r + 1, H, rowelems, bufX);
+        row_fetch<T, kS>(ag, gi, r + 1, H, rowelems, bufG);
+        if (PRE) row_fetch<T, kS>(ag, pri, r + 1, H, rowelems, bufP);
+        float yrow[kS];
+#pragma unroll
+        for (int j = 0; j < kS; ++j) {
+          // window index of column (col + 1 - k) in the dV rows (which start at col - 1): j + 2 - k
+          float s9 = w[0] * UC.v[j + 2];
+          s9 = fmaf(w[1], UC.v[j + 1], s9); s9 = fmaf(w[2], UC.v[j], s9);
+          s9 = fmaf(w[3], UB.v[j + 2], s9); s9 = fmaf(w[4], UB.v[j + 1], s9); s9 = fmaf(w[5], UB.v[j], s9);
+          s9 = fmaf(w[6], UA.v[j + 2], s9); s9 = fmaf(w[7], UA.v[j + 1], s9); s9 = fmaf(w[8], UA.v[j], s9);
+          float y = fmaf(resf, gr.v[j], s9 + dy);
+          if (mask) y = (xr.v[j] > 0.f) ? y : 0.f;
+          yrow[j] = y;
+          // (x is zero beyond the image, so columns of a ragged last strip drop out of the sums by themselves; with the
+          // mask their y is zero as well)
+          if (PRE) {                                 // of dpre AS STORED (rounded to T)
+            const float yq = to_f(from_f<T>(y));
+            pm[0] += yq;
+            pm[1] = fmaf(yq, pr.v[j] - pcen, pm[1]);
+          }
+          const float xv = xr.v[j];
+          wg[0] = fmaf(xv, UC.v[j + 2], wg[0]); wg[1] = fmaf(xv, UC.v[j + 1], wg[1]); wg[2] = fmaf(xv, UC.v[j], wg[2]);
+          wg[3] = fmaf(xv, UB.v[j + 2], wg[3]); wg[4] = fmaf(xv, UB.v[j + 1], wg[4]); wg[5] = fmaf(xv, UB.v[j], wg[5]);
+          wg[6] = fmaf(xv, UA.v[j + 2], wg[6]); wg[7] = fmaf(xv, UA.v[j + 1], wg[7]); wg[8] = fmaf(xv, UA.v[j], wg[8]);
+        }
+        row_store<T, kS>(as, dxo, r, rowelems, lane, bufS, yrow);
+      };
+      MRLA_ROTATE3(H, step, ua, ub, uc)
+      rows_landed();
+    }
+  }
+  wg_reduce<9>(wg, red, lane, wave, nwaves);
+  if (wave == 0) {
+#pragma unroll
+    for (int k = 0; k < 9; ++k) dwv_part[((size_t)blockIdx.y * C + c) * 9 + k] = wg[k];
+  }
+  if (PRE) {
+    wg_reduce<2>(pm, red, lane, wave, nwaves);
+    if (wave == 0) {
+      pre_tmom[((size_t)blockIdx.y * C + c) * 2 + 0] = pm[0];
+      pre_tmom[((size_t)blockIdx.y * C + c) * 2 + 1] = pm[1];
+    }
+  }
+}
+
 struct WideLaunch { dim3 grid, block; size_t lds; int BG; };
 static WideLaunch wide_launch(int B, int C, int W, int nred, size_t wave_bytes, int bg, int max_waves = kMaxStrips) {
   WideLaunch L;
@@ -930,6 +1045,31 @@ int launch_light_stats_bwd_wide(const void* dout, const void* x, const void* o, 
   MRLA_DISPATCH_T_N(dtype, act, o != nullptr, CALL)
 #undef CALL
 #undef CALL_N
+  return hip_status(hipGetLastError());
+}
+
+int launch_base_value_bwd_wide(const void* dout, const void* x, const float* wv, const void* dv, const float* dyx, void* dx,
+                               float* dwv_part, const void* pre, const float* pre_center, float* pre_tmom, int B, int C,
+                               int H, int W, int res, int dtype, hipStream_t st) {
+  if (C % kWave) return MRLA_EUNSUPPORTED;
+  if (pre_tmom && (!pre || !(res & 2))) return MRLA_EINVAL;
+  const int bg = nhwc_images_per_group(B, C, W);
+#define CALL_P(T, PR)                                                                                               \
+  {                                                                                                                 \
+    const WideLaunch L = wide_launch(B, C, W, 9, base_vbwd_wave_bytes<T, PR>(), bg);                                 \
+    if (set_lds_n(base_value_bwd_wide<T, PR>, L.lds) != hipSuccess) return MRLA_EHIP;                                \
+    hipLaunchKernelGGL((base_value_bwd_wide<T, PR>), L.grid, L.block, L.lds, st, (const T*)dout, (const T*)x, wv,    \
+                       (const T*)dv, dyx, (T*)dx, dwv_part, (const T*)pre, pre_center, pre_tmom, B, C, H, W, L.BG, res); \
+  }
+#define CALL(T) { if (pre_tmom) CALL_P(T, true) else CALL_P(T, false) }
+  switch (dtype) {
+    case MRLA_F32:  CALL(float) break;
+    case MRLA_BF16: CALL(bf16_t) break;
+    case MRLA_F16:  CALL(f16_t) break;
+    default: return MRLA_EINVAL;
+  }
+#undef CALL
+#undef CALL_P
   return hip_status(hipGetLastError());
 }
 

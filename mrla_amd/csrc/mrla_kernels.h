@@ -123,6 +123,9 @@ int launch_base_attend_bwd_nhwc(const void* dout, const void* attn, const float*
                                 const float* cb, const void* Vring, void* dAring, float* pmom_part, int B, int C, int HW,
                                 int T, int t, int dtype, hipStream_t st, int ext_gap = 0, int ext_off = 0);
 int launch_base_pmom_reduce(const float* part, float* pmom, int B, int C, int t, int tiles, hipStream_t st);
+int launch_base_value_bwd_wide(const void* dout, const void* x, const float* wv, const void* dv, const float* dyx, void* dx,
+                               float* dwv_part, const void* pre, const float* pre_center, float* pre_tmom, int B, int C,
+                               int H, int W, int res, int dtype, hipStream_t st);      // light_nhwc_wide.hip (C % 64 == 0)
 int launch_base_value_bwd_nhwc(const void* dout, const void* x, const float* wv, const void* dv, const float* dyx,
                                void* dx, float* dwv_part, const void* pre, const float* pre_center, float* pre_tmom, int B,
                                int C, int H, int W, int res, int dtype, hipStream_t st);

@@ -20,9 +20,9 @@
 // fit a SIMD, i.e. ONE eight-wave workgroup per CU on the 56-wide stage -- half the waves apply_fwd keeps in flight on the
 // same 3N bytes (SQ counters side by side: 37 % of its wave cycles wait against apply_fwd's 71 %: too few waves, 2.4 x the
 // vector instructions).  An instance capped at 128 registers (four waves per SIMD; 19 - 26 values spilled) ran the 56-wide
-// launch 305 -> 280 us ALONE, but inside the training step the pass got slower (118.5 -> 123 us per launch on average,
-// 558 -> 578 MB of HBM traffic per launch: the spills are traffic) -- measured, not kept; four-wave workgroups walking two
-// strips each: 3 % slower.
+// launch 305 -> 280 us ALONE, but inside the training step it bought nothing measurable (123.0 us per launch on average
+// with it, 122.8 us without) and cost 20 MB of HBM traffic per launch (558 -> 578 MB: the spills are traffic) -- measured, not
+// kept; four-wave workgroups walking two strips each: 3 % slower.
 // Cache policy of the row fetches (template AUX: 0 = default, 2 = nt / streaming) and image order, measured in the
 // training step (b = 256, same box, GB/s):            stats_fwd_fused  apply_fwd  stats_bwd  apply_bwd
 //   default policy, images in launch order                  4069         4681       4773       4846

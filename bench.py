@@ -98,6 +98,10 @@ def parse():
                          "from backward's hooks as they fill (DistributedDataParallel's schedule, resnet/train.py:174); ab "
                          "(default): time both on this hardware, report both, run the timed region with the faster")
     ap.add_argument("--ab-steps", type=int, default=6, help="steps per schedule of the --exchange ab comparison")
+    ap.add_argument("--split-graph", action="store_true",
+                    help="N > 1: replay the step from TWO HIP graphs (fwd+loss+bwd+gradient gather | SGD) around an eagerly "
+                         "launched all-reduce -- what runs by itself when the collective cannot be captured (gloo; a failed "
+                         "pre-flight); this flag forces it (diagnostic)")
     ap.add_argument("--inject-capture-failure", action="store_true",
                     help="diagnostic: raise inside the stream capture of the data-parallel step, after its collective has been "
                          "enqueued -- exercises the 'report the eager region, leave without the communicator' path")
@@ -517,7 +521,23 @@ def main():
     # (a gloo exchange stages through the host: not capturable)
     use_graph = args.graph == 1 or (args.graph < 0 and dp != "ddp" and (not dist_on or args.backend == "nccl"))
     launch_note = ""
-    if use_graph and dist_on and args.backend == "nccl":
+    # can the collective itself go into a HIP graph?  (a gloo exchange stages through the host; RCCL: ask the pre-flight)
+    split_why = None
+    if dist_on and dp == "flat" and args.graph != 0:
+        if args.backend != "nccl":
+            split_why = f"a {args.backend} all-reduce stages through the host and cannot be captured"
+        elif args.split_graph:
+            split_why = "--split-graph"
+        elif use_graph:
+            try:
+                preflight_capture(seen)
+            except Exception as e:
+                print(f"warning: pre-flight capture of a 4-element all-reduce failed ({type(e).__name__}: {e}); the step is "
+                      "replayed from two graphs around an eagerly launched all-reduce", file=sys.stderr)
+                split_why = f"the pre-flight capture of a small all-reduce failed ({type(e).__name__})"
+        if split_why:
+            use_graph = False
+    elif use_graph and dist_on and args.backend == "nccl":
         try:
             preflight_capture(seen)
         except Exception as e:
@@ -569,7 +589,48 @@ def main():
                                "used again)"))
         leave_without_the_communicator(0)
 
-    if dp == "flat":
+    split_graphs = None
+    if dp == "flat" and split_why:
+        # ---- the collective cannot be captured: two graphs around an eagerly launched all-reduce (after backward) ----
+        net = net.cuda().train()
+        opt = sgd(net.parameters())
+        ex = D.FlatGradientExchange(net.parameters(), overlap=False)
+        eager_step = step = make_step(net, opt, x, y, ex)
+        R.update(exchange=ex, schedule="after_backward")
+        for _ in range(args.warmup):
+            step()
+
+        def part1():
+            with torch.autocast("cuda", dtype=torch.bfloat16):
+                loss = torch.nn.functional.cross_entropy(net(x).float(), y)
+            opt.zero_grad(set_to_none=True)
+            loss.backward()
+            ex.gather()
+
+        def part3():
+            ex.adopt()
+            opt.step()
+        err = None
+        try:                                             # (no collective inside either capture: a failure here is local)
+            g1 = capture(part1, False, 2)
+            ex.allreduce_flat()
+            g3 = capture(part3, False, 0)
+        except Exception as e:                           # noqa: BLE001
+            err = e
+        if all_ranks_ok(err is None, "capture/split", rank, world):
+            split_graphs = (g1, g3)
+
+            def step():
+                g1.replay()
+                ex.allreduce_flat()
+                g3.replay()
+            launch = ("two HIP graphs per step (fwd+loss+bwd+gradient gather | SGD) around an eagerly launched all-reduce ("
+                      + split_why + ")")
+        else:
+            print(f"warning: HIP graph capture failed ({type(err).__name__ if err else 'on another rank'}: {err}); timing eager "
+                  "launches", file=sys.stderr)
+            ex.adopt()
+    elif dp == "flat":
         # ---- the flat exchange, both schedules measured on this hardware (config.gradient_exchange_ab_ms) ----
         net = net.cuda().train()
         opt = sgd(net.parameters())
@@ -625,7 +686,7 @@ def main():
             except Exception as e:
                 print(f"warning: HIP graph capture failed ({type(e).__name__}: {e}); timing eager launches", file=sys.stderr)
                 step = eager_step
-    use_graph = graph is not None
+    use_graph = graph is not None or split_graphs is not None
 
     timer = Fm.KernelTimer()                             # every C-ABI launch
     # the timed region: exactly `steps` steps between barrier + synchronize
@@ -642,7 +703,7 @@ def main():
         Fm.TIMER = None
         dt_eager = dt
     if rank == 0:
-        graph = step = eager_step = None                 # (report() may hand the GPU to child processes)
+        graph = split_graphs = step = eager_step = None  # (report() may hand the GPU to child processes)
         report(dict(R, dt=dt, dt_eager=dt_eager, timer=timer, use_graph=use_graph, launch=launch, net=net))
     if dist_on:
         D.barrier()

@@ -108,6 +108,7 @@ class FlatGradientExchange:
         self._pending = [len(m) for m in self.members]
         self._works = [None] * len(self.buckets)
         self._sent = [False] * len(self.buckets)
+        self._gathered = [False] * len(self.buckets)
         self._hooks = []
         if overlap:
             for i, p in enumerate(self.params):
@@ -127,7 +128,8 @@ class FlatGradientExchange:
                 self._send(k)
         return hook
 
-    def _send(self, k):
+    def _gather(self, k):
+        """Bucket k's gradients -> its slice of the flat buffer (one `_foreach_copy_`; no collective)."""
         dst, src = [], []
         for i in self.members[k]:
             g, v = self.params[i].grad, self.views[i]
@@ -138,6 +140,9 @@ class FlatGradientExchange:
                 src.append(g)                    # (any strides: copy_ semantics; the usual case is the parameter's own)
         if dst:
             torch._foreach_copy_(dst, src)
+        self._gathered[k] = True
+
+    def _allreduce(self, k):
         if dist.is_initialized():
             buf = self.buckets[k]
             if self._avg:
@@ -146,21 +151,56 @@ class FlatGradientExchange:
                 if self.world > 1:
                     buf.div_(self.world)
                 self._works[k] = dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+
+    def _send(self, k):
+        self._gather(k)
+        self._allreduce(k)
         self._sent[k] = True
 
-    def reduce(self):
-        """After backward: finish the exchange; afterwards every `p.grad` is a view of the flat buffer holding the average."""
+    # The stages of reduce() on their own, for a step that is replayed from HIP graphs AROUND a collective that cannot be
+    # captured (gloo; an RCCL build whose collectives do not survive stream capture):
+    #   graph 1: forward, loss, backward, gather()   |   allreduce_flat(), launched eagerly   |   graph 2: adopt(), optimizer step
+    # gather() and allreduce_flat() keep no state between calls (a replayed graph does not re-run the Python around it).
+    def gather(self):
+        """After backward: every bucket's gradients into the flat buffer (capturable: copies only)."""
         for k in range(len(self.buckets)):
-            if not self._sent[k]:                # no hooks (overlap=False), or a bucket with a parameter that got no gradient
-                self._send(k)
+            self._gather(k)
+            self._gathered[k] = False            # (stateless: reduce() / exchange() after it would simply gather again)
+
+    def allreduce_flat(self):
+        """All-reduce (average) every bucket of the flat buffer as it stands, and wait."""
+        for k in range(len(self.buckets)):
+            self._allreduce(k)
         for k, w in enumerate(self._works):
             if w is not None:
                 w.wait()
             self._works[k] = None
-            self._sent[k] = False
+
+    def exchange(self):
+        """Stateful form used by reduce(): send what the hooks have not sent yet, wait for everything."""
+        for k in range(len(self.buckets)):
+            if not self._sent[k]:
+                if not self._gathered[k]:
+                    self._gather(k)
+                self._allreduce(k)
+                self._sent[k] = True
+        for k, w in enumerate(self._works):
+            if w is not None:
+                w.wait()
+            self._works[k] = None
+
+    def adopt(self):
+        """Every `p.grad` becomes its view of the flat buffer (no kernel); the bookkeeping is reset for the next step."""
+        for k in range(len(self.buckets)):
+            self._sent[k] = self._gathered[k] = False
             self._pending[k] = len(self.members[k])
         for p, v in zip(self.params, self.views):
             p.grad = v
+
+    def reduce(self):
+        """After backward: finish the exchange; afterwards every `p.grad` is a view of the flat buffer holding the average."""
+        self.exchange()
+        self.adopt()
 
     def remove_hooks(self):
         for h in self._hooks:

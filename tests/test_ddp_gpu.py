@@ -125,7 +125,11 @@ def test_bench_py_under_torch_distributed_run_two_ranks_one_gpu(dp):
     assert rec["config"]["global_batch"] == 16 and rec["config"]["parallelism"] == "dp2"
     assert rec["scaling"] == "weak" and rec["higher_is_better"] is True and rec["unit"] == "images/sec"
     assert rec["metric"].startswith("images/sec fwd+bwd resnet50_mrlal") and rec["value"] > 0
-    assert rec["config"]["launch"].startswith("kernel by kernel")             # gloo: nothing to capture
+    if dp == "ddp":
+        assert rec["config"]["launch"].startswith("kernel by kernel")         # DistributedDataParallel: launched eagerly
+    else:       # a gloo all-reduce cannot be captured: the step replays from two graphs around the eagerly launched exchange
+        assert rec["config"]["launch"].startswith("two HIP graphs per step (fwd+loss+bwd+gradient gather | SGD)")
+        assert rec["config"]["gradient_exchange_schedule"] == "after_backward"
     assert ("DistributedDataParallel" if dp == "ddp" else "all-reduce(s) (RCCL avg) over one flat") in rec["config"]["gradient_exchange"]
     assert rec["config"]["ranks_seen"] == 2 and rec["config"]["backend"] == "gloo"
     assert rec["roofline"] is not None and rec["roofline"]["bound"] == "hbm" and rec["roofline"]["achieved"] > 0
@@ -139,13 +143,14 @@ def test_bench_py_plain_launch_starts_its_own_ranks():
     """`python bench.py --gpus 2` with NO torch.distributed environment (resnet/train.py:127-133 spawns its own workers, :153
     init_process_group): bench.py must start the two ranks itself -- before touching the GPU, as a child process -- and the
     line must prove them: n_gpus 2, ranks_seen 2 (an all-reduce of ones over the backend), global batch 16.  gloo, because
-    RCCL refuses two ranks on the one GPU of this box; both exchange schedules are timed (eagerly: gloo is not capturable)."""
+    RCCL refuses two ranks on the one GPU of this box; `--graph 0 --dp flat`: both exchange schedules are timed on the two
+    ranks, launched eagerly (the default over gloo -- two graphs around the eager all-reduce -- is the other test's)."""
     import json
     root = os.path.dirname(HERE)
     env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
     env.update(HSA_ENABLE_IPC_MODE_LEGACY="0", MRLA_DIST_BACKEND="gloo", PYTHONPATH=root)
     cmd = [sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--batch", "8",
-           "--no-baselines"]
+           "--no-baselines", "--graph", "0", "--dp", "flat"]
     p = subprocess.run(cmd, env=env, cwd=root, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=1500)
     out, err = p.stdout.decode(errors="replace"), p.stderr.decode(errors="replace")
     assert p.returncode == 0, (out + err)[-4000:]
@@ -185,6 +190,26 @@ def test_bench_py_graph_captures_the_rccl_exchange_one_rank():
     assert rec["value"] > 0 and rec["eager_launch_ms_per_step"] > 0
 
 
+def test_bench_py_two_graphs_around_an_eager_rccl_all_reduce_one_rank():
+    """The tier between "whole step in one graph" and "everything eager": when the collective cannot be captured (what the
+    pre-flight decides at N > 1; forced here with --split-graph on a one-rank RCCL group), forward + backward + the gradient
+    gather replay from one HIP graph, the all-reduce is launched eagerly, the optimizer step replays from a second graph --
+    an N > 1 point then still runs without the eager launch gaps the N = 1 point does not have."""
+    import json
+    root = os.path.dirname(HERE)
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", PYTHONPATH=root)
+    env.pop("MRLA_DIST_BACKEND", None)
+    cmd = [sys.executable, os.path.join(root, "bench.py"), "--ddp-probe", "--steps", "3", "--warmup", "1", "--batch", "8",
+           "--no-baselines", "--benchmark", "0", "--split-graph"]
+    p = subprocess.run(cmd, env=env, cwd=root, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=1200)
+    out, err = p.stdout.decode(errors="replace"), p.stderr.decode(errors="replace")
+    assert p.returncode == 0, (out + err)[-4000:]
+    rec = json.loads([ln for ln in out.splitlines() if ln.startswith("{")][0])
+    assert rec["config"]["launch"].startswith("two HIP graphs per step"), err[-2000:]
+    assert rec["config"]["gradient_exchange_schedule"] == "after_backward" and rec["config"]["gradient_exchange_ab_ms"] is None
+    assert rec["value"] > 0 and rec["ms_per_step"] < rec["eager_launch_ms_per_step"] * 1.05
+
+
 def test_bench_py_reports_the_eager_region_when_the_capture_breaks():
     """A capture that fails AFTER a collective went into it leaves the communicator in unknown state: bench.py must not
     limp on with it (on N ranks: a hang) and must not lose the measurement either.  With a failure injected inside the
@@ -208,10 +233,13 @@ def test_bench_py_reports_the_eager_region_when_the_capture_breaks():
     assert "reporting the eager steps measured before it" in err
 
 
-def test_flat_exchange_step_replayed_from_a_graph_equals_eager_steps():
+@pytest.mark.parametrize("mode", ["one-graph", "two-graphs"])
+def test_flat_exchange_step_replayed_from_a_graph_equals_eager_steps(mode):
     """`.grad` is re-pointed at views of the flat buffer inside the captured step: the optimizer kernels of the REPLAYED graph
     must read the gradients of the replay, not of the capture.  Same toy network, same data, 4 steps launched eagerly vs 4
-    steps of one captured graph (weights, momentum buffers and BatchNorm statistics compared)."""
+    steps of one captured graph (weights, momentum buffers and BatchNorm statistics compared); `two-graphs`: the form bench.py
+    uses when the collective cannot be captured -- forward/backward/gather in one graph, `allreduce_flat()` launched eagerly,
+    adopt + optimizer in a second graph."""
     from mrla_amd import distributed as D
 
     def run(graphed):
@@ -219,7 +247,7 @@ def test_flat_exchange_step_replayed_from_a_graph_equals_eager_steps():
         net = torch.nn.Sequential(torch.nn.Conv2d(3, 16, 3, padding=1), torch.nn.BatchNorm2d(16), torch.nn.ReLU(),
                                   torch.nn.Conv2d(16, 8, 1), torch.nn.AdaptiveAvgPool2d(1), torch.nn.Flatten(),
                                   torch.nn.Linear(8, 5)).cuda().to(memory_format=torch.channels_last)
-        ex = D.FlatGradientExchange(net.parameters())
+        ex = D.FlatGradientExchange(net.parameters(), overlap=(mode == "one-graph"))
         opt = torch.optim.SGD(net.parameters(), lr=0.05, momentum=0.9)
         g = torch.Generator(device="cuda").manual_seed(11)
         x = torch.randn(8, 3, 12, 12, device="cuda", generator=g)
@@ -240,9 +268,32 @@ def test_flat_exchange_step_replayed_from_a_graph_equals_eager_steps():
                 for _ in range(3):
                     step()                                  # (warm-up: allocates the optimizer state)
             torch.cuda.current_stream().wait_stream(side)
-            gr = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(gr):
-                step()
+            if mode == "one-graph":
+                gr = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(gr):
+                    step()
+                replay = gr.replay
+            else:
+                def part1():
+                    loss = torch.nn.functional.cross_entropy(net(x), y)
+                    opt.zero_grad(set_to_none=True)
+                    loss.backward()
+                    ex.gather()
+
+                def part3():
+                    ex.adopt()
+                    opt.step()
+                g1, g3 = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g1):
+                    part1()
+                ex.allreduce_flat()
+                with torch.cuda.graph(g3):
+                    part3()
+
+                def replay():
+                    g1.replay()
+                    ex.allreduce_flat()
+                    g3.replay()
             with torch.no_grad():                           # back to the initial state, then 4 replays on fresh inputs
                 for t, s0 in zip(list(net.parameters()) + list(net.buffers()), state):
                     t.copy_(s0)
@@ -250,7 +301,7 @@ def test_flat_exchange_step_replayed_from_a_graph_equals_eager_steps():
                     st["momentum_buffer"].zero_()
             for xi in xs:
                 x.copy_(xi)
-                gr.replay()
+                replay()
         else:
             for xi in xs:
                 x.copy_(xi)

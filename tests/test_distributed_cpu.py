@@ -63,7 +63,7 @@ def test_ddp_gloo_world2_matches_manual_average():
     assert not torch.allclose(res[0]["rm"], res[1]["rm"])
 
 
-def _flat_worker(rank, world, port, out, bucket_mb, overlap):
+def _flat_worker(rank, world, port, out, bucket_mb, overlap, stages=False):
     os.environ.update(RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1",
                       MASTER_PORT=str(port))
     from mrla_amd import distributed as D
@@ -86,7 +86,12 @@ def _flat_worker(rank, world, port, out, bucket_mb, overlap):
         opt.zero_grad(set_to_none=True)
         nn.functional.cross_entropy(net[:7](x), y).backward()
         local = [None if p.grad is None else p.grad.clone() for p in net.parameters()]
-        ex.reduce()
+        if stages:                                       # what bench.py replays from two HIP graphs around an eager all-reduce
+            ex.gather()
+            ex.allreduce_flat()
+            ex.adopt()
+        else:
+            ex.reduce()
         for p, v in zip(ex.params, ex.views):
             assert p.grad is v and p.grad.stride() == p.stride()
         steps.append(dict(local=local, avg=[p.grad.clone() for p in net.parameters()]))
@@ -98,17 +103,19 @@ def _flat_worker(rank, world, port, out, bucket_mb, overlap):
 import pytest  # noqa: E402
 
 
-@pytest.mark.parametrize("bucket_mb,overlap", [(25, True), (2e-4, True), (25, False)], ids=["one-bucket", "many-buckets", "no-overlap"])
-def test_flat_gradient_exchange_gloo_world2(bucket_mb, overlap):
+@pytest.mark.parametrize("bucket_mb,overlap,stages", [(25, True, False), (2e-4, True, False), (25, False, False), (25, False, True)],
+                         ids=["one-bucket", "many-buckets", "no-overlap", "no-overlap-staged"])
+def test_flat_gradient_exchange_gloo_world2(bucket_mb, overlap, stages):
     """The exchange bench.py captures into the HIP graph at N > 1: initial weights broadcast from rank 0, gradients =
     the average of the ranks' local gradients (zeros for a parameter without one), `.grad` = views of the flat buffer with
     the parameters' own (channels_last) strides, identical weights on both ranks after two optimizer steps.  With tiny
     buckets the per-bucket hooks send several asynchronous all-reduces during backward (one bucket holds only parameters
-    that never receive a gradient: reduce() sends it)."""
+    that never receive a gradient: reduce() sends it).  `staged`: the three stateless stages gather() / allreduce_flat() /
+    adopt() that bench.py puts into and between two HIP graphs when the collective cannot be captured."""
     world, port = 2, _free_port()
     mgr = mp.Manager()
     out = mgr.dict()
-    mp.spawn(_flat_worker, args=(world, port, out, bucket_mb, overlap), nprocs=world, join=True)
+    mp.spawn(_flat_worker, args=(world, port, out, bucket_mb, overlap, stages), nprocs=world, join=True)
     a, b = out[0], out[1]
     for x, y in zip(a["w0"], b["w0"]):
         assert torch.equal(x, y)

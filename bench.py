@@ -15,8 +15,9 @@ plainly with `--gpus N`, this file starts `python -m torch.distributed.run ... b
 process before anything has touched the GPU, lets rank 0's JSON line through and exits with the child's code.  Every
 rank proves the process group (`config.ranks_seen` = an all-reduce of ones over `config.backend`).  The step is captured
 into one HIP graph with the gradient exchange inside it (mrla_amd/distributed.py: FlatGradientExchange) after a
-pre-flight (capture + replay of a 4-element all-reduce: if THAT fails the step is launched eagerly and the line says
-so).  Two exchange schedules are timed on the hardware -- ONE all-reduce after backward, and ~25 MB buckets sent from
+pre-flight (capture + replay of a 4-element all-reduce).  If the collective cannot be captured -- the pre-flight fails, or
+the backend is gloo -- the step still replays from graphs: forward + loss + backward + the gradient gather from one, the
+optimizer step from a second, the all-reduce launched eagerly between them (`config.launch` says which tier ran).  Two exchange schedules are timed on the hardware -- ONE all-reduce after backward, and ~25 MB buckets sent from
 backward's hooks while backward still runs (what DistributedDataParallel does) -- both reported
 (`config.gradient_exchange_ab_ms`); the faster one runs the timed region (`--exchange` pins one).  An N > 1 run never
 ends without its number: BEFORE any collective goes into a capture, `steps` eagerly launched steps are timed as the

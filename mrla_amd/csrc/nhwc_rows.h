@@ -183,48 +183,6 @@ __device__ __forceinline__ void row_read_fence<11>(RawRow<11>& o, bool wait) {
 #undef MRLA_D16
 
 
-// fp32 rows (the DeiT residual stream): the same split issue / fence form with `ds_read_b32`, written in asm so that the
-// compiler cannot order the reads behind LDS-DMA loads that are still in flight for ANOTHER buffer (it fences every LDS
-// access it can see with `s_waitcnt vmcnt(0)` while a DMA is outstanding: profiles/r02_notes.md) -- what a second row of
-// look-ahead needs.  Used through row_read_issue_asm / row_read_fence_asm by the kernels that keep two steps in flight.
-#define MRLA_B32(i, off) "ds_read_b32 %" #i ", %[a] offset:" #off "\n\t"
-// (early-clobber outputs: the address register is read by every ds_read of the block)
-template <int NPX> __device__ __forceinline__ void row_read_issue_f32(const float* buf, int lane, RawRow<NPX>& o, int px0 = 0);
-template <>
-__device__ __forceinline__ void row_read_issue_f32<7>(const float* buf, int lane, RawRow<7>& o, int px0) {
-  const unsigned a = lds_addr_of(buf) + (px0 * kWave + lane) * 4;
-  asm volatile(MRLA_B32(0, 0) MRLA_B32(1, 256) MRLA_B32(2, 512) MRLA_B32(3, 768) MRLA_B32(4, 1024) MRLA_B32(5, 1280) MRLA_B32(6, 1536) ""
-               : "=&v"(o.v[0]), "=&v"(o.v[1]), "=&v"(o.v[2]), "=&v"(o.v[3]), "=&v"(o.v[4]), "=&v"(o.v[5]), "=&v"(o.v[6])
-               : [a] "v"(a) : "memory");
-}
-template <>
-__device__ __forceinline__ void row_read_issue_f32<9>(const float* buf, int lane, RawRow<9>& o, int px0) {
-  const unsigned a = lds_addr_of(buf) + (px0 * kWave + lane) * 4;
-  asm volatile(MRLA_B32(0, 0) MRLA_B32(1, 256) MRLA_B32(2, 512) MRLA_B32(3, 768) MRLA_B32(4, 1024) MRLA_B32(5, 1280) MRLA_B32(6, 1536) MRLA_B32(7, 1792) MRLA_B32(8, 2048) ""
-               : "=&v"(o.v[0]), "=&v"(o.v[1]), "=&v"(o.v[2]), "=&v"(o.v[3]), "=&v"(o.v[4]), "=&v"(o.v[5]), "=&v"(o.v[6]), "=&v"(o.v[7]), "=&v"(o.v[8])
-               : [a] "v"(a) : "memory");
-}
-template <>
-__device__ __forceinline__ void row_read_issue_f32<11>(const float* buf, int lane, RawRow<11>& o, int px0) {
-  const unsigned a = lds_addr_of(buf) + (px0 * kWave + lane) * 4;
-  asm volatile(MRLA_B32(0, 0) MRLA_B32(1, 256) MRLA_B32(2, 512) MRLA_B32(3, 768) MRLA_B32(4, 1024) MRLA_B32(5, 1280) MRLA_B32(6, 1536) MRLA_B32(7, 1792) MRLA_B32(8, 2048) MRLA_B32(9, 2304) MRLA_B32(10, 2560) ""
-               : "=&v"(o.v[0]), "=&v"(o.v[1]), "=&v"(o.v[2]), "=&v"(o.v[3]), "=&v"(o.v[4]), "=&v"(o.v[5]), "=&v"(o.v[6]), "=&v"(o.v[7]), "=&v"(o.v[8]), "=&v"(o.v[9]), "=&v"(o.v[10])
-               : [a] "v"(a) : "memory");
-}
-#undef MRLA_B32
-// Type dispatch for kernels templated on T: asm reads for bf16 (above) and fp32; other types fall back to row_read
-// (complete, waited-for reads -- correct with any look-ahead depth only as long as the compiler's own fences hold).
-template <typename T, int NPX>
-__device__ __forceinline__ void row_read_issue_asm(const T* buf, int lane, RawRow<NPX>& o, int px0 = 0) {
-  if constexpr (sizeof(T) == 4) row_read_issue_f32<NPX>(reinterpret_cast<const float*>(buf), lane, o, px0);
-  else row_read_issue<T, NPX>(buf, lane, o, px0);
-}
-template <typename T, int NPX>
-__device__ __forceinline__ void row_read_fence_asm(RawRow<NPX>& o, bool wait) {
-  if constexpr (sizeof(T) == 4) row_read_fence<NPX>(o, wait);      // (the <7>/<9>/<11> fences tie the registers to one lgkmcnt(0))
-  else row_read_fence<NPX>(o, wait);
-}
-
 // lane = channel values v[0 .. NPX) of one row piece -> global row r (16 B per lane through the LDS buffer `buf`);
 // `a` was made with npx = the number of pixels that exist (the rest is dropped by the bounds check).
 template <typename T, int NPX>

@@ -238,20 +238,11 @@ __device__ __forceinline__ void stat_fence_wait(StatRow<kS>& o) {
   asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(o.v[0]), "+v"(o.v[1]), "+v"(o.v[2]), "+v"(o.v[3]), "+v"(o.v[4]), "+v"(o.v[5]), "+v"(o.v[6]) : : "memory");
 }
 
-// Rows of DMA look-ahead of the backward kernel (build-time: scripts/build_variant.sh).  1: the next step's rows are in
-// flight while a step computes.  2: two steps' rows -- the kernel is latency-bound (16 dependent row steps per wave, 1.5
-// two-wave workgroups per SIMD, ~1 150 instructions per step against a DMA round trip of about the same length), so the
-// wait at the top of a step is for a fetch issued a whole step earlier; needs double row buffers, a counted
-// `s_waitcnt vmcnt(N)` and LDS reads the compiler cannot fence behind the younger DMA (row_read_issue_asm).
-#ifndef MRLA_TOKEN_BWD_DEPTH
-#define MRLA_TOKEN_BWD_DEPTH 1
-#endif
-constexpr int kTokDepth = MRLA_TOKEN_BWD_DEPTH;
-static_assert(kTokDepth == 1 || kTokDepth == 2, "look-ahead depth");
-
+// (A second row of DMA look-ahead -- double row buffers, counted `s_waitcnt vmcnt(N)`, asm LDS reads -- was built and measured
+// in round 4: bit-identical, 57.6 -> 58.1 us; the waits were the scalar LayerNorm-statistics loads, see above.  Removed.)
 template <typename T> constexpr int tok_bwd_wave_bytes() {
-  return kTokDepth * (RowIO<T, kS + 4>::kBytes + RowIO<T, kS + 2>::kBytes + RowIO<T, kS>::kBytes) + RowIO<float, kS>::kBytes +
-         (kTokDepth + 2) * kStatBufBytes;
+  return RowIO<T, kS + 4>::kBytes + RowIO<T, kS + 2>::kBytes + RowIO<T, kS>::kBytes + RowIO<float, kS>::kBytes +
+         3 * kStatBufBytes;
 }
 
 // BASE: the MRLA-base token module's value backward (mrla_token_base_value_bwd): dU is READ -- the dense dV_t image
@@ -268,19 +259,15 @@ __global__ __launch_bounds__(kMaxStrips * kWave) void token_apply_bwd_rows(
   float* red = reinterpret_cast<float*>(smem_raw);
   unsigned char* wbuf = smem_raw + (size_t)nwaves * (TQ_N + 1) * kWave * sizeof(float) + (size_t)wave * tok_bwd_wave_bytes<T>();
   constexpr int XB_ = RowIO<T, kS + 4>::kBytes, GB_ = RowIO<T, kS + 2>::kBytes, OB_ = RowIO<T, kS>::kBytes;
-  constexpr int SET = XB_ + GB_ + OB_;               // one step's row buffers; kTokDepth sets, parity (rr + 1) & 1
-  auto bufX = [&](int par) { return reinterpret_cast<T*>(wbuf + par * SET); };
-  auto bufG = [&](int par) { return reinterpret_cast<T*>(wbuf + par * SET + XB_); };
-  auto bufO = [&](int par) { return reinterpret_cast<T*>(wbuf + par * SET + XB_ + GB_); };
-  float* bufS = reinterpret_cast<float*>(wbuf + kTokDepth * SET);
-  // LayerNorm records of map row r live in stat buffer r mod (kTokDepth + 2): rows rr .. rr + kTokDepth are alive in a step,
-  // and the row fetched during the step must not land on row rr's (its LN_o records are read late in the step)
+  T* bufX = reinterpret_cast<T*>(wbuf);
+  T* bufG = reinterpret_cast<T*>(wbuf + XB_);
+  T* bufO = reinterpret_cast<T*>(wbuf + XB_ + GB_);
+  float* bufS = reinterpret_cast<float*>(wbuf + XB_ + GB_ + OB_);
+  // LayerNorm records of map row r live in stat buffer r mod 3: rows rr and rr + 1 are alive in a step, and the row fetched
+  // during the step (rr + 2) must not land on row rr's, whose LN_o records are read late in the step
   auto sbuf = [&](int r) {
-    const int m = r + (kTokDepth + 2);               // r >= -1
-    return reinterpret_cast<float*>(wbuf + kTokDepth * SET + RowIO<float, kS>::kBytes) + (m % (kTokDepth + 2)) * (kStatBufBytes / 4);
+    return reinterpret_cast<float*>(wbuf + XB_ + GB_ + OB_ + RowIO<float, kS>::kBytes) + ((r + 3) % 3) * (kStatBufBytes / 4);   // r >= -1
   };
-  // vector-memory instructions a step issues: its row fetches (+ the stats row), then (steps rr >= 1) its row stores
-  constexpr int NF = RowIO<T, kS + 4>::NL + RowIO<T, kS + 2>::NL + (BASE ? 0 : RowIO<T, kS>::NL) + 1, NS = RowIO<float, kS>::NL;
   const int cbase = blockIdx.x * kWave, c = cbase + lane;
   const int b = blockIdx.y, W = side, H = side;
   const int nstrips = (W + kS - 1) / kS;
@@ -327,48 +314,28 @@ __global__ __launch_bounds__(kMaxStrips * kWave) void token_apply_bwd_rows(
 #pragma unroll
     for (int j = 0; j < kS; ++j) { h0[j] = 0.f; h1[j] = 0.f; }
     // step rr (= -1 .. H) consumes x row rr+1 and dOut / o rows rr
-    row_fetch<T, kS + 4>(ax, xi, 0, H, rowelems, bufX(0));
-    row_fetch<T, kS + 2>(ag, gi, -1, H, rowelems, bufG(0));
-    if (!BASE) row_fetch<T, kS>(ao, oi, -1, H, rowelems, bufO(0));
+    row_fetch<T, kS + 4>(ax, xi, 0, H, rowelems, bufX);
+    row_fetch<T, kS + 2>(ag, gi, -1, H, rowelems, bufG);
+    if (!BASE) row_fetch<T, kS>(ao, oi, -1, H, rowelems, bufO);
     if (!BASE) stat_fetch(stats, tok0, side, -1, svoff, sbuf(-1));      // (zeros: LN_o of the row above the map)
     stat_fetch(stats, tok0, side, 0, svoff, sbuf(0));
-    if (kTokDepth == 2) {                            // ... and step 0's rows
-      row_fetch<T, kS + 4>(ax, xi, 1, H, rowelems, bufX(1));
-      row_fetch<T, kS + 2>(ag, gi, 0, H, rowelems, bufG(1));
-      if (!BASE) row_fetch<T, kS>(ao, oi, 0, H, rowelems, bufO(1));
-      stat_fetch(stats, tok0, side, 1, svoff, sbuf(1));
-    }
     auto step = [&](int rr, float (&XA)[kS + 4], float (&XB)[kS + 4], float (&XC)[kS + 4], float (&UA)[kS + 2],
                     float (&UB)[kS + 2], float (&UC)[kS + 2], float (&H0)[kS], float (&H1)[kS], float (&H2)[kS]) {
-      const int par = kTokDepth == 2 ? ((rr + 1) & 1) : 0;
-      if (kTokDepth == 2) {
-        // this step's rows were fetched a whole step ago; what may stay in flight is everything issued after them: the
-        // previous step's fetches (for the NEXT step) and, once steps store (rr - 1 >= 1), its row stores
-        if (rr >= 2) rows_landed_keep<NF + NS>(); else rows_landed_keep<NF>();
-        row_read_issue_asm<T, kS + 4>(bufX(par), lane, xr);
-        row_read_issue_asm<T, kS + 2>(bufG(par), lane, gv);
-        if (!BASE) row_read_issue_asm<T, kS>(bufO(par), lane, ov);
-        stat_read_issue_x(sbuf(rr + 1), sx);
-        row_read_fence_asm<T, kS + 4>(xr, true);
-        row_read_fence_asm<T, kS + 2>(gv, false);
-        if (!BASE) row_read_fence_asm<T, kS>(ov, false);
-      } else {
-        rows_landed();
-        row_read_issue<T, kS + 4>(bufX(par), lane, xr);
-        row_read_issue<T, kS + 2>(bufG(par), lane, gv);
-        if (!BASE) row_read_issue<T, kS>(bufO(par), lane, ov);
-        stat_read_issue_x(sbuf(rr + 1), sx);
-        row_read_fence(xr, true);
-        row_read_fence(gv, false);
-        if (!BASE) row_read_fence(ov, false);
-        if (sizeof(T) == 4) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // (generic fp32 row reads carry no fence)
-      }
+      rows_landed();
+      row_read_issue<T, kS + 4>(bufX, lane, xr);
+      row_read_issue<T, kS + 2>(bufG, lane, gv);
+      if (!BASE) row_read_issue<T, kS>(bufO, lane, ov);
+      stat_read_issue_x(sbuf(rr + 1), sx);
+      row_read_fence(xr, true);
+      row_read_fence(gv, false);
+      if (!BASE) row_read_fence(ov, false);
+      if (sizeof(T) == 4) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");     // (generic fp32 row reads carry no fence)
       stat_fence(sx);
-      // the buffers just read are free: the rows of step rr + kTokDepth go there
-      row_fetch<T, kS + 4>(ax, xi, rr + 1 + kTokDepth, H, rowelems, bufX(par));
-      row_fetch<T, kS + 2>(ag, gi, rr + kTokDepth, H, rowelems, bufG(par));
-      if (!BASE) row_fetch<T, kS>(ao, oi, rr + kTokDepth, H, rowelems, bufO(par));
-      stat_fetch(stats, tok0, side, rr + 1 + kTokDepth, svoff, sbuf(rr + 1 + kTokDepth));
+      // the buffers just read are free: the next step's rows go there
+      row_fetch<T, kS + 4>(ax, xi, rr + 2, H, rowelems, bufX);
+      row_fetch<T, kS + 2>(ag, gi, rr + 1, H, rowelems, bufG);
+      if (!BASE) row_fetch<T, kS>(ao, oi, rr + 1, H, rowelems, bufO);
+      stat_fetch(stats, tok0, side, rr + 2, svoff, sbuf(rr + 2));
       // LN_x on the way in (row rr+1); pixels outside the map come out as exact zeros
 #pragma unroll
       for (int j = 0; j < kS + 4; ++j) {

@@ -4,7 +4,7 @@
 # RECORD of what was run (profiles/r04_notes.md sections 5, 6).  The two variants of the fused statistics pass were built with
 # build-time switches that existed at commit 1ac855d only (-DMRLA_FUSED_MAXWAVES=4, -DMRLA_FUSED_WAVES_PER_EU=4 through
 # scripts/build_variant.sh; the switches were removed from the source once measured); the token look-ahead switch
-# (-DMRLA_TOKEN_BWD_DEPTH=2) is still in tokens_nhwc.hip.
+# (-DMRLA_TOKEN_BWD_DEPTH=2) existed from commit 1ac855d until it was removed after two measurements (no gain).
 # Usage: bash scripts/r04_experiments.sh <outdir>
 set -u
 OUT=${1:-gpurun_out/r04_exp}; mkdir -p $OUT

@@ -1,3 +1,5 @@
+# RECORD of the token-backward look-ahead experiment (profiles/r04_notes.md section 6): the tokdepth2 variant was built with
+# -DMRLA_TOKEN_BWD_DEPTH=2, a build-time switch tokens_nhwc.hip carried from commit 1ac855d until it was removed (no gain).
 set -u
 OUT=gpurun_out/r04_exp; mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT

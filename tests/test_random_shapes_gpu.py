@@ -12,7 +12,7 @@ import torch
 
 from oracle import detgen, mrla_numpy as mn
 from tests import cases
-from tests.test_light_gpu import ACT_TOL, TINY_BN_TOL, oracle_light, par_tol, relmax, run_light
+from tests.test_light_gpu import ACT_TOL, TINY_BN_TOL, assert_bf16_close, bf16_round, oracle_light, par_tol, relmax, run_light
 
 pytestmark = pytest.mark.gpu
 
@@ -62,6 +62,30 @@ def test_light_tail_random_shapes_fp32(shape, cl):
                          ("mrla.lambda_t", "dlam"), ("bn_mrla.weight", "dgamma"), ("bn_mrla.bias", "dbeta")):
         want = np.asarray(g[theirs]).ravel()
         assert relmax(got["grad/" + ours].ravel(), want) < (TINY_BN_TOL if tiny else par_tol(theirs)), ours
+
+
+@pytest.mark.parametrize("shape", LIGHT_SHAPES[:8], ids=lambda s: "x".join(map(str, s)))
+@pytest.mark.parametrize("cl", [False, True], ids=["nchw", "nhwc"])
+def test_light_tail_random_shapes_bf16(shape, cl):
+    """bf16 I/O protocol: inputs pre-rounded to bf16, the kernel's bf16 outputs vs the fp64 oracle on
+    the same inputs rounded once to bf16 -- within 1 bf16 ulp elementwise; the parameter gradients (fp32 sums) to the fp32
+    bounds."""
+    b, c, h, w, d = shape
+    if b * h * w <= 9:
+        pytest.skip("BatchNorm over a handful of values: covered in fp32 with its own bound")
+    s = detgen.seed_of(f"rand-light16/{shape}")
+    x = bf16_round(np.maximum(detgen.normalish((b, c, h, w), s), 0) + 0.2 * detgen.normalish((b, c, h, w), s + 1))
+    o = bf16_round(detgen.normalish((b, c, h, w), s + 2))
+    gup = bf16_round(detgen.normalish((b, c, h, w), s + 3))
+    P = cases.block_params(c, 23)
+    got = run_light(x, o, P, d, "train", None, 0.0, gup, torch.bfloat16, cl=cl)
+    out, cache, g = oracle_light(x, o, P, d, "train", None, 0.0, gup)
+    assert_bf16_close(got["out"], out, "out")
+    assert_bf16_close(got["dx"], g["dx"], "dx")
+    assert_bf16_close(got["do"], g["do_prev"], "do")
+    for ours, theirs in (("mrla.mrla.Wq.weight", "dwq"), ("mrla.mrla.Wk.weight", "dwk"), ("mrla.mrla.Wv.weight", "dwv"),
+                         ("mrla.lambda_t", "dlam"), ("bn_mrla.weight", "dgamma"), ("bn_mrla.bias", "dbeta")):
+        assert relmax(got["grad/" + ours].ravel(), np.asarray(g[theirs]).ravel()) < par_tol(theirs), ours
 
 
 def _base_shape(rng):

@@ -370,8 +370,14 @@ def pmc_traffic(args, kernel):
     workload (2*FETCH_SIZE + WRITE_SIZE, the gfx950 correction of MI355X_MICROARCH.md; scripts/pmc_bench.sh), else
     (None, None): a kernel may have changed since an older round's pass, so older files are never substituted."""
     rel = os.path.join("profiles", f"{ROUND}_pmc_traffic_{args.arch}_b{args.batch}.json")
+    # C-ABI entry point -> the device kernel's name in the profile where they differ (the token MRLA-base module runs the flat
+    # history kernels of base_nhwc.hip; the value backward's kernels are called base_value_bwd_*)
+    alias = {"token_base_attend_bwd": "base_attend_bwd", "base_value_bwd_dv": "base_value_bwd",
+             "base_pool_value_fwd": "light_stats_fwd_fused", "token_base_value_fwd": "token_value_fwd"}
     try:
-        rec = json.load(open(os.path.join(ROOT, rel))).get(kernel.replace("mrla_", ""))
+        table = json.load(open(os.path.join(ROOT, rel)))
+        name = kernel.replace("mrla_", "")
+        rec = table.get(name) or table.get(alias.get(name, ""))
         if rec:
             return int(rec["hbm_bytes_per_launch"]), rel
     except (OSError, ValueError, KeyError):

@@ -85,6 +85,57 @@ __global__ __launch_bounds__(kThreads) void token_stats_kernel(const T* __restri
   }
 }
 
+// 16 bytes per lane (round 4; it was one element per lane and load: the address unit pays per instruction, not per byte):
+// a lane holds VEC = 16 / sizeof(T) consecutive channels per pass, a wave-pass covers 64 * VEC channels (DeiT-tiny's 192 fp32
+// channels: one pass, 48 lanes).  C % VEC != 0 keeps the element-wise form below.
+constexpr int kTokVecPasses = 4;     // C <= 64 * VEC * 4 (1024 fp32 / 2048 16-bit channels)
+
+template <typename T>
+__global__ __launch_bounds__(kThreads) void token_stats_vec_kernel(const T* __restrict__ x, const T* __restrict__ o, float eps,
+                                                                   float* __restrict__ stats, int ntok, int C) {
+  constexpr int VEC = 16 / sizeof(T);
+  typedef T VT __attribute__((ext_vector_type(VEC)));
+  const int lane = threadIdx.x & (kWave - 1), wave = threadIdx.x / kWave;
+  const float invc = 1.0f / (float)C;
+  const int nv = C / VEC;                               // 16-byte vectors per token row
+  for (int tok = blockIdx.x * kWaves + wave; tok < ntok; tok += gridDim.x * kWaves) {
+    const VT* xr = reinterpret_cast<const VT*>(x + (size_t)tok * C);
+    const VT* orow = o ? reinterpret_cast<const VT*>(o + (size_t)tok * C) : nullptr;
+    float xv[kTokVecPasses][VEC], ov[kTokVecPasses][VEC];
+    float sx = 0.f, so = 0.f;
+#pragma unroll
+    for (int k = 0; k < kTokVecPasses; ++k) {
+      const int v = lane + k * kWave;
+      const bool in = v < nv;
+      VT a, b;
+      if (in) a = xr[v];
+      if (in && o) b = orow[v];
+#pragma unroll
+      for (int i = 0; i < VEC; ++i) {
+        xv[k][i] = in ? to_f(a[i]) : 0.f;
+        ov[k][i] = (in && o) ? to_f(b[i]) : 0.f;
+        sx += xv[k][i]; so += ov[k][i];
+      }
+    }
+    const float mx = wave_sum(sx) * invc, mo = o ? wave_sum(so) * invc : 0.f;
+    float vx = 0.f, vo = 0.f;
+#pragma unroll
+    for (int k = 0; k < kTokVecPasses; ++k) {
+      const bool in = lane + k * kWave < nv;
+#pragma unroll
+      for (int i = 0; i < VEC; ++i) {
+        const float dxv = in ? xv[k][i] - mx : 0.f, dov = in ? ov[k][i] - mo : 0.f;
+        vx = fmaf(dxv, dxv, vx);
+        vo = fmaf(dov, dov, vo);
+      }
+    }
+    const float rx = rsqrtf(wave_sum(vx) * invc + eps);
+    const float ro = o ? rsqrtf(wave_sum(vo) * invc + eps) : rx;
+    // (MRLA-base on tokens has no o_{t-1}: x's statistics fill both pairs)
+    if (lane == 0) *reinterpret_cast<float4*>(stats + (size_t)tok * S_N) = make_float4(mx, rx, o ? mo : mx, ro);
+  }
+}
+
 // mom[b,c,0] = wx[c] * sum_{i>=1} (x[b,i,c] - mean_i) * rstd_i + (n-1) * bx[c]   (other slots 0).  grid (C/64.., b);
 // the four waves of a workgroup take every fourth token each (a single wave per (image, 64 channels) walked 196 tokens
 // in 49 dependent steps: 20 us for a 39 MB read), partial sums combined in wave order.
@@ -399,9 +450,16 @@ int launch_token_norm_pool(const void* x, const void* o, const float* wx, const 
   if (C > kWave * kTokRowRegs) return MRLA_EUNSUPPORTED;
   const int ntok = B * n;
   const int wgs = std::max(1, std::min((ntok + kWaves - 1) / kWaves, 256 * 32));
+  const int vec = 16 / (int)dtype_size(dtype);
+  const bool vec_ok = C % vec == 0 && C <= kWave * vec * kTokVecPasses &&
+                      ((uintptr_t)x & 15) == 0 && (!o || ((uintptr_t)o & 15) == 0);
 #define CALL(TT)                                                                                                     \
-  hipLaunchKernelGGL((token_stats_kernel<TT>), dim3(wgs), dim3(kThreads), 0, st, (const TT*)x, (const TT*)o, eps, stats, \
-                     ntok, C);                                                                                       \
+  if (vec_ok)                                                                                                        \
+    hipLaunchKernelGGL((token_stats_vec_kernel<TT>), dim3(wgs), dim3(kThreads), 0, st, (const TT*)x, (const TT*)o, eps, \
+                       stats, ntok, C);                                                                              \
+  else                                                                                                               \
+    hipLaunchKernelGGL((token_stats_kernel<TT>), dim3(wgs), dim3(kThreads), 0, st, (const TT*)x, (const TT*)o, eps, stats, \
+                       ntok, C);                                                                                     \
   hipLaunchKernelGGL((token_pool_kernel<TT>), dim3((C + kWave - 1) / kWave, B), dim3(kThreads), 0, st, (const TT*)x, stats, \
                      wx, bx, mom, n, C);
   MRLA_DISPATCH_TT(dtype, CALL)

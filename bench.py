@@ -13,7 +13,8 @@ launches instead).
 N > 1 (resnet/train.py:127-133 spawns its own workers with mp.spawn; :153 init_process_group; :174 DDP).  Launched
 plainly with `--gpus N`, this file starts `python -m torch.distributed.run ... bench.py <same arguments>` as a CHILD
 process before anything has touched the GPU, lets rank 0's JSON line through and exits with the child's code.  Every
-rank proves the process group (`config.ranks_seen` = an all-reduce of ones over `config.backend`).  The step is captured
+rank proves the process group (`config.ranks_seen` = an all-reduce of ones over `config.backend`) and, after the last step,
+that the exchange did its job (`config.replicas_in_sync`: bit-identical weights on all ranks).  The step is captured
 into one HIP graph with the gradient exchange inside it (mrla_amd/distributed.py: FlatGradientExchange) after a
 pre-flight (capture + replay of a 4-element all-reduce).  If the collective cannot be captured -- the pre-flight fails, or
 the backend is gloo -- the step still replays from graphs: forward + loss + backward + the gradient gather from one, the
@@ -709,9 +710,12 @@ def main():
         dt = timed(step, args.steps, 0)
         Fm.TIMER = None
         dt_eager = dt
+    # after warm-up, A/B, timed and event-timed steps: do all ranks still hold the same weights?  (they do if and only if every
+    # step's exchange -- captured or not -- handed every rank the same averaged gradients)
+    in_sync = D.replicas_in_sync(list(net.parameters())) if dist_on else None
     if rank == 0:
         graph = split_graphs = step = eager_step = None  # (report() may hand the GPU to child processes)
-        report(dict(R, dt=dt, dt_eager=dt_eager, timer=timer, use_graph=use_graph, launch=launch, net=net))
+        report(dict(R, dt=dt, dt_eager=dt_eager, timer=timer, use_graph=use_graph, launch=launch, net=net, in_sync=in_sync))
     if dist_on:
         D.barrier()
         torch.distributed.destroy_process_group()

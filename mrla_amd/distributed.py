@@ -221,6 +221,21 @@ def _is_dense(t):
     return True
 
 
+def replicas_in_sync(params, group=None):
+    """True when every rank holds bit-identical parameters (per-parameter float64 sums, all-reduced with MIN and MAX): what
+    data-parallel training guarantees after any number of steps if -- and only if -- every rank applied the same averaged
+    gradients to the same starting weights.  BatchNorm buffers are not compared: they stay per-GPU by design."""
+    if not dist.is_initialized() or dist.get_world_size(group) == 1:
+        return True
+    sums = torch.stack([p.detach().double().sum() for p in params])
+    if dist.get_backend(group) != "nccl":
+        sums = sums.cpu()
+    lo, hi = sums.clone(), sums.clone()
+    dist.all_reduce(lo, op=dist.ReduceOp.MIN, group=group)
+    dist.all_reduce(hi, op=dist.ReduceOp.MAX, group=group)
+    return bool(torch.equal(lo, hi))
+
+
 def max_over_ranks(seconds, device=None):
     """The contract's timing rule: the slowest rank's wall time."""
     if not dist.is_initialized() or dist.get_world_size() == 1:

@@ -132,6 +132,7 @@ def test_bench_py_under_torch_distributed_run_two_ranks_one_gpu(dp):
         assert rec["config"]["gradient_exchange_schedule"] == "after_backward"
     assert ("DistributedDataParallel" if dp == "ddp" else "all-reduce(s) (RCCL avg) over one flat") in rec["config"]["gradient_exchange"]
     assert rec["config"]["ranks_seen"] == 2 and rec["config"]["backend"] == "gloo"
+    assert rec["config"]["replicas_in_sync"] is True          # both ranks applied the same averaged gradients, every step
     assert rec["roofline"] is not None and rec["roofline"]["bound"] == "hbm" and rec["roofline"]["achieved"] > 0
     assert rec["roofline"]["kernel"].startswith("mrla_light_apply_bwd")
     assert "cpu_baseline" not in rec and "forward_only" not in rec            # N = 1 legs only
@@ -159,6 +160,7 @@ def test_bench_py_plain_launch_starts_its_own_ranks():
     rec = json.loads(lines[0])
     assert rec["n_gpus"] == 2 and rec["config"]["ranks_seen"] == 2 and rec["config"]["global_batch"] == 16
     assert rec["config"]["backend"] == "gloo" and rec["config"]["parallelism"] == "dp2"
+    assert rec["config"]["replicas_in_sync"] is True
     ab = rec["config"]["gradient_exchange_ab_ms"]
     assert set(ab) == {"after_backward", "bucketed_overlap"} and all(v > 0 for v in ab.values())
     assert rec["config"]["gradient_exchange_schedule"] == min(ab, key=ab.get)

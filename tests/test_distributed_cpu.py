@@ -150,3 +150,28 @@ def test_flat_exchange_refuses_a_second_backward_before_reduce():
     ex2.reduce()
     for p, w in zip(net.parameters(), want):
         assert torch.equal(p.grad, w)
+
+
+def _sync_worker(rank, world, port, out):
+    os.environ.update(RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1",
+                      MASTER_PORT=str(port))
+    from mrla_amd import distributed as D
+    D.init_from_env("gloo")
+    torch.manual_seed(5)                                 # the same weights on both ranks
+    net = nn.Sequential(nn.Linear(6, 5), nn.ReLU(), nn.Linear(5, 3))
+    same = D.replicas_in_sync(list(net.parameters()))
+    if rank == 1:
+        with torch.no_grad():
+            net[2].bias[1] += 1e-7                       # one weight off by one ulp-ish on one rank
+    differ = D.replicas_in_sync(list(net.parameters()))
+    out[rank] = (same, differ)
+    torch.distributed.destroy_process_group()
+
+
+def test_replicas_in_sync_detects_a_single_diverged_weight():
+    """bench.py's `config.replicas_in_sync`: per-parameter float64 sums, all-reduced with MIN and MAX."""
+    world, port = 2, _free_port()
+    mgr = mp.Manager()
+    out = mgr.dict()
+    mp.spawn(_sync_worker, args=(world, port, out), nprocs=world, join=True)
+    assert out[0] == (True, False) and out[1] == (True, False)

@@ -771,7 +771,7 @@ def report(R):
                       "ranks_seen": seen,
                       "backend": ({"nccl": "nccl (RCCL)"}.get(args.backend, args.backend) if dist_on else "none (single process)"),
                       **({"gradient_exchange": gx_desc, "gradient_exchange_schedule": schedule,
-                          "gradient_exchange_ab_ms": ab_ms} if dist_on else {}),
+                          "gradient_exchange_ab_ms": ab_ms, "replicas_in_sync": R.get("in_sync")} if dist_on else {}),
                       "path": "eager restatement" if args.eager else
                               f"mrla_amd (HIP MRLA tails incl. shortcut add+ReLU, HIP BatchNorm+ReLU(+stem max-pool), HIP MFMA GEMMs for the "
                               f"1x1 convolutions fwd / dgrad / wgrad where eligible, stock 3x3 / 7x7 / strided convolutions; {layout})"},

@@ -22,122 +22,6 @@ enum { TQ_WV = 0, TQ_LAM = 9, TQ_LNXW = 10, TQ_LNXB = 11, TQ_LNOW = 12, TQ_LNOB 
 static_assert(TQ_N == kTokParts && TQ_LNXW == kTokPartLnxW && TQ_LNXB == kTokPartLnxB && TQ_H == kTokPartHat,
               "the gate backward (gate.hip) patches these slots");
 
-// (mean, rstd) of LN_x (which = 0) or LN_o (which = 2) of the map pixel (r, col) of image b: wave-uniform -> scalar load
-__device__ __forceinline__ float2 tok_stat(const float* __restrict__ stats, int tok0, int side, int r, int col, int which) {
-  const int idx = __builtin_amdgcn_readfirstlane((tok0 + r * side + col) * TS_N + which);
-  return *reinterpret_cast<const float2*>(stats + idx);
-}
-
-// raw row -> LN_x(x) row on window columns col0 .. col0+NPX-1 of map row r (0 outside the map).
-// Two phases: ALL the row's (mean, rstd) scalar loads are issued first and waited for once (written pixel by pixel the
-// compiler put one `s_load_dwordx2` + `s_waitcnt lgkmcnt(0)` in front of every pixel's arithmetic -- NPX dependent scalar-
-// cache round trips per row step, the same stall the backward kernel had: profiles/r04_notes.md).
-template <int NPX>
-__device__ __forceinline__ void normalise_row(float (&v)[NPX], const float* __restrict__ stats, int tok0, int side, int r,
-                                              int col0, float wxc, float bxc) {
-  const bool rowok = r >= 0 && r < side;
-  float2 st[NPX];
-#pragma unroll
-  for (int j = 0; j < NPX; ++j) {
-    const int col = col0 + j;
-    const bool ok = rowok && col >= 0 && col < side;               // wave-uniform
-    st[j] = tok_stat(stats, tok0, side, ok ? r : 0, ok ? col : 0, TS_MX);     // (a valid record when masked)
-  }
-  asm volatile("" ::: "memory");                                   // keep the loads together, ahead of the arithmetic
-#pragma unroll
-  for (int j = 0; j < NPX; ++j) {
-    const int col = col0 + j;
-    const bool ok = rowok && col >= 0 && col < side;
-    v[j] = ok ? fmaf((v[j] - st[j].x) * st[j].y, wxc, bxc) : 0.f;
-  }
-}
-
-#define MRLA_TOK_PROLOGUE(NRED)                                                                           \
-  extern __shared__ __align__(16) unsigned char smem_raw[];                                               \
-  const int lane = threadIdx.x & (kWave - 1), wave = threadIdx.x / kWave, nwaves = blockDim.x / kWave;    \
-  float* red = reinterpret_cast<float*>(smem_raw);                                                        \
-  constexpr int SB = scratch_bytes<float>();          /* every buffer is sized for fp32 rows */             \
-  unsigned char* my = smem_raw + (size_t)nwaves * (NRED) * kWave * sizeof(float) + (size_t)wave * 2 * SB;  \
-  T* scrT = reinterpret_cast<T*>(my);                 /* gathers */                                        \
-  unsigned char* scrS = my + SB;                      /* scatters */                                       \
-  const int cbase = blockIdx.x * kWave, c = cbase + lane;                                                 \
-  const int b = blockIdx.y, W = side, H = side;                                                           \
-  const int nstrips = (W + kS - 1) / kS;                                                                  \
-  const int tok0 = b * n + 1;                         /* token index of map pixel (0, 0) */                \
-  const size_t ioff = (size_t)tok0 * C;                                                                   \
-  /* row band of this workgroup (grid.z bands; 1 band = the whole map) */                                 \
-  const int r0 = (int)((H * blockIdx.z) / gridDim.z), r1 = (int)((H * (blockIdx.z + 1)) / gridDim.z);     \
-  (void)red; (void)scrS; (void)r0; (void)r1;
-
-// ------------------------------------------------------------------------------------------------
-// forward apply (map rows); grid (C/64, b)
-// ------------------------------------------------------------------------------------------------
-template <typename T>
-__global__ __launch_bounds__(kMaxStrips * kWave) void token_apply_fwd_nhwc(
-    const T* __restrict__ x, const T* __restrict__ o, const float* __restrict__ stats, const float* __restrict__ wx,
-    const float* __restrict__ bx, const float* __restrict__ wo, const float* __restrict__ bo,
-    const float* __restrict__ wv, const float* __restrict__ gate, const float* __restrict__ lam, T* __restrict__ out,
-    int n, int C, int side, int d, int res) {
-  MRLA_TOK_PROLOGUE(0)
-  float w[9];
-#pragma unroll
-  for (int k = 0; k < 9; ++k) w[k] = wv[c * 9 + k];
-  const float a = gate[(size_t)b * (C / d) + c / d];
-  const float lm = lam[c], wxc = wx[c], bxc = bx[c], woc = wo[c], boc = bo[c];
-  const float resf = res ? 1.f : 0.f;
-  const T* xi = x + ioff;
-  const T* oi = o + ioff;
-  T* yo = out + ioff;
-  for (int s = wave; s < nstrips; s += nwaves) {
-    const int s0 = s * kS, nc = min(kS, W - s0);
-    float ra[kS + 2], rb[kS + 2], rc[kS + 2], xraw[kS], xnext[kS];
-    RowLoad<T, kS + 2> qx;
-    RowLoad<T, kS> qo;
-    RowAddr<T, kS + 2> ax;
-    RowAddr<T, kS> ao;
-    make_row_addr<T, kS + 2>(ax, s0 - 1, W, C, cbase, lane);
-    make_row_addr<T, kS>(ao, s0, W, C, cbase, lane);
-    read_row<T, true, kS + 2>(xi, r0 - 1, s0 - 1, H, W, C, cbase, c, lane, scrT, ra);      // (zeros above the map)
-    normalise_row<kS + 2>(ra, stats, tok0, side, r0 - 1, s0 - 1, wxc, bxc);
-    read_row<T, true, kS + 2>(xi, r0, s0 - 1, H, W, C, cbase, c, lane, scrT, rb);
-#pragma unroll
-    for (int j = 0; j < kS; ++j) xraw[j] = rb[j + 1];
-    normalise_row<kS + 2>(rb, stats, tok0, side, r0, s0 - 1, wxc, bxc);
-    issue_row<T, kS + 2>(qx, xi, r0 + 1, H, W * C, ax);
-    issue_row<T, kS>(qo, oi, r0, H, W * C, ao);
-    for (int r = r0; r < r1; ++r) {
-      float ov[kS], y[kS];
-      finish_row<T, kS + 2>(qx, lane, scrT, rc);
-      finish_row<T, kS>(qo, lane, scrT, ov);
-      issue_row<T, kS + 2>(qx, xi, r + 2, H, W * C, ax);
-      issue_row<T, kS>(qo, oi, r + 1, H, W * C, ao);
-#pragma unroll
-      for (int j = 0; j < kS; ++j) xnext[j] = rc[j + 1];
-      normalise_row<kS + 2>(rc, stats, tok0, side, r + 1, s0 - 1, wxc, bxc);
-      float2 sto[kS];
-#pragma unroll
-      for (int j = 0; j < kS; ++j) sto[j] = tok_stat(stats, tok0, side, r, j < nc ? s0 + j : s0, TS_MO);   // issued together
-      asm volatile("" ::: "memory");
-#pragma unroll
-      for (int j = 0; j < kS; ++j) {
-        const float on = j < nc ? fmaf((ov[j] - sto[j].x) * sto[j].y, woc, boc) : 0.f;
-        y[j] = fmaf(a, gelu_f(conv_at(w, ra, rb, rc, j)), fmaf(lm, on, resf * xraw[j]));
-      }
-      write_row<T, true, kS>(yo, r, s0, nc, W, C, cbase, c, true, lane, reinterpret_cast<T*>(scrS), y);
-#pragma unroll
-      for (int j = 0; j < kS + 2; ++j) { ra[j] = rb[j]; rb[j] = rc[j]; }
-#pragma unroll
-      for (int j = 0; j < kS; ++j) xraw[j] = xnext[j];
-    }
-  }
-  if (wave == 0 && blockIdx.z == 0) {        // cls row of this (image, 64 channels): out = res*x + LN_x(x)
-    const size_t g = (size_t)b * n * C + c;
-    const float* s = stats + (size_t)b * n * TS_N;
-    const float xv = to_f(x[g]);
-    out[g] = from_f<T>(fmaf(resf, xv, fmaf((xv - s[TS_MX]) * s[TS_RX], wxc, bxc)));
-  }
-}
-
 // cls row: out[b, 0, :] = res*x + LN_x(x)   (one thread per channel; grid (ceil(C/256), b)) -- MRLA-base on tokens, whose
 // map rows come from a flat kernel
 template <typename T>
@@ -168,21 +52,9 @@ __global__ __launch_bounds__(kThreads) void token_cls_fwd_kernel(const T* __rest
 // register-staged row gathers, windows rotated by copies, exec-mask branches -- spent ~3 000 instructions per row step, 450
 // of them register moves and 160 SGPR-spill lane moves: profiles/r03_notes.md section 8; this one ~1 150.)
 // ------------------------------------------------------------------------------------------------
-// (mean, rstd, bias switch) of LN_x for window pixel (r, col): rstd = 0 and switch = 0 outside the map
-__device__ __forceinline__ void tok_stat_masked(const float* __restrict__ stats, int tok0, int side, int r, int col,
-                                                float& mean, float& rstd, float& on) {
-  const bool ok = r >= 0 && r < side && col >= 0 && col < side;                  // wave-uniform
-  const int idx = __builtin_amdgcn_readfirstlane((tok0 + (ok ? r * side + col : 0)) * TS_N + TS_MX);
-  const float2 s = *reinterpret_cast<const float2*>(stats + idx);
-  mean = s.x;
-  rstd = ok ? s.y : 0.f;
-  on = ok ? 1.f : 0.f;
-}
-
-
 // ------------------------------------------------------------------------------------------------
 // LayerNorm statistics of a window row through LDS (round 4).  The (mean, rstd) pairs of the window's tokens are
-// wave-uniform; fetched one by one through the scalar cache (tok_stat_masked: 18 dependent `s_load_dwordx2` + waits per
+// wave-uniform; fetched one by one through the scalar cache (18 dependent `s_load_dwordx2` + `s_waitcnt` per
 // row step) they were what the backward kernel's waves waited for -- SQ counters: 34 % of its wave cycles in waits that a
 // second row of DMA look-ahead did not move (profiles/r04_notes.md).  Here the window's 11 records [mean_x, rstd_x, mean_o,
 // rstd_o] travel with the rows: ONE `buffer_load_dword ... lds` per step (lane l -> float l of the window's records;
@@ -427,41 +299,158 @@ __global__ __launch_bounds__(kMaxStrips * kWave) void token_apply_bwd_rows(
 // MRLA-base on tokens (deit/deit_mrla_base.py:224-243): the value map V_t = dwconv3x3(LN_x(x) map) goes straight into the
 // stage's slot-major NHWC ring (a dense [b, side, side, c] image per slot) -- LN_x(x) itself is never materialised --
 // and the backward (token_apply_bwd_rows<.., BASE = true> above) turns dV_t (dense, from mrla_base_dv_combine) into dxn'
-// on the token rows.
+// on the token rows.  Its forward is the VALUE form of the kernel below.
 // ------------------------------------------------------------------------------------------------
-template <typename T>
-__global__ __launch_bounds__(kMaxStrips * kWave) void token_value_fwd_nhwc(
-    const T* __restrict__ x, const float* __restrict__ stats, const float* __restrict__ wx, const float* __restrict__ bx,
-    const float* __restrict__ wv, T* __restrict__ vslot, int n, int C, int side) {
-  MRLA_TOK_PROLOGUE(0)
+// forward on the LDS-DMA row pipeline (round 4; it replaced the register-staged row gathers of rounds 1 - 3: token_apply_fwd
+// 0.387 -> 0.323 ms, token_base_value_fwd 0.269 -> 0.216 ms per step): rows by `buffer_load ... lds` with zeros outside the
+// map, the LayerNorm records of a window row through LDS (one dword DMA per step, broadcast ds_read_b64), the three LN_x rows
+// rotating by name.
+//   VALUE = false (mrla_token_apply_fwd):  out[b,i>=1] = res*x + a*gelu(dwconv3x3(LN_x(x) map)) + lam*LN_o(o_prev); cls row
+//   VALUE = true  (mrla_token_base_value_fwd): V_t = dwconv3x3(LN_x(x) map) -> the dense [b, side, side, c] ring slot
+// Step r (r0-2 .. r1-1 of the workgroup's row band) normalises x row r+1 and, from r0 on, writes output row r.
+// ------------------------------------------------------------------------------------------------
+// LN_x records of the 9 window tokens s0-1 .. s0+7 / LN_o records of the owned tokens = window tokens 1 .. 7
+#define MRLA_B64(i, off) "ds_read_b64 %" #i ", %[a] offset:" #off "\n\t"
+__device__ __forceinline__ void stat_read_issue_x9(const float* sbuf, StatRow<kS + 2>& o) {
+  static_assert(kS + 2 == 9, "window width");
+  const unsigned a = lds_addr_of(sbuf);
+  asm volatile(MRLA_B64(0, 0) MRLA_B64(1, 16) MRLA_B64(2, 32) MRLA_B64(3, 48) MRLA_B64(4, 64) MRLA_B64(5, 80) MRLA_B64(6, 96)
+               MRLA_B64(7, 112) MRLA_B64(8, 128) ""
+               : "=&v"(o.v[0]), "=&v"(o.v[1]), "=&v"(o.v[2]), "=&v"(o.v[3]), "=&v"(o.v[4]), "=&v"(o.v[5]), "=&v"(o.v[6]),
+                 "=&v"(o.v[7]), "=&v"(o.v[8])
+               : [a] "v"(a) : "memory");
+}
+__device__ __forceinline__ void stat_read_issue_o9(const float* sbuf, StatRow<kS>& o) {
+  const unsigned a = lds_addr_of(sbuf);
+  asm volatile(MRLA_B64(0, 24) MRLA_B64(1, 40) MRLA_B64(2, 56) MRLA_B64(3, 72) MRLA_B64(4, 88) MRLA_B64(5, 104) MRLA_B64(6, 120) ""
+               : "=&v"(o.v[0]), "=&v"(o.v[1]), "=&v"(o.v[2]), "=&v"(o.v[3]), "=&v"(o.v[4]), "=&v"(o.v[5]), "=&v"(o.v[6])
+               : [a] "v"(a) : "memory");
+}
+#undef MRLA_B64
+__device__ __forceinline__ void stat_fence_wait(StatRow<kS + 2>& o) {
+  asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(o.v[0]), "+v"(o.v[1]), "+v"(o.v[2]), "+v"(o.v[3]), "+v"(o.v[4]), "+v"(o.v[5]), "+v"(o.v[6]),
+                                        "+v"(o.v[7]), "+v"(o.v[8]) : : "memory");
+}
+__device__ __forceinline__ void stat_fence(StatRow<kS>& o) {
+  asm volatile("" : "+v"(o.v[0]), "+v"(o.v[1]), "+v"(o.v[2]), "+v"(o.v[3]), "+v"(o.v[4]), "+v"(o.v[5]), "+v"(o.v[6]) : : "memory");
+}
+
+template <typename T> constexpr int tok_fwd_wave_bytes() {
+  return RowIO<T, kS + 2>::kBytes + 2 * RowIO<T, kS>::kBytes + 3 * kStatBufBytes;
+}
+
+template <typename T, bool VALUE>
+__global__ __launch_bounds__(kMaxStrips * kWave) void token_fwd_rows(
+    const T* __restrict__ x, const T* __restrict__ o, const float* __restrict__ stats, const float* __restrict__ wx,
+    const float* __restrict__ bx, const float* __restrict__ wo, const float* __restrict__ bo,
+    const float* __restrict__ wv, const float* __restrict__ gate, const float* __restrict__ lam, T* __restrict__ out,
+    int n, int C, int side, int d, int res) {
+  extern __shared__ __align__(16) unsigned char smem_raw[];
+  const int lane = threadIdx.x & (kWave - 1), wave = threadIdx.x / kWave, nwaves = blockDim.x / kWave;
+  unsigned char* wbuf = smem_raw + (size_t)wave * tok_fwd_wave_bytes<T>();
+  constexpr int XB_ = RowIO<T, kS + 2>::kBytes, OB_ = RowIO<T, kS>::kBytes;
+  T* bufX = reinterpret_cast<T*>(wbuf);
+  T* bufO = reinterpret_cast<T*>(wbuf + XB_);
+  T* bufS = reinterpret_cast<T*>(wbuf + XB_ + OB_);
+  auto sbuf = [&](int r) { return reinterpret_cast<float*>(wbuf + XB_ + 2 * OB_) + ((r + 6) % 3) * (kStatBufBytes / 4); };   // r >= -2
+  const int cbase = blockIdx.x * kWave, c = cbase + lane;
+  const int b = blockIdx.y, W = side, H = side;
+  const int nstrips = (W + kS - 1) / kS;
+  const int tok0 = b * n + 1;
+  const size_t ioff = (size_t)tok0 * C;
+  const int rowelems = W * C;
+  const int r0 = (int)((H * blockIdx.z) / gridDim.z), r1 = (int)((H * (blockIdx.z + 1)) / gridDim.z);   // this workgroup's row band
   float w[9];
 #pragma unroll
   for (int k = 0; k < 9; ++k) w[k] = wv[c * 9 + k];
+  const float a = VALUE ? 1.f : gate[(size_t)b * (C / d) + c / d];
   const float wxc = wx[c], bxc = bx[c];
+  const float lm = VALUE ? 0.f : lam[c], woc = VALUE ? 0.f : wo[c], boc = VALUE ? 0.f : bo[c];
+  const float resf = (!VALUE && res) ? 1.f : 0.f;
   const T* xi = x + ioff;
-  T* vo = vslot + (size_t)b * H * W * C;
+  const T* oi = VALUE ? nullptr : o + ioff;
+  T* yo = VALUE ? out + (size_t)b * H * W * C : out + ioff;       // the dense ring slot / the token rows of `out`
   for (int s = wave; s < nstrips; s += nwaves) {
     const int s0 = s * kS, nc = min(kS, W - s0);
-    float ra[kS + 2], rb[kS + 2], rc[kS + 2];
-    RowLoad<T, kS + 2> qx;
-    RowAddr<T, kS + 2> ax;
-    make_row_addr<T, kS + 2>(ax, s0 - 1, W, C, cbase, lane);
-    read_row<T, true, kS + 2>(xi, r0 - 1, s0 - 1, H, W, C, cbase, c, lane, scrT, ra);
-    normalise_row<kS + 2>(ra, stats, tok0, side, r0 - 1, s0 - 1, wxc, bxc);
-    read_row<T, true, kS + 2>(xi, r0, s0 - 1, H, W, C, cbase, c, lane, scrT, rb);
-    normalise_row<kS + 2>(rb, stats, tok0, side, r0, s0 - 1, wxc, bxc);
-    issue_row<T, kS + 2>(qx, xi, r0 + 1, H, W * C, ax);
-    for (int r = r0; r < r1; ++r) {
-      float y[kS];
-      finish_row<T, kS + 2>(qx, lane, scrT, rc);
-      issue_row<T, kS + 2>(qx, xi, r + 2, H, W * C, ax);
-      normalise_row<kS + 2>(rc, stats, tok0, side, r + 1, s0 - 1, wxc, bxc);
+    RowIO<T, kS + 2> ax;
+    RowIO<T, kS> ao, as;
+    make_row_io<T, kS + 2>(ax, s0 - 1, kS + 2, W, C, cbase, lane);
+    make_row_io<T, kS>(ao, s0, nc, W, C, cbase, lane);
+    make_row_io<T, kS>(as, s0, nc, W, C, cbase, lane);
+    const unsigned svoff = stat_voff(s0 - 1, kS + 2, side, lane);
+    RawRow<kS + 2> xr;
+    RawRow<kS> ov;
+    StatRow<kS + 2> sx;
+    StatRow<kS> so;
+    xr.clear(); ov.clear();
+    float xa[kS + 2], xb[kS + 2], xc[kS + 2];        // LN_x rows r-1, r, r+1 on columns s0-1 .. s0+kS
+    float raw0[kS], raw1[kS];                        // raw x of the owned pixels of rows r / r+1 (the block residual)
 #pragma unroll
-      for (int j = 0; j < kS; ++j) y[j] = conv_at(w, ra, rb, rc, j);
-      write_row<T, true, kS>(vo, r, s0, nc, W, C, cbase, c, true, lane, reinterpret_cast<T*>(scrS), y);
+    for (int j = 0; j < kS + 2; ++j) { xa[j] = 0.f; xb[j] = 0.f; }
 #pragma unroll
-      for (int j = 0; j < kS + 2; ++j) { ra[j] = rb[j]; rb[j] = rc[j]; }
+    for (int j = 0; j < kS; ++j) raw0[j] = 0.f;
+    // step r consumes x row r+1 and o row r
+    row_fetch<T, kS + 2>(ax, xi, r0 - 1, H, rowelems, bufX);
+    if (!VALUE) row_fetch<T, kS>(ao, oi, r0 - 2, H, rowelems, bufO);
+    stat_fetch(stats, tok0, side, r0 - 2, svoff, sbuf(r0 - 2));
+    stat_fetch(stats, tok0, side, r0 - 1, svoff, sbuf(r0 - 1));
+    auto step = [&](int r, float (&XA)[kS + 2], float (&XB)[kS + 2], float (&XC)[kS + 2]) {
+      // step r-1 (if it wrote a row) stored after its fetches: that store may stay in flight
+      if (r <= r0) rows_landed(); else rows_landed_keep<RowIO<T, kS>::NL>();
+      row_read_issue<T, kS + 2>(bufX, lane, xr);
+      if (!VALUE) row_read_issue<T, kS>(bufO, lane, ov);
+      stat_read_issue_x9(sbuf(r + 1), sx);
+      if (!VALUE) stat_read_issue_o9(sbuf(r), so);
+      row_read_fence(xr, true);
+      if (!VALUE) row_read_fence(ov, false);
+      stat_fence_wait(sx);
+      if (!VALUE) stat_fence(so);
+      row_fetch<T, kS + 2>(ax, xi, r + 2, H, rowelems, bufX);
+      if (!VALUE) row_fetch<T, kS>(ao, oi, r + 1, H, rowelems, bufO);
+      stat_fetch(stats, tok0, side, r + 2, svoff, sbuf(r + 2));
+      // LN_x on the way in (row r+1); pixels outside the map come out as exact zeros
+#pragma unroll
+      for (int j = 0; j < kS + 2; ++j) {
+        const bool ok = r + 1 >= 0 && r + 1 < side && s0 - 1 + j >= 0 && s0 - 1 + j < side;      // wave-uniform
+        const float hat = (xr.v[j] - sx.v[j].x) * sx.v[j].y;        // (rstd arrives as 0 outside the map)
+        XC[j] = fmaf(hat, wxc, ok ? bxc : 0.f);
+        if (j >= 1 && j <= kS) raw1[j - 1] = xr.v[j];
+      }
+      if (r >= r0) {
+        float y[kS];
+#pragma unroll
+        for (int j = 0; j < kS; ++j) {
+          const float u = conv_at(w, XA, XB, XC, j);
+          if (VALUE) {
+            y[j] = u;
+          } else {
+            const float on = fmaf((ov.v[j] - so.v[j].x) * so.v[j].y, woc, boc);
+            y[j] = fmaf(a, gelu_f(u), fmaf(lm, on, resf * raw0[j]));
+          }
+        }
+        row_store<T, kS>(as, yo, r, rowelems, lane, bufS, y);
+      }
+#pragma unroll
+      for (int j = 0; j < kS; ++j) raw0[j] = raw1[j];
+    };
+    // steps r0-2 .. r1-1: after three steps every array is back in its starting role
+    int r = r0 - 2;
+    for (; r + 3 <= r1; r += 3) {
+      step(r,     xa, xb, xc);
+      step(r + 1, xb, xc, xa);
+      step(r + 2, xc, xa, xb);
     }
+    if (r < r1) {
+      step(r, xa, xb, xc);
+      if (r + 1 < r1) step(r + 1, xb, xc, xa);
+    }
+    rows_landed();
+  }
+  if (!VALUE && wave == 0 && blockIdx.z == 0) {      // cls row of this (image, 64 channels): out = res*x + LN_x(x)
+    const size_t g = (size_t)b * n * C + c;
+    const float* st = stats + (size_t)b * n * TS_N;
+    const float xv = to_f(x[g]);
+    out[g] = from_f<T>(fmaf(resf, xv, fmaf((xv - st[TS_MX]) * st[TS_RX], wxc, bxc)));
   }
 }
 
@@ -492,20 +481,16 @@ int token_bands(int B, int C, int side) {
   return bands;
 }
 
-static size_t tok_lds(int nwaves, int nred) {
-  return (size_t)nwaves * nred * kWave * sizeof(float) + (size_t)nwaves * 2 * scratch_bytes<float>();
-}
-
 int launch_token_apply_fwd_nhwc(const void* x, const void* o, const float* stats, const float* wx, const float* bx,
                                 const float* wo, const float* bo, const float* wv, const float* gate, const float* lam,
                                 void* out, int B, int n, int C, int side, int d, int res, int dtype, hipStream_t st) {
   const int nwaves = std::min((side + kS - 1) / kS, kMaxStrips);
   const dim3 grid(C / kWave, B, token_bands(B, C, side)), block(nwaves * kWave);
-  const size_t lds = tok_lds(nwaves, 0);
 #define CALL(TT)                                                                                                    \
   {                                                                                                                 \
-    if (set_lds_n(token_apply_fwd_nhwc<TT>, lds) != hipSuccess) return MRLA_EHIP;                                     \
-    hipLaunchKernelGGL((token_apply_fwd_nhwc<TT>), grid, block, lds, st, (const TT*)x, (const TT*)o, stats, wx, bx, wo, \
+    const size_t lds = (size_t)nwaves * tok_fwd_wave_bytes<TT>();                                                   \
+    if (set_lds_n(token_fwd_rows<TT, false>, lds) != hipSuccess) return MRLA_EHIP;                                   \
+    hipLaunchKernelGGL((token_fwd_rows<TT, false>), grid, block, lds, st, (const TT*)x, (const TT*)o, stats, wx, bx, wo, \
                        bo, wv, gate, lam, (TT*)out, n, C, side, d, res);                                            \
   }
   MRLA_DISPATCH_TN(dtype, CALL)
@@ -539,12 +524,13 @@ int launch_token_value_fwd_nhwc(const void* x, const float* stats, const float* 
   if (!token_nhwc_applies(C)) return MRLA_EUNSUPPORTED;
   const int nwaves = std::min((side + kS - 1) / kS, kMaxStrips);
   const dim3 grid(C / kWave, B, token_bands(B, C, side)), block(nwaves * kWave);
-  const size_t lds = tok_lds(nwaves, 0);
 #define CALL(TT)                                                                                                    \
   {                                                                                                                 \
-    if (set_lds_n(token_value_fwd_nhwc<TT>, lds) != hipSuccess) return MRLA_EHIP;                                     \
-    hipLaunchKernelGGL((token_value_fwd_nhwc<TT>), grid, block, lds, st, (const TT*)x, stats, wx, bx, wv, (TT*)vslot, \
-                       n, C, side);                                                                                 \
+    const size_t lds = (size_t)nwaves * tok_fwd_wave_bytes<TT>();                                                   \
+    if (set_lds_n(token_fwd_rows<TT, true>, lds) != hipSuccess) return MRLA_EHIP;                                    \
+    hipLaunchKernelGGL((token_fwd_rows<TT, true>), grid, block, lds, st, (const TT*)x, (const TT*)nullptr, stats, wx, bx, \
+                       (const float*)nullptr, (const float*)nullptr, wv, (const float*)nullptr, (const float*)nullptr, \
+                       (TT*)vslot, n, C, side, 1, 0);                                                               \
   }
   MRLA_DISPATCH_TN(dtype, CALL)
 #undef CALL

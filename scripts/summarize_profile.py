@@ -15,6 +15,12 @@ out = sys.argv[2] if len(sys.argv) > 2 else raw
 
 
 def short(name):
+    if "token_fwd_rows" in name:            # <T, VALUE>: VALUE = true is the MRLA-base token module's value forward
+        return "token_value_fwd" if (", true>" in name or "Lb1EE" in name) else "token_apply_fwd"
+    if "base_value_bwd_wide" in name:
+        return "base_value_bwd"
+    if "token_stats_vec_kernel" in name:
+        return "token_stats_kernel"
     if "token_apply_bwd_rows" in name:      # <T, RAGGED, BASE>: the MRLA-base token module's value backward is BASE = true
         return "token_base_value_bwd" if (", true>" in name or "Lb1EEv" in name) else "token_apply_bwd"
     for key in ("light_stats_fwd_fused", "conv1x1_kstream", "conv1x1_wide", "conv1x1_fwd", "conv1x1_wgrad_reduce", "conv1x1_wgrad", "weight_bank",

@@ -259,10 +259,19 @@ class ResNet_mrlal(_ResNetMRLA):
 
     def forward_features(self, x):
         if self.channels_last and x.is_cuda:
-            x = x.contiguous(memory_format=torch.channels_last)
+            x = _to_channels_last(x)
         with F_.batched_bookkeeping(self._stochastic_depth_blocks(), self._weight_bank() if x.is_cuda else None):
             x = F_.bn_relu_maxpool(self.conv1(x), self.bn1, self.maxpool)
             return self.layer4(self.layer3(self.layer2(self.layer1(x))))
+
+
+def _to_channels_last(x):
+    """The image batch in channels_last -- and, under autocast, already in the autocast dtype: the stem convolution would cast
+    it anyway (same values), and one copy kernel instead of two halves the passes over the largest input of the step (154 MB
+    fp32 at b = 256)."""
+    if x.dtype == torch.float32 and torch.is_autocast_enabled("cuda"):
+        return x.to(dtype=torch.get_autocast_dtype("cuda"), memory_format=torch.channels_last)
+    return x.contiguous(memory_format=torch.channels_last)
 
 
 class ResNet_mrlab(_ResNetMRLA):
@@ -301,7 +310,7 @@ class ResNet_mrlab(_ResNetMRLA):
 
     def forward_features(self, x):
         if self.channels_last and x.is_cuda:
-            x = x.contiguous(memory_format=torch.channels_last)
+            x = _to_channels_last(x)
         with F_.batched_bookkeeping(self._stochastic_depth_blocks(), self._weight_bank() if x.is_cuda else None):
             x = F_.bn_relu_maxpool(self.conv1(x), self.bn1, self.maxpool)
             k = v = None

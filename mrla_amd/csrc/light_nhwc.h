@@ -124,19 +124,21 @@ __device__ __forceinline__ float conv_at(const float (&w)[9], const float* __res
   return s;
 }
 
-// Sum per-lane accumulators over the waves of the workgroup (fixed order); result valid in wave 0.
+// Sum per-lane accumulators over the waves of the workgroup that hold the same channels -- waves v with equal v % wc (wc = 1:
+// all of them) -- in a fixed order; result valid in waves 0 .. wc-1.
 template <int K>
-__device__ __forceinline__ void wg_reduce(float (&acc)[K], float* __restrict__ red, int lane, int wave, int nwaves) {
-  if (nwaves == 1) return;
+__device__ __forceinline__ void wg_reduce(float (&acc)[K], float* __restrict__ red, int lane, int wave, int nwaves,
+                                          int wc = 1) {
+  if (nwaves == wc) return;
   __syncthreads();
 #pragma unroll
   for (int k = 0; k < K; ++k) red[(wave * K + k) * kWave + lane] = acc[k];
   __syncthreads();
-  if (wave == 0) {
+  if (wave < wc) {
 #pragma unroll
     for (int k = 0; k < K; ++k) {
       float s = 0.f;
-      for (int v = 0; v < nwaves; ++v) s += red[(v * K + k) * kWave + lane];
+      for (int v = wave; v < nwaves; v += wc) s += red[(v * K + k) * kWave + lane];
       acc[k] = s;
     }
   }

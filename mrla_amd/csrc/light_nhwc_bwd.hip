@@ -160,16 +160,7 @@ __global__ __launch_bounds__(kMaxStrips * kWave) void light_apply_bwd_nhwc(
 // ------------------------------------------------------------------------------------------------
 // launchers
 // ------------------------------------------------------------------------------------------------
-// Images a workgroup walks through, at most 8.
-// W > 0 (the dWv-producing backward kernels, 2 waves per SIMD = 2048 wave slots): about one round of resident waves, so
-// that the prologue, the dWv reduction and its partial rows are amortised over several images (14x14 stage: +25 %).
-// W == 0 (the lighter passes, twice the occupancy): >= 2048 workgroups; they are faster with more, shorter workgroups.
-int nhwc_images_per_group(int B, int C, int W) {
-  const long wgs = (long)B * ((C + kWave - 1) / kWave);
-  if (W <= 0) return (int)std::max(1L, std::min(8L, wgs / 2048));
-  const int nstrips = (W + kS - 1) / kS;
-  return (int)std::max(1L, std::min(8L, wgs * std::min(nstrips, kMaxStrips) / 2048));
-}
+// (nhwc_images_per_group(): light_nhwc_wide.hip, next to the launch geometry it belongs to)
 
 int launch_light_apply_bwd_nhwc(const void* dout, const void* x, const void* o, const float* wv, const float* gate,
                                 const float* cb, const float* lam, const float* dp, const float* dyx, void* dx,

@@ -37,14 +37,17 @@
 namespace mrla {
 
 // Per-wave LDS row buffers follow the cross-wave reduction area.
+// The waves of a workgroup are `wc` NEIGHBOURING channel groups x (waves / wc) strips side by side (wave = strip slot * wc +
+// channel-group slot); gridDim.z splits the strips further in the passes that keep no sums over them.  See wide_shape().
 #define MRLA_WIDE_PROLOGUE(NRED, WAVE_BYTES)                                                              \
   extern __shared__ __align__(16) unsigned char smem_raw[];                                               \
   const int lane = threadIdx.x & (kWave - 1), wave = threadIdx.x / kWave, nwaves = blockDim.x / kWave;    \
   float* red = reinterpret_cast<float*>(smem_raw);                                                        \
   unsigned char* wbuf = smem_raw + (size_t)nwaves * (NRED) * kWave * sizeof(float) + (size_t)wave * (WAVE_BYTES); \
-  const int cbase = blockIdx.x * kWave;                                                                   \
+  const int cbase = (blockIdx.x * wc + wave % wc) * kWave;                                                \
   const int c = cbase + lane;                                                                             \
   const int nstrips = (W + kS - 1) / kS;                                                                  \
+  const int sfirst = blockIdx.z * (nwaves / wc) + wave / wc, sstep = gridDim.z * (nwaves / wc);           \
   const int rowelems = W * C;                                                                             \
   (void)red;
 
@@ -85,18 +88,19 @@ struct WaveMoments {
     n += an;
   }
 };
-// Workgroup reduction in wave order; wave 0 writes the record of (image b, channel c).
+// Workgroup reduction over the waves that hold the same channels (v % wc equal), in wave order; waves 0 .. wc-1 write the
+// records of (image b, their channels c).
 __device__ __forceinline__ void store_moments(WaveMoments& w, float* __restrict__ red, float* __restrict__ mom, int lane,
-                                              int wave, int nwaves) {
-  if (nwaves > 1) {
+                                              int wave, int nwaves, int wc) {
+  if (nwaves > wc) {
     __syncthreads();
     float* mine = red + (size_t)wave * kMomRed * kWave;
 #pragma unroll
     for (int k = 0; k < M_N; ++k) mine[k * kWave + lane] = w.s[k];
     mine[M_N * kWave + lane] = w.pv; mine[(M_N + 1) * kWave + lane] = w.po; mine[(M_N + 2) * kWave + lane] = w.n;
     __syncthreads();
-    if (wave == 0) {
-      for (int v = 1; v < nwaves; ++v) {
+    if (wave < wc) {
+      for (int v = wave + wc; v < nwaves; v += wc) {
         const float* o = red + (size_t)v * kMomRed * kWave;
         float a[M_N];
 #pragma unroll
@@ -106,7 +110,7 @@ __device__ __forceinline__ void store_moments(WaveMoments& w, float* __restrict_
       }
     }
   }
-  if (wave == 0) {
+  if (wave < wc) {
 #pragma unroll
     for (int k = 0; k < M_N; ++k) mom[k] = w.s[k];
     mom[M_PV] = w.pv;
@@ -125,7 +129,7 @@ template <typename T> constexpr int stats_bwd_wave_bytes() { return RowIO<T, kS 
 template <typename T, bool GELU, bool HAS_O, int AUX>
 __global__ __launch_bounds__(kMaxStrips * kWave) void light_stats_bwd_wide(
     const T* __restrict__ dout, const T* __restrict__ x, const T* __restrict__ o, const float* __restrict__ wv,
-    const float* __restrict__ mom, float* __restrict__ bmom, int B, int C, int H, int W, int BG) {
+    const float* __restrict__ mom, float* __restrict__ bmom, int B, int C, int H, int W, int BG, int wc) {
   MRLA_WIDE_PROLOGUE(D_N, stats_bwd_wave_bytes<T>())
   T* bufX = reinterpret_cast<T*>(wbuf);
   T* bufG = reinterpret_cast<T*>(wbuf + RowIO<T, kS + 2>::kBytes);
@@ -142,7 +146,7 @@ __global__ __launch_bounds__(kMaxStrips * kWave) void light_stats_bwd_wide(
     float acc[D_N] = {0.f, 0.f, 0.f};
     const float pV = mom ? mom[((size_t)b * C + c) * M_REC + M_PV] : 0.f;
     const float pO = (mom && HAS_O) ? mom[((size_t)b * C + c) * M_REC + M_PO] : 0.f;
-    for (int s = wave; s < nstrips; s += nwaves) {
+    for (int s = sfirst; s < nstrips; s += sstep) {
       const int s0 = s * kS;
       RowIO<T, kS + 2> ax;
       RowIO<T, kS> ag;
@@ -181,8 +185,8 @@ __global__ __launch_bounds__(kMaxStrips * kWave) void light_stats_bwd_wide(
       MRLA_ROTATE3(H, step, xa, xb, xc)
       rows_landed();                                 // the look-ahead rows of the last step (zeros) are still in flight
     }
-    wg_reduce<D_N>(acc, red, lane, wave, nwaves);
-    if (wave == 0) {
+    wg_reduce<D_N>(acc, red, lane, wave, nwaves, wc);
+    if (wave < wc) {
 #pragma unroll
       for (int k = 0; k < D_N; ++k) bmom[((size_t)b * C + c) * D_N + k] = acc[k];
     }
@@ -199,7 +203,7 @@ template <typename T> constexpr int stats_fwd_wave_bytes() { return RowIO<T, kS 
 template <typename T, bool GELU, bool HAS_O, bool RAGGED>
 __global__ __launch_bounds__(kMaxStrips * kWave) void light_stats_fwd_wide(
     const T* __restrict__ x, const T* __restrict__ o, const float* __restrict__ wv, float* __restrict__ mom,
-    T* __restrict__ vout, int B, int C, int H, int W, int BG) {
+    T* __restrict__ vout, int B, int C, int H, int W, int BG, int wc) {
   MRLA_WIDE_PROLOGUE(kMomRed, stats_fwd_wave_bytes<T>())
   T* bufX = reinterpret_cast<T*>(wbuf);
   T* bufO = reinterpret_cast<T*>(wbuf + RowIO<T, kS + 2>::kBytes);
@@ -215,7 +219,7 @@ __global__ __launch_bounds__(kMaxStrips * kWave) void light_stats_fwd_wide(
     T* vo = vout ? vout + ioff : nullptr;
     WaveMoments wm;
     wm.clear();
-    for (int s = wave; s < nstrips; s += nwaves) {
+    for (int s = sfirst; s < nstrips; s += sstep) {
       float acc[M_N] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
       float pV = 0.f, pO = 0.f;                       // this strip's pivots: its first V and o
       const int s0 = s * kS, nc = min(kS, W - s0);
@@ -267,7 +271,7 @@ __global__ __launch_bounds__(kMaxStrips * kWave) void light_stats_fwd_wide(
       rows_landed();
       wm.merge(acc, pV, pO, (float)(H * nc));
     }
-    store_moments(wm, red, mom + ((size_t)b * C + c) * M_REC, lane, wave, nwaves);
+    store_moments(wm, red, mom + ((size_t)b * C + c) * M_REC, lane, wave, nwaves, wc);
   }
 }
 
@@ -317,7 +321,7 @@ template <typename T, bool AFF, bool RAGGED, int AUX>
 __device__ __forceinline__ void light_stats_fwd_fused_body(
     const T* __restrict__ pre, const T* __restrict__ o, const float* __restrict__ wv, float* __restrict__ mom,
     T* __restrict__ xout, const float* __restrict__ psc, const float* __restrict__ psh, T* __restrict__ vout, int B,
-    int C, int H, int W, int BG) {
+    int C, int H, int W, int BG, int wc) {
   MRLA_WIDE_PROLOGUE(kMomRed, fused_wave_bytes<T>())
   constexpr int RB = RowIO<T, kS + 2>::kBytes;
   T* bufP = reinterpret_cast<T*>(wbuf);
@@ -336,7 +340,7 @@ __device__ __forceinline__ void light_stats_fwd_fused_body(
     T* vo = vout ? vout + ioff : nullptr;
     WaveMoments wm;
     wm.clear();
-    for (int s = wave; s < nstrips; s += nwaves) {
+    for (int s = sfirst; s < nstrips; s += sstep) {
       float acc[M_N] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
       float pV = 0.f, pO = 0.f;                       // this strip's pivots: its first V and o
       const int s0 = s * kS, nc = min(kS, W - s0);
@@ -409,7 +413,7 @@ __device__ __forceinline__ void light_stats_fwd_fused_body(
       rows_landed();
       wm.merge(acc, pV, pO, (float)(H * nc));
     }
-    store_moments(wm, red, mom + ((size_t)b * C + c) * M_REC, lane, wave, nwaves);
+    store_moments(wm, red, mom + ((size_t)b * C + c) * M_REC, lane, wave, nwaves, wc);
   }
 }
 
@@ -417,8 +421,8 @@ template <typename T, bool AFF, bool RAGGED, int AUX>
 __global__ __launch_bounds__(kMaxStrips * kWave) void light_stats_fwd_fused_wide(
     const T* __restrict__ pre, const T* __restrict__ o, const float* __restrict__ wv, float* __restrict__ mom,
     T* __restrict__ xout, const float* __restrict__ psc, const float* __restrict__ psh, T* __restrict__ vout, int B,
-    int C, int H, int W, int BG) {
-  light_stats_fwd_fused_body<T, AFF, RAGGED, AUX>(pre, o, wv, mom, xout, psc, psh, vout, B, C, H, W, BG);
+    int C, int H, int W, int BG, int wc) {
+  light_stats_fwd_fused_body<T, AFF, RAGGED, AUX>(pre, o, wv, mom, xout, psc, psh, vout, B, C, H, W, BG, wc);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -431,7 +435,7 @@ template <typename T, bool GELU, bool HAS_O, int AUX>
 __global__ __launch_bounds__(kMaxStrips * kWave) void light_apply_fwd_wide(
     const T* __restrict__ x, const T* __restrict__ o, const float* __restrict__ wv, const float* __restrict__ gate,
     const float* __restrict__ sc, const float* __restrict__ sh, const float* __restrict__ lam,
-    const float* __restrict__ dp, T* __restrict__ out, int B, int C, int H, int W, int BG, int d, int res) {
+    const float* __restrict__ dp, T* __restrict__ out, int B, int C, int H, int W, int BG, int d, int res, int wc) {
   MRLA_WIDE_PROLOGUE(0, apply_fwd_wave_bytes<T>())
   T* bufX = reinterpret_cast<T*>(wbuf);
   T* bufO = reinterpret_cast<T*>(wbuf + RowIO<T, kS + 2>::kBytes);
@@ -457,7 +461,7 @@ __global__ __launch_bounds__(kMaxStrips * kWave) void light_apply_fwd_wide(
 #pragma unroll
     for (int k = 0; k < 9; ++k) w[k] = GELU ? w0[k] : w0[k] * A;
     if (!GELU) w[4] += resf;
-    for (int s = wave; s < nstrips; s += nwaves) {
+    for (int s = sfirst; s < nstrips; s += sstep) {
       const int s0 = s * kS, nc = min(kS, W - s0);
       RowIO<T, kS + 2> ax;
       RowIO<T, kS> ao, as;
@@ -503,7 +507,7 @@ __global__ __launch_bounds__(kMaxStrips * kWave) void light_apply_fwd_pre_wide(
     const T* __restrict__ pre, const T* __restrict__ o, const float* __restrict__ psc, const float* __restrict__ psh,
     const float* __restrict__ wv, const float* __restrict__ gate, const float* __restrict__ sc,
     const float* __restrict__ sh, const float* __restrict__ lam, const float* __restrict__ dp, T* __restrict__ out, int B,
-    int C, int H, int W, int BG, int d, int res) {
+    int C, int H, int W, int BG, int d, int res, int wc) {
   MRLA_WIDE_PROLOGUE(0, fused_wave_bytes<T>())
   constexpr int RB = RowIO<T, kS + 2>::kBytes;
   T* bufP = reinterpret_cast<T*>(wbuf);
@@ -530,7 +534,7 @@ __global__ __launch_bounds__(kMaxStrips * kWave) void light_apply_fwd_pre_wide(
 #pragma unroll
     for (int k = 0; k < 9; ++k) w[k] = w0[k] * A;
     w[4] += resf;
-    for (int s = wave; s < nstrips; s += nwaves) {
+    for (int s = sfirst; s < nstrips; s += sstep) {
       const int s0 = s * kS, nc = min(kS, W - s0);
       RowIO<T, kS + 2> ax;
       RowIO<T, kS> as;
@@ -608,7 +612,7 @@ __global__ __launch_bounds__(kBwdWaves * kWave) void light_apply_bwd_wide(
     const float* __restrict__ gate, const float* __restrict__ cb, const float* __restrict__ lam,
     const float* __restrict__ dp, const float* __restrict__ dyx, T* __restrict__ dx, T* __restrict__ dprev,
     float* __restrict__ dwv_part, const T* __restrict__ pre, const float* __restrict__ pre_center,
-    float* __restrict__ pre_tmom, int B, int C, int H, int W, int BG, int d, int res) {
+    float* __restrict__ pre_tmom, int B, int C, int H, int W, int BG, int d, int res, int wc) {
   static_assert(!PRE || RELU, "the deferred-BatchNorm sums belong to the fused relu(pre + o) producer");
   MRLA_WIDE_PROLOGUE(9, (apply_bwd_wave_bytes<T, PRE>()))
   constexpr int XB_ = RowIO<T, kS + 4>::kBytes, GB = RowIO<T, kS + 2>::kBytes, SB = RowIO<T, kS>::kBytes;
@@ -643,7 +647,7 @@ __global__ __launch_bounds__(kBwdWaves * kWave) void light_apply_bwd_wide(
     const float a = gate[(size_t)b * G + c / d];
     const float E = e_ * dpb, F = f_ * a;
     const float dy = dyx[(size_t)b * C + c];
-    for (int s = wave; s < nstrips; s += nwaves) {
+    for (int s = sfirst; s < nstrips; s += sstep) {
       const int s0 = s * kS, nc = min(kS, W - s0);
       RowIO<T, kS + 4> ax;
       RowIO<T, kS + 2> ag;
@@ -759,14 +763,14 @@ __global__ __launch_bounds__(kBwdWaves * kWave) void light_apply_bwd_wide(
       rows_landed();
     }
   }
-  wg_reduce<9>(wg, red, lane, wave, nwaves);
-  if (wave == 0) {
+  wg_reduce<9>(wg, red, lane, wave, nwaves, wc);
+  if (wave < wc) {
 #pragma unroll
     for (int k = 0; k < 9; ++k) dwv_part[((size_t)blockIdx.y * C + c) * 9 + k] = wg[k];
   }
   if (PRE) {
-    wg_reduce<2>(pm, red, lane, wave, nwaves);
-    if (wave == 0) {
+    wg_reduce<2>(pm, red, lane, wave, nwaves, wc);
+    if (wave < wc) {
       pre_tmom[((size_t)blockIdx.y * C + c) * 2 + 0] = pm[0];
       pre_tmom[((size_t)blockIdx.y * C + c) * 2 + 1] = pm[1];
     }
@@ -788,7 +792,7 @@ template <typename T, bool PRE>
 __global__ __launch_bounds__(kMaxStrips * kWave) void base_value_bwd_wide(
     const T* __restrict__ dout, const T* __restrict__ x, const float* __restrict__ wv, const T* __restrict__ dv,
     const float* __restrict__ dyx, T* __restrict__ dx, float* __restrict__ dwv_part, const T* __restrict__ pre,
-    const float* __restrict__ pre_center, float* __restrict__ pre_tmom, int B, int C, int H, int W, int BG, int res) {
+    const float* __restrict__ pre_center, float* __restrict__ pre_tmom, int B, int C, int H, int W, int BG, int res, int wc) {
   MRLA_WIDE_PROLOGUE(9, (base_vbwd_wave_bytes<T, PRE>()))
   constexpr int UB_ = RowIO<T, kS + 2>::kBytes, SB = RowIO<T, kS>::kBytes;
   T* bufU = reinterpret_cast<T*>(wbuf);
@@ -813,7 +817,7 @@ __global__ __launch_bounds__(kMaxStrips * kWave) void base_value_bwd_wide(
     const T* pri = PRE ? pre + ioff : nullptr;
     T* dxo = dx + ioff;
     const float dy = dyx[(size_t)b * C + c];
-    for (int s = wave; s < nstrips; s += nwaves) {
+    for (int s = sfirst; s < nstrips; s += sstep) {
       const int s0 = s * kS, nc = min(kS, W - s0);
       RowIO<T, kS + 2> au;
       RowIO<T, kS> ag, as;
@@ -874,28 +878,80 @@ __global__ __launch_bounds__(kMaxStrips * kWave) void base_value_bwd_wide(
       rows_landed();
     }
   }
-  wg_reduce<9>(wg, red, lane, wave, nwaves);
-  if (wave == 0) {
+  wg_reduce<9>(wg, red, lane, wave, nwaves, wc);
+  if (wave < wc) {
 #pragma unroll
     for (int k = 0; k < 9; ++k) dwv_part[((size_t)blockIdx.y * C + c) * 9 + k] = wg[k];
   }
   if (PRE) {
-    wg_reduce<2>(pm, red, lane, wave, nwaves);
-    if (wave == 0) {
+    wg_reduce<2>(pm, red, lane, wave, nwaves, wc);
+    if (wave < wc) {
       pre_tmom[((size_t)blockIdx.y * C + c) * 2 + 0] = pm[0];
       pre_tmom[((size_t)blockIdx.y * C + c) * 2 + 1] = pm[1];
     }
   }
 }
 
-struct WideLaunch { dim3 grid, block; size_t lds; int BG; };
-static WideLaunch wide_launch(int B, int C, int W, int nred, size_t wave_bytes, int bg, int max_waves = kMaxStrips) {
+// Launch geometry.  A workgroup's waves are `wc` NEIGHBOURING channel groups x `ws` strips side by side: the row pieces a CU
+// has in flight at one time are then contiguous wc x 128 B per pixel, and a plain copy in this geometry runs 5 - 13 % faster
+// than with the waves spread over the strips of ONE channel group (scripts/micro/stream.hip; the passes themselves:
+// profiles/r04_notes.md section 9).  The strips a workgroup's waves do not cover side by side are walked by the same waves
+// one after the other (passes with sums over the plane: the sums stay inside the workgroup) or go to gridDim.z (`split`).
+struct WideLaunch { dim3 grid, block; size_t lds; int BG, wc; };
+enum WidePass { P_STATS_FUSED, P_STATS_FWD, P_APPLY_FWD, P_STATS_BWD, P_APPLY_BWD };   // (P_APPLY_BWD: also the MRLA-base value backward)
+// Waves side by side in a workgroup: wc channel groups x ws strips.  Measured per pass and stage shape (b = 256, bf16,
+// scripts/wc_sweep.sh, profiles/r04_notes.md section 9):
+//   * wc = 4 wherever there are >= 8 channel groups (>= 512 channels): -9 ... -16 % per launch; wc = 8 is no better;
+//   * 256 channels (56-wide maps): -3 % at wc = 2 for the passes without a dWv reduction, nothing for apply_bwd;
+//   * the fused forward statistics pass keeps 3 waves per SIMD (150 - 162 registers): FOUR-wave workgroups fill the CU
+//     (three of them) where one eight-wave workgroup leaves a third of the slots empty, so below 8 strips it takes
+//     4 / strips channel groups (14-wide: 81 -> 66 us, 7-wide: 37 -> 34 us; 28-wide: 4 strips of one group, as before).
+static void wide_shape(WidePass pass, int C, int W, int* wc_out, int* ws_out) {
+  const int ncg = C / kWave, nstrips = (W + kS - 1) / kS;
+  int wc, waves = kMaxStrips;
+  switch (pass) {
+    case P_STATS_FUSED:
+      if (nstrips >= kMaxStrips) { wc = 1; break; }
+      waves = 4;
+      wc = nstrips >= 4 ? 1 : nstrips >= 2 ? 2 : 4;
+      break;
+    case P_APPLY_BWD: wc = ncg >= 8 ? 4 : 1; break;
+    default:          wc = ncg >= 8 ? 4 : 2; break;
+  }
+#ifdef MRLA_WC_EXPERIMENT
+  static const char* names[] = {"MRLA_WC_STATS_FUSED", "MRLA_WC_STATS_FWD", "MRLA_WC_APPLY_FWD", "MRLA_WC_STATS_BWD", "MRLA_WC_APPLY_BWD"};
+  if (getenv(names[pass])) { wc = atoi(getenv(names[pass])); waves = getenv("MRLA_WAVES") ? atoi(getenv("MRLA_WAVES")) : kMaxStrips; }
+#endif
+  wc = std::max(1, std::min(wc, waves));
+  while (ncg % wc) wc >>= 1;
+  *wc_out = wc;
+  *ws_out = std::max(1, std::min(waves / wc, nstrips));
+}
+
+// Images a workgroup walks through, at most 8.
+// W > 0 (the dWv-producing backward kernels, 2 waves per SIMD = 2048 wave slots): about one round of resident waves, so
+// that the prologue, the dWv reduction and its partial rows are amortised over several images (14x14 stage: +25 %).
+// W == 0 (the lighter passes, twice the occupancy): >= 2048 workgroups; they are faster with more, shorter workgroups.
+int nhwc_images_per_group(int B, int C, int W) {
+  const long wgs = (long)B * ((C + kWave - 1) / kWave);
+  if (W <= 0) return (int)std::max(1L, std::min(8L, wgs / 2048));
+  int wc = 1, ws = std::min((W + kS - 1) / kS, kMaxStrips);
+  if (C % kWave == 0) wide_shape(P_APPLY_BWD, C, W, &wc, &ws);        // (the row pipeline's workgroups)
+  return (int)std::max(1L, std::min(8L, wgs * ws / 2048));
+}
+
+static WideLaunch wide_launch(WidePass pass, int B, int C, int W, int nred, size_t wave_bytes, int bg, bool split) {
   WideLaunch L;
-  const int nwaves = std::min((W + kS - 1) / kS, max_waves);
+  const int ncg = C / kWave, nstrips = (W + kS - 1) / kS;
+  int wc, ws;
+  wide_shape(pass, C, W, &wc, &ws);
+  const int nz = split ? (nstrips + ws - 1) / ws : 1;
+  if (bg <= 0) bg = (int)std::max(1L, std::min(8L, (long)B * (ncg / wc) * nz / 2048));
+  L.wc = wc;
   L.BG = bg;
-  L.grid = dim3(C / kWave, (B + bg - 1) / bg);
-  L.block = dim3(nwaves * kWave);
-  L.lds = (size_t)nwaves * nred * kWave * sizeof(float) + (size_t)nwaves * wave_bytes;
+  L.grid = dim3(ncg / wc, (B + bg - 1) / bg, nz);
+  L.block = dim3(wc * ws * kWave);
+  L.lds = (size_t)wc * ws * ((size_t)nred * kWave * sizeof(float) + wave_bytes);
   return L;
 }
 
@@ -909,18 +965,18 @@ int launch_light_stats_fwd_wide(const void* x, const void* o, const float* wv, f
                                 const float* psh, void* vout, int B, int C, int H, int W, int dtype, int act,
                                 hipStream_t st) {
   const bool ragged = (W % kS) != 0;
-  const int bg = nhwc_images_per_group(B, C, 0);
+  const int bg = 0;               // (wide_launch(): >= 2048 workgroups)
   if (xout) {                     // the fused producer (needs o, no activation on V)
     if (!o || act) return MRLA_EINVAL;
 #define CALL_K(KERNEL, T, AF, RG, NT)                                                                               \
   {                                                                                                                 \
     if (set_lds_n(KERNEL<T, AF, RG, NT>, L.lds) != hipSuccess) return MRLA_EHIP;                                     \
     hipLaunchKernelGGL((KERNEL<T, AF, RG, NT>), L.grid, L.block, L.lds, st, (const T*)x, (const T*)o, wv, mom,       \
-                       (T*)xout, psc, psh, (T*)vout, B, C, H, W, L.BG);                                             \
+                       (T*)xout, psc, psh, (T*)vout, B, C, H, W, L.BG, L.wc);                                             \
   }
 #define CALL_N(T, AF, RG, NT)                                                                                       \
   {                                                                                                                 \
-    const WideLaunch L = wide_launch(B, C, W, kMomRed, fused_wave_bytes<T>(), bg);                                   \
+    const WideLaunch L = wide_launch(P_STATS_FUSED, B, C, W, kMomRed, fused_wave_bytes<T>(), bg, false);                                   \
     CALL_K(light_stats_fwd_fused_wide, T, AF, RG, NT)                                                               \
   }
 #define CALL_R(T, AF, RG) { if (stream_fetches(B, C, H, W, sizeof(T))) CALL_N(T, AF, RG, 2) else CALL_N(T, AF, RG, 0) }
@@ -941,10 +997,10 @@ int launch_light_stats_fwd_wide(const void* x, const void* o, const float* wv, f
   }
 #define CALL_R(T, A, O, RG)                                                                                         \
   {                                                                                                                 \
-    const WideLaunch L = wide_launch(B, C, W, kMomRed, stats_fwd_wave_bytes<T>(), bg);                                   \
+    const WideLaunch L = wide_launch(P_STATS_FWD, B, C, W, kMomRed, stats_fwd_wave_bytes<T>(), bg, false);                                   \
     if (set_lds_n(light_stats_fwd_wide<T, A, O, RG>, L.lds) != hipSuccess) return MRLA_EHIP;                          \
     hipLaunchKernelGGL((light_stats_fwd_wide<T, A, O, RG>), L.grid, L.block, L.lds, st, (const T*)x, (const T*)o, wv, \
-                       mom, (T*)vout, B, C, H, W, L.BG);                                                            \
+                       mom, (T*)vout, B, C, H, W, L.BG, L.wc);                                                            \
   }
 #define CALL(T, A, O) { if (ragged) CALL_R(T, A, O, true) else CALL_R(T, A, O, false) }
   MRLA_DISPATCH_T_N(dtype, act, o != nullptr, CALL)
@@ -959,10 +1015,10 @@ int launch_light_apply_fwd_wide(const void* x, const void* o, const float* wv, c
 #define CALL(T, A, O) { if (stream_fetches(B, C, H, W, sizeof(T))) CALL_N(T, A, O, 2) else CALL_N(T, A, O, 0) }
 #define CALL_N(T, A, O, NT)                                                                                        \
   {                                                                                                                \
-    const WideLaunch L = wide_launch(B, C, W, 0, apply_fwd_wave_bytes<T>(), nhwc_images_per_group(B, C, 0));        \
+    const WideLaunch L = wide_launch(P_APPLY_FWD, B, C, W, 0, apply_fwd_wave_bytes<T>(), 0, true);                                             \
     if (set_lds_n(light_apply_fwd_wide<T, A, O, NT>, L.lds) != hipSuccess) return MRLA_EHIP;                        \
     hipLaunchKernelGGL((light_apply_fwd_wide<T, A, O, NT>), L.grid, L.block, L.lds, st, (const T*)x, (const T*)o, wv,   \
-                       gate, sc, sh, lam, dp, (T*)out, B, C, H, W, L.BG, d, res);                                  \
+                       gate, sc, sh, lam, dp, (T*)out, B, C, H, W, L.BG, d, res, L.wc);                            \
   }
   MRLA_DISPATCH_T_N(dtype, act, o != nullptr, CALL)
 #undef CALL
@@ -976,10 +1032,10 @@ int launch_light_apply_fwd_pre_wide(const void* pre, const void* o, const float*
                                     hipStream_t st) {
 #define CALL_A(T, AF)                                                                                                \
   {                                                                                                                  \
-    const WideLaunch L = wide_launch(B, C, W, 0, fused_wave_bytes<T>(), nhwc_images_per_group(B, C, 0));              \
+    const WideLaunch L = wide_launch(P_APPLY_FWD, B, C, W, 0, fused_wave_bytes<T>(), 0, true);              \
     if (set_lds_n(light_apply_fwd_pre_wide<T, AF>, L.lds) != hipSuccess) return MRLA_EHIP;                            \
     hipLaunchKernelGGL((light_apply_fwd_pre_wide<T, AF>), L.grid, L.block, L.lds, st, (const T*)pre, (const T*)o, psc, \
-                       psh, wv, gate, sc, sh, lam, dp, (T*)out, B, C, H, W, L.BG, d, res);                           \
+                       psh, wv, gate, sc, sh, lam, dp, (T*)out, B, C, H, W, L.BG, d, res, L.wc);                           \
   }
 #define CALL(T) { if (psc) CALL_A(T, true) else CALL_A(T, false) }
   switch (dtype) {
@@ -1004,11 +1060,11 @@ int launch_light_apply_bwd_wide(const void* dout, const void* x, const void* o, 
   if (pre_tmom && dtype == MRLA_F32) return MRLA_EUNSUPPORTED;      // (LDS: see mrla_light_apply_bwd_pre_sums)
 #define CALL_G(T, A, O, R, RG, PR)                                                                                   \
   {                                                                                                                  \
-    const WideLaunch L = wide_launch(B, C, W, 9, apply_bwd_wave_bytes<T, PR>(), bg, kBwdWaves);                       \
+    const WideLaunch L = wide_launch(P_APPLY_BWD, B, C, W, 9, apply_bwd_wave_bytes<T, PR>(), bg, false);                       \
     if (set_lds_n(light_apply_bwd_wide<T, A, O, R, RG, PR>, L.lds) != hipSuccess) return MRLA_EHIP;                    \
     hipLaunchKernelGGL((light_apply_bwd_wide<T, A, O, R, RG, PR>), L.grid, L.block, L.lds, st, (const T*)dout,        \
                        (const T*)x, (const T*)o, wv, gate, cb, lam, dp, dyx, (T*)dx, (T*)dprev, dwv_part,             \
-                       (const T*)pre, pre_center, pre_tmom, B, C, H, W, L.BG, d, res);                               \
+                       (const T*)pre, pre_center, pre_tmom, B, C, H, W, L.BG, d, res, L.wc);                               \
   }
 #define CALL_R(T, A, O, R) { if (ragged) CALL_G(T, A, O, R, true, false) else CALL_G(T, A, O, R, false, false) }
 #define CALL_P(T)                                                                                       \
@@ -1037,10 +1093,10 @@ int launch_light_stats_bwd_wide(const void* dout, const void* x, const void* o, 
 #define CALL(T, A, O) CALL_N(T, A, O, 0)      /* default policy: apply_bwd re-reads these tensors right after */
 #define CALL_N(T, A, O, NT)                                                                                        \
   {                                                                                                                \
-    const WideLaunch L = wide_launch(B, C, W, D_N, stats_bwd_wave_bytes<T>(), nhwc_images_per_group(B, C, 0));     \
+    const WideLaunch L = wide_launch(P_STATS_BWD, B, C, W, D_N, stats_bwd_wave_bytes<T>(), 0, false);     \
     if (set_lds_n(light_stats_bwd_wide<T, A, O, NT>, L.lds) != hipSuccess) return MRLA_EHIP;                        \
     hipLaunchKernelGGL((light_stats_bwd_wide<T, A, O, NT>), L.grid, L.block, L.lds, st, (const T*)dout, (const T*)x,    \
-                       (const T*)o, wv, mom, bmom, B, C, H, W, L.BG);                                              \
+                       (const T*)o, wv, mom, bmom, B, C, H, W, L.BG, L.wc);                                              \
   }
   MRLA_DISPATCH_T_N(dtype, act, o != nullptr, CALL)
 #undef CALL
@@ -1056,10 +1112,10 @@ int launch_base_value_bwd_wide(const void* dout, const void* x, const float* wv,
   const int bg = nhwc_images_per_group(B, C, W);
 #define CALL_P(T, PR)                                                                                               \
   {                                                                                                                 \
-    const WideLaunch L = wide_launch(B, C, W, 9, base_vbwd_wave_bytes<T, PR>(), bg);                                 \
+    const WideLaunch L = wide_launch(P_APPLY_BWD, B, C, W, 9, base_vbwd_wave_bytes<T, PR>(), bg, false);                                 \
     if (set_lds_n(base_value_bwd_wide<T, PR>, L.lds) != hipSuccess) return MRLA_EHIP;                                \
     hipLaunchKernelGGL((base_value_bwd_wide<T, PR>), L.grid, L.block, L.lds, st, (const T*)dout, (const T*)x, wv,    \
-                       (const T*)dv, dyx, (T*)dx, dwv_part, (const T*)pre, pre_center, pre_tmom, B, C, H, W, L.BG, res); \
+                       (const T*)dv, dyx, (T*)dx, dwv_part, (const T*)pre, pre_center, pre_tmom, B, C, H, W, L.BG, res, L.wc); \
   }
 #define CALL(T) { if (pre_tmom) CALL_P(T, true) else CALL_P(T, false) }
   switch (dtype) {

@@ -918,10 +918,6 @@ static void wide_shape(WidePass pass, int C, int W, int* wc_out, int* ws_out) {
     case P_APPLY_BWD: wc = ncg >= 8 ? 4 : 1; break;
     default:          wc = ncg >= 8 ? 4 : 2; break;
   }
-#ifdef MRLA_WC_EXPERIMENT
-  static const char* names[] = {"MRLA_WC_STATS_FUSED", "MRLA_WC_STATS_FWD", "MRLA_WC_APPLY_FWD", "MRLA_WC_STATS_BWD", "MRLA_WC_APPLY_BWD"};
-  if (getenv(names[pass])) { wc = atoi(getenv(names[pass])); waves = getenv("MRLA_WAVES") ? atoi(getenv("MRLA_WAVES")) : kMaxStrips; }
-#endif
   wc = std::max(1, std::min(wc, waves));
   while (ncg % wc) wc >>= 1;
   *wc_out = wc;

@@ -1,5 +1,6 @@
 """GPU micro-benchmark of the fused BatchNorm(+ReLU) passes through the C ABI on every BatchNorm shape of
-ResNet-50 at b=256 (bf16, channels_last by default).  Usage: python scripts/bnbench.py [reps]"""
+ResNet-50 at b=256 (bf16, channels_last by default).
+Usage: [KBENCH_LIB=scripts/variants/libmrla_hip_<name>.so] python scripts/bnbench.py [reps]"""
 import ctypes
 import os
 import sys
@@ -9,6 +10,8 @@ import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from mrla_amd import _lib as L  # noqa: E402
 
+if os.environ.get("KBENCH_LIB"):          # an experiment build (scripts/build_variant.sh) instead of the product library
+    L.LIB_PATH = os.path.abspath(os.environ["KBENCH_LIB"])
 reps = int(sys.argv[1]) if len(sys.argv) > 1 else 20
 B = int(os.environ.get("B", 256))
 LAY = L.NCHW if os.environ.get("LAYOUT", "nhwc") == "nchw" else L.NHWC

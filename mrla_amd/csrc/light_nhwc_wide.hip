@@ -3,10 +3,12 @@
 // counts with plain per-lane accesses); reference: resnet/models/modules/mrla_light_module.py:52-74,
 // resnet/models/resnet_mrla_light.py:40-43,113-116.
 //
-// These kernels are bound by vector-instruction issue, not by HBM (profiles/r02_notes.md), so the loops are written
-// for instruction count: row windows rotate by NAME (three steps per trip, no register copies), everything outside the
+// The loops are written for instruction count (the register-staged kernels of round 1 were bound by vector issue,
+// profiles/r02_notes.md): row windows rotate by NAME (three steps per trip, no register copies), everything outside the
 // image arrives as zeros from the buffer bounds check (no predicates in the arithmetic), bf16 rows need no conversion
 // instruction, and the file is compiled without the SLP vectoriser (its v_pk_fma_f32 pairs cost more moves than they save).
+// What bounds them on this pipeline is WHICH BYTES A CU REQUESTS AT ONE TIME (profiles/r04_notes.md section 9): hence the
+// workgroups of neighbouring channel groups, wide_shape() below.
 #include "light_nhwc.h"
 #include "nhwc_rows.h"
 

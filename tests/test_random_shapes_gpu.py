@@ -35,6 +35,11 @@ def _light_shape(rng):
 
 
 LIGHT_SHAPES = _shapes(20240401, 14, _light_shape)
+# The row pipeline's workgroups hold neighbouring channel groups side by side once there are >= 8 of them (wide_shape() in
+# light_nhwc_wide.hip): these shapes put 4 groups x 2 strips in a workgroup with the strips walked unevenly (5 strips on 2
+# strip slots), ragged last strips, a group count 4 does not divide (9 -> one group per workgroup), 12 and 16 groups, and a
+# map wider than 8 strips.
+LIGHT_SHAPES += [(3, 512, 5, 23, 32), (2, 768, 6, 30, 32), (2, 576, 4, 9, 32), (2, 1024, 9, 16, 16), (1, 512, 3, 61, 32)]
 
 
 @pytest.mark.parametrize("shape", LIGHT_SHAPES, ids=lambda s: "x".join(map(str, s)))
@@ -64,7 +69,7 @@ def test_light_tail_random_shapes_fp32(shape, cl):
         assert relmax(got["grad/" + ours].ravel(), want) < (TINY_BN_TOL if tiny else par_tol(theirs)), ours
 
 
-@pytest.mark.parametrize("shape", LIGHT_SHAPES[:8], ids=lambda s: "x".join(map(str, s)))
+@pytest.mark.parametrize("shape", LIGHT_SHAPES[:8] + LIGHT_SHAPES[-5:], ids=lambda s: "x".join(map(str, s)))
 @pytest.mark.parametrize("cl", [False, True], ids=["nchw", "nhwc"])
 def test_light_tail_random_shapes_bf16(shape, cl):
     """bf16 I/O protocol: inputs pre-rounded to bf16, the kernel's bf16 outputs vs the fp64 oracle on
@@ -95,6 +100,7 @@ def _base_shape(rng):
 
 
 BASE_SHAPES = _shapes(20240402, 10, _base_shape)
+BASE_SHAPES += [(2, 512, 5, 23, 16, 3), (2, 768, 4, 30, 16, 2)]      # (the value backward's workgroups of neighbouring channel groups)
 
 
 @pytest.mark.parametrize("shape", BASE_SHAPES, ids=lambda s: "x".join(map(str, s)))

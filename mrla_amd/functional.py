@@ -47,6 +47,17 @@ class KernelTimer:
 
 
 TIMER = None      # set to a KernelTimer to time launches
+SEQUENCES = True  # a tail / BatchNorm direction = ONE call of a sequence entry point (mrla_light_tail_fwd, mrla_bn_bwd, ...;
+#                   include/mrla_hip.h ABI 4) instead of one call per pass.  Same kernels, same buffers, bit-identical
+#                   results; per-pass calls are used while a KernelTimer is on (events around every kernel) or when False.
+
+
+def _seq():
+    return SEQUENCES and TIMER is None
+
+
+def _seq_call(name, *args):
+    L.call(name, *args)
 
 
 def _call(name, nbytes, *args, entry=None, alg=None, path=0):
@@ -64,7 +75,9 @@ def _call(name, nbytes, *args, entry=None, alg=None, path=0):
 
 
 def _ptr(t):
-    return ctypes.c_void_p(t.data_ptr()) if t is not None else None
+    """Device address as a plain int (ctypes converts it for a void* parameter; None is NULL) -- a c_void_p object per
+    argument costs ~0.3 us on a path that passes ~6000 pointers per training step."""
+    return t.data_ptr() if t is not None else None
 
 
 # ------------------------------------------------------------------------------------------------------
@@ -137,8 +150,8 @@ def _stream():
     """The current stream of the current device as the C ABI takes it (the raw-handle query: torch.cuda.current_stream()
     builds a Stream object, ~10 us on a path that launches ~600 kernels per step)."""
     if _raw_stream is not None:
-        return ctypes.c_void_p(_raw_stream(torch.cuda.current_device()))
-    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+        return _raw_stream(torch.cuda.current_device())
+    return torch.cuda.current_stream().cuda_stream
 
 
 def _f32(t):
@@ -336,30 +349,51 @@ class _LightFn(torch.autograd.Function):
                   _ptr(bnbuf[1]) if bnbuf is not None else None, _ptr(lam32), _ptr(dp32), _ptr(out), b, c, h, w, d,
                   cfg.res, dt, layout, st, path=xc.numel() * xc.element_size() * 3)
             return out.contiguous() if via_nhwc else out
-        if cfg.fuse:
-            pre, xc = xc, torch.empty_like(xc)
-            psc, psh = cfg.pre_affine if cfg.pre_affine is not None else (None, None)
-            _call("mrla_light_stats_fwd_fused", xc.numel() * xc.element_size() * 3, _ptr(pre), _ptr(psc), _ptr(psh),
-                  _ptr(oc), _ptr(wv32), _ptr(mom), _ptr(xc), b, c, h, w, dt, layout, st)
+        pre = None
+        if _seq():
+            psc = psh = None
+            if cfg.fuse:
+                pre, xc = xc, torch.empty_like(xc)
+                psc, psh = cfg.pre_affine if cfg.pre_affine is not None else (None, None)
+            gate = torch.empty((b, G), dtype=torch.float32, device=dev)
+            bnbuf = gamma32 = beta32 = rs = None
+            if cfg.bn_mode != L.BN_NONE:
+                gamma32, beta32 = _f32(gamma), _f32(beta)
+                rs = _RunningStats(running_mean, running_var, c, "mrla light forward")
+                bnbuf = torch.empty((4, c), dtype=torch.float32, device=dev)       # sc, sh, save_mean, save_inv
+            out = torch.empty_like(xc)
+            _seq_call("mrla_light_tail_fwd", _ptr(pre if cfg.fuse else xc), _ptr(psc), _ptr(psh), _ptr(oc), _ptr(wq32),
+                      _ptr(wk32), ks, _ptr(wv32), _ptr(lam32), _ptr(gamma32), _ptr(beta32),
+                      _ptr(rs.rm) if rs is not None else None, _ptr(rs.rv) if rs is not None else None, cfg.bn_mode,
+                      float(cfg.momentum), float(cfg.eps), _ptr(dp32), _ptr(mom), _ptr(xc) if cfg.fuse else None, _ptr(gate),
+                      _ptr(bnbuf), _ptr(out), b, c, h, w, d, cfg.res, int(cfg.fuse), dt, layout, cfg.act, st)
+            if rs is not None:
+                rs.finish(cfg.bn_mode == L.BN_TRAIN)
         else:
-            _call("mrla_light_stats_fwd", xc.numel() * xc.element_size() * (2 if oc is not None else 1), _ptr(xc),
-                  _ptr(oc), _ptr(wv32), _ptr(mom), b, c, h, w, dt, layout, cfg.act, st)
-        gate = torch.empty((b, G), dtype=torch.float32, device=dev)
-        _call("mrla_light_gate_fwd", 0, _ptr(mom), _ptr(wq32), _ptr(wk32), ks, _ptr(gate), b, c, h * w, d, st)
-        bnbuf = gamma32 = None
-        if cfg.bn_mode != L.BN_NONE:
-            gamma32, beta32 = _f32(gamma), _f32(beta)
-            rs = _RunningStats(running_mean, running_var, c, "mrla light forward")
-            bnbuf = torch.empty((4, c), dtype=torch.float32, device=dev)       # sc, sh, save_mean, save_inv
-            _call("mrla_light_bn_fwd", 0, _ptr(mom), _ptr(gate), _ptr(lam32), _ptr(gamma32), _ptr(beta32),
-                   _ptr(rs.rm), _ptr(rs.rv), cfg.bn_mode, float(cfg.momentum), float(cfg.eps),
-                   _ptr(bnbuf[0]), _ptr(bnbuf[1]), _ptr(bnbuf[2]), _ptr(bnbuf[3]), b, c, h * w, d, st)
-            rs.finish(cfg.bn_mode == L.BN_TRAIN)
-        out = torch.empty_like(xc)
-        _call("mrla_light_apply_fwd", xc.numel() * xc.element_size() * (3 if oc is not None else 2), _ptr(xc), _ptr(oc), _ptr(wv32), _ptr(gate),
-               _ptr(bnbuf[0]) if bnbuf is not None else None, _ptr(bnbuf[1]) if bnbuf is not None else None,
-               _ptr(lam32), _ptr(dp32), _ptr(out), b, c, h, w, d, cfg.res, dt, layout, cfg.act, st,
-               path=xc.numel() * xc.element_size() * (3 if oc is not None else 2))
+            if cfg.fuse:
+                pre, xc = xc, torch.empty_like(xc)
+                psc, psh = cfg.pre_affine if cfg.pre_affine is not None else (None, None)
+                _call("mrla_light_stats_fwd_fused", xc.numel() * xc.element_size() * 3, _ptr(pre), _ptr(psc), _ptr(psh),
+                      _ptr(oc), _ptr(wv32), _ptr(mom), _ptr(xc), b, c, h, w, dt, layout, st)
+            else:
+                _call("mrla_light_stats_fwd", xc.numel() * xc.element_size() * (2 if oc is not None else 1), _ptr(xc),
+                      _ptr(oc), _ptr(wv32), _ptr(mom), b, c, h, w, dt, layout, cfg.act, st)
+            gate = torch.empty((b, G), dtype=torch.float32, device=dev)
+            _call("mrla_light_gate_fwd", 0, _ptr(mom), _ptr(wq32), _ptr(wk32), ks, _ptr(gate), b, c, h * w, d, st)
+            bnbuf = gamma32 = None
+            if cfg.bn_mode != L.BN_NONE:
+                gamma32, beta32 = _f32(gamma), _f32(beta)
+                rs = _RunningStats(running_mean, running_var, c, "mrla light forward")
+                bnbuf = torch.empty((4, c), dtype=torch.float32, device=dev)       # sc, sh, save_mean, save_inv
+                _call("mrla_light_bn_fwd", 0, _ptr(mom), _ptr(gate), _ptr(lam32), _ptr(gamma32), _ptr(beta32),
+                       _ptr(rs.rm), _ptr(rs.rv), cfg.bn_mode, float(cfg.momentum), float(cfg.eps),
+                       _ptr(bnbuf[0]), _ptr(bnbuf[1]), _ptr(bnbuf[2]), _ptr(bnbuf[3]), b, c, h * w, d, st)
+                rs.finish(cfg.bn_mode == L.BN_TRAIN)
+            out = torch.empty_like(xc)
+            _call("mrla_light_apply_fwd", xc.numel() * xc.element_size() * (3 if oc is not None else 2), _ptr(xc), _ptr(oc), _ptr(wv32), _ptr(gate),
+                   _ptr(bnbuf[0]) if bnbuf is not None else None, _ptr(bnbuf[1]) if bnbuf is not None else None,
+                   _ptr(lam32), _ptr(dp32), _ptr(out), b, c, h, w, d, cfg.res, dt, layout, cfg.act, st,
+                   path=xc.numel() * xc.element_size() * (3 if oc is not None else 2))
 
         ctx.cfg, ctx.layout, ctx.ks = cfg, layout, ks
         ctx.shapes = (wq.shape, wk.shape, wv.shape, lam.shape if lam is not None else None)
@@ -386,43 +420,69 @@ class _LightFn(torch.autograd.Function):
             dout = dout.to(xc.dtype)
         dout = _layout_of(dout, layout)[1]
 
-        bmom = torch.empty((b, c, L.BWD_MOMENTS), dtype=torch.float32, device=dev)
-        _call("mrla_light_stats_bwd", xc.numel() * xc.element_size() * (3 if oc is not None else 2), _ptr(dout), _ptr(xc), _ptr(oc), _ptr(wv32), _ptr(mom), _ptr(bmom), b, c, h, w, dt, layout,
-               cfg.act, st)
-        small = torch.empty((11, c), dtype=torch.float32, device=dev)     # cb[c,4] | dgamma | dbeta | dlam | cb_lo[c,4]
-        cb, cb_lo = small[:4].view(c, 4), small[7:].view(c, 4)
         has_bn = cfg.bn_mode != L.BN_NONE
-        _call("mrla_light_bn_bwd", 0, _ptr(mom), _ptr(bmom), _ptr(gate), _ptr(lam32), _ptr(gamma32) if has_bn else None,
-               _ptr(dp32), _ptr(bnbuf[2]) if has_bn else None, _ptr(bnbuf[3]) if has_bn else None, cfg.bn_mode,
-               _ptr(cb), _ptr(cb_lo), _ptr(small[4]) if has_bn else None, _ptr(small[5]) if has_bn else None,
-               _ptr(small[6]) if lam32 is not None else None, b, c, h * w, d, st)
-        dyx = torch.empty((b, c), dtype=torch.float32, device=dev)
-        dwqk_part = torch.empty((b, 2 * ks), dtype=torch.float32, device=dev)
-        _call("mrla_light_gate_bwd", 0, _ptr(mom), _ptr(bmom), _ptr(gate), _ptr(cb), _ptr(cb_lo), _ptr(dp32), _ptr(wq32),
-               _ptr(wk32), ks, _ptr(dyx), _ptr(dwqk_part), b, c, h * w, d, st)
-        rows = L.load().mrla_light_wgrad_rows(b, c, h, w, dt, layout)
-        L.check(min(rows, 0), "mrla_light_wgrad_rows")
-        dwv_part = torch.empty((rows, c * 9), dtype=torch.float32, device=dev)
-        dx = torch.empty_like(xc)
-        do = torch.empty_like(oc) if oc is not None else None
-        # the deferred bn3's backward sums (sum dpre, sum dpre*y3) ride in this pass: one more row fetch, no 2N pass
-        pre_tmom = None
-        if pre is not None and (b * h * w) % rows == 0:
-            pre_tmom = torch.empty((rows, c, 2), dtype=torch.float32, device=dev)
+        if _seq():
+            bmom = torch.empty((b, c, L.BWD_MOMENTS), dtype=torch.float32, device=dev)
+            small = torch.empty((11, c), dtype=torch.float32, device=dev)     # cb[c,4] | dgamma | dbeta | dlam | cb_lo[c,4]
+            dyx = torch.empty((b, c), dtype=torch.float32, device=dev)
+            dwqk_part = torch.empty((b, 2 * ks), dtype=torch.float32, device=dev)
+            rows = L.load().mrla_light_wgrad_rows(b, c, h, w, dt, layout)
+            L.check(min(rows, 0), "mrla_light_wgrad_rows")
+            dwv_part = torch.empty((rows, c * 9), dtype=torch.float32, device=dev)
+            dx = torch.empty_like(xc)
+            do = torch.empty_like(oc) if oc is not None else None
+            pre_tmom = None
+            if pre is not None and (b * h * w) % rows == 0:
+                pre_tmom = torch.empty((rows, c, 2), dtype=torch.float32, device=dev)
+            else:
+                pre = None
+            wsum = torch.empty((c * 9 + 2 * ks,), dtype=torch.float32, device=dev)
+            _seq_call("mrla_light_tail_bwd", _ptr(dout), _ptr(xc), _ptr(oc), _ptr(wq32), _ptr(wk32), ks, _ptr(wv32),
+                      _ptr(lam32), _ptr(gamma32) if has_bn else None, _ptr(dp32), _ptr(mom), _ptr(gate),
+                      _ptr(bnbuf) if has_bn else None, cfg.bn_mode, _ptr(bmom), _ptr(small), _ptr(dyx), _ptr(dwqk_part),
+                      _ptr(dwv_part), rows, _ptr(dx), _ptr(do), _ptr(pre),
+                      _ptr(cfg.pre_box.center) if pre is not None else None, _ptr(pre_tmom), _ptr(wsum), b, c, h, w, d,
+                      cfg.res, int(cfg.fuse), dt, layout, cfg.act, st)
+            if pre_tmom is not None:
+                cfg.pre_box.put(dx, pre_tmom, rows)
         else:
-            pre = None
-        _call("mrla_light_apply_bwd", xc.numel() * xc.element_size() * ((5 if oc is not None else 3) + (pre is not None)),
-              _ptr(dout), _ptr(xc), _ptr(oc), _ptr(wv32), _ptr(gate), _ptr(cb), _ptr(lam32),
-              _ptr(dp32), _ptr(dyx), _ptr(dx), _ptr(do), _ptr(dwv_part), _ptr(pre),
-              _ptr(cfg.pre_box.center) if pre is not None else None, _ptr(pre_tmom), b, c, h, w, d, cfg.res,
-              int(cfg.fuse), dt, layout, cfg.act, st,
-              # section 8(d): dOut, x_t, o_prev in; dx, do out (the y3 row read for bn3's folded sums is not in that count)
-              alg=xc.numel() * xc.element_size() * (5 if oc is not None else 3),
-              path=xc.numel() * xc.element_size() * (5 if oc is not None else 3))
-        if pre_tmom is not None:
-            cfg.pre_box.put(dx, pre_tmom, rows)
-        wsum = torch.empty((c * 9 + 2 * ks,), dtype=torch.float32, device=dev)
-        _call("mrla_reduce_rows2", 0, _ptr(dwv_part), _ptr(wsum), rows, c * 9, _ptr(dwqk_part), _ptr(wsum[c * 9:]), b, 2 * ks, st)
+            bmom = torch.empty((b, c, L.BWD_MOMENTS), dtype=torch.float32, device=dev)
+            _call("mrla_light_stats_bwd", xc.numel() * xc.element_size() * (3 if oc is not None else 2), _ptr(dout), _ptr(xc), _ptr(oc), _ptr(wv32), _ptr(mom), _ptr(bmom), b, c, h, w, dt, layout,
+                   cfg.act, st)
+            small = torch.empty((11, c), dtype=torch.float32, device=dev)     # cb[c,4] | dgamma | dbeta | dlam | cb_lo[c,4]
+            cb, cb_lo = small[:4].view(c, 4), small[7:].view(c, 4)
+            has_bn = cfg.bn_mode != L.BN_NONE
+            _call("mrla_light_bn_bwd", 0, _ptr(mom), _ptr(bmom), _ptr(gate), _ptr(lam32), _ptr(gamma32) if has_bn else None,
+                   _ptr(dp32), _ptr(bnbuf[2]) if has_bn else None, _ptr(bnbuf[3]) if has_bn else None, cfg.bn_mode,
+                   _ptr(cb), _ptr(cb_lo), _ptr(small[4]) if has_bn else None, _ptr(small[5]) if has_bn else None,
+                   _ptr(small[6]) if lam32 is not None else None, b, c, h * w, d, st)
+            dyx = torch.empty((b, c), dtype=torch.float32, device=dev)
+            dwqk_part = torch.empty((b, 2 * ks), dtype=torch.float32, device=dev)
+            _call("mrla_light_gate_bwd", 0, _ptr(mom), _ptr(bmom), _ptr(gate), _ptr(cb), _ptr(cb_lo), _ptr(dp32), _ptr(wq32),
+                   _ptr(wk32), ks, _ptr(dyx), _ptr(dwqk_part), b, c, h * w, d, st)
+            rows = L.load().mrla_light_wgrad_rows(b, c, h, w, dt, layout)
+            L.check(min(rows, 0), "mrla_light_wgrad_rows")
+            dwv_part = torch.empty((rows, c * 9), dtype=torch.float32, device=dev)
+            dx = torch.empty_like(xc)
+            do = torch.empty_like(oc) if oc is not None else None
+            # the deferred bn3's backward sums (sum dpre, sum dpre*y3) ride in this pass: one more row fetch, no 2N pass
+            pre_tmom = None
+            if pre is not None and (b * h * w) % rows == 0:
+                pre_tmom = torch.empty((rows, c, 2), dtype=torch.float32, device=dev)
+            else:
+                pre = None
+            _call("mrla_light_apply_bwd", xc.numel() * xc.element_size() * ((5 if oc is not None else 3) + (pre is not None)),
+                  _ptr(dout), _ptr(xc), _ptr(oc), _ptr(wv32), _ptr(gate), _ptr(cb), _ptr(lam32),
+                  _ptr(dp32), _ptr(dyx), _ptr(dx), _ptr(do), _ptr(dwv_part), _ptr(pre),
+                  _ptr(cfg.pre_box.center) if pre is not None else None, _ptr(pre_tmom), b, c, h, w, d, cfg.res,
+                  int(cfg.fuse), dt, layout, cfg.act, st,
+                  # section 8(d): dOut, x_t, o_prev in; dx, do out (the y3 row read for bn3's folded sums is not in that count)
+                  alg=xc.numel() * xc.element_size() * (5 if oc is not None else 3),
+                  path=xc.numel() * xc.element_size() * (5 if oc is not None else 3))
+            if pre_tmom is not None:
+                cfg.pre_box.put(dx, pre_tmom, rows)
+            wsum = torch.empty((c * 9 + 2 * ks,), dtype=torch.float32, device=dev)
+            _call("mrla_reduce_rows2", 0, _ptr(dwv_part), _ptr(wsum), rows, c * 9, _ptr(dwqk_part), _ptr(wsum[c * 9:]), b, 2 * ks, st)
 
         sq, sk, sv, sl = ctx.shapes
         tq, tk, tv, tl, tg = ctx.pdtypes
@@ -599,47 +659,75 @@ class _BaseFn(torch.autograd.Function):
         mom = torch.empty((b, c, L.FWD_MOMENTS), dtype=torch.float32, device=dev)
         nhwc = layout == L.NHWC
         es = xc.element_size()
-        if nhwc:                # one pass: pooling moments, V_t -> ring slot (and x_t = relu(x + identity) when fused)
+        if nhwc and _seq():     # the whole layer + tail: one call (mrla_base_layer_fwd)
             idc = pre = None
             if cfg.fuse:
                 idc = _layout_of(identity, layout)[1]
                 pre, xc = xc, torch.empty_like(xc)
             psc, psh = cfg.pre_affine if cfg.pre_affine is not None else (None, None)
-            _call("mrla_base_pool_value_fwd", xc.numel() * es * (4 if cfg.fuse else 2), _ptr(pre if cfg.fuse else xc),
-                  _ptr(psc), _ptr(psh), _ptr(idc), _ptr(wv32), _ptr(mom), _ptr(xc) if cfg.fuse else None,
-                  _ptr(stage.V[t - 1]), b, c, h, w, dt, layout, st, path=xc.numel() * es * 2)
-        elif cfg.fuse:          # x is the pre-activation: x_t = relu(x + identity) formed by the pooling pass
-            idc = _layout_of(identity, L.NCHW)[1]
-            pre, xc = xc, torch.empty_like(xc)
-            _call("mrla_light_stats_fwd_fused", xc.numel() * xc.element_size() * 3, _ptr(pre), None, None, _ptr(idc),
-                  _ptr(wv32), _ptr(mom), _ptr(xc), b, c, h, w, dt, layout, st)
+            q = torch.empty((b, c), dtype=torch.float32, device=dev)
+            attn = torch.empty_like(xc)
+            arows = L.load().mrla_base_tile_rows(b, c, h, w, dt, layout)
+            L.check(min(arows, 0), "mrla_base_tile_rows")
+            amom = torch.empty((arows, c, 2), dtype=torch.float32, device=dev)
+            bnbuf = gamma32 = beta32 = rs = None
+            out = attn
+            if cfg.tail:
+                gamma32, beta32 = _f32(gamma), _f32(beta)
+                rs = _RunningStats(running_mean, running_var, c, "mrla base forward")
+                bnbuf = torch.empty((4, c), dtype=torch.float32, device=dev)
+                out = torch.empty_like(xc)
+            _seq_call("mrla_base_layer_fwd", _ptr(pre if cfg.fuse else xc), _ptr(psc), _ptr(psh), _ptr(idc), _ptr(wq32),
+                      _ptr(wk32), ks, _ptr(wv32), _ptr(gamma32), _ptr(beta32), _ptr(rs.rm) if rs is not None else None,
+                      _ptr(rs.rv) if rs is not None else None, cfg.bn_mode if cfg.tail else L.BN_NONE, float(cfg.momentum),
+                      float(cfg.eps), _ptr(dp32), _ptr(mom), _ptr(xc) if cfg.fuse else None, _ptr(stage.V), _ptr(stage.K),
+                      _ptr(stage.P), _ptr(q), _ptr(attn), _ptr(amom), arows, _ptr(bnbuf), _ptr(out) if cfg.tail else None,
+                      int(cfg.tail), b, c, h, w, d, T, t, dt, st)
+            if rs is not None:
+                rs.finish(cfg.bn_mode == L.BN_TRAIN)
+            stage.t = t
         else:
-            _call("mrla_light_stats_fwd", xc.numel() * xc.element_size(), _ptr(xc), None, _ptr(wv32), _ptr(mom), b, c, h,
-                  w, dt, layout, L.ACT_NONE, st)
-        q = torch.empty((b, c), dtype=torch.float32, device=dev)
-        _call("mrla_base_gate_fwd", 0, _ptr(mom), _ptr(wq32), _ptr(wk32), ks, _ptr(stage.K), _ptr(stage.P), _ptr(q), b, c,
-               h * w, d, T, t, st)
-        attn = torch.empty_like(xc)
-        arows = L.load().mrla_base_tile_rows(b, c, h, w, dt, layout)      # rows of the (sum, sum^2) partials
-        L.check(min(arows, 0), "mrla_base_tile_rows")
-        amom = torch.empty((arows, c, 2), dtype=torch.float32, device=dev)
-        _call("mrla_base_attend_fwd", xc.numel() * es * ((t + 1) if nhwc else (t + 2)), None if nhwc else _ptr(xc),
-              _ptr(wv32), _ptr(stage.V), _ptr(stage.P), _ptr(attn), _ptr(amom), b, c, h, w, d, T, t, dt, layout, st,
-              path=xc.numel() * es * (t - 1 if nhwc else t + 1))      # section 8(d): (t + 2) N per layer with the value pass + tail
-        stage.t = t
-        bnbuf = gamma32 = None
-        out = attn
-        if cfg.tail:
-            gamma32, beta32 = _f32(gamma), _f32(beta)
-            rs = _RunningStats(running_mean, running_var, c, "mrla base forward")
-            bnbuf = torch.empty((4, c), dtype=torch.float32, device=dev)
-            _call("mrla_bn_stats_fwd", 0, _ptr(amom), None, _ptr(gamma32), _ptr(beta32), _ptr(rs.rm), _ptr(rs.rv),
-                   cfg.bn_mode, float(cfg.momentum), float(cfg.eps), _ptr(bnbuf[0]), _ptr(bnbuf[1]), _ptr(bnbuf[2]),
-                   _ptr(bnbuf[3]), arows, c, b * h * w // arows, st)
-            rs.finish(cfg.bn_mode == L.BN_TRAIN)
-            out = torch.empty_like(xc)
-            _call("mrla_base_tail_fwd", xc.numel() * xc.element_size() * 3, _ptr(xc), _ptr(attn), _ptr(bnbuf[0]),
-                  _ptr(bnbuf[1]), _ptr(dp32), _ptr(out), b, c, h, w, dt, layout, st, path=xc.numel() * xc.element_size())
+            if nhwc:                # one pass: pooling moments, V_t -> ring slot (and x_t = relu(x + identity) when fused)
+                idc = pre = None
+                if cfg.fuse:
+                    idc = _layout_of(identity, layout)[1]
+                    pre, xc = xc, torch.empty_like(xc)
+                psc, psh = cfg.pre_affine if cfg.pre_affine is not None else (None, None)
+                _call("mrla_base_pool_value_fwd", xc.numel() * es * (4 if cfg.fuse else 2), _ptr(pre if cfg.fuse else xc),
+                      _ptr(psc), _ptr(psh), _ptr(idc), _ptr(wv32), _ptr(mom), _ptr(xc) if cfg.fuse else None,
+                      _ptr(stage.V[t - 1]), b, c, h, w, dt, layout, st, path=xc.numel() * es * 2)
+            elif cfg.fuse:          # x is the pre-activation: x_t = relu(x + identity) formed by the pooling pass
+                idc = _layout_of(identity, L.NCHW)[1]
+                pre, xc = xc, torch.empty_like(xc)
+                _call("mrla_light_stats_fwd_fused", xc.numel() * xc.element_size() * 3, _ptr(pre), None, None, _ptr(idc),
+                      _ptr(wv32), _ptr(mom), _ptr(xc), b, c, h, w, dt, layout, st)
+            else:
+                _call("mrla_light_stats_fwd", xc.numel() * xc.element_size(), _ptr(xc), None, _ptr(wv32), _ptr(mom), b, c, h,
+                      w, dt, layout, L.ACT_NONE, st)
+            q = torch.empty((b, c), dtype=torch.float32, device=dev)
+            _call("mrla_base_gate_fwd", 0, _ptr(mom), _ptr(wq32), _ptr(wk32), ks, _ptr(stage.K), _ptr(stage.P), _ptr(q), b, c,
+                   h * w, d, T, t, st)
+            attn = torch.empty_like(xc)
+            arows = L.load().mrla_base_tile_rows(b, c, h, w, dt, layout)      # rows of the (sum, sum^2) partials
+            L.check(min(arows, 0), "mrla_base_tile_rows")
+            amom = torch.empty((arows, c, 2), dtype=torch.float32, device=dev)
+            _call("mrla_base_attend_fwd", xc.numel() * es * ((t + 1) if nhwc else (t + 2)), None if nhwc else _ptr(xc),
+                  _ptr(wv32), _ptr(stage.V), _ptr(stage.P), _ptr(attn), _ptr(amom), b, c, h, w, d, T, t, dt, layout, st,
+                  path=xc.numel() * es * (t - 1 if nhwc else t + 1))      # section 8(d): (t + 2) N per layer with the value pass + tail
+            stage.t = t
+            bnbuf = gamma32 = None
+            out = attn
+            if cfg.tail:
+                gamma32, beta32 = _f32(gamma), _f32(beta)
+                rs = _RunningStats(running_mean, running_var, c, "mrla base forward")
+                bnbuf = torch.empty((4, c), dtype=torch.float32, device=dev)
+                _call("mrla_bn_stats_fwd", 0, _ptr(amom), None, _ptr(gamma32), _ptr(beta32), _ptr(rs.rm), _ptr(rs.rv),
+                       cfg.bn_mode, float(cfg.momentum), float(cfg.eps), _ptr(bnbuf[0]), _ptr(bnbuf[1]), _ptr(bnbuf[2]),
+                       _ptr(bnbuf[3]), arows, c, b * h * w // arows, st)
+                rs.finish(cfg.bn_mode == L.BN_TRAIN)
+                out = torch.empty_like(xc)
+                _call("mrla_base_tail_fwd", xc.numel() * xc.element_size() * 3, _ptr(xc), _ptr(attn), _ptr(bnbuf[0]),
+                      _ptr(bnbuf[1]), _ptr(dp32), _ptr(out), b, c, h, w, dt, layout, st, path=xc.numel() * xc.element_size())
         ctx.cfg, ctx.layout, ctx.ks, ctx.stage, ctx.t = cfg, layout, ks, stage, t
         ctx.shapes = (wq.shape, wk.shape, wv.shape)
         ctx.wv_stride = wv.stride()
@@ -669,61 +757,97 @@ class _BaseFn(torch.autograd.Function):
         Tc = stage.bwd_top            # later layers that received no gradient in this pass left no dA slot behind
         es = xc.element_size()
 
-        cb = dgamma = dbeta = None
-        if cfg.tail:
-            trows = L.load().mrla_bn_moment_rows(b, c, h, w, layout) if nhwc else b
-            tmom = torch.empty((trows, c, 2), dtype=torch.float32, device=dev)
-            center = bnbuf[2] if nhwc else None      # sums about the saved batch mean (the NCHW slab kernel keeps raw sums)
-            _call("mrla_base_tail_stats_bwd", xc.numel() * es * 2, _ptr(dout), _ptr(attn), _ptr(bnbuf[0]), _ptr(bnbuf[1]),
-                  _ptr(center), _ptr(dp32), _ptr(tmom), b, c, h, w, dt, layout, st)
-            small = torch.empty((5, c), dtype=torch.float32, device=dev)         # cb[c,3] | dgamma | dbeta
-            cb = small[:3].view(c, 3)
-            _call("mrla_bn_stats_bwd", 0, _ptr(tmom), _ptr(gamma32), _ptr(bnbuf[2]), _ptr(bnbuf[3]), cfg.bn_mode,
-                   int(center is not None), _ptr(cb), _ptr(small[3]), _ptr(small[4]), trows, c, b * h * w // trows, st)
-            dgamma, dbeta = small[3].to(ctx.pdtypes[3]), small[4].to(ctx.pdtypes[3])
-        pmom = torch.empty((b, c, t), dtype=torch.float32, device=dev)
-        prows = L.load().mrla_base_pmom_rows(b, c, h, w, dt, layout)
-        ppart = torch.empty((prows, t, c), dtype=torch.float32, device=dev) if nhwc else pmom
-        # (t + 3) N of streams + the fp32 partial rows of <dA_t, V_j> (one row of t x c floats per 16-pixel tile: 2 / 16 of the
-        # V bytes it reads -- the "9 %" the PMC pass sees above (t + 3) N; mrla_base_pmom_reduce reads them back)
-        _call("mrla_base_attend_bwd", xc.numel() * es * (t + 3) + (ppart.numel() * 4 if nhwc else 0), _ptr(dout), _ptr(attn),
-              _ptr(bnbuf[0]) if cfg.tail else None, _ptr(bnbuf[1]) if cfg.tail else None, _ptr(dp32), _ptr(cb),
-              _ptr(stage.V), _ptr(stage.dA), _ptr(ppart), b, c, h, w, T, t, dt, layout, st,
-              alg=xc.numel() * es * (t + 3),
-              path=xc.numel() * es * (t + 1))                         # section 8(d): ~(2t + 3) N per layer, backward
-        if nhwc:
-            _call("mrla_base_pmom_reduce", (ppart.numel() + pmom.numel()) * 4, _ptr(ppart), _ptr(pmom), b, c, t, prows, st)
-        dyx = torch.empty((b, c), dtype=torch.float32, device=dev)
-        dwqk_part = torch.empty((b, 2 * ks), dtype=torch.float32, device=dev)
-        _call("mrla_base_gate_bwd", 0, _ptr(mom), _ptr(pmom), _ptr(stage.P), _ptr(q), _ptr(stage.K), _ptr(stage.dK),
-               _ptr(wq32), _ptr(wk32), ks, _ptr(dyx), _ptr(dwqk_part), b, c, h * w, d, T, t, int(first), st)
-        rows = L.load().mrla_light_wgrad_rows(b, c, h, w, dt, layout)
-        L.check(min(rows, 0), "mrla_light_wgrad_rows")
-        dwv_part = torch.empty((rows, c * 9), dtype=torch.float32, device=dev)
-        dx = torch.empty_like(xc)
-        res = int(cfg.tail) | (2 if cfg.fuse else 0)
-        if nhwc:                # dV_t from the dA slots t..Tc, then the transposed 3x3 pass
+        if nhwc and _seq():     # the whole layer + tail backward: one call (mrla_base_layer_bwd)
+            dgamma = dbeta = small = tmom = None
+            trows = 1
+            if cfg.tail:
+                trows = L.load().mrla_bn_moment_rows(b, c, h, w, layout)
+                tmom = torch.empty((trows, c, 2), dtype=torch.float32, device=dev)
+                small = torch.empty((5, c), dtype=torch.float32, device=dev)         # cb[c,3] | dgamma | dbeta
+            pmom = torch.empty((b, c, t), dtype=torch.float32, device=dev)
+            prows = L.load().mrla_base_pmom_rows(b, c, h, w, dt, layout)
+            L.check(min(prows, 0), "mrla_base_pmom_rows")
+            ppart = torch.empty((prows, t, c), dtype=torch.float32, device=dev)
+            dyx = torch.empty((b, c), dtype=torch.float32, device=dev)
+            dwqk_part = torch.empty((b, 2 * ks), dtype=torch.float32, device=dev)
+            rows = L.load().mrla_light_wgrad_rows(b, c, h, w, dt, layout)
+            L.check(min(rows, 0), "mrla_light_wgrad_rows")
+            dwv_part = torch.empty((rows, c * 9), dtype=torch.float32, device=dev)
+            dx = torch.empty_like(xc)
             dv = torch.empty((b, h, w, c), dtype=xc.dtype, device=dev)
-            _call("mrla_base_dv_combine", xc.numel() * es * (Tc - t + 2), _ptr(stage.dA), _ptr(stage.P), _ptr(dv),
-                  b, c, h, w, d, T, t, Tc, dt, layout, st, path=xc.numel() * es * (Tc - t + 1))
-            # the deferred bn3's backward sums (sum dpre, sum dpre*(y3 - mean)) ride in this pass: one more row fetch, no 2N pass
+            res = int(cfg.tail) | (2 if cfg.fuse else 0)
             pre_tmom = None
             if pre is not None and (b * h * w) % rows == 0:
                 pre_tmom = torch.empty((rows, c, 2), dtype=torch.float32, device=dev)
             else:
                 pre = None
-            _call("mrla_base_value_bwd_dv", xc.numel() * es * (4 + (pre is not None)), _ptr(dout), _ptr(xc), _ptr(wv32),
-                  _ptr(dv), _ptr(dyx), _ptr(dx), _ptr(dwv_part), _ptr(pre),
-                  _ptr(cfg.pre_box.center) if pre is not None else None, _ptr(pre_tmom), b, c, h, w, res, dt, layout, st,
-                  alg=xc.numel() * es * 4, path=xc.numel() * es)
+            wsum = torch.empty((c * 9 + 2 * ks,), dtype=torch.float32, device=dev)
+            _seq_call("mrla_base_layer_bwd", _ptr(dout), _ptr(xc), _ptr(attn), _ptr(wq32), _ptr(wk32), ks, _ptr(wv32),
+                      _ptr(gamma32), _ptr(dp32), _ptr(mom), _ptr(q), _ptr(bnbuf), cfg.bn_mode if cfg.tail else L.BN_NONE,
+                      _ptr(stage.V), _ptr(stage.dA), _ptr(stage.K), _ptr(stage.dK), _ptr(stage.P), _ptr(tmom), trows,
+                      _ptr(small), _ptr(ppart), prows, _ptr(pmom), _ptr(dyx), _ptr(dwqk_part), _ptr(dv), _ptr(dwv_part), rows,
+                      _ptr(dx), _ptr(pre), _ptr(cfg.pre_box.center) if pre is not None else None, _ptr(pre_tmom), _ptr(wsum),
+                      int(cfg.tail), int(first), res, b, c, h, w, d, T, t, Tc, dt, st)
             if pre_tmom is not None:
                 cfg.pre_box.put(dx, pre_tmom, rows)
+            if cfg.tail:
+                dgamma, dbeta = small[3].to(ctx.pdtypes[3]), small[4].to(ctx.pdtypes[3])
         else:
-            _call("mrla_base_value_bwd", xc.numel() * es * (Tc - t + 4), _ptr(dout), _ptr(xc), _ptr(wv32),
-                  _ptr(stage.dA), _ptr(stage.P), _ptr(dyx), _ptr(dx), _ptr(dwv_part), b, c, h, w, d, T, t, Tc, res, dt,
-                  layout, st, path=xc.numel() * es * (Tc - t + 2))
-        wsum = torch.empty((c * 9 + 2 * ks,), dtype=torch.float32, device=dev)
-        _call("mrla_reduce_rows2", 0, _ptr(dwv_part), _ptr(wsum), rows, c * 9, _ptr(dwqk_part), _ptr(wsum[c * 9:]), b, 2 * ks, st)
+            cb = dgamma = dbeta = None
+            if cfg.tail:
+                trows = L.load().mrla_bn_moment_rows(b, c, h, w, layout) if nhwc else b
+                tmom = torch.empty((trows, c, 2), dtype=torch.float32, device=dev)
+                center = bnbuf[2] if nhwc else None      # sums about the saved batch mean (the NCHW slab kernel keeps raw sums)
+                _call("mrla_base_tail_stats_bwd", xc.numel() * es * 2, _ptr(dout), _ptr(attn), _ptr(bnbuf[0]), _ptr(bnbuf[1]),
+                      _ptr(center), _ptr(dp32), _ptr(tmom), b, c, h, w, dt, layout, st)
+                small = torch.empty((5, c), dtype=torch.float32, device=dev)         # cb[c,3] | dgamma | dbeta
+                cb = small[:3].view(c, 3)
+                _call("mrla_bn_stats_bwd", 0, _ptr(tmom), _ptr(gamma32), _ptr(bnbuf[2]), _ptr(bnbuf[3]), cfg.bn_mode,
+                       int(center is not None), _ptr(cb), _ptr(small[3]), _ptr(small[4]), trows, c, b * h * w // trows, st)
+                dgamma, dbeta = small[3].to(ctx.pdtypes[3]), small[4].to(ctx.pdtypes[3])
+            pmom = torch.empty((b, c, t), dtype=torch.float32, device=dev)
+            prows = L.load().mrla_base_pmom_rows(b, c, h, w, dt, layout)
+            ppart = torch.empty((prows, t, c), dtype=torch.float32, device=dev) if nhwc else pmom
+            # (t + 3) N of streams + the fp32 partial rows of <dA_t, V_j> (one row of t x c floats per 16-pixel tile: 2 / 16 of the
+            # V bytes it reads -- the "9 %" the PMC pass sees above (t + 3) N; mrla_base_pmom_reduce reads them back)
+            _call("mrla_base_attend_bwd", xc.numel() * es * (t + 3) + (ppart.numel() * 4 if nhwc else 0), _ptr(dout), _ptr(attn),
+                  _ptr(bnbuf[0]) if cfg.tail else None, _ptr(bnbuf[1]) if cfg.tail else None, _ptr(dp32), _ptr(cb),
+                  _ptr(stage.V), _ptr(stage.dA), _ptr(ppart), b, c, h, w, T, t, dt, layout, st,
+                  alg=xc.numel() * es * (t + 3),
+                  path=xc.numel() * es * (t + 1))                         # section 8(d): ~(2t + 3) N per layer, backward
+            if nhwc:
+                _call("mrla_base_pmom_reduce", (ppart.numel() + pmom.numel()) * 4, _ptr(ppart), _ptr(pmom), b, c, t, prows, st)
+            dyx = torch.empty((b, c), dtype=torch.float32, device=dev)
+            dwqk_part = torch.empty((b, 2 * ks), dtype=torch.float32, device=dev)
+            _call("mrla_base_gate_bwd", 0, _ptr(mom), _ptr(pmom), _ptr(stage.P), _ptr(q), _ptr(stage.K), _ptr(stage.dK),
+                   _ptr(wq32), _ptr(wk32), ks, _ptr(dyx), _ptr(dwqk_part), b, c, h * w, d, T, t, int(first), st)
+            rows = L.load().mrla_light_wgrad_rows(b, c, h, w, dt, layout)
+            L.check(min(rows, 0), "mrla_light_wgrad_rows")
+            dwv_part = torch.empty((rows, c * 9), dtype=torch.float32, device=dev)
+            dx = torch.empty_like(xc)
+            res = int(cfg.tail) | (2 if cfg.fuse else 0)
+            if nhwc:                # dV_t from the dA slots t..Tc, then the transposed 3x3 pass
+                dv = torch.empty((b, h, w, c), dtype=xc.dtype, device=dev)
+                _call("mrla_base_dv_combine", xc.numel() * es * (Tc - t + 2), _ptr(stage.dA), _ptr(stage.P), _ptr(dv),
+                      b, c, h, w, d, T, t, Tc, dt, layout, st, path=xc.numel() * es * (Tc - t + 1))
+                # the deferred bn3's backward sums (sum dpre, sum dpre*(y3 - mean)) ride in this pass: one more row fetch, no 2N pass
+                pre_tmom = None
+                if pre is not None and (b * h * w) % rows == 0:
+                    pre_tmom = torch.empty((rows, c, 2), dtype=torch.float32, device=dev)
+                else:
+                    pre = None
+                _call("mrla_base_value_bwd_dv", xc.numel() * es * (4 + (pre is not None)), _ptr(dout), _ptr(xc), _ptr(wv32),
+                      _ptr(dv), _ptr(dyx), _ptr(dx), _ptr(dwv_part), _ptr(pre),
+                      _ptr(cfg.pre_box.center) if pre is not None else None, _ptr(pre_tmom), b, c, h, w, res, dt, layout, st,
+                      alg=xc.numel() * es * 4, path=xc.numel() * es)
+                if pre_tmom is not None:
+                    cfg.pre_box.put(dx, pre_tmom, rows)
+            else:
+                _call("mrla_base_value_bwd", xc.numel() * es * (Tc - t + 4), _ptr(dout), _ptr(xc), _ptr(wv32),
+                      _ptr(stage.dA), _ptr(stage.P), _ptr(dyx), _ptr(dx), _ptr(dwv_part), b, c, h, w, d, T, t, Tc, res, dt,
+                      layout, st, path=xc.numel() * es * (Tc - t + 2))
+            wsum = torch.empty((c * 9 + 2 * ks,), dtype=torch.float32, device=dev)
+            _call("mrla_reduce_rows2", 0, _ptr(dwv_part), _ptr(wsum), rows, c * 9, _ptr(dwqk_part), _ptr(wsum[c * 9:]), b, 2 * ks, st)
         sq, sk, sv = ctx.shapes
         tq, tk, tv, _ = ctx.pdtypes
         return (dx, dx if cfg.fuse else None, wsum[c * 9:c * 9 + ks].view(sq).to(tq), wsum[c * 9 + ks:].view(sk).to(tk),
@@ -772,14 +896,19 @@ class _TokenLightFn(torch.autograd.Function):
         ks = wq32.numel()
         stats = torch.empty((b, n, 4), dtype=torch.float32, device=dev)
         mom = torch.empty((b, c, L.FWD_MOMENTS), dtype=torch.float32, device=dev)
-        _call("mrla_token_norm_pool", 0, _ptr(xc), _ptr(oc), _ptr(wxw), _ptr(wxb), float(eps), _ptr(stats), _ptr(mom), b, n,
-               c, dt, st)
         gate = torch.empty((b, c // d), dtype=torch.float32, device=dev)
-        _call("mrla_light_gate_fwd", 0, _ptr(mom), _ptr(wq32), _ptr(wk32), ks, _ptr(gate), b, c, n - 1, d, st)
         out = torch.empty_like(xc)
-        _call("mrla_token_apply_fwd", xc.numel() * xc.element_size() * 3, _ptr(xc), _ptr(oc), _ptr(stats), _ptr(wxw),
-              _ptr(wxb), _ptr(wow), _ptr(wob), _ptr(wv32), _ptr(gate), _ptr(lam32), _ptr(out), b, n, c, d, int(res), dt, st,
-              path=xc.numel() * xc.element_size() * 3)
+        if _seq():
+            _seq_call("mrla_token_light_fwd", _ptr(xc), _ptr(oc), _ptr(wxw), _ptr(wxb), _ptr(wow), _ptr(wob), _ptr(wq32),
+                      _ptr(wk32), ks, _ptr(wv32), _ptr(lam32), float(eps), _ptr(stats), _ptr(mom), _ptr(gate), _ptr(out), b, n,
+                      c, d, int(res), dt, st)
+        else:
+            _call("mrla_token_norm_pool", 0, _ptr(xc), _ptr(oc), _ptr(wxw), _ptr(wxb), float(eps), _ptr(stats), _ptr(mom), b, n,
+                   c, dt, st)
+            _call("mrla_light_gate_fwd", 0, _ptr(mom), _ptr(wq32), _ptr(wk32), ks, _ptr(gate), b, c, n - 1, d, st)
+            _call("mrla_token_apply_fwd", xc.numel() * xc.element_size() * 3, _ptr(xc), _ptr(oc), _ptr(stats), _ptr(wxw),
+                  _ptr(wxb), _ptr(wow), _ptr(wob), _ptr(wv32), _ptr(gate), _ptr(lam32), _ptr(out), b, n, c, d, int(res), dt, st,
+                  path=xc.numel() * xc.element_size() * 3)
         ctx.d, ctx.res, ctx.ks = d, int(res), ks
         ctx.meta = [(t.shape, t.dtype) for t in (lnx_w, lnx_b, lno_w, lno_b, wq, wk, wv, lam)]
         ctx.save_for_backward(xc, oc, wxw, wxb, wow, wob, wq32, wk32, wv32, lam32, stats, mom, gate)
@@ -803,19 +932,25 @@ class _TokenLightFn(torch.autograd.Function):
         prow = L.load().mrla_token_part_rows(b, n, c, dt)
         L.check(min(prow, 0), "mrla_token_part_rows")
         part = torch.empty((prow, c * L.TOKEN_PARTIALS), dtype=torch.float32, device=dev)
-        _call("mrla_token_apply_bwd", xc.numel() * es * 3 + dxn.numel() * 4, _ptr(dout), _ptr(xc), _ptr(oc), _ptr(stats),
-              _ptr(wxw), _ptr(wxb), _ptr(wow), _ptr(wob), _ptr(wv32), _ptr(gate), _ptr(lam32), _ptr(dxn), _ptr(part),
-              _ptr(bmom), b, n, c, d, dt, st, path=xc.numel() * es * 5)      # section 8(d) backward: 5 N s for the block
         dyx = torch.empty((b, c), dtype=torch.float32, device=dev)
         dwqk_part = torch.empty((b, 2 * ks), dtype=torch.float32, device=dev)
-        _call("mrla_token_gate_bwd", 0, _ptr(mom), _ptr(bmom), _ptr(gate), _ptr(wq32), _ptr(wk32), ks, _ptr(dyx),
-               _ptr(dwqk_part), _ptr(part), b, n, c, d, dt, st)
         dx, do = torch.empty_like(xc), torch.empty_like(oc)
-        _call("mrla_token_ln_bwd", xc.numel() * es * 5 + dxn.numel() * 4, _ptr(dout), _ptr(xc), _ptr(oc), _ptr(dxn),
-              _ptr(dyx), _ptr(stats), _ptr(wxw), _ptr(wow), _ptr(lam32), _ptr(dx), _ptr(do), b, n, c, res, dt, st)
         sums = torch.empty((c * L.TOKEN_PARTIALS + 2 * ks,), dtype=torch.float32, device=dev)
-        _call("mrla_reduce_rows2", 0, _ptr(part), _ptr(sums), prow, c * L.TOKEN_PARTIALS, _ptr(dwqk_part),
-               _ptr(sums[c * L.TOKEN_PARTIALS:]), b, 2 * ks, st)
+        if _seq():
+            _seq_call("mrla_token_light_bwd", _ptr(dout), _ptr(xc), _ptr(oc), _ptr(stats), _ptr(wxw), _ptr(wxb), _ptr(wow),
+                      _ptr(wob), _ptr(wq32), _ptr(wk32), ks, _ptr(wv32), _ptr(gate), _ptr(lam32), _ptr(mom), _ptr(dxn),
+                      _ptr(part), prow, _ptr(bmom), _ptr(dyx), _ptr(dwqk_part), _ptr(dx), _ptr(do), _ptr(sums), b, n, c, d, res,
+                      dt, st)
+        else:
+            _call("mrla_token_apply_bwd", xc.numel() * es * 3 + dxn.numel() * 4, _ptr(dout), _ptr(xc), _ptr(oc), _ptr(stats),
+                  _ptr(wxw), _ptr(wxb), _ptr(wow), _ptr(wob), _ptr(wv32), _ptr(gate), _ptr(lam32), _ptr(dxn), _ptr(part),
+                  _ptr(bmom), b, n, c, d, dt, st, path=xc.numel() * es * 5)      # section 8(d) backward: 5 N s for the block
+            _call("mrla_token_gate_bwd", 0, _ptr(mom), _ptr(bmom), _ptr(gate), _ptr(wq32), _ptr(wk32), ks, _ptr(dyx),
+                   _ptr(dwqk_part), _ptr(part), b, n, c, d, dt, st)
+            _call("mrla_token_ln_bwd", xc.numel() * es * 5 + dxn.numel() * 4, _ptr(dout), _ptr(xc), _ptr(oc), _ptr(dxn),
+                  _ptr(dyx), _ptr(stats), _ptr(wxw), _ptr(wow), _ptr(lam32), _ptr(dx), _ptr(do), b, n, c, res, dt, st)
+            _call("mrla_reduce_rows2", 0, _ptr(part), _ptr(sums), prow, c * L.TOKEN_PARTIALS, _ptr(dwqk_part),
+                   _ptr(sums[c * L.TOKEN_PARTIALS:]), b, 2 * ks, st)
         pc = sums[:c * L.TOKEN_PARTIALS].view(c, L.TOKEN_PARTIALS)
         dwqk = sums[c * L.TOKEN_PARTIALS:]
         raw = (pc[:, 10], pc[:, 11], pc[:, 12], pc[:, 13], dwqk[:ks], dwqk[ks:], pc[:, :9], pc[:, 9])
@@ -967,15 +1102,28 @@ class _BnActFn(torch.autograd.Function):
             amom = torch.empty((rows, c, 2), dtype=torch.float32, device=dev)
             if training:           # sums about a per-channel pivot (a sample of the channel): robust for |mean| >> sigma
                 pivot = torch.empty((c,), dtype=torch.float32, device=dev)
+        if defer and relu:
+            raise L.MrlaHipError("a deferred BatchNorm cannot carry a ReLU")
+        y = None if defer else torch.empty_like(xc)
+        if _seq():
+            _seq_call("mrla_bn_fwd", _ptr(xc), _ptr(amom) if records else None, frows, None if records else _ptr(amom),
+                      _ptr(pivot), rows, _ptr(gamma32), _ptr(beta32), _ptr(rs.rm), _ptr(rs.rv),
+                      L.BN_TRAIN if training else L.BN_EVAL, float(momentum), float(eps), _ptr(bnbuf), int(relu), _ptr(y),
+                      b, c, h, w, dt, layout, st)
+        else:
+            if training and not records:
                 _call("mrla_bn_plane_moments", xc.numel() * xc.element_size(), _ptr(xc), _ptr(amom), _ptr(pivot), b, c, h, w,
                       dt, layout, st)
-        if records:
-            _call("mrla_bn_stats_fwd_rows", 0, _ptr(amom), _ptr(gamma32), _ptr(beta32), _ptr(rs.rm), _ptr(rs.rv), L.BN_TRAIN,
-                   float(momentum), float(eps), _ptr(bnbuf[0]), _ptr(bnbuf[1]), _ptr(bnbuf[2]), _ptr(bnbuf[3]), frows, c, st)
-        else:
-            _call("mrla_bn_stats_fwd", 0, _ptr(amom), _ptr(pivot), _ptr(gamma32), _ptr(beta32), _ptr(rs.rm), _ptr(rs.rv),
-                   L.BN_TRAIN if training else L.BN_EVAL, float(momentum), float(eps), _ptr(bnbuf[0]), _ptr(bnbuf[1]),
-                   _ptr(bnbuf[2]), _ptr(bnbuf[3]), frows, c, b * h * w // frows, st)
+            if records:
+                _call("mrla_bn_stats_fwd_rows", 0, _ptr(amom), _ptr(gamma32), _ptr(beta32), _ptr(rs.rm), _ptr(rs.rv), L.BN_TRAIN,
+                       float(momentum), float(eps), _ptr(bnbuf[0]), _ptr(bnbuf[1]), _ptr(bnbuf[2]), _ptr(bnbuf[3]), frows, c, st)
+            else:
+                _call("mrla_bn_stats_fwd", 0, _ptr(amom), _ptr(pivot), _ptr(gamma32), _ptr(beta32), _ptr(rs.rm), _ptr(rs.rv),
+                       L.BN_TRAIN if training else L.BN_EVAL, float(momentum), float(eps), _ptr(bnbuf[0]), _ptr(bnbuf[1]),
+                       _ptr(bnbuf[2]), _ptr(bnbuf[3]), frows, c, b * h * w // frows, st)
+            if y is not None:
+                _call("mrla_bn_act_fwd", xc.numel() * xc.element_size() * 2, _ptr(xc), _ptr(bnbuf[0]), _ptr(bnbuf[1]), int(relu),
+                      _ptr(y), b, c, h, w, dt, layout, st)
         rs.finish(training)
         ctx.training, ctx.relu, ctx.gdtype, ctx.layout, ctx.rows = training, int(relu), gamma.dtype, layout, rows
         ctx.box = box if defer else None
@@ -983,13 +1131,8 @@ class _BnActFn(torch.autograd.Function):
             ctx.box.center = bnbuf[2]
         ctx.save_for_backward(xc, gamma32, bnbuf)
         if defer:
-            if relu:
-                raise L.MrlaHipError("a deferred BatchNorm cannot carry a ReLU")
             ctx.mark_non_differentiable(bnbuf)
             return xc.detach(), bnbuf
-        y = torch.empty_like(xc)
-        _call("mrla_bn_act_fwd", xc.numel() * xc.element_size() * 2, _ptr(xc), _ptr(bnbuf[0]), _ptr(bnbuf[1]), int(relu),
-              _ptr(y), b, c, h, w, dt, layout, st)
         return y
 
     @staticmethod
@@ -1010,16 +1153,21 @@ class _BnActFn(torch.autograd.Function):
             tmom, rows = handed
         else:
             tmom = torch.empty((rows, c, 2), dtype=torch.float32, device=dev)
-            _call("mrla_bn_plane_dmoments", xc.numel() * es * 2, _ptr(dy), _ptr(xc), _ptr(bnbuf[0]), _ptr(bnbuf[1]),
-                  _ptr(bnbuf[2]), ctx.relu, _ptr(tmom), b, c, h, w, dt, layout, st)
         small = torch.empty((5, c), dtype=torch.float32, device=dev)          # cb[c,3] | dgamma | dbeta
-        cb = small[:3].view(c, 3)
-        _call("mrla_bn_stats_bwd", 0, _ptr(tmom), _ptr(gamma32), _ptr(bnbuf[2]), _ptr(bnbuf[3]),
-               L.BN_TRAIN if ctx.training else L.BN_EVAL, 1, _ptr(cb), _ptr(small[3]), _ptr(small[4]), rows, c,
-               b * h * w // rows, st)
         dx = torch.empty_like(xc)
-        _call("mrla_bn_act_bwd", xc.numel() * es * 3, _ptr(dy), _ptr(xc), _ptr(bnbuf[0]), _ptr(bnbuf[1]), _ptr(cb), ctx.relu,
-              _ptr(dx), b, c, h, w, dt, layout, st)
+        mode = L.BN_TRAIN if ctx.training else L.BN_EVAL
+        if _seq():
+            _seq_call("mrla_bn_bwd", _ptr(dy), _ptr(xc), _ptr(gamma32), _ptr(bnbuf), _ptr(tmom), rows, int(handed is not None),
+                      mode, ctx.relu, _ptr(small), _ptr(dx), b, c, h, w, dt, layout, st)
+        else:
+            if handed is None:
+                _call("mrla_bn_plane_dmoments", xc.numel() * es * 2, _ptr(dy), _ptr(xc), _ptr(bnbuf[0]), _ptr(bnbuf[1]),
+                      _ptr(bnbuf[2]), ctx.relu, _ptr(tmom), b, c, h, w, dt, layout, st)
+            cb = small[:3].view(c, 3)
+            _call("mrla_bn_stats_bwd", 0, _ptr(tmom), _ptr(gamma32), _ptr(bnbuf[2]), _ptr(bnbuf[3]), mode, 1, _ptr(cb),
+                  _ptr(small[3]), _ptr(small[4]), rows, c, b * h * w // rows, st)
+            _call("mrla_bn_act_bwd", xc.numel() * es * 3, _ptr(dy), _ptr(xc), _ptr(bnbuf[0]), _ptr(bnbuf[1]), _ptr(cb), ctx.relu,
+                  _ptr(dx), b, c, h, w, dt, layout, st)
         return dx, small[3].to(ctx.gdtype), small[4].to(ctx.gdtype), None, None, None, None, None, None, None, None, None
 
 

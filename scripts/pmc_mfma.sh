@@ -10,8 +10,10 @@ ROOT=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}; cd /tmp && export TM
 ARGS=${BENCH_ARGS:-}
 rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES SQ_INSTS_VALU_MFMA_MOPS_BF16 GRBM_GUI_ACTIVE --output-format csv -d $RAW/m -- python3 bench.py $ARGS --steps 2 --warmup 2 --no-baselines --no-forward-only --benchmark 0 --graph 0 > $OUT/mfma.log 2>&1
 python3 - "$RAW" "$OUT" $ARGS <<'PY'
-import csv, glob, sys, collections, json
+import csv, glob, sys, collections, json, os
 raw, out = sys.argv[1], sys.argv[2]
+sys.path.insert(0, "scripts")
+import lib_identity
 f = glob.glob(raw + "/m/*/*_counter_collection.csv")
 agg = collections.defaultdict(float); per = collections.defaultdict(lambda: collections.defaultdict(float))
 rows = list(csv.DictReader(open(f[0])))
@@ -25,7 +27,8 @@ for r in rows:
     agg[r["Counter_Name"]] += float(r["Counter_Value"])
     per[r["Kernel_Name"][:60]][r["Counter_Name"]] += float(r["Counter_Value"])
 res = {"command": "bench.py " + " ".join(sys.argv[3:]) + " --steps 2 --warmup 2 --no-baselines --benchmark 0 --graph 0",
-       "dispatches_counted": len([i for i in ids if i >= cut]), "totals": dict(agg)}
+       "dispatches_counted": len([i for i in ids if i >= cut]), "totals": dict(agg),
+       "_meta": lib_identity.identity(os.getcwd())}
 if agg.get("SQ_BUSY_CU_CYCLES"):
     res["mfma_busy_over_cu_busy"] = agg.get("SQ_VALU_MFMA_BUSY_CYCLES", 0.0) / agg["SQ_BUSY_CU_CYCLES"]
 if agg.get("GRBM_GUI_ACTIVE"):

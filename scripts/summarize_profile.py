@@ -60,6 +60,11 @@ for k in sorted(set(fetch) | set(write)):
     traffic[k] = {"launches_profiled": len(fl), "fetch_kb_per_launch_raw": sum(fl) / len(fl),
                   "write_kb_per_launch": sum(wl) / len(wl),
                   "hbm_bytes_per_launch": (2.0 * sum(fl) / len(fl) + sum(wl) / len(wl)) * 1024.0}
+# the library these counters were measured on (bench.py quotes them only for the same build: roofline.traffic_stale)
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+import lib_identity  # noqa: E402
+traffic["_meta"] = dict(lib_identity.identity(os.path.join(os.path.dirname(os.path.abspath(__file__)), "..")),
+                        command=os.environ.get("PMC_COMMAND", "scripts/pmc_bench.sh"))
 json.dump(traffic, open(os.path.join(out, "summary_traffic.json"), "w"), indent=1)
 
 f = glob.glob(os.path.join(raw, "trace", "*", "*_kernel_trace.csv"))

@@ -511,6 +511,9 @@ def check_replay(eager_step, replay, static_loss, net, opt, rank, world, tag):
     from mrla_amd import graphs
     rep = graphs.replay_matches_eager(eager_step, replay, net, opt, steps=REPLAY_CHECK_STEPS, replay_loss=static_loss,
                                       tol=REPLAY_TOL)
+    if not rep["ok"]:
+        print(f"warning: rank {rank}: the replayed graph ({tag}) does not reproduce the eager step: "
+              + json.dumps({k: v for k, v in rep.items() if k != "what"}), file=sys.stderr, flush=True)
     ok = all_ranks_ok(rep["ok"], "replay/" + tag, rank, world)
     rec = {k: (float(f"{v:.3e}") if isinstance(v, float) else v) for k, v in rep.items()}
     rec["what"] = (f"{REPLAY_CHECK_STEPS} consecutive replays of the captured step, each against an eagerly launched step from the SAME "
@@ -839,7 +842,10 @@ def main():
                 warm_up(st, args.warmup if first else 2)
                 if first:
                     R.update(exchange=ex, schedule=name)
-                    state["eager"] = measured_eagerly_first(st)
+                    fbk = state["eager"] = measured_eagerly_first(st)
+                    if rank == 0:          # the eager region's finished line, should the very first capture break (as above)
+                        state["eager_line"] = report(dict(R, dt=fbk["dt"], dt_eager=fbk["dt"], timer=fbk["timer"], use_graph=False,
+                                                          legs=False, rank_ms=fbk["rank_ms"], launch="kernel by kernel"), emit=False)
                 return dict(exchange=ex, step=st, name=name)
 
             def capture_graph(h, name):
@@ -853,6 +859,16 @@ def main():
             def after_region(rec):           # kept with that region: per-rank times, replicas in sync, weights finite
                 rec["rank_ms"] = dict(RANK_MS)
                 rec["in_sync"], rec["finite"] = states_after()
+                # ... and the finished LINE of that region, built NOW: if a later, optional capture breaks, rank 0 prints it and
+                # every rank leaves at once -- RCCL's watchdog thread aborts the process within moments of a broken capture
+                # that had collectives in it, so nothing may be left to compute then
+                if rank == 0:
+                    fbk = state["eager"]
+                    rec["line"] = report(dict(R, dt=rec["dt"], dt_eager=fbk["dt"], timer=fbk["timer"], use_graph=True, legs=False,
+                                              exchange=rec["handle"]["exchange"], schedule=rec["handle"]["name"],
+                                              ab_ms={rec["handle"]["name"]: round(1e3 * rec["dt"] / args.steps, 3)},
+                                              replay=rec["check"], rank_ms=rec["rank_ms"], in_sync=rec["in_sync"],
+                                              finite=rec["finite"], launch=graph_launch), emit=False)
 
             recs, chosen, failure = measure_exchange_schedules(
                 names, prepare, capture_graph, lambda run, n: timed(run, n, 1 if n != args.steps else 0), args.steps,
@@ -867,19 +883,22 @@ def main():
                 if chosen is None:
                     # the first capture broke: the eager region measured before it
                     print("reporting the eager steps measured before it", file=sys.stderr, flush=True)
-                    report_and_leave(dict(dt=fb["dt"], dt_eager=fb["dt"], timer=fb["timer"], use_graph=False, legs=False,
-                                          rank_ms=fb["rank_ms"],
-                                          launch="kernel by kernel (PyTorch eager launches; the HIP graph capture of the step failed -- "
-                                                 f"{why} -- so this is the eager region timed before the capture; the communicator was "
-                                                 "not used again)"))
+                    if rank == 0:
+                        rec0 = json.loads(state["eager_line"])
+                        rec0["config"]["launch"] = ("kernel by kernel (PyTorch eager launches; the HIP graph capture of the step failed -- "
+                                                    f"{why} -- so this is the eager region timed before the capture; the communicator was "
+                                                    "not used again)")
+                        print(json.dumps(rec0), flush=True)
+                    leave_without_the_communicator(0)
                 # an optional later schedule broke: the finished graph-replayed region of the earlier one stands
-                c = recs[chosen]
                 print(f"reporting the finished graph-replayed region of schedule {chosen}", file=sys.stderr, flush=True)
-                report_and_leave(dict(dt=c["dt"], dt_eager=fb["dt"], timer=fb["timer"], use_graph=True, legs=False,
-                                      exchange=c["handle"]["exchange"], schedule=chosen, ab_ms=ab_ms, replay=c["check"],
-                                      rank_ms=c["rank_ms"], in_sync=c["in_sync"], finite=c["finite"],
-                                      launch=graph_launch + f" (schedule {chosen}; the capture of the optional schedule {fname} failed -- "
-                                             f"{why} -- after this region had been timed; the communicator was not used again)"))
+                if rank == 0:
+                    rec0 = json.loads(recs[chosen]["line"])
+                    rec0["config"]["launch"] += (f" (schedule {chosen}; the capture of the optional schedule {fname} failed -- {why} -- "
+                                                 "after this region had been timed; the communicator was not used again)")
+                    rec0["config"]["gradient_exchange_ab_ms"] = ab_ms
+                    print(json.dumps(rec0), flush=True)
+                leave_without_the_communicator(0)
             if chosen is None:                 # no replay reproduced the eager step: time the eager launches of schedule 0
                 h = recs[names[0]]["handle"]
                 for k, v in recs.items():
@@ -997,8 +1016,8 @@ def main():
         torch.distributed.destroy_process_group()
 
 
-def report(R):
-    """Rank 0: build and print the ONE JSON line from a finished measurement R (see main())."""
+def report(R, emit=True):
+    """Rank 0: build the ONE JSON line from a finished measurement R (see main()), print it (emit) and return it."""
     from mrla_amd import functional as Fm  # noqa: F401
     args, world, seen, dist_on, dp = R["args"], R["world"], R["seen"], R["dist_on"], R["dp"]
     dt, dt_eager, timer, launch, use_graph = R["dt"], R["dt_eager"], R["timer"], R["launch"], R["use_graph"]
@@ -1090,7 +1109,10 @@ def report(R):
             gc.collect()
             torch.cuda.empty_cache()
             out["other_configs"] = run_other_configs()
-    print(json.dumps(out), flush=True)
+    line = json.dumps(out)
+    if emit:
+        print(line, flush=True)
+    return line
 
 
 if __name__ == "__main__":

@@ -25,6 +25,48 @@ def _pair(v):
     return v if isinstance(v, tuple) else (v, v)
 
 
+class _LinearFn(torch.autograd.Function):
+    """F.linear whose bias gradient is a GEMM (ones^T dY) instead of torch's column-sum reduction.
+
+    Why: replayed from a HIP graph, the training step of these DeiT models returned NaN in a random handful of nn.Linear
+    BIAS gradients from the second replay on (weights' gradients of the same layers finite; eager launches always right) --
+    with bf16 autocast, stochastic depth on and self-attention in the block; none of this package's kernels involved (the
+    same blocks without the MRLA module show it; scripts/deit_replay_debug*.py, profiles/r05_notes.md).  Taking the bias
+    gradient through a matrix product (fp32 accumulation, rounded once to the activation dtype -- what the reduction does)
+    removes it; everything else is the stock linear: forward with the fused bias epilogue, dX = dY W, dW = dY^T X."""
+
+    @staticmethod
+    def forward(ctx, x, w, b):
+        ctx.save_for_backward(x, w)
+        ctx.has_bias = b is not None
+        return F.linear(x, w, b)
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, w = ctx.saved_tensors
+        dy2, x2 = dy.reshape(-1, dy.shape[-1]), x.reshape(-1, x.shape[-1])
+        dx = (dy2 @ w).view(x.shape) if ctx.needs_input_grad[0] else None
+        dw = dy2.t() @ x2 if ctx.needs_input_grad[1] else None
+        db = None
+        if ctx.has_bias and ctx.needs_input_grad[2]:
+            db = (dy2.new_ones((1, dy2.shape[0])) @ dy2).view(-1)
+        return dx, dw, db
+
+
+def _linear(mod, x):
+    """`mod(x)` for an nn.Linear on a CUDA tensor through _LinearFn (autocast handled here: the Function runs with autocast
+    off on operands already in the autocast dtype, as torch.amp.custom_fwd(cast_inputs=...) would arrange)."""
+    if not (type(mod) is nn.Linear and x.is_cuda and torch.is_grad_enabled()):
+        return mod(x)
+    w, b = mod.weight, mod.bias
+    if torch.is_autocast_enabled("cuda"):
+        dt = torch.get_autocast_dtype("cuda")
+        x, w, b = x.to(dt), w.to(dt), (b.to(dt) if b is not None else None)
+        with torch.autocast("cuda", enabled=False):
+            return _LinearFn.apply(x, w, b)
+    return _LinearFn.apply(x, w, b)
+
+
 class PatchEmbed(nn.Module):
     def __init__(self, img_size=224, patch_size=16, in_chans=3, embed_dim=768, norm_layer=None):
         super().__init__()
@@ -50,7 +92,7 @@ class Mlp(nn.Module):
         self.fc2, self.drop2 = nn.Linear(hidden_features, out_features), nn.Dropout(d2)
 
     def forward(self, x):
-        return self.drop2(self.fc2(self.drop1(self.act(self.fc1(x)))))
+        return self.drop2(_linear(self.fc2, self.drop1(self.act(_linear(self.fc1, x)))))
 
 
 class Attention(nn.Module):
@@ -70,13 +112,13 @@ class Attention(nn.Module):
 
     def forward(self, x):
         B, N, C = x.shape
-        q, k, v = self.qkv(x).reshape(B, N, 3, self.num_heads, C // self.num_heads).permute(2, 0, 3, 1, 4).unbind(0)
+        q, k, v = _linear(self.qkv, x).reshape(B, N, 3, self.num_heads, C // self.num_heads).permute(2, 0, 3, 1, 4).unbind(0)
         if self.fused_attn and x.is_cuda:
             y = F.scaled_dot_product_attention(q, k, v, dropout_p=self.attn_drop.p if self.training else 0.0,
                                                scale=self.scale)
         else:
             y = self.attn_drop(((q @ k.transpose(-2, -1)) * self.scale).softmax(dim=-1)) @ v
-        return self.proj_drop(self.proj(y.transpose(1, 2).reshape(B, N, C)))
+        return self.proj_drop(_linear(self.proj, y.transpose(1, 2).reshape(B, N, C)))
 
 
 class Block(nn.Module):
@@ -170,7 +212,8 @@ class ViT_mrlal(nn.Module):
         return self.pre_logits(x[:, 0])
 
     def forward(self, x):
-        return self.head(self.forward_features(x))
+        x = self.forward_features(x)
+        return _linear(self.head, x) if isinstance(self.head, nn.Linear) else self.head(x)
 
 
 class Block_base(nn.Module):

@@ -20,7 +20,7 @@ def test_library_exports_every_declared_symbol():
         assert hasattr(lib, name), name
     # the version the header declares == what the library reports == what the ctypes binding was written against
     hdr_version = int(re.search(r"#define\s+MRLA_ABI_VERSION\s+(\d+)", hdr).group(1))
-    assert lib.mrla_abi_version() == hdr_version == _lib.ABI_VERSION == 3
+    assert lib.mrla_abi_version() == hdr_version == _lib.ABI_VERSION == 4
 
 
 def test_argument_validation_without_a_gpu():
@@ -53,6 +53,17 @@ def test_argument_validation_without_a_gpu():
     assert lib.mrla_conv1x1_wgrad_rows(64, 96, 64, _lib.BF16) == _lib.EUNSUPPORTED
     assert lib.mrla_conv1x1_wgrad_rows(1 << 24, 128, 64, _lib.BF16) == _lib.EUNSUPPORTED  # 32-bit buffer offsets
     assert lib.mrla_conv1x1_wgrad(None, None, None, None, 64, 64, 64, _lib.BF16, _lib.BF16, None) == _lib.EINVAL
+    # the sequence entry points (ABI 4) validate like the passes they issue: the first pass's code comes back, nothing is launched
+    P = [None]
+    assert lib.mrla_light_tail_fwd(*P * 6, 5, *P * 6, _lib.BN_TRAIN, 0.1, 1e-5, *P * 6, 2, 64, 8, 8, 32, 1, 1, _lib.BF16, _lib.NHWC,
+                                   0, None) == _lib.EINVAL
+    assert lib.mrla_light_tail_bwd(*P * 5, 5, *P * 7, _lib.BN_TRAIN, *P * 5, 1, *P * 6, 2, 64, 8, 8, 32, 1, 1, _lib.BF16,
+                                   _lib.NHWC, 0, None) == _lib.EINVAL
+    assert lib.mrla_bn_fwd(None, None, 0, None, None, 8, *P * 4, _lib.BN_TRAIN, 0.1, 1e-5, None, 1, None, 2, 64, 8, 8, _lib.BF16,
+                           _lib.NHWC, None) == _lib.EINVAL
+    assert lib.mrla_bn_bwd(*P * 5, 8, 0, _lib.BN_TRAIN, 1, None, None, 2, 64, 8, 8, _lib.BF16, _lib.NHWC, None) == _lib.EINVAL
+    assert lib.mrla_token_light_fwd(*P * 8, 5, None, None, 1e-6, *P * 4, 2, 17, 64, 16, 1, _lib.F32, None) == _lib.EINVAL
+    assert lib.mrla_token_light_bwd(*P * 10, 5, *P * 6, 2, *P * 6, 2, 17, 64, 16, 1, _lib.F32, None) == _lib.EINVAL
 
 
 def test_model_surface_matches_reference_names():

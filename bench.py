@@ -86,6 +86,11 @@ def parse():
     ap.add_argument("--benchmark", type=int, default=1,
                     help="torch.backends.cudnn.benchmark for the timed model: 1 as resnet/train.py:247 sets it (MIOpen picks its "
                          "solvers by measuring them during the warm-up steps), 0 for MIOpen's immediate-mode choice")
+    ap.add_argument("--deterministic", type=int, default=-1,
+                    help="torch.backends.cudnn.deterministic for the timed model (resnet/train.py:107-110 sets it with --seed): MIOpen "
+                         "then leaves out its atomically accumulating (split-K) solvers.  1 / 0: on / off; -1 (default): off, and "
+                         "switched ON for one more attempt if the replayed HIP graph does not reproduce the eager step -- such a "
+                         "solver is right when launched eagerly and garbage from the second replay of a graph on")
     ap.add_argument("--graph", type=int, default=-1,
                     help="1: the timed steps replay the whole step (fwd+bwd+SGD) from one HIP graph; 0: launched kernel by "
                          "kernel; -1 (default): 1, except with --dp ddp or a non-RCCL backend")
@@ -304,6 +309,8 @@ def cpu_baseline(arch, budget_s=75.0):
 def eager_rocm(arch, batch, drop_path, steps=6):
     from oracle import eager_models as em
     torch.manual_seed(0)
+    was_det = torch.backends.cudnn.deterministic
+    torch.backends.cudnn.deterministic = False      # the baseline always gets MIOpen's full solver list (it launches eagerly)
     kw = {"drop_path_rate": drop_path} if arch.startswith("deit") else {"drop_path": drop_path}
     net = getattr(em, "eager_" + arch)(**kw).cuda().train()
     x = torch.randn(batch, 3, 224, 224, device="cuda")
@@ -331,6 +338,7 @@ def eager_rocm(arch, batch, drop_path, steps=6):
             fw = (time.perf_counter() - t0) / steps
         fwd[bm] = (round(batch / fw, 1), round(t_find, 1))
     torch.backends.cudnn.benchmark = was
+    torch.backends.cudnn.deterministic = was_det
     return {"fwd_bwd_images_per_sec": round(batch * steps / dt, 1),
             "fwd_images_per_sec": max(fwd[False][0], fwd[True][0]),
             "fwd_images_per_sec_benchmark_false": fwd[False][0], "fwd_images_per_sec_benchmark_true": fwd[True][0],
@@ -587,7 +595,7 @@ def run_other_configs():
             rec = json.loads(lines[-1])
             out[arch] = {"value": rec["value"], "unit": rec["unit"], "ms_per_step": rec["ms_per_step"], "batch": batch,
                          "steps": rec["steps"], "launch": rec["config"]["launch"], "roofline": rec["roofline"],
-                         "replay_matches_eager": rec["config"].get("replay_matches_eager"),
+                         "replay_matches_eager": rec["config"].get("replay_matches_eager"), "miopen": rec["config"].get("miopen"),
                          "replay_check": rec["config"].get("replay_check"), "weights_finite": rec["config"].get("weights_finite"),
                          "eager_launch_ms_per_step": rec.get("eager_launch_ms_per_step"),
                          "workload": rec["config"]["workload"], "wall_s": round(time.perf_counter() - t0, 1)}
@@ -625,6 +633,13 @@ def main():
     # image's driver without it.  Set for EVERY rank before the first GPU call -- the ranks of the driver's own
     # `python -m torch.distributed.run ... bench.py` line never pass through launch_ranks().
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    # ProcessGroupNCCL's watchdog thread must never query an event that was last recorded inside a stream capture
+    # (hipErrorCapturedEvent -> std::terminate: seen in one run out of two of the one-rank RCCL tests once the captured steps
+    # carried collectives on side streams).  Its event cache hands events of captured collectives to later eager ones, and
+    # the flight recorder keeps events of captured collectives for the watchdog to retire: both off for this process.
+    for k, v in (("TORCH_NCCL_CUDA_EVENT_CACHE", "0"), ("TORCH_NCCL_TRACE_BUFFER_SIZE", "0"), ("TORCH_FR_BUFFER_SIZE", "0"),
+                 ("TORCH_NCCL_RETHROW_CUDA_ERRORS", "0")):
+        os.environ.setdefault(k, v)
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ and not args.ddp_probe:
         sys.exit(launch_ranks(args))              # (nothing before this line has touched the GPU)
 
@@ -649,6 +664,7 @@ def main():
 
     from mrla_amd import functional as Fm
     torch.backends.cudnn.benchmark = bool(args.benchmark)
+    torch.backends.cudnn.deterministic = args.deterministic == 1
     if not args.benchmark and args.graph < 0:
         # MIOpen's immediate mode picks, for some small-batch 3x3 shapes, a weight-gradient solver that accumulates into memory
         # it zeroes only once: eager launches are right, a REPLAYED graph returns garbage dW from the second replay on
@@ -723,6 +739,26 @@ def main():
         for _ in range(n):
             st()
 
+    def deterministic_retry(first_check, st, n_warm):
+        """The replay did not reproduce the eager step.  With --deterministic -1 (the default): switch
+        torch.backends.cudnn.deterministic on -- MIOpen then leaves out its atomically accumulating (split-K) solvers, which
+        are right when launched eagerly and garbage from the second replay of a graph on -- re-run the warm-up (MIOpen
+        searches again among the others) and tell the caller to capture and check once more.  Returns True when it did."""
+        if args.deterministic != -1 or torch.backends.cudnn.deterministic:
+            return False
+        torch.backends.cudnn.deterministic = True
+        R["miopen_deterministic_why"] = ("switched on after the first captured graph did not reproduce the eager step "
+                                         f"(update_rel_l2 {(first_check or {}).get('update_rel_l2')}, noise "
+                                         f"{(first_check or {}).get('noise_update_rel_l2')}, worst parameter "
+                                         f"{(first_check or {}).get('worst_parameter')})")
+        R["replay_first_attempt"] = first_check
+        if rank == 0:
+            print("note: torch.backends.cudnn.deterministic = True from here on (MIOpen's atomically accumulating solvers do not "
+                  "survive graph replay); warming up, capturing and checking once more", file=sys.stderr, flush=True)
+        warm_up(st, n_warm)
+        torch.cuda.synchronize()
+        return True
+
     def find_first(module):
         """MIOpen's solver search (torch.backends.cudnn.benchmark), rank 0 alone first: forward + loss + backward of the bare
         module, twice -- every convolution's forward, input-gradient and weight-gradient problem of the step -- with NO
@@ -746,11 +782,13 @@ def main():
         collective goes into a stream capture.  If the FIRST capture then fails on any rank, THIS is what the line reports (the
         ranks agree on that through the TCP store and leave without touching the communicator): an N > 1 run never ends
         without its number.  (A later, optional capture that fails costs nothing: measure_exchange_schedules.)"""
-        t = Fm.KernelTimer()
+        d = timed(st, args.steps, 0)                     # as a training loop launches it: one C call per tail, no events
+        rms = dict(RANK_MS)
+        t = Fm.KernelTimer()                             # ... and once more with an event pair around every kernel (roofline)
         Fm.TIMER = t
-        d = timed(st, args.steps, 0)
+        de = timed(st, args.steps, 0)
         Fm.TIMER = None
-        return dict(dt=d, timer=t, rank_ms=dict(RANK_MS))
+        return dict(dt=d, dt_events=de, timer=t, rank_ms=rms)
 
     def capture_voted(st, tag, warm):
         """capture(st) with the ranks' vote; raises CaptureBroken when it failed on any rank."""
@@ -806,9 +844,9 @@ def main():
             opt.step()
         err = None
         try:                                             # (no collective inside either capture: a failure here is local)
-            g1 = capture(part1, False, 2)
+            g1 = capture(part1, dist_on, 2)        # (thread-local capture mode: the watchdog may query eager works meanwhile)
             ex.allreduce_flat()
-            g3 = capture(part3, False, 0)
+            g3 = capture(part3, dist_on, 0)
         except Exception as e:                           # noqa: BLE001
             err = e
         if all_ranks_ok(err is None, "capture/split", rank, world):
@@ -844,7 +882,8 @@ def main():
                     R.update(exchange=ex, schedule=name)
                     fbk = state["eager"] = measured_eagerly_first(st)
                     if rank == 0:          # the eager region's finished line, should the very first capture break (as above)
-                        state["eager_line"] = report(dict(R, dt=fbk["dt"], dt_eager=fbk["dt"], timer=fbk["timer"], use_graph=False,
+                        state["eager_line"] = report(dict(R, dt=fbk["dt"], dt_eager=fbk["dt"], dt_events=fbk["dt_events"],
+                                                          timer=fbk["timer"], use_graph=False,
                                                           legs=False, rank_ms=fbk["rank_ms"], launch="kernel by kernel"), emit=False)
                 return dict(exchange=ex, step=st, name=name)
 
@@ -864,15 +903,25 @@ def main():
                 # that had collectives in it, so nothing may be left to compute then
                 if rank == 0:
                     fbk = state["eager"]
-                    rec["line"] = report(dict(R, dt=rec["dt"], dt_eager=fbk["dt"], timer=fbk["timer"], use_graph=True, legs=False,
+                    rec["line"] = report(dict(R, dt=rec["dt"], dt_eager=fbk["dt"], dt_events=fbk["dt_events"], timer=fbk["timer"],
+                                              use_graph=True, legs=False,
                                               exchange=rec["handle"]["exchange"], schedule=rec["handle"]["name"],
                                               ab_ms={rec["handle"]["name"]: round(1e3 * rec["dt"] / args.steps, 3)},
                                               replay=rec["check"], rank_ms=rec["rank_ms"], in_sync=rec["in_sync"],
                                               finite=rec["finite"], launch=graph_launch), emit=False)
 
-            recs, chosen, failure = measure_exchange_schedules(
-                names, prepare, capture_graph, lambda run, n: timed(run, n, 1 if n != args.steps else 0), args.steps,
-                args.ab_steps, verify, after_region)
+            for attempt in (0, 1):
+                recs, chosen, failure = measure_exchange_schedules(
+                    names, prepare, capture_graph, lambda run, n: timed(run, n, 1 if n != args.steps else 0), args.steps,
+                    args.ab_steps, verify, after_region)
+                if chosen is not None or failure is not None or attempt == 1:
+                    break
+                # no schedule's replay reproduced the eager step (the ranks agree: every check was voted): once more with
+                # MIOpen's deterministic solvers, on fresh exchanges
+                for v in recs.values():
+                    v["handle"]["exchange"].remove_hooks()
+                if not deterministic_retry(recs[names[0]]["check"], recs[names[0]]["handle"]["step"], max(3, args.warmup)):
+                    break
             fb = state["eager"]
             eager_record = fb
             ab_ms = {k: v["ab_ms"] for k, v in recs.items() if v["ab_ms"] is not None} if len(names) > 1 else None
@@ -957,7 +1006,8 @@ def main():
             except CaptureBroken as e:
                 print(f"warning: HIP graph capture of the data-parallel step failed ({e}); reporting the eager steps measured "
                       "before it", file=sys.stderr, flush=True)
-                report_and_leave(dict(dt=fb["dt"], dt_eager=fb["dt"], timer=fb["timer"], use_graph=False, legs=False,
+                report_and_leave(dict(dt=fb["dt"], dt_eager=fb["dt"], dt_events=fb["dt_events"], timer=fb["timer"], use_graph=False,
+                                      legs=False,
                                       rank_ms=fb["rank_ms"],
                                       launch="kernel by kernel (PyTorch eager launches; the HIP graph capture of the step failed -- "
                                              f"{str(e)[:200]} -- so this is the eager region timed before the capture; the "
@@ -972,12 +1022,15 @@ def main():
             # replay it -- the same kernels on the same buffers, minus the launch gaps -- after proving that the replay
             # computes what the eager launches compute (config.replay_matches_eager)
             try:
-                graph = capture(eager_step, False, 2)
-                R["replay"], ok = check_replay(eager_step, graph.replay, eager_step.loss, net, opt, rank, world, "n1")
-                if ok:
-                    step, launch = graph.replay, graph_launch
-                else:
+                for attempt in (0, 1):
+                    graph = capture(eager_step, dist_on, 2)
+                    R["replay"], ok = check_replay(eager_step, graph.replay, eager_step.loss, net, opt, rank, world, f"n1/{attempt}")
+                    if ok:
+                        step, launch = graph.replay, graph_launch
+                        break
                     graph, launch = None, not_reproduced
+                    if attempt == 1 or not deterministic_retry(R["replay"], eager_step, max(3, args.warmup)):
+                        break
             except Exception as e:
                 print(f"warning: HIP graph capture failed ({type(e).__name__}: {e}); timing eager launches", file=sys.stderr)
                 graph, step = None, eager_step
@@ -992,20 +1045,20 @@ def main():
         else:
             dt = timed(step, args.steps, 0)
             R["rank_ms"] = dict(RANK_MS) if dist_on else None
-        if eager_record is not None:                     # the eager region with events was taken before the captures
-            timer, dt_eager = eager_record["timer"], eager_record["dt"]
-        else:
-            # per-kernel HIP events cannot be read out of a replayed graph: the same `steps` steps once more, launched kernel
-            # by kernel with the events on the launch stream (this second region feeds `roofline` / `mrla_kernels` only)
-            Fm.TIMER = timer
-            dt_eager = timed(eager_step, args.steps, 0)
-            Fm.TIMER = None
     else:
-        Fm.TIMER = timer
-        dt = timed(step, args.steps, 0)
-        Fm.TIMER = None
-        dt_eager = dt
+        dt = timed(step, args.steps, 0)                  # eager launches as a training loop issues them (no events)
         R["rank_ms"] = dict(RANK_MS) if dist_on else None
+    if eager_record is not None:                         # the eager regions were taken before the captures
+        timer, dt_eager, dt_events = eager_record["timer"], eager_record["dt"], eager_record["dt_events"]
+    else:
+        # the same `steps` steps launched kernel by kernel: what resnet/train.py's loop gets unchanged ...
+        dt_eager = timed(eager_step, args.steps, 0) if use_graph else dt
+        # ... and once more with a HIP-event pair on the launch stream around EVERY kernel (events cannot be read out of a
+        # replayed graph; this region feeds `roofline` / `mrla_kernels` only; the C ABI is then called pass by pass)
+        Fm.TIMER = timer
+        dt_events = timed(eager_step, args.steps, 0)
+        Fm.TIMER = None
+    R["dt_events"] = dt_events
     in_sync, finite = states_after()
     if rank == 0:
         graph = split_graphs = step = eager_step = None  # (report() may hand the GPU to child processes)
@@ -1065,6 +1118,10 @@ def report(R, emit=True):
                                   f"fp32 master weights, drop_path {args.drop_path}",
                       "global_batch": world * args.batch, "parallelism": f"dp{world}", "launch": launch,
                       "ranks_seen": seen, "weights_finite": R.get("finite"),
+                      "miopen": {"find_mode": bool(torch.backends.cudnn.benchmark),          # resnet/train.py:247
+                                 "deterministic_solvers_only": bool(torch.backends.cudnn.deterministic),   # train.py:107-110 (--seed)
+                                 **({"why": R["miopen_deterministic_why"], "first_attempt": R.get("replay_first_attempt")}
+                                    if R.get("miopen_deterministic_why") else {})},
                       # the replayed graph against eagerly launched steps from the same state (max over parameters of the
                       # relative L2 difference of the weights); null when the timed steps were launched eagerly anyway
                       "replay_matches_eager": (R.get("replay") or {}).get("weights_rel_l2"),
@@ -1077,6 +1134,8 @@ def report(R, emit=True):
                               f"mrla_amd (HIP MRLA tails incl. shortcut add+ReLU, HIP BatchNorm+ReLU(+stem max-pool), HIP MFMA GEMMs for the "
                               f"1x1 convolutions fwd / dgrad / wgrad where eligible, stock 3x3 / 7x7 / strided convolutions; {layout})"},
            "eager_launch_ms_per_step": round(1e3 * dt_eager / args.steps, 3),
+           **({"eager_launch_with_kernel_events_ms_per_step": round(1e3 * R["dt_events"] / args.steps, 3)}
+              if R.get("dt_events") is not None else {}),
            # what resnet/train.py gets UNCHANGED (its loop launches the step eagerly, :387-409); `value` is the same step
            # replayed from one HIP graph -- mrla_amd.graphed_step(model, optimizer, criterion, (images, target)), INTEGRATION.md
            "eager_launch_images_per_sec": round(world * args.batch * args.steps / dt_eager, 1),

@@ -62,7 +62,7 @@ enum { MRLA_BN_NONE = 0, MRLA_BN_TRAIN = 1, MRLA_BN_EVAL = 2 };
  *   2 -> 3: mrla_base_value_bwd_dv gained pre / pre_center / pre_tmom (bn3's backward sums folded into the MRLA-base value
  *           backward, as mrla_light_apply_bwd has them); mrla_base_value_bwd_pre_sums was added.
  *   3 -> 4: the "sequence" entry points were added (mrla_light_tail_fwd / _bwd, mrla_bn_fwd / _bwd, mrla_base_layer_fwd /
- *           _bwd, mrla_token_light_fwd / _bwd: one call issues the static launch sequence of a whole tail and direction;
+ *           _bwd, mrla_token_light_fwd / _bwd, mrla_stem_fwd / _bwd: one call issues the static launch sequence of a whole tail and direction;
  *           the per-pass entry points are unchanged).
  * A consumer compares mrla_abi_version() (what the loaded library was built from) against this constant before its
  * first call. */
@@ -512,6 +512,16 @@ int mrla_bn_fwd(const void* x, const float* records, int rec_rows, float* amom, 
 int mrla_bn_bwd(const void* dy, const void* x, const float* gamma, const float* bnbuf, float* tmom, int rows, int have_tmom,
                 int bn_mode, int relu, float* small, void* dx, int b, int c, int h, int w, int dtype, int layout,
                 void* stream);
+
+/* The stem tail maxpool3x3/s2/p1(relu(bn1(x))) (resnet_mrla_light.py:220-222), forward:
+ *   [TRAIN: mrla_bn_plane_moments(x, amom, pivot)] -> mrla_bn_stats_fwd(amom, pivot, ..., rows) -> mrla_bn_relu_pool_fwd;
+ * backward: mrla_bn_relu_pool_dmoments(center = save_mean) -> mrla_bn_stats_bwd(centered = 1, rows) ->
+ *   [dx != NULL: mrla_bn_relu_pool_bwd].   rows: mrla_bn_moment_rows() forward, mrla_bn_pool_rows() backward; small: [5, c]. */
+int mrla_stem_fwd(const void* x, float* amom, float* pivot, int rows, const float* gamma, const float* beta,
+                  float* running_mean, float* running_var, int bn_mode, float momentum, float eps, float* bnbuf, void* out,
+                  int b, int c, int h, int w, int dtype, int layout, void* stream);
+int mrla_stem_bwd(const void* dp, const void* x, const float* gamma, const float* bnbuf, float* tmom, int rows, int bn_mode,
+                  float* small, void* dx, int b, int c, int h, int w, int dtype, int layout, void* stream);
 
 /* MRLA-base layer + tail on a channels_last stage (MRLA_NHWC rings), forward -- the sequence documented at
  * mrla_base_tile_rows:  mrla_base_pool_value_fwd -> mrla_base_gate_fwd -> mrla_base_attend_fwd ->

@@ -93,6 +93,8 @@ SIGNATURES = {
     "mrla_light_tail_bwd": [_P] * 5 + [_I] + [_P] * 7 + [_I] + [_P] * 5 + [_I] + [_P] * 6 + [_I] * 10 + [_P],
     "mrla_bn_fwd": [_P, _P, _I, _P, _P, _I, _P, _P, _P, _P, _I, _F, _F, _P, _I, _P] + [_I] * 6 + [_P],
     "mrla_bn_bwd": [_P] * 5 + [_I] * 4 + [_P, _P] + [_I] * 6 + [_P],
+    "mrla_stem_fwd": [_P, _P, _P, _I, _P, _P, _P, _P, _I, _F, _F, _P, _P] + [_I] * 6 + [_P],
+    "mrla_stem_bwd": [_P] * 5 + [_I, _I, _P, _P] + [_I] * 6 + [_P],
     "mrla_base_layer_fwd": [_P] * 6 + [_I] + [_P] * 5 + [_I, _F, _F] + [_P] * 9 + [_I] + [_P, _P] + [_I] * 9 + [_P],
     "mrla_base_layer_bwd": ([_P] * 5 + [_I] + [_P] * 6 + [_I] + [_P] * 6 + [_I] + [_P, _P] + [_I] + [_P] * 5 + [_I] + [_P] * 5
                             + [_I] * 12 + [_P]),

@@ -92,6 +92,30 @@ int mrla_bn_bwd(const void* dy, const void* x, const float* gamma, const float* 
   return mrla_bn_act_bwd(dy, x, bnbuf, bnbuf + C, small, relu, dx, b, c, h, w, dtype, layout, stream);
 }
 
+int mrla_stem_fwd(const void* x, float* amom, float* pivot, int rows, const float* gamma, const float* beta,
+                  float* running_mean, float* running_var, int bn_mode, float momentum, float eps, float* bnbuf, void* out,
+                  int b, int c, int h, int w, int dtype, int layout, void* stream) {
+  if (!bnbuf || !amom || rows <= 0 || ((long)b * h * w) % rows || (bn_mode != MRLA_BN_TRAIN && bn_mode != MRLA_BN_EVAL))
+    return MRLA_EINVAL;
+  const size_t C = (size_t)c;
+  const bool train = bn_mode == MRLA_BN_TRAIN;
+  if (train) MRLA_TRY(mrla_bn_plane_moments(x, amom, pivot, b, c, h, w, dtype, layout, stream));
+  MRLA_TRY(mrla_bn_stats_fwd(amom, train ? pivot : nullptr, gamma, beta, running_mean, running_var, bn_mode, momentum, eps,
+                             bnbuf, bnbuf + C, bnbuf + 2 * C, bnbuf + 3 * C, rows, c, (int)((long)b * h * w / rows), stream));
+  return mrla_bn_relu_pool_fwd(x, bnbuf, bnbuf + C, out, b, c, h, w, dtype, layout, stream);
+}
+
+int mrla_stem_bwd(const void* dp, const void* x, const float* gamma, const float* bnbuf, float* tmom, int rows, int bn_mode,
+                  float* small, void* dx, int b, int c, int h, int w, int dtype, int layout, void* stream) {
+  if (!bnbuf || !tmom || !small || rows <= 0 || ((long)b * h * w) % rows) return MRLA_EINVAL;
+  const size_t C = (size_t)c;
+  MRLA_TRY(mrla_bn_relu_pool_dmoments(dp, x, bnbuf, bnbuf + C, bnbuf + 2 * C, tmom, b, c, h, w, dtype, layout, stream));
+  MRLA_TRY(mrla_bn_stats_bwd(tmom, gamma, bnbuf + 2 * C, bnbuf + 3 * C, bn_mode, 1, small, small + 3 * C, small + 4 * C, rows, c,
+                             (int)((long)b * h * w / rows), stream));
+  if (!dx) return MRLA_OK;
+  return mrla_bn_relu_pool_bwd(dp, x, bnbuf, bnbuf + C, small, dx, b, c, h, w, dtype, layout, stream);
+}
+
 int mrla_base_layer_fwd(const void* x, const float* pre_sc, const float* pre_sh, const void* identity, const float* wq,
                         const float* wk, int ksize, const float* wv, const float* gamma, const float* beta,
                         float* running_mean, float* running_var, int bn_mode, float momentum, float eps, const float* dp,

@@ -1210,19 +1210,23 @@ class _BnReluPoolFn(torch.autograd.Function):
         bnbuf = torch.empty((4, c), dtype=torch.float32, device=dev)       # sc, sh, save_mean, save_inv
         rows = L.load().mrla_bn_moment_rows(b, c, h, w, layout)
         amom = torch.empty((rows, c, 2), dtype=torch.float32, device=dev)
-        pivot = None
-        if training:
-            pivot = torch.empty((c,), dtype=torch.float32, device=dev)
-            _call("mrla_bn_plane_moments", xc.numel() * xc.element_size(), _ptr(xc), _ptr(amom), _ptr(pivot), b, c, h, w, dt,
-                  layout, st)
-        _call("mrla_bn_stats_fwd", 0, _ptr(amom), _ptr(pivot), _ptr(gamma32), _ptr(beta32), _ptr(rs.rm), _ptr(rs.rv),
-               L.BN_TRAIN if training else L.BN_EVAL, float(momentum), float(eps), _ptr(bnbuf[0]), _ptr(bnbuf[1]),
-               _ptr(bnbuf[2]), _ptr(bnbuf[3]), rows, c, b * h * w // rows, st)
-        rs.finish(training)
+        pivot = torch.empty((c,), dtype=torch.float32, device=dev) if training else None
         ho, wo = (h - 1) // 2 + 1, (w - 1) // 2 + 1
         out = torch.empty((b, c, ho, wo), dtype=xc.dtype, device=dev, memory_format=_CL)
-        _call("mrla_bn_relu_pool_fwd", (xc.numel() + out.numel()) * xc.element_size(), _ptr(xc), _ptr(bnbuf[0]),
-              _ptr(bnbuf[1]), _ptr(out), b, c, h, w, dt, layout, st)
+        mode = L.BN_TRAIN if training else L.BN_EVAL
+        if _seq():
+            _seq_call("mrla_stem_fwd", _ptr(xc), _ptr(amom), _ptr(pivot), rows, _ptr(gamma32), _ptr(beta32), _ptr(rs.rm),
+                      _ptr(rs.rv), mode, float(momentum), float(eps), _ptr(bnbuf), _ptr(out), b, c, h, w, dt, layout, st)
+        else:
+            if training:
+                _call("mrla_bn_plane_moments", xc.numel() * xc.element_size(), _ptr(xc), _ptr(amom), _ptr(pivot), b, c, h, w, dt,
+                      layout, st)
+            _call("mrla_bn_stats_fwd", 0, _ptr(amom), _ptr(pivot), _ptr(gamma32), _ptr(beta32), _ptr(rs.rm), _ptr(rs.rv),
+                   mode, float(momentum), float(eps), _ptr(bnbuf[0]), _ptr(bnbuf[1]), _ptr(bnbuf[2]), _ptr(bnbuf[3]), rows, c,
+                   b * h * w // rows, st)
+            _call("mrla_bn_relu_pool_fwd", (xc.numel() + out.numel()) * xc.element_size(), _ptr(xc), _ptr(bnbuf[0]),
+                  _ptr(bnbuf[1]), _ptr(out), b, c, h, w, dt, layout, st)
+        rs.finish(training)
         ctx.training, ctx.gdtype = training, gamma.dtype
         ctx.save_for_backward(xc, gamma32, bnbuf)
         return out
@@ -1240,18 +1244,21 @@ class _BnReluPoolFn(torch.autograd.Function):
         rows = L.load().mrla_bn_pool_rows(b, c, h, w, dt, L.NHWC)
         L.check(min(rows, 0), "mrla_bn_pool_rows")
         tmom = torch.empty((rows, c, 2), dtype=torch.float32, device=dev)
-        _call("mrla_bn_relu_pool_dmoments", (xc.numel() + dp.numel()) * es, _ptr(dp), _ptr(xc), _ptr(bnbuf[0]), _ptr(bnbuf[1]),
-              _ptr(bnbuf[2]), _ptr(tmom), b, c, h, w, dt, L.NHWC, st)
         small = torch.empty((5, c), dtype=torch.float32, device=dev)          # cb[c,3] | dgamma | dbeta
-        cb = small[:3].view(c, 3)
-        _call("mrla_bn_stats_bwd", 0, _ptr(tmom), _ptr(gamma32), _ptr(bnbuf[2]), _ptr(bnbuf[3]),
-               L.BN_TRAIN if ctx.training else L.BN_EVAL, 1, _ptr(cb), _ptr(small[3]), _ptr(small[4]), rows, c,
-               b * h * w // rows, st)
-        dx = None
-        if ctx.needs_input_grad[0]:
-            dx = torch.empty_like(xc)
-            _call("mrla_bn_relu_pool_bwd", (2 * xc.numel() + dp.numel()) * es, _ptr(dp), _ptr(xc), _ptr(bnbuf[0]),
-                  _ptr(bnbuf[1]), _ptr(cb), _ptr(dx), b, c, h, w, dt, L.NHWC, st)
+        dx = torch.empty_like(xc) if ctx.needs_input_grad[0] else None
+        mode = L.BN_TRAIN if ctx.training else L.BN_EVAL
+        if _seq():
+            _seq_call("mrla_stem_bwd", _ptr(dp), _ptr(xc), _ptr(gamma32), _ptr(bnbuf), _ptr(tmom), rows, mode, _ptr(small),
+                      _ptr(dx), b, c, h, w, dt, L.NHWC, st)
+        else:
+            _call("mrla_bn_relu_pool_dmoments", (xc.numel() + dp.numel()) * es, _ptr(dp), _ptr(xc), _ptr(bnbuf[0]), _ptr(bnbuf[1]),
+                  _ptr(bnbuf[2]), _ptr(tmom), b, c, h, w, dt, L.NHWC, st)
+            cb = small[:3].view(c, 3)
+            _call("mrla_bn_stats_bwd", 0, _ptr(tmom), _ptr(gamma32), _ptr(bnbuf[2]), _ptr(bnbuf[3]), mode, 1, _ptr(cb),
+                  _ptr(small[3]), _ptr(small[4]), rows, c, b * h * w // rows, st)
+            if dx is not None:
+                _call("mrla_bn_relu_pool_bwd", (2 * xc.numel() + dp.numel()) * es, _ptr(dp), _ptr(xc), _ptr(bnbuf[0]),
+                      _ptr(bnbuf[1]), _ptr(cb), _ptr(dx), b, c, h, w, dt, L.NHWC, st)
         return dx, small[3].to(ctx.gdtype), small[4].to(ctx.gdtype), None, None, None, None, None
 
 
@@ -1300,7 +1307,9 @@ class WeightBank:
 
     @staticmethod
     def eligible(conv):
-        return (type(conv) is torch.nn.Conv2d and conv.kernel_size == (1, 1) and conv.stride == (1, 1)
+        # (strided 1x1 convolutions -- the downsample branch of a stage's first block -- run the same GEMM on the
+        # subsampled input: conv_bn_act)
+        return (type(conv) is torch.nn.Conv2d and conv.kernel_size == (1, 1)
                 and conv.padding == (0, 0) and conv.dilation == (1, 1) and conv.groups == 1 and conv.bias is None
                 and conv.in_channels % 64 == 0 and conv.out_channels % 64 == 0)
 
@@ -1443,10 +1452,36 @@ class _Conv1x1Fn(torch.autograd.Function):
         return gx, gw, None, None, None, None
 
 
-def conv1x1_applies(conv, x):
+class _SubsampleFn(torch.autograd.Function):
+    """x[:, :, ::sh, ::sw] as a dense channels_last tensor, with a backward that stays channels_last: zeros everywhere, the
+    incoming gradient at the sampled pixels (autograd's own slice backward answers in NCHW memory, which would cost the
+    consumer -- conv1's input-gradient GEMM takes it as the shortcut's gradient -- a full-size layout conversion)."""
+
+    @staticmethod
+    def forward(ctx, x, sh, sw):
+        ctx.shape, ctx.s = x.shape, (sh, sw)
+        return x[:, :, ::sh, ::sw].contiguous(memory_format=_CL)
+
+    @staticmethod
+    def backward(ctx, g):
+        sh, sw = ctx.s
+        dx = torch.empty(ctx.shape, dtype=g.dtype, device=g.device, memory_format=_CL).zero_()
+        dx[:, :, ::sh, ::sw] = g
+        return dx, None, None
+
+
+def _strided_1x1(conv):
+    """nn.Conv2d 1x1, no padding, stride > 1 (resnet_mrla_light.py:196-199: the downsample branch of a stage's first block)."""
+    return (type(conv) is torch.nn.Conv2d and conv.kernel_size == (1, 1) and conv.stride != (1, 1)
+            and conv.padding == (0, 0) and conv.dilation == (1, 1) and conv.groups == 1 and conv.bias is None)
+
+
+def conv1x1_applies(conv, x, strided=False):
     """True when `conv(x)` belongs on the HIP GEMMs: nn.Conv2d 1x1 / stride 1 / no bias, channels_last bf16 input, and a
-    shape the forward kernel (mrla_conv1x1_rows) or the weight-gradient kernel (mrla_conv1x1_wgrad_rows) takes."""
-    if not (type(conv) is torch.nn.Conv2d and conv.kernel_size == (1, 1) and conv.stride == (1, 1)
+    shape the forward kernel (mrla_conv1x1_rows) or the weight-gradient kernel (mrla_conv1x1_wgrad_rows) takes.
+    strided: the question is asked for a strided 1x1 convolution, which runs as the stride-1 GEMM on the subsampled input
+    (`x` is the full-size input; the pixel count is the subsampled one)."""
+    if not (type(conv) is torch.nn.Conv2d and conv.kernel_size == (1, 1) and (strided or conv.stride == (1, 1))
             and conv.padding == (0, 0) and conv.dilation == (1, 1) and conv.groups == 1 and conv.bias is None):
         return False
     if not (x.is_cuda and x.dim() == 4 and x.dtype == torch.bfloat16 and x.is_contiguous(memory_format=_CL)
@@ -1455,6 +1490,8 @@ def conv1x1_applies(conv, x):
     b, k, h, w = x.shape
     if k != conv.in_channels:
         return False
+    if strided:
+        h, w = (h + conv.stride[0] - 1) // conv.stride[0], (w + conv.stride[1] - 1) // conv.stride[1]
     lib, m, n = L.load(), b * h * w, conv.out_channels
     if lib.mrla_conv1x1_rows(m, k, n, L.BF16) >= 0:
         return True
@@ -1469,7 +1506,15 @@ def conv_bn_act(x, conv, bn, relu, defer=False, passthrough=False):
     uses x' as the block's shortcut (resnet_mrla_light.py:91,110-114) gets the shortcut gradient added inside the
     convolution's input-gradient GEMM instead of by a separate accumulation pass."""
     fused_bn = (type(bn) is torch.nn.BatchNorm2d and bn.affine and bn.track_running_stats)
-    if conv1x1_applies(conv, x):
+    # A strided 1x1 convolution is the stride-1 one on the subsampled input: one strided copy (a quarter of the pixels), then
+    # the same GEMMs -- forward with the BatchNorm statistics in its epilogue, input gradient, weight gradient.  Not for speed
+    # alone: MIOpen's input gradient of exactly these convolutions is right when launched eagerly and garbage from the second
+    # replay of a HIP graph on (every mode: immediate, find, deterministic; scripts/miopen_bwd_graph_probe.py,
+    # profiles/r05_notes.md section 2) -- with them on the GEMMs the whole step replays correctly.
+    strided = _strided_1x1(conv) and not passthrough and x.dim() == 4 and conv1x1_applies(conv, x, True)
+    if strided or conv1x1_applies(conv, x):
+        if strided:
+            x = _SubsampleFn.apply(x, conv.stride[0], conv.stride[1])
         wt, w16, w16t = conv.weight, None, None
         if wt.dtype != x.dtype:
             book = current_bookkeeping()

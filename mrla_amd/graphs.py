@@ -23,7 +23,9 @@ What the recipe takes care of (each item was a bug or a trap at some point of th
     same weights, optimizer state, BatchNorm buffers, inputs and generator state (`replay_matches_eager`).  A library kernel
     that misbehaves under replay -- MIOpen's split-K 3x3 weight gradient did at small batches, finite but wrong,
     profiles/r04_notes.md section 10 -- is caught here instead of training on garbage: `graphed_step` raises GraphReplayMismatch
-    (or, with `on_mismatch="eager"`, hands out the eagerly launched step).
+    (or, with `on_mismatch="eager"`, hands out the eagerly launched step) -- after one more attempt with
+    `torch.backends.cudnn.deterministic = True`, which makes MIOpen leave those solvers out (at batch 256 its solver search
+    picked one for resnet50_mrlal on one box of round 5: the headline's own shapes).
 The optimizer must be capturable (torch.optim.SGD in its foreach / fused forms is; Adam needs `capturable=True`).
 """
 import torch
@@ -35,10 +37,15 @@ class GraphReplayMismatch(MrlaHipError):
     pass
 
 
-def capture_step(step, warmup=3, distributed=False, pool=None):
+def capture_step(step, warmup=3, distributed=None, pool=None):
     """PyTorch's whole-network-capture recipe: `warmup` eager calls of `step()` on a side stream, then one captured call.
-    Returns the torch.cuda.CUDAGraph.  distributed: a collective is enqueued inside (RCCL's watchdog thread may query
-    events while this thread captures: thread-local capture-error mode)."""
+    Returns the torch.cuda.CUDAGraph.  distributed (default: is a torch.distributed process group initialised?): RCCL's
+    watchdog thread may query the events of earlier, eagerly launched collectives while this thread captures -- whether or not
+    a collective is enqueued inside; in the default (global) capture-error mode that query invalidates the capture
+    (hipErrorStreamCaptureUnsupported; seen with the two-graph tier), so such captures run in thread-local mode."""
+    if distributed is None:
+        import torch.distributed as dist
+        distributed = dist.is_available() and dist.is_initialized()
     torch.cuda.synchronize()
     side = torch.cuda.Stream()
     side.wait_stream(torch.cuda.current_stream())
@@ -207,7 +214,7 @@ class GraphedStep:
     """See graphed_step()."""
 
     def __init__(self, model, optimizer, loss_fn, example_inputs, autocast=torch.bfloat16, exchange=None, warmup=3,
-                 verify=2, tol=1e-2, on_mismatch="raise"):
+                 verify=2, tol=1e-2, on_mismatch="raise", deterministic_fallback=True):
         if not isinstance(example_inputs, (tuple, list)) or not example_inputs:
             raise MrlaHipError("example_inputs: a tuple (model input, *loss_fn arguments)")
         if not all(isinstance(t, torch.Tensor) and t.is_cuda for t in example_inputs):
@@ -218,22 +225,36 @@ class GraphedStep:
         self.loss = self.output = None           # of the latest step (static tensors while the graph is in use)
         self.graph = None
         self.report = None
-        dist_on = exchange is not None
-        self.graph = capture_step(self.eager, warmup=max(1, warmup), distributed=dist_on)
-        self._static = (self.loss, self.output)  # what the captured step wrote: every replay overwrites these two
-        if verify:
+        import torch.distributed as dist
+        dist_on = exchange is not None or (dist.is_available() and dist.is_initialized())
+        self.miopen_deterministic = bool(torch.backends.cudnn.deterministic)
+        for attempt in (0, 1):
+            self.graph = capture_step(self.eager, warmup=max(1, warmup), distributed=dist_on)
+            self._static = (self.loss, self.output)  # what the captured step wrote: every replay overwrites these two
+            if not verify:
+                break
             self.report = replay_matches_eager(self.eager, self.graph.replay, model, optimizer, steps=verify,
                                                replay_loss=self._static[0], tol=tol)
-            if not self.report["ok"]:
-                msg = ("the replayed HIP graph of the training step does not reproduce the eagerly launched step: "
-                       + ", ".join(f"{k} {self.report[k]:.3g}" for k in ("weights_rel_l2", "update_rel_l2", "noise_update_rel_l2"))
-                       + f", worst parameter {self.report['worst_parameter']}"
-                       + "".join(f", {k}: {self.report[k]}" for k in ("nonfinite", "counter_mismatch") if k in self.report))
-                if on_mismatch != "eager":
-                    raise GraphReplayMismatch(msg)
-                import warnings
-                warnings.warn(msg + "; launching the step eagerly instead")
+            if self.report["ok"]:
+                break
+            msg = ("the replayed HIP graph of the training step does not reproduce the eagerly launched step: "
+                   + ", ".join(f"{k} {self.report[k]:.3g}" for k in ("weights_rel_l2", "update_rel_l2", "noise_update_rel_l2"))
+                   + f", worst parameter {self.report['worst_parameter']}"
+                   + "".join(f", {k}: {self.report[k]}" for k in ("nonfinite", "counter_mismatch") if k in self.report))
+            import warnings
+            if attempt == 0 and deterministic_fallback and not torch.backends.cudnn.deterministic and exchange is None:
+                # MIOpen's atomically accumulating (split-K) weight-gradient solvers are right when launched eagerly and
+                # garbage from the second replay of a graph on; cudnn.deterministic leaves them out (resnet/train.py:107-110
+                # sets it with --seed).  One more attempt with it: warm-up (MIOpen searches again), capture, check.
+                warnings.warn(msg + "; trying once more with torch.backends.cudnn.deterministic = True")
+                torch.backends.cudnn.deterministic = self.miopen_deterministic = True
                 self.graph = None
+                continue
+            if on_mismatch != "eager":
+                raise GraphReplayMismatch(msg)
+            warnings.warn(msg + "; launching the step eagerly instead")
+            self.graph = None
+            break
 
     def eager(self):
         """One step on the static buffers, launched kernel by kernel (also what gets captured)."""
@@ -279,5 +300,7 @@ def graphed_step(model, optimizer, loss_fn, example_inputs, **kw):
     logits); `step.report` holds the replay-vs-eager comparison made before it was handed out.
     Keywords: autocast (dtype or None, default torch.bfloat16), exchange (a distributed.FlatGradientExchange for N > 1),
     warmup (eager steps before the capture, default 3), verify (steps of the replay-vs-eager check, 0 = skip, default 2),
-    tol (its bound on the weights' relative L2 difference), on_mismatch ("raise" | "eager")."""
+    tol (its bound on the weights' relative L2 difference), on_mismatch ("raise" | "eager"), deterministic_fallback (default
+    True: if the check fails, switch torch.backends.cudnn.deterministic on -- MIOpen then leaves out its atomically accumulating
+    solvers, the known cause -- and capture + check once more before giving up; `step.miopen_deterministic` says what is on)."""
     return GraphedStep(model, optimizer, loss_fn, example_inputs, **kw)

@@ -306,7 +306,8 @@ def test_weight_bank_refresh_and_fp32_weight_gradient():
     torch.manual_seed(3)
     convs = [torch.nn.Conv2d(k, n, 1, bias=False).cuda() for k, n in ((64, 256), (256, 64), (512, 2048), (1024, 256), (128, 128))]
     convs[1].to(memory_format=torch.channels_last)
-    odd = [torch.nn.Conv2d(64, 96, 1, bias=False).cuda(), torch.nn.Conv2d(64, 64, 1, stride=2, bias=False).cuda(),
+    convs.append(torch.nn.Conv2d(64, 64, 1, stride=2, bias=False).cuda())      # strided 1x1: the same GEMM on the subsampled input
+    odd = [torch.nn.Conv2d(64, 96, 1, bias=False).cuda(), torch.nn.Conv2d(64, 64, 1, padding=1, bias=False).cuda(),
            torch.nn.Conv2d(64, 64, 3, padding=1, bias=False).cuda()]
     bank = Fm.WeightBank(convs + odd).refresh()
     torch.cuda.synchronize()
@@ -486,3 +487,55 @@ def test_conv_bn_statistics_when_the_mean_dwarfs_sigma(shape, ratio):
     dy = (bn.weight.double() * inv) * (gu - dbeta / m - yhat * dgamma / m)
     dgot = yt.grad.permute(0, 2, 3, 1).reshape(m, n).double()
     assert ((dgot - dy).abs() <= 2.0 ** -7 * dy.abs() + 1e-3 * dy.abs().max()).all()
+
+
+@pytest.mark.parametrize("shape", [(4, 28, 28, 256, 512, 2), (3, 14, 14, 512, 1024, 2), (2, 15, 13, 128, 256, 2), (2, 14, 14, 1024, 2048, 2)],
+                         ids=lambda s: "x".join(map(str, s)))
+def test_strided_downsample_convolution_on_the_gemm_matches_stock_modules(shape):
+    """The downsample branch of a stage's first block (resnet_mrla_light.py:196-199: 1x1 convolution with stride 2 +
+    BatchNorm): conv_bn_act runs it as the stride-1 GEMM on the subsampled input (forward with the BatchNorm statistics in
+    its epilogue, input gradient scattered back into a zero-filled channels_last tensor, weight gradient) -- vs the stock
+    strided nn.Conv2d -> nn.BatchNorm2d in fp32 on the same bf16 operands: outputs, running statistics, every gradient,
+    and zeros exactly at the pixels the stride skips (odd map sizes included)."""
+    from mrla_amd import functional as Fm
+    b, h, w, k, n, st = shape
+    x, wt = _operands(b, h, w, k, n, salt=7)
+    conv = torch.nn.Conv2d(k, n, 1, stride=st, bias=False).cuda().to(memory_format=torch.channels_last)
+    bn = torch.nn.BatchNorm2d(n).cuda()
+    with torch.no_grad():
+        conv.weight.copy_(torch.from_numpy(wt).view(n, k, 1, 1))
+        bn.weight.copy_(torch.from_numpy(1 + 0.2 * detgen.uniform((n,), 5)))
+        bn.bias.copy_(torch.from_numpy(0.1 * detgen.uniform((n,), 6)))
+    xt = torch.from_numpy(x).cuda().bfloat16().permute(0, 3, 1, 2).requires_grad_(True)
+    used = []
+    orig = Fm._Conv1x1Fn.apply
+    try:
+        Fm._Conv1x1Fn.apply = staticmethod(lambda *a: (used.append(a[0].shape), orig(*a))[1])
+        out = Fm.conv_bn_act(xt, conv, bn, relu=False)
+    finally:
+        Fm._Conv1x1Fn.apply = orig
+    ho, wo = (h + st - 1) // st, (w + st - 1) // st
+    assert used == [torch.Size((b, k, ho, wo))], used                 # the GEMM path, on the subsampled input
+    assert out.shape == (b, n, ho, wo) and out.is_contiguous(memory_format=torch.channels_last)
+    gup = torch.from_numpy(bf16_round(detgen.normalish((b, n, ho, wo), 9))).cuda().bfloat16().contiguous(memory_format=torch.channels_last)
+    out.backward(gup)
+    conv_r = torch.nn.Conv2d(k, n, 1, stride=st, bias=False).cuda()
+    bn_r = torch.nn.BatchNorm2d(n).cuda()
+    conv_r.load_state_dict(conv.state_dict()); bn_r.load_state_dict(bn.state_dict())
+    bn_r.running_mean.zero_(); bn_r.running_var.fill_(1.0); bn_r.num_batches_tracked.zero_()
+    xr = xt.detach().float().requires_grad_(True)
+    zr = bn_r(conv_r(xr).bfloat16().float())
+    zr.backward(gup.float())
+    a, r = out.detach().float(), zr.detach()
+    bad = (a - r).abs() > 2.0 ** -7 * (r.abs() + 0.05 * r.abs().max())
+    assert bad.float().mean().item() < 1e-4
+    # (reductions over 256 - 1024 channels: the two products differ in the last bf16 bit of a few outputs)
+    assert torch.allclose(bn.running_mean, bn_r.running_mean, rtol=1e-3, atol=2e-5)
+    assert torch.allclose(bn.running_var, bn_r.running_var, rtol=1e-3, atol=1e-6)
+    assert xt.grad.is_contiguous(memory_format=torch.channels_last)
+    mask = torch.zeros(h, w, dtype=torch.bool, device="cuda")
+    mask[::st, ::st] = True
+    assert float(xt.grad[:, :, ~mask].abs().max()) == 0.0             # exact zeros where the stride skips
+    for got, want, tol in ((bn.weight.grad, bn_r.weight.grad, 2e-2), (bn.bias.grad, bn_r.bias.grad, 2e-2),
+                           (conv.weight.grad, conv_r.weight.grad, 3e-2), (xt.grad.float(), xr.grad, 3e-2)):
+        assert ((got.float() - want).norm() / want.norm()).item() < tol

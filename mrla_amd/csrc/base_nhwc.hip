@@ -554,8 +554,10 @@ int launch_base_value_bwd_nhwc(const void* dout, const void* x, const float* wv,
   const int nwaves = std::min(nstrips, kMaxStrips);
   const int BG = nhwc_images_per_group(B, C, W);
   const dim3 grid((C + kWave - 1) / kWave, (B + BG - 1) / BG), block(nwaves * kWave);
-  const bool wide = (C % kWave) == 0;
-  if (pre_tmom && (!pre || !wide || !(res & 2))) return MRLA_EUNSUPPORTED;
+  // C % 64 == 0 runs on the LDS-DMA row pipeline (launch_base_value_bwd_wide, capi.hip); only the other channel counts come
+  // here, and the deferred-BatchNorm sums (pre / pre_tmom) exist on that form only
+  if (C % kWave == 0 || pre_tmom) return MRLA_EUNSUPPORTED;
+  (void)pre;
   const size_t tb = dtype == MRLA_F32 ? scratch_bytes<float>() : scratch_bytes<bf16_t>();
   const size_t lds = (size_t)nwaves * 9 * kWave * sizeof(float) + (size_t)nwaves * 3 * tb;
 #define CALL_W(TT, WD, PR)                                                                                          \
@@ -564,7 +566,7 @@ int launch_base_value_bwd_nhwc(const void* dout, const void* x, const float* wv,
     hipLaunchKernelGGL((base_value_bwd_nhwc<TT, WD, PR>), grid, block, lds, st, (const TT*)dout, (const TT*)x, wv,     \
                        (const TT*)dv, dyx, (TT*)dx, dwv_part, (const TT*)pre, pre_center, pre_tmom, B, C, H, W, BG, res); \
   }
-#define CALL(TT) { if (pre_tmom) CALL_W(TT, true, true) else if (wide) CALL_W(TT, true, false) else CALL_W(TT, false, false) }
+#define CALL(TT) CALL_W(TT, false, false)
   MRLA_DISPATCH_B(dtype, CALL)
 #undef CALL
 #undef CALL_W

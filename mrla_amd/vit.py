@@ -32,8 +32,7 @@ class _LinearFn(torch.autograd.Function):
     BIAS gradients from the second replay on (weights' gradients of the same layers finite; eager launches always right) --
     with bf16 autocast, stochastic depth on and self-attention in the block; none of this package's kernels involved (the
     same blocks without the MRLA module show it; scripts/deit_replay_debug*.py, profiles/r05_notes.md).  Taking the bias
-    gradient through a matrix product (fp32 accumulation, rounded once to the activation dtype -- what the reduction does)
-    removes it; everything else is the stock linear: forward with the fused bias epilogue, dX = dY W, dW = dY^T X."""
+    gradient through matrix products (ones^T dY per image, then over the images; fp32 accumulation inside each) removes it; everything else is the stock linear: forward with the fused bias epilogue, dX = dY W, dW = dY^T X."""
 
     @staticmethod
     def forward(ctx, x, w, b):
@@ -49,7 +48,13 @@ class _LinearFn(torch.autograd.Function):
         dw = dy2.t() @ x2 if ctx.needs_input_grad[1] else None
         db = None
         if ctx.has_bias and ctx.needs_input_grad[2]:
-            db = (dy2.new_ones((1, dy2.shape[0])) @ dy2).view(-1)
+            if dy.dim() == 3 and dy.is_contiguous():
+                # per image first ([b, 1, n] x [b, n, N] -> b x N partial sums: b independent products fill the chip; ONE
+                # product over all b*n rows is a 50 000-long reduction in N/64 workgroups: +2 ms per deit_mrlal_tiny step)
+                part = torch.bmm(dy.new_ones((dy.shape[0], 1, dy.shape[1])), dy).view(dy.shape[0], -1)
+                db = (part.new_ones((1, part.shape[0])) @ part).view(-1)
+            else:
+                db = (dy2.new_ones((1, dy2.shape[0])) @ dy2).view(-1)
         return dx, dw, db
 
 

@@ -2,6 +2,7 @@
 # In-step A/B of the workgroup count of nhwc_affine_flat (BatchNorm(+ReLU) apply, forward and backward): the product (about
 # 4096 workgroups walking `iters` 4 KB chunks each) against variants with more, shorter workgroups (working-tree switch
 # -DMRLA_AFFINE_WGS=<n>, scripts/build_variant.sh).  RECORD of what was run (profiles/r04_notes.md section 9).
+cp mrla_amd/libmrla_hip.so /tmp/product_libmrla_hip.so && trap 'cp /tmp/product_libmrla_hip.so mrla_amd/libmrla_hip.so' EXIT   # 
 set -u
 mkdir -p gpurun_out/aff
 python3 scripts/bnbench.py 30 2>/dev/null | tail -14 | sed "s/^/product /" > gpurun_out/aff/bnbench.txt

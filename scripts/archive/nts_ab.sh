@@ -1,3 +1,4 @@
+cp mrla_amd/libmrla_hip.so /tmp/product_libmrla_hip.so && trap 'cp /tmp/product_libmrla_hip.so mrla_amd/libmrla_hip.so' EXIT   # 
 set -u
 mkdir -p gpurun_out/nts
 cp mrla_amd/libmrla_hip.so /tmp/product.so

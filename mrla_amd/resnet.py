@@ -126,6 +126,57 @@ class MRLA_Bottleneck(_BottleneckTrunk):
         return layers.light_block_tail(pre, identity, self.mrla, self.bn_mrla, self.drop_path, pre_activation=True)
 
 
+class MRLA_BasicBlock(nn.Module):
+    """BUILD-SIDE EXTENSION -- the reference defines no BasicBlock network (BASELINE.json's
+    config 1 names a `resnet18_mrlal` that does not exist upstream; `grep resnet18` is empty, the factories are
+    resnet_mrla_light.py:242-250).  torchvision's BasicBlock (two 3x3 convolutions, expansion 1) with the reference's own
+    light `mrla_module(planes)` tail: out <- relu(bn2(conv2(.)) + identity); out <- out + DropPath(bn_mrla(mrla(out,
+    identity))) -- resnet_mrla_light.py:113-116 word for word, c = 64 / 128 / 256 / 512 (k = 3 / 5 / 5 / 5, 2 / 4 / 8 / 16
+    heads of 32 channels).  Parity is pinned at MODULE level (rows a1 - a3 at those channel counts, tests/test_light_gpu.py)
+    and, for the whole network, against the eager restatement of the same definition (oracle/eager_models.py); there is no
+    reference output to compare with, and the tests say so."""
+    expansion = 1
+
+    def __init__(self, inplanes, planes, stride=1, downsample=None, SE=False, ECA_size=None, groups=1, base_width=64,
+                 dilation=1, norm_layer=nn.BatchNorm2d, drop_path=0.0):
+        super().__init__()
+        norm_layer = norm_layer or nn.BatchNorm2d
+        if groups != 1 or base_width != 64:
+            raise ValueError("BasicBlock only supports groups=1 and base_width=64")
+        if dilation > 1:
+            raise NotImplementedError("Dilation > 1 not supported in BasicBlock")
+        self.conv1 = _conv3x3(inplanes, planes, stride)
+        self.bn1 = norm_layer(planes)
+        self.relu = nn.ReLU(inplace=True)
+        self.conv2 = _conv3x3(planes, planes)
+        self.bn2 = norm_layer(planes)
+        self.downsample = downsample
+        self.stride = stride
+        self.se = se_layer(planes, reduction=16) if SE else None
+        self.eca = eca_layer(planes, int(ECA_size)) if ECA_size is not None else None
+        self.mrla = layers.mrla_module(input_dim=planes)
+        self.bn_mrla = norm_layer(planes)
+        self.drop_path = layers.DropPath(drop_path) if drop_path > 0.0 else nn.Identity()
+
+    def forward(self, x):
+        identity = x
+        out = F_.bn_act(self.conv1(x), self.bn1, relu=True)
+        # bn2's affine, the shortcut add and the ReLU all run inside the first MRLA pass (as bn3's do in the bottleneck)
+        defer = layers.light_tail_is_fused(self.bn_mrla) and self.se is None and self.eca is None
+        out = F_.bn_act(self.conv2(out), self.bn2, relu=False, defer=defer)
+        if self.se is not None:
+            out = self.se(out)
+        if self.eca is not None:
+            out = self.eca(out)
+        if self.downsample is not None:
+            ds = self.downsample
+            if isinstance(ds, nn.Sequential) and len(ds) == 2 and isinstance(ds[0], nn.Conv2d):
+                identity = F_.conv_bn_act(x, ds[0], ds[1], relu=False)
+            else:
+                identity = ds(x)
+        return layers.light_block_tail(out, identity, self.mrla, self.bn_mrla, self.drop_path, pre_activation=True)
+
+
 class MRLA_Bottleneck_base(_BottleneckTrunk):
     """Bottleneck + MRLA-base tail (resnet_mrla_base.py:55-131; `MRLA_Bottleneck` there)."""
 
@@ -194,6 +245,8 @@ class _ResNetMRLA(nn.Module):
             for m in self.modules():
                 if isinstance(m, _BottleneckTrunk):
                     nn.init.constant_(m.bn3.weight, 0)
+                elif isinstance(m, MRLA_BasicBlock):
+                    nn.init.constant_(m.bn2.weight, 0)
 
     def _weight_bank(self):
         """The refreshed WeightBank of this network's 1x1 convolutions (one cast launch per step instead of one per
@@ -204,6 +257,7 @@ class _ResNetMRLA(nn.Module):
             for m in self.modules():
                 if isinstance(m, _BottleneckTrunk):
                     convs += [m.conv1, m.conv3]
+                if isinstance(m, (_BottleneckTrunk, MRLA_BasicBlock)):
                     if isinstance(m.downsample, nn.Sequential) and len(m.downsample) == 2:
                         convs.append(m.downsample[0])
             bank = self.__dict__["_bank"] = F_.WeightBank(convs)
@@ -217,7 +271,7 @@ class _ResNetMRLA(nn.Module):
             return 0
         n = self.__dict__.get("_n_trunks")
         if n is None:                      # (the block list is fixed after construction; counted once)
-            n = sum(1 for m in self.modules() if isinstance(m, _BottleneckTrunk))
+            n = sum(1 for m in self.modules() if isinstance(m, (_BottleneckTrunk, MRLA_BasicBlock)))
             self.__dict__["_n_trunks"] = n
         return n
 
@@ -328,6 +382,18 @@ def resnet50_mrlab(**kwargs):
 def resnet101_mrlab(**kwargs):
     print("Constructing resnet101_mrla-base......")
     return ResNet_mrlab(MRLA_Bottleneck_base, [3, 4, 23, 3], **kwargs)
+
+
+def resnet18_mrlal(**kwargs):
+    """Build-side extension (see MRLA_BasicBlock): BASELINE.json's config 1 by its literal name."""
+    print("Constructing resnet18_mrla-light (build-side BasicBlock extension)......")
+    return ResNet_mrlal(MRLA_BasicBlock, [2, 2, 2, 2], **kwargs)
+
+
+def resnet34_mrlal(**kwargs):
+    """Build-side extension (see MRLA_BasicBlock)."""
+    print("Constructing resnet34_mrla-light (build-side BasicBlock extension)......")
+    return ResNet_mrlal(MRLA_BasicBlock, [3, 4, 6, 3], **kwargs)
 
 
 def resnet50_mrlal(**kwargs):

@@ -167,6 +167,32 @@ class EagerLightBottleneck(nn.Module):
         return xt + stochastic_depth(z, self.p_drop, self.training, self.dp_mask)
 
 
+class EagerLightBasicBlock(nn.Module):
+    """Build-side extension (mrla_amd.resnet.MRLA_BasicBlock): torchvision's BasicBlock + the light tail of
+    resnet_mrla_light.py:113-116.  There is no reference counterpart; this is the restatement the product is compared with."""
+    expansion = 1
+
+    def __init__(self, inplanes, planes, stride=1, downsample=None, groups=1, base_width=64, dilation=1,
+                 norm_layer=nn.BatchNorm2d, drop_path=0.0):
+        super().__init__()
+        self.conv1 = nn.Conv2d(inplanes, planes, 3, stride, 1, bias=False)
+        self.bn1 = norm_layer(planes)
+        self.conv2 = nn.Conv2d(planes, planes, 3, 1, 1, bias=False)
+        self.bn2 = norm_layer(planes)
+        self.downsample = downsample
+        self.mrla = EagerLightModule(planes)
+        self.bn_mrla = norm_layer(planes)
+        self.p_drop = drop_path
+        self.dp_mask = None
+
+    def forward(self, x):
+        identity = x if self.downsample is None else self.downsample(x)
+        out = self.bn2(self.conv2(F.relu(self.bn1(self.conv1(x)))))
+        xt = F.relu(out + identity)
+        z = self.bn_mrla(self.mrla(xt, identity))
+        return xt + stochastic_depth(z, self.p_drop, self.training, self.dp_mask)
+
+
 class EagerBaseBottleneck(nn.Module):
     """resnet_mrla_base.py:55-131."""
     expansion = 4
@@ -204,21 +230,21 @@ class _EagerResNet(nn.Module):
         if dilate:
             self.dilation *= stride
             stride = 1
-        down = None
-        if stride != 1 or self.inplanes != planes * 4:
-            down = nn.Sequential(nn.Conv2d(self.inplanes, planes * 4, 1, stride, bias=False),
-                                 self._norm(planes * 4))
+        down, ex = None, getattr(block, "expansion", 4)
+        if stride != 1 or self.inplanes != planes * ex:
+            down = nn.Sequential(nn.Conv2d(self.inplanes, planes * ex, 1, stride, bias=False),
+                                 self._norm(planes * ex))
         common = dict(groups=self.groups, base_width=self.base_width, norm_layer=self._norm,
                       drop_path=self.drop_path)
         blocks = [block(self.inplanes, planes, stride, down, dilation=prev_dil, **common, **extra_first)]
-        self.inplanes = planes * 4
+        self.inplanes = planes * ex
         rest = {k: (False if k == "init_cell" else v) for k, v in extra_first.items()}
         blocks += [block(self.inplanes, planes, dilation=self.dilation, **common, **rest) for _ in range(1, n)]
         return blocks
 
     def _finish_init(self, zero_init_last_bn):
         self.avgpool = nn.AdaptiveAvgPool2d(1)
-        self.fc = nn.Linear(2048, self.num_classes)
+        self.fc = nn.Linear(self.inplanes, self.num_classes)
         for m in self.modules():
             if isinstance(m, nn.Conv2d):
                 nn.init.kaiming_normal_(m.weight, mode="fan_out", nonlinearity="relu")
@@ -229,6 +255,8 @@ class _EagerResNet(nn.Module):
             for m in self.modules():
                 if isinstance(m, (EagerLightBottleneck, EagerBaseBottleneck)):
                     nn.init.zeros_(m.bn3.weight)
+                elif isinstance(m, EagerLightBasicBlock):
+                    nn.init.zeros_(m.bn2.weight)
 
     def forward(self, x):
         x = torch.flatten(self.avgpool(self.forward_features(x)), 1)
@@ -242,7 +270,7 @@ class EagerResNetLight(_EagerResNet):
 
     def __init__(self, layers, num_classes=1000, SE=False, ECA=None, zero_init_last_bn=True, groups=1,
                  width_per_group=64, replace_stride_with_dilation=None, norm_layer=nn.BatchNorm2d,
-                 drop_rate=0.0, drop_path=0.0):
+                 drop_rate=0.0, drop_path=0.0, block=None):
         super().__init__()
         assert not SE and ECA is None, "SE/ECA are out of scope for the oracle"
         self._init_common(num_classes, zero_init_last_bn, groups, width_per_group,
@@ -250,7 +278,7 @@ class EagerResNetLight(_EagerResNet):
         self.conv1 = nn.Conv2d(3, 64, 7, 2, 3, bias=False)
         self.bn1 = self._norm(64)
         self.maxpool = nn.MaxPool2d(3, 2, 1)
-        B = EagerLightBottleneck
+        B = block or EagerLightBottleneck
         self.layer1 = nn.Sequential(*self._stage(B, 64, layers[0]))
         self.layer2 = nn.Sequential(*self._stage(B, 128, layers[1], 2, self._rswd[0]))
         self.layer3 = nn.Sequential(*self._stage(B, 256, layers[2], 2, self._rswd[1]))
@@ -332,6 +360,11 @@ class EagerDetBackbone(EagerResNetLight):
                 if isinstance(m, nn.modules.batchnorm._BatchNorm):
                     m.eval()
         return self
+
+
+def eager_resnet18_mrlal(**kw):
+    """Build-side extension (no reference counterpart): see EagerLightBasicBlock."""
+    return EagerResNetLight([2, 2, 2, 2], block=EagerLightBasicBlock, **kw)
 
 
 def eager_resnet50_mrlal(**kw):

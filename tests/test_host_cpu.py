@@ -81,6 +81,33 @@ def test_model_surface_matches_reference_names():
         mrla_light_layer(64)
 
 
+def test_resnet18_mrlal_is_a_labelled_build_side_extension():
+    """BASELINE.json's config 1: "resnet18_mrlal forward on 8x3x224x224 random tensors, CPU reference path (plumbing, no GPU)".
+    The reference defines no such network; the build's extension (torchvision BasicBlock + the
+    reference's light tail) exists under that name, mirrors its eager restatement key for key, and the CPU plumbing runs: the
+    eager restatement forwards config 1's input on the host.  (The reference-pinned CPU case stays resnet50_mrlal:
+    tests/test_eager_models_golden.py.)"""
+    import contextlib
+    import io
+    from mrla_amd import models, resnet
+    from oracle import eager_models as em
+    assert "resnet18_mrlal" in models.__all__ and "extension" in (resnet.MRLA_BasicBlock.__doc__ or "").lower()
+    with contextlib.redirect_stdout(io.StringIO()):
+        net = models.resnet18_mrlal(drop_path=0.1)
+    ref = em.eager_resnet18_mrlal()
+    assert {k: tuple(v.shape) for k, v in net.state_dict().items()} == {k: tuple(v.shape) for k, v in ref.state_dict().items()}
+    assert [len(getattr(net, f"layer{i}")) for i in (1, 2, 3, 4)] == [2, 2, 2, 2]
+    assert tuple(net.layer1[0].mrla.lambda_t.shape) == (64, 1, 1) and net.layer1[0].mrla.mrla.heads == 2
+    assert tuple(net.layer1[0].mrla.mrla.Wq.weight.shape) == (1, 1, 3) and tuple(net.layer4[1].mrla.mrla.Wq.weight.shape) == (1, 1, 5)
+    assert float(net.layer3[1].bn2.weight.abs().max()) == 0.0                      # zero_init_last_bn reaches the BasicBlock's bn2
+    ref.eval()
+    with torch.no_grad():
+        y = ref(torch.randn(8, 3, 224, 224, generator=torch.Generator().manual_seed(0)))
+    assert y.shape == (8, 1000) and torch.isfinite(y).all()
+    with pytest.raises(ValueError):
+        resnet.MRLA_BasicBlock(64, 64, groups=2)
+
+
 def test_product_has_no_cpu_fallback():
     from mrla_amd import _lib, models
     net = models.resnet50_mrlal()
@@ -188,7 +215,8 @@ def test_top_level_models_package_serves_train_py_unedited():
 
     import models
     names = sorted(n for n in models.__dict__ if n.islower() and not n.startswith("__") and callable(models.__dict__[n]))
-    assert names == ["resnet101_mrlab", "resnet101_mrlal", "resnet50_mrlab", "resnet50_mrlal"]
+    # the reference's four + the two build-side BasicBlock extensions (resnet18 / 34: SURVEY.md section 8(a)-note)
+    assert names == ["resnet101_mrlab", "resnet101_mrlal", "resnet18_mrlal", "resnet34_mrlal", "resnet50_mrlab", "resnet50_mrlal"]
     with redirect_stdout(io.StringIO()):
         net = models.__dict__["resnet50_mrlal"](drop_rate=0.0, drop_path=0.2)
     from mrla_amd.resnet import ResNet_mrlal

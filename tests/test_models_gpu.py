@@ -276,3 +276,57 @@ def test_per_forward_bookkeeping_is_batched_but_equivalent():
     bn = torch.nn.BatchNorm2d(64).cuda()
     Fm.bn_act(torch.randn(2, 64, 8, 8, device="cuda"), bn, relu=True)
     assert int(bn.num_batches_tracked) == 1
+
+
+def test_resnet18_mrlal_extension_matches_its_eager_restatement():
+    """BASELINE.json's config 1 by its literal name.  `resnet18_mrlal` is a BUILD-SIDE EXTENSION (the reference defines no
+    BasicBlock network: SURVEY.md section 8(a)-note) -- torchvision's BasicBlock + the reference's light tail -- so there is
+    no reference output to compare with: the product is compared with the eager restatement of the same definition
+    (oracle/eager_models.py::EagerLightBasicBlock) on the same deterministic weights -- eval logits at 8 x 3 x 224 x 224
+    (config 1's input), a train step with every gradient, NCHW against channels_last, bf16 autocast -- and the MRLA operators
+    at its channel counts (64 / 128 / 256 / 512) are pinned against the oracle and the reference at module level
+    (tests/test_light_gpu.py)."""
+    from mrla_amd import models
+    torch.backends.cudnn.allow_tf32 = False
+    net, ref = models.resnet18_mrlal().cuda(), em.eager_resnet18_mrlal().cuda()
+    load_det(net)
+    ref.load_state_dict(net.state_dict())
+    net.eval(); ref.eval()
+    x = torch.from_numpy(cases.image_batch(8)).cuda()
+    with torch.no_grad():
+        y, yr = net(x), ref(x)
+    assert rel(y.cpu().numpy(), yr.cpu().numpy()) < 5e-6
+    net.train(); ref.train()
+    xt = torch.from_numpy(cases.image_batch(4, "img-train")).cuda()
+    tgt = (torch.arange(4) * 37 % 1000).cuda()
+    y, yr = net(xt), ref(xt)
+    assert rel(y.detach().cpu().numpy(), yr.detach().cpu().numpy()) < 2e-5
+    torch.nn.functional.cross_entropy(y, tgt).backward()
+    torch.nn.functional.cross_entropy(yr, tgt).backward()
+    gp, gr = dict(net.named_parameters()), dict(ref.named_parameters())
+    tight, dots = (0.0, ""), np.zeros(3)
+    for k in gp:
+        a, b = gp[k].grad.cpu().numpy().ravel().astype(np.float64), gr[k].grad.cpu().numpy().ravel().astype(np.float64)
+        if np.abs(b).sum() < 1e-4:
+            continue
+        if k.endswith(("mrla.mrla.Wv.weight", "mrla.lambda_t", "bn_mrla.weight", "bn_mrla.bias", "bn2.weight", "bn2.bias")):
+            tight = max(tight, (np.abs(a - b).sum() / np.abs(b).sum(), k))
+        dots += np.array([a @ b, a @ a, b @ b])
+    assert tight[0] < 2e-2, tight                          # where the deferred bn2 affine and the fused producer are wired
+    assert dots[0] / np.sqrt(dots[1] * dots[2]) > 0.9999
+    for k in ("layer1.0.bn_mrla.running_mean", "layer4.1.bn_mrla.running_var", "layer2.0.bn2.running_var"):
+        assert rel(net.state_dict()[k].float().cpu().numpy(), ref.state_dict()[k].float().cpu().numpy()) < 1e-5, k
+    # the NCHW kernels (the reference's layout contract) against the channels_last ones, and bf16 autocast
+    b = models.resnet18_mrlal().cuda()
+    b.load_state_dict(net.state_dict())
+    b.channels_last = False
+    b.to(memory_format=torch.contiguous_format)
+    b.train()
+    net.zero_grad(set_to_none=True)
+    ya, yb = net(xt), b(xt)
+    assert rel(ya.detach().cpu().numpy(), yb.detach().cpu().numpy()) < 2e-5
+    with torch.autocast("cuda", dtype=torch.bfloat16):
+        y16 = net(xt)
+    torch.nn.functional.cross_entropy(y16.float(), tgt).backward()
+    assert torch.isfinite(y16).all() and all(torch.isfinite(p.grad).all() for p in net.parameters())
+    assert rel(y16.detach().float().cpu().numpy(), ya.detach().cpu().numpy()) < 0.1

@@ -18,6 +18,15 @@
 #ifndef MRLA_STREAM_MB
 #define MRLA_STREAM_MB 128
 #endif
+// Channel groups side by side in apply_bwd's workgroups on 28-wide maps (4 strips, >= 8 channel groups).  4 (round 4): two
+// strips at a time, the other two walked afterwards -- the halo columns between strips 1 and 2 are then fetched twice, far
+// apart in time: PMC 1 357 MB per launch at 512 x 28^2, b = 256 = 1.10 x its 6N (the 56-wide stage, whose eight strips run
+// side by side: 1.015 x; 14-wide: 1.05 x; 7-wide: 1.00 x).  2 (round 5): all four strips side by side: 1 261 MB = 1.02 x, at
+// the same 275 - 282 us per launch (profiles/r05_notes.md section 9).  The lighter passes keep 4 (their row pieces overlap
+// by two columns, not four, and they gained 9 - 16 % from the wider contiguous request).
+#ifndef MRLA_APPLY_BWD_WC_4STRIPS
+#define MRLA_APPLY_BWD_WC_4STRIPS 2
+#endif
 // Occupancy of the fused forward statistics pass (round 4, profiles/r04_notes.md section 5): at 150 - 162 VGPRs three waves
 // fit a SIMD, i.e. ONE eight-wave workgroup per CU on the 56-wide stage -- half the waves apply_fwd keeps in flight on the
 // same 3N bytes (SQ counters side by side: 37 % of its wave cycles wait against apply_fwd's 71 %: too few waves, 2.4 x the
@@ -917,7 +926,7 @@ static void wide_shape(WidePass pass, int C, int W, int* wc_out, int* ws_out) {
       waves = 4;
       wc = nstrips >= 4 ? 1 : nstrips >= 2 ? 2 : 4;
       break;
-    case P_APPLY_BWD: wc = ncg >= 8 ? 4 : 1; break;
+    case P_APPLY_BWD: wc = ncg >= 8 ? (nstrips == 4 ? MRLA_APPLY_BWD_WC_4STRIPS : 4) : 1; break;
     default:          wc = ncg >= 8 ? 4 : 2; break;
   }
   wc = std::max(1, std::min(wc, waves));

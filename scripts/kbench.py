@@ -1,5 +1,5 @@
 """GPU micro-benchmark of the MRLA streaming kernels through the C ABI, per ResNet-50 stage shape (b=256, bf16).
-Usage: [KBENCH_LIB=scripts/variants/libmrla_hip_<name>.so] [LAYOUT=nhwc] python scripts/kbench.py [reps] [kernel-substring]"""
+Usage: [KBENCH_LIB=scripts/variants/libmrla_hip_<name>.so] [LAYOUT=nhwc] [STAGE=0..3] python scripts/kbench.py [reps] [kernel-substring]"""
 import ctypes
 import os
 import sys
@@ -19,6 +19,8 @@ RELU = int(os.environ.get("RELU", 1))
 LAY = L.NHWC if os.environ.get("LAYOUT", "nchw") == "nhwc" else L.NCHW
 FMT = torch.channels_last if LAY == L.NHWC else torch.contiguous_format
 STAGES = [(256, 56), (512, 28), (1024, 14), (2048, 7)]
+if os.environ.get("STAGE"):               # one stage only (counter passes: the summaries average over equal grid sizes)
+    STAGES = [STAGES[int(os.environ["STAGE"])]]
 dt = torch.bfloat16
 lib = L.load()
 P = lambda t: ctypes.c_void_p(t.data_ptr()) if t is not None else None  # noqa: E731

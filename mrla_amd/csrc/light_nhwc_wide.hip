@@ -20,9 +20,9 @@
 #endif
 // Channel groups side by side in apply_bwd's workgroups on 28-wide maps (4 strips, >= 8 channel groups).  4 (round 4): two
 // strips at a time, the other two walked afterwards -- the halo columns between strips 1 and 2 are then fetched twice, far
-// apart in time: PMC 1 357 MB per launch at 512 x 28^2, b = 256 = 1.10 x its 6N (the 56-wide stage, whose eight strips run
-// side by side: 1.015 x; 14-wide: 1.05 x; 7-wide: 1.00 x).  2 (round 5): all four strips side by side: 1 261 MB = 1.02 x, at
-// the same 275 - 282 us per launch (profiles/r05_notes.md section 9).  The lighter passes keep 4 (their row pieces overlap
+// apart in time: PMC 1 390 MB per launch at 512 x 28^2, b = 256 = 1.13 x its 6N (the 56-wide stage, whose eight strips run
+// side by side: 1.04 x; 14-wide: 1.07 x; 7-wide: 1.03 x).  2 (round 5): all four strips side by side: 1 291 MB = 1.05 x, at
+// the same 275 - 282 us per launch (profiles/r05_notes.md section 9, profiles/r05_sq_counters_row_pipeline.md).  The lighter passes keep 4 (their row pieces overlap
 // by two columns, not four, and they gained 9 - 16 % from the wider contiguous request).
 #ifndef MRLA_APPLY_BWD_WC_4STRIPS
 #define MRLA_APPLY_BWD_WC_4STRIPS 2

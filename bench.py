@@ -8,7 +8,14 @@ ImageNet-shaped data (BASELINE.json metric / configs[1]; configs[2] for --gpus N
 
 A "step" = forward + loss + backward + SGD update on one synthetic batch already resident in HBM.  On a single GPU the
 timed steps replay the whole step from one HIP graph (`config.launch`; `--graph 0` times PyTorch's kernel-by-kernel
-launches instead).  `config.weights_finite`: the weights are still numbers after the timed and the event-timed regions.
+launches instead) -- AFTER the graph has proven itself: `config.replay_matches_eager` / `config.replay_check` = three
+consecutive replays, each against an eagerly launched step from the same weights, momentum, BatchNorm buffers, inputs and
+generator state (mrla_amd.graphs.replay_matches_eager; the eager step twice for the run-to-run noise floor).  A graph that
+does not reproduce the eager step is never timed as `value`: one more attempt with torch.backends.cudnn.deterministic
+(`--deterministic -1`, `config.miopen`), else the eager launches are timed and `config.launch` says so.
+`eager_launch_images_per_sec` / `eager_launch_ms_per_step`: the same steps launched eagerly, i.e. what resnet/train.py gets
+UNCHANGED (:387-409); `eager_launch_with_kernel_events_ms_per_step`: once more with a HIP-event pair around every kernel (the
+region `roofline` / `mrla_kernels` come from).  `config.weights_finite`: the weights are still numbers at the end.
 
 N > 1 (resnet/train.py:127-133 spawns its own workers with mp.spawn; :153 init_process_group; :174 DDP).  Launched
 plainly with `--gpus N`, this file starts `python -m torch.distributed.run ... bench.py <same arguments>` as a CHILD
@@ -25,7 +32,10 @@ ends without its number: BEFORE any collective goes into a capture, `steps` eage
 contract says; if capturing the full step then fails on any rank (the ranks vote through the process group's TCP store,
 not through the collective library), rank 0 prints the line from that eager region (`config.launch` says so) and every
 rank leaves without touching the communicator again -- its state is unknown after a failed capture, and limping on with
-it is a hang on N ranks, not a fallback.  (Ranks that die instead: the self-launching parent starts ONE fresh set with
+it is a hang on N ranks, not a fallback.  If the capture of the OPTIONAL second schedule fails, the line is the first
+schedule's finished graph-replayed region (built before the second was tried: measure_exchange_schedules).  MIOpen's solver
+search runs on rank 0 alone first (`config.miopen_find_rank0_first_s`); `config.rank_ms_per_step`: the fastest / slowest
+rank's own step time.  (Ranks that die instead: the self-launching parent starts ONE fresh set with
 `--graph 0`.)  `--dp ddp` runs torch's DistributedDataParallel, launched kernel by kernel.  Rank 0 prints ONE JSON line.
 Besides the contract keys it carries
   roofline      -- HBM roofline of the dominant MRLA kernel (mrla_light_apply_bwd), timed live with HIP events on the
@@ -37,7 +47,9 @@ Besides the contract keys it carries
                    bn3's backward sums are folded into this pass, which deleted a 2*N*s pass of its own).  `path_frac`:
                    section 8(d)'s compulsory bytes of the whole MRLA path per step (3N forward + 5N backward per block)
                    over the time of ALL kernels of the path (two passes per direction + the [b,c]-sized kernels).
-                   `traffic`: HBM bytes per launch from THIS round's committed PMC passes (`traffic_source`), else null;
+                   `traffic`: HBM bytes per launch from THIS round's committed PMC passes (`traffic_source`), quoted only if
+                   those passes were taken on the library loaded now (`traffic_tied_by`: its sha256, or that of its sources;
+                   scripts/lib_identity.py), else null with `traffic_stale`: true;
   cpu_baseline  -- the eager CPU restatement (oracle/eager_models.py, kind "port") forward on the host cores, the best of a
                    thread-count sweep, bounded sample, rank 0 at N=1 only;
   eager_rocm    -- the same restatement run eager on this GPU (the north-star's ">=4x" denominator), N=1 only;

@@ -11,8 +11,8 @@ timed steps replay the whole step from one HIP graph (`config.launch`; `--graph 
 launches instead) -- AFTER the graph has proven itself: `config.replay_matches_eager` / `config.replay_check` = three
 consecutive replays, each against an eagerly launched step from the same weights, momentum, BatchNorm buffers, inputs and
 generator state (mrla_amd.graphs.replay_matches_eager; the eager step twice for the run-to-run noise floor).  A graph that
-does not reproduce the eager step is never timed as `value`: one more attempt with torch.backends.cudnn.deterministic
-(`--deterministic -1`, `config.miopen`), else the eager launches are timed and `config.launch` says so.
+does not reproduce the eager step is never timed as `value`: the eager launches are timed instead and `config.launch` says
+so (`--deterministic -1`: one more capture + check with torch.backends.cudnn.deterministic first; `config.miopen`).
 `eager_launch_images_per_sec` / `eager_launch_ms_per_step`: the same steps launched eagerly, i.e. what resnet/train.py gets
 UNCHANGED (:387-409); `eager_launch_with_kernel_events_ms_per_step`: once more with a HIP-event pair around every kernel (the
 region `roofline` / `mrla_kernels` come from).  `config.weights_finite`: the weights are still numbers at the end.
@@ -98,11 +98,13 @@ def parse():
     ap.add_argument("--benchmark", type=int, default=1,
                     help="torch.backends.cudnn.benchmark for the timed model: 1 as resnet/train.py:247 sets it (MIOpen picks its "
                          "solvers by measuring them during the warm-up steps), 0 for MIOpen's immediate-mode choice")
-    ap.add_argument("--deterministic", type=int, default=-1,
+    ap.add_argument("--deterministic", type=int, default=0,
                     help="torch.backends.cudnn.deterministic for the timed model (resnet/train.py:107-110 sets it with --seed): MIOpen "
-                         "then leaves out its atomically accumulating (split-K) solvers.  1 / 0: on / off; -1 (default): off, and "
-                         "switched ON for one more attempt if the replayed HIP graph does not reproduce the eager step -- such a "
-                         "solver is right when launched eagerly and garbage from the second replay of a graph on")
+                         "then leaves out its atomically accumulating (split-K) solvers -- the ones that are right when launched "
+                         "eagerly and garbage from the second replay of a graph on.  1 / 0 (default): on / off; -1: off, and switched "
+                         "ON for one more capture + check if the replayed graph does not reproduce the eager step (abandoned again if "
+                         "the eager step then runs > 1.5 x slower).  Not the default: MIOpen's deterministic solver list runs "
+                         "resnet50_mrlal b = 256 at 7.3 s per step on MI355X (bit-reproducible, 240 x slower; profiles/r05_notes.md)")
     ap.add_argument("--graph", type=int, default=-1,
                     help="1: the timed steps replay the whole step (fwd+bwd+SGD) from one HIP graph; 0: launched kernel by "
                          "kernel; -1 (default): 1, except with --dp ddp or a non-RCCL backend")
@@ -758,16 +760,40 @@ def main():
         searches again among the others) and tell the caller to capture and check once more.  Returns True when it did."""
         if args.deterministic != -1 or torch.backends.cudnn.deterministic:
             return False
+
+        def ms_per_step(n=2):
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(n):
+                st()
+            torch.cuda.synchronize()
+            return 1e3 * (time.perf_counter() - t0) / n
+        before = ms_per_step()
         torch.backends.cudnn.deterministic = True
-        R["miopen_deterministic_why"] = ("switched on after the first captured graph did not reproduce the eager step "
-                                         f"(update_rel_l2 {(first_check or {}).get('update_rel_l2')}, noise "
-                                         f"{(first_check or {}).get('noise_update_rel_l2')}, worst parameter "
-                                         f"{(first_check or {}).get('worst_parameter')})")
-        R["replay_first_attempt"] = first_check
         if rank == 0:
             print("note: torch.backends.cudnn.deterministic = True from here on (MIOpen's atomically accumulating solvers do not "
                   "survive graph replay); warming up, capturing and checking once more", file=sys.stderr, flush=True)
         warm_up(st, n_warm)
+        after = ms_per_step()
+        # MIOpen's deterministic solver list can be catastrophically slow (resnet50_mrlal b = 256 on MI355X: 7.3 s per step
+        # against 30 ms -- bit-reproducible, and useless): a retry that costs more than it can win is abandoned, on every rank
+        worth_it = all_ranks_ok(after <= 1.5 * before, "deterministic-worth-it", rank, world)
+        R["replay_first_attempt"] = first_check
+        if not worth_it:
+            torch.backends.cudnn.deterministic = False
+            R["miopen_deterministic_why"] = ("tried after the first captured graph did not reproduce the eager step, and switched "
+                                             f"off again: the eager step took {after:.0f} ms with MIOpen's deterministic solvers "
+                                             f"against {before:.0f} ms without")
+            if rank == 0:
+                print(f"note: deterministic solvers run the step in {after:.0f} ms against {before:.0f} ms: switched off again",
+                      file=sys.stderr, flush=True)
+            warm_up(st, 1)
+            torch.cuda.synchronize()
+            return False
+        R["miopen_deterministic_why"] = ("switched on after the first captured graph did not reproduce the eager step "
+                                         f"(update_rel_l2 {(first_check or {}).get('update_rel_l2')}, noise "
+                                         f"{(first_check or {}).get('noise_update_rel_l2')}, worst parameter "
+                                         f"{(first_check or {}).get('worst_parameter')})")
         torch.cuda.synchronize()
         return True
 

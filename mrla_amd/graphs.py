@@ -23,9 +23,8 @@ What the recipe takes care of (each item was a bug or a trap at some point of th
     same weights, optimizer state, BatchNorm buffers, inputs and generator state (`replay_matches_eager`).  A library kernel
     that misbehaves under replay -- MIOpen's split-K 3x3 weight gradient did at small batches, finite but wrong,
     profiles/r04_notes.md section 10 -- is caught here instead of training on garbage: `graphed_step` raises GraphReplayMismatch
-    (or, with `on_mismatch="eager"`, hands out the eagerly launched step) -- after one more attempt with
-    `torch.backends.cudnn.deterministic = True`, which makes MIOpen leave those solvers out (at batch 256 its solver search
-    picked one for resnet50_mrlal on one box of round 5: the headline's own shapes).
+    (or, with `on_mismatch="eager"`, hands out the eagerly launched step); `deterministic_fallback=True` tries once more
+    with `torch.backends.cudnn.deterministic = True` first, which makes MIOpen leave those solvers out.
 The optimizer must be capturable (torch.optim.SGD in its foreach / fused forms is; Adam needs `capturable=True`).
 """
 import torch
@@ -214,7 +213,7 @@ class GraphedStep:
     """See graphed_step()."""
 
     def __init__(self, model, optimizer, loss_fn, example_inputs, autocast=torch.bfloat16, exchange=None, warmup=3,
-                 verify=2, tol=1e-2, on_mismatch="raise", deterministic_fallback=True):
+                 verify=2, tol=1e-2, on_mismatch="raise", deterministic_fallback=False):
         if not isinstance(example_inputs, (tuple, list)) or not example_inputs:
             raise MrlaHipError("example_inputs: a tuple (model input, *loss_fn arguments)")
         if not all(isinstance(t, torch.Tensor) and t.is_cuda for t in example_inputs):
@@ -246,15 +245,36 @@ class GraphedStep:
                 # MIOpen's atomically accumulating (split-K) weight-gradient solvers are right when launched eagerly and
                 # garbage from the second replay of a graph on; cudnn.deterministic leaves them out (resnet/train.py:107-110
                 # sets it with --seed).  One more attempt with it: warm-up (MIOpen searches again), capture, check.
-                warnings.warn(msg + "; trying once more with torch.backends.cudnn.deterministic = True")
-                torch.backends.cudnn.deterministic = self.miopen_deterministic = True
-                self.graph = None
-                continue
+                before = self._eager_ms()
+                torch.backends.cudnn.deterministic = True
+                for _ in range(max(1, warmup)):
+                    self.eager()                     # (MIOpen searches again)
+                after = self._eager_ms()
+                if after <= 1.5 * before:
+                    warnings.warn(msg + "; trying once more with torch.backends.cudnn.deterministic = True")
+                    self.miopen_deterministic = True
+                    self.graph = None
+                    continue
+                # MIOpen's deterministic solver list can be catastrophically slow (resnet50_mrlal b = 256: 7.3 s per step
+                # against 30 ms): a fallback that costs more than the graph can win is no fallback
+                torch.backends.cudnn.deterministic = False
+                self.eager()
+                msg += (f"; torch.backends.cudnn.deterministic was tried and switched off again ({after:.0f} ms per eager step "
+                        f"against {before:.0f} ms)")
             if on_mismatch != "eager":
                 raise GraphReplayMismatch(msg)
             warnings.warn(msg + "; launching the step eagerly instead")
             self.graph = None
             break
+
+    def _eager_ms(self, n=2):
+        import time
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(n):
+            self.eager()
+        torch.cuda.synchronize()
+        return 1e3 * (time.perf_counter() - t0) / n
 
     def eager(self):
         """One step on the static buffers, launched kernel by kernel (also what gets captured)."""
@@ -301,6 +321,8 @@ def graphed_step(model, optimizer, loss_fn, example_inputs, **kw):
     Keywords: autocast (dtype or None, default torch.bfloat16), exchange (a distributed.FlatGradientExchange for N > 1),
     warmup (eager steps before the capture, default 3), verify (steps of the replay-vs-eager check, 0 = skip, default 2),
     tol (its bound on the weights' relative L2 difference), on_mismatch ("raise" | "eager"), deterministic_fallback (default
-    True: if the check fails, switch torch.backends.cudnn.deterministic on -- MIOpen then leaves out its atomically accumulating
-    solvers, the known cause -- and capture + check once more before giving up; `step.miopen_deterministic` says what is on)."""
+    False; True: if the check fails, switch torch.backends.cudnn.deterministic on -- MIOpen then leaves out its atomically
+    accumulating solvers, one known cause -- and capture + check once more before giving up, unless the eager step then runs
+    > 1.5 x slower: MIOpen's deterministic solver list took 7.3 s per resnet50_mrlal step at b = 256 on MI355X, against 30 ms;
+    `step.miopen_deterministic` says what is on)."""
     return GraphedStep(model, optimizer, loss_fn, example_inputs, **kw)

@@ -651,8 +651,7 @@ def main():
     # (hipErrorCapturedEvent -> std::terminate: seen in one run out of two of the one-rank RCCL tests once the captured steps
     # carried collectives on side streams).  Its event cache hands events of captured collectives to later eager ones, and
     # the flight recorder keeps events of captured collectives for the watchdog to retire: both off for this process.
-    for k, v in (("TORCH_NCCL_CUDA_EVENT_CACHE", "0"), ("TORCH_NCCL_TRACE_BUFFER_SIZE", "0"), ("TORCH_FR_BUFFER_SIZE", "0"),
-                 ("TORCH_NCCL_RETHROW_CUDA_ERRORS", "0")):
+    for k, v in (("TORCH_NCCL_CUDA_EVENT_CACHE", "0"), ("TORCH_FR_BUFFER_SIZE", "0"), ("TORCH_NCCL_RETHROW_CUDA_ERRORS", "0")):
         os.environ.setdefault(k, v)
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ and not args.ddp_probe:
         sys.exit(launch_ranks(args))              # (nothing before this line has touched the GPU)

@@ -175,3 +175,43 @@ def test_replicas_in_sync_detects_a_single_diverged_weight():
     out = mgr.dict()
     mp.spawn(_sync_worker, args=(world, port, out), nprocs=world, join=True)
     assert out[0] == (True, False) and out[1] == (True, False)
+
+
+def _rank0_first_worker(rank, world, port, out):
+    """bench.py's rank-0-first section (MIOpen's solver search) and its votes, on two gloo ranks: rank 0's body has finished
+    before any other rank's starts, nobody deadlocks, the votes agree on every rank, and the per-rank timing spread is
+    reported as (fastest, slowest)."""
+    import sys
+    import time
+    os.environ.update(RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1",
+                      MASTER_PORT=str(port))
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    if root not in sys.path:
+        sys.path.insert(0, root)
+    import bench
+    from mrla_amd import distributed as D
+    D.init_from_env("gloo")
+    stamps = {}
+
+    def body():
+        stamps["start"] = time.time()
+        time.sleep(0.5 if rank == 0 else 0.05)
+        stamps["end"] = time.time()
+    bench.rank0_first(body, rank, world, "unit")
+    lo, hi = D.min_max_over_ranks(10.0 + rank)
+    yes = bench.all_ranks_ok(True, "unit/yes", rank, world)
+    no = bench.all_ranks_ok(rank != 1, "unit/no", rank, world)          # one rank says no: every rank hears no
+    D.barrier()
+    out[rank] = dict(stamps=stamps, lo=lo, hi=hi, yes=yes, no=no)
+    torch.distributed.destroy_process_group()
+
+
+def test_rank0_first_votes_and_rank_spread_on_two_gloo_ranks():
+    world, port = 2, _free_port()
+    mgr = mp.Manager()
+    out = mgr.dict()
+    mp.spawn(_rank0_first_worker, args=(world, port, out), nprocs=world, join=True)
+    a, b = out[0], out[1]
+    assert a["stamps"]["end"] <= b["stamps"]["start"] + 1e-3         # rank 0's section is over before rank 1's begins
+    assert (a["lo"], a["hi"]) == (b["lo"], b["hi"]) == (10.0, 11.0)
+    assert a["yes"] is True and b["yes"] is True and a["no"] is False and b["no"] is False

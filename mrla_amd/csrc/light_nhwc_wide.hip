@@ -15,6 +15,14 @@
 #ifndef MRLA_REVERSE_APPLY
 #define MRLA_REVERSE_APPLY 1
 #endif
+// 1: the instances of light_apply_bwd_wide without GELU run in packed FP32 (light_apply_bwd_pk.h); 0: the plain kernel
+#ifndef MRLA_APPLY_BWD_PK
+#define MRLA_APPLY_BWD_PK 1
+#endif
+// row sets in flight per wave in the packed apply_bwd, 16-bit types (light_apply_bwd_pk.h)
+#ifndef MRLA_APPLY_BWD_DEPTH
+#define MRLA_APPLY_BWD_DEPTH 2
+#endif
 #ifndef MRLA_STREAM_MB
 #define MRLA_STREAM_MB 128
 #endif
@@ -788,6 +796,10 @@ __global__ __launch_bounds__(kBwdWaves * kWave) void light_apply_bwd_wide(
   }
 }
 
+}  // namespace mrla
+#include "light_apply_bwd_pk.h"      // the packed-FP32 form of the kernel above (every instance without GELU)
+namespace mrla {
+
 // ------------------------------------------------------------------------------------------------
 // MRLA-base value backward on the row pipeline (round 4; base_nhwc.hip keeps the register-staged form for C % 64 != 0):
 //   dx = [x > 0 if res&2] * ((res&1) * dOut + dwconv3x3^T(dV) + dyx);  dWv partials;  PRE: bn3's backward sums
@@ -1067,11 +1079,20 @@ int launch_light_apply_bwd_wide(const void* dout, const void* x, const void* o, 
   if (pre_tmom && dtype == MRLA_F32) return MRLA_EUNSUPPORTED;      // (LDS: see mrla_light_apply_bwd_pre_sums)
 #define CALL_G(T, A, O, R, RG, PR)                                                                                   \
   {                                                                                                                  \
-    const WideLaunch L = wide_launch(P_APPLY_BWD, B, C, W, 9, apply_bwd_wave_bytes<T, PR>(), bg, false);                       \
-    if (set_lds_n(light_apply_bwd_wide<T, A, O, R, RG, PR>, L.lds) != hipSuccess) return MRLA_EHIP;                    \
-    hipLaunchKernelGGL((light_apply_bwd_wide<T, A, O, R, RG, PR>), L.grid, L.block, L.lds, st, (const T*)dout,        \
-                       (const T*)x, (const T*)o, wv, gate, cb, lam, dp, dyx, (T*)dx, (T*)dprev, dwv_part,             \
-                       (const T*)pre, pre_center, pre_tmom, B, C, H, W, L.BG, d, res, L.wc);                               \
+    if constexpr (MRLA_APPLY_BWD_PK && !(A)) {                                                                       \
+      constexpr int DP = sizeof(T) == 2 ? MRLA_APPLY_BWD_DEPTH : 1;                                                  \
+      const WideLaunch L = wide_launch(P_APPLY_BWD, B, C, W, 0, apply_bwd_pk_wave_bytes<T, PR, DP>(), bg, false);    \
+      if (set_lds_n(light_apply_bwd_wide_pk<T, O, R, RG, PR, DP>, L.lds) != hipSuccess) return MRLA_EHIP;             \
+      hipLaunchKernelGGL((light_apply_bwd_wide_pk<T, O, R, RG, PR, DP>), L.grid, L.block, L.lds, st, (const T*)dout,  \
+                         (const T*)x, (const T*)o, wv, gate, cb, lam, dp, dyx, (T*)dx, (T*)dprev, dwv_part,           \
+                         (const T*)pre, pre_center, pre_tmom, B, C, H, W, L.BG, d, res, L.wc);                        \
+    } else {                                                                                                         \
+      const WideLaunch L = wide_launch(P_APPLY_BWD, B, C, W, 9, apply_bwd_wave_bytes<T, PR>(), bg, false);           \
+      if (set_lds_n(light_apply_bwd_wide<T, A, O, R, RG, PR>, L.lds) != hipSuccess) return MRLA_EHIP;                  \
+      hipLaunchKernelGGL((light_apply_bwd_wide<T, A, O, R, RG, PR>), L.grid, L.block, L.lds, st, (const T*)dout,      \
+                         (const T*)x, (const T*)o, wv, gate, cb, lam, dp, dyx, (T*)dx, (T*)dprev, dwv_part,           \
+                         (const T*)pre, pre_center, pre_tmom, B, C, H, W, L.BG, d, res, L.wc);                        \
+    }                                                                                                                \
   }
 #define CALL_R(T, A, O, R) { if (ragged) CALL_G(T, A, O, R, true, false) else CALL_G(T, A, O, R, false, false) }
 #define CALL_P(T)                                                                                       \

@@ -80,23 +80,43 @@ def test_replayed_fp32_step_equals_eager_steps():
 
 def test_graphed_step_is_a_drop_in_training_step():
     """`mrla_amd.graphed_step` as a loop uses it: built with its self-check on (verify=2), fed fresh batches, it keeps
-    training -- the loss of a repeated batch goes down, the logits are exposed, a batch of another shape is refused."""
+    training -- the loss of a repeated batch goes down, the logits are exposed; building it leaves the training state as it was
+    (resume-from-checkpoint runs start where resnet/train.py's would); a smaller last batch is stepped eagerly on its own
+    tensors; another image size is refused."""
     import mrla_amd
     net = _build("resnet50_mrlal", 0.0)
     opt = torch.optim.SGD(net.parameters(), lr=0.02, momentum=0.9)
     x, y = _data(32)               # (32: the smallest batch MIOpen's immediate-mode 3x3 weight gradient replays correctly at)
+    entry = {k: v.detach().clone() for k, v in net.state_dict().items()}
+    rng = torch.cuda.get_rng_state()
     step = mrla_amd.graphed_step(net, opt, torch.nn.functional.cross_entropy, (x, y))
     assert step.report is not None and step.report["ok"] and step.graph is not None
+    # the warm-up, capture and self-check steps were real optimizer steps on the example batch -- and left no trace: weights,
+    # BatchNorm statistics and counters, the generator are as on entry; the momentum buffers they created are zero (= none)
+    now = net.state_dict()
+    assert all(torch.equal(v, now[k]) for k, v in entry.items()), [k for k, v in entry.items() if not torch.equal(v, now[k])][:3]
+    assert int(net.bn1.num_batches_tracked) == 0 and torch.equal(torch.cuda.get_rng_state(), rng)
+    assert len(opt.state) > 0 and all(float(st["momentum_buffer"].abs().max()) == 0.0 for st in opt.state.values())
     losses = []
     for _ in range(6):
         losses.append(float(step(x, y)))
+    assert step.last_launch == "graph" and int(net.bn1.num_batches_tracked) == 6
     assert step.output.shape == (32, 1000) and all(v == v for v in losses)
     assert losses[-1] < losses[0]
     x2, y2 = _data(32)
     step(x2 * 0.5, y2)                                   # another batch of the captured shape
     assert torch.isfinite(step.loss)
+    # the tail batch of an epoch: stepped eagerly ON THE TENSORS GIVEN (the static buffers keep the previous batch)
+    held = step.static[0].clone()
+    w = net.fc.weight.detach().clone()
+    loss8 = step(x[:8], y[:8])
+    assert step.last_launch == "eager (other shape)" and step.output.shape == (8, 1000) and torch.isfinite(loss8)
+    assert torch.equal(step.static[0], held) and not torch.equal(net.fc.weight.detach(), w)
+    assert int(net.bn1.num_batches_tracked) == 8
+    step(x, y)
+    assert step.last_launch == "graph" and step.output.shape == (32, 1000)      # and the graph is still good afterwards
     with pytest.raises(mrla_amd._lib.MrlaHipError):
-        step(x[:8], y[:8])
+        step(x[:8, :, :128, :128], y[:8])
     # a mismatch is reported, not trained on: a "replay" that skips the optimizer is caught by the same check
     from mrla_amd import graphs
     rep = graphs.replay_matches_eager(step.eager, lambda: None, net, opt, steps=2)
@@ -144,6 +164,59 @@ def test_deit_fp16_autocast_with_loss_scaler_tracks_the_eager_restatement():
     # (the bound of test_models_gpu.py's bf16 twin: 16-bit storage through 12 blocks at batch 16 -- two equivalent
     # implementations agree on the gradient's direction to ~0.9; the fp32 tests pin the arithmetic)
     assert rel < 5e-2 and cos > 0.8
+
+
+def test_deit_fp16_loss_scaler_step_replays_from_one_graph():
+    """deit/engine.py:37,51 inside the graph: fp16 autocast, GradScaler (timm's NativeScaler), fused AdamW (deit/main.py's
+    default optimizer is adamw) -- scale, backward, unscale + inf check + update and the scale's own update are all device
+    work, so `graphed_step(..., scaler=...)` captures them.  (a) the self-check passes (replays == eager steps from the same
+    state, the scaler's tensors included); (b) replays track an eager loop of the same recipe; (c) an inf injected into the
+    loss is handled as the eager scaler handles it: the step is skipped (weights stand still) and the scale halves."""
+    import mrla_amd
+    was = torch.backends.cudnn.benchmark
+    torch.backends.cudnn.benchmark = True
+    try:
+        x, y = _data(32)
+
+        def build():
+            net = _build("deit_mrlal_tiny_patch16_224", 0.0)
+            opt = torch.optim.AdamW(net.parameters(), lr=5e-4, weight_decay=0.05, fused=True)
+            return net, opt, torch.amp.GradScaler("cuda", init_scale=4096.0, growth_interval=4)
+        poison = torch.zeros((), device="cuda")
+
+        def loss_fn(logits, target, extra):
+            return torch.nn.functional.cross_entropy(logits, target) + extra       # extra = 0, or inf for the skipped step
+
+        net, opt, scaler = build()
+        step = mrla_amd.graphed_step(net, opt, loss_fn, (x, y, poison), autocast=torch.float16, scaler=scaler, verify=2)
+        assert step.graph is not None and step.report["ok"], step.report
+        assert scaler.get_scale() == 4096.0 and len(opt.state) > 0                 # the state restore covers the scaler too
+        ref, ropt, rscaler = build()
+        ref.load_state_dict(net.state_dict())
+
+        def eager_ref(extra):
+            with torch.autocast("cuda", dtype=torch.float16):
+                loss = loss_fn(ref(x).float(), y, extra)
+            ropt.zero_grad(set_to_none=True)
+            rscaler.scale(loss).backward()
+            rscaler.step(ropt)
+            rscaler.update()
+            return float(loss)
+        got, want = [], []
+        for k in range(6):
+            extra = torch.full((), float("inf"), device="cuda") if k == 2 else poison
+            before = net.head.weight.detach().clone()
+            got.append(float(step(x, y, extra)))
+            want.append(eager_ref(extra))
+            assert step.last_launch == "graph"
+            moved = not torch.equal(net.head.weight.detach(), before)
+            assert moved == (k != 2), (k, moved)                                       # the poisoned step is skipped on the device
+            assert scaler.get_scale() == rscaler.get_scale(), (k, scaler.get_scale(), rscaler.get_scale())
+        assert scaler.get_scale() == 2048.0 or scaler.get_scale() == 4096.0           # halved at step 2 (grown back after 4 good ones)
+        assert all(abs(a - b) <= 2e-2 * abs(b) + 1e-3 for a, b in zip(got, want) if b == b and abs(b) != float("inf")), (got, want)
+        assert got[-1] < got[0]
+    finally:
+        torch.backends.cudnn.benchmark = was
 
 
 def test_a_library_kernel_that_misbehaves_under_replay_is_caught_before_training_on_it():

@@ -64,9 +64,12 @@ enum { MRLA_BN_NONE = 0, MRLA_BN_TRAIN = 1, MRLA_BN_EVAL = 2 };
  *   3 -> 4: the "sequence" entry points were added (mrla_light_tail_fwd / _bwd, mrla_bn_fwd / _bwd, mrla_base_layer_fwd /
  *           _bwd, mrla_token_light_fwd / _bwd, mrla_stem_fwd / _bwd: one call issues the static launch sequence of a whole tail and direction;
  *           the per-pass entry points are unchanged).
+ *   4 -> 5: the training tail without a stored x_t (13N instead of 15N elements per block and step): mrla_light_lean_supported,
+ *           mrla_light_stats_bwd_fused and mrla_light_apply_bwd_fused were added, mrla_light_stats_fwd_fused takes x_out = NULL,
+ *           mrla_light_tail_fwd takes fuse = 2 and mrla_light_tail_bwd gained pre_sc / pre_sh (x = NULL selects that form).
  * A consumer compares mrla_abi_version() (what the loaded library was built from) against this constant before its
  * first call. */
-#define MRLA_ABI_VERSION 4
+#define MRLA_ABI_VERSION 5
 int mrla_abi_version(void);
 
 /* Number of rows of the `dwv_part` scratch that mrla_light_apply_bwd writes for this problem
@@ -86,7 +89,9 @@ int mrla_light_stats_fwd(const void* x, const void* o_prev, const float* wv /*[c
  * Replaces `out += identity; out = self.relu(out)` (resnet_mrla_light.py:113-114) on top of the statistics pass.
  * pre_sc / pre_sh [opt, c floats each]: the affine of the BatchNorm in front (bn3, resnet_mrla_light.py:102) when the
  * caller defers its elementwise pass: x_t = relu((pre_sc*pre + pre_sh) + o_prev), the affine result rounded to the
- * storage type as the stand-alone pass would have stored it; `pre` is then conv3's raw output. */
+ * storage type as the stand-alone pass would have stored it; `pre` is then conv3's raw output.
+ * x_out == NULL (only where mrla_light_lean_supported() == 1): x_t is formed for the statistics and NOT written -- the caller
+ * re-forms it in every later pass (mrla_light_apply_fwd_fused, mrla_light_stats_bwd_fused, mrla_light_apply_bwd_fused). */
 int mrla_light_stats_fwd_fused(const void* pre, const float* pre_sc, const float* pre_sh, const void* o_prev,
                                const float* wv, float* mom, void* x_out, int b, int c, int h, int w, int dtype,
                                int layout, void* stream);
@@ -171,6 +176,26 @@ int mrla_light_apply_bwd(const void* dout, const void* x, const void* o_prev, co
                          const float* cb, const float* lam, const float* dp, const float* dyx, void* dx,
                          void* do_prev, float* dwv_part, const void* pre, const float* pre_center, float* pre_tmom, int b,
                          int c, int h, int w, int d, int res, int relu_mask, int dtype, int layout, int act, void* stream);
+
+/* ---- the training tail WITHOUT a stored x_t (ABI 5; MRLA_NHWC, c % 64 == 0, 16-bit activations) -------------------------
+ * x_t = relu((pre_sc*pre + pre_sh) + o_prev) (resnet_mrla_light.py:101-114) is what the MRLA branch convolves
+ * (mrla_light_module.py:61).  Every pass of the tail reads o_prev anyway, and the backward apply pass reads `pre` for bn3's
+ * sums, so x_t can be re-formed from rows that are in LDS already -- by the formula of mrla_light_stats_fwd_fused, hence
+ * bit-identical -- instead of being written once and read three times: 13N elements per block and training step, not 15N
+ *   forward : mrla_light_stats_fwd_fused(x_out = NULL) [2N]  ->  gate, bn  ->  mrla_light_apply_fwd_fused [3N]
+ *   backward: mrla_light_stats_bwd_fused [3N]  ->  bn_bwd, gate_bwd  ->  mrla_light_apply_bwd_fused [5N = section 8(d)'s count].
+ * mrla_light_lean_supported: 1 where these kernels exist for the shape, else 0.  The two backward entry points take the
+ * arguments of mrla_light_stats_bwd / mrla_light_apply_bwd (relu_mask = 1, act = none) with (pre, pre_sc, pre_sh) in the
+ * place of x; pre_tmom [opt] as there (pre itself is always given here). */
+int mrla_light_lean_supported(int b, int c, int h, int w, int dtype, int layout);
+int mrla_light_stats_bwd_fused(const void* dout, const void* pre, const float* pre_sc, const float* pre_sh,
+                               const void* o_prev, const float* wv, const float* mom, float* bmom, int b, int c, int h, int w,
+                               int dtype, int layout, void* stream);
+int mrla_light_apply_bwd_fused(const void* dout, const void* pre, const float* pre_sc, const float* pre_sh,
+                               const void* o_prev, const float* wv, const float* gate, const float* cb, const float* lam,
+                               const float* dp, const float* dyx, void* dx, void* do_prev, float* dwv_part,
+                               const float* pre_center, float* pre_tmom, int b, int c, int h, int w, int d, int res,
+                               int dtype, int layout, void* stream);
 
 /* =====================================================================================================
  * MRLA-base: softmax over the depth of a stage (resnet/models/modules/mrla_base_module.py:54-89 and the
@@ -477,8 +502,10 @@ int mrla_reduce_rows2(const float* in1, float* out1, int rows1, int n1, const fl
  * ===================================================================================================== */
 
 /* Light block tail, forward (resnet_mrla_light.py:113-116 / mrla_light_module.py:52-74):
- *   fuse == 0: mrla_light_stats_fwd(x, ...)                      fuse != 0: mrla_light_stats_fwd_fused(x = pre, ..., x_out)
+ *   fuse == 0: mrla_light_stats_fwd(x, ...)                      fuse == 1: mrla_light_stats_fwd_fused(x = pre, ..., x_out)
  *   -> mrla_light_gate_fwd -> [bn_mode != MRLA_BN_NONE: mrla_light_bn_fwd] -> mrla_light_apply_fwd (on x_out when fused).
+ *   fuse == 2 (x_out = NULL; mrla_light_lean_supported): mrla_light_stats_fwd_fused(x = pre, ..., NULL) -> gate -> bn ->
+ *   mrla_light_apply_fwd_fused(pre, ...): x_t is never written.
  * bnbuf [opt unless BN]: [4, c] floats = sc | sh | save_mean | save_inv (rows 0, 1 feed the apply pass). */
 int mrla_light_tail_fwd(const void* x, const float* pre_sc, const float* pre_sh, const void* o_prev, const float* wq,
                         const float* wk, int ksize, const float* wv, const float* lam, const float* gamma,
@@ -488,14 +515,17 @@ int mrla_light_tail_fwd(const void* x, const float* pre_sc, const float* pre_sh,
 
 /* Light block tail, backward:
  *   mrla_light_stats_bwd -> mrla_light_bn_bwd -> mrla_light_gate_bwd -> mrla_light_apply_bwd -> mrla_reduce_rows2.
+ * x == NULL (the forward ran with fuse = 2): mrla_light_stats_bwd_fused / mrla_light_apply_bwd_fused on (pre, pre_sc, pre_sh)
+ * instead; pre_sc / pre_sh are read in that form only.
  * small: [11, c] floats = cb[c,4] | dgamma | dbeta | dlam | cb_lo[c,4] (the layout mrla_amd/functional.py uses);
  * wsum: [c*9 + 2*ksize] floats = dWv | dWq | dWk; rows = mrla_light_wgrad_rows(). */
 int mrla_light_tail_bwd(const void* dout, const void* x, const void* o_prev, const float* wq, const float* wk, int ksize,
                         const float* wv, const float* lam, const float* gamma, const float* dp, const float* mom,
                         const float* gate, const float* bnbuf, int bn_mode, float* bmom, float* small, float* dyx,
                         float* dwqk_part, float* dwv_part, int rows, void* dx, void* do_prev, const void* pre,
-                        const float* pre_center, float* pre_tmom, float* wsum, int b, int c, int h, int w, int d, int res,
-                        int relu_mask, int dtype, int layout, int act, void* stream);
+                        const float* pre_sc, const float* pre_sh, const float* pre_center, float* pre_tmom, float* wsum,
+                        int b, int c, int h, int w, int d, int res, int relu_mask, int dtype, int layout, int act,
+                        void* stream);
 
 /* BatchNorm2d(+ReLU), forward:  [records == NULL and TRAIN: mrla_bn_plane_moments(x, amom, pivot)] ->
  *   records != NULL: mrla_bn_stats_fwd_rows(records, ..., rec_rows)   else: mrla_bn_stats_fwd(amom, pivot, ..., rows)

@@ -9,7 +9,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libmrla_hip.so")
 
-ABI_VERSION = 4          # MRLA_ABI_VERSION of include/mrla_hip.h
+ABI_VERSION = 5          # MRLA_ABI_VERSION of include/mrla_hip.h
 OK, EINVAL, EUNSUPPORTED, EHIP = 0, -1, -2, -3
 F32, BF16, F16 = 0, 1, 2
 NCHW, NHWC = 0, 1
@@ -36,6 +36,9 @@ SIGNATURES = {
     "mrla_light_gate_bwd": [_P, _P, _P, _P, _P, _P, _P, _P, _I, _P, _P, _I, _I, _I, _I, _P],
     "mrla_light_apply_bwd_pre_sums": [_I] * 6,
     "mrla_light_apply_bwd": [_P] * 15 + [_I] * 10 + [_P],
+    "mrla_light_lean_supported": [_I] * 6,
+    "mrla_light_stats_bwd_fused": [_P] * 8 + [_I] * 6 + [_P],
+    "mrla_light_apply_bwd_fused": [_P] * 16 + [_I] * 8 + [_P],
     "mrla_light_pool_fused": [_P] * 6 + [_I] * 6 + [_P],
     "mrla_light_apply_fwd_fused": [_P] * 11 + [_I] * 8 + [_P],
     "mrla_light_stats_fwd_fused": [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P],
@@ -90,7 +93,7 @@ SIGNATURES = {
     "mrla_reduce_rows2": [_P, _P, _I, _I, _P, _P, _I, _I, _P],
     # sequence entry points (ABI 4): one call = the static launch sequence of a tail and direction
     "mrla_light_tail_fwd": [_P] * 6 + [_I] + [_P] * 6 + [_I, _F, _F] + [_P] * 6 + [_I] * 10 + [_P],
-    "mrla_light_tail_bwd": [_P] * 5 + [_I] + [_P] * 7 + [_I] + [_P] * 5 + [_I] + [_P] * 6 + [_I] * 10 + [_P],
+    "mrla_light_tail_bwd": [_P] * 5 + [_I] + [_P] * 7 + [_I] + [_P] * 5 + [_I] + [_P] * 8 + [_I] * 10 + [_P],
     "mrla_bn_fwd": [_P, _P, _I, _P, _P, _I, _P, _P, _P, _P, _I, _F, _F, _P, _I, _P] + [_I] * 6 + [_P],
     "mrla_bn_bwd": [_P] * 5 + [_I] * 4 + [_P, _P] + [_I] * 6 + [_P],
     "mrla_stem_fwd": [_P, _P, _P, _I, _P, _P, _P, _P, _I, _F, _F, _P, _P] + [_I] * 6 + [_P],

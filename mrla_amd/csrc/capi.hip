@@ -127,11 +127,12 @@ int mrla_light_stats_fwd(const void* x, const void* o_prev, const float* wv, flo
 int mrla_light_stats_fwd_fused(const void* pre, const float* pre_sc, const float* pre_sh, const void* o_prev,
                                const float* wv, float* mom, void* x_out, int b, int c, int h, int w, int dtype,
                                int layout, void* stream) {
-  if (!pre || !o_prev || !wv || !mom || !x_out || bad_dims(b, c, h, w) || bad_dtype(dtype)) return MRLA_EINVAL;
+  if (!pre || !o_prev || !wv || !mom || bad_dims(b, c, h, w) || bad_dtype(dtype)) return MRLA_EINVAL;
   if ((pre_sc == nullptr) != (pre_sh == nullptr)) return MRLA_EINVAL;
+  if (!x_out && mrla_light_lean_supported(b, c, h, w, dtype, layout) != 1) return MRLA_EUNSUPPORTED;
   if (layout == MRLA_NHWC)
     return launch_light_stats_fwd_nhwc(pre, o_prev, wv, mom, x_out, pre_sc, pre_sh, nullptr, b, c, h, w, dtype,
-                                       MRLA_ACT_NONE, (hipStream_t)stream);
+                                       MRLA_ACT_NONE, (hipStream_t)stream, x_out == nullptr);
   if (layout != MRLA_NCHW) return MRLA_EINVAL;
   SlabGeo g;
   const int rc = light_geo(&g, b, c, h, w, dtype);
@@ -251,6 +252,36 @@ int mrla_light_apply_bwd(const void* dout, const void* x, const void* o_prev, co
   if (rc != MRLA_OK) return rc;
   return launch_light_apply_bwd_nchw(dout, x, o_prev, wv, gate, cb, lam, dp, dyx, dx, do_prev, dwv_part, g, d, res,
                                      relu_mask, dtype, act, (hipStream_t)stream);
+}
+
+int mrla_light_lean_supported(int b, int c, int h, int w, int dtype, int layout) {
+  if (bad_dims(b, c, h, w) || bad_dtype(dtype)) return MRLA_EINVAL;
+  if (layout != MRLA_NHWC && layout != MRLA_NCHW) return MRLA_EINVAL;
+  return (layout == MRLA_NHWC && light_lean_supported(b, c, h, w, dtype) == 1) ? 1 : 0;
+}
+
+int mrla_light_stats_bwd_fused(const void* dout, const void* pre, const float* pre_sc, const float* pre_sh,
+                               const void* o_prev, const float* wv, const float* mom, float* bmom, int b, int c, int h, int w,
+                               int dtype, int layout, void* stream) {
+  if (!dout || !pre || !o_prev || !wv || !mom || !bmom || bad_dims(b, c, h, w) || bad_dtype(dtype)) return MRLA_EINVAL;
+  if ((pre_sc == nullptr) != (pre_sh == nullptr)) return MRLA_EINVAL;
+  if (mrla_light_lean_supported(b, c, h, w, dtype, layout) != 1) return MRLA_EUNSUPPORTED;
+  return launch_light_stats_bwd_lean_wide(dout, pre, o_prev, wv, pre_sc, pre_sh, mom, bmom, b, c, h, w, dtype,
+                                          (hipStream_t)stream);
+}
+
+int mrla_light_apply_bwd_fused(const void* dout, const void* pre, const float* pre_sc, const float* pre_sh,
+                               const void* o_prev, const float* wv, const float* gate, const float* cb, const float* lam,
+                               const float* dp, const float* dyx, void* dx, void* do_prev, float* dwv_part,
+                               const float* pre_center, float* pre_tmom, int b, int c, int h, int w, int d, int res,
+                               int dtype, int layout, void* stream) {
+  if (!dout || !pre || !o_prev || !wv || !gate || !lam || !dyx || !dx || !do_prev || !dwv_part || bad_dims(b, c, h, w) ||
+      bad_dtype(dtype) || d <= 0 || c % d)
+    return MRLA_EINVAL;
+  if ((pre_sc == nullptr) != (pre_sh == nullptr)) return MRLA_EINVAL;
+  if (mrla_light_lean_supported(b, c, h, w, dtype, layout) != 1) return MRLA_EUNSUPPORTED;
+  return launch_light_apply_bwd_lean_wide(dout, pre, o_prev, wv, pre_sc, pre_sh, gate, cb, lam, dp, dyx, dx, do_prev,
+                                          dwv_part, pre_center, pre_tmom, b, c, h, w, d, res, dtype, (hipStream_t)stream);
 }
 
 static bool bad_ring(int T, int t) { return T <= 0 || t <= 0 || t > T; }

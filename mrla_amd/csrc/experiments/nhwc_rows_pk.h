@@ -9,7 +9,7 @@
 // value, nhwc_rows.h).  The reads are separate asm statements on the scalar halves and the FENCE ties the 64-bit pairs: a
 // single asm with every half as a tied operand makes the register coalescer copy each odd half (one v_mov per pair and row).
 #pragma once
-#include "nhwc_rows.h"
+#include "../nhwc_rows.h"
 
 namespace mrla {
 

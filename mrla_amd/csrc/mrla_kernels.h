@@ -195,7 +195,7 @@ int launch_weight_bank_refresh(const long long* table, int entries, int max_tile
 // light_nhwc_wide.hip -- the C % 64 == 0 forms on the LDS-DMA row pipeline (nhwc_rows.h)
 int launch_light_stats_fwd_wide(const void* x, const void* o, const float* wv, float* mom, void* xout, const float* psc,
                                 const float* psh, void* vout, int B, int C, int H, int W, int dtype, int act,
-                                hipStream_t st);
+                                hipStream_t st, bool fused_no_x = false);
 int launch_light_apply_fwd_wide(const void* x, const void* o, const float* wv, const float* gate, const float* sc,
                                 const float* sh, const float* lam, const float* dp, void* out, int B, int C, int H,
                                 int W, int d, int res, int dtype, int act, hipStream_t st);
@@ -209,9 +209,19 @@ int launch_light_apply_bwd_wide(const void* dout, const void* x, const void* o, 
                                 int B, int C, int H, int W, int d, int res, int relu, int dtype, int act, hipStream_t st);
 int launch_light_stats_bwd_wide(const void* dout, const void* x, const void* o, const float* wv, const float* mom,
                                 float* bmom, int B, int C, int H, int W, int dtype, int act, hipStream_t st);
+// light_nhwc_lean.hip -- the backward passes that re-form x_t from conv3's output and the shortcut (no stored x_t)
+int light_lean_supported(int B, int C, int H, int W, int dtype);
+int launch_light_stats_bwd_lean_wide(const void* dout, const void* pre, const void* o, const float* wv, const float* psc,
+                                     const float* psh, const float* mom, float* bmom, int B, int C, int H, int W, int dtype,
+                                     hipStream_t st);
+int launch_light_apply_bwd_lean_wide(const void* dout, const void* pre, const void* o, const float* wv, const float* psc,
+                                     const float* psh, const float* gate, const float* cb, const float* lam,
+                                     const float* dp, const float* dyx, void* dx, void* dprev, float* dwv_part,
+                                     const float* pre_center, float* pre_tmom, int B, int C, int H, int W, int d, int res,
+                                     int dtype, hipStream_t st);
 int launch_light_stats_fwd_nhwc(const void* x, const void* o, const float* wv, float* mom, void* xout,
                                 const float* psc, const float* psh, void* vout, int B, int C, int H, int W, int dtype,
-                                int act, hipStream_t st);
+                                int act, hipStream_t st, bool fused_no_x = false);
 int launch_light_apply_fwd_nhwc(const void* x, const void* o, const float* wv, const float* gate, const float* sc,
                                 const float* sh, const float* lam, const float* dp, void* out, int B, int C, int H,
                                 int W, int d, int res, int dtype, int act, hipStream_t st);

@@ -19,9 +19,13 @@ int mrla_light_tail_fwd(const void* x, const float* pre_sc, const float* pre_sh,
                         const float* dp, float* mom, void* x_out, float* gate, float* bnbuf, void* out, int b, int c,
                         int h, int w, int d, int res, int fuse, int dtype, int layout, int act, void* stream) {
   if (bn_mode != MRLA_BN_NONE && !bnbuf) return MRLA_EINVAL;
-  if (fuse && (!x_out || act != MRLA_ACT_NONE)) return MRLA_EINVAL;
+  if (fuse && ((fuse == 1 && !x_out) || act != MRLA_ACT_NONE)) return MRLA_EINVAL;
   const void* xt = x;
-  if (fuse) {
+  if (fuse == 2) {                 // x_t is never written: the apply pass re-forms it from (pre = x, o_prev)
+    if (mrla_light_lean_supported(b, c, h, w, dtype, layout) != 1) return MRLA_EUNSUPPORTED;
+    MRLA_TRY(mrla_light_stats_fwd_fused(x, pre_sc, pre_sh, o_prev, wv, mom, nullptr, b, c, h, w, dtype, layout, stream));
+    xt = nullptr;
+  } else if (fuse) {
     MRLA_TRY(mrla_light_stats_fwd_fused(x, pre_sc, pre_sh, o_prev, wv, mom, x_out, b, c, h, w, dtype, layout, stream));
     xt = x_out;
   } else {
@@ -35,6 +39,9 @@ int mrla_light_tail_fwd(const void* x, const float* pre_sc, const float* pre_sh,
     sc = bnbuf;
     sh = bnbuf + c;
   }
+  if (fuse == 2)
+    return mrla_light_apply_fwd_fused(x, pre_sc, pre_sh, o_prev, wv, gate, sc, sh, lam, dp, out, b, c, h, w, d, res, dtype,
+                                      layout, stream);
   return mrla_light_apply_fwd(xt, o_prev, wv, gate, sc, sh, lam, dp, out, b, c, h, w, d, res, dtype, layout, act, stream);
 }
 
@@ -42,20 +49,28 @@ int mrla_light_tail_bwd(const void* dout, const void* x, const void* o_prev, con
                         const float* wv, const float* lam, const float* gamma, const float* dp, const float* mom,
                         const float* gate, const float* bnbuf, int bn_mode, float* bmom, float* small, float* dyx,
                         float* dwqk_part, float* dwv_part, int rows, void* dx, void* do_prev, const void* pre,
-                        const float* pre_center, float* pre_tmom, float* wsum, int b, int c, int h, int w, int d, int res,
-                        int relu_mask, int dtype, int layout, int act, void* stream) {
+                        const float* pre_sc, const float* pre_sh, const float* pre_center, float* pre_tmom, float* wsum,
+                        int b, int c, int h, int w, int d, int res, int relu_mask, int dtype, int layout, int act,
+                        void* stream) {
   if (!small || !wsum || rows <= 0 || ksize <= 0) return MRLA_EINVAL;
   const bool has_bn = bn_mode != MRLA_BN_NONE;
   if (has_bn && (!bnbuf || !gamma)) return MRLA_EINVAL;
   const size_t C = (size_t)c;
   float *cb = small, *dgamma = small + 4 * C, *dbeta = small + 5 * C, *dlam = small + 6 * C, *cb_lo = small + 7 * C;
-  MRLA_TRY(mrla_light_stats_bwd(dout, x, o_prev, wv, mom, bmom, b, c, h, w, dtype, layout, act, stream));
+  const bool lean = x == nullptr;      // the forward never wrote x_t: re-formed from (pre, pre_sc, pre_sh, o_prev)
+  if (lean && (!pre || !relu_mask || act != MRLA_ACT_NONE)) return MRLA_EINVAL;
+  if (lean) MRLA_TRY(mrla_light_stats_bwd_fused(dout, pre, pre_sc, pre_sh, o_prev, wv, mom, bmom, b, c, h, w, dtype, layout, stream));
+  else MRLA_TRY(mrla_light_stats_bwd(dout, x, o_prev, wv, mom, bmom, b, c, h, w, dtype, layout, act, stream));
   MRLA_TRY(mrla_light_bn_bwd(mom, bmom, gate, lam, has_bn ? gamma : nullptr, dp, has_bn ? bnbuf + 2 * C : nullptr,
                              has_bn ? bnbuf + 3 * C : nullptr, bn_mode, cb, cb_lo, has_bn ? dgamma : nullptr,
                              has_bn ? dbeta : nullptr, lam ? dlam : nullptr, b, c, h * w, d, stream));
   MRLA_TRY(mrla_light_gate_bwd(mom, bmom, gate, cb, cb_lo, dp, wq, wk, ksize, dyx, dwqk_part, b, c, h * w, d, stream));
-  MRLA_TRY(mrla_light_apply_bwd(dout, x, o_prev, wv, gate, cb, lam, dp, dyx, dx, do_prev, dwv_part, pre, pre_center,
-                                pre_tmom, b, c, h, w, d, res, relu_mask, dtype, layout, act, stream));
+  if (lean)
+    MRLA_TRY(mrla_light_apply_bwd_fused(dout, pre, pre_sc, pre_sh, o_prev, wv, gate, cb, lam, dp, dyx, dx, do_prev, dwv_part,
+                                        pre_center, pre_tmom, b, c, h, w, d, res, dtype, layout, stream));
+  else
+    MRLA_TRY(mrla_light_apply_bwd(dout, x, o_prev, wv, gate, cb, lam, dp, dyx, dx, do_prev, dwv_part, pre, pre_center,
+                                  pre_tmom, b, c, h, w, d, res, relu_mask, dtype, layout, act, stream));
   return mrla_reduce_rows2(dwv_part, wsum, rows, c * 9, dwqk_part, wsum + 9 * C, b, 2 * ksize, stream);
 }
 

@@ -52,6 +52,13 @@ SEQUENCES = True  # a tail / BatchNorm direction = ONE call of a sequence entry 
 #                   results; per-pass calls are used while a KernelTimer is on (events around every kernel) or when False.
 
 
+LEAN = False      # True: the fused training tail does not store x_t where the library can re-form it (mrla_light_lean_supported:
+#                   13N instead of 15N elements of HBM traffic per block and step, 1N less activation memory, bit-identical
+#                   results).  Not the default: inside the resnet50_mrlal step the two forms take the same time on MI355X
+#                   (29.96 - 29.99 ms lean, 29.80 - 29.95 ms stored: the backward statistics pass pays for re-forming x_t
+#                   what the forward one saves, profiles/r06_notes.md section 3) -- switch it on for the memory.
+
+
 def _seq():
     return SEQUENCES and TIMER is None
 
@@ -350,10 +357,13 @@ class _LightFn(torch.autograd.Function):
                   cfg.res, dt, layout, st, path=xc.numel() * xc.element_size() * 3)
             return out.contiguous() if via_nhwc else out
         pre = None
+        # x_t = relu(bn3(pre) + o_prev) is re-formed by every pass that needs it instead of being stored (ABI 5)
+        lean = bool(LEAN and cfg.fuse and not via_nhwc and L.load().mrla_light_lean_supported(b, c, h, w, dt, layout) == 1)
+        nb = xc.numel() * xc.element_size()
         if _seq():
             psc = psh = None
             if cfg.fuse:
-                pre, xc = xc, torch.empty_like(xc)
+                pre, xc = xc, (None if lean else torch.empty_like(xc))
                 psc, psh = cfg.pre_affine if cfg.pre_affine is not None else (None, None)
             gate = torch.empty((b, G), dtype=torch.float32, device=dev)
             bnbuf = gamma32 = beta32 = rs = None
@@ -361,19 +371,20 @@ class _LightFn(torch.autograd.Function):
                 gamma32, beta32 = _f32(gamma), _f32(beta)
                 rs = _RunningStats(running_mean, running_var, c, "mrla light forward")
                 bnbuf = torch.empty((4, c), dtype=torch.float32, device=dev)       # sc, sh, save_mean, save_inv
-            out = torch.empty_like(xc)
+            out = torch.empty_like(oc if lean else xc)
             _seq_call("mrla_light_tail_fwd", _ptr(pre if cfg.fuse else xc), _ptr(psc), _ptr(psh), _ptr(oc), _ptr(wq32),
                       _ptr(wk32), ks, _ptr(wv32), _ptr(lam32), _ptr(gamma32), _ptr(beta32),
                       _ptr(rs.rm) if rs is not None else None, _ptr(rs.rv) if rs is not None else None, cfg.bn_mode,
-                      float(cfg.momentum), float(cfg.eps), _ptr(dp32), _ptr(mom), _ptr(xc) if cfg.fuse else None, _ptr(gate),
-                      _ptr(bnbuf), _ptr(out), b, c, h, w, d, cfg.res, int(cfg.fuse), dt, layout, cfg.act, st)
+                      float(cfg.momentum), float(cfg.eps), _ptr(dp32), _ptr(mom), _ptr(xc) if (cfg.fuse and not lean) else None,
+                      _ptr(gate), _ptr(bnbuf), _ptr(out), b, c, h, w, d, cfg.res, (2 if lean else int(cfg.fuse)), dt, layout,
+                      cfg.act, st)
             if rs is not None:
                 rs.finish(cfg.bn_mode == L.BN_TRAIN)
         else:
             if cfg.fuse:
-                pre, xc = xc, torch.empty_like(xc)
+                pre, xc = xc, (None if lean else torch.empty_like(xc))
                 psc, psh = cfg.pre_affine if cfg.pre_affine is not None else (None, None)
-                _call("mrla_light_stats_fwd_fused", xc.numel() * xc.element_size() * 3, _ptr(pre), _ptr(psc), _ptr(psh),
+                _call("mrla_light_stats_fwd_fused", nb * (2 if lean else 3), _ptr(pre), _ptr(psc), _ptr(psh),
                       _ptr(oc), _ptr(wv32), _ptr(mom), _ptr(xc), b, c, h, w, dt, layout, st)
             else:
                 _call("mrla_light_stats_fwd", xc.numel() * xc.element_size() * (2 if oc is not None else 1), _ptr(xc),
@@ -389,11 +400,17 @@ class _LightFn(torch.autograd.Function):
                        _ptr(rs.rm), _ptr(rs.rv), cfg.bn_mode, float(cfg.momentum), float(cfg.eps),
                        _ptr(bnbuf[0]), _ptr(bnbuf[1]), _ptr(bnbuf[2]), _ptr(bnbuf[3]), b, c, h * w, d, st)
                 rs.finish(cfg.bn_mode == L.BN_TRAIN)
-            out = torch.empty_like(xc)
-            _call("mrla_light_apply_fwd", xc.numel() * xc.element_size() * (3 if oc is not None else 2), _ptr(xc), _ptr(oc), _ptr(wv32), _ptr(gate),
-                   _ptr(bnbuf[0]) if bnbuf is not None else None, _ptr(bnbuf[1]) if bnbuf is not None else None,
-                   _ptr(lam32), _ptr(dp32), _ptr(out), b, c, h, w, d, cfg.res, dt, layout, cfg.act, st,
-                   path=xc.numel() * xc.element_size() * (3 if oc is not None else 2))
+            if lean:
+                out = torch.empty_like(oc)
+                _call("mrla_light_apply_fwd_fused", nb * 3, _ptr(pre), _ptr(psc), _ptr(psh), _ptr(oc), _ptr(wv32), _ptr(gate),
+                      _ptr(bnbuf[0]) if bnbuf is not None else None, _ptr(bnbuf[1]) if bnbuf is not None else None,
+                      _ptr(lam32), _ptr(dp32), _ptr(out), b, c, h, w, d, cfg.res, dt, layout, st, path=nb * 3)
+            else:
+                out = torch.empty_like(xc)
+                _call("mrla_light_apply_fwd", nb * (3 if oc is not None else 2), _ptr(xc), _ptr(oc), _ptr(wv32), _ptr(gate),
+                      _ptr(bnbuf[0]) if bnbuf is not None else None, _ptr(bnbuf[1]) if bnbuf is not None else None,
+                      _ptr(lam32), _ptr(dp32), _ptr(out), b, c, h, w, d, cfg.res, dt, layout, cfg.act, st,
+                      path=nb * (3 if oc is not None else 2))
 
         ctx.cfg, ctx.layout, ctx.ks = cfg, layout, ks
         ctx.shapes = (wq.shape, wk.shape, wv.shape, lam.shape if lam is not None else None)
@@ -403,21 +420,26 @@ class _LightFn(torch.autograd.Function):
         # conv3's raw output, when the BatchNorm behind it was deferred and its backward sums can ride in apply_bwd
         keep_pre = (cfg.fuse and cfg.pre_box is not None and not via_nhwc
                     and L.load().mrla_light_apply_bwd_pre_sums(b, c, h, w, dt, layout) == 1)
-        ctx.save_for_backward(xc, oc, wq32, wk32, wv32, lam32, gamma32, dp32, mom, gate, bnbuf, pre if keep_pre else None)
+        ctx.lean, ctx.pre_sums = lean, keep_pre
+        psc, psh = cfg.pre_affine if (lean and cfg.pre_affine is not None) else (None, None)
+        ctx.save_for_backward(xc, oc, wq32, wk32, wv32, lam32, gamma32, dp32, mom, gate, bnbuf,
+                              pre if (keep_pre or lean) else None, psc, psh)
         return out.contiguous() if via_nhwc else out
 
     @staticmethod
     @_on_device
     def backward(ctx, dout):
-        xc, oc, wq32, wk32, wv32, lam32, gamma32, dp32, mom, gate, bnbuf, pre = ctx.saved_tensors
-        cfg, layout, ks = ctx.cfg, ctx.layout, ctx.ks
-        b, c, h, w = xc.shape
+        xc, oc, wq32, wk32, wv32, lam32, gamma32, dp32, mom, gate, bnbuf, pre, psc, psh = ctx.saved_tensors
+        cfg, layout, ks, lean = ctx.cfg, ctx.layout, ctx.ks, ctx.lean
+        like = oc if lean else xc                    # (lean: x_t was never stored; it is re-formed from pre, psc, psh, oc)
+        b, c, h, w = like.shape
         d = cfg.d
-        dt = _DT[xc.dtype]
-        dev = xc.device
+        dt = _DT[like.dtype]
+        dev = like.device
         st = _stream()
-        if dout.dtype != xc.dtype:
-            dout = dout.to(xc.dtype)
+        nb = like.numel() * like.element_size()
+        if dout.dtype != like.dtype:
+            dout = dout.to(like.dtype)
         dout = _layout_of(dout, layout)[1]
 
         has_bn = cfg.bn_mode != L.BN_NONE
@@ -429,26 +451,30 @@ class _LightFn(torch.autograd.Function):
             rows = L.load().mrla_light_wgrad_rows(b, c, h, w, dt, layout)
             L.check(min(rows, 0), "mrla_light_wgrad_rows")
             dwv_part = torch.empty((rows, c * 9), dtype=torch.float32, device=dev)
-            dx = torch.empty_like(xc)
+            dx = torch.empty_like(like)
             do = torch.empty_like(oc) if oc is not None else None
             pre_tmom = None
-            if pre is not None and (b * h * w) % rows == 0:
+            if ctx.pre_sums and pre is not None and (b * h * w) % rows == 0:
                 pre_tmom = torch.empty((rows, c, 2), dtype=torch.float32, device=dev)
-            else:
+            elif not lean:
                 pre = None
             wsum = torch.empty((c * 9 + 2 * ks,), dtype=torch.float32, device=dev)
             _seq_call("mrla_light_tail_bwd", _ptr(dout), _ptr(xc), _ptr(oc), _ptr(wq32), _ptr(wk32), ks, _ptr(wv32),
                       _ptr(lam32), _ptr(gamma32) if has_bn else None, _ptr(dp32), _ptr(mom), _ptr(gate),
                       _ptr(bnbuf) if has_bn else None, cfg.bn_mode, _ptr(bmom), _ptr(small), _ptr(dyx), _ptr(dwqk_part),
-                      _ptr(dwv_part), rows, _ptr(dx), _ptr(do), _ptr(pre),
-                      _ptr(cfg.pre_box.center) if pre is not None else None, _ptr(pre_tmom), _ptr(wsum), b, c, h, w, d,
+                      _ptr(dwv_part), rows, _ptr(dx), _ptr(do), _ptr(pre), _ptr(psc), _ptr(psh),
+                      _ptr(cfg.pre_box.center) if pre_tmom is not None else None, _ptr(pre_tmom), _ptr(wsum), b, c, h, w, d,
                       cfg.res, int(cfg.fuse), dt, layout, cfg.act, st)
             if pre_tmom is not None:
                 cfg.pre_box.put(dx, pre_tmom, rows)
         else:
             bmom = torch.empty((b, c, L.BWD_MOMENTS), dtype=torch.float32, device=dev)
-            _call("mrla_light_stats_bwd", xc.numel() * xc.element_size() * (3 if oc is not None else 2), _ptr(dout), _ptr(xc), _ptr(oc), _ptr(wv32), _ptr(mom), _ptr(bmom), b, c, h, w, dt, layout,
-                   cfg.act, st)
+            if lean:
+                _call("mrla_light_stats_bwd_fused", nb * 3, _ptr(dout), _ptr(pre), _ptr(psc), _ptr(psh), _ptr(oc), _ptr(wv32),
+                      _ptr(mom), _ptr(bmom), b, c, h, w, dt, layout, st)
+            else:
+                _call("mrla_light_stats_bwd", nb * (3 if oc is not None else 2), _ptr(dout), _ptr(xc), _ptr(oc), _ptr(wv32),
+                      _ptr(mom), _ptr(bmom), b, c, h, w, dt, layout, cfg.act, st)
             small = torch.empty((11, c), dtype=torch.float32, device=dev)     # cb[c,4] | dgamma | dbeta | dlam | cb_lo[c,4]
             cb, cb_lo = small[:4].view(c, 4), small[7:].view(c, 4)
             has_bn = cfg.bn_mode != L.BN_NONE
@@ -463,22 +489,28 @@ class _LightFn(torch.autograd.Function):
             rows = L.load().mrla_light_wgrad_rows(b, c, h, w, dt, layout)
             L.check(min(rows, 0), "mrla_light_wgrad_rows")
             dwv_part = torch.empty((rows, c * 9), dtype=torch.float32, device=dev)
-            dx = torch.empty_like(xc)
+            dx = torch.empty_like(like)
             do = torch.empty_like(oc) if oc is not None else None
             # the deferred bn3's backward sums (sum dpre, sum dpre*y3) ride in this pass: one more row fetch, no 2N pass
             pre_tmom = None
-            if pre is not None and (b * h * w) % rows == 0:
+            if ctx.pre_sums and pre is not None and (b * h * w) % rows == 0:
                 pre_tmom = torch.empty((rows, c, 2), dtype=torch.float32, device=dev)
-            else:
+            elif not lean:
                 pre = None
-            _call("mrla_light_apply_bwd", xc.numel() * xc.element_size() * ((5 if oc is not None else 3) + (pre is not None)),
-                  _ptr(dout), _ptr(xc), _ptr(oc), _ptr(wv32), _ptr(gate), _ptr(cb), _ptr(lam32),
-                  _ptr(dp32), _ptr(dyx), _ptr(dx), _ptr(do), _ptr(dwv_part), _ptr(pre),
-                  _ptr(cfg.pre_box.center) if pre is not None else None, _ptr(pre_tmom), b, c, h, w, d, cfg.res,
-                  int(cfg.fuse), dt, layout, cfg.act, st,
-                  # section 8(d): dOut, x_t, o_prev in; dx, do out (the y3 row read for bn3's folded sums is not in that count)
-                  alg=xc.numel() * xc.element_size() * (5 if oc is not None else 3),
-                  path=xc.numel() * xc.element_size() * (5 if oc is not None else 3))
+            if lean:
+                # dOut, y3, o_prev in; dx, do out: section 8(d)'s five passes exactly (x_t is re-formed, bn3's sums ride along)
+                _call("mrla_light_apply_bwd", nb * 5, _ptr(dout), _ptr(pre), _ptr(psc), _ptr(psh), _ptr(oc), _ptr(wv32),
+                      _ptr(gate), _ptr(cb), _ptr(lam32), _ptr(dp32), _ptr(dyx), _ptr(dx), _ptr(do), _ptr(dwv_part),
+                      _ptr(cfg.pre_box.center) if pre_tmom is not None else None, _ptr(pre_tmom), b, c, h, w, d, cfg.res, dt,
+                      layout, st, entry="mrla_light_apply_bwd_fused", alg=nb * 5, path=nb * 5)
+            else:
+                _call("mrla_light_apply_bwd", nb * ((5 if oc is not None else 3) + (pre is not None)),
+                      _ptr(dout), _ptr(xc), _ptr(oc), _ptr(wv32), _ptr(gate), _ptr(cb), _ptr(lam32),
+                      _ptr(dp32), _ptr(dyx), _ptr(dx), _ptr(do), _ptr(dwv_part), _ptr(pre),
+                      _ptr(cfg.pre_box.center) if pre is not None else None, _ptr(pre_tmom), b, c, h, w, d, cfg.res,
+                      int(cfg.fuse), dt, layout, cfg.act, st,
+                      # section 8(d): dOut, x_t, o_prev in; dx, do out (the y3 row read for bn3's folded sums is not in that count)
+                      alg=nb * (5 if oc is not None else 3), path=nb * (5 if oc is not None else 3))
             if pre_tmom is not None:
                 cfg.pre_box.put(dx, pre_tmom, rows)
             wsum = torch.empty((c * 9 + 2 * ks,), dtype=torch.float32, device=dev)
@@ -1460,12 +1492,14 @@ class _SubsampleFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, sh, sw):
         ctx.shape, ctx.s = x.shape, (sh, sw)
-        return x[:, :, ::sh, ::sw].contiguous(memory_format=_CL)
+        # (the memory format of the input is kept: NCHW models stay NCHW)
+        ctx.fmt = _CL if x.is_contiguous(memory_format=_CL) and not x.is_contiguous() else torch.contiguous_format
+        return x[:, :, ::sh, ::sw].contiguous(memory_format=ctx.fmt)
 
     @staticmethod
     def backward(ctx, g):
         sh, sw = ctx.s
-        dx = torch.empty(ctx.shape, dtype=g.dtype, device=g.device, memory_format=_CL).zero_()
+        dx = torch.empty(ctx.shape, dtype=g.dtype, device=g.device, memory_format=ctx.fmt).zero_()
         dx[:, :, ::sh, ::sw] = g
         return dx, None, None
 
@@ -1529,5 +1563,11 @@ def conv_bn_act(x, conv, bn, relu, defer=False, passthrough=False):
         y, part = _Conv1x1Fn.apply(x, wt, bool(fused_bn and bn.training), False, w16, w16t)
         out = bn_act(y, bn, relu, defer, pre_moments=part if part.numel() else None)
         return (out, x) if passthrough else out
+    if _strided_1x1(conv) and not passthrough and x.dim() == 4 and x.is_cuda:
+        # every other dtype / layout (resnet/train.py itself trains in fp32, :397-409): still the stride-1 convolution on the
+        # subsampled input -- a plain GEMM for MIOpen, whose input gradient needs no zero-fill + scatter; the zero-fill and
+        # the strided copy of _SubsampleFn are ordinary captured kernels.  (F.conv2d: autocast casts as for the module.)
+        xs = _SubsampleFn.apply(x, conv.stride[0], conv.stride[1])
+        return bn_act(torch.nn.functional.conv2d(xs, conv.weight), bn, relu, defer)
     out = bn_act(conv(x), bn, relu, defer)
     return (out, x) if passthrough else out

@@ -50,12 +50,34 @@ class _LinearFn(torch.autograd.Function):
         if ctx.has_bias and ctx.needs_input_grad[2]:
             if dy.dim() == 3 and dy.is_contiguous():
                 # per image first ([b, 1, n] x [b, n, N] -> b x N partial sums: b independent products fill the chip; ONE
-                # product over all b*n rows is a 50 000-long reduction in N/64 workgroups: +2 ms per deit_mrlal_tiny step)
-                part = torch.bmm(dy.new_ones((dy.shape[0], 1, dy.shape[1])), dy).view(dy.shape[0], -1)
-                db = (part.new_ones((1, part.shape[0])) @ part).view(-1)
+                # product over all b*n rows is a 50 000-long reduction in N/64 workgroups: +2 ms per deit_mrlal_tiny step).
+                # The partial sums stay in fp32 where the batched product can return them (no second rounding, no fp16
+                # overflow of a partial under a GradScaler's scale); the sum over the images is an fp32 product either way.
+                part = _bmm_f32(dy.new_ones((dy.shape[0], 1, dy.shape[1])), dy).view(dy.shape[0], -1)
+                db = (part.new_ones((1, part.shape[0])) @ part).view(-1).to(dy.dtype)
             else:
                 db = (dy2.new_ones((1, dy2.shape[0])) @ dy2).view(-1)
         return dx, dw, db
+
+
+_BMM_OUT_F32 = None        # does torch.bmm take out_dtype=float32 for 16-bit operands on this build?  (asked once, on first use)
+
+
+def _bmm_f32(a, b):
+    """a @ b (batched) with the fp32 accumulator as the result where torch.bmm can hand it out, else the product in the
+    operands' dtype widened afterwards."""
+    global _BMM_OUT_F32
+    if a.dtype == torch.float32:
+        return torch.bmm(a, b)
+    if _BMM_OUT_F32 is None and not torch.cuda.is_current_stream_capturing():
+        try:
+            torch.bmm(a[:1, :, :1], b[:1, :1, :1], out_dtype=torch.float32)
+            _BMM_OUT_F32 = True
+        except (TypeError, RuntimeError):
+            _BMM_OUT_F32 = False
+    if _BMM_OUT_F32:
+        return torch.bmm(a, b, out_dtype=torch.float32)
+    return torch.bmm(a, b).float()
 
 
 def _linear(mod, x):

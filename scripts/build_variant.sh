@@ -10,7 +10,7 @@ cd "$ROOT/mrla_amd/csrc"
 make -j4 > /dev/null
 mkdir -p build/variants "$ROOT/scripts/variants"
 FLAGS="-O3 -std=c++17 --offload-arch=gfx950 -fPIC -ffp-contract=fast -Wall -Wno-unused-function"
-case $SRC in light_nhwc_bwd.hip|light_nhwc_wide.hip|tokens_nhwc.hip) FLAGS="$FLAGS -fno-slp-vectorize";; esac
+case $SRC in light_nhwc_bwd.hip|light_nhwc_wide.hip|light_nhwc_lean.hip|tokens_nhwc.hip) FLAGS="$FLAGS -fno-slp-vectorize";; esac
 OBJ=build/variants/${NAME}_${SRC%.hip}.o
 /opt/rocm/bin/hipcc $FLAGS $EXTRA -c $SRC -o $OBJ
 OTHERS=$(ls build/*.o | grep -v "build/${SRC%.hip}.o")

@@ -19,6 +19,8 @@ if os.environ.get("KBENCH_LIB"):
 import bench  # noqa: E402
 from mrla_amd import functional as Fm, models, vit  # noqa: E402
 
+if os.environ.get("MRLA_LEAN") is not None:       # A/B of the tail without a stored x_t (functional.LEAN) against the storing passes
+    Fm.LEAN = os.environ["MRLA_LEAN"] == "1"
 steps = int(sys.argv[1]) if len(sys.argv) > 1 else 10
 only = sys.argv[2] if len(sys.argv) > 2 else ""
 arch = sys.argv[3] if len(sys.argv) > 3 else "resnet50_mrlal"
@@ -52,7 +54,7 @@ for name, nbytes, e0, e1, alg, path in timer.records:
     d = rows.setdefault((name, nbytes), [0, 0.0])
     d[0] += 1
     d[1] += e0.elapsed_time(e1)
-out = {"lib": os.path.basename(L.LIB_PATH), "arch": arch, "batch": batch, "steps": steps,
+out = {"lib": os.path.basename(L.LIB_PATH), "lean": Fm.LEAN, "arch": arch, "batch": batch, "steps": steps,
        "eager_ms_per_step": round(1e3 * dt_plain / steps, 3), "events_ms_per_step": round(1e3 * dt / steps, 3), "kernels": []}
 tot = {}
 for (name, nbytes), (n, ms) in sorted(rows.items(), key=lambda kv: (kv[0][0], -kv[0][1])):

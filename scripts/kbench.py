@@ -83,6 +83,18 @@ for c, hw in STAGES:
                                                                   L.BF16, LAY, 0, st)),
         "stats_fused": (3, lambda: lib.mrla_light_stats_fwd_fused(P(g), P(bn[0]), P(bn[1]), P(o), P(wv), P(mom), P(out), B, c, hw, hw, L.BF16, LAY, st)),
     }
+    if LAY == L.NHWC and lib.mrla_light_lean_supported(B, c, hw, hw, L.BF16, LAY) == 1:
+        # the passes of the tail without a stored x_t (ABI 5): x_t re-formed from y3 (= g here), the affine (bn[0], bn[1]) and o
+        K.update({
+            "lean stats_fwd": (2, lambda: lib.mrla_light_stats_fwd_fused(P(g), P(bn[0]), P(bn[1]), P(o), P(wv), P(mom), None, B, c, hw, hw, L.BF16, LAY, st)),
+            "lean apply_fwd": (3, lambda: lib.mrla_light_apply_fwd_fused(P(g), P(bn[0]), P(bn[1]), P(o), P(wv), P(gate), P(bn[0]), P(bn[1]),
+                                                                         P(lam), P(dp), P(out), B, c, hw, hw, d, 1, L.BF16, LAY, st)),
+            "lean stats_bwd": (3, lambda: lib.mrla_light_stats_bwd_fused(P(x), P(g), P(bn[0]), P(bn[1]), P(o), P(wv), P(mom), P(bmom), B, c, hw, hw,
+                                                                         L.BF16, LAY, st)),
+            "lean apply_bwd": (5, lambda: lib.mrla_light_apply_bwd_fused(P(x), P(g), P(bn[0]), P(bn[1]), P(o), P(wv), P(gate), P(cb), P(lam), P(dp),
+                                                                         P(dyx), P(dx), P(do), P(dwv), P(bn[2]), P(pre_tmom), B, c, hw, hw, d, 1,
+                                                                         L.BF16, LAY, st)),
+        })
     for name, (passes, fn) in K.items():
         if only and only not in name:
             continue

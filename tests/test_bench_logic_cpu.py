@@ -1,4 +1,5 @@
-"""CPU: the decision logic of bench.py that cannot wait for an 8-GPU box to be exercised for the first time.
+"""CPU: the decision logic of bench.py (benchkit/ranks.py, benchkit/report.py) that cannot wait for an 8-GPU box to be exercised
+for the first time.
 
 * `measure_exchange_schedules`: a failure while capturing the OPTIONAL second exchange schedule must leave the first
   schedule's finished graph-replayed measurement standing -- mocked captures, no GPU.
@@ -13,7 +14,8 @@ import pytest
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
-import bench  # noqa: E402
+import bench  # noqa: E402  (re-exports the pieces below)
+from benchkit import ranks as bench_ranks, report as bench_report  # noqa: E402
 
 
 class _Clock:
@@ -105,8 +107,9 @@ def test_counter_passes_are_tied_to_the_library(tmp_path, monkeypatch):
 
     class A:
         arch, batch = "resnet50_mrlal", 256
-    monkeypatch.setattr(bench, "ROOT", str(tmp_path))
-    monkeypatch.setattr(bench, "library_identity", lambda: me)
+    assert bench.measure_exchange_schedules is bench_ranks.measure_exchange_schedules and bench.pmc_traffic is bench_report.pmc_traffic
+    monkeypatch.setattr(bench_report, "ROOT", str(tmp_path))
+    monkeypatch.setattr(bench_report, "library_identity", lambda: me)
     os.makedirs(tmp_path / "profiles")
     path = tmp_path / "profiles" / f"{bench.ROUND}_pmc_traffic_resnet50_mrlal_b256.json"
     rec = {"light_apply_bwd": {"hbm_bytes_per_launch": 1.1e9}}

@@ -539,3 +539,70 @@ def test_strided_downsample_convolution_on_the_gemm_matches_stock_modules(shape)
     for got, want, tol in ((bn.weight.grad, bn_r.weight.grad, 2e-2), (bn.bias.grad, bn_r.bias.grad, 2e-2),
                            (conv.weight.grad, conv_r.weight.grad, 3e-2), (xt.grad.float(), xr.grad, 3e-2)):
         assert ((got.float() - want).norm() / want.norm()).item() < tol
+
+
+@pytest.mark.parametrize("dtype,fmt", [(torch.float32, "nhwc"), (torch.float32, "nchw"), (torch.float16, "nhwc")])
+def test_strided_downsample_in_other_dtypes_is_the_stride_1_convolution_on_the_subsampled_input(dtype, fmt):
+    """resnet/train.py trains in fp32 (:397-409; no autocast) and deit's recipe is fp16: the strided 1x1 downsample convolution
+    (resnet_mrla_light.py:196-199) must not reach MIOpen as a STRIDED convolution in any dtype -- its input gradient is right
+    when launched eagerly and garbage from the second replay of a HIP graph on (profiles/r05_notes.md section 2).  conv_bn_act
+    subsamples and runs the stride-1 convolution: same outputs, running statistics and gradients as the stock strided modules
+    (fp32: to accumulation noise), exact zeros at the skipped pixels, the input's memory format kept -- and the input gradient
+    of three replays of a captured forward + backward equals the eagerly launched one."""
+    from mrla_amd import functional as Fm
+    b, h, w, k, n, st = 8, 14, 14, 64, 128, 2
+    cl = fmt == "nhwc"
+    torch.manual_seed(3)
+    conv = torch.nn.Conv2d(k, n, 1, stride=st, bias=False).cuda().to(dtype)
+    bn = torch.nn.BatchNorm2d(n).cuda()
+    if cl:
+        conv = conv.to(memory_format=torch.channels_last)
+    x0 = torch.randn(b, k, h, w, device="cuda").to(dtype)
+    x0 = x0.contiguous(memory_format=torch.channels_last) if cl else x0
+    gup = torch.randn(b, n, h // st, w // st, device="cuda").to(dtype)
+    gup = gup.contiguous(memory_format=torch.channels_last) if cl else gup
+    calls = []
+    orig = torch.nn.functional.conv2d
+    xt = x0.clone().requires_grad_(True)
+    try:
+        torch.nn.functional.conv2d = lambda inp, wt, *a, **kw: (calls.append((tuple(inp.shape), a, kw)), orig(inp, wt, *a, **kw))[1]
+        out = Fm.conv_bn_act(xt, conv, bn, relu=False)
+    finally:
+        torch.nn.functional.conv2d = orig
+    assert calls == [((b, k, h // st, w // st), (), {})], calls           # stride 1, on the subsampled input
+    out.backward(gup)
+    conv_r = torch.nn.Conv2d(k, n, 1, stride=st, bias=False).cuda().to(dtype)
+    bn_r = torch.nn.BatchNorm2d(n).cuda()
+    conv_r.load_state_dict(conv.state_dict())
+    xr = x0.clone().requires_grad_(True)
+    zr = bn_r(conv_r(xr))
+    zr.backward(gup)
+    tol = 1e-5 if dtype == torch.float32 else 2e-2
+    assert ((out.float() - zr.float()).norm() / zr.float().norm()).item() < tol
+    assert torch.allclose(bn.running_mean, bn_r.running_mean, rtol=1e-3, atol=1e-5)
+    assert torch.allclose(bn.running_var, bn_r.running_var, rtol=1e-3, atol=1e-5)
+    assert xt.grad.is_contiguous(memory_format=torch.channels_last if cl else torch.contiguous_format)
+    mask = torch.zeros(h, w, dtype=torch.bool, device="cuda")
+    mask[::st, ::st] = True
+    assert float(xt.grad[:, :, ~mask].abs().max()) == 0.0
+    for got, want in ((xt.grad, xr.grad), (conv.weight.grad, conv_r.weight.grad), (bn.weight.grad, bn_r.weight.grad)):
+        assert ((got.float() - want.float()).norm() / want.float().norm()).item() < 5 * tol
+    # under replay: the pool poisoned with NaN between replays (a solver that relies on memory it zeroed at capture time shows)
+    xs = x0.clone().requires_grad_(True)
+    bn.train()
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        for _ in range(2):
+            (gx,) = torch.autograd.grad(Fm.conv_bn_act(xs, conv, bn, relu=False), xs, gup)
+    torch.cuda.current_stream().wait_stream(side)
+    want = gx.detach().clone()
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph):
+        (gx_static,) = torch.autograd.grad(Fm.conv_bn_act(xs, conv, bn, relu=False), xs, gup)
+    for _ in range(3):
+        gx_static.fill_(float("nan"))
+        graph.replay()
+        torch.cuda.synchronize()
+        assert torch.isfinite(gx_static).all()
+        assert ((gx_static.float() - want.float()).norm() / want.float().norm()).item() < 5 * tol

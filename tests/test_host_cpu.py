@@ -20,7 +20,7 @@ def test_library_exports_every_declared_symbol():
         assert hasattr(lib, name), name
     # the version the header declares == what the library reports == what the ctypes binding was written against
     hdr_version = int(re.search(r"#define\s+MRLA_ABI_VERSION\s+(\d+)", hdr).group(1))
-    assert lib.mrla_abi_version() == hdr_version == _lib.ABI_VERSION == 4
+    assert lib.mrla_abi_version() == hdr_version == _lib.ABI_VERSION == 5
 
 
 def test_argument_validation_without_a_gpu():
@@ -57,7 +57,7 @@ def test_argument_validation_without_a_gpu():
     P = [None]
     assert lib.mrla_light_tail_fwd(*P * 6, 5, *P * 6, _lib.BN_TRAIN, 0.1, 1e-5, *P * 6, 2, 64, 8, 8, 32, 1, 1, _lib.BF16, _lib.NHWC,
                                    0, None) == _lib.EINVAL
-    assert lib.mrla_light_tail_bwd(*P * 5, 5, *P * 7, _lib.BN_TRAIN, *P * 5, 1, *P * 6, 2, 64, 8, 8, 32, 1, 1, _lib.BF16,
+    assert lib.mrla_light_tail_bwd(*P * 5, 5, *P * 7, _lib.BN_TRAIN, *P * 5, 1, *P * 8, 2, 64, 8, 8, 32, 1, 1, _lib.BF16,
                                    _lib.NHWC, 0, None) == _lib.EINVAL
     assert lib.mrla_bn_fwd(None, None, 0, None, None, 8, *P * 4, _lib.BN_TRAIN, 0.1, 1e-5, None, 1, None, 2, 64, 8, 8, _lib.BF16,
                            _lib.NHWC, None) == _lib.EINVAL

@@ -75,7 +75,7 @@ if ROOT not in sys.path:
 
 from benchkit import common  # noqa: E402
 from benchkit.common import ROUND, free_port, make_step, parse, sgd, timed  # noqa: E402,F401  (re-exported: scripts/, tests/)
-from benchkit.ranks import (CaptureBroken, all_ranks_ok, launch_ranks, measure_exchange_schedules,  # noqa: E402,F401
+from benchkit.ranks import (CaptureBroken, all_ranks_ok, launch_ranks, measure_exchange_schedules, rank0_first,  # noqa: E402,F401
                             ranks_seen)
 from benchkit.report import counters_current, library_identity, pmc_traffic, report  # noqa: E402,F401
 

@@ -9,7 +9,7 @@ import time
 
 import torch
 
-from .common import BENCH, OTHER_CONFIGS, ROOT, autocast, make_step, sgd, timed
+from .common import BENCH, DET_LR, OTHER_CONFIGS, ROOT, autocast, make_step, sgd, timed
 
 
 def cpu_model_name():
@@ -122,7 +122,7 @@ def eager_rocm_detection(x, steps=6):
     from oracle import eager_models as em
     torch.manual_seed(0)
     net = em.EagerDetBackbone(frozen_stages=1, norm_eval=True).cuda().to(memory_format=torch.channels_last).train()
-    opt = sgd(p for p in net.parameters() if p.requires_grad)
+    opt = sgd((p for p in net.parameters() if p.requires_grad), lr=DET_LR)
 
     def step():
         with autocast():

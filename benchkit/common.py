@@ -17,6 +17,7 @@ MFMA_BF16_PEAK_TFLOPS = 2500.0   # dense bf16 MFMA peak (same guide)
 MODEL_GFLOP_PER_IMAGE = {"resnet50_mrlal": 24.8, "resnet101_mrlab": 48.7}
 OTHER_CONFIGS = (("deit_mrlal_tiny_patch16_224", 256), ("resnet101_mrlab", 128))      # BASELINE.json configs 4 and 5
 STATUS_ENV = "MRLA_BENCH_STATUS_FILE"
+DET_LR = 1e-5             # the detection backbone is timed without a head: a loss on the raw feature maps wants a small step
 AUTOCAST = {"bf16": torch.bfloat16, "fp16": torch.float16, "none": None}
 DTYPE_NAME = {"bf16": "bf16", "fp16": "fp16", "none": "fp32"}
 
@@ -126,17 +127,17 @@ def make_step(net, opt, x, y, exchange=None):
 SGD_FUSED = True          # (--sgd-fused 0: the foreach implementation -- four multi-tensor passes instead of one)
 
 
-def sgd(params):
+def sgd(params, lr=0.1):
     """resnet/train.py:199-201: torch.optim.SGD(lr 0.1, momentum 0.9, weight decay 1e-4).  `fused=True` is the same optimizer
     in its single-pass implementation (gradient, weight and momentum buffer read once, weight and buffer written once: 5
     tensor-passes per step instead of foreach's 11); product run and eager baseline both use it."""
     params = list(params)
     if SGD_FUSED:
         try:
-            return torch.optim.SGD(params, lr=0.1, momentum=0.9, weight_decay=1e-4, fused=True)
+            return torch.optim.SGD(params, lr=lr, momentum=0.9, weight_decay=1e-4, fused=True)
         except (RuntimeError, TypeError, ValueError):
             pass
-    return torch.optim.SGD(params, lr=0.1, momentum=0.9, weight_decay=1e-4)
+    return torch.optim.SGD(params, lr=lr, momentum=0.9, weight_decay=1e-4)
 
 
 RANK_MS = {}              # per-rank step time of the latest timed() region: {"min": ..., "max": ...} (ms; N > 1 only)

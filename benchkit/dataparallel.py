@@ -14,7 +14,7 @@ import torch
 
 from . import common
 from .common import sgd, timed
-from .core import GRAPH_NOT_REPRODUCED, print_line_with
+from .core import GRAPH_NOT_REPRODUCED, prefer_ddp_line, print_line_with
 from .ranks import all_ranks_ok, capture, leave_without_the_communicator, measure_exchange_schedules
 from .report import report
 
@@ -47,18 +47,6 @@ def ddp_eager_first(run):
     torch.cuda.synchronize()
     R["ddp_first"] = rec
     return dt, line
-
-
-def never_worse_than_ddp(run, dt, ddp):
-    """The line that is about to be printed took `dt` for the region; tier 0 took ddp[0].  Returns True when tier 0's finished
-    line was printed instead."""
-    if ddp is None or dt <= ddp[0]:
-        return False
-    if run.rank == 0:
-        print(f"note: the tier that finished ({1e3 * dt / run.args.steps:.2f} ms per step) is slower than plain DistributedDataParallel "
-              f"launched eagerly ({1e3 * ddp[0] / run.args.steps:.2f} ms): reporting the latter", file=sys.stderr, flush=True)
-        print(ddp[1], flush=True)
-    return True
 
 
 def flat_split(run):
@@ -194,17 +182,17 @@ def flat_schedules(run):
         if chosen is None:
             # the first capture broke: the eager region measured before it (or tier 0, if that was faster)
             print("reporting the eager steps measured before it", file=sys.stderr, flush=True)
-            if not never_worse_than_ddp(run, state["eager"]["dt"], ddp) and rank == 0:
-                print_line_with(state["eager_line"], launch=(
-                    "kernel by kernel (PyTorch eager launches; the HIP graph capture of the step failed -- "
-                    f"{why} -- so this is the eager region timed before the capture; the communicator was not used again)"))
+            broke = ("kernel by kernel (PyTorch eager launches; the HIP graph capture of the step failed -- "
+                     f"{why} -- so this is the eager region timed before the capture; the communicator was not used again)")
+            if not prefer_ddp_line(run, state["eager"]["dt"], ddp, broke) and rank == 0:
+                print_line_with(state["eager_line"], launch=broke)
             leave_without_the_communicator(0)
         # an optional later schedule broke: the finished graph-replayed region of the earlier one stands
         print(f"reporting the finished graph-replayed region of schedule {chosen}", file=sys.stderr, flush=True)
-        if not never_worse_than_ddp(run, recs[chosen]["dt"], ddp) and rank == 0:
-            print_line_with(recs[chosen]["line"], gradient_exchange_ab_ms=ab_ms, launch_suffix=(
-                f" (schedule {chosen}; the capture of the optional schedule {fname} failed -- {why} -- after this region had "
-                "been timed; the communicator was not used again)"))
+        suffix = (f" (schedule {chosen}; the capture of the optional schedule {fname} failed -- {why} -- after this region had "
+                  "been timed; the communicator was not used again)")
+        if not prefer_ddp_line(run, recs[chosen]["dt"], ddp, run.graph_launch + suffix) and rank == 0:
+            print_line_with(recs[chosen]["line"], gradient_exchange_ab_ms=ab_ms, launch_suffix=suffix)
         leave_without_the_communicator(0)
     if chosen is None:                 # no replay reproduced the eager step: time the eager launches of schedule 0
         h = recs[names[0]]["handle"]
@@ -227,4 +215,4 @@ def flat_schedules(run):
     return ddp
 
 
-__all__ = ["ddp_eager_first", "flat_schedules", "flat_split", "never_worse_than_ddp"]
+__all__ = ["ddp_eager_first", "flat_schedules", "flat_split"]

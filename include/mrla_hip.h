@@ -66,7 +66,11 @@ enum { MRLA_BN_NONE = 0, MRLA_BN_TRAIN = 1, MRLA_BN_EVAL = 2 };
  *           the per-pass entry points are unchanged).
  *   4 -> 5: the training tail without a stored x_t (13N instead of 15N elements per block and step): mrla_light_lean_supported,
  *           mrla_light_stats_bwd_fused and mrla_light_apply_bwd_fused were added, mrla_light_stats_fwd_fused takes x_out = NULL,
- *           mrla_light_tail_fwd takes fuse = 2 and mrla_light_tail_bwd gained pre_sc / pre_sh (x = NULL selects that form).
+ *           mrla_light_tail_fwd takes fuse = 2 and mrla_light_tail_bwd gained pre_sc / pre_sh (x = NULL selects that form);
+ *           few, large images (detection batches): the backward passes spread an image's column strips over more workgroups --
+ *           mrla_light_wgrad_rows counts the extra partial rows, mrla_light_bmom_splits was added and mrla_light_bn_bwd /
+ *           mrla_light_gate_bwd gained bmom_splits (bmom is [bmom_splits, b, c, MRLA_BWD_MOMENTS]); mrla_light_mom_splits was
+ *           added (mom of mrla_light_stats_fwd / _fused / mrla_light_tail_fwd is [mom_splits, b, c, MRLA_FWD_MOMENTS]).
  * A consumer compares mrla_abi_version() (what the loaded library was built from) against this constant before its
  * first call. */
 #define MRLA_ABI_VERSION 5
@@ -81,6 +85,10 @@ int mrla_light_wgrad_rows(int b, int c, int h, int w, int dtype, int layout);
  * Replaces: avg_pool + Wv conv of mrla_light_module.py:56,61 (deit_mrla_light.py:161,166-167) as the
  * producer of everything the gate and the train-mode bn_mrla statistics (resnet_mrla_light.py:116)
  * need.  o_prev [opt]: block input `identity` (resnet_mrla_light.py:110-111). */
+/* mom is [mrla_light_mom_splits(), b, c, MRLA_FWD_MOMENTS] floats (ABI 5): 1 at the classification batches; for few, large
+ * images the statistics passes spread an image's column strips over that many workgroup ranges, each leaving its record in
+ * mom[z], and fold them into mom[0] -- the [b, c, MRLA_FWD_MOMENTS] block every other entry point reads. */
+int mrla_light_mom_splits(int b, int c, int h, int w, int dtype, int layout);
 int mrla_light_stats_fwd(const void* x, const void* o_prev, const float* wv /*[c,3,3]*/, float* mom,
                          int b, int c, int h, int w, int dtype, int layout, int act, void* stream);
 
@@ -133,11 +141,15 @@ int mrla_light_apply_fwd(const void* x, const void* o_prev, const float* wv, con
                          const float* sh, const float* lam, const float* dp, void* out, int b, int c, int h, int w,
                          int d, int res, int dtype, int layout, int act, void* stream);
 
-/* ---- backward pass 1 of 2: bmom[b, c, 3] ---------------------------------------------------------
+/* ---- backward pass 1 of 2: bmom[splits, b, c, 3] ---------------------------------------------------
  * The reductions autograd performs in MulBackward / ExpandBackward / NativeBatchNormBackward.
+ * splits = mrla_light_bmom_splits(): 1 at the classification batches; for few, large images (a detection batch: 2 x 256 x
+ * 200 x 336) the pass spreads an image's column strips over `splits` workgroup ranges, each leaving its own partial record;
+ * mrla_light_bn_bwd / mrla_light_gate_bwd (bmom_splits) add them in range order.
  * mom: the forward record of the same block (mrla_light_stats_fwd*): the sums over dOut*V and dOut*o are taken about its
  * pivots (pV, pO), so that what survives the cancellations of the BatchNorm backward keeps fp32 accuracy when
  * |mean| >> sigma; mrla_light_bn_bwd / mrla_light_gate_bwd (given the same mom) undo the shift in double. */
+int mrla_light_bmom_splits(int b, int c, int h, int w, int dtype, int layout);
 int mrla_light_stats_bwd(const void* dout, const void* x, const void* o_prev, const float* wv, const float* mom,
                          float* bmom, int b, int c, int h, int w, int dtype, int layout, int act, void* stream);
 
@@ -149,7 +161,8 @@ int mrla_light_stats_bwd(const void* dout, const void* x, const void* o_prev, co
  * lam, dp, dlam [opt]. */
 int mrla_light_bn_bwd(const float* mom, const float* bmom, const float* gate, const float* lam, const float* gamma,
                       const float* dp, const float* save_mean, const float* save_inv, int bn_mode, float* cb,
-                      float* cb_lo, float* dgamma, float* dbeta, float* dlam, int b, int c, int hw, int d, void* stream);
+                      float* cb_lo, float* dgamma, float* dbeta, float* dlam, int b, int c, int hw, int d, int bmom_splits,
+                      void* stream);
 
 /* ---- gate backward -------------------------------------------------------------------------------
  * dyx[b, c] = (gradient wrt the pooled descriptor y) / hw ; dwqk_part[b, 2*ksize] = per-image partial
@@ -157,7 +170,7 @@ int mrla_light_bn_bwd(const float* mom, const float* bmom, const float* gate, co
 int mrla_light_gate_bwd(const float* mom, const float* bmom, const float* gate, const float* cb, const float* cb_lo,
                         const float* dp,
                         const float* wq, const float* wk, int ksize, float* dyx, float* dwqk_part, int b, int c,
-                        int hw, int d, void* stream);
+                        int hw, int d, int bmom_splits, void* stream);
 
 /* ---- backward pass 2 of 2 ------------------------------------------------------------------------
  * dx = res*dOut + dwconv^T(a*dm*act'(U)) + dyx ;  do_prev = lam*dm ;  dwv_part[rows, c, 9] partial sums

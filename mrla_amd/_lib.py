@@ -32,8 +32,10 @@ SIGNATURES = {
     "mrla_light_bn_fwd": [_P, _P, _P, _P, _P, _P, _P, _I, _F, _F, _P, _P, _P, _P, _I, _I, _I, _I, _P],
     "mrla_light_apply_fwd": [_P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P],
     "mrla_light_stats_bwd": [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P],
-    "mrla_light_bn_bwd": [_P, _P, _P, _P, _P, _P, _P, _P, _I, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P],
-    "mrla_light_gate_bwd": [_P, _P, _P, _P, _P, _P, _P, _P, _I, _P, _P, _I, _I, _I, _I, _P],
+    "mrla_light_bmom_splits": [_I] * 6,
+    "mrla_light_mom_splits": [_I] * 6,
+    "mrla_light_bn_bwd": [_P, _P, _P, _P, _P, _P, _P, _P, _I, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P],
+    "mrla_light_gate_bwd": [_P, _P, _P, _P, _P, _P, _P, _P, _I, _P, _P, _I, _I, _I, _I, _I, _P],
     "mrla_light_apply_bwd_pre_sums": [_I] * 6,
     "mrla_light_apply_bwd": [_P] * 15 + [_I] * 10 + [_P],
     "mrla_light_lean_supported": [_I] * 6,

@@ -270,14 +270,14 @@ __global__ __launch_bounds__(kBwdWaves * kWave) void light_apply_bwd_wide_pk(
   wg_reduce<9>(wg, red, lane, wave, nwaves, wc);
   if (wave < wc) {
 #pragma unroll
-    for (int k = 0; k < 9; ++k) dwv_part[((size_t)blockIdx.y * C + c) * 9 + k] = wg[k];
+    for (int k = 0; k < 9; ++k) dwv_part[(((size_t)blockIdx.z * gridDim.y + blockIdx.y) * C + c) * 9 + k] = wg[k];
   }
   if (PRE) {
     float pm[2] = {pm0.x + pm0.y, pm1.x + pm1.y};
     wg_reduce<2>(pm, red, lane, wave, nwaves, wc);
     if (wave < wc) {
-      pre_tmom[((size_t)blockIdx.y * C + c) * 2 + 0] = pm[0];
-      pre_tmom[((size_t)blockIdx.y * C + c) * 2 + 1] = pm[1];
+      pre_tmom[(((size_t)blockIdx.z * gridDim.y + blockIdx.y) * C + c) * 2 + 0] = pm[0];
+      pre_tmom[(((size_t)blockIdx.z * gridDim.y + blockIdx.y) * C + c) * 2 + 1] = pm[1];
     }
   }
 }

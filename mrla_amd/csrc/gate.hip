@@ -5,10 +5,25 @@
 // Reference statements covered: mrla_light_module.py:59-60,67,70 (Wq/Wk conv1d, per-head dot product,
 // sigmoid); nn.BatchNorm2d statistics / running update / backward of `bn_mrla`
 // (resnet_mrla_light.py:85,116); the reductions autograd performs for lambda_t, Wq, Wk.
+#include <algorithm>
+
 #include "mrla_device.h"
 #include "mrla_kernels.h"
 
 namespace mrla {
+
+// The backward statistics pass may leave `nsplit` partial records per (image, channel) (strip ranges, mrla_light_bmom_splits):
+// bmom[nsplit][B][C][D_N]; their sum, taken in range order.
+struct BwdMoments { float d, dv, d_o; };
+__device__ __forceinline__ BwdMoments load_bmom(const float* __restrict__ bmom, int b, int c, int B, int C, int nsplit) {
+  const float* p = bmom + ((size_t)b * C + c) * D_N;
+  BwdMoments r = {p[D_D], p[D_DV], p[D_DO]};
+  for (int z = 1; z < nsplit; ++z) {
+    p += (size_t)B * C * D_N;
+    r.d += p[D_D]; r.dv += p[D_DV]; r.d_o += p[D_DO];
+  }
+  return r;
+}
 
 constexpr int kBnCh = 4;                     // channels per workgroup in the per-channel kernels (more, smaller workgroups:
                                              // C/4 of them, 64 image lanes each -- these kernels are latency-bound)
@@ -111,7 +126,7 @@ __global__ __launch_bounds__(kThreads) void bn_bwd_kernel(
     const float* __restrict__ lam, const float* __restrict__ gamma, const float* __restrict__ dp,
     const float* __restrict__ save_mean, const float* __restrict__ save_inv, int training, float* __restrict__ cb,
     float* __restrict__ cb_lo, float* __restrict__ dgamma, float* __restrict__ dbeta, float* __restrict__ dlam, int B,
-    int C, int HW, int d) {
+    int C, int HW, int d, int nsplit) {
   __shared__ double r1[kBnLanes][kBnCh], r2[kBnLanes][kBnCh];
   __shared__ double coef[4][kBnCh];
   const int cc = threadIdx.x % kBnCh, bl = threadIdx.x / kBnCh;
@@ -123,13 +138,13 @@ __global__ __launch_bounds__(kThreads) void bn_bwd_kernel(
   if (live) {
 #pragma unroll 4
     for (int b = bl; b < B; b += kBnLanes) {
-      const float* bm = bmom + ((size_t)b * C + c) * D_N;
+      const BwdMoments bm = load_bmom(bmom, b, c, B, C, nsplit);
       const float* m = mom + ((size_t)b * C + c) * M_REC;
       const float a = gate[(size_t)b * G + c / d];
       const double dpb = dp ? dp[b] : 1.f;
       // (bmom's sums over dOut*V and dOut*o are about the forward pivots: un-shift in double)
-      const double dv = (double)bm[D_DV] + (double)m[M_PV] * bm[D_D], dO = (double)bm[D_DO] + (double)m[M_PO] * bm[D_D];
-      s1 += dpb * bm[D_D];
+      const double dv = (double)bm.dv + (double)m[M_PV] * bm.d, dO = (double)bm.d_o + (double)m[M_PO] * bm.d;
+      s1 += dpb * bm.d;
       s2 += dpb * ((double)a * dv + (double)l * dO);
     }
   }
@@ -173,13 +188,13 @@ __global__ __launch_bounds__(kThreads) void bn_bwd_kernel(
     const double P0 = mom[(size_t)c * M_REC + M_PO];                 // image 0's pivot of o for this channel
     for (int b = bl; b < B; b += kBnLanes) {
       const float* m = mom + ((size_t)b * C + c) * M_REC;
-      const float* bm = bmom + ((size_t)b * C + c) * D_N;
+      const BwdMoments bm = load_bmom(bmom, b, c, B, C, nsplit);
       const double a = gate[(size_t)b * G + c / d];
       const double dpb = dp ? dp[b] : 1.f;
       const double n = (double)HW, pv = m[M_PV], po = m[M_PO];
       const double so = m[M_SO], sv = m[M_SV];                       // shifted: sum (o - po), sum (V - pv)
-      const double dm_o = e * dpb * bm[D_DO] + f * a * ((double)m[M_SVO] + pv * so) + Gc * ((double)m[M_SOO] + po * so) + Hc * so;
-      const double dm_1 = e * dpb * bm[D_D] + f * a * (sv + n * pv) + Gc * (so + n * po) + Hc * n;
+      const double dm_o = e * dpb * bm.d_o + f * a * ((double)m[M_SVO] + pv * so) + Gc * ((double)m[M_SOO] + po * so) + Hc * so;
+      const double dm_1 = e * dpb * bm.d + f * a * (sv + n * pv) + Gc * (so + n * po) + Hc * n;
       s3 += dm_o + (po - P0) * dm_1;
       st += dm_1;
     }
@@ -213,7 +228,7 @@ __global__ __launch_bounds__(kThreads) void gate_bwd_kernel(
     const float* __restrict__ mom, const float* __restrict__ bmom, const float* __restrict__ gate,
     const float* __restrict__ cb, const float* __restrict__ cb_lo, const float* __restrict__ dp,
     const float* __restrict__ wq, const float* __restrict__ wk, int ks, float* __restrict__ dyx,
-    float* __restrict__ dwqk_part, int C, int HW, int d, float* __restrict__ tok_part, int tok_bands) {
+    float* __restrict__ dwqk_part, int C, int HW, int d, float* __restrict__ tok_part, int tok_bands, int nsplit) {
   extern __shared__ float sm[];
   const int p = (ks - 1) / 2;
   const int CPD = C + 2 * p;
@@ -244,14 +259,14 @@ __global__ __launch_bounds__(kThreads) void gate_bwd_kernel(
     qs[c] = q;
     kk[c] = k;
     const float* m = mom + ((size_t)b * C + c) * M_REC;
-    const float* bm = bmom + ((size_t)b * C + c) * D_N;
+    const BwdMoments bm = load_bmom(bmom, b, c, (int)gridDim.x, C, nsplit);
     const float a = gate[(size_t)b * G + c / d];
     double e = 1.0, f = 0.0, Gc = 0.0, Hc = 0.0;
     if (cb) { e = cb[c * 4 + 0]; f = cb[c * 4 + 1]; Gc = cb[c * 4 + 2]; Hc = cb[c * 4 + 3]; }
     if (cb && cb_lo) { e += cb_lo[c * 4 + 0]; f += cb_lo[c * 4 + 1]; Gc += cb_lo[c * 4 + 2]; Hc += cb_lo[c * 4 + 3]; }
     // sum_hw dm * V  for this channel
     const RawMoments r = raw_moments(m, (double)HW);
-    dqs[p + c] = (float)(e * dpb * ((double)bm[D_DV] + (double)m[M_PV] * bm[D_D]) + f * a * r.svv + Gc * r.svo + Hc * r.sv);
+    dqs[p + c] = (float)(e * dpb * ((double)bm.dv + (double)m[M_PV] * bm.d) + f * a * r.svv + Gc * r.svo + Hc * r.sv);
   }
   __syncthreads();
   const float s = rsqrtf((float)d);
@@ -361,20 +376,20 @@ int launch_bn_fwd(const float* mom, const float* gate, const float* lam, const f
 
 int launch_bn_bwd(const float* mom, const float* bmom, const float* gate, const float* lam, const float* gamma,
                   const float* dp, const float* save_mean, const float* save_inv, int training, float* cb, float* cb_lo,
-                  float* dgamma, float* dbeta, float* dlam, int B, int C, int HW, int d, hipStream_t st) {
+                  float* dgamma, float* dbeta, float* dlam, int B, int C, int HW, int d, hipStream_t st, int nsplit) {
   hipLaunchKernelGGL(bn_bwd_kernel, dim3((C + kBnCh - 1) / kBnCh), dim3(kThreads), 0, st, mom, bmom, gate, lam, gamma,
-                     dp, save_mean, save_inv, training, cb, cb_lo, dgamma, dbeta, dlam, B, C, HW, d);
+                     dp, save_mean, save_inv, training, cb, cb_lo, dgamma, dbeta, dlam, B, C, HW, d, std::max(1, nsplit));
   return hip_status(hipGetLastError());
 }
 
 int launch_gate_bwd(const float* mom, const float* bmom, const float* gate, const float* cb, const float* cb_lo,
                     const float* dp, const float* wq, const float* wk, int ks, float* dyx, float* dwqk_part, int B, int C, int HW,
-                    int d, hipStream_t st, float* tok_part, int tok_bands) {
+                    int d, hipStream_t st, float* tok_part, int tok_bands, int nsplit) {
   const int p = (ks - 1) / 2;
   const size_t lds = (size_t)(3 * (C + 2 * p) + 2 * C + C / d + kWaves) * sizeof(float);
   if (lds > 64 * 1024) return MRLA_EUNSUPPORTED;
   hipLaunchKernelGGL(gate_bwd_kernel, dim3(B), dim3(kThreads), lds, st, mom, bmom, gate, cb, cb_lo, dp, wq, wk, ks, dyx,
-                     dwqk_part, C, HW, d, tok_part, tok_bands);
+                     dwqk_part, C, HW, d, tok_part, tok_bands, std::max(1, nsplit));
   return hip_status(hipGetLastError());
 }
 

@@ -349,10 +349,10 @@ __global__ __launch_bounds__(kMaxStrips * kWave) void light_stats_bwd_nhwc(
 
 int launch_light_stats_fwd_nhwc(const void* x, const void* o, const float* wv, float* mom, void* xout,
                                 const float* psc, const float* psh, void* vout, int B, int C, int H, int W, int dtype,
-                                int act, hipStream_t st, bool fused_no_x) {
+                                int act, hipStream_t st, bool fused_no_x, int mom_ranges) {
   const NhwcLaunch L = nhwc_launch(B, C, W, M_N, dtype);
   if (L.wide)          // C % 64 == 0: the LDS-DMA row pipeline (light_nhwc_wide.hip)
-    return launch_light_stats_fwd_wide(x, o, wv, mom, xout, psc, psh, vout, B, C, H, W, dtype, act, st, fused_no_x);
+    return launch_light_stats_fwd_wide(x, o, wv, mom, xout, psc, psh, vout, B, C, H, W, dtype, act, st, fused_no_x, mom_ranges);
   if (fused_no_x) return MRLA_EUNSUPPORTED;       // (x_t stays unmaterialised on the row pipeline only)
 #define CALL_W(T, A, O, F, WD)                                                                                       \
   {                                                                                                                  \

@@ -139,7 +139,7 @@ __global__ __launch_bounds__(kMaxStrips * kWave) __attribute__((amdgpu_waves_per
     wg_reduce<D_N>(acc, red, lane, wave, nwaves, wc);
     if (wave < wc) {
 #pragma unroll
-      for (int k = 0; k < D_N; ++k) bmom[((size_t)b * C + c) * D_N + k] = acc[k];
+      for (int k = 0; k < D_N; ++k) bmom[(((size_t)blockIdx.z * B + b) * C + c) * D_N + k] = acc[k];      // (range z's record)
     }
   }
 }
@@ -327,13 +327,13 @@ __global__ __launch_bounds__(kBwdWaves * kWave) void light_apply_bwd_lean_wide(
   wg_reduce<9>(wg, red, lane, wave, nwaves, wc);
   if (wave < wc) {
 #pragma unroll
-    for (int k = 0; k < 9; ++k) dwv_part[((size_t)blockIdx.y * C + c) * 9 + k] = wg[k];
+    for (int k = 0; k < 9; ++k) dwv_part[(((size_t)blockIdx.z * gridDim.y + blockIdx.y) * C + c) * 9 + k] = wg[k];
   }
   if (PRE) {
     wg_reduce<2>(pm, red, lane, wave, nwaves, wc);
     if (wave < wc) {
-      pre_tmom[((size_t)blockIdx.y * C + c) * 2 + 0] = pm[0];
-      pre_tmom[((size_t)blockIdx.y * C + c) * 2 + 1] = pm[1];
+      pre_tmom[(((size_t)blockIdx.z * gridDim.y + blockIdx.y) * C + c) * 2 + 0] = pm[0];
+      pre_tmom[(((size_t)blockIdx.z * gridDim.y + blockIdx.y) * C + c) * 2 + 1] = pm[1];
     }
   }
 }
@@ -352,7 +352,7 @@ int launch_light_stats_bwd_lean_wide(const void* dout, const void* pre, const vo
   const bool ragged = (W % kS) != 0;
 #define CALL_K(T, AF, RG)                                                                                          \
   {                                                                                                                \
-    const WideLaunch L = wide_launch(P_STATS_FUSED, B, C, W, D_N, stats_bwd_lean_wave_bytes<T>(), 0, false);       \
+    const WideLaunch L = wide_launch(P_STATS_BWD, B, C, W, D_N, stats_bwd_lean_wave_bytes<T>(), 0, false, nhwc_bmom_ranges(B, C, W)); \
     if (set_lds_n(light_stats_bwd_lean_wide<T, AF, RG>, L.lds) != hipSuccess) return MRLA_EHIP;                     \
     hipLaunchKernelGGL((light_stats_bwd_lean_wide<T, AF, RG>), L.grid, L.block, L.lds, st, (const T*)dout,          \
                        (const T*)pre, (const T*)o, wv, psc, psh, mom, bmom, B, C, H, W, L.BG, L.wc);               \
@@ -373,10 +373,11 @@ int launch_light_apply_bwd_lean_wide(const void* dout, const void* pre, const vo
                                      int dtype, hipStream_t st) {
   if (!light_lean_supported(B, C, H, W, dtype)) return MRLA_EUNSUPPORTED;
   const bool ragged = (W % kS) != 0;
-  const int bg = nhwc_images_per_group(B, C, W);          // = the rows mrla_light_wgrad_rows() promised
+  const int bg = nhwc_images_per_group(B, C, W);          // image groups x strip ranges = the rows mrla_light_wgrad_rows() promised
+  const int nz = nhwc_wgrad_ranges(B, C, W);
 #define CALL_K(T, AF, RG, PR)                                                                                      \
   {                                                                                                                \
-    const WideLaunch L = wide_launch(P_APPLY_BWD, B, C, W, 9, apply_bwd_lean_wave_bytes<T>(), bg, false);          \
+    const WideLaunch L = wide_launch(P_APPLY_BWD, B, C, W, 9, apply_bwd_lean_wave_bytes<T>(), bg, false, nz);      \
     if (set_lds_n(light_apply_bwd_lean_wide<T, AF, RG, PR>, L.lds) != hipSuccess) return MRLA_EHIP;                 \
     hipLaunchKernelGGL((light_apply_bwd_lean_wide<T, AF, RG, PR>), L.grid, L.block, L.lds, st, (const T*)dout,      \
                        (const T*)pre, (const T*)o, wv, psc, psh, gate, cb, lam, dp, dyx, (T*)dx, (T*)dprev,         \

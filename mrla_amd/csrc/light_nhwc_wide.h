@@ -158,13 +158,19 @@ static inline void wide_shape(WidePass pass, int C, int W, int* wc_out, int* ws_
 }
 
 int nhwc_images_per_group(int B, int C, int W);
+int nhwc_wgrad_ranges(int B, int C, int W);       // strip ranges of the dWv-producing backward passes (rows = image groups x ranges)
+int nhwc_bmom_ranges(int B, int C, int W);        // ... of the backward statistics pass (partial records)
+int nhwc_mom_ranges(int B, int C, int W);         // ... of the forward statistics passes (records mom[z], merged into mom[0])
 
-static inline WideLaunch wide_launch(WidePass pass, int B, int C, int W, int nred, size_t wave_bytes, int bg, bool split) {
+// split: every strip round of an image gets its own workgroup (gridDim.z; passes that keep no sums over the plane);
+// nz > 1: the strips are cut into that many ranges (passes WITH sums: every range leaves its own partial record / row).
+static inline WideLaunch wide_launch(WidePass pass, int B, int C, int W, int nred, size_t wave_bytes, int bg, bool split,
+                                     int nz_ranges = 1) {
   WideLaunch L;
   const int ncg = C / kWave, nstrips = (W + kS - 1) / kS;
   int wc, ws;
   wide_shape(pass, C, W, &wc, &ws);
-  const int nz = split ? (nstrips + ws - 1) / ws : 1;
+  const int nz = split ? (nstrips + ws - 1) / ws : std::max(1, nz_ranges);
   if (bg <= 0) bg = (int)std::max(1L, std::min(8L, (long)B * (ncg / wc) * nz / 2048));
   L.wc = wc;
   L.BG = bg;
@@ -174,6 +180,23 @@ static inline WideLaunch wide_launch(WidePass pass, int B, int C, int W, int nre
   return L;
 }
 
+// Strip ranges (gridDim.z) of the passes that keep sums over the plane.  At the classification batches a workgroup walks all
+// strips of its images and the grid still fills the chip several times (1 range).  A detection batch does not: 2 images of
+// 256 x 200 x 336 are 4 channel groups x 2 images = 8 workgroups of eight waves walking 48 strips six rounds each on 256 CUs
+// (round 6: mrla_light_apply_bwd 781 us per launch = 0.44 TB/s, mrla_light_stats_bwd 0.15 TB/s at 2 x 3 x 800 x 1344).  So when
+// the launch would leave most CUs without a workgroup, the strip rounds are spread over gridDim.z -- each range writes its
+// own partial row (dWv / bn3 sums: mrla_light_wgrad_rows counts them) or partial record (mrla_light_bmom_splits), summed
+// by the consumers in range order.
+static inline int wide_strip_ranges(WidePass pass, int B, int C, int W, int bg) {
+  int wc, ws;
+  wide_shape(pass, C, W, &wc, &ws);
+  const int nstrips = (W + kS - 1) / kS, rounds = (nstrips + ws - 1) / ws;
+  if (rounds <= 1) return 1;
+  if (bg <= 0) bg = (int)std::max(1L, std::min(8L, (long)B * (C / kWave / wc) / 2048));
+  const long wgs = (long)(C / kWave / wc) * ((B + bg - 1) / bg);
+  if (wgs >= 256) return 1;                            // a workgroup per CU already
+  return (int)std::min<long>(rounds, (512 + wgs - 1) / wgs);
+}
 
 // tensors of this size and beyond are fetched `nt` by the 3N passes (see the note at the top of the file)
 static inline bool stream_fetches(int B, int C, int H, int W, size_t elem) {

@@ -65,6 +65,42 @@ __device__ __forceinline__ void store_moments(WaveMoments& w, float* __restrict_
   }
 }
 
+// The forward statistics passes spread an image's strip rounds over gridDim.z ranges when the launch would otherwise leave
+// most of the chip idle (wide_strip_ranges(): detection batches); range z leaves its record at mom[z][b][c].  This kernel
+// folds ranges 1 .. nz-1 into record 0 -- the one every consumer reads -- by the algebra of WaveMoments::merge (re-based onto
+// range 0's pivots, in range order); n_z = pixels of range z = strip rounds r with r % nz == z, `ws` strips each.
+__global__ __launch_bounds__(kThreads) void light_mom_merge_kernel(float* __restrict__ mom, int B, int C, int H, int W, int ws,
+                                                                   int nz) {
+  const int i = blockIdx.x * kThreads + threadIdx.x;
+  if (i >= B * C) return;
+  const int nstrips = (W + kS - 1) / kS;
+  auto pixels_of = [&](int z) {
+    int n = 0;
+    for (int r = z; r * ws < nstrips; r += nz)
+      for (int j = 0; j < ws && r * ws + j < nstrips; ++j) n += min(kS, W - (r * ws + j) * kS);
+    return (float)(n * H);
+  };
+  float* m0 = mom + (size_t)i * M_REC;
+  WaveMoments w;
+  w.clear();
+  float sx = 0.f;
+  for (int z = 0; z < nz; ++z) {
+    const float* mz = m0 + (size_t)z * B * C * M_REC;
+    const float n = pixels_of(z);
+    if (n == 0.f) continue;
+    float a[M_N];
+#pragma unroll
+    for (int k = 0; k < M_N; ++k) a[k] = mz[k];
+    sx += a[M_SX];
+    w.merge(a, mz[M_PV], mz[M_PO], n);
+  }
+  w.s[M_SX] = sx;
+#pragma unroll
+  for (int k = 0; k < M_N; ++k) m0[k] = w.s[k];
+  m0[M_PV] = w.pv;
+  m0[M_PO] = w.po;
+}
+
 // ------------------------------------------------------------------------------------------------
 // backward statistics: per (image, channel) sums of dOut, dOut*(V - pV), dOut*(o - pO) -- about the pivots the forward
 // statistics pass recorded for the plane (mom[.., M_PV / M_PO]; mom == null: raw sums).  The per-channel kernels put
@@ -135,7 +171,7 @@ __global__ __launch_bounds__(kMaxStrips * kWave) void light_stats_bwd_wide(
     wg_reduce<D_N>(acc, red, lane, wave, nwaves, wc);
     if (wave < wc) {
 #pragma unroll
-      for (int k = 0; k < D_N; ++k) bmom[((size_t)b * C + c) * D_N + k] = acc[k];
+      for (int k = 0; k < D_N; ++k) bmom[(((size_t)blockIdx.z * B + b) * C + c) * D_N + k] = acc[k];      // (range z's record)
     }
   }
 }
@@ -218,7 +254,7 @@ __global__ __launch_bounds__(kMaxStrips * kWave) void light_stats_fwd_wide(
       rows_landed();
       wm.merge(acc, pV, pO, (float)(H * nc));
     }
-    store_moments(wm, red, mom + ((size_t)b * C + c) * M_REC, lane, wave, nwaves, wc);
+    store_moments(wm, red, mom + (((size_t)blockIdx.z * B + b) * C + c) * M_REC, lane, wave, nwaves, wc);      // (range z's record)
   }
 }
 
@@ -325,7 +361,7 @@ __device__ __forceinline__ void light_stats_fwd_fused_body(
       rows_landed();
       wm.merge(acc, pV, pO, (float)(H * nc));
     }
-    store_moments(wm, red, mom + ((size_t)b * C + c) * M_REC, lane, wave, nwaves, wc);
+    store_moments(wm, red, mom + (((size_t)blockIdx.z * B + b) * C + c) * M_REC, lane, wave, nwaves, wc);      // (range z's record)
   }
 }
 
@@ -670,13 +706,13 @@ __global__ __launch_bounds__(kBwdWaves * kWave) void light_apply_bwd_wide(
   wg_reduce<9>(wg, red, lane, wave, nwaves, wc);
   if (wave < wc) {
 #pragma unroll
-    for (int k = 0; k < 9; ++k) dwv_part[((size_t)blockIdx.y * C + c) * 9 + k] = wg[k];
+    for (int k = 0; k < 9; ++k) dwv_part[(((size_t)blockIdx.z * gridDim.y + blockIdx.y) * C + c) * 9 + k] = wg[k];
   }
   if (PRE) {
     wg_reduce<2>(pm, red, lane, wave, nwaves, wc);
     if (wave < wc) {
-      pre_tmom[((size_t)blockIdx.y * C + c) * 2 + 0] = pm[0];
-      pre_tmom[((size_t)blockIdx.y * C + c) * 2 + 1] = pm[1];
+      pre_tmom[(((size_t)blockIdx.z * gridDim.y + blockIdx.y) * C + c) * 2 + 0] = pm[0];
+      pre_tmom[(((size_t)blockIdx.z * gridDim.y + blockIdx.y) * C + c) * 2 + 1] = pm[1];
     }
   }
 }
@@ -791,13 +827,13 @@ __global__ __launch_bounds__(kMaxStrips * kWave) void base_value_bwd_wide(
   wg_reduce<9>(wg, red, lane, wave, nwaves, wc);
   if (wave < wc) {
 #pragma unroll
-    for (int k = 0; k < 9; ++k) dwv_part[((size_t)blockIdx.y * C + c) * 9 + k] = wg[k];
+    for (int k = 0; k < 9; ++k) dwv_part[(((size_t)blockIdx.z * gridDim.y + blockIdx.y) * C + c) * 9 + k] = wg[k];
   }
   if (PRE) {
     wg_reduce<2>(pm, red, lane, wave, nwaves, wc);
     if (wave < wc) {
-      pre_tmom[((size_t)blockIdx.y * C + c) * 2 + 0] = pm[0];
-      pre_tmom[((size_t)blockIdx.y * C + c) * 2 + 1] = pm[1];
+      pre_tmom[(((size_t)blockIdx.z * gridDim.y + blockIdx.y) * C + c) * 2 + 0] = pm[0];
+      pre_tmom[(((size_t)blockIdx.z * gridDim.y + blockIdx.y) * C + c) * 2 + 1] = pm[1];
     }
   }
 }
@@ -814,11 +850,32 @@ int nhwc_images_per_group(int B, int C, int W) {
   return (int)std::max(1L, std::min(8L, wgs * ws / 2048));
 }
 
+int nhwc_wgrad_ranges(int B, int C, int W) {
+  if (C % kWave) return 1;                             // (the row pipeline only)
+  return wide_strip_ranges(P_APPLY_BWD, B, C, W, nhwc_images_per_group(B, C, W));
+}
+int nhwc_mom_ranges(int B, int C, int W) {
+  if (C % kWave) return 1;
+  return wide_strip_ranges(P_STATS_FUSED, B, C, W, 0);
+}
+int nhwc_bmom_ranges(int B, int C, int W) {
+  if (C % kWave) return 1;
+  return wide_strip_ranges(P_STATS_BWD, B, C, W, 0);
+}
+
 int launch_light_stats_fwd_wide(const void* x, const void* o, const float* wv, float* mom, void* xout, const float* psc,
                                 const float* psh, void* vout, int B, int C, int H, int W, int dtype, int act,
-                                hipStream_t st, bool fused_no_x) {
+                                hipStream_t st, bool fused_no_x, int mom_ranges) {
   const bool ragged = (W % kS) != 0;
   const int bg = 0;               // (wide_launch(): >= 2048 workgroups)
+  const int nz = std::max(1, mom_ranges);      // strip ranges, each with its own record in mom[z]: merged below
+  auto merged = [&](int ws) {
+    if (nz > 1)
+      hipLaunchKernelGGL(light_mom_merge_kernel, dim3((B * C + kThreads - 1) / kThreads), dim3(kThreads), 0, st, mom, B, C, H, W,
+                         ws, nz);
+    return hip_status(hipGetLastError());
+  };
+  int ws_used = 1;
   if (xout || fused_no_x) {       // the fused producer (needs o, no activation on V); fused_no_x: x_t is not written
     if (!o || act) return MRLA_EINVAL;
 #define CALL_K(KERNEL, T, AF, RG, NT, SX)                                                                           \
@@ -829,7 +886,8 @@ int launch_light_stats_fwd_wide(const void* x, const void* o, const float* wv, f
   }
 #define CALL_N(T, AF, RG, NT)                                                                                       \
   {                                                                                                                 \
-    const WideLaunch L = wide_launch(P_STATS_FUSED, B, C, W, kMomRed, fused_wave_bytes<T>(), bg, false);                                   \
+    const WideLaunch L = wide_launch(P_STATS_FUSED, B, C, W, kMomRed, fused_wave_bytes<T>(), bg, false, nz);                               \
+    ws_used = (int)(L.block.x / kWave) / L.wc;                                                                      \
     if (xout) CALL_K(light_stats_fwd_fused_wide, T, AF, RG, NT, true)                                               \
     else CALL_K(light_stats_fwd_fused_wide, T, AF, RG, NT, false)                                                   \
   }
@@ -847,11 +905,12 @@ int launch_light_stats_fwd_wide(const void* x, const void* o, const float* wv, f
 #undef CALL_R
 #undef CALL_N
 #undef CALL_K
-    return hip_status(hipGetLastError());
+    return merged(ws_used);
   }
 #define CALL_R(T, A, O, RG)                                                                                         \
   {                                                                                                                 \
-    const WideLaunch L = wide_launch(P_STATS_FWD, B, C, W, kMomRed, stats_fwd_wave_bytes<T>(), bg, false);                                   \
+    const WideLaunch L = wide_launch(P_STATS_FWD, B, C, W, kMomRed, stats_fwd_wave_bytes<T>(), bg, false, nz);                               \
+    ws_used = (int)(L.block.x / kWave) / L.wc;                                                                      \
     if (set_lds_n(light_stats_fwd_wide<T, A, O, RG>, L.lds) != hipSuccess) return MRLA_EHIP;                          \
     hipLaunchKernelGGL((light_stats_fwd_wide<T, A, O, RG>), L.grid, L.block, L.lds, st, (const T*)x, (const T*)o, wv, \
                        mom, (T*)vout, B, C, H, W, L.BG, L.wc);                                                            \
@@ -860,7 +919,7 @@ int launch_light_stats_fwd_wide(const void* x, const void* o, const float* wv, f
   MRLA_DISPATCH_T_N(dtype, act, o != nullptr, CALL)
 #undef CALL
 #undef CALL_R
-  return hip_status(hipGetLastError());
+  return merged(ws_used);
 }
 
 int launch_light_apply_fwd_wide(const void* x, const void* o, const float* wv, const float* gate, const float* sc,
@@ -909,12 +968,13 @@ int launch_light_apply_bwd_wide(const void* dout, const void* x, const void* o, 
                                 void* dprev, float* dwv_part, const void* pre, const float* pre_center, float* pre_tmom,
                                 int B, int C, int H, int W, int d, int res, int relu, int dtype, int act, hipStream_t st) {
   const bool ragged = (W % kS) != 0;
-  const int bg = nhwc_images_per_group(B, C, W);          // = the rows mrla_light_wgrad_rows() promised
+  const int bg = nhwc_images_per_group(B, C, W);          // image groups x strip ranges = the rows mrla_light_wgrad_rows() promised
+  const int nz = nhwc_wgrad_ranges(B, C, W);
   if (pre_tmom && (!pre || !relu)) return MRLA_EINVAL;
   if (pre_tmom && dtype == MRLA_F32) return MRLA_EUNSUPPORTED;      // (LDS: see mrla_light_apply_bwd_pre_sums)
 #define CALL_PLAIN(T, A, O, R, RG, PR)                                                                               \
   {                                                                                                                  \
-    const WideLaunch L = wide_launch(P_APPLY_BWD, B, C, W, 9, apply_bwd_wave_bytes<T, PR>(), bg, false);             \
+    const WideLaunch L = wide_launch(P_APPLY_BWD, B, C, W, 9, apply_bwd_wave_bytes<T, PR>(), bg, false, nz);         \
     if (set_lds_n(light_apply_bwd_wide<T, A, O, R, RG, PR>, L.lds) != hipSuccess) return MRLA_EHIP;                    \
     hipLaunchKernelGGL((light_apply_bwd_wide<T, A, O, R, RG, PR>), L.grid, L.block, L.lds, st, (const T*)dout,        \
                        (const T*)x, (const T*)o, wv, gate, cb, lam, dp, dyx, (T*)dx, (T*)dprev, dwv_part,             \
@@ -925,7 +985,7 @@ int launch_light_apply_bwd_wide(const void* dout, const void* x, const void* o, 
   {                                                                                                                  \
     if constexpr (!(A)) {                                                                                            \
       constexpr int DP = sizeof(T) == 2 ? MRLA_APPLY_BWD_DEPTH : 1;                                                  \
-      const WideLaunch L = wide_launch(P_APPLY_BWD, B, C, W, 0, apply_bwd_pk_wave_bytes<T, PR, DP>(), bg, false);    \
+      const WideLaunch L = wide_launch(P_APPLY_BWD, B, C, W, 0, apply_bwd_pk_wave_bytes<T, PR, DP>(), bg, false, nz); \
       if (set_lds_n(light_apply_bwd_wide_pk<T, O, R, RG, PR, DP>, L.lds) != hipSuccess) return MRLA_EHIP;             \
       hipLaunchKernelGGL((light_apply_bwd_wide_pk<T, O, R, RG, PR, DP>), L.grid, L.block, L.lds, st, (const T*)dout,  \
                          (const T*)x, (const T*)o, wv, gate, cb, lam, dp, dyx, (T*)dx, (T*)dprev, dwv_part,           \
@@ -963,7 +1023,7 @@ int launch_light_stats_bwd_wide(const void* dout, const void* x, const void* o, 
 #define CALL(T, A, O) CALL_N(T, A, O, 0)      /* default policy: apply_bwd re-reads these tensors right after */
 #define CALL_N(T, A, O, NT)                                                                                        \
   {                                                                                                                \
-    const WideLaunch L = wide_launch(P_STATS_BWD, B, C, W, D_N, stats_bwd_wave_bytes<T>(), 0, false);     \
+    const WideLaunch L = wide_launch(P_STATS_BWD, B, C, W, D_N, stats_bwd_wave_bytes<T>(), 0, false, nhwc_bmom_ranges(B, C, W)); \
     if (set_lds_n(light_stats_bwd_wide<T, A, O, NT>, L.lds) != hipSuccess) return MRLA_EHIP;                        \
     hipLaunchKernelGGL((light_stats_bwd_wide<T, A, O, NT>), L.grid, L.block, L.lds, st, (const T*)dout, (const T*)x,    \
                        (const T*)o, wv, mom, bmom, B, C, H, W, L.BG, L.wc);                                              \
@@ -980,9 +1040,10 @@ int launch_base_value_bwd_wide(const void* dout, const void* x, const float* wv,
   if (C % kWave) return MRLA_EUNSUPPORTED;
   if (pre_tmom && (!pre || !(res & 2))) return MRLA_EINVAL;
   const int bg = nhwc_images_per_group(B, C, W);
+  const int nz = nhwc_wgrad_ranges(B, C, W);
 #define CALL_P(T, PR)                                                                                               \
   {                                                                                                                 \
-    const WideLaunch L = wide_launch(P_APPLY_BWD, B, C, W, 9, base_vbwd_wave_bytes<T, PR>(), bg, false);                                 \
+    const WideLaunch L = wide_launch(P_APPLY_BWD, B, C, W, 9, base_vbwd_wave_bytes<T, PR>(), bg, false, nz);                             \
     if (set_lds_n(base_value_bwd_wide<T, PR>, L.lds) != hipSuccess) return MRLA_EHIP;                                \
     hipLaunchKernelGGL((base_value_bwd_wide<T, PR>), L.grid, L.block, L.lds, st, (const T*)dout, (const T*)x, wv,    \
                        (const T*)dv, dyx, (T*)dx, dwv_part, (const T*)pre, pre_center, pre_tmom, B, C, H, W, L.BG, res, L.wc); \

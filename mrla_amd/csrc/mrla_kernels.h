@@ -57,11 +57,15 @@ int launch_bn_fwd(const float* mom, const float* gate, const float* lam, const f
                   float* save_mean, float* save_inv, int B, int C, int HW, int d, hipStream_t st);
 int launch_bn_bwd(const float* mom, const float* bmom, const float* gate, const float* lam, const float* gamma,
                   const float* dp, const float* save_mean, const float* save_inv, int training, float* cb, float* cb_lo,
-                  float* dgamma, float* dbeta, float* dlam, int B, int C, int HW, int d, hipStream_t st);
+                  float* dgamma, float* dbeta, float* dlam, int B, int C, int HW, int d, hipStream_t st, int nsplit = 1);
 // tok_part != null (token path): [tok_bands * B][C][kTokParts] partials of mrla_token_apply_bwd, completed in place with dy
 int launch_gate_bwd(const float* mom, const float* bmom, const float* gate, const float* cb, const float* cb_lo,
                     const float* dp, const float* wq, const float* wk, int ks, float* dyx, float* dwqk_part, int B, int C, int HW,
-                    int d, hipStream_t st, float* tok_part = nullptr, int tok_bands = 0);
+                    int d, hipStream_t st, float* tok_part = nullptr, int tok_bands = 0, int nsplit = 1);
+// (nsplit: partial records per (image, channel) in bmom -- the strip ranges of the backward statistics pass)
+int nhwc_wgrad_ranges(int B, int C, int W);
+int nhwc_bmom_ranges(int B, int C, int W);
+int nhwc_mom_ranges(int B, int C, int W);         // ... of the forward statistics passes (records mom[z], merged into mom[0])
 int launch_reduce_rows(const float* in, float* out, int rows, int n, hipStream_t st);
 int launch_reduce_rows2(const float* in1, float* out1, int rows1, int n1, const float* in2, float* out2, int rows2, int n2,
                         hipStream_t st);
@@ -195,7 +199,7 @@ int launch_weight_bank_refresh(const long long* table, int entries, int max_tile
 // light_nhwc_wide.hip -- the C % 64 == 0 forms on the LDS-DMA row pipeline (nhwc_rows.h)
 int launch_light_stats_fwd_wide(const void* x, const void* o, const float* wv, float* mom, void* xout, const float* psc,
                                 const float* psh, void* vout, int B, int C, int H, int W, int dtype, int act,
-                                hipStream_t st, bool fused_no_x = false);
+                                hipStream_t st, bool fused_no_x = false, int mom_ranges = 1);
 int launch_light_apply_fwd_wide(const void* x, const void* o, const float* wv, const float* gate, const float* sc,
                                 const float* sh, const float* lam, const float* dp, void* out, int B, int C, int H,
                                 int W, int d, int res, int dtype, int act, hipStream_t st);
@@ -221,7 +225,7 @@ int launch_light_apply_bwd_lean_wide(const void* dout, const void* pre, const vo
                                      int dtype, hipStream_t st);
 int launch_light_stats_fwd_nhwc(const void* x, const void* o, const float* wv, float* mom, void* xout,
                                 const float* psc, const float* psh, void* vout, int B, int C, int H, int W, int dtype,
-                                int act, hipStream_t st, bool fused_no_x = false);
+                                int act, hipStream_t st, bool fused_no_x = false, int mom_ranges = 1);
 int launch_light_apply_fwd_nhwc(const void* x, const void* o, const float* wv, const float* gate, const float* sc,
                                 const float* sh, const float* lam, const float* dp, void* out, int B, int C, int H,
                                 int W, int d, int res, int dtype, int act, hipStream_t st);

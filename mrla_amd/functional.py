@@ -328,7 +328,10 @@ class _LightFn(torch.autograd.Function):
         G = c // d
         st = _stream()
 
-        mom = torch.empty((b, c, L.FWD_MOMENTS), dtype=torch.float32, device=dev)
+        # (the statistics passes leave one record per strip range and fold them into mom[0]; > 1 range only for few, large images)
+        msplits = L.load().mrla_light_mom_splits(b, c, h, w, dt, layout)
+        L.check(min(msplits, 0), "mrla_light_mom_splits")
+        mom = torch.empty((msplits, b, c, L.FWD_MOMENTS), dtype=torch.float32, device=dev)
         if cfg.fuse and (oc is None or cfg.act != L.ACT_NONE):
             raise L.MrlaHipError("the fused relu(pre + o_prev) producer needs o_prev and no activation on V")
         # inference form: nothing will be differentiated and bn_mrla does not need the batch statistics of m, so x_t is
@@ -443,8 +446,11 @@ class _LightFn(torch.autograd.Function):
         dout = _layout_of(dout, layout)[1]
 
         has_bn = cfg.bn_mode != L.BN_NONE
+        # (partial records of the backward statistics pass: > 1 only for few, large images -- detection batches)
+        splits = L.load().mrla_light_bmom_splits(b, c, h, w, dt, layout)
+        L.check(min(splits, 0), "mrla_light_bmom_splits")
         if _seq():
-            bmom = torch.empty((b, c, L.BWD_MOMENTS), dtype=torch.float32, device=dev)
+            bmom = torch.empty((splits, b, c, L.BWD_MOMENTS), dtype=torch.float32, device=dev)
             small = torch.empty((11, c), dtype=torch.float32, device=dev)     # cb[c,4] | dgamma | dbeta | dlam | cb_lo[c,4]
             dyx = torch.empty((b, c), dtype=torch.float32, device=dev)
             dwqk_part = torch.empty((b, 2 * ks), dtype=torch.float32, device=dev)
@@ -468,7 +474,7 @@ class _LightFn(torch.autograd.Function):
             if pre_tmom is not None:
                 cfg.pre_box.put(dx, pre_tmom, rows)
         else:
-            bmom = torch.empty((b, c, L.BWD_MOMENTS), dtype=torch.float32, device=dev)
+            bmom = torch.empty((splits, b, c, L.BWD_MOMENTS), dtype=torch.float32, device=dev)
             if lean:
                 _call("mrla_light_stats_bwd_fused", nb * 3, _ptr(dout), _ptr(pre), _ptr(psc), _ptr(psh), _ptr(oc), _ptr(wv32),
                       _ptr(mom), _ptr(bmom), b, c, h, w, dt, layout, st)
@@ -481,11 +487,11 @@ class _LightFn(torch.autograd.Function):
             _call("mrla_light_bn_bwd", 0, _ptr(mom), _ptr(bmom), _ptr(gate), _ptr(lam32), _ptr(gamma32) if has_bn else None,
                    _ptr(dp32), _ptr(bnbuf[2]) if has_bn else None, _ptr(bnbuf[3]) if has_bn else None, cfg.bn_mode,
                    _ptr(cb), _ptr(cb_lo), _ptr(small[4]) if has_bn else None, _ptr(small[5]) if has_bn else None,
-                   _ptr(small[6]) if lam32 is not None else None, b, c, h * w, d, st)
+                   _ptr(small[6]) if lam32 is not None else None, b, c, h * w, d, splits, st)
             dyx = torch.empty((b, c), dtype=torch.float32, device=dev)
             dwqk_part = torch.empty((b, 2 * ks), dtype=torch.float32, device=dev)
             _call("mrla_light_gate_bwd", 0, _ptr(mom), _ptr(bmom), _ptr(gate), _ptr(cb), _ptr(cb_lo), _ptr(dp32), _ptr(wq32),
-                   _ptr(wk32), ks, _ptr(dyx), _ptr(dwqk_part), b, c, h * w, d, st)
+                   _ptr(wk32), ks, _ptr(dyx), _ptr(dwqk_part), b, c, h * w, d, splits, st)
             rows = L.load().mrla_light_wgrad_rows(b, c, h, w, dt, layout)
             L.check(min(rows, 0), "mrla_light_wgrad_rows")
             dwv_part = torch.empty((rows, c * 9), dtype=torch.float32, device=dev)
@@ -688,7 +694,9 @@ class _BaseFn(torch.autograd.Function):
         stage.reserve_slot()
         t, T = stage.t + 1, stage.T
 
-        mom = torch.empty((b, c, L.FWD_MOMENTS), dtype=torch.float32, device=dev)
+        # ([splits, b, c, 8]: mrla_light_stats_fwd* -- the NCHW path's pooling pass below -- may leave a record per strip range)
+        mom = torch.empty((max(1, L.load().mrla_light_mom_splits(b, c, h, w, dt, layout)), b, c, L.FWD_MOMENTS), dtype=torch.float32,
+                          device=dev)
         nhwc = layout == L.NHWC
         es = xc.element_size()
         if nhwc and _seq():     # the whole layer + tail: one call (mrla_base_layer_fwd)

@@ -39,7 +39,8 @@ What the recipe takes care of (each item was a bug or a trap at some point of th
 The optimizer must be capturable (torch.optim.SGD in its foreach / fused forms is; Adam needs `capturable=True`).
 `scaler=torch.amp.GradScaler(...)` (deit/engine.py:37,51: fp16 autocast + timm's NativeScaler): the scaled backward, the
 unscale + inf check and the scale update go into the graph as well; that needs an optimizer whose step takes the scaler's
-`grad_scale` / `found_inf` tensors on the device (the `fused=True` forms of SGD / Adam / AdamW) -- no host decision remains.
+`grad_scale` / `found_inf` tensors on the device (the `fused=True` forms of SGD / Adam / AdamW; Adam / AdamW also need
+`capturable=True`) -- no host decision remains.
 """
 import torch
 

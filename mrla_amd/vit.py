@@ -31,7 +31,7 @@ class _LinearFn(torch.autograd.Function):
     Why: replayed from a HIP graph, the training step of these DeiT models returned NaN in a random handful of nn.Linear
     BIAS gradients from the second replay on (weights' gradients of the same layers finite; eager launches always right) --
     with bf16 autocast, stochastic depth on and self-attention in the block; none of this package's kernels involved (the
-    same blocks without the MRLA module show it; scripts/deit_replay_debug*.py, profiles/r05_notes.md).  Taking the bias
+    same blocks without the MRLA module show it; scripts/archive/deit_replay_debug*.py, profiles/r05_notes.md).  Taking the bias
     gradient through matrix products (ones^T dY per image, then over the images; fp32 accumulation inside each) removes it; everything else is the stock linear: forward with the fused bias epilogue, dX = dY W, dW = dY^T X."""
 
     @staticmethod

@@ -1,8 +1,8 @@
 #!/bin/bash
-# Round-5 measurement set on the GPU box: the GPU suite (fresh parity log), the driver's own bench command, and the per-config
-# bench / trace / counter passes.  Usage: bash scripts/r05_final.sh [suite] [default] [profiles]
+# Round-6 measurement set on the GPU box: the GPU suite (fresh parity log), the driver's own bench command, and the per-config
+# bench / trace / counter passes.  Usage: bash scripts/r06_final.sh [suite] [default] [profiles]
 set -u
-OUT=gpurun_out/r05_final
+OUT=gpurun_out/r06_final
 mkdir -p $OUT
 for what in "$@"; do
   case $what in

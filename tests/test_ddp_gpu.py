@@ -122,7 +122,8 @@ def test_bench_py_under_torch_distributed_run_two_ranks_one_gpu(dp):
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
            "--master-port", str(_free_port()), os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
            "--batch", str(batch), "--no-baselines", "--benchmark", "0"]
-    cmd += ["--graph", "0", "--dp", "ddp"] if dp == "ddp" else ["--graph", "1", "--dp", "flat"]
+    # (--ddp-first 0: this test is about the graph tier's own line; the never-worse-than-DDP rule has its own test below)
+    cmd += ["--graph", "0", "--dp", "ddp"] if dp == "ddp" else ["--graph", "1", "--dp", "flat", "--ddp-first", "0"]
     p = subprocess.run(cmd, env=env, cwd=root, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=1200)
     out, err = p.stdout.decode(errors="replace"), p.stderr.decode(errors="replace")
     assert p.returncode == 0, (out + err)[-4000:]
@@ -165,7 +166,7 @@ def test_bench_py_plain_launch_starts_its_own_ranks():
     env.update(MRLA_DIST_BACKEND="gloo", PYTHONPATH=root)
     env.pop("HSA_ENABLE_IPC_MODE_LEGACY", None)
     cmd = [sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--batch", "8",
-           "--no-baselines", "--graph", "0", "--dp", "flat"]
+           "--no-baselines", "--graph", "0", "--dp", "flat", "--ddp-first", "0"]
     p = subprocess.run(cmd, env=env, cwd=root, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=1500)
     out, err = p.stdout.decode(errors="replace"), p.stderr.decode(errors="replace")
     assert p.returncode == 0, (out + err)[-4000:]
@@ -192,7 +193,7 @@ def test_bench_py_graph_captures_the_rccl_exchange_one_rank():
     env = dict(os.environ, PYTHONPATH=root)
     env.pop("MRLA_DIST_BACKEND", None)
     env.pop("HSA_ENABLE_IPC_MODE_LEGACY", None)
-    cmd = [sys.executable, os.path.join(root, "bench.py"), "--ddp-probe", "--steps", "3", "--warmup", "1", "--batch", "32",
+    cmd = [sys.executable, os.path.join(root, "bench.py"), "--ddp-probe", "--ddp-first", "0", "--steps", "3", "--warmup", "1", "--batch", "32",
            "--no-baselines", "--benchmark", "0", "--graph", "1"]
     p = subprocess.run(cmd, env=env, cwd=root, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=1200)
     out, err = p.stdout.decode(errors="replace"), p.stderr.decode(errors="replace")
@@ -218,7 +219,7 @@ def test_bench_py_two_graphs_around_an_eager_rccl_all_reduce_one_rank():
     env = dict(os.environ, PYTHONPATH=root)
     env.pop("MRLA_DIST_BACKEND", None)
     env.pop("HSA_ENABLE_IPC_MODE_LEGACY", None)
-    cmd = [sys.executable, os.path.join(root, "bench.py"), "--ddp-probe", "--steps", "3", "--warmup", "1", "--batch", "32",
+    cmd = [sys.executable, os.path.join(root, "bench.py"), "--ddp-probe", "--ddp-first", "0", "--steps", "3", "--warmup", "1", "--batch", "32",
            "--no-baselines", "--benchmark", "0", "--graph", "1", "--split-graph"]
     p = subprocess.run(cmd, env=env, cwd=root, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=1200)
     out, err = p.stdout.decode(errors="replace"), p.stderr.decode(errors="replace")
@@ -239,7 +240,7 @@ def test_bench_py_reports_the_eager_region_when_the_capture_breaks():
     env = dict(os.environ, PYTHONPATH=root)
     env.pop("MRLA_DIST_BACKEND", None)
     env.pop("HSA_ENABLE_IPC_MODE_LEGACY", None)
-    cmd = [sys.executable, os.path.join(root, "bench.py"), "--ddp-probe", "--steps", "2", "--warmup", "1", "--batch", "32",
+    cmd = [sys.executable, os.path.join(root, "bench.py"), "--ddp-probe", "--ddp-first", "0", "--steps", "2", "--warmup", "1", "--batch", "32",
            "--no-baselines", "--benchmark", "0", "--graph", "1", "--inject-capture-failure"]
     p = subprocess.run(cmd, env=env, cwd=root, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=1200)
     out, err = p.stdout.decode(errors="replace"), p.stderr.decode(errors="replace")
@@ -263,7 +264,7 @@ def test_bench_py_keeps_the_first_schedules_graph_measurement_when_the_optional_
     env = dict(os.environ, PYTHONPATH=root)
     env.pop("MRLA_DIST_BACKEND", None)
     env.pop("HSA_ENABLE_IPC_MODE_LEGACY", None)
-    cmd = [sys.executable, os.path.join(root, "bench.py"), "--ddp-probe", "--steps", "3", "--warmup", "1", "--batch", "32",
+    cmd = [sys.executable, os.path.join(root, "bench.py"), "--ddp-probe", "--ddp-first", "0", "--steps", "3", "--warmup", "1", "--batch", "32",
            "--no-baselines", "--benchmark", "0", "--graph", "1", "--inject-capture-failure", "bucketed_overlap"]
     p = subprocess.run(cmd, env=env, cwd=root, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=1200)
     out, err = p.stdout.decode(errors="replace"), p.stderr.decode(errors="replace")
@@ -358,3 +359,32 @@ def test_flat_exchange_step_replayed_from_a_graph_equals_eager_steps(mode):
     a, b = run(False), run(True)
     for u, v in zip(a, b):
         assert torch.allclose(u, v, rtol=1e-4, atol=1e-5), (u - v).abs().max()
+
+
+def test_the_printed_line_is_never_slower_than_plain_ddp_two_ranks_one_gpu():
+    """N > 1 with the flat exchange (the default): plain DistributedDataParallel, launched kernel by kernel -- resnet/train.py:174
+    unchanged -- is timed FIRST for the full region (`config.ddp_eager_first`), its finished line kept; whatever tier finishes
+    afterwards, the printed line's step time is not above it (if a later tier was slower the first tier's own line is printed,
+    naming the tier it was preferred over).  Two gloo ranks on the one GPU, the driver's launch line."""
+    import json
+    root = os.path.dirname(HERE)
+    env = dict(os.environ, MRLA_DIST_BACKEND="gloo", PYTHONPATH=root)
+    env.pop("HSA_ENABLE_IPC_MODE_LEGACY", None)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1",
+           "--batch", "32", "--no-baselines", "--benchmark", "0"]
+    p = subprocess.run(cmd, env=env, cwd=root, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=1500)
+    out, err = p.stdout.decode(errors="replace"), p.stderr.decode(errors="replace")
+    assert p.returncode == 0, (out + err)[-4000:]
+    lines = [ln for ln in out.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, out[-2000:]
+    rec = json.loads(lines[0])
+    first = rec["config"]["ddp_eager_first"]
+    assert first["steps"] == 3 and first["replicas_in_sync"] is True and first["ms_per_step"] > 0
+    assert rec["ms_per_step"] <= first["ms_per_step"] * (1 + 1e-6), (rec["ms_per_step"], first)
+    assert rec["n_gpus"] == 2 and rec["config"]["global_batch"] == 64 and rec["value"] > 0
+    if "slower_tier" in rec["config"]:           # the first tier's line: says which later tier it was preferred over
+        assert rec["ms_per_step"] == first["ms_per_step"] and rec["config"]["slower_tier"]["ms_per_step"] > first["ms_per_step"]
+        assert "DistributedDataParallel" in rec["config"]["launch"]
+    else:                                        # a later tier's line: it beat (or tied) plain DDP
+        assert rec["config"]["replicas_in_sync"] is True and rec["config"]["weights_finite"] is True

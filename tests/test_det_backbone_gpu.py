@@ -51,3 +51,64 @@ def test_det_backbone_wide_image_fp32_and_bf16_autocast_vs_eager():
     for k, g in r_grads.items():
         if g.norm() > 1e-9:
             assert dist(c_grads[k], g) <= 2.0 * dist(b_grads[k], g) + 2e-2, k
+
+
+@pytest.mark.parametrize("shape", [(2, 256, 200, 336), (2, 512, 100, 168)], ids=lambda s: "x".join(map(str, s)))
+@pytest.mark.parametrize("mode", ["norm_eval", "train"])
+def test_light_tail_at_detection_size_vs_eager(shape, mode):
+    """The block tail where the detection backbone runs it (mmdetection/mmdet/models/backbones/resnet_mrlal.py:283-293 at
+    2 x 3 x 800 x 1344: stage-1 maps 200 x 336, stage-2 100 x 168): two large images instead of 256 small ones, 48 / 24 column
+    strips per image -- the backward passes spread them over strip RANGES (gridDim.z; mrla_light_wgrad_rows /
+    mrla_light_bmom_splits > 1 here), each leaving partial rows / records that the small kernels add up.  Product (bf16,
+    channels_last, x_t = relu(pre + identity) formed inside) vs the eager restatement in fp32 on the same bf16 inputs:
+    out and both input gradients to the last bf16 bits, every parameter gradient to fp32-accumulation accuracy.
+    `norm_eval`: bn_mrla is a fixed affine (what the backbone trains with); `train`: batch statistics."""
+    from mrla_amd import _lib as L
+    from mrla_amd.functional import mrla_light
+    b, c, h, w = shape
+    lib = L.load()
+    assert lib.mrla_light_wgrad_rows(b, c, h, w, L.BF16, L.NHWC) > b and lib.mrla_light_bmom_splits(b, c, h, w, L.BF16, L.NHWC) > 1
+    g = torch.Generator(device="cuda").manual_seed(c + h)
+    mk = lambda s=1.0: (s * torch.randn(b, c, h, w, device="cuda", generator=g)).bfloat16().contiguous(memory_format=torch.channels_last)
+    pre, idn, gup = mk(), mk(), mk(0.1)
+    ref = em.EagerLightModule(c).cuda()
+    bn = torch.nn.BatchNorm2d(c).cuda()
+    with torch.no_grad():
+        ref.mrla.Wv.weight.mul_(0.5)
+        bn.weight.uniform_(0.5, 1.5, generator=g); bn.bias.uniform_(-0.2, 0.2, generator=g)
+        bn.running_mean.uniform_(-0.1, 0.1, generator=g); bn.running_var.uniform_(0.5, 1.5, generator=g)
+    bn.train(mode == "train")
+    bn0 = {k: v.clone() for k, v in bn.state_dict().items()}
+    params = dict(wq=ref.mrla.Wq.weight, wk=ref.mrla.Wk.weight, wv=ref.mrla.Wv.weight, lam=ref.lambda_t, gamma=bn.weight, beta=bn.bias)
+
+    def grads():
+        out = {k: p.grad.detach().double().clone() for k, p in params.items()}
+        for p in params.values():
+            p.grad = None
+        return out
+    # product
+    pg, ig = pre.clone().requires_grad_(True), idn.clone().requires_grad_(True)
+    out = mrla_light(pg, params["wq"], params["wk"], params["wv"], 32, o_prev=ig, lam=params["lam"],
+                     bn=dict(weight=bn.weight, bias=bn.bias, running_mean=bn.running_mean, running_var=bn.running_var,
+                             training=(mode == "train"), momentum=0.1, eps=1e-5), res=True, pre_activation=True)
+    out.backward(gup)
+    got = dict(out=out.detach().float(), dpre=pg.grad.float(), didn=ig.grad.float(), **grads())
+    stats = (bn.running_mean.clone(), bn.running_var.clone())
+    bn.load_state_dict(bn0)
+    # eager restatement, fp32 arithmetic on the same values (resnet_mrlal.py:108-112)
+    pr, ir = pre.float().requires_grad_(True), idn.float().requires_grad_(True)
+    xt = torch.relu(pr + ir)
+    xt = xt + (xt.detach().bfloat16().float() - xt.detach())              # x_t as the product forms it: rounded once to bf16
+    o = xt + bn(ref(xt, ir))
+    o.backward(gup.float())
+    want = dict(out=o.detach(), dpre=pr.grad, didn=ir.grad, **grads())
+    rel = lambda a, r: ((a.double() - r.double()).norm() / r.double().norm().clamp_min(1e-30)).item()
+    for k in ("out", "dpre", "didn"):
+        a, r = got[k], want[k]
+        bad = (a - r).abs() > 2.0 ** -6 * (r.abs() + 0.02 * r.abs().max())
+        assert bad.float().mean().item() < 1e-4, (k, bad.float().mean().item())
+        assert rel(a, r) < 4e-3, (k, rel(a, r))
+    for k in params:
+        assert rel(got[k], want[k]) < 2e-2, (k, rel(got[k], want[k]))
+    if mode == "train":
+        assert torch.allclose(stats[0], bn.running_mean, rtol=1e-3, atol=1e-5) and torch.allclose(stats[1], bn.running_var, rtol=1e-3, atol=1e-5)

@@ -188,7 +188,8 @@ def test_deit_fp16_loss_scaler_step_replays_from_one_graph():
 
         def build():
             net = _build("deit_mrlal_tiny_patch16_224", 0.0)
-            opt = torch.optim.AdamW(net.parameters(), lr=5e-4, weight_decay=0.05, fused=True)
+            # (fused: the step takes the scaler's grad_scale / found_inf on the device; capturable: Adam's step counter too)
+            opt = torch.optim.AdamW(net.parameters(), lr=5e-4, weight_decay=0.05, fused=True, capturable=True)
             return net, opt, torch.amp.GradScaler("cuda", init_scale=4096.0, growth_interval=4)
         poison = torch.zeros((), device="cuda")
 

@@ -123,9 +123,10 @@ class TrainingState:
                 t.copy_(saved)
             if zero_new_state:
                 known = {id(t) for _, t, _ in self.entries}
-                for _, t in _state_tensors(self.model, self.optimizer, self.scaler):
+                for k, t in _state_tensors(self.model, self.optimizer, self.scaler):
                     if id(t) not in known:
-                        t.zero_()
+                        # (a GradScaler creates its tensors at the first scale(): back to what that call starts from)
+                        t.fill_(float(self.scaler._init_scale)) if k == "optim:scaler_scale" else t.zero_()
         torch.cuda.set_rng_state(self.rng)
 
     def now(self):

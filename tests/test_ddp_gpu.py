@@ -372,7 +372,7 @@ def test_the_printed_line_is_never_slower_than_plain_ddp_two_ranks_one_gpu():
     env.pop("HSA_ENABLE_IPC_MODE_LEGACY", None)
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
            "--master-port", str(_free_port()), os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1",
-           "--batch", "32", "--no-baselines", "--benchmark", "0"]
+           "--batch", "32", "--no-baselines", "--benchmark", "0", "--graph", "1", "--dp", "flat"]
     p = subprocess.run(cmd, env=env, cwd=root, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=1500)
     out, err = p.stdout.decode(errors="replace"), p.stderr.decode(errors="replace")
     assert p.returncode == 0, (out + err)[-4000:]

@@ -191,10 +191,10 @@ def test_deit_fp16_loss_scaler_step_replays_from_one_graph():
             # (fused: the step takes the scaler's grad_scale / found_inf on the device; capturable: Adam's step counter too)
             opt = torch.optim.AdamW(net.parameters(), lr=5e-4, weight_decay=0.05, fused=True, capturable=True)
             return net, opt, torch.amp.GradScaler("cuda", init_scale=4096.0, growth_interval=4)
-        poison = torch.zeros((), device="cuda")
+        poison = torch.ones((), device="cuda")
 
-        def loss_fn(logits, target, extra):
-            return torch.nn.functional.cross_entropy(logits, target) + extra       # extra = 0, or inf for the skipped step
+        def loss_fn(logits, target, factor):
+            return torch.nn.functional.cross_entropy(logits, target) * factor      # factor = 1, or inf: every gradient inf / NaN
 
         net, opt, scaler = build()
         step = mrla_amd.graphed_step(net, opt, loss_fn, (x, y, poison), autocast=torch.float16, scaler=scaler, verify=2)
@@ -223,6 +223,7 @@ def test_deit_fp16_loss_scaler_step_replays_from_one_graph():
             assert scaler.get_scale() == rscaler.get_scale(), (k, scaler.get_scale(), rscaler.get_scale())
         assert scaler.get_scale() == 2048.0 or scaler.get_scale() == 4096.0           # halved at step 2 (grown back after 4 good ones)
         assert all(abs(a - b) <= 2e-2 * abs(b) + 1e-3 for a, b in zip(got, want) if b == b and abs(b) != float("inf")), (got, want)
+        assert got[2] == float("inf") and want[2] == float("inf")
         assert got[-1] < got[0]
     finally:
         torch.backends.cudnn.benchmark = was

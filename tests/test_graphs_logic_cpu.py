@@ -190,3 +190,24 @@ def test_every_rank_reaches_the_same_verdict_gloo_world2():
     out = mp.Manager().dict()
     mp.spawn(_verdict_worker, args=(2, port, out), nprocs=2, join=True)
     assert out[0] == out[1] == (True, False, False)
+
+
+def test_restore_resets_a_loss_scaler_that_was_created_since_to_its_initial_scale(monkeypatch):
+    """A GradScaler creates its scale / growth-tracker tensors at the first scale() call -- i.e. during graphed_step's warm-up:
+    the restore puts them back to what a first call starts from (init_scale, 0), not to zero."""
+    from mrla_amd import graphs
+    monkeypatch.setattr(torch.cuda, "get_rng_state", torch.get_rng_state)
+    monkeypatch.setattr(torch.cuda, "set_rng_state", torch.set_rng_state)
+
+    class _Scaler:                        # the two attributes TrainingState looks at, created lazily like torch.amp.GradScaler's
+        _init_scale = 1024.0
+        _scale = _growth_tracker = None
+    net, sc = torch.nn.Linear(2, 2), _Scaler()
+    entry = graphs.TrainingState(net, None, sc)
+    sc._scale, sc._growth_tracker = torch.full((), 256.0), torch.full((), 3, dtype=torch.int32)
+    entry.restore(zero_new_state=True)
+    assert float(sc._scale) == 1024.0 and int(sc._growth_tracker) == 0
+    later = graphs.TrainingState(net, None, sc)          # once they exist they are part of the snapshot like everything else
+    sc._scale.fill_(64.0)
+    later.restore(zero_new_state=True)
+    assert float(sc._scale) == 1024.0

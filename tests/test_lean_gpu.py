@@ -38,14 +38,14 @@ def _calls(fn):
     return out, names
 
 
-def _same(a, b, stock=()):
-    """Bit-identical -- except `stock`: gradients MIOpen accumulates with atomics (the 3x3 convolution's weight gradient is not
-    bit-reproducible between two runs of the SAME path): those to accumulation noise."""
+def _same(a, b, noisy=()):
+    """Bit-identical -- except the keys in `noisy`: results that differ between two runs of the SAME path (MIOpen accumulates
+    some gradients -- and, at small batches, some forward products -- with atomics): those to that noise's level."""
     assert a.keys() == b.keys()
     for k in a:
         assert a[k].shape == b[k].shape, k
-        if k in stock:
-            assert ((a[k].float() - b[k].float()).norm() / b[k].float().norm()).item() < 1e-2, k
+        if k in noisy:
+            assert ((a[k].float() - b[k].float()).norm() / b[k].float().norm().clamp_min(1e-20)).item() < 1e-2, k
         else:
             assert torch.equal(a[k], b[k]), (k, float((a[k].float() - b[k].float()).abs().max()))
 
@@ -90,6 +90,7 @@ def test_bottleneck_without_stored_xt_is_bit_identical(shape, seq):
             a, ca = _calls(run)
         with lean(False):
             s, cs = _calls(run)
+            s2, _ = _calls(run)              # the storing path against ITSELF: what is not bit-reproducible on this shape anyway
     finally:
         Fm.SEQUENCES = was
     assert Fm._DT[torch.bfloat16] is not None
@@ -100,7 +101,11 @@ def test_bottleneck_without_stored_xt_is_bit_identical(shape, seq):
                 "mrla_light_apply_bwd_fused"} <= set(ca), ca
         assert not {"mrla_light_apply_fwd", "mrla_light_stats_bwd", "mrla_light_apply_bwd"} & set(ca), ca
         assert {"mrla_light_apply_fwd", "mrla_light_stats_bwd", "mrla_light_apply_bwd"} <= set(cs), cs
-    _same(a, s, stock=("grad:conv2.weight",))
+    # (the stock 3x3 convolution is not run-to-run reproducible at every shape -- b = 3 at 128 x 28 x 28: 704 of 1.2 M outputs of the
+    # block differ between two runs of the storing path -- and everything downstream inherits that)
+    noisy = {k for k in s if not torch.equal(s[k], s2[k])}
+    assert "grad:mrla.lambda_t" not in noisy or "out" in noisy
+    _same(a, s, noisy=noisy)
     assert all(torch.isfinite(v.float()).all() for v in a.values())
     assert float(a["grad:bn3.weight"].abs().max()) > 0 and float(a["grad:mrla.lambda_t"].abs().max()) > 0
 

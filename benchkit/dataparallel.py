@@ -28,21 +28,22 @@ def ddp_eager_first(run):
     opt = sgd(run.net.parameters())
     st = run.new_step(ddp, opt)
     run.warm_up(st, max(2, args.warmup))
-    dt = timed(st, args.steps, 0)
-    rms = dict(common.RANK_MS)
-    in_sync = D.replicas_in_sync(list(run.net.parameters()))
+    fb = run.measured_eagerly_first(st)          # the contract's region, then once more with the per-kernel events (roofline)
+    dt, rms = fb["dt"], fb["rank_ms"]
+    in_sync, finite = run.states_after()
     rec = {"ms_per_step": round(1e3 * dt / args.steps, 3), "images_per_sec": round(run.world * args.batch * args.steps / dt, 1),
            "steps": args.steps, "rank_ms_per_step": rms, "replicas_in_sync": in_sync,
            "what": "torch DistributedDataParallel (32 MB buckets, overlapped with backward), launched kernel by kernel: "
                    "resnet/train.py:174 unchanged; timed before any other tier"}
     line = None
     if run.rank == 0:
-        timer = run.Fm.KernelTimer()
-        line = report(dict(R, dt=dt, dt_eager=dt, dt_events=None, timer=timer, use_graph=False, legs=False, rank_ms=rms, dp="ddp",
-                           in_sync=in_sync, finite=True, net=None, ddp_first=rec,
+        line = report(dict(R, dt=dt, dt_eager=dt, dt_events=fb["dt_events"], timer=fb["timer"], use_graph=False, legs=False,
+                           rank_ms=rms, dp="ddp", in_sync=in_sync, finite=finite, net=None, ddp_first=rec,
                            launch="kernel by kernel (PyTorch eager launches, DistributedDataParallel): the tier that ran first; "
                                   "no later tier finished faster"), emit=False)
-    del st, opt, ddp
+    del st, opt, ddp, fb                 # (the wrapper's reducer takes its autograd hooks with it)
+    import gc
+    gc.collect()
     run.net.zero_grad(set_to_none=True)
     torch.cuda.synchronize()
     R["ddp_first"] = rec

@@ -384,10 +384,12 @@ PoolGeo pool_geo(int B, int C, int H, int W, int ps) {
   g.Ho = (H - 1) / 2 + 1;
   g.Wo = (W - 1) / 2 + 1;
   g.nwaves = std::min(kPoolWaves, (g.Wo + ps - 1) / ps);
-  // ~2 workgroups per CU; bands must split the pixel count evenly for the statistics kernel's (rows, count) form
+  // ~2 workgroups per CU; bands must split the pixel count evenly for the statistics kernel's (rows, count) form.
+  // (up to 32 row bands: a detection batch -- 2 x 64 x 400 x 672 -- is two (image, channel-group) pairs; with the 4 bands that
+  // were enough at b = 256 its stem ran on 8 workgroups at 0.17 TB/s, round 6)
   const int wgs = (C / kWave) * B;
   g.bands = 1;
-  while (wgs * g.bands < 512 && g.bands < 4 && (H * W) % (g.bands * 2) == 0 && g.Ho / (g.bands * 2) >= 4) g.bands *= 2;
+  while (wgs * g.bands < 512 && g.bands < 32 && (H * W) % (g.bands * 2) == 0 && g.Ho / (g.bands * 2) >= 4) g.bands *= 2;
   return g;
 }
 

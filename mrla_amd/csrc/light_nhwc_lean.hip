@@ -278,9 +278,11 @@ __global__ __launch_bounds__(kBwdWaves * kWave) void light_apply_bwd_lean_wide(
             if (j >= 1 && j <= kS) {                                        // owned column (compile-time after unroll)
               DC[j - 1] = lm * dm;                   // (columns beyond the image are dropped by the store)
               // dWv[i][k] += dU[rr][col] * x[rr+i-1][col+k-1]
+              if (!MRLA_EXP_SKIP_WG) {
               wg[0] = fmaf(du, XA[j], wg[0]); wg[1] = fmaf(du, XA[j + 1], wg[1]); wg[2] = fmaf(du, XA[j + 2], wg[2]);
               wg[3] = fmaf(du, XB[j], wg[3]); wg[4] = fmaf(du, XB[j + 1], wg[4]); wg[5] = fmaf(du, XB[j + 2], wg[5]);
               wg[6] = fmaf(du, XC[j], wg[6]); wg[7] = fmaf(du, XC[j + 1], wg[7]); wg[8] = fmaf(du, XC[j + 2], wg[8]);
+              }
             }
             UC[j] = du;
           }

@@ -30,6 +30,12 @@
 #ifndef MRLA_APPLY_BWD_WC_4STRIPS
 #define MRLA_APPLY_BWD_WC_4STRIPS 2
 #endif
+// Experiment switch (scripts/build_variant.sh only; the product builds with 0): leave the dWv sums out of the backward apply
+// passes -- 63 of their ~350 / ~427 vector instructions per row step -- to see which of them the vector pipe bounds
+// (profiles/r06_notes.md section 2).  The results are WRONG with 1.
+#ifndef MRLA_EXP_SKIP_WG
+#define MRLA_EXP_SKIP_WG 0
+#endif
 // Occupancy of the fused forward statistics pass (round 4, profiles/r04_notes.md section 5): at 150 - 162 VGPRs three waves
 // fit a SIMD, i.e. ONE eight-wave workgroup per CU on the 56-wide stage -- half the waves apply_fwd keeps in flight on the
 // same 3N bytes (SQ counters side by side: 37 % of its wave cycles wait against apply_fwd's 71 %: too few waves, 2.4 x the

@@ -68,9 +68,13 @@ enum { MRLA_BN_NONE = 0, MRLA_BN_TRAIN = 1, MRLA_BN_EVAL = 2 };
  *           mrla_light_stats_bwd_fused and mrla_light_apply_bwd_fused were added, mrla_light_stats_fwd_fused takes x_out = NULL,
  *           mrla_light_tail_fwd takes fuse = 2 and mrla_light_tail_bwd gained pre_sc / pre_sh (x = NULL selects that form);
  *           few, large images (detection batches): the backward passes spread an image's column strips over more workgroups --
- *           mrla_light_wgrad_rows counts the extra partial rows, mrla_light_bmom_splits was added and mrla_light_bn_bwd /
- *           mrla_light_gate_bwd gained bmom_splits (bmom is [bmom_splits, b, c, MRLA_BWD_MOMENTS]); mrla_light_mom_splits was
- *           added (mom of mrla_light_stats_fwd / _fused / mrla_light_tail_fwd is [mom_splits, b, c, MRLA_FWD_MOMENTS]).
+ *           mrla_light_wgrad_rows counts the extra partial rows, mrla_light_bmom_splits was added (bmom of
+ *           mrla_light_stats_bwd* / mrla_light_tail_bwd is [bmom_splits, b, c, MRLA_BWD_MOMENTS], folded into bmom[0] by the
+ *           pass) and so was mrla_light_mom_splits (mom of mrla_light_stats_fwd / _fused / mrla_light_tail_fwd is
+ *           [mom_splits, b, c, MRLA_FWD_MOMENTS], folded into mom[0]).
+ *           Where the strips do not fill the chip either, the ROWS of an image are cut into ranges as well (a range re-fetches
+ *           its two halo rows; the backward apply pass re-computes one row of dU): the same three queries count those
+ *           ranges too, nothing else changes for a caller.  mrla_tuning_row_ranges() was added.
  * A consumer compares mrla_abi_version() (what the loaded library was built from) against this constant before its
  * first call. */
 #define MRLA_ABI_VERSION 5
@@ -89,6 +93,12 @@ int mrla_light_wgrad_rows(int b, int c, int h, int w, int dtype, int layout);
  * images the statistics passes spread an image's column strips over that many workgroup ranges, each leaving its record in
  * mom[z], and fold them into mom[0] -- the [b, c, MRLA_FWD_MOMENTS] block every other entry point reads. */
 int mrla_light_mom_splits(int b, int c, int h, int w, int dtype, int layout);
+/* Row ranges of the channels_last row pipeline (see ABI 5 above): mode 0 = cut an image's rows where a launch would leave most
+ * CUs without a workgroup and the tensor has >= 8 Mi elements (default), 1 = never, 2 = wherever an image has >= 16 rows
+ * (the parity tests drive small shapes through the cut kernels with it).  Process-wide; returns the previous mode (or
+ * MRLA_EINVAL).  Set it BEFORE sizing buffers with mrla_light_mom_splits / mrla_light_bmom_splits / mrla_light_wgrad_rows:
+ * the passes read the mode again when they are launched. */
+int mrla_tuning_row_ranges(int mode);
 int mrla_light_stats_fwd(const void* x, const void* o_prev, const float* wv /*[c,3,3]*/, float* mom,
                          int b, int c, int h, int w, int dtype, int layout, int act, void* stream);
 
@@ -144,8 +154,9 @@ int mrla_light_apply_fwd(const void* x, const void* o_prev, const float* wv, con
 /* ---- backward pass 1 of 2: bmom[splits, b, c, 3] ---------------------------------------------------
  * The reductions autograd performs in MulBackward / ExpandBackward / NativeBatchNormBackward.
  * splits = mrla_light_bmom_splits(): 1 at the classification batches; for few, large images (a detection batch: 2 x 256 x
- * 200 x 336) the pass spreads an image's column strips over `splits` workgroup ranges, each leaving its own partial record;
- * mrla_light_bn_bwd / mrla_light_gate_bwd (bmom_splits) add them in range order.
+ * 200 x 336) the pass spreads an image's column strips (and rows) over `splits` workgroup ranges, each leaving its own partial
+ * record, and folds them -- in range order, in double -- into bmom[0]: the [b, c, 3] block mrla_light_bn_bwd /
+ * mrla_light_gate_bwd read (the same convention as mom).
  * mom: the forward record of the same block (mrla_light_stats_fwd*): the sums over dOut*V and dOut*o are taken about its
  * pivots (pV, pO), so that what survives the cancellations of the BatchNorm backward keeps fp32 accuracy when
  * |mean| >> sigma; mrla_light_bn_bwd / mrla_light_gate_bwd (given the same mom) undo the shift in double. */
@@ -161,7 +172,7 @@ int mrla_light_stats_bwd(const void* dout, const void* x, const void* o_prev, co
  * lam, dp, dlam [opt]. */
 int mrla_light_bn_bwd(const float* mom, const float* bmom, const float* gate, const float* lam, const float* gamma,
                       const float* dp, const float* save_mean, const float* save_inv, int bn_mode, float* cb,
-                      float* cb_lo, float* dgamma, float* dbeta, float* dlam, int b, int c, int hw, int d, int bmom_splits,
+                      float* cb_lo, float* dgamma, float* dbeta, float* dlam, int b, int c, int hw, int d,
                       void* stream);
 
 /* ---- gate backward -------------------------------------------------------------------------------
@@ -170,7 +181,7 @@ int mrla_light_bn_bwd(const float* mom, const float* bmom, const float* gate, co
 int mrla_light_gate_bwd(const float* mom, const float* bmom, const float* gate, const float* cb, const float* cb_lo,
                         const float* dp,
                         const float* wq, const float* wk, int ksize, float* dyx, float* dwqk_part, int b, int c,
-                        int hw, int d, int bmom_splits, void* stream);
+                        int hw, int d, void* stream);
 
 /* ---- backward pass 2 of 2 ------------------------------------------------------------------------
  * dx = res*dOut + dwconv^T(a*dm*act'(U)) + dyx ;  do_prev = lam*dm ;  dwv_part[rows, c, 9] partial sums

@@ -7,7 +7,8 @@ import ctypes
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libmrla_hip.so")
+# (MRLA_HIP_LIB: an experiment build of the same library -- scripts/build_variant.sh -- for A/B runs of whole programs)
+LIB_PATH = os.environ.get("MRLA_HIP_LIB") or os.path.join(_HERE, "libmrla_hip.so")
 
 ABI_VERSION = 5          # MRLA_ABI_VERSION of include/mrla_hip.h
 OK, EINVAL, EUNSUPPORTED, EHIP = 0, -1, -2, -3
@@ -34,8 +35,9 @@ SIGNATURES = {
     "mrla_light_stats_bwd": [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P],
     "mrla_light_bmom_splits": [_I] * 6,
     "mrla_light_mom_splits": [_I] * 6,
-    "mrla_light_bn_bwd": [_P, _P, _P, _P, _P, _P, _P, _P, _I, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P],
-    "mrla_light_gate_bwd": [_P, _P, _P, _P, _P, _P, _P, _P, _I, _P, _P, _I, _I, _I, _I, _I, _P],
+    "mrla_tuning_row_ranges": [_I],
+    "mrla_light_bn_bwd": [_P, _P, _P, _P, _P, _P, _P, _P, _I, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P],
+    "mrla_light_gate_bwd": [_P, _P, _P, _P, _P, _P, _P, _P, _I, _P, _P, _I, _I, _I, _I, _P],
     "mrla_light_apply_bwd_pre_sums": [_I] * 6,
     "mrla_light_apply_bwd": [_P] * 15 + [_I] * 10 + [_P],
     "mrla_light_lean_supported": [_I] * 6,

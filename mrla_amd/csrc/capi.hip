@@ -98,9 +98,9 @@ int mrla_abi_version(void) { return MRLA_ABI_VERSION; }
 
 int mrla_light_wgrad_rows(int b, int c, int h, int w, int dtype, int layout) {
   if (bad_dims(b, c, h, w) || bad_dtype(dtype)) return MRLA_EINVAL;
-  if (layout == MRLA_NHWC) {          // image groups x strip ranges (ranges > 1: few, large images -- detection batches)
+  if (layout == MRLA_NHWC) {          // image groups x (strip ranges x row ranges) (ranges > 1: few, large images -- detection batches)
     const int bg = nhwc_images_per_group(b, c, w);
-    return (b + bg - 1) / bg * nhwc_wgrad_ranges(b, c, w);
+    return (b + bg - 1) / bg * nhwc_wgrad_ranges(b, c, h, w);
   }
   if (layout != MRLA_NCHW) return MRLA_EINVAL;
   SlabGeo g;
@@ -119,7 +119,7 @@ int mrla_light_stats_fwd(const void* x, const void* o_prev, const float* wv, flo
   if (!x || !wv || !mom || bad_dims(b, c, h, w) || bad_dtype(dtype)) return MRLA_EINVAL;
   if (layout == MRLA_NHWC)
     return launch_light_stats_fwd_nhwc(x, o_prev, wv, mom, nullptr, nullptr, nullptr, nullptr, b, c, h, w, dtype, act,
-                                       (hipStream_t)stream, false, nhwc_mom_ranges(b, c, w));
+                                       (hipStream_t)stream, false, nhwc_mom_ranges(b, c, h, w));
   if (layout != MRLA_NCHW) return MRLA_EINVAL;
   SlabGeo g;
   const int rc = light_geo(&g, b, c, h, w, dtype);
@@ -135,7 +135,7 @@ int mrla_light_stats_fwd_fused(const void* pre, const float* pre_sc, const float
   if (!x_out && mrla_light_lean_supported(b, c, h, w, dtype, layout) != 1) return MRLA_EUNSUPPORTED;
   if (layout == MRLA_NHWC)
     return launch_light_stats_fwd_nhwc(pre, o_prev, wv, mom, x_out, pre_sc, pre_sh, nullptr, b, c, h, w, dtype,
-                                       MRLA_ACT_NONE, (hipStream_t)stream, x_out == nullptr, nhwc_mom_ranges(b, c, w));
+                                       MRLA_ACT_NONE, (hipStream_t)stream, x_out == nullptr, nhwc_mom_ranges(b, c, h, w));
   if (layout != MRLA_NCHW) return MRLA_EINVAL;
   SlabGeo g;
   const int rc = light_geo(&g, b, c, h, w, dtype);
@@ -209,37 +209,40 @@ int mrla_light_stats_bwd(const void* dout, const void* x, const void* o_prev, co
   return launch_light_stats_bwd_nchw(dout, x, o_prev, wv, mom, bmom, g, dtype, act, (hipStream_t)stream);
 }
 
+int mrla_tuning_row_ranges(int mode) {
+  if (mode < 0 || mode > 2) return MRLA_EINVAL;
+  return nhwc_set_row_cut_mode(mode);
+}
+
 int mrla_light_mom_splits(int b, int c, int h, int w, int dtype, int layout) {
   if (bad_dims(b, c, h, w) || bad_dtype(dtype)) return MRLA_EINVAL;
   if (layout != MRLA_NHWC && layout != MRLA_NCHW) return MRLA_EINVAL;
-  return layout == MRLA_NHWC ? nhwc_mom_ranges(b, c, w) : 1;
+  return layout == MRLA_NHWC ? nhwc_mom_ranges(b, c, h, w) : 1;
 }
 
 int mrla_light_bmom_splits(int b, int c, int h, int w, int dtype, int layout) {
   if (bad_dims(b, c, h, w) || bad_dtype(dtype)) return MRLA_EINVAL;
   if (layout != MRLA_NHWC && layout != MRLA_NCHW) return MRLA_EINVAL;
-  return layout == MRLA_NHWC ? nhwc_bmom_ranges(b, c, w) : 1;
+  return layout == MRLA_NHWC ? nhwc_bmom_ranges(b, c, h, w) : 1;
 }
 
 int mrla_light_bn_bwd(const float* mom, const float* bmom, const float* gate, const float* lam, const float* gamma,
                       const float* dp, const float* save_mean, const float* save_inv, int bn_mode, float* cb,
-                      float* cb_lo, float* dgamma, float* dbeta, float* dlam, int b, int c, int hw, int d, int bmom_splits,
-                      void* stream) {
-  if (!mom || !bmom || !gate || !cb || b <= 0 || c <= 0 || hw <= 0 || d <= 0 || c % d || bmom_splits < 1) return MRLA_EINVAL;
+                      float* cb_lo, float* dgamma, float* dbeta, float* dlam, int b, int c, int hw, int d, void* stream) {
+  if (!mom || !bmom || !gate || !cb || b <= 0 || c <= 0 || hw <= 0 || d <= 0 || c % d) return MRLA_EINVAL;
   if (gamma && (!save_mean || !save_inv || !dgamma || !dbeta)) return MRLA_EINVAL;
   if (dlam && !lam) return MRLA_EINVAL;
   return launch_bn_bwd(mom, bmom, gate, lam, gamma, dp, save_mean, save_inv, bn_mode == MRLA_BN_TRAIN, cb, cb_lo, dgamma,
-                       dbeta, dlam, b, c, hw, d, (hipStream_t)stream, bmom_splits);
+                       dbeta, dlam, b, c, hw, d, (hipStream_t)stream);
 }
 
 int mrla_light_gate_bwd(const float* mom, const float* bmom, const float* gate, const float* cb, const float* cb_lo,
                         const float* dp, const float* wq, const float* wk, int ksize, float* dyx, float* dwqk_part, int b, int c,
-                        int hw, int d, int bmom_splits, void* stream) {
+                        int hw, int d, void* stream) {
   if (!mom || !bmom || !gate || !wq || !wk || !dyx || !dwqk_part || b <= 0 || c <= 0 || hw <= 0 || d <= 0 || c % d ||
-      ksize <= 0 || !(ksize & 1) || bmom_splits < 1)
+      ksize <= 0 || !(ksize & 1))
     return MRLA_EINVAL;
-  return launch_gate_bwd(mom, bmom, gate, cb, cb_lo, dp, wq, wk, ksize, dyx, dwqk_part, b, c, hw, d, (hipStream_t)stream, nullptr,
-                         0, bmom_splits);
+  return launch_gate_bwd(mom, bmom, gate, cb, cb_lo, dp, wq, wk, ksize, dyx, dwqk_part, b, c, hw, d, (hipStream_t)stream);
 }
 
 int mrla_light_apply_bwd_pre_sums(int b, int c, int h, int w, int dtype, int layout) {

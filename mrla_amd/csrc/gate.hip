@@ -12,17 +12,12 @@
 
 namespace mrla {
 
-// The backward statistics pass may leave `nsplit` partial records per (image, channel) (strip ranges, mrla_light_bmom_splits):
-// bmom[nsplit][B][C][D_N]; their sum, taken in range order.
+// bmom[B][C][D_N]: record 0 of the backward statistics pass's buffer -- where the pass leaves partial records (strip / row
+// ranges, mrla_light_bmom_splits) it folds them into record 0 itself (launch_fold_rows).
 struct BwdMoments { float d, dv, d_o; };
-__device__ __forceinline__ BwdMoments load_bmom(const float* __restrict__ bmom, int b, int c, int B, int C, int nsplit) {
+__device__ __forceinline__ BwdMoments load_bmom(const float* __restrict__ bmom, int b, int c, int C) {
   const float* p = bmom + ((size_t)b * C + c) * D_N;
-  BwdMoments r = {p[D_D], p[D_DV], p[D_DO]};
-  for (int z = 1; z < nsplit; ++z) {
-    p += (size_t)B * C * D_N;
-    r.d += p[D_D]; r.dv += p[D_DV]; r.d_o += p[D_DO];
-  }
-  return r;
+  return {p[D_D], p[D_DV], p[D_DO]};
 }
 
 constexpr int kBnCh = 4;                     // channels per workgroup in the per-channel kernels (more, smaller workgroups:
@@ -126,7 +121,7 @@ __global__ __launch_bounds__(kThreads) void bn_bwd_kernel(
     const float* __restrict__ lam, const float* __restrict__ gamma, const float* __restrict__ dp,
     const float* __restrict__ save_mean, const float* __restrict__ save_inv, int training, float* __restrict__ cb,
     float* __restrict__ cb_lo, float* __restrict__ dgamma, float* __restrict__ dbeta, float* __restrict__ dlam, int B,
-    int C, int HW, int d, int nsplit) {
+    int C, int HW, int d) {
   __shared__ double r1[kBnLanes][kBnCh], r2[kBnLanes][kBnCh];
   __shared__ double coef[4][kBnCh];
   const int cc = threadIdx.x % kBnCh, bl = threadIdx.x / kBnCh;
@@ -138,7 +133,7 @@ __global__ __launch_bounds__(kThreads) void bn_bwd_kernel(
   if (live) {
 #pragma unroll 4
     for (int b = bl; b < B; b += kBnLanes) {
-      const BwdMoments bm = load_bmom(bmom, b, c, B, C, nsplit);
+      const BwdMoments bm = load_bmom(bmom, b, c, C);
       const float* m = mom + ((size_t)b * C + c) * M_REC;
       const float a = gate[(size_t)b * G + c / d];
       const double dpb = dp ? dp[b] : 1.f;
@@ -188,7 +183,7 @@ __global__ __launch_bounds__(kThreads) void bn_bwd_kernel(
     const double P0 = mom[(size_t)c * M_REC + M_PO];                 // image 0's pivot of o for this channel
     for (int b = bl; b < B; b += kBnLanes) {
       const float* m = mom + ((size_t)b * C + c) * M_REC;
-      const BwdMoments bm = load_bmom(bmom, b, c, B, C, nsplit);
+      const BwdMoments bm = load_bmom(bmom, b, c, C);
       const double a = gate[(size_t)b * G + c / d];
       const double dpb = dp ? dp[b] : 1.f;
       const double n = (double)HW, pv = m[M_PV], po = m[M_PO];
@@ -228,7 +223,7 @@ __global__ __launch_bounds__(kThreads) void gate_bwd_kernel(
     const float* __restrict__ mom, const float* __restrict__ bmom, const float* __restrict__ gate,
     const float* __restrict__ cb, const float* __restrict__ cb_lo, const float* __restrict__ dp,
     const float* __restrict__ wq, const float* __restrict__ wk, int ks, float* __restrict__ dyx,
-    float* __restrict__ dwqk_part, int C, int HW, int d, float* __restrict__ tok_part, int tok_bands, int nsplit) {
+    float* __restrict__ dwqk_part, int C, int HW, int d, float* __restrict__ tok_part, int tok_bands) {
   extern __shared__ float sm[];
   const int p = (ks - 1) / 2;
   const int CPD = C + 2 * p;
@@ -259,7 +254,7 @@ __global__ __launch_bounds__(kThreads) void gate_bwd_kernel(
     qs[c] = q;
     kk[c] = k;
     const float* m = mom + ((size_t)b * C + c) * M_REC;
-    const BwdMoments bm = load_bmom(bmom, b, c, (int)gridDim.x, C, nsplit);
+    const BwdMoments bm = load_bmom(bmom, b, c, C);
     const float a = gate[(size_t)b * G + c / d];
     double e = 1.0, f = 0.0, Gc = 0.0, Hc = 0.0;
     if (cb) { e = cb[c * 4 + 0]; f = cb[c * 4 + 1]; Gc = cb[c * 4 + 2]; Hc = cb[c * 4 + 3]; }
@@ -318,7 +313,7 @@ __global__ __launch_bounds__(kThreads) void gate_bwd_kernel(
 
 // out[i] = sum_r in[r, i].  A workgroup covers `cpb` columns (power of two <= 64) with 256/cpb row lanes each, so
 // narrow matrices (the [b, 2k] Wq/Wk partials) still get hundreds of loads in flight; fixed summation order.
-__global__ __launch_bounds__(kThreads) void reduce_rows_kernel(const float* __restrict__ in, float* __restrict__ out,
+__global__ __launch_bounds__(kThreads) void reduce_rows_kernel(const float* in, float* out,       // (out may be row 0 of in)
                                                                int rows, int n, int cpb) {
   __shared__ double part[kThreads];
   const int cx = threadIdx.x % cpb, ry = threadIdx.x / cpb, rl = kThreads / cpb;
@@ -376,20 +371,20 @@ int launch_bn_fwd(const float* mom, const float* gate, const float* lam, const f
 
 int launch_bn_bwd(const float* mom, const float* bmom, const float* gate, const float* lam, const float* gamma,
                   const float* dp, const float* save_mean, const float* save_inv, int training, float* cb, float* cb_lo,
-                  float* dgamma, float* dbeta, float* dlam, int B, int C, int HW, int d, hipStream_t st, int nsplit) {
+                  float* dgamma, float* dbeta, float* dlam, int B, int C, int HW, int d, hipStream_t st) {
   hipLaunchKernelGGL(bn_bwd_kernel, dim3((C + kBnCh - 1) / kBnCh), dim3(kThreads), 0, st, mom, bmom, gate, lam, gamma,
-                     dp, save_mean, save_inv, training, cb, cb_lo, dgamma, dbeta, dlam, B, C, HW, d, std::max(1, nsplit));
+                     dp, save_mean, save_inv, training, cb, cb_lo, dgamma, dbeta, dlam, B, C, HW, d);
   return hip_status(hipGetLastError());
 }
 
 int launch_gate_bwd(const float* mom, const float* bmom, const float* gate, const float* cb, const float* cb_lo,
                     const float* dp, const float* wq, const float* wk, int ks, float* dyx, float* dwqk_part, int B, int C, int HW,
-                    int d, hipStream_t st, float* tok_part, int tok_bands, int nsplit) {
+                    int d, hipStream_t st, float* tok_part, int tok_bands) {
   const int p = (ks - 1) / 2;
   const size_t lds = (size_t)(3 * (C + 2 * p) + 2 * C + C / d + kWaves) * sizeof(float);
   if (lds > 64 * 1024) return MRLA_EUNSUPPORTED;
   hipLaunchKernelGGL(gate_bwd_kernel, dim3(B), dim3(kThreads), lds, st, mom, bmom, gate, cb, cb_lo, dp, wq, wk, ks, dyx,
-                     dwqk_part, C, HW, d, tok_part, tok_bands, std::max(1, nsplit));
+                     dwqk_part, C, HW, d, tok_part, tok_bands);
   return hip_status(hipGetLastError());
 }
 
@@ -407,6 +402,12 @@ int launch_reduce_rows(const float* in, float* out, int rows, int n, hipStream_t
   const int cpb = reduce_cpb(rows, n);
   hipLaunchKernelGGL(reduce_rows_kernel, dim3((n + cpb - 1) / cpb), dim3(kThreads), 0, st, in, out, rows, n, cpb);
   return hip_status(hipGetLastError());
+}
+
+// buf[0, i] = sum_r buf[r, i] in place (every column is read by the threads that hold it before its sum is written)
+int launch_fold_rows(float* buf, int rows, int n, hipStream_t st) {
+  if (rows <= 1) return MRLA_OK;
+  return launch_reduce_rows(buf, buf, rows, n, st);
 }
 
 int launch_reduce_rows2(const float* in1, float* out1, int rows1, int n1, const float* in2, float* out2, int rows2, int n2,

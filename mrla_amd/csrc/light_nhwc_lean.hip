@@ -276,7 +276,9 @@ __global__ __launch_bounds__(kBwdWaves * kWave) void light_apply_bwd_lean_wide(
             float du = a * dm;
             if (RAGGED || j == 0 || j == kS + 1) du = in ? du : 0.f;
             if (j >= 1 && j <= kS) {                                        // owned column (compile-time after unroll)
-              DC[j - 1] = lm * dm;                   // (columns beyond the image are dropped by the store)
+              float ldm = lm * dm;                   // (a rounded product, as in light_apply_bwd_wide: see the note there)
+              asm("" : "+v"(ldm));
+              DC[j - 1] = ldm;                       // (columns beyond the image are dropped by the store)
               // dWv[i][k] += dU[rr][col] * x[rr+i-1][col+k-1]
               if (!MRLA_EXP_SKIP_WG) {
               wg[0] = fmaf(du, XA[j], wg[0]); wg[1] = fmaf(du, XA[j + 1], wg[1]); wg[2] = fmaf(du, XA[j + 2], wg[2]);
@@ -344,7 +346,11 @@ __global__ __launch_bounds__(kBwdWaves * kWave) void light_apply_bwd_lean_wide(
 // launchers
 // ------------------------------------------------------------------------------------------------
 int light_lean_supported(int B, int C, int H, int W, int dtype) {
-  return (C % kWave == 0 && (dtype == MRLA_BF16 || dtype == MRLA_F16)) ? 1 : 0;
+  if (C % kWave || !(dtype == MRLA_BF16 || dtype == MRLA_F16)) return 0;
+  // (these passes walk whole images: where the x_t-storing passes cut the ROWS as well -- a few very large images, RowCut in
+  // light_nhwc_wide.h -- the partial records would not match; the stored form runs there)
+  return (nhwc_mom_zranges(B, C, H, W).rows == 1 && nhwc_bmom_zranges(B, C, H, W).rows == 1 &&
+          nhwc_wgrad_zranges(B, C, H, W).rows == 1) ? 1 : 0;
 }
 
 int launch_light_stats_bwd_lean_wide(const void* dout, const void* pre, const void* o, const float* wv, const float* psc,
@@ -354,7 +360,7 @@ int launch_light_stats_bwd_lean_wide(const void* dout, const void* pre, const vo
   const bool ragged = (W % kS) != 0;
 #define CALL_K(T, AF, RG)                                                                                          \
   {                                                                                                                \
-    const WideLaunch L = wide_launch(P_STATS_BWD, B, C, W, D_N, stats_bwd_lean_wave_bytes<T>(), 0, false, nhwc_bmom_ranges(B, C, W)); \
+    const WideLaunch L = wide_launch(P_STATS_BWD, B, C, W, D_N, stats_bwd_lean_wave_bytes<T>(), 0, false, nhwc_bmom_zranges(B, C, H, W).strips); \
     if (set_lds_n(light_stats_bwd_lean_wide<T, AF, RG>, L.lds) != hipSuccess) return MRLA_EHIP;                     \
     hipLaunchKernelGGL((light_stats_bwd_lean_wide<T, AF, RG>), L.grid, L.block, L.lds, st, (const T*)dout,          \
                        (const T*)pre, (const T*)o, wv, psc, psh, mom, bmom, B, C, H, W, L.BG, L.wc);               \
@@ -365,7 +371,8 @@ int launch_light_stats_bwd_lean_wide(const void* dout, const void* pre, const vo
 #undef CALL
 #undef CALL_A
 #undef CALL_K
-  return hip_status(hipGetLastError());
+  if (hipGetLastError() != hipSuccess) return MRLA_EHIP;
+  return launch_fold_rows(bmom, nhwc_bmom_zranges(B, C, H, W).strips, B * C * D_N, st);      // partial records -> record 0
 }
 
 int launch_light_apply_bwd_lean_wide(const void* dout, const void* pre, const void* o, const float* wv, const float* psc,
@@ -376,7 +383,7 @@ int launch_light_apply_bwd_lean_wide(const void* dout, const void* pre, const vo
   if (!light_lean_supported(B, C, H, W, dtype)) return MRLA_EUNSUPPORTED;
   const bool ragged = (W % kS) != 0;
   const int bg = nhwc_images_per_group(B, C, W);          // image groups x strip ranges = the rows mrla_light_wgrad_rows() promised
-  const int nz = nhwc_wgrad_ranges(B, C, W);
+  const int nz = nhwc_wgrad_zranges(B, C, H, W).strips;
 #define CALL_K(T, AF, RG, PR)                                                                                      \
   {                                                                                                                \
     const WideLaunch L = wide_launch(P_APPLY_BWD, B, C, W, 9, apply_bwd_lean_wave_bytes<T>(), bg, false, nz);      \

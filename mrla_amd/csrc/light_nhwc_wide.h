@@ -59,7 +59,8 @@ namespace mrla {
 // Per-wave LDS row buffers follow the cross-wave reduction area.
 // The waves of a workgroup are `wc` NEIGHBOURING channel groups x (waves / wc) strips side by side (wave = strip slot * wc +
 // channel-group slot); gridDim.z splits the strips further in the passes that keep no sums over them.  See wide_shape().
-#define MRLA_WIDE_PROLOGUE(NRED, WAVE_BYTES)                                                              \
+// (ZS of NZS: this workgroup's strip range -- blockIdx.z of gridDim.z, unless the rows are cut as well: RowCut below)
+#define MRLA_WIDE_PROLOGUE_Z(NRED, WAVE_BYTES, ZS, NZS)                                                   \
   extern __shared__ __align__(16) unsigned char smem_raw[];                                               \
   const int lane = threadIdx.x & (kWave - 1), wave = threadIdx.x / kWave, nwaves = blockDim.x / kWave;    \
   float* red = reinterpret_cast<float*>(smem_raw);                                                        \
@@ -67,9 +68,49 @@ namespace mrla {
   const int cbase = (blockIdx.x * wc + wave % wc) * kWave;                                                \
   const int c = cbase + lane;                                                                             \
   const int nstrips = (W + kS - 1) / kS;                                                                  \
-  const int sfirst = blockIdx.z * (nwaves / wc) + wave / wc, sstep = gridDim.z * (nwaves / wc);           \
+  const int sfirst = (ZS) * (nwaves / wc) + wave / wc, sstep = (NZS) * (nwaves / wc);                     \
   const int rowelems = W * C;                                                                             \
   (void)red;
+#define MRLA_WIDE_PROLOGUE(NRED, WAVE_BYTES) MRLA_WIDE_PROLOGUE_Z(NRED, WAVE_BYTES, blockIdx.z, gridDim.z)
+
+// Row ranges (round 6).  The row pipeline's parallelism is images x channel groups x strips; a detection batch (2 images of
+// 256 x 200 x 336) has 384 waves of that kind for 2 048 slots.  Where a launch would leave most CUs without a workgroup even
+// after its strip rounds went to gridDim.z, the ROWS of an image are cut into `nzr` ranges as well: gridDim.z = strip ranges x
+// row ranges, blockIdx.z = row range * strip ranges + strip range.  A workgroup then walks rows [r0, r0 + n) of its images in
+// a frame that starts at r0: the halo rows above and below are fetched from the neighbouring ranges' rows (the image's rows
+// are [lo, hi) = [-r0, H - r0) in that frame) instead of arriving as zeros, sums are kept over the owned rows only, and every
+// range leaves its own partial record / row, exactly as the strip ranges do.  CUT = false is the kernel as it was: one range,
+// r0 = 0, every expression below a constant or H itself.
+template <bool CUT> struct RowCut;
+template <> struct RowCut<false> {
+  int H;
+  __device__ __forceinline__ RowCut(int H_, int, int) : H(H_) {}
+  __device__ __forceinline__ int zs() const { return blockIdx.z; }
+  __device__ __forceinline__ int nzs() const { return gridDim.z; }
+  __device__ __forceinline__ int r0() const { return 0; }
+  __device__ __forceinline__ int n() const { return H; }
+  __device__ __forceinline__ int lo() const { return 0; }
+  __device__ __forceinline__ int hi() const { return H; }
+  __device__ __forceinline__ bool above() const { return false; }      // rows above the range that belong to the image
+};
+template <> struct RowCut<true> {
+  int zs_, nzs_, r0_, n_, hi_;
+  __device__ __forceinline__ RowCut(int H, int nzr, int) {
+    nzs_ = gridDim.z / nzr;
+    zs_ = blockIdx.z % nzs_;
+    const int per = (H + nzr - 1) / nzr;
+    r0_ = (int)(blockIdx.z / nzs_) * per;
+    n_ = min(per, H - r0_);
+    hi_ = H - r0_;
+  }
+  __device__ __forceinline__ int zs() const { return zs_; }
+  __device__ __forceinline__ int nzs() const { return nzs_; }
+  __device__ __forceinline__ int r0() const { return r0_; }
+  __device__ __forceinline__ int n() const { return n_; }
+  __device__ __forceinline__ int lo() const { return -r0_; }
+  __device__ __forceinline__ int hi() const { return hi_; }
+  __device__ __forceinline__ bool above() const { return r0_ > 0; }
+};
 
 // Runs step(r, A, B, C) for r = 0 .. n-1 with the three row windows rotating by name.
 #define MRLA_ROTATE3(n, step, A, B, C)                       \
@@ -163,15 +204,21 @@ static inline void wide_shape(WidePass pass, int C, int W, int* wc_out, int* ws_
   *ws_out = std::max(1, std::min(waves / wc, nstrips));
 }
 
+struct ZRanges { int strips, rows; };              // gridDim.z = strips x rows
 int nhwc_images_per_group(int B, int C, int W);
-int nhwc_wgrad_ranges(int B, int C, int W);       // strip ranges of the dWv-producing backward passes (rows = image groups x ranges)
-int nhwc_bmom_ranges(int B, int C, int W);        // ... of the backward statistics pass (partial records)
-int nhwc_mom_ranges(int B, int C, int W);         // ... of the forward statistics passes (records mom[z], merged into mom[0])
+// gridDim.z of the passes that keep sums (strip ranges x row ranges; the public queries return strips * rows):
+ZRanges nhwc_wgrad_zranges(int B, int C, int H, int W);     // the dWv-producing backward passes (partial rows = image groups x z)
+ZRanges nhwc_bmom_zranges(int B, int C, int H, int W);      // the backward statistics pass (partial records)
+ZRanges nhwc_mom_zranges(int B, int C, int H, int W);       // the forward statistics passes (records mom[z], merged into mom[0])
+int nhwc_wgrad_ranges(int B, int C, int H, int W);
+int nhwc_bmom_ranges(int B, int C, int H, int W);
+int nhwc_mom_ranges(int B, int C, int H, int W);
 
 // split: every strip round of an image gets its own workgroup (gridDim.z; passes that keep no sums over the plane);
 // nz > 1: the strips are cut into that many ranges (passes WITH sums: every range leaves its own partial record / row).
+// nz_rows: row ranges (RowCut; the kernel gets the same number as `nzr`).
 static inline WideLaunch wide_launch(WidePass pass, int B, int C, int W, int nred, size_t wave_bytes, int bg, bool split,
-                                     int nz_ranges = 1) {
+                                     int nz_ranges = 1, int nz_rows = 1) {
   WideLaunch L;
   const int ncg = C / kWave, nstrips = (W + kS - 1) / kS;
   int wc, ws;
@@ -180,7 +227,7 @@ static inline WideLaunch wide_launch(WidePass pass, int B, int C, int W, int nre
   if (bg <= 0) bg = (int)std::max(1L, std::min(8L, (long)B * (ncg / wc) * nz / 2048));
   L.wc = wc;
   L.BG = bg;
-  L.grid = dim3(ncg / wc, (B + bg - 1) / bg, nz);
+  L.grid = dim3(ncg / wc, (B + bg - 1) / bg, nz * std::max(1, nz_rows));
   L.block = dim3(wc * ws * kWave);
   L.lds = (size_t)wc * ws * ((size_t)nred * kWave * sizeof(float) + wave_bytes);
   return L;
@@ -202,6 +249,51 @@ static inline int wide_strip_ranges(WidePass pass, int B, int C, int W, int bg) 
   const long wgs = (long)(C / kWave / wc) * ((B + bg - 1) / bg);
   if (wgs >= 256) return 1;                            // a workgroup per CU already
   return (int)std::min<long>(rounds, (512 + wgs - 1) / wgs);
+}
+
+// Row ranges of a launch that has `wgs` workgroups after its strip rounds were spread (see RowCut): none when every CU has
+// a workgroup, or when the tensor is too small for the launch to matter (below kMinCutElems elements a pass moves < 100 MB);
+// otherwise towards kCutTargetWgs workgroups, ranges of at least kMinCutRows rows (each range re-fetches two halo rows and
+// waits for its first rows alone, and the backward apply pass re-computes one row of dU), every range non-empty.
+// Measured on the detection backbone's step (2 x 3 x 800 x 1344, scripts/r06_cut_sweep.sh, ms per step, two rounds):
+// (rows >= 8, 512 workgroups) 9.05 / 9.03, (12, 384) 8.88 / 8.88, (16, 256) 9.22 / 9.31, (16, 512) 9.21 / 9.22,
+// (24, 512) 9.02 / 9.08, (8, 768) 9.37 / 9.32; uncut: 11.4.
+// nhwc_row_cut_mode(): 0 = as described, 1 = never, 2 = wherever an image has >= 16 rows, ranges of >= 8 (the parity tests
+// run small shapes through the cut kernels with it: mrla_tuning_row_ranges()).
+#ifndef MRLA_CUT_MIN_ROWS
+#define MRLA_CUT_MIN_ROWS 12
+#endif
+#ifndef MRLA_CUT_TARGET_WGS
+#define MRLA_CUT_TARGET_WGS 384
+#endif
+constexpr int kMinCutRows = MRLA_CUT_MIN_ROWS;
+constexpr long kCutTargetWgs = MRLA_CUT_TARGET_WGS;
+constexpr long kMinCutElems = 8L << 20;
+int nhwc_row_cut_mode();
+static inline int wide_row_ranges(long wgs, int H, long elems) {
+  const int mode = nhwc_row_cut_mode();
+  const int min_rows = mode == 2 ? 8 : kMinCutRows;
+  const long target = mode == 2 ? 512 : kCutTargetWgs;
+  if (mode == 1 || H < 2 * min_rows) return 1;
+  if (mode == 0 && (wgs >= 256 || elems < kMinCutElems)) return 1;
+  const int n = (int)std::min<long>(std::max(2L, (target + wgs - 1) / wgs), H / min_rows);
+  if (n <= 1) return 1;
+  const int per = (H + n - 1) / n;
+  return (H + per - 1) / per;
+}
+// workgroups of a launch of `pass` with `nzs` strip ranges (bg <= 0: wide_launch()'s own choice)
+static inline long wide_workgroups(WidePass pass, int B, int C, int W, int bg, int nzs) {
+  int wc, ws;
+  wide_shape(pass, C, W, &wc, &ws);
+  const int ncg = C / kWave;
+  if (bg <= 0) bg = (int)std::max(1L, std::min(8L, (long)B * (ncg / wc) * nzs / 2048));
+  return (long)(ncg / wc) * ((B + bg - 1) / bg) * nzs;
+}
+// strip rounds of a pass without sums (wide_launch(split = true) gives each its own workgroup)
+static inline int wide_strip_rounds(WidePass pass, int C, int W) {
+  int wc, ws;
+  wide_shape(pass, C, W, &wc, &ws);
+  return ((W + kS - 1) / kS + ws - 1) / ws;
 }
 
 // tensors of this size and beyond are fetched `nt` by the 3N passes (see the note at the top of the file)

@@ -9,6 +9,7 @@
 // instruction, and the file is compiled without the SLP vectoriser (its v_pk_fma_f32 pairs cost more moves than they save).
 // What bounds them on this pipeline is WHICH BYTES A CU REQUESTS AT ONE TIME (profiles/r04_notes.md section 9): hence the
 // workgroups of neighbouring channel groups, wide_shape() below.
+#include <atomic>
 #include "light_nhwc_wide.h"
 
 namespace mrla {
@@ -65,26 +66,29 @@ __device__ __forceinline__ void store_moments(WaveMoments& w, float* __restrict_
   }
 }
 
-// The forward statistics passes spread an image's strip rounds over gridDim.z ranges when the launch would otherwise leave
-// most of the chip idle (wide_strip_ranges(): detection batches); range z leaves its record at mom[z][b][c].  This kernel
-// folds ranges 1 .. nz-1 into record 0 -- the one every consumer reads -- by the algebra of WaveMoments::merge (re-based onto
-// range 0's pivots, in range order); n_z = pixels of range z = strip rounds r with r % nz == z, `ws` strips each.
+// The forward statistics passes spread an image's strip rounds -- and, beyond that, its rows (RowCut) -- over gridDim.z ranges
+// when the launch would otherwise leave most of the chip idle (detection batches); range z leaves its record at mom[z][b][c].
+// This kernel folds ranges 1 .. nz-1 into record 0 -- the one every consumer reads -- by the algebra of WaveMoments::merge
+// (re-based onto range 0's pivots, in range order); z = row range * nzs + strip range, n_z = pixels of range z = (strip rounds
+// r with r % nzs == strip range, `ws` strips each) x (rows of the row range).
 __global__ __launch_bounds__(kThreads) void light_mom_merge_kernel(float* __restrict__ mom, int B, int C, int H, int W, int ws,
-                                                                   int nz) {
+                                                                   int nzs, int nzr) {
   const int i = blockIdx.x * kThreads + threadIdx.x;
   if (i >= B * C) return;
   const int nstrips = (W + kS - 1) / kS;
+  const int per = (H + nzr - 1) / nzr;
   auto pixels_of = [&](int z) {
+    const int zs = z % nzs, zr = z / nzs;
     int n = 0;
-    for (int r = z; r * ws < nstrips; r += nz)
+    for (int r = zs; r * ws < nstrips; r += nzs)
       for (int j = 0; j < ws && r * ws + j < nstrips; ++j) n += min(kS, W - (r * ws + j) * kS);
-    return (float)(n * H);
+    return (float)(n * max(0, min(per, H - zr * per)));
   };
   float* m0 = mom + (size_t)i * M_REC;
   WaveMoments w;
   w.clear();
   float sx = 0.f;
-  for (int z = 0; z < nz; ++z) {
+  for (int z = 0; z < nzs * nzr; ++z) {
     const float* mz = m0 + (size_t)z * B * C * M_REC;
     const float n = pixels_of(z);
     if (n == 0.f) continue;
@@ -109,11 +113,12 @@ __global__ __launch_bounds__(kThreads) void light_mom_merge_kernel(float* __rest
 // ------------------------------------------------------------------------------------------------
 template <typename T> constexpr int stats_bwd_wave_bytes() { return RowIO<T, kS + 2>::kBytes + 2 * RowIO<T, kS>::kBytes; }
 
-template <typename T, bool GELU, bool HAS_O, int AUX>
+template <typename T, bool GELU, bool HAS_O, int AUX, bool CUT>
 __global__ __launch_bounds__(kMaxStrips * kWave) void light_stats_bwd_wide(
     const T* __restrict__ dout, const T* __restrict__ x, const T* __restrict__ o, const float* __restrict__ wv,
-    const float* __restrict__ mom, float* __restrict__ bmom, int B, int C, int H, int W, int BG, int wc) {
-  MRLA_WIDE_PROLOGUE(D_N, stats_bwd_wave_bytes<T>())
+    const float* __restrict__ mom, float* __restrict__ bmom, int B, int C, int H, int W, int BG, int wc, int nzr) {
+  const RowCut<CUT> rc(H, nzr, 0);
+  MRLA_WIDE_PROLOGUE_Z(D_N, stats_bwd_wave_bytes<T>(), rc.zs(), rc.nzs())
   T* bufX = reinterpret_cast<T*>(wbuf);
   T* bufG = reinterpret_cast<T*>(wbuf + RowIO<T, kS + 2>::kBytes);
   T* bufO = reinterpret_cast<T*>(wbuf + RowIO<T, kS + 2>::kBytes + RowIO<T, kS>::kBytes);
@@ -122,7 +127,7 @@ __global__ __launch_bounds__(kMaxStrips * kWave) void light_stats_bwd_wide(
   for (int k = 0; k < 9; ++k) w[k] = wv[c * 9 + k];
   const int b_end = min(B, (int)(blockIdx.y + 1) * BG);
   for (int b = blockIdx.y * BG; b < b_end; ++b) {
-    const size_t ioff = (size_t)b * H * rowelems;
+    const size_t ioff = ((size_t)b * H + rc.r0()) * rowelems;
     const T* xi = x + ioff;
     const T* gi = dout + ioff;
     const T* oi = HAS_O ? o + ioff : nullptr;
@@ -138,12 +143,17 @@ __global__ __launch_bounds__(kMaxStrips * kWave) void light_stats_bwd_wide(
       RawRow<kS + 2> xa, xb, xc;                     // x rows r-1, r, r+1 on columns s0-1 .. s0+kS
       RawRow<kS> gv, ov;
       xa.clear(); xb.clear(); xc.clear(); gv.clear(); ov.clear();
-      row_fetch<T, kS + 2, AUX>(ax, xi, 0, H, rowelems, bufX);
+      if (CUT && rc.above()) {                       // the row above the range belongs to the image
+        row_fetch_in<T, kS + 2, AUX>(ax, xi, -1, rc.lo(), rc.hi(), rowelems, bufX);
+        rows_landed();
+        row_read<T, kS + 2>(bufX, lane, xa);
+      }
+      row_fetch_in<T, kS + 2, AUX>(ax, xi, 0, rc.lo(), rc.hi(), rowelems, bufX);
       rows_landed();
       row_read<T, kS + 2>(bufX, lane, xb);
-      row_fetch<T, kS + 2, AUX>(ax, xi, 1, H, rowelems, bufX);
-      row_fetch<T, kS, AUX>(ag, gi, 0, H, rowelems, bufG);
-      if (HAS_O) row_fetch<T, kS, AUX>(ag, oi, 0, H, rowelems, bufO);
+      row_fetch_in<T, kS + 2, AUX>(ax, xi, 1, rc.lo(), rc.hi(), rowelems, bufX);
+      row_fetch_in<T, kS, AUX>(ag, gi, 0, rc.lo(), rc.hi(), rowelems, bufG);
+      if (HAS_O) row_fetch_in<T, kS, AUX>(ag, oi, 0, rc.lo(), rc.hi(), rowelems, bufO);
       // dOut (and o) are zero beyond the image, so columns of a ragged last strip drop out of every sum by themselves
       auto step = [&](int r, RawRow<kS + 2>& XA, RawRow<kS + 2>& XB, RawRow<kS + 2>& XC) {
         rows_landed();
@@ -153,9 +163,9 @@ __global__ __launch_bounds__(kMaxStrips * kWave) void light_stats_bwd_wide(
         row_read_fence(XC, true);
         row_read_fence(gv, false);
         if (HAS_O) row_read_fence(ov, false);
-        row_fetch<T, kS + 2, AUX>(ax, xi, r + 2, H, rowelems, bufX);
-        row_fetch<T, kS, AUX>(ag, gi, r + 1, H, rowelems, bufG);
-        if (HAS_O) row_fetch<T, kS, AUX>(ag, oi, r + 1, H, rowelems, bufO);
+        row_fetch_in<T, kS + 2, AUX>(ax, xi, r + 2, rc.lo(), rc.hi(), rowelems, bufX);
+        row_fetch_in<T, kS, AUX>(ag, gi, r + 1, rc.lo(), rc.hi(), rowelems, bufG);
+        if (HAS_O) row_fetch_in<T, kS, AUX>(ag, oi, r + 1, rc.lo(), rc.hi(), rowelems, bufO);
 #pragma unroll
         for (int j = 0; j < kS; ++j) {
           float v = conv_at(w, XA.v, XB.v, XC.v, j);
@@ -165,7 +175,7 @@ __global__ __launch_bounds__(kMaxStrips * kWave) void light_stats_bwd_wide(
           if (HAS_O) acc[D_DO] = fmaf(gv.v[j], ov.v[j] - pO, acc[D_DO]);
         }
       };
-      MRLA_ROTATE3(H, step, xa, xb, xc)
+      MRLA_ROTATE3(rc.n(), step, xa, xb, xc)
       rows_landed();                                 // the look-ahead rows of the last step (zeros) are still in flight
     }
     wg_reduce<D_N>(acc, red, lane, wave, nwaves, wc);
@@ -183,11 +193,12 @@ __global__ __launch_bounds__(kMaxStrips * kWave) void light_stats_bwd_wide(
 // ------------------------------------------------------------------------------------------------
 template <typename T> constexpr int stats_fwd_wave_bytes() { return RowIO<T, kS + 2>::kBytes + 2 * RowIO<T, kS>::kBytes; }
 
-template <typename T, bool GELU, bool HAS_O, bool RAGGED>
+template <typename T, bool GELU, bool HAS_O, bool RAGGED, bool CUT>
 __global__ __launch_bounds__(kMaxStrips * kWave) void light_stats_fwd_wide(
     const T* __restrict__ x, const T* __restrict__ o, const float* __restrict__ wv, float* __restrict__ mom,
-    T* __restrict__ vout, int B, int C, int H, int W, int BG, int wc) {
-  MRLA_WIDE_PROLOGUE(kMomRed, stats_fwd_wave_bytes<T>())
+    T* __restrict__ vout, int B, int C, int H, int W, int BG, int wc, int nzr) {
+  const RowCut<CUT> rc(H, nzr, 0);
+  MRLA_WIDE_PROLOGUE_Z(kMomRed, stats_fwd_wave_bytes<T>(), rc.zs(), rc.nzs())
   T* bufX = reinterpret_cast<T*>(wbuf);
   T* bufO = reinterpret_cast<T*>(wbuf + RowIO<T, kS + 2>::kBytes);
   T* bufS = reinterpret_cast<T*>(wbuf + RowIO<T, kS + 2>::kBytes + RowIO<T, kS>::kBytes);
@@ -196,7 +207,7 @@ __global__ __launch_bounds__(kMaxStrips * kWave) void light_stats_fwd_wide(
   for (int k = 0; k < 9; ++k) w[k] = wv[c * 9 + k];
   const int b_end = min(B, (int)(blockIdx.y + 1) * BG);
   for (int b = blockIdx.y * BG; b < b_end; ++b) {
-    const size_t ioff = (size_t)b * H * rowelems;
+    const size_t ioff = ((size_t)b * H + rc.r0()) * rowelems;
     const T* xi = x + ioff;
     const T* oi = HAS_O ? o + ioff : nullptr;
     T* vo = vout ? vout + ioff : nullptr;
@@ -214,19 +225,24 @@ __global__ __launch_bounds__(kMaxStrips * kWave) void light_stats_fwd_wide(
       RawRow<kS + 2> xa, xb, xc;
       RawRow<kS> ov;
       xa.clear(); xb.clear(); xc.clear(); ov.clear();
-      row_fetch<T, kS + 2>(ax, xi, 0, H, rowelems, bufX);
+      if (CUT && rc.above()) {                       // the row above the range belongs to the image
+        row_fetch_in<T, kS + 2>(ax, xi, -1, rc.lo(), rc.hi(), rowelems, bufX);
+        rows_landed();
+        row_read<T, kS + 2>(bufX, lane, xa);
+      }
+      row_fetch_in<T, kS + 2>(ax, xi, 0, rc.lo(), rc.hi(), rowelems, bufX);
       rows_landed();
       row_read<T, kS + 2>(bufX, lane, xb);
-      row_fetch<T, kS + 2>(ax, xi, 1, H, rowelems, bufX);
-      if (HAS_O) row_fetch<T, kS>(ao, oi, 0, H, rowelems, bufO);
+      row_fetch_in<T, kS + 2>(ax, xi, 1, rc.lo(), rc.hi(), rowelems, bufX);
+      if (HAS_O) row_fetch_in<T, kS>(ao, oi, 0, rc.lo(), rc.hi(), rowelems, bufO);
       auto step = [&](int r, RawRow<kS + 2>& XA, RawRow<kS + 2>& XB, RawRow<kS + 2>& XC) {
         rows_landed();
         row_read_issue<T, kS + 2>(bufX, lane, XC);
         if (HAS_O) row_read_issue<T, kS>(bufO, lane, ov);
         row_read_fence(XC, true);
         if (HAS_O) row_read_fence(ov, false);
-        row_fetch<T, kS + 2>(ax, xi, r + 2, H, rowelems, bufX);
-        if (HAS_O) row_fetch<T, kS>(ao, oi, r + 1, H, rowelems, bufO);
+        row_fetch_in<T, kS + 2>(ax, xi, r + 2, rc.lo(), rc.hi(), rowelems, bufX);
+        if (HAS_O) row_fetch_in<T, kS>(ao, oi, r + 1, rc.lo(), rc.hi(), rowelems, bufO);
         float vrow[kS];
 #pragma unroll
         for (int j = 0; j < kS; ++j) {
@@ -250,9 +266,9 @@ __global__ __launch_bounds__(kMaxStrips * kWave) void light_stats_fwd_wide(
         }
         if (vo) row_store<T, kS>(as, vo, r, rowelems, lane, bufS, vrow);
       };
-      MRLA_ROTATE3(H, step, xa, xb, xc)
+      MRLA_ROTATE3(rc.n(), step, xa, xb, xc)
       rows_landed();
-      wm.merge(acc, pV, pO, (float)(H * nc));
+      wm.merge(acc, pV, pO, (float)(rc.n() * nc));
     }
     store_moments(wm, red, mom + (((size_t)blockIdx.z * B + b) * C + c) * M_REC, lane, wave, nwaves, wc);      // (range z's record)
   }
@@ -265,12 +281,13 @@ __global__ __launch_bounds__(kMaxStrips * kWave) void light_stats_fwd_wide(
 // ------------------------------------------------------------------------------------------------
 // STORE_X = false (round 6): x_t is formed for the statistics and NOT written -- the training tail that re-forms it from `pre`
 // and `o` in every later pass (apply_fwd_pre, light_nhwc_lean.hip) moves 2N here instead of 3N.
-template <typename T, bool AFF, bool RAGGED, int AUX, bool STORE_X>
+template <typename T, bool AFF, bool RAGGED, int AUX, bool STORE_X, bool CUT>
 __device__ __forceinline__ void light_stats_fwd_fused_body(
     const T* __restrict__ pre, const T* __restrict__ o, const float* __restrict__ wv, float* __restrict__ mom,
     T* __restrict__ xout, const float* __restrict__ psc, const float* __restrict__ psh, T* __restrict__ vout, int B,
-    int C, int H, int W, int BG, int wc) {
-  MRLA_WIDE_PROLOGUE(kMomRed, fused_wave_bytes<T>())
+    int C, int H, int W, int BG, int wc, int nzr) {
+  const RowCut<CUT> rc(H, nzr, 0);
+  MRLA_WIDE_PROLOGUE_Z(kMomRed, fused_wave_bytes<T>(), rc.zs(), rc.nzs())
   constexpr int RB = RowIO<T, kS + 2>::kBytes;
   T* bufP = reinterpret_cast<T*>(wbuf);
   unsigned char* bufO2 = wbuf + RB;                  // o row r lives in half (r & 1)
@@ -281,7 +298,7 @@ __device__ __forceinline__ void light_stats_fwd_fused_body(
   const float asc = AFF ? psc[c] : 1.f, ash = AFF ? psh[c] : 0.f;
   const int b_end = min(B, (int)(blockIdx.y + 1) * BG);
   for (int b = blockIdx.y * BG; b < b_end; ++b) {
-    const size_t ioff = (size_t)b * H * rowelems;
+    const size_t ioff = ((size_t)b * H + rc.r0()) * rowelems;
     const T* pi = pre + ioff;
     const T* oi = o + ioff;
     T* xo = STORE_X ? xout + ioff : nullptr;
@@ -309,15 +326,24 @@ __device__ __forceinline__ void light_stats_fwd_fused_body(
         for (int j = 0; j < kS; ++j) own[j] = row[j + 1];
         row_store<T, kS>(as, dst, r, rowelems, lane, bufS, own);
       };
+      if (CUT && rc.above()) {                       // x_t of the row above the range (it belongs to the image)
+        row_fetch_in<T, kS + 2, AUX>(ax, pi, -1, rc.lo(), rc.hi(), rowelems, bufP);
+        row_fetch_in<T, kS + 2, AUX>(ax, oi, -1, rc.lo(), rc.hi(), rowelems, obuf(0));
+        rows_landed();
+        row_read<T, kS + 2>(bufP, lane, praw);
+        row_read<T, kS + 2>(obuf(0), lane, oraw);
+        form_x_row<T, AFF, RAGGED>(praw, oraw, asc, shj, xa);
+      } else {
 #pragma unroll
-      for (int j = 0; j < kS + 2; ++j) xa[j] = 0.f;
-      row_fetch<T, kS + 2, AUX>(ax, pi, 0, H, rowelems, bufP);
-      row_fetch<T, kS + 2, AUX>(ax, oi, 0, H, rowelems, obuf(0));
+        for (int j = 0; j < kS + 2; ++j) xa[j] = 0.f;
+      }
+      row_fetch_in<T, kS + 2, AUX>(ax, pi, 0, rc.lo(), rc.hi(), rowelems, bufP);
+      row_fetch_in<T, kS + 2, AUX>(ax, oi, 0, rc.lo(), rc.hi(), rowelems, obuf(0));
       rows_landed();
       row_read<T, kS + 2>(bufP, lane, praw);
       row_read<T, kS + 2>(obuf(0), lane, oraw);
-      row_fetch<T, kS + 2, AUX>(ax, pi, 1, H, rowelems, bufP);
-      row_fetch<T, kS + 2, AUX>(ax, oi, 1, H, rowelems, obuf(1));
+      row_fetch_in<T, kS + 2, AUX>(ax, pi, 1, rc.lo(), rc.hi(), rowelems, bufP);
+      row_fetch_in<T, kS + 2, AUX>(ax, oi, 1, rc.lo(), rc.hi(), rowelems, obuf(1));
       form_x_row<T, AFF, RAGGED>(praw, oraw, asc, shj, xb);
       if (STORE_X) store_owned(xo, 0, xb);
       auto step = [&](int r, float (&XA)[kS + 2], float (&XB)[kS + 2], float (&XC)[kS + 2]) {
@@ -331,11 +357,11 @@ __device__ __forceinline__ void light_stats_fwd_fused_body(
         row_read_fence(praw, true);
         row_read_fence(oraw, false);
         row_read_fence(ov, false);
-        row_fetch<T, kS + 2, AUX>(ax, pi, r + 2, H, rowelems, bufP);
-        row_fetch<T, kS + 2, AUX>(ax, oi, r + 2, H, rowelems, obuf(r));
-        if (r + 1 < H) {
+        row_fetch_in<T, kS + 2, AUX>(ax, pi, r + 2, rc.lo(), rc.hi(), rowelems, bufP);
+        row_fetch_in<T, kS + 2, AUX>(ax, oi, r + 2, rc.lo(), rc.hi(), rowelems, obuf(r));
+        if (r + 1 < rc.hi()) {
           form_x_row<T, AFF, RAGGED>(praw, oraw, asc, shj, XC);
-          if (STORE_X) store_owned(xo, r + 1, XC);
+          if (STORE_X && (!CUT || r + 1 < rc.n())) store_owned(xo, r + 1, XC);      // (the row below the range: its owner's)
         } else {
 #pragma unroll
           for (int j = 0; j < kS + 2; ++j) XC[j] = 0.f;
@@ -357,20 +383,20 @@ __device__ __forceinline__ void light_stats_fwd_fused_body(
         }
         if (vo) row_store<T, kS>(as, vo, r, rowelems, lane, bufS, vrow);
       };
-      MRLA_ROTATE3(H, step, xa, xb, xc)
+      MRLA_ROTATE3(rc.n(), step, xa, xb, xc)
       rows_landed();
-      wm.merge(acc, pV, pO, (float)(H * nc));
+      wm.merge(acc, pV, pO, (float)(rc.n() * nc));
     }
     store_moments(wm, red, mom + (((size_t)blockIdx.z * B + b) * C + c) * M_REC, lane, wave, nwaves, wc);      // (range z's record)
   }
 }
 
-template <typename T, bool AFF, bool RAGGED, int AUX, bool STORE_X>
+template <typename T, bool AFF, bool RAGGED, int AUX, bool STORE_X, bool CUT>
 __global__ __launch_bounds__(kMaxStrips * kWave) void light_stats_fwd_fused_wide(
     const T* __restrict__ pre, const T* __restrict__ o, const float* __restrict__ wv, float* __restrict__ mom,
     T* __restrict__ xout, const float* __restrict__ psc, const float* __restrict__ psh, T* __restrict__ vout, int B,
-    int C, int H, int W, int BG, int wc) {
-  light_stats_fwd_fused_body<T, AFF, RAGGED, AUX, STORE_X>(pre, o, wv, mom, xout, psc, psh, vout, B, C, H, W, BG, wc);
+    int C, int H, int W, int BG, int wc, int nzr) {
+  light_stats_fwd_fused_body<T, AFF, RAGGED, AUX, STORE_X, CUT>(pre, o, wv, mom, xout, psc, psh, vout, B, C, H, W, BG, wc, nzr);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -379,12 +405,13 @@ __global__ __launch_bounds__(kMaxStrips * kWave) void light_stats_fwd_fused_wide
 // ------------------------------------------------------------------------------------------------
 template <typename T> constexpr int apply_fwd_wave_bytes() { return RowIO<T, kS + 2>::kBytes + 2 * RowIO<T, kS>::kBytes; }
 
-template <typename T, bool GELU, bool HAS_O, int AUX>
+template <typename T, bool GELU, bool HAS_O, int AUX, bool CUT>
 __global__ __launch_bounds__(kMaxStrips * kWave) void light_apply_fwd_wide(
     const T* __restrict__ x, const T* __restrict__ o, const float* __restrict__ wv, const float* __restrict__ gate,
     const float* __restrict__ sc, const float* __restrict__ sh, const float* __restrict__ lam,
-    const float* __restrict__ dp, T* __restrict__ out, int B, int C, int H, int W, int BG, int d, int res, int wc) {
-  MRLA_WIDE_PROLOGUE(0, apply_fwd_wave_bytes<T>())
+    const float* __restrict__ dp, T* __restrict__ out, int B, int C, int H, int W, int BG, int d, int res, int wc, int nzr) {
+  const RowCut<CUT> rc(H, nzr, 0);
+  MRLA_WIDE_PROLOGUE_Z(0, apply_fwd_wave_bytes<T>(), rc.zs(), rc.nzs())
   T* bufX = reinterpret_cast<T*>(wbuf);
   T* bufO = reinterpret_cast<T*>(wbuf + RowIO<T, kS + 2>::kBytes);
   T* bufS = reinterpret_cast<T*>(wbuf + RowIO<T, kS + 2>::kBytes + RowIO<T, kS>::kBytes);
@@ -397,7 +424,7 @@ __global__ __launch_bounds__(kMaxStrips * kWave) void light_apply_fwd_wide(
   const int yy = MRLA_REVERSE_APPLY ? (int)(gridDim.y - 1 - blockIdx.y) : (int)blockIdx.y;   // (see the note at the top)
   const int b_end = min(B, (yy + 1) * BG);
   for (int b = yy * BG; b < b_end; ++b) {
-    const size_t ioff = (size_t)b * H * rowelems;
+    const size_t ioff = ((size_t)b * H + rc.r0()) * rowelems;
     const T* xi = x + ioff;
     const T* oi = HAS_O ? o + ioff : nullptr;
     T* yo = out + ioff;
@@ -419,11 +446,16 @@ __global__ __launch_bounds__(kMaxStrips * kWave) void light_apply_fwd_wide(
       RawRow<kS + 2> xa, xb, xc;
       RawRow<kS> ov;
       xa.clear(); xb.clear(); xc.clear(); ov.clear();
-      row_fetch<T, kS + 2, AUX>(ax, xi, 0, H, rowelems, bufX);
+      if (CUT && rc.above()) {                       // the row above the range belongs to the image
+        row_fetch_in<T, kS + 2, AUX>(ax, xi, -1, rc.lo(), rc.hi(), rowelems, bufX);
+        rows_landed();
+        row_read<T, kS + 2>(bufX, lane, xa);
+      }
+      row_fetch_in<T, kS + 2, AUX>(ax, xi, 0, rc.lo(), rc.hi(), rowelems, bufX);
       rows_landed();
       row_read<T, kS + 2>(bufX, lane, xb);
-      row_fetch<T, kS + 2, AUX>(ax, xi, 1, H, rowelems, bufX);
-      if (HAS_O) row_fetch<T, kS, AUX>(ao, oi, 0, H, rowelems, bufO);
+      row_fetch_in<T, kS + 2, AUX>(ax, xi, 1, rc.lo(), rc.hi(), rowelems, bufX);
+      if (HAS_O) row_fetch_in<T, kS, AUX>(ao, oi, 0, rc.lo(), rc.hi(), rowelems, bufO);
       auto step = [&](int r, RawRow<kS + 2>& XA, RawRow<kS + 2>& XB, RawRow<kS + 2>& XC) {
         // the previous step's output row (its newest memory instructions) may stay in flight
         if (r == 0) rows_landed(); else rows_landed_keep<RowIO<T, kS>::NL>();
@@ -431,8 +463,8 @@ __global__ __launch_bounds__(kMaxStrips * kWave) void light_apply_fwd_wide(
         if (HAS_O) row_read_issue<T, kS>(bufO, lane, ov);
         row_read_fence(XC, true);
         if (HAS_O) row_read_fence(ov, false);
-        row_fetch<T, kS + 2, AUX>(ax, xi, r + 2, H, rowelems, bufX);
-        if (HAS_O) row_fetch<T, kS, AUX>(ao, oi, r + 1, H, rowelems, bufO);
+        row_fetch_in<T, kS + 2, AUX>(ax, xi, r + 2, rc.lo(), rc.hi(), rowelems, bufX);
+        if (HAS_O) row_fetch_in<T, kS, AUX>(ao, oi, r + 1, rc.lo(), rc.hi(), rowelems, bufO);
         float y[kS];
 #pragma unroll
         for (int j = 0; j < kS; ++j) {
@@ -442,7 +474,7 @@ __global__ __launch_bounds__(kMaxStrips * kWave) void light_apply_fwd_wide(
         }
         row_store<T, kS>(as, yo, r, rowelems, lane, bufS, y);
       };
-      MRLA_ROTATE3(H, step, xa, xb, xc)
+      MRLA_ROTATE3(rc.n(), step, xa, xb, xc)
       rows_landed();
     }
   }
@@ -450,13 +482,14 @@ __global__ __launch_bounds__(kMaxStrips * kWave) void light_apply_fwd_wide(
 
 // Inference form of the apply pass: x_t is re-formed from conv3's output and the shortcut while it is convolved (it is
 // neither needed again nor saved when nothing is differentiated): the block tail moves 5N instead of 6N elements.
-template <typename T, bool AFF>
+template <typename T, bool AFF, bool CUT>
 __global__ __launch_bounds__(kMaxStrips * kWave) void light_apply_fwd_pre_wide(
     const T* __restrict__ pre, const T* __restrict__ o, const float* __restrict__ psc, const float* __restrict__ psh,
     const float* __restrict__ wv, const float* __restrict__ gate, const float* __restrict__ sc,
     const float* __restrict__ sh, const float* __restrict__ lam, const float* __restrict__ dp, T* __restrict__ out, int B,
-    int C, int H, int W, int BG, int d, int res, int wc) {
-  MRLA_WIDE_PROLOGUE(0, fused_wave_bytes<T>())
+    int C, int H, int W, int BG, int d, int res, int wc, int nzr) {
+  const RowCut<CUT> rc(H, nzr, 0);
+  MRLA_WIDE_PROLOGUE_Z(0, fused_wave_bytes<T>(), rc.zs(), rc.nzs())
   constexpr int RB = RowIO<T, kS + 2>::kBytes;
   T* bufP = reinterpret_cast<T*>(wbuf);
   unsigned char* bufO2 = wbuf + RB;
@@ -470,7 +503,7 @@ __global__ __launch_bounds__(kMaxStrips * kWave) void light_apply_fwd_pre_wide(
   const float asc = AFF ? psc[c] : 1.f, ash = AFF ? psh[c] : 0.f;
   const int b_end = min(B, (int)(blockIdx.y + 1) * BG);
   for (int b = blockIdx.y * BG; b < b_end; ++b) {
-    const size_t ioff = (size_t)b * H * rowelems;
+    const size_t ioff = ((size_t)b * H + rc.r0()) * rowelems;
     const T* pi = pre + ioff;
     const T* oi = o + ioff;
     T* yo = out + ioff;
@@ -495,15 +528,24 @@ __global__ __launch_bounds__(kMaxStrips * kWave) void light_apply_fwd_pre_wide(
       praw.clear(); oraw.clear(); ov.clear();
       float xa[kS + 2], xb[kS + 2], xc[kS + 2];
       auto obuf = [&](int r) { return reinterpret_cast<T*>(bufO2 + (r & 1) * RB); };
+      if (CUT && rc.above()) {                       // x_t of the row above the range (it belongs to the image)
+        row_fetch_in<T, kS + 2>(ax, pi, -1, rc.lo(), rc.hi(), rowelems, bufP);
+        row_fetch_in<T, kS + 2>(ax, oi, -1, rc.lo(), rc.hi(), rowelems, obuf(0));
+        rows_landed();
+        row_read<T, kS + 2>(bufP, lane, praw);
+        row_read<T, kS + 2>(obuf(0), lane, oraw);
+        form_x_row<T, AFF, true>(praw, oraw, asc, shj, xa);
+      } else {
 #pragma unroll
-      for (int j = 0; j < kS + 2; ++j) xa[j] = 0.f;
-      row_fetch<T, kS + 2>(ax, pi, 0, H, rowelems, bufP);
-      row_fetch<T, kS + 2>(ax, oi, 0, H, rowelems, obuf(0));
+        for (int j = 0; j < kS + 2; ++j) xa[j] = 0.f;
+      }
+      row_fetch_in<T, kS + 2>(ax, pi, 0, rc.lo(), rc.hi(), rowelems, bufP);
+      row_fetch_in<T, kS + 2>(ax, oi, 0, rc.lo(), rc.hi(), rowelems, obuf(0));
       rows_landed();
       row_read<T, kS + 2>(bufP, lane, praw);
       row_read<T, kS + 2>(obuf(0), lane, oraw);
-      row_fetch<T, kS + 2>(ax, pi, 1, H, rowelems, bufP);
-      row_fetch<T, kS + 2>(ax, oi, 1, H, rowelems, obuf(1));
+      row_fetch_in<T, kS + 2>(ax, pi, 1, rc.lo(), rc.hi(), rowelems, bufP);
+      row_fetch_in<T, kS + 2>(ax, oi, 1, rc.lo(), rc.hi(), rowelems, obuf(1));
       form_x_row<T, AFF, true>(praw, oraw, asc, shj, xb);
       auto step = [&](int r, float (&XA)[kS + 2], float (&XB)[kS + 2], float (&XC)[kS + 2]) {
         if (r == 0) rows_landed(); else rows_landed_keep<RowIO<T, kS>::NL>();
@@ -513,9 +555,9 @@ __global__ __launch_bounds__(kMaxStrips * kWave) void light_apply_fwd_pre_wide(
         row_read_fence(praw, true);
         row_read_fence(oraw, false);
         row_read_fence(ov, false);
-        row_fetch<T, kS + 2>(ax, pi, r + 2, H, rowelems, bufP);
-        row_fetch<T, kS + 2>(ax, oi, r + 2, H, rowelems, obuf(r));
-        if (r + 1 < H) {
+        row_fetch_in<T, kS + 2>(ax, pi, r + 2, rc.lo(), rc.hi(), rowelems, bufP);
+        row_fetch_in<T, kS + 2>(ax, oi, r + 2, rc.lo(), rc.hi(), rowelems, obuf(r));
+        if (r + 1 < rc.hi()) {
           form_x_row<T, AFF, true>(praw, oraw, asc, shj, XC);
         } else {
 #pragma unroll
@@ -526,7 +568,7 @@ __global__ __launch_bounds__(kMaxStrips * kWave) void light_apply_fwd_pre_wide(
         for (int j = 0; j < kS; ++j) y[j] = fmaf(Bc, ov.v[j], conv_at(w, XA, XB, XC, j) + Cc);
         row_store<T, kS>(as, yo, r, rowelems, lane, bufS, y);
       };
-      MRLA_ROTATE3(H, step, xa, xb, xc)
+      MRLA_ROTATE3(rc.n(), step, xa, xb, xc)
       rows_landed();
     }
   }
@@ -546,15 +588,16 @@ __global__ __launch_bounds__(kMaxStrips * kWave) void light_apply_fwd_pre_wide(
 // here, so the two sums are taken here as well (one more kS-wide row fetch per step, two accumulators): the separate
 // 2N statistics pass over (dpre, y3) disappears.  y3 cannot be reconstructed from x_t - o instead: bn3's scale is zero
 // at initialisation (zero_init_last_bn) and tiny early in training.
-template <typename T, bool GELU, bool HAS_O, bool RELU, bool RAGGED, bool PRE>
+template <typename T, bool GELU, bool HAS_O, bool RELU, bool RAGGED, bool PRE, bool CUT>
 __global__ __launch_bounds__(kBwdWaves * kWave) void light_apply_bwd_wide(
     const T* __restrict__ dout, const T* __restrict__ x, const T* __restrict__ o, const float* __restrict__ wv,
     const float* __restrict__ gate, const float* __restrict__ cb, const float* __restrict__ lam,
     const float* __restrict__ dp, const float* __restrict__ dyx, T* __restrict__ dx, T* __restrict__ dprev,
     float* __restrict__ dwv_part, const T* __restrict__ pre, const float* __restrict__ pre_center,
-    float* __restrict__ pre_tmom, int B, int C, int H, int W, int BG, int d, int res, int wc) {
+    float* __restrict__ pre_tmom, int B, int C, int H, int W, int BG, int d, int res, int wc, int nzr) {
   static_assert(!PRE || RELU, "the deferred-BatchNorm sums belong to the fused relu(pre + o) producer");
-  MRLA_WIDE_PROLOGUE(9, (apply_bwd_wave_bytes<T, PRE>()))
+  const RowCut<CUT> rc(H, nzr, 0);
+  MRLA_WIDE_PROLOGUE_Z(9, (apply_bwd_wave_bytes<T, PRE>()), rc.zs(), rc.nzs())
   constexpr int XB_ = RowIO<T, kS + 4>::kBytes, GB = RowIO<T, kS + 2>::kBytes, SB = RowIO<T, kS>::kBytes;
   T* bufX = reinterpret_cast<T*>(wbuf);
   unsigned char* bufG2 = wbuf + XB_;                 // dOut row rr lives in half (rr & 1)
@@ -576,7 +619,7 @@ __global__ __launch_bounds__(kBwdWaves * kWave) void light_apply_bwd_wide(
   const int yy = MRLA_REVERSE_APPLY ? (int)(gridDim.y - 1 - blockIdx.y) : (int)blockIdx.y;   // (see the note at the top)
   const int b_end = min(B, (yy + 1) * BG);
   for (int b = yy * BG; b < b_end; ++b) {
-    const size_t ioff = (size_t)b * H * rowelems;
+    const size_t ioff = ((size_t)b * H + rc.r0()) * rowelems;
     const T* xi = x + ioff;
     const T* gi = dout + ioff;
     const T* oi = HAS_O ? o + ioff : nullptr;
@@ -607,12 +650,20 @@ __global__ __launch_bounds__(kBwdWaves * kWave) void light_apply_bwd_wide(
 #pragma unroll
       for (int j = 0; j < kS; ++j) d0[j] = 0.f;
       auto gbuf = [&](int r) { return reinterpret_cast<T*>(bufG2 + (r & 1) * GB); };
-      row_fetch<T, kS + 4>(ax, xi, 0, H, rowelems, bufX);
+      // CUT, rows above the range: the walk starts one row early -- dU of the row above the range is re-computed (the upper
+      // neighbour computes it too), its dx / do rows and its share of the sums are the neighbour's
+      const int st = (CUT && rc.above()) ? -1 : 0;
+      if (CUT && rc.above()) {
+        row_fetch_in<T, kS + 4>(ax, xi, st - 1, rc.lo(), rc.hi(), rowelems, bufX);
+        rows_landed();
+        row_read<T, kS + 4>(bufX, lane, xa);
+      }
+      row_fetch_in<T, kS + 4>(ax, xi, st, rc.lo(), rc.hi(), rowelems, bufX);
       rows_landed();
       row_read<T, kS + 4>(bufX, lane, xb);
-      row_fetch<T, kS + 4>(ax, xi, 1, H, rowelems, bufX);
-      row_fetch<T, kS + 2>(ag, gi, 0, H, rowelems, gbuf(0));
-      if (HAS_O) row_fetch<T, kS + 2>(ag, oi, 0, H, rowelems, bufO);
+      row_fetch_in<T, kS + 4>(ax, xi, st + 1, rc.lo(), rc.hi(), rowelems, bufX);
+      row_fetch_in<T, kS + 2>(ag, gi, st, rc.lo(), rc.hi(), rowelems, gbuf(st));
+      if (HAS_O) row_fetch_in<T, kS + 2>(ag, oi, st, rc.lo(), rc.hi(), rowelems, bufO);
       auto step = [&](int rr, RawRow<kS + 4>& XA, RawRow<kS + 4>& XB, RawRow<kS + 4>& XC, float (&UA)[kS + 2],
                       float (&UB)[kS + 2], float (&UC)[kS + 2], float (&DP)[kS], float (&DC)[kS]) {
         // steps rr-1 >= 1 stored two rows (dx and do) after their fetches; those may stay in flight
@@ -627,12 +678,14 @@ __global__ __launch_bounds__(kBwdWaves * kWave) void light_apply_bwd_wide(
         if (HAS_O) row_read_fence(ov, false);
         row_read_fence(gp, false);
         if (PRE) row_read_fence(pv, false);
-        row_fetch<T, kS + 4>(ax, xi, rr + 2, H, rowelems, bufX);
-        row_fetch<T, kS + 2>(ag, gi, rr + 1, H, rowelems, gbuf(rr + 1));
-        if (HAS_O) row_fetch<T, kS + 2>(ag, oi, rr + 1, H, rowelems, bufO);
-        if (PRE) row_fetch<T, kS>(as, pri, rr, H, rowelems, bufP);           // for step rr+1 (pixels past the image: zeros)
+        row_fetch_in<T, kS + 4>(ax, xi, rr + 2, rc.lo(), rc.hi(), rowelems, bufX);
+        row_fetch_in<T, kS + 2>(ag, gi, rr + 1, rc.lo(), rc.hi(), rowelems, gbuf(rr + 1));
+        if (HAS_O) row_fetch_in<T, kS + 2>(ag, oi, rr + 1, rc.lo(), rc.hi(), rowelems, bufO);
+        if (PRE) row_fetch_in<T, kS>(as, pri, rr, rc.lo(), rc.hi(), rowelems, bufP);      // for step rr+1 (pixels past the image: zeros)
+        // CUT: dU of the rows just above and below the range is formed for dx of the range's first and last row only
+        const bool own = !CUT || (rr >= 0 && rr < rc.n());
         float dorow[kS];
-        if (rr >= H) {             // the step past the last row only finishes dx[H-1]
+        if (rr >= rc.hi()) {       // the step past the image's last row only finishes dx[H-1]
 #pragma unroll
           for (int j = 0; j < kS + 2; ++j) UC[j] = 0.f;
 #pragma unroll
@@ -652,18 +705,23 @@ __global__ __launch_bounds__(kBwdWaves * kWave) void light_apply_bwd_wide(
             if (GELU) du *= gelu_grad_f(u);
             if (RAGGED || j == 0 || j == kS + 1) du = in ? du : 0.f;
             if (j >= 1 && j <= kS) {                                        // owned column (compile-time after unroll)
-              DC[j - 1] = lm * dm;                   // (columns beyond the image are dropped by the store)
+              // (kept a rounded product: left to the compiler, lam*dm is contracted into next step's `+ dx` where both sit in one
+              // unrolled loop body and not across its back edge -- do[r] would depend on r % 3 and on where a row range starts)
+              float ldm = lm * dm;
+              asm("" : "+v"(ldm));
+              DC[j - 1] = ldm;                       // (columns beyond the image are dropped by the store)
               dorow[j - 1] = DC[j - 1];
               // dWv[i][k] += dU[rr][col] * x[rr+i-1][col+k-1]
               if (!MRLA_EXP_SKIP_WG) {
-              wg[0] = fmaf(du, XA.v[j], wg[0]); wg[1] = fmaf(du, XA.v[j + 1], wg[1]); wg[2] = fmaf(du, XA.v[j + 2], wg[2]);
-              wg[3] = fmaf(du, XB.v[j], wg[3]); wg[4] = fmaf(du, XB.v[j + 1], wg[4]); wg[5] = fmaf(du, XB.v[j + 2], wg[5]);
-              wg[6] = fmaf(du, XC.v[j], wg[6]); wg[7] = fmaf(du, XC.v[j + 1], wg[7]); wg[8] = fmaf(du, XC.v[j + 2], wg[8]);
+              const float dw = (CUT && !own) ? 0.f : du;
+              wg[0] = fmaf(dw, XA.v[j], wg[0]); wg[1] = fmaf(dw, XA.v[j + 1], wg[1]); wg[2] = fmaf(dw, XA.v[j + 2], wg[2]);
+              wg[3] = fmaf(dw, XB.v[j], wg[3]); wg[4] = fmaf(dw, XB.v[j + 1], wg[4]); wg[5] = fmaf(dw, XB.v[j + 2], wg[5]);
+              wg[6] = fmaf(dw, XC.v[j], wg[6]); wg[7] = fmaf(dw, XC.v[j + 1], wg[7]); wg[8] = fmaf(dw, XC.v[j + 2], wg[8]);
               }
             }
             UC[j] = du;
           }
-          if (HAS_O && !RELU) row_store<T, kS>(as, doo, rr, rowelems, lane, bufS2, dorow);
+          if (HAS_O && !RELU && own) row_store<T, kS>(as, doo, rr, rowelems, lane, bufS2, dorow);
         }
         // dx[rr-1] on the owned columns:  dx[ro][col] = sum_{i,k} w[i][k] * dU[ro-i+1][col-k+1]
         if (rr >= 1) {
@@ -692,15 +750,15 @@ __global__ __launch_bounds__(kBwdWaves * kWave) void light_apply_bwd_wide(
         }
       };
       // steps rr = 0 .. H; after three steps every array is back in its starting role
-      int rr = 0;
-      for (; rr + 2 <= H; rr += 3) {
+      int rr = st;
+      for (; rr + 2 <= rc.n(); rr += 3) {
         step(rr,     xa, xb, xc, ua, ub, uc, d0, d1);
         step(rr + 1, xb, xc, xa, ub, uc, ua, d1, d2);
         step(rr + 2, xc, xa, xb, uc, ua, ub, d2, d0);
       }
-      if (rr <= H) {
+      if (rr <= rc.n()) {
         step(rr, xa, xb, xc, ua, ub, uc, d0, d1);
-        if (rr + 1 <= H) step(rr + 1, xb, xc, xa, ub, uc, ua, d1, d2);
+        if (rr + 1 <= rc.n()) step(rr + 1, xb, xc, xa, ub, uc, ua, d1, d2);
       }
       rows_landed();
     }
@@ -852,43 +910,60 @@ int nhwc_images_per_group(int B, int C, int W) {
   return (int)std::max(1L, std::min(8L, wgs * ws / 2048));
 }
 
-int nhwc_wgrad_ranges(int B, int C, int W) {
-  if (C % kWave) return 1;                             // (the row pipeline only)
-  return wide_strip_ranges(P_APPLY_BWD, B, C, W, nhwc_images_per_group(B, C, W));
+// mrla_tuning_row_ranges(): process-wide, read at every query and launch (set it before the buffers are sized)
+static std::atomic<int> g_row_cut_mode{0};
+int nhwc_row_cut_mode() { return g_row_cut_mode.load(std::memory_order_relaxed); }
+int nhwc_set_row_cut_mode(int mode) { return g_row_cut_mode.exchange(mode, std::memory_order_relaxed); }
+
+// gridDim.z of the passes that keep sums: strip ranges (wide_strip_ranges()) x row ranges (wide_row_ranges())
+static ZRanges sum_pass_zranges(WidePass pass, int B, int C, int H, int W, int bg) {
+  ZRanges z = {1, 1};
+  if (C % kWave) return z;                             // (the row pipeline only)
+  z.strips = wide_strip_ranges(pass, B, C, W, bg);
+  z.rows = wide_row_ranges(wide_workgroups(pass, B, C, W, bg, z.strips), H, (long)B * C * H * W);
+  return z;
 }
-int nhwc_mom_ranges(int B, int C, int W) {
-  if (C % kWave) return 1;
-  return wide_strip_ranges(P_STATS_FUSED, B, C, W, 0);
+ZRanges nhwc_wgrad_zranges(int B, int C, int H, int W) {
+  return sum_pass_zranges(P_APPLY_BWD, B, C, H, W, nhwc_images_per_group(B, C, W));
 }
-int nhwc_bmom_ranges(int B, int C, int W) {
-  if (C % kWave) return 1;
-  return wide_strip_ranges(P_STATS_BWD, B, C, W, 0);
-}
+ZRanges nhwc_mom_zranges(int B, int C, int H, int W) { return sum_pass_zranges(P_STATS_FUSED, B, C, H, W, 0); }
+ZRanges nhwc_bmom_zranges(int B, int C, int H, int W) { return sum_pass_zranges(P_STATS_BWD, B, C, H, W, 0); }
+int nhwc_wgrad_ranges(int B, int C, int H, int W) { const ZRanges z = nhwc_wgrad_zranges(B, C, H, W); return z.strips * z.rows; }
+int nhwc_mom_ranges(int B, int C, int H, int W) { const ZRanges z = nhwc_mom_zranges(B, C, H, W); return z.strips * z.rows; }
+int nhwc_bmom_ranges(int B, int C, int H, int W) { const ZRanges z = nhwc_bmom_zranges(B, C, H, W); return z.strips * z.rows; }
 
 int launch_light_stats_fwd_wide(const void* x, const void* o, const float* wv, float* mom, void* xout, const float* psc,
                                 const float* psh, void* vout, int B, int C, int H, int W, int dtype, int act,
                                 hipStream_t st, bool fused_no_x, int mom_ranges) {
   const bool ragged = (W % kS) != 0;
   const int bg = 0;               // (wide_launch(): >= 2048 workgroups)
-  const int nz = std::max(1, mom_ranges);      // strip ranges, each with its own record in mom[z]: merged below
+  // mom_ranges = the records the caller holds (mrla_light_mom_splits(); 1: the callers that never split): strip ranges x row
+  // ranges, each with its own record in mom[z], merged below
+  ZRanges zr = {1, 1};
+  if (mom_ranges > 1) {
+    zr = nhwc_mom_zranges(B, C, H, W);
+    if (zr.strips * zr.rows != mom_ranges) return MRLA_EINVAL;
+  }
+  const int nz = zr.strips, nzr = zr.rows;
   auto merged = [&](int ws) {
-    if (nz > 1)
+    if (nz * nzr > 1)
       hipLaunchKernelGGL(light_mom_merge_kernel, dim3((B * C + kThreads - 1) / kThreads), dim3(kThreads), 0, st, mom, B, C, H, W,
-                         ws, nz);
+                         ws, nz, nzr);
     return hip_status(hipGetLastError());
   };
   int ws_used = 1;
   if (xout || fused_no_x) {       // the fused producer (needs o, no activation on V); fused_no_x: x_t is not written
     if (!o || act) return MRLA_EINVAL;
-#define CALL_K(KERNEL, T, AF, RG, NT, SX)                                                                           \
+#define CALL_C(KERNEL, T, AF, RG, NT, SX, CT)                                                                       \
   {                                                                                                                 \
-    if (set_lds_n(KERNEL<T, AF, RG, NT, SX>, L.lds) != hipSuccess) return MRLA_EHIP;                                 \
-    hipLaunchKernelGGL((KERNEL<T, AF, RG, NT, SX>), L.grid, L.block, L.lds, st, (const T*)x, (const T*)o, wv, mom,   \
-                       (T*)xout, psc, psh, (T*)vout, B, C, H, W, L.BG, L.wc);                                             \
+    if (set_lds_n(KERNEL<T, AF, RG, NT, SX, CT>, L.lds) != hipSuccess) return MRLA_EHIP;                             \
+    hipLaunchKernelGGL((KERNEL<T, AF, RG, NT, SX, CT>), L.grid, L.block, L.lds, st, (const T*)x, (const T*)o, wv, mom, \
+                       (T*)xout, psc, psh, (T*)vout, B, C, H, W, L.BG, L.wc, nzr);                                  \
   }
+#define CALL_K(KERNEL, T, AF, RG, NT, SX) { if (nzr > 1) CALL_C(KERNEL, T, AF, RG, NT, SX, true) else CALL_C(KERNEL, T, AF, RG, NT, SX, false) }
 #define CALL_N(T, AF, RG, NT)                                                                                       \
   {                                                                                                                 \
-    const WideLaunch L = wide_launch(P_STATS_FUSED, B, C, W, kMomRed, fused_wave_bytes<T>(), bg, false, nz);                               \
+    const WideLaunch L = wide_launch(P_STATS_FUSED, B, C, W, kMomRed, fused_wave_bytes<T>(), bg, false, nz, nzr);   \
     ws_used = (int)(L.block.x / kWave) / L.wc;                                                                      \
     if (xout) CALL_K(light_stats_fwd_fused_wide, T, AF, RG, NT, true)                                               \
     else CALL_K(light_stats_fwd_fused_wide, T, AF, RG, NT, false)                                                   \
@@ -907,37 +982,44 @@ int launch_light_stats_fwd_wide(const void* x, const void* o, const float* wv, f
 #undef CALL_R
 #undef CALL_N
 #undef CALL_K
+#undef CALL_C
     return merged(ws_used);
   }
-#define CALL_R(T, A, O, RG)                                                                                         \
+#define CALL_C(T, A, O, RG, CT)                                                                                     \
   {                                                                                                                 \
-    const WideLaunch L = wide_launch(P_STATS_FWD, B, C, W, kMomRed, stats_fwd_wave_bytes<T>(), bg, false, nz);                               \
+    const WideLaunch L = wide_launch(P_STATS_FWD, B, C, W, kMomRed, stats_fwd_wave_bytes<T>(), bg, false, nz, nzr); \
     ws_used = (int)(L.block.x / kWave) / L.wc;                                                                      \
-    if (set_lds_n(light_stats_fwd_wide<T, A, O, RG>, L.lds) != hipSuccess) return MRLA_EHIP;                          \
-    hipLaunchKernelGGL((light_stats_fwd_wide<T, A, O, RG>), L.grid, L.block, L.lds, st, (const T*)x, (const T*)o, wv, \
-                       mom, (T*)vout, B, C, H, W, L.BG, L.wc);                                                            \
+    if (set_lds_n(light_stats_fwd_wide<T, A, O, RG, CT>, L.lds) != hipSuccess) return MRLA_EHIP;                     \
+    hipLaunchKernelGGL((light_stats_fwd_wide<T, A, O, RG, CT>), L.grid, L.block, L.lds, st, (const T*)x, (const T*)o, wv, \
+                       mom, (T*)vout, B, C, H, W, L.BG, L.wc, nzr);                                                 \
   }
+#define CALL_R(T, A, O, RG) { if (nzr > 1) CALL_C(T, A, O, RG, true) else CALL_C(T, A, O, RG, false) }
 #define CALL(T, A, O) { if (ragged) CALL_R(T, A, O, true) else CALL_R(T, A, O, false) }
   MRLA_DISPATCH_T_N(dtype, act, o != nullptr, CALL)
 #undef CALL
 #undef CALL_R
+#undef CALL_C
   return merged(ws_used);
 }
 
 int launch_light_apply_fwd_wide(const void* x, const void* o, const float* wv, const float* gate, const float* sc,
                                 const float* sh, const float* lam, const float* dp, void* out, int B, int C, int H,
                                 int W, int d, int res, int dtype, int act, hipStream_t st) {
+  // (no sums: every strip round has its own workgroup; the rows are cut as well where that still leaves CUs idle)
+  const int nzr = wide_row_ranges(wide_workgroups(P_APPLY_FWD, B, C, W, 0, wide_strip_rounds(P_APPLY_FWD, C, W)), H, (long)B * C * H * W);
 #define CALL(T, A, O) { if (stream_fetches(B, C, H, W, sizeof(T))) CALL_N(T, A, O, 2) else CALL_N(T, A, O, 0) }
-#define CALL_N(T, A, O, NT)                                                                                        \
+#define CALL_N(T, A, O, NT) { if (nzr > 1) CALL_C(T, A, O, NT, true) else CALL_C(T, A, O, NT, false) }
+#define CALL_C(T, A, O, NT, CT)                                                                                    \
   {                                                                                                                \
-    const WideLaunch L = wide_launch(P_APPLY_FWD, B, C, W, 0, apply_fwd_wave_bytes<T>(), 0, true);                                             \
-    if (set_lds_n(light_apply_fwd_wide<T, A, O, NT>, L.lds) != hipSuccess) return MRLA_EHIP;                        \
-    hipLaunchKernelGGL((light_apply_fwd_wide<T, A, O, NT>), L.grid, L.block, L.lds, st, (const T*)x, (const T*)o, wv,   \
-                       gate, sc, sh, lam, dp, (T*)out, B, C, H, W, L.BG, d, res, L.wc);                            \
+    const WideLaunch L = wide_launch(P_APPLY_FWD, B, C, W, 0, apply_fwd_wave_bytes<T>(), 0, true, 1, nzr);         \
+    if (set_lds_n(light_apply_fwd_wide<T, A, O, NT, CT>, L.lds) != hipSuccess) return MRLA_EHIP;                    \
+    hipLaunchKernelGGL((light_apply_fwd_wide<T, A, O, NT, CT>), L.grid, L.block, L.lds, st, (const T*)x, (const T*)o, wv, \
+                       gate, sc, sh, lam, dp, (T*)out, B, C, H, W, L.BG, d, res, L.wc, nzr);                       \
   }
   MRLA_DISPATCH_T_N(dtype, act, o != nullptr, CALL)
 #undef CALL
 #undef CALL_N
+#undef CALL_C
   return hip_status(hipGetLastError());
 }
 
@@ -945,13 +1027,15 @@ int launch_light_apply_fwd_pre_wide(const void* pre, const void* o, const float*
                                     const float* gate, const float* sc, const float* sh, const float* lam,
                                     const float* dp, void* out, int B, int C, int H, int W, int d, int res, int dtype,
                                     hipStream_t st) {
-#define CALL_A(T, AF)                                                                                                \
+  const int nzr = wide_row_ranges(wide_workgroups(P_APPLY_FWD, B, C, W, 0, wide_strip_rounds(P_APPLY_FWD, C, W)), H, (long)B * C * H * W);
+#define CALL_C(T, AF, CT)                                                                                            \
   {                                                                                                                  \
-    const WideLaunch L = wide_launch(P_APPLY_FWD, B, C, W, 0, fused_wave_bytes<T>(), 0, true);              \
-    if (set_lds_n(light_apply_fwd_pre_wide<T, AF>, L.lds) != hipSuccess) return MRLA_EHIP;                            \
-    hipLaunchKernelGGL((light_apply_fwd_pre_wide<T, AF>), L.grid, L.block, L.lds, st, (const T*)pre, (const T*)o, psc, \
-                       psh, wv, gate, sc, sh, lam, dp, (T*)out, B, C, H, W, L.BG, d, res, L.wc);                           \
+    const WideLaunch L = wide_launch(P_APPLY_FWD, B, C, W, 0, fused_wave_bytes<T>(), 0, true, 1, nzr);               \
+    if (set_lds_n(light_apply_fwd_pre_wide<T, AF, CT>, L.lds) != hipSuccess) return MRLA_EHIP;                        \
+    hipLaunchKernelGGL((light_apply_fwd_pre_wide<T, AF, CT>), L.grid, L.block, L.lds, st, (const T*)pre, (const T*)o, psc, \
+                       psh, wv, gate, sc, sh, lam, dp, (T*)out, B, C, H, W, L.BG, d, res, L.wc, nzr);                \
   }
+#define CALL_A(T, AF) { if (nzr > 1) CALL_C(T, AF, true) else CALL_C(T, AF, false) }
 #define CALL(T) { if (psc) CALL_A(T, true) else CALL_A(T, false) }
   switch (dtype) {
     case MRLA_F32:  CALL(float) break;
@@ -961,6 +1045,7 @@ int launch_light_apply_fwd_pre_wide(const void* pre, const void* o, const float*
   }
 #undef CALL
 #undef CALL_A
+#undef CALL_C
   return hip_status(hipGetLastError());
 }
 
@@ -971,21 +1056,23 @@ int launch_light_apply_bwd_wide(const void* dout, const void* x, const void* o, 
                                 int B, int C, int H, int W, int d, int res, int relu, int dtype, int act, hipStream_t st) {
   const bool ragged = (W % kS) != 0;
   const int bg = nhwc_images_per_group(B, C, W);          // image groups x strip ranges = the rows mrla_light_wgrad_rows() promised
-  const int nz = nhwc_wgrad_ranges(B, C, W);
+  const ZRanges zr = nhwc_wgrad_zranges(B, C, H, W);
+  const int nz = zr.strips, nzr = zr.rows;
   if (pre_tmom && (!pre || !relu)) return MRLA_EINVAL;
   if (pre_tmom && dtype == MRLA_F32) return MRLA_EUNSUPPORTED;      // (LDS: see mrla_light_apply_bwd_pre_sums)
-#define CALL_PLAIN(T, A, O, R, RG, PR)                                                                               \
+#define CALL_CUT(T, A, O, R, RG, PR, CT)                                                                             \
   {                                                                                                                  \
-    const WideLaunch L = wide_launch(P_APPLY_BWD, B, C, W, 9, apply_bwd_wave_bytes<T, PR>(), bg, false, nz);         \
-    if (set_lds_n(light_apply_bwd_wide<T, A, O, R, RG, PR>, L.lds) != hipSuccess) return MRLA_EHIP;                    \
-    hipLaunchKernelGGL((light_apply_bwd_wide<T, A, O, R, RG, PR>), L.grid, L.block, L.lds, st, (const T*)dout,        \
+    const WideLaunch L = wide_launch(P_APPLY_BWD, B, C, W, 9, apply_bwd_wave_bytes<T, PR>(), bg, false, nz, nzr);    \
+    if (set_lds_n(light_apply_bwd_wide<T, A, O, R, RG, PR, CT>, L.lds) != hipSuccess) return MRLA_EHIP;               \
+    hipLaunchKernelGGL((light_apply_bwd_wide<T, A, O, R, RG, PR, CT>), L.grid, L.block, L.lds, st, (const T*)dout,    \
                        (const T*)x, (const T*)o, wv, gate, cb, lam, dp, dyx, (T*)dx, (T*)dprev, dwv_part,             \
-                       (const T*)pre, pre_center, pre_tmom, B, C, H, W, L.BG, d, res, L.wc);                          \
+                       (const T*)pre, pre_center, pre_tmom, B, C, H, W, L.BG, d, res, L.wc, nzr);                     \
   }
+#define CALL_PLAIN(T, A, O, R, RG, PR) { if (nzr > 1) CALL_CUT(T, A, O, R, RG, PR, true) else CALL_CUT(T, A, O, R, RG, PR, false) }
 #if MRLA_APPLY_BWD_PK
 #define CALL_G(T, A, O, R, RG, PR)                                                                                   \
   {                                                                                                                  \
-    if constexpr (!(A)) {                                                                                            \
+    if (!(A) && nzr == 1) {                                                                                          \
       constexpr int DP = sizeof(T) == 2 ? MRLA_APPLY_BWD_DEPTH : 1;                                                  \
       const WideLaunch L = wide_launch(P_APPLY_BWD, B, C, W, 0, apply_bwd_pk_wave_bytes<T, PR, DP>(), bg, false, nz); \
       if (set_lds_n(light_apply_bwd_wide_pk<T, O, R, RG, PR, DP>, L.lds) != hipSuccess) return MRLA_EHIP;             \
@@ -1017,23 +1104,29 @@ int launch_light_apply_bwd_wide(const void* dout, const void* x, const void* o, 
 #undef CALL_R
 #undef CALL_G
 #undef CALL_PLAIN
+#undef CALL_CUT
   return hip_status(hipGetLastError());
 }
 
 int launch_light_stats_bwd_wide(const void* dout, const void* x, const void* o, const float* wv, const float* mom,
                                 float* bmom, int B, int C, int H, int W, int dtype, int act, hipStream_t st) {
 #define CALL(T, A, O) CALL_N(T, A, O, 0)      /* default policy: apply_bwd re-reads these tensors right after */
-#define CALL_N(T, A, O, NT)                                                                                        \
+  const ZRanges zr = nhwc_bmom_zranges(B, C, H, W);
+#define CALL_N(T, A, O, NT) { if (zr.rows > 1) CALL_C(T, A, O, NT, true) else CALL_C(T, A, O, NT, false) }
+#define CALL_C(T, A, O, NT, CT)                                                                                    \
   {                                                                                                                \
-    const WideLaunch L = wide_launch(P_STATS_BWD, B, C, W, D_N, stats_bwd_wave_bytes<T>(), 0, false, nhwc_bmom_ranges(B, C, W)); \
-    if (set_lds_n(light_stats_bwd_wide<T, A, O, NT>, L.lds) != hipSuccess) return MRLA_EHIP;                        \
-    hipLaunchKernelGGL((light_stats_bwd_wide<T, A, O, NT>), L.grid, L.block, L.lds, st, (const T*)dout, (const T*)x,    \
-                       (const T*)o, wv, mom, bmom, B, C, H, W, L.BG, L.wc);                                              \
+    const WideLaunch L = wide_launch(P_STATS_BWD, B, C, W, D_N, stats_bwd_wave_bytes<T>(), 0, false, zr.strips, zr.rows); \
+    if (set_lds_n(light_stats_bwd_wide<T, A, O, NT, CT>, L.lds) != hipSuccess) return MRLA_EHIP;                    \
+    hipLaunchKernelGGL((light_stats_bwd_wide<T, A, O, NT, CT>), L.grid, L.block, L.lds, st, (const T*)dout, (const T*)x, \
+                       (const T*)o, wv, mom, bmom, B, C, H, W, L.BG, L.wc, zr.rows);                               \
   }
   MRLA_DISPATCH_T_N(dtype, act, o != nullptr, CALL)
 #undef CALL
 #undef CALL_N
-  return hip_status(hipGetLastError());
+#undef CALL_C
+  if (hipGetLastError() != hipSuccess) return MRLA_EHIP;
+  // the ranges' partial records -> record 0, the one mrla_light_bn_bwd / mrla_light_gate_bwd read
+  return launch_fold_rows(bmom, zr.strips * zr.rows, B * C * D_N, st);
 }
 
 int launch_base_value_bwd_wide(const void* dout, const void* x, const float* wv, const void* dv, const float* dyx, void* dx,
@@ -1042,7 +1135,13 @@ int launch_base_value_bwd_wide(const void* dout, const void* x, const float* wv,
   if (C % kWave) return MRLA_EUNSUPPORTED;
   if (pre_tmom && (!pre || !(res & 2))) return MRLA_EINVAL;
   const int bg = nhwc_images_per_group(B, C, W);
-  const int nz = nhwc_wgrad_ranges(B, C, W);
+  const ZRanges zr = nhwc_wgrad_zranges(B, C, H, W);
+  const int nz = zr.strips;
+  if (zr.rows > 1) {      // this kernel walks whole images: the partial rows of the other row ranges (mrla_light_wgrad_rows) are zero
+    const size_t groups = (size_t)((B + bg - 1) / bg), used = groups * nz, all = used * zr.rows;
+    if (hipMemsetAsync(dwv_part + used * C * 9, 0, (all - used) * C * 9 * sizeof(float), st) != hipSuccess) return MRLA_EHIP;
+    if (pre_tmom && hipMemsetAsync(pre_tmom + used * C * 2, 0, (all - used) * C * 2 * sizeof(float), st) != hipSuccess) return MRLA_EHIP;
+  }
 #define CALL_P(T, PR)                                                                                               \
   {                                                                                                                 \
     const WideLaunch L = wide_launch(P_APPLY_BWD, B, C, W, 9, base_vbwd_wave_bytes<T, PR>(), bg, false, nz);                             \

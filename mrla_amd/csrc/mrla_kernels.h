@@ -57,16 +57,18 @@ int launch_bn_fwd(const float* mom, const float* gate, const float* lam, const f
                   float* save_mean, float* save_inv, int B, int C, int HW, int d, hipStream_t st);
 int launch_bn_bwd(const float* mom, const float* bmom, const float* gate, const float* lam, const float* gamma,
                   const float* dp, const float* save_mean, const float* save_inv, int training, float* cb, float* cb_lo,
-                  float* dgamma, float* dbeta, float* dlam, int B, int C, int HW, int d, hipStream_t st, int nsplit = 1);
+                  float* dgamma, float* dbeta, float* dlam, int B, int C, int HW, int d, hipStream_t st);
 // tok_part != null (token path): [tok_bands * B][C][kTokParts] partials of mrla_token_apply_bwd, completed in place with dy
 int launch_gate_bwd(const float* mom, const float* bmom, const float* gate, const float* cb, const float* cb_lo,
                     const float* dp, const float* wq, const float* wk, int ks, float* dyx, float* dwqk_part, int B, int C, int HW,
-                    int d, hipStream_t st, float* tok_part = nullptr, int tok_bands = 0, int nsplit = 1);
-// (nsplit: partial records per (image, channel) in bmom -- the strip ranges of the backward statistics pass)
-int nhwc_wgrad_ranges(int B, int C, int W);
-int nhwc_bmom_ranges(int B, int C, int W);
-int nhwc_mom_ranges(int B, int C, int W);         // ... of the forward statistics passes (records mom[z], merged into mom[0])
+                    int d, hipStream_t st, float* tok_part = nullptr, int tok_bands = 0);
+// (the ranges gridDim.z cuts an image's strips AND rows into where few, large images would leave the chip idle: light_nhwc_wide.h)
+int nhwc_set_row_cut_mode(int mode);              // 0 auto, 1 never, 2 wherever possible; returns the previous mode
+int nhwc_wgrad_ranges(int B, int C, int H, int W);
+int nhwc_bmom_ranges(int B, int C, int H, int W);
+int nhwc_mom_ranges(int B, int C, int H, int W);  // ... of the forward statistics passes (records mom[z], merged into mom[0])
 int launch_reduce_rows(const float* in, float* out, int rows, int n, hipStream_t st);
+int launch_fold_rows(float* buf, int rows, int n, hipStream_t st);      // buf[0, :] = sum of the rows, in place
 int launch_reduce_rows2(const float* in1, float* out1, int rows1, int n1, const float* in2, float* out2, int rows2, int n2,
                         hipStream_t st);
 

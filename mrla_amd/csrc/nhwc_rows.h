@@ -72,6 +72,21 @@ __device__ __forceinline__ void row_fetch(const RowIO<T, NPX>& a, const T* img, 
 #endif
 }
 
+// The same for a workgroup that walks a RANGE of an image's rows (light_nhwc_wide.h: RowCut): `img` points at the range's
+// first row, r counts from there (negative: the halo rows above), and the image's rows are [lo, hi) in that frame.
+template <typename T, int NPX, int AUX = MRLA_ROW_LOAD_AUX>
+__device__ __forceinline__ void row_fetch_in(const RowIO<T, NPX>& a, const T* img, int r, int lo, int hi, int rowelems, T* buf) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  typedef RowIO<T, NPX> Q;
+  const bool live = r >= lo && r < hi;              // wave-uniform
+  const auto rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<T*>(img) + (ptrdiff_t)(live ? r : 0) * rowelems, 0,
+                                                    live ? rowelems * (int)sizeof(T) : 0, kBufFlags);
+#pragma unroll
+  for (int l = 0; l < Q::NL; ++l)
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_void_ptr)(reinterpret_cast<char*>(buf) + l * 1024), 16, a.voff[l], 0, 0, AUX);
+#endif
+}
+
 // All DMA rows issued so far have landed (also orders them against the LDS reads below).
 __device__ __forceinline__ void rows_landed() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
 // ... except that the NEWEST `KEEP` vector-memory instructions may still be in flight: the row stores a step issued after

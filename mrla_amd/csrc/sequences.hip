@@ -57,16 +57,14 @@ int mrla_light_tail_bwd(const void* dout, const void* x, const void* o_prev, con
   if (has_bn && (!bnbuf || !gamma)) return MRLA_EINVAL;
   const size_t C = (size_t)c;
   float *cb = small, *dgamma = small + 4 * C, *dbeta = small + 5 * C, *dlam = small + 6 * C, *cb_lo = small + 7 * C;
-  const int splits = mrla_light_bmom_splits(b, c, h, w, dtype, layout);      // partial records of the statistics pass in bmom
-  if (splits < 1) return splits;
   const bool lean = x == nullptr;      // the forward never wrote x_t: re-formed from (pre, pre_sc, pre_sh, o_prev)
   if (lean && (!pre || !relu_mask || act != MRLA_ACT_NONE)) return MRLA_EINVAL;
   if (lean) MRLA_TRY(mrla_light_stats_bwd_fused(dout, pre, pre_sc, pre_sh, o_prev, wv, mom, bmom, b, c, h, w, dtype, layout, stream));
   else MRLA_TRY(mrla_light_stats_bwd(dout, x, o_prev, wv, mom, bmom, b, c, h, w, dtype, layout, act, stream));
   MRLA_TRY(mrla_light_bn_bwd(mom, bmom, gate, lam, has_bn ? gamma : nullptr, dp, has_bn ? bnbuf + 2 * C : nullptr,
                              has_bn ? bnbuf + 3 * C : nullptr, bn_mode, cb, cb_lo, has_bn ? dgamma : nullptr,
-                             has_bn ? dbeta : nullptr, lam ? dlam : nullptr, b, c, h * w, d, splits, stream));
-  MRLA_TRY(mrla_light_gate_bwd(mom, bmom, gate, cb, cb_lo, dp, wq, wk, ksize, dyx, dwqk_part, b, c, h * w, d, splits, stream));
+                             has_bn ? dbeta : nullptr, lam ? dlam : nullptr, b, c, h * w, d, stream));
+  MRLA_TRY(mrla_light_gate_bwd(mom, bmom, gate, cb, cb_lo, dp, wq, wk, ksize, dyx, dwqk_part, b, c, h * w, d, stream));
   if (lean)
     MRLA_TRY(mrla_light_apply_bwd_fused(dout, pre, pre_sc, pre_sh, o_prev, wv, gate, cb, lam, dp, dyx, dx, do_prev, dwv_part,
                                         pre_center, pre_tmom, b, c, h, w, d, res, dtype, layout, stream));

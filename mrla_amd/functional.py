@@ -261,6 +261,8 @@ class _DeferredBnBox:
         self.center = None         # that BatchNorm's saved mean [c]: the sums are taken about it
 
     def put(self, dpre, tmom, rows):
+        if (dpre.numel() // dpre.shape[1]) % rows:       # the BatchNorm backward takes rows of equally many pixels: fold them
+            tmom, rows = tmom.sum(0, keepdim=True, dtype=torch.float64).float(), 1
         self.ptr, self.shape, self.tmom, self.rows = dpre.data_ptr(), tuple(dpre.shape), tmom, rows
         self.ref, self.version = weakref.ref(dpre), dpre._version
 
@@ -460,7 +462,7 @@ class _LightFn(torch.autograd.Function):
             dx = torch.empty_like(like)
             do = torch.empty_like(oc) if oc is not None else None
             pre_tmom = None
-            if ctx.pre_sums and pre is not None and (b * h * w) % rows == 0:
+            if ctx.pre_sums and pre is not None:
                 pre_tmom = torch.empty((rows, c, 2), dtype=torch.float32, device=dev)
             elif not lean:
                 pre = None
@@ -487,11 +489,11 @@ class _LightFn(torch.autograd.Function):
             _call("mrla_light_bn_bwd", 0, _ptr(mom), _ptr(bmom), _ptr(gate), _ptr(lam32), _ptr(gamma32) if has_bn else None,
                    _ptr(dp32), _ptr(bnbuf[2]) if has_bn else None, _ptr(bnbuf[3]) if has_bn else None, cfg.bn_mode,
                    _ptr(cb), _ptr(cb_lo), _ptr(small[4]) if has_bn else None, _ptr(small[5]) if has_bn else None,
-                   _ptr(small[6]) if lam32 is not None else None, b, c, h * w, d, splits, st)
+                   _ptr(small[6]) if lam32 is not None else None, b, c, h * w, d, st)
             dyx = torch.empty((b, c), dtype=torch.float32, device=dev)
             dwqk_part = torch.empty((b, 2 * ks), dtype=torch.float32, device=dev)
             _call("mrla_light_gate_bwd", 0, _ptr(mom), _ptr(bmom), _ptr(gate), _ptr(cb), _ptr(cb_lo), _ptr(dp32), _ptr(wq32),
-                   _ptr(wk32), ks, _ptr(dyx), _ptr(dwqk_part), b, c, h * w, d, splits, st)
+                   _ptr(wk32), ks, _ptr(dyx), _ptr(dwqk_part), b, c, h * w, d, st)
             rows = L.load().mrla_light_wgrad_rows(b, c, h, w, dt, layout)
             L.check(min(rows, 0), "mrla_light_wgrad_rows")
             dwv_part = torch.empty((rows, c * 9), dtype=torch.float32, device=dev)
@@ -499,7 +501,7 @@ class _LightFn(torch.autograd.Function):
             do = torch.empty_like(oc) if oc is not None else None
             # the deferred bn3's backward sums (sum dpre, sum dpre*y3) ride in this pass: one more row fetch, no 2N pass
             pre_tmom = None
-            if ctx.pre_sums and pre is not None and (b * h * w) % rows == 0:
+            if ctx.pre_sums and pre is not None:
                 pre_tmom = torch.empty((rows, c, 2), dtype=torch.float32, device=dev)
             elif not lean:
                 pre = None
@@ -817,7 +819,7 @@ class _BaseFn(torch.autograd.Function):
             dv = torch.empty((b, h, w, c), dtype=xc.dtype, device=dev)
             res = int(cfg.tail) | (2 if cfg.fuse else 0)
             pre_tmom = None
-            if pre is not None and (b * h * w) % rows == 0:
+            if pre is not None:
                 pre_tmom = torch.empty((rows, c, 2), dtype=torch.float32, device=dev)
             else:
                 pre = None
@@ -872,7 +874,7 @@ class _BaseFn(torch.autograd.Function):
                       b, c, h, w, d, T, t, Tc, dt, layout, st, path=xc.numel() * es * (Tc - t + 1))
                 # the deferred bn3's backward sums (sum dpre, sum dpre*(y3 - mean)) ride in this pass: one more row fetch, no 2N pass
                 pre_tmom = None
-                if pre is not None and (b * h * w) % rows == 0:
+                if pre is not None:
                     pre_tmom = torch.empty((rows, c, 2), dtype=torch.float32, device=dev)
                 else:
                     pre = None

@@ -73,9 +73,9 @@ for c, hw in STAGES:
                                                           B, c, hw, hw, d, 1, L.BF16, LAY, 0, st)),
         "stats_bwd": (3, lambda: lib.mrla_light_stats_bwd(P(g), P(x), P(o), P(wv), P(mom), P(bmom), B, c, hw, hw, L.BF16, LAY, 0, st)),
         "bn_bwd": (0, lambda: lib.mrla_light_bn_bwd(P(mom), P(bmom), P(gate), P(lam), P(gamma), P(dp), P(bn[2]), P(bn[3]), 1,
-                                                     P(cb), None, P(small[0]), P(small[1]), P(small[2]), B, c, hw * hw, d, 1, st)),
+                                                     P(cb), None, P(small[0]), P(small[1]), P(small[2]), B, c, hw * hw, d, st)),
         "gate_bwd": (0, lambda: lib.mrla_light_gate_bwd(P(mom), P(bmom), P(gate), P(cb), None, P(dp), P(wq), P(wk), ks, P(dyx), P(dwqk),
-                                                        B, c, hw * hw, d, 1, st)),
+                                                        B, c, hw * hw, d, st)),
         "apply_bwd": (5, lambda: lib.mrla_light_apply_bwd(P(g), P(x), P(o), P(wv), P(gate), P(cb), P(lam), P(dp), P(dyx), P(dx),
                                                           P(do), P(dwv), None, None, None, B, c, hw, hw, d, 1, RELU, L.BF16, LAY, 0, st)),
         "apply_bwd+bn3sums": (6, lambda: lib.mrla_light_apply_bwd(P(g), P(x), P(o), P(wv), P(gate), P(cb), P(lam), P(dp), P(dyx), P(dx),

@@ -60,12 +60,19 @@ def test_argument_validation_without_a_gpu():
     assert lib.mrla_light_lean_supported(256, 96, 56, 56, _lib.BF16, _lib.NHWC) == 0
     assert lib.mrla_light_stats_bwd_fused(*[None] * 8, 2, 64, 8, 8, _lib.BF16, _lib.NHWC, None) == _lib.EINVAL
     assert lib.mrla_light_apply_bwd_fused(*[None] * 16, 2, 64, 8, 8, 32, 1, _lib.BF16, _lib.NHWC, None) == _lib.EINVAL
-    # ... and few, large images (a detection batch) spread an image's column strips over workgroup ranges: partial rows / records
-    for shape, (mom, bmom, rows) in {(256, 256, 56, 56): (1, 1, 64), (128, 1024, 14, 14): (1, 1, 64), (2, 256, 200, 336): (6, 12, 12),
-                                     (2, 512, 100, 168): (3, 12, 24), (2, 2048, 25, 42): (2, 3, 6)}.items():
-        assert lib.mrla_light_mom_splits(*shape, _lib.BF16, _lib.NHWC) == mom, shape
-        assert lib.mrla_light_bmom_splits(*shape, _lib.BF16, _lib.NHWC) == bmom, shape
-        assert lib.mrla_light_wgrad_rows(*shape, _lib.BF16, _lib.NHWC) == rows, shape
+    # ... and few, large images (a detection batch) spread an image's column strips -- and, where that does not fill the chip
+    # either, its rows -- over workgroup ranges: partial rows / records = image groups x strip ranges x row ranges
+    counts = lambda shape: tuple(f(*shape, _lib.BF16, _lib.NHWC) for f in (lib.mrla_light_mom_splits, lib.mrla_light_bmom_splits,      # noqa: E731
+                                                                          lib.mrla_light_wgrad_rows))
+    for shape, want in {(256, 256, 56, 56): (1, 1, 64), (128, 1024, 14, 14): (1, 1, 64), (2, 256, 200, 336): (6 * 8, 12 * 8, 12 * 8),
+                        (2, 512, 100, 168): (3 * 8, 12 * 8, 24 * 8), (2, 1024, 50, 84): (2 * 4, 6 * 4, 12 * 4), (2, 2048, 25, 42): (2, 3, 6)}.items():
+        assert counts(shape) == want, shape
+    assert lib.mrla_light_lean_supported(2, 512, 100, 168, _lib.BF16, _lib.NHWC) == 0      # (the x_t-free passes walk whole images)
+    assert lib.mrla_tuning_row_ranges(1) == 0                 # never cut rows: the strip ranges alone
+    assert counts((2, 256, 200, 336)) == (6, 12, 12) and counts((2, 512, 100, 168)) == (3, 12, 24)
+    assert lib.mrla_tuning_row_ranges(2) == 1                 # wherever an image has >= 16 rows
+    assert counts((4, 256, 56, 56)) == (7, 14, 28) and counts((4, 256, 15, 56)) == (1, 2, 4)
+    assert lib.mrla_tuning_row_ranges(0) == 2 and lib.mrla_tuning_row_ranges(3) == _lib.EINVAL
     assert lib.mrla_light_mom_splits(2, 96, 200, 336, _lib.BF16, _lib.NHWC) == 1          # (off the 64-lane grid: one workgroup per image)
     assert lib.mrla_light_bmom_splits(2, 256, 56, 56, _lib.BF16, _lib.NCHW) == 1 and lib.mrla_light_bmom_splits(0, 1, 1, 1, 0, 0) == _lib.EINVAL
     # the sequence entry points (ABI 4) validate like the passes they issue: the first pass's code comes back, nothing is launched

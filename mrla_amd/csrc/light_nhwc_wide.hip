@@ -77,26 +77,27 @@ __global__ __launch_bounds__(kThreads) void light_mom_merge_kernel(float* __rest
   if (i >= B * C) return;
   const int nstrips = (W + kS - 1) / kS;
   const int per = (H + nzr - 1) / nzr;
-  auto pixels_of = [&](int z) {
-    const int zs = z % nzs, zr = z / nzs;
-    int n = 0;
-    for (int r = zs; r * ws < nstrips; r += nzs)
-      for (int j = 0; j < ws && r * ws + j < nstrips; ++j) n += min(kS, W - (r * ws + j) * kS);
-    return (float)(n * max(0, min(per, H - zr * per)));
-  };
   float* m0 = mom + (size_t)i * M_REC;
   WaveMoments w;
   w.clear();
   float sx = 0.f;
-  for (int z = 0; z < nzs * nzr; ++z) {
-    const float* mz = m0 + (size_t)z * B * C * M_REC;
-    const float n = pixels_of(z);
-    if (n == 0.f) continue;
-    float a[M_N];
+  for (int zs = 0; zs < nzs; ++zs) {               // (record 0 = strip range 0 of row range 0 comes first: its pivots are the base)
+    int cols = 0;                                    // pixels per row of this strip range
+    for (int r = zs; r * ws < nstrips; r += nzs) {
+      const int s_lo = r * ws, s_hi = min(nstrips, s_lo + ws);
+      cols += min(W, s_hi * kS) - s_lo * kS;
+    }
+    if (cols == 0) continue;
+    for (int zr = 0; zr < nzr; ++zr) {
+      const int rows = min(per, H - zr * per);
+      if (rows <= 0) continue;
+      const float* mz = m0 + (size_t)(zr * nzs + zs) * B * C * M_REC;
+      float a[M_N];
 #pragma unroll
-    for (int k = 0; k < M_N; ++k) a[k] = mz[k];
-    sx += a[M_SX];
-    w.merge(a, mz[M_PV], mz[M_PO], n);
+      for (int k = 0; k < M_N; ++k) a[k] = mz[k];
+      sx += a[M_SX];
+      w.merge(a, mz[M_PV], mz[M_PO], (float)(cols * rows));
+    }
   }
   w.s[M_SX] = sx;
 #pragma unroll
@@ -1129,6 +1130,12 @@ int launch_light_stats_bwd_wide(const void* dout, const void* x, const void* o, 
   return launch_fold_rows(bmom, zr.strips * zr.rows, B * C * D_N, st);
 }
 
+__global__ __launch_bounds__(kThreads) void zero_rows_kernel(float* __restrict__ a, size_t na, float* __restrict__ b, size_t nb) {
+  const size_t i = (size_t)blockIdx.x * kThreads + threadIdx.x;
+  if (i < na) a[i] = 0.f;
+  else if (i - na < nb) b[i - na] = 0.f;
+}
+
 int launch_base_value_bwd_wide(const void* dout, const void* x, const float* wv, const void* dv, const float* dyx, void* dx,
                                float* dwv_part, const void* pre, const float* pre_center, float* pre_tmom, int B, int C,
                                int H, int W, int res, int dtype, hipStream_t st) {
@@ -1138,9 +1145,12 @@ int launch_base_value_bwd_wide(const void* dout, const void* x, const float* wv,
   const ZRanges zr = nhwc_wgrad_zranges(B, C, H, W);
   const int nz = zr.strips;
   if (zr.rows > 1) {      // this kernel walks whole images: the partial rows of the other row ranges (mrla_light_wgrad_rows) are zero
+    // (a kernel, not hipMemsetAsync: inside a captured HIP graph the memset node left these rows unwritten on ROCm 7.2 --
+    // tests/test_graph_replay_gpu.py, resnet101_mrlab at batch 32)
     const size_t groups = (size_t)((B + bg - 1) / bg), used = groups * nz, all = used * zr.rows;
-    if (hipMemsetAsync(dwv_part + used * C * 9, 0, (all - used) * C * 9 * sizeof(float), st) != hipSuccess) return MRLA_EHIP;
-    if (pre_tmom && hipMemsetAsync(pre_tmom + used * C * 2, 0, (all - used) * C * 2 * sizeof(float), st) != hipSuccess) return MRLA_EHIP;
+    const size_t n1 = (all - used) * C * 9, n2 = pre_tmom ? (all - used) * C * 2 : 0;
+    hipLaunchKernelGGL(zero_rows_kernel, dim3((unsigned)((n1 + n2 + kThreads - 1) / kThreads)), dim3(kThreads), 0, st,
+                       dwv_part + used * C * 9, n1, pre_tmom ? pre_tmom + used * C * 2 : nullptr, n2);
   }
 #define CALL_P(T, PR)                                                                                               \
   {                                                                                                                 \

@@ -112,8 +112,8 @@ def test_deferred_bn3_affine_is_bit_identical_to_the_separate_pass(shape, traini
     # pass by fp32 summation order only; everything else stays bit-identical.
     from mrla_amd import _lib as L
     dt = L.BF16 if dtype == torch.bfloat16 else L.F32
-    fused_sums = (cl and L.load().mrla_light_apply_bwd_pre_sums(b, c, h, w, dt, L.NHWC) == 1
-                  and (b * h * w) % L.load().mrla_light_wgrad_rows(b, c, h, w, dt, L.NHWC) == 0)
+    # (partial rows that do not divide the pixel count are folded by the hand-over box: _DeferredBnBox.put)
+    fused_sums = cl and L.load().mrla_light_apply_bwd_pre_sums(b, c, h, w, dt, L.NHWC) == 1
     for i, (a, bb) in enumerate(zip(*results)):
         if fused_sums and i in (3, 4):          # bn3.weight.grad, bn3.bias.grad
             tol = 2e-5

@@ -58,8 +58,9 @@ def test_det_backbone_wide_image_fp32_and_bf16_autocast_vs_eager():
 def test_light_tail_at_detection_size_vs_eager(shape, mode):
     """The block tail where the detection backbone runs it (mmdetection/mmdet/models/backbones/resnet_mrlal.py:283-293 at
     2 x 3 x 800 x 1344: stage-1 maps 200 x 336, stage-2 100 x 168): two large images instead of 256 small ones, 48 / 24 column
-    strips per image -- the backward passes spread them over strip RANGES (gridDim.z; mrla_light_wgrad_rows /
-    mrla_light_bmom_splits > 1 here), each leaving partial rows / records that the small kernels add up.  Product (bf16,
+    strips per image -- the passes spread them over strip RANGES and cut the rows into ranges as well (gridDim.z;
+    mrla_light_wgrad_rows / mrla_light_bmom_splits / mrla_light_mom_splits count them: 8 row ranges of 25 / 13 rows here), each
+    leaving partial rows / records that are folded into the ones the small kernels read.  Product (bf16,
     channels_last, x_t = relu(pre + identity) formed inside) vs the eager restatement in fp32 on the same bf16 inputs:
     out and both input gradients to the last bf16 bits, every parameter gradient to fp32-accumulation accuracy.
     `norm_eval`: bn_mrla is a fixed affine (what the backbone trains with); `train`: batch statistics."""
@@ -68,6 +69,7 @@ def test_light_tail_at_detection_size_vs_eager(shape, mode):
     b, c, h, w = shape
     lib = L.load()
     assert lib.mrla_light_wgrad_rows(b, c, h, w, L.BF16, L.NHWC) > b and lib.mrla_light_bmom_splits(b, c, h, w, L.BF16, L.NHWC) > 1
+    assert lib.mrla_light_mom_splits(b, c, h, w, L.BF16, L.NHWC) % 8 == 0            # (strip ranges x 8 row ranges)
     g = torch.Generator(device="cuda").manual_seed(c + h)
     mk = lambda s=1.0: (s * torch.randn(b, c, h, w, device="cuda", generator=g)).bfloat16().contiguous(memory_format=torch.channels_last)
     pre, idn, gup = mk(), mk(), mk(0.1)

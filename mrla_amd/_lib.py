@@ -126,6 +126,10 @@ def load():
         raise MrlaHipError(
             f"{LIB_PATH} not found: the MRLA HIP extension is not built. Run `python -c 'import __graft_entry__ as g; "
             "g.build()'` (or `make -C mrla_amd/csrc`) -- mrla_amd has no CPU/PyTorch fallback for its operators.")
+    # torch FIRST: the library's DT_NEEDED libamdhip64.so.7 must resolve to the HIP runtime torch brought into the process.
+    # Loaded before `import torch`, it pulls in /opt/rocm's copy instead, torch then binds to that one by SONAME, and launches
+    # on torch's streams fail ("HIP runtime error at kernel launch": scripts/archive/r06_load_order_probe.py).
+    import torch  # noqa: F401
     lib = ctypes.CDLL(LIB_PATH)
     for name, argtypes in SIGNATURES.items():
         fn = getattr(lib, name)          # AttributeError here = header/library mismatch: fail loudly

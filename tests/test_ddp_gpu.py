@@ -232,6 +232,20 @@ def test_bench_py_two_graphs_around_an_eager_rccl_all_reduce_one_rank():
     assert rec["value"] > 0 and rec["ms_per_step"] < rec["eager_launch_ms_per_step"] * 1.05
 
 
+def _run_beating_the_watchdog(cmd, env, root):
+    """The fault-injection runs below break a capture that already holds collectives.  From that moment ProcessGroupNCCL's
+    watchdog thread may query an event that was recorded inside the broken capture and std::terminate the process
+    (hipErrorCapturedEvent, SIGABRT) -- which is WHY bench.py prints its finished line and leaves at once, without another
+    collective.  Normally it wins that race by a wide margin (the watchdog polls every 100 ms); when the watchdog wins, the run
+    is repeated: the test is about what bench.py prints when it gets to print, the abort is torch's."""
+    for attempt in range(3):
+        p = subprocess.run(cmd, env=env, cwd=root, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=1200)
+        err = p.stderr.decode(errors="replace")
+        if not (p.returncode == -6 and "hipErrorCapturedEvent" in err):
+            break
+    return p
+
+
 def test_bench_py_reports_the_eager_region_when_the_capture_breaks():
     """A capture that fails AFTER a collective went into it leaves the communicator in unknown state: bench.py must not
     limp on with it (on N ranks: a hang) and must not lose the measurement either.  With a failure injected inside the
@@ -244,7 +258,7 @@ def test_bench_py_reports_the_eager_region_when_the_capture_breaks():
     env.pop("HSA_ENABLE_IPC_MODE_LEGACY", None)
     cmd = [sys.executable, os.path.join(root, "bench.py"), "--ddp-probe", "--ddp-first", "0", "--steps", "2", "--warmup", "1", "--batch", "32",
            "--no-baselines", "--benchmark", "0", "--graph", "1", "--inject-capture-failure"]
-    p = subprocess.run(cmd, env=env, cwd=root, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=1200)
+    p = _run_beating_the_watchdog(cmd, env, root)
     out, err = p.stdout.decode(errors="replace"), p.stderr.decode(errors="replace")
     assert p.returncode == 0, (out + err)[-4000:]
     lines = [ln for ln in out.splitlines() if ln.startswith("{")]
@@ -268,7 +282,7 @@ def test_bench_py_keeps_the_first_schedules_graph_measurement_when_the_optional_
     env.pop("HSA_ENABLE_IPC_MODE_LEGACY", None)
     cmd = [sys.executable, os.path.join(root, "bench.py"), "--ddp-probe", "--ddp-first", "0", "--steps", "3", "--warmup", "1", "--batch", "32",
            "--no-baselines", "--benchmark", "0", "--graph", "1", "--inject-capture-failure", "bucketed_overlap"]
-    p = subprocess.run(cmd, env=env, cwd=root, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=1200)
+    p = _run_beating_the_watchdog(cmd, env, root)
     out, err = p.stdout.decode(errors="replace"), p.stderr.decode(errors="replace")
     assert p.returncode == 0, (out + err)[-4000:]
     lines = [ln for ln in out.splitlines() if ln.startswith("{")]

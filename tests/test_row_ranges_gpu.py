@@ -108,7 +108,9 @@ def _run_passes(lib, L, mode, T, coef=None):
     return R
 
 
-SHAPES = [(2, 64, 37, 45, 32), (3, 128, 16, 9, 32), (1, 256, 50, 23, 32), (2, 512, 24, 28, 32), (2, 64, 33, 7, 16)]
+# (the last one: workgroups of the backward apply pass that walk TWO images each -- mrla_light_wgrad_rows < b uncut)
+SHAPES = [(2, 64, 37, 45, 32), (3, 128, 16, 9, 32), (1, 256, 50, 23, 32), (2, 512, 24, 28, 32), (2, 64, 33, 7, 16),
+          (128, 512, 28, 28, 32)]
 
 
 @pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float32, torch.float16], ids=["bf16", "fp32", "fp16"])
@@ -124,7 +126,11 @@ def test_every_pass_cut_against_uncut_through_the_c_abi(shape, dtype, row_ranges
     T = dict(shape=(b, c, h, w, d, dt), x=act(), o=act(), g=act(), y3=act(), wv=rnd(c, 9) * 0.3, wq=rnd(5), wk=rnd(5), lam=rnd(c),
              gamma=rnd(c).abs() + 0.5, beta=rnd(c) * 0.1, psc=rnd(c).abs() + 0.3, psh=rnd(c) * 0.2, center=rnd(c) * 0.1,
              dp=torch.tensor(([1.25, 0.0, 1.25] * b)[:b], device="cuda"))
+    if b >= 128 and dtype != torch.bfloat16:
+        pytest.skip("the large shape runs once")
     A = _run_passes(lib, L, 1, T)
+    if b >= 128:
+        assert A["counts"][2] < b, "this shape is meant to put several images into one workgroup of apply_bwd"
     Bc = _run_passes(lib, L, 2, T, coef=A["coef"])
     # the rows really were cut -- more partial records / rows than the uncut launch has
     assert all(n2 > n1 for n1, n2 in zip(A["counts"], Bc["counts"])), (A["counts"], Bc["counts"])
@@ -138,6 +144,61 @@ def test_every_pass_cut_against_uncut_through_the_c_abi(shape, dtype, row_ranges
         else:           # sums: another order of summation
             err = float((a.double() - bb.double()).abs().max() / a.double().abs().max().clamp_min(1e-30))
             assert err < 2e-6, (k, err)
+
+
+@pytest.mark.parametrize("act", [0, 1], ids=["linear", "gelu"])
+@pytest.mark.parametrize("shape", [(2, 128, 37, 30, 32), (1, 64, 24, 9, 16)], ids=lambda s: "x".join(map(str, s[:4])))
+def test_layer_form_without_o_prev_cut_against_uncut(shape, act, row_ranges):
+    """The passes as mrla_light_layer uses them (mrla_light_module.py:52-74: no o_prev, no BatchNorm; act = 1: the GELU on V of
+    the DeiT form on an image) -- the other template instances of the cut kernels."""
+    from mrla_amd import _lib as L
+    lib = L.load()
+    b, c, h, w, d = shape
+    dt, lay, st = L.F32, L.NHWC, ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+    gen = torch.Generator(device="cuda").manual_seed(c + h + act)
+    rnd = lambda *s: torch.randn(*s, device="cuda", generator=gen)           # noqa: E731
+    x, g = (rnd(b, c, h, w).contiguous(memory_format=torch.channels_last) for _ in range(2))
+    wv, wq, wk = rnd(c, 9) * 0.3, rnd(3), rnd(3)
+    f32 = dict(device="cuda", dtype=torch.float32)
+
+    def run(mode, coef=None):
+        lib.mrla_tuning_row_ranges(mode)
+        q = lambda f: f(b, c, h, w, dt, lay)                                  # noqa: E731
+        ms, bs, rows = q(lib.mrla_light_mom_splits), q(lib.mrla_light_bmom_splits), q(lib.mrla_light_wgrad_rows)
+        mom = torch.full((ms, b, c, L.FWD_MOMENTS), float("nan"), **f32)
+        L.check(lib.mrla_light_stats_fwd(P(x), None, P(wv), P(mom), b, c, h, w, dt, lay, act, st), "stats_fwd")
+        if coef is None:
+            gate = torch.empty(b, c // d, **f32)
+            L.check(lib.mrla_light_gate_fwd(P(mom), P(wq), P(wk), 3, P(gate), b, c, h * w, d, st), "gate_fwd")
+        else:
+            gate = coef["gate"]
+        out = torch.empty_like(x)
+        L.check(lib.mrla_light_apply_fwd(P(x), None, P(wv), P(gate), None, None, None, None, P(out), b, c, h, w, d, 0, dt, lay, act, st),
+                "apply_fwd")
+        bmom = torch.full((bs, b, c, 3), float("nan"), **f32)
+        L.check(lib.mrla_light_stats_bwd(P(g), P(x), None, P(wv), P(mom if coef is None else coef["mom"]), P(bmom), b, c, h, w, dt, lay,
+                                         act, st), "stats_bwd")
+        if coef is None:
+            dyx, dwqk = torch.empty(b, c, **f32), torch.empty(b, 6, **f32)
+            L.check(lib.mrla_light_gate_bwd(P(mom), P(bmom), P(gate), None, None, None, P(wq), P(wk), 3, P(dyx), P(dwqk), b, c, h * w, d,
+                                            st), "gate_bwd")
+        else:
+            dyx = coef["dyx"]
+        dx = torch.empty_like(x)
+        dwv = torch.full((rows, c * 9), float("nan"), **f32)
+        L.check(lib.mrla_light_apply_bwd(P(g), P(x), None, P(wv), P(gate), None, None, None, P(dyx), P(dx), None, P(dwv), None, None,
+                                         None, b, c, h, w, d, 0, 0, dt, lay, act, st), "apply_bwd")
+        torch.cuda.synchronize()
+        return dict(counts=(ms, bs, rows), mom=mom[0].clone(), out=out, bmom=bmom[0].clone(), dx=dx, dwv=dwv.double().sum(0),
+                    coef=dict(gate=gate, dyx=dyx, mom=mom))
+    A = run(1)
+    Bc = run(2, coef=A["coef"])
+    assert all(n2 > n1 for n1, n2 in zip(A["counts"], Bc["counts"])), (A["counts"], Bc["counts"])
+    for k in ("out", "dx"):
+        assert torch.equal(A[k], Bc[k]), (k, float((A[k] - Bc[k]).abs().max()))
+    for k in ("mom", "bmom", "dwv"):
+        err = float((A[k].double() - Bc[k].double()).abs().max() / A[k].double().abs().max().clamp_min(1e-30))
+        assert err < 2e-6, (k, err)
 
 
 CUT_CASES = [(4, 256, 56, 56, 32), (4, 512, 28, 28, 32), (17, 256, 56, 56, 32), (2, 64, 37, 45, 32), (3, 128, 16, 9, 16),

@@ -295,6 +295,17 @@ def test_bottleneck_with_deferred_bn3_cut_against_uncut(shape, row_ranges):
     assert float(s["grad:bn3.weight"].abs().max()) > 0
 
 
+@pytest.mark.parametrize("arch", ["resnet50_mrlal", "resnet50_mrlab"])
+def test_whole_models_with_cut_rows_track_the_eager_restatement(arch, row_ranges):
+    """tests/test_models_gpu.py's five-SGD-steps and bf16-autocast train-step tests with the rows cut wherever a map has >= 16
+    rows (stages 1 and 2 at these batches): the light model end to end, and the MRLA-base model, whose value backward walks whole
+    images and zeroes the partial rows of the row ranges it does not write."""
+    from tests import test_models_gpu as tm
+    row_ranges(2)
+    tm.test_five_sgd_steps_track_the_eager_restatement(arch)
+    tm.test_bf16_autocast_train_step_tracks_the_eager_restatement(arch)
+
+
 def test_modes_and_counts(row_ranges):
     """0: cuts only where the launch would leave CUs idle AND the tensor is large (ranges of >= 12 rows); 1: never; 2: wherever >= 16 rows.  Off the row
     pipeline (C % 64 != 0, NCHW) nothing is ever cut; the x_t-free tail reports itself unavailable where rows are cut."""

@@ -27,3 +27,16 @@ def pytest_collection_modifyitems(config, items):
     for it in items:
         if "gpu" in it.keywords:
             it.add_marker(skip)
+
+
+@pytest.fixture(autouse=True)
+def _row_range_mode_of_the_session():
+    """MRLA_TEST_ROW_RANGES=2 pytest -m gpu ...: every test runs with the rows of the channels_last row pipeline cut wherever a map
+    has >= 16 rows (mrla_tuning_row_ranges; include/mrla_hip.h) -- the whole suite as a test of the cut kernels.  Tests that pin
+    the uncut geometry (the counts of tests/test_host_cpu.py, the x_t-free passes of tests/test_lean_gpu.py, which do not exist
+    where rows are cut) are expected to object; everything that compares results must not.  Unset: nothing happens."""
+    mode = os.environ.get("MRLA_TEST_ROW_RANGES")
+    if mode:
+        from mrla_amd import _lib
+        _lib.load().mrla_tuning_row_ranges(int(mode))
+    yield

@@ -69,7 +69,7 @@ def test_light_tail_at_detection_size_vs_eager(shape, mode):
     b, c, h, w = shape
     lib = L.load()
     assert lib.mrla_light_wgrad_rows(b, c, h, w, L.BF16, L.NHWC) > b and lib.mrla_light_bmom_splits(b, c, h, w, L.BF16, L.NHWC) > 1
-    assert lib.mrla_light_mom_splits(b, c, h, w, L.BF16, L.NHWC) % 8 == 0            # (strip ranges x 8 row ranges)
+    assert lib.mrla_light_mom_splits(b, c, h, w, L.BF16, L.NHWC) >= 24               # (3 or 6 strip ranges x 8 row ranges; more under MRLA_TEST_ROW_RANGES=2)
     g = torch.Generator(device="cuda").manual_seed(c + h)
     mk = lambda s=1.0: (s * torch.randn(b, c, h, w, device="cuda", generator=g)).bfloat16().contiguous(memory_format=torch.channels_last)
     pre, idn, gup = mk(), mk(), mk(0.1)
